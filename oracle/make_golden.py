@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference) on seeded inputs.
+
+Test infrastructure only.  Run in the build container (the reference does not exist on the GPU box):
+
+    python oracle/make_golden.py
+
+The reference is imported behind oracle/ref_shim (a cv2 / torchvision stand-in: the reference's
+utils/__init__ imports both, neither wheel is installed here).  No reference source is copied;
+only its inputs/outputs are stored.  Every fixture is a flat npz: arrays plus a ``__cases__`` JSON string
+listing (name, function, kwargs, input keys, output key) so the tests can replay each case.
+"""
+import hashlib
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("PTB_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "ref_shim"))
+sys.path.insert(0, REF)
+warnings.filterwarnings("ignore")
+
+import torch  # noqa: E402
+
+from pytorch_toolbelt.inference import tiles as rt  # noqa: E402
+from pytorch_toolbelt.inference import tta as rtta  # noqa: E402
+from pytorch_toolbelt.inference import functional as rfn  # noqa: E402
+from pytorch_toolbelt import losses as rl  # noqa: E402
+from pytorch_toolbelt.losses import functional as rlf  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, arrays, cases):
+    arrays = dict(arrays)
+    arrays["__cases__"] = np.array(json.dumps(cases))
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {len(cases)} cases, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------- tiles
+def gen_tiles():
+    A, cases = {}, []
+    geoms = [
+        dict(image_shape=[1024, 1024, 3], tile_size=256, tile_step=128),            # BASELINE cfg1
+        dict(image_shape=[5000, 5000, 3], tile_size=[512, 512], tile_step=[256, 256]),  # cfg2/3
+        dict(image_shape=[500, 500, 3], tile_size=51, tile_step=26),                # ref tests/test_tiles.py:13-18
+        dict(image_shape=[563, 512, 3], tile_size=[128, 128], tile_step=[128, 128]),  # ref tests/test_tiles.py:21-26
+        dict(image_shape=[5632, 5120, 3], tile_size=[1280, 1280], tile_step=[1280, 1280]),
+        dict(image_shape=[75, 83, 3], tile_size=[32, 24], tile_step=[16, 12]),
+        dict(image_shape=[40, 40], tile_size=64, tile_step=32),                     # image smaller than a tile
+        dict(image_shape=[100, 130, 1], tile_size=[48, 64], tile_step=[48, 32], image_margin=8),
+        dict(image_shape=[100, 130, 1], tile_size=[48, 64], tile_step=[24, 64], image_margin=[3, 5, 7, 9]),
+        dict(image_shape=[4096, 4096, 3], tile_size=512, tile_step=256),
+        dict(image_shape=[97, 61, 2], tile_size=[17, 13], tile_step=[5, 13]),
+    ]
+    for k, g in enumerate(geoms):
+        s = rt.ImageSlicer(g["image_shape"], g["tile_size"], g["tile_step"], image_margin=g.get("image_margin", 0))
+        A[f"geom{k}_crops"] = s.crops.astype(np.int64)
+        A[f"geom{k}_bbox"] = s.bbox_crops.astype(np.int64)
+        A[f"geom{k}_meta"] = np.array(
+            [s.margin_left, s.margin_right, s.margin_top, s.margin_bottom, *s.target_shape, *s.tile_size, *s.tile_step],
+            dtype=np.int64,
+        )
+        cases.append(dict(name=f"geom{k}", fn="geometry", kwargs=g))
+
+    # pyramid windows: small ones in full, the 512x512 one by digest + probes
+    for (w, h) in [(32, 24), (51, 51), (17, 13), (64, 64)]:
+        W, Dc, De = rt.compute_pyramid_patch_weight_loss(w, h)
+        A[f"pyr_{w}x{h}_W"], A[f"pyr_{w}x{h}_Dc"], A[f"pyr_{w}x{h}_De"] = W, Dc, De
+        cases.append(dict(name=f"pyr_{w}x{h}", fn="pyramid", kwargs=dict(width=w, height=h)))
+    for (w, h) in [(512, 512), (256, 256), (1280, 1280)]:
+        W, _, _ = rt.compute_pyramid_patch_weight_loss(w, h)
+        A[f"pyr_{w}x{h}_sha256"] = np.array(hashlib.sha256(np.ascontiguousarray(W).tobytes()).hexdigest())
+        A[f"pyr_{w}x{h}_stats"] = np.array([W.min(), W.max(), W.sum(), W[3, 5], W[h // 2, w // 3]])
+        cases.append(dict(name=f"pyr_{w}x{h}", fn="pyramid_digest", kwargs=dict(width=w, height=h)))
+
+    # split / cut_patch / iter_split / merge (fp64 numpy) on a non-zero image
+    rng = np.random.default_rng(0)
+    for k, (shape, ts, st, wname) in enumerate(
+        [((75, 83, 3), (32, 24), (16, 12), "pyramid"), ((64, 50, 2), (32, 32), (16, 16), "mean"), ((50, 47, 1), (16, 16), (16, 16), "mean")]
+    ):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        s = rt.ImageSlicer(img.shape, ts, st, weight=wname)
+        tl = s.split(img)
+        A[f"split{k}_image"] = img
+        A[f"split{k}_tiles"] = np.stack(tl)
+        A[f"split{k}_cut"] = np.stack([s.cut_patch(img, i) for i in range(len(s.crops))])
+        it = list(s.iter_split(img))
+        A[f"split{k}_iter_tiles"] = np.stack([t for t, _ in it])
+        A[f"split{k}_iter_coords"] = np.stack([c for _, c in it]).astype(np.int64)
+        A[f"split{k}_merge_f32"] = s.merge(tl, dtype=np.float32)
+        A[f"split{k}_merge_u8"] = s.merge(tl, dtype=np.uint8)
+        ftiles = [rng.standard_normal(t.shape) for t in tl]
+        A[f"split{k}_ftiles"] = np.stack(ftiles)
+        A[f"split{k}_fmerge"] = s.merge(ftiles, dtype=np.float32)
+        cases.append(dict(name=f"split{k}", fn="split_merge", kwargs=dict(image_shape=list(shape), tile_size=list(ts), tile_step=list(st), weight=wname)))
+
+    # TileMerger (torch CPU fp32): integrate in batches, then merge
+    g = torch.Generator().manual_seed(0)
+    for k, (shape, ts, st, wname, C, bs) in enumerate(
+        [((96, 80, 3), (32, 32), (16, 16), "pyramid", 3, 4), ((75, 83, 3), (32, 24), (16, 12), "pyramid", 2, 5),
+         ((64, 64, 3), (32, 32), (32, 32), "mean", 1, 3), ((50, 70, 3), (20, 28), (7, 9), "pyramid", 2, 8)]
+    ):
+        s = rt.ImageSlicer(shape, ts, st, weight=wname)
+        n = len(s.crops)
+        pred = torch.randn((n, C, ts[0], ts[1]), generator=g)
+        m = rt.TileMerger(s.target_shape, C, s.weight)
+        for b0 in range(0, n, bs):
+            m.integrate_batch(pred[b0:b0 + bs], s.crops[b0:b0 + bs])
+        A[f"merger{k}_pred"] = t2n(pred)
+        A[f"merger{k}_image"] = t2n(m.image)
+        A[f"merger{k}_norm"] = t2n(m.norm_mask)
+        A[f"merger{k}_merged"] = t2n(m.merge())
+        cases.append(dict(name=f"merger{k}", fn="tile_merger", kwargs=dict(image_shape=list(shape), tile_size=list(ts), tile_step=list(st), weight=wname, channels=C, batch=bs)))
+    save("tiles.npz", A, cases)
+
+
+# ----------------------------------------------------------------------------------------------- tta
+def gen_tta():
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand((2, 3, 16, 16), generator=g)
+    xr = torch.rand((2, 3, 12, 20), generator=g)           # non-square for flip / d2 / flips
+    A["x_sq"], A["x_rect"] = t2n(x), t2n(xr)
+    groups = dict(fliplr=2, flipud=2, flips=3, d2=4, d4=8)
+    for grp, nv in groups.items():
+        for tag, src in (("sq", x), ("rect", xr)):
+            if grp == "d4" and tag == "rect":
+                continue
+            aug = getattr(rtta, f"{grp}_image_augment")(src)
+            A[f"aug_{grp}_{tag}"] = t2n(aug)
+            cases.append(dict(name=f"aug_{grp}_{tag}", fn="image_augment", kwargs=dict(group=grp), inputs=[f"x_{tag}"], output=f"aug_{grp}_{tag}"))
+        for tag, shape in (("sq", (nv * 2, 3, 16, 16)), ("rect", (nv * 2, 3, 12, 20))):
+            if grp == "d4" and tag == "rect":
+                continue
+            y = torch.rand(shape, generator=g) * 0.98 + 0.01
+            A[f"y_{grp}_{tag}"] = t2n(y)
+            for red in ["mean", "sum", "gmean", "hmean", "harmonic1p", "logodd", "log1p", None]:
+                out = getattr(rtta, f"{grp}_image_deaugment")(y, reduction=red)
+                key = f"deaug_{grp}_{tag}_{red}"
+                A[key] = t2n(out)
+                cases.append(dict(name=key, fn="image_deaugment", kwargs=dict(group=grp, reduction=red), inputs=[f"y_{grp}_{tag}"], output=key))
+    # gmean on zeros / negatives (reference: 0 -> 0, negative -> NaN), hmean clamp
+    y = torch.rand((16, 1, 8, 8), generator=g)
+    y[0, 0, 0, 0] = 0.0
+    y[3, 0, 1, 1] = -0.5
+    y[5, 0, 2, 2] = 1e-9
+    A["y_d4_edge"] = t2n(y)
+    for red in ["gmean", "hmean", "logodd", "log1p", "harmonic1p"]:
+        key = f"deaug_d4_edge_{red}"
+        A[key] = t2n(rtta.d4_image_deaugment(y, reduction=red))
+        cases.append(dict(name=key, fn="image_deaugment", kwargs=dict(group="d4", reduction=red), inputs=["y_d4_edge"], output=key))
+
+    # label variants (incl. the b7,b7 quirk of d4_labels_deaugment)
+    for grp, nv in dict(groups, fivecrop=5).items():
+        lg = torch.rand((nv * 3, 5), generator=g)
+        A[f"labels_{grp}"] = t2n(lg)
+        fn = rtta.fivecrop_label_deaugment if grp == "fivecrop" else getattr(rtta, f"{grp}_labels_deaugment")
+        for red in ["mean", "sum", "gmean", None]:
+            key = f"labdeaug_{grp}_{red}"
+            A[key] = t2n(fn(lg, reduction=red))
+            cases.append(dict(name=key, fn="labels_deaugment", kwargs=dict(group=grp, reduction=red), inputs=[f"labels_{grp}"], output=key))
+    A["fivecrop_aug"] = t2n(rtta.fivecrop_image_augment(x, (8, 10)))
+    cases.append(dict(name="fivecrop_aug", fn="fivecrop_image_augment", kwargs=dict(crop_size=[8, 10]), inputs=["x_sq"], output="fivecrop_aug"))
+
+    # multiscale
+    xm = torch.rand((1, 2, 24, 20), generator=g)
+    A["x_ms"] = t2n(xm)
+    offsets = [-8, 0, 6, [4, -4]]
+    for ac in (False, True):
+        augs = rtta.ms_image_augment(xm, offsets, mode="bilinear", align_corners=ac)
+        for i, a in enumerate(augs):
+            A[f"ms_aug_ac{int(ac)}_{i}"] = t2n(a)
+        cases.append(dict(name=f"ms_aug_ac{int(ac)}", fn="ms_image_augment", kwargs=dict(size_offsets=offsets, align_corners=ac), inputs=["x_ms"], output=[f"ms_aug_ac{int(ac)}_{i}" for i in range(len(offsets))]))
+    fmaps = [torch.rand((1, 2, 24 + (o[0] if isinstance(o, list) else o), 20 + (o[1] if isinstance(o, list) else o)), generator=g) * 0.9 + 0.05 for o in offsets]
+    for i, f in enumerate(fmaps):
+        A[f"ms_fm_{i}"] = t2n(f)
+    for ac in (False, True):
+        for red in ("mean", "gmean"):
+            key = f"ms_deaug_ac{int(ac)}_{red}"
+            A[key] = t2n(rtta.ms_image_deaugment(fmaps, offsets, reduction=red, mode="bilinear", align_corners=ac))
+            cases.append(dict(name=key, fn="ms_image_deaugment", kwargs=dict(size_offsets=offsets, reduction=red, align_corners=ac, stride=1), inputs=[f"ms_fm_{i}" for i in range(len(offsets))], output=key))
+    # stride 2 with negative non-multiple offsets (floor-division quirk Q3)
+    offs2 = [-5, 0, 7]
+    fm2 = [torch.rand((1, 2, 12 + o // 2 + (0 if o % 2 == 0 or o > 0 else 0), 10 + o // 2), generator=g) for o in offs2]
+    # feature maps of a stride-2 model: size = (input + offset) // 2 is the caller's business; any sizes are legal inputs
+    for i, f in enumerate(fm2):
+        A[f"ms2_fm_{i}"] = t2n(f)
+    key = "ms_deaug_stride2"
+    A[key] = t2n(rtta.ms_image_deaugment(fm2, offs2, reduction="mean", mode="bilinear", align_corners=True, stride=2))
+    cases.append(dict(name=key, fn="ms_image_deaugment", kwargs=dict(size_offsets=offs2, reduction="mean", align_corners=True, stride=2), inputs=[f"ms2_fm_{i}" for i in range(3)], output=key))
+
+    # reductions on a [T, ...] stack directly (inference/functional.py:250-333)
+    st = torch.rand((5, 7, 9), generator=g)
+    A["red_stack"] = t2n(st)
+    for nm, fn in [("geometric_mean", rfn.geometric_mean), ("harmonic_mean", rfn.harmonic_mean), ("harmonic1p_mean", rfn.harmonic1p_mean), ("logodd_mean", rfn.logodd_mean), ("log1p_mean", rfn.log1p_mean)]:
+        A[f"red_{nm}"] = t2n(fn(st, dim=0))
+        cases.append(dict(name=f"red_{nm}", fn="reduction", kwargs=dict(which=nm), inputs=["red_stack"], output=f"red_{nm}"))
+    save("tta.npz", A, cases)
+
+
+# ----------------------------------------------------------------------------------------------- losses
+def gen_losses():
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W = 3, 5, 12, 10
+    logits = torch.randn((B, C, H, W), generator=g) * 3.0
+    # non-iid across images so per_image Lovasz differs from the batch version
+    logits[1] += 1.5
+    logits[2] *= 0.3
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels[0, :3] = 2
+    labels_ign = labels.clone()
+    labels_ign[torch.rand((B, H, W), generator=g) < 0.15] = 255
+    onehot = torch.nn.functional.one_hot(labels, C).permute(0, 3, 1, 2).float()
+    multilabel = (torch.rand((B, C, H, W), generator=g) < 0.3).float()
+    multilabel[:, 4] = 0  # an empty class -> its loss term is zeroed
+    multilabel_ign = multilabel.clone()
+    multilabel_ign[torch.rand((B, C, H, W), generator=g) < 0.1] = 255
+    cw = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.25])
+    bin_logits = torch.randn((B, 1, H, W), generator=g) * 2.0
+    bin_logits[1] -= 1.0
+    bin_t = (torch.rand((B, 1, H, W), generator=g) < 0.4).float()
+    bin_t_ign = bin_t.clone()
+    bin_t_ign[torch.rand((B, 1, H, W), generator=g) < 0.1] = 255
+    for k, v in dict(logits=logits, labels=labels, labels_ign=labels_ign, onehot=onehot, multilabel=multilabel,
+                     multilabel_ign=multilabel_ign, class_weights=cw, bin_logits=bin_logits, bin_t=bin_t, bin_t_ign=bin_t_ign).items():
+        A[k] = t2n(v)
+
+    def add(name, fn, kwargs, inputs, value):
+        A[name] = t2n(value) if torch.is_tensor(value) else np.asarray(value)
+        cases.append(dict(name=name, fn=fn, kwargs=kwargs, inputs=inputs, output=name))
+
+    # focal_loss_with_logits option matrix
+    focal_opts = [
+        dict(), dict(alpha=None), dict(gamma=1.5, alpha=0.6), dict(reduction="sum"), dict(reduction="batchwise_mean"),
+        dict(reduction="none"), dict(normalized=True), dict(reduced_threshold=0.5), dict(reduced_threshold=0.3, normalized=True),
+        dict(gamma=0.0, alpha=None), dict(gamma=3.0),
+    ]
+    for i, kw in enumerate(focal_opts):
+        add(f"focal_fn_{i}", "focal_loss_with_logits", kw, ["logits", "onehot"], rlf.focal_loss_with_logits(logits, onehot, **kw))
+    add("focal_fn_cw", "focal_loss_with_logits", dict(class_weights=True), ["logits", "onehot"], rlf.focal_loss_with_logits(logits, onehot, class_weights=cw))
+    add("focal_fn_softmax", "focal_loss_with_logits", dict(activation="softmax", softmax_dim=1), ["logits", "onehot"], rlf.focal_loss_with_logits(logits, onehot, activation="softmax", softmax_dim=1))
+    add("focal_fn_soft_targets", "focal_loss_with_logits", dict(alpha=0.3), ["logits", "multilabel"], rlf.focal_loss_with_logits(logits, multilabel * 0.7 + 0.1, alpha=0.3))
+    A["soft_targets"] = t2n(multilabel * 0.7 + 0.1)
+    cases[-1]["inputs"] = ["logits", "soft_targets"]
+    add("focal_fn_ign", "focal_loss_with_logits", dict(ignore_index=255, normalized=True), ["logits", "multilabel_ign"], rlf.focal_loss_with_logits(logits, multilabel_ign, ignore_index=255, normalized=True))
+
+    # BinaryFocalLoss module (label targets -> one-hot, ignore handling)
+    bf_opts = [dict(), dict(alpha=0.25), dict(ignore_index=255), dict(ignore_index=255, normalized=True, alpha=0.4),
+               dict(reduction="sum", gamma=1.0), dict(reduced_threshold=0.5, reduction="sum"), dict(class_weights=True)]
+    for i, kw in enumerate(bf_opts):
+        k2 = dict(kw)
+        if k2.pop("class_weights", None):
+            k2["class_weights"] = cw
+        lab = labels_ign if kw.get("ignore_index") is not None else labels
+        add(f"binary_focal_{i}", "binary_focal_loss", kw, ["logits", "labels_ign" if kw.get("ignore_index") is not None else "labels"], rl.BinaryFocalLoss(**k2)(logits, lab))
+    add("binary_focal_same_shape", "binary_focal_loss", dict(alpha=0.5), ["bin_logits", "bin_t"], rl.BinaryFocalLoss(alpha=0.5)(bin_logits, bin_t))
+
+    # CrossEntropyFocalLoss / softmax_focal_loss_with_logits
+    sf_opts = [dict(), dict(gamma=1.0), dict(reduction="sum"), dict(reduction="batchwise_mean"), dict(reduction="none"),
+               dict(normalized=True), dict(reduced_threshold=0.5), dict(ignore_index=255), dict(ignore_index=255, class_weights=True, gamma=1.5)]
+    for i, kw in enumerate(sf_opts):
+        k2 = dict(kw)
+        if k2.pop("class_weights", None):
+            k2["class_weights"] = cw
+        lab = labels_ign if kw.get("ignore_index") is not None else labels
+        add(f"softmax_focal_{i}", "softmax_focal_loss_with_logits", kw, ["logits", "labels_ign" if kw.get("ignore_index") is not None else "labels"], rlf.softmax_focal_loss_with_logits(logits, lab, **k2))
+
+    # soft scores
+    probs = torch.softmax(logits, dim=1)
+    A["probs"] = t2n(probs)
+    for nm, fn in (("soft_dice_score", rlf.soft_dice_score), ("soft_jaccard_score", rlf.soft_jaccard_score)):
+        add(f"{nm}_all", nm, dict(), ["probs", "onehot"], fn(probs, onehot))
+        add(f"{nm}_dims", nm, dict(smooth=1.0, dims=[0, 2, 3]), ["probs", "onehot"], fn(probs, onehot, smooth=1.0, dims=(0, 2, 3)))
+
+    # Dice / Jaccard modules
+    for cls_name, cls in (("dice_loss", rl.DiceLoss), ("jaccard_loss", rl.JaccardLoss)):
+        opts = [
+            (dict(mode="multiclass"), "logits", "labels"),
+            (dict(mode="multiclass", log_loss=True, smooth=1.0), "logits", "labels"),
+            (dict(mode="multiclass", from_logits=False), "probs", "labels"),
+            (dict(mode="multilabel"), "logits", "multilabel"),
+            (dict(mode="multilabel", smooth=0.5, log_loss=True), "logits", "multilabel"),
+            (dict(mode="binary"), "bin_logits", "bin_t"),
+            (dict(mode="binary", log_loss=True), "bin_logits", "bin_t"),
+            (dict(mode="multiclass", classes=[0, 2, 3]), "logits", "labels"),
+        ]
+        if cls_name == "dice_loss":
+            opts += [
+                (dict(mode="multiclass", ignore_index=255), "logits", "labels_ign"),
+                (dict(mode="multilabel", ignore_index=255), "logits", "multilabel_ign"),
+                (dict(mode="binary", ignore_index=255), "bin_logits", "bin_t_ign"),
+            ]
+        for i, (kw, a, b) in enumerate(opts):
+            k2 = dict(kw)
+            if "classes" in k2:
+                # the reference's list handling is broken (np.ndarray(list) -> NaN); a tensor works
+                k2["classes"] = torch.tensor(k2["classes"])
+            val = cls(**k2)(torch.from_numpy(A[a]), torch.from_numpy(A[b]))
+            add(f"{cls_name}_{i}", cls_name, kw, [a, b], val)
+
+    # Lovasz (the reference has no test for it at all)
+    for i, kw in enumerate([dict(), dict(per_image=True), dict(ignore=255), dict(per_image=True, ignore=255)]):
+        lab = labels_ign if "ignore" in kw else labels
+        add(f"lovasz_softmax_{i}", "lovasz_softmax", kw, ["probs", "labels_ign" if "ignore" in kw else "labels"], rl.LovaszLoss(**kw)(probs, lab))
+    bl = bin_logits[:, 0].contiguous()
+    bt = bin_t[:, 0].contiguous()
+    bti = bin_t_ign[:, 0].contiguous()
+    A["bl"], A["bt"], A["bti"] = t2n(bl), t2n(bt), t2n(bti)
+    for i, kw in enumerate([dict(), dict(per_image=True), dict(ignore_index=255), dict(per_image=True, ignore_index=255)]):
+        add(f"lovasz_hinge_{i}", "lovasz_hinge", kw, ["bl", "bti" if "ignore_index" in kw else "bt"], rl.BinaryLovaszLoss(**kw)(bl, bti if "ignore_index" in kw else bt))
+
+    # gradients of the training losses w.r.t. logits (autograd of the reference)
+    def grad_of(fn):
+        x = logits.clone().requires_grad_(True)
+        fn(x).backward()
+        return x.grad
+
+    add("grad_binary_focal", "grad_binary_focal", dict(alpha=0.25), ["logits", "labels"], grad_of(lambda x: rl.BinaryFocalLoss(alpha=0.25)(x, labels)))
+    add("grad_binary_focal_norm_ign", "grad_binary_focal", dict(ignore_index=255, normalized=True), ["logits", "labels_ign"], grad_of(lambda x: rl.BinaryFocalLoss(ignore_index=255, normalized=True)(x, labels_ign)))
+    add("grad_softmax_focal", "grad_softmax_focal", dict(), ["logits", "labels"], grad_of(lambda x: rl.CrossEntropyFocalLoss()(x, labels)))
+    add("grad_dice_mc", "grad_dice", dict(mode="multiclass"), ["logits", "labels"], grad_of(lambda x: rl.DiceLoss("multiclass")(x, labels)))
+    add("grad_dice_ml_log", "grad_dice", dict(mode="multilabel", log_loss=True, smooth=1.0), ["logits", "multilabel"], grad_of(lambda x: rl.DiceLoss("multilabel", log_loss=True, smooth=1.0)(x, multilabel)))
+    add("grad_jaccard_mc", "grad_jaccard", dict(mode="multiclass"), ["logits", "labels"], grad_of(lambda x: rl.JaccardLoss("multiclass")(x, labels)))
+    add("grad_jaccard_ml", "grad_jaccard", dict(mode="multilabel"), ["logits", "multilabel"], grad_of(lambda x: rl.JaccardLoss("multilabel")(x, multilabel)))
+    save("losses.npz", A, cases)
+
+
+if __name__ == "__main__":
+    gen_tiles()
+    gen_tta()
+    gen_losses()

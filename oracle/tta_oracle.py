@@ -1,0 +1,239 @@
+"""Oracle (test infrastructure only) for inference/tta.py + inference/functional.py of the reference.
+
+numpy restatement built on explicit index maps instead of rot90/transpose chains.
+Citations: ``tta.py:LINE`` = pytorch_toolbelt/inference/tta.py, ``fn.py:LINE`` = pytorch_toolbelt/inference/functional.py.
+
+A *view transform* is a triple (T, fr, fc) meaning
+    out[..., i, j] = src[..., r, c],  (r, c) = (j, i) if T else (i, j),
+    then r -> rows-1-r if fr, c -> cols-1-c if fc         (rows/cols of ``src``).
+The eight triples are the dihedral group D4.
+"""
+import numpy as np
+
+# name -> (T, fr, fc); index semantics follow torch.rot90/flip/transpose on dims (2,3)
+IDENT = (0, 0, 0)      # fn.py:38 torch_none
+FLIPLR = (0, 0, 1)     # fn.py:117-123  out[i][j] = x[i][W-1-j]
+FLIPUD = (0, 1, 0)     # fn.py:108-114  out[i][j] = x[H-1-i][j]
+ROT180 = (0, 1, 1)     # fn.py:81-87    out[i][j] = x[H-1-i][W-1-j]
+TRANSPOSE = (1, 0, 0)  # fn.py:126-132  out[i][j] = x[j][i]
+ROT90_CCW = (1, 0, 1)  # fn.py:47-48    rot90(k=1):  out[i][j] = x[j][N-1-i]
+ROT90_CW = (1, 1, 0)   # fn.py:51-52    rot90(k=-1): out[i][j] = x[N-1-j][i]
+ANTITRANSPOSE = (1, 1, 1)  # fn.py:90-91 rot180 then transpose: out[i][j] = x[N-1-j][N-1-i]
+
+# forward (augment) view lists, in the order the reference concatenates them
+AUG_VIEWS = {
+    "fliplr": [IDENT, FLIPLR],                                   # tta.py:257-269
+    "flipud": [IDENT, FLIPUD],                                   # tta.py:272-284
+    "flips": [IDENT, FLIPLR, FLIPUD],                            # tta.py:470-484
+    "d2": [IDENT, FLIPLR, FLIPUD, ROT180],                       # tta.py:319-341
+    # tta.py:409-422: x, rot90_cw, rot180, rot90_ccw, xT, rot90_cw(xT), rot180(xT), rot90_ccw(xT)
+    # rot90_cw(xT)[i][j] = xT[N-1-j][i] = x[i][N-1-j] (fliplr); rot180(xT) = antitranspose; rot90_ccw(xT) = flipud
+    "d4": [IDENT, ROT90_CW, ROT180, ROT90_CCW, TRANSPOSE, FLIPLR, ANTITRANSPOSE, FLIPUD],
+}
+
+# inverse (de-augment) view lists
+DEAUG_VIEWS = {
+    "fliplr": [IDENT, FLIPLR],                                   # tta.py:287-300
+    "flipud": [IDENT, FLIPUD],                                   # tta.py:303-316
+    "flips": [IDENT, FLIPLR, FLIPUD],                            # tta.py:503-524
+    "d2": [IDENT, FLIPLR, FLIPUD, ROT180],                       # tta.py:344-365 (flipud(fliplr) = rot180)
+    # tta.py:455-466: b1, rot90_ccw(b2), rot180(b3), rot90_cw(b4), transpose(b5),
+    #   rot90_ccw_transpose(b6) [= fliplr], rot180_transpose(b7) [= antitranspose], rot90_cw_transpose(b8) [= flipud]
+    "d4": [IDENT, ROT90_CCW, ROT180, ROT90_CW, TRANSPOSE, FLIPLR, ANTITRANSPOSE, FLIPUD],
+}
+
+
+def apply_view(x, view):
+    """Apply one (T, fr, fc) transform to the last two axes of ``x``."""
+    T, fr, fc = view
+    y = x
+    if fr:
+        y = y[..., ::-1, :]
+    if fc:
+        y = y[..., :, ::-1]
+    if T:
+        y = np.swapaxes(y, -1, -2)
+    return y
+
+
+def split_into_chunks(x, n):
+    """tta.py:55-60 -- second argument is the NUMBER of chunks (quirk Q16); RuntimeError if not divisible."""
+    if x.shape[0] % n != 0:
+        raise RuntimeError(f"Input batch size ({x.shape[0]}) must be divisible by {n}.")
+    step = x.shape[0] // n
+    return [x[k * step:(k + 1) * step] for k in range(n)]
+
+
+# --------------------------------------------------------------------------- reductions
+def geometric_mean(x, axis=0):
+    """fn.py:250-261: exp(mean(log x)).  0 -> 0, negative -> NaN."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.exp(np.mean(np.log(x), axis=axis, dtype=x.dtype))
+
+
+def harmonic_mean(x, axis=0, eps=1e-6):
+    """fn.py:264-278: 1/clamp_min(mean(1/clamp_min(x,eps)), eps)."""
+    one = x.dtype.type(1)
+    e = x.dtype.type(eps)
+    r = one / np.maximum(x, e)
+    m = np.mean(r, axis=axis, dtype=x.dtype)
+    return one / np.maximum(m, e)
+
+
+def harmonic1p_mean(x, axis=0):
+    """fn.py:281-295: 1/mean(1/(x+1)) - 1."""
+    one = x.dtype.type(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = np.mean(one / (x + one), axis=axis, dtype=x.dtype)
+        return one / m - one
+
+
+def logodd_mean(x, axis=0, eps=1e-6):
+    """fn.py:298-315: clamp to [eps, 1-eps]; logit; mean; e^m / (1 + e^m)."""
+    one = x.dtype.type(1)
+    lo = x.dtype.type(eps)
+    hi = x.dtype.type(1.0 - eps)
+    p = np.clip(x, lo, hi)
+    m = np.mean(np.log(p / (one - p)), axis=axis, dtype=x.dtype)
+    e = np.exp(m)
+    return e / (one + e)
+
+
+def log1p_mean(x, axis=0):
+    """fn.py:318-333: exp(mean(log1p x)) - 1."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.exp(np.mean(np.log1p(x), axis=axis, dtype=x.dtype)) - x.dtype.type(1)
+
+
+def deaugment_averaging(x, reduction):
+    """tta.py:63-96: reduce dim 0 of [T, B, ...]."""
+    if reduction == "mean":
+        return np.mean(x, axis=0, dtype=x.dtype)
+    if reduction == "sum":
+        return np.sum(x, axis=0, dtype=x.dtype)
+    if reduction in ("gmean", "geometric_mean"):
+        return geometric_mean(x)
+    if reduction in ("hmean", "harmonic_mean"):
+        return harmonic_mean(x)
+    if reduction == "harmonic1p":
+        return harmonic1p_mean(x)
+    if reduction == "logodd":
+        return logodd_mean(x)
+    if reduction == "log1p":
+        return log1p_mean(x)
+    if callable(reduction):
+        return reduction(x, 0)
+    if reduction in (None, "None", "none"):
+        return x
+    raise KeyError(f"Unsupported reduction mode {reduction}")
+
+
+# --------------------------------------------------------------------------- image TTA
+def image_augment(x, group):
+    """cat of the group's forward views along dim 0 -> [V*B, C, H, W] (chunk-major)."""
+    if group == "d4" and x.shape[2] != x.shape[3]:
+        raise ValueError("Input tensor must have number of rows equal to number of cols.")  # tta.py:403-407
+    return np.concatenate([np.ascontiguousarray(apply_view(x, v)) for v in AUG_VIEWS[group]], axis=0)
+
+
+def image_deaugment(y, group, reduction="mean"):
+    """chunk -> inverse view per chunk -> stack -> reduce."""
+    views = DEAUG_VIEWS[group]
+    chunks = split_into_chunks(y, len(views))
+    stack = np.stack([np.ascontiguousarray(apply_view(c, v)) for c, v in zip(chunks, views)])
+    return deaugment_averaging(stack, reduction)
+
+
+# --------------------------------------------------------------------------- label TTA
+LABEL_VIEWS = {"fliplr": 2, "flipud": 2, "flips": 3, "d2": 4, "d4": 8, "fivecrop": 5}
+
+
+def labels_augment(labels, group):
+    """tta.py:487-500: plain repetition."""
+    return np.concatenate([labels] * LABEL_VIEWS[group], axis=0)
+
+
+def labels_deaugment(logits, group, reduction="mean"):
+    """tta.py:368-382 (d2), :425-439 (d4), :527-581 (flips/fliplr/flipud), :145-150 (fivecrop)."""
+    n = LABEL_VIEWS[group]
+    if group == "flips" and logits.shape[0] % 3 != 0:
+        raise RuntimeError("Batch size must be divisible by 3")            # tta.py:576-577
+    c = split_into_chunks(logits, n)
+    if group == "d4":
+        c = [c[0], c[1], c[2], c[3], c[4], c[6], c[6], c[7]]              # tta.py:437 -- b6 dropped, b7 twice (quirk Q1)
+    return deaugment_averaging(np.stack(c), reduction)
+
+
+def fivecrop_image_augment(x, crop_size):
+    """tta.py:99-142: TL, TR, BL, BR, centre crops concatenated along dim 0."""
+    H, W = x.shape[2], x.shape[3]
+    ch, cw = crop_size
+    if ch > H:
+        raise ValueError(f"Tensor height ({H}) is less than requested crop size ({ch})")
+    if cw > W:
+        raise ValueError(f"Tensor width ({W}) is less than requested crop size ({cw})")
+    by, rx = H - ch, W - cw
+    cy, cx = (H - ch) // 2, (W - cw) // 2
+    parts = [x[..., :ch, :cw], x[..., :ch, rx:], x[..., by:, :cw], x[..., by:, rx:], x[..., cy:cy + ch, cx:cx + cw]]
+    return np.concatenate(parts, axis=0)
+
+
+# --------------------------------------------------------------------------- multiscale
+def _offsets(offset):
+    if isinstance(offset, (tuple, list)):
+        return int(offset[0]), int(offset[1])
+    return int(offset), int(offset)
+
+
+def _axis_taps(n_in, n_out, align_corners, dtype):
+    """Source taps of torch's bilinear upsample (aten UpSample.h area_pixel_compute_source_index /
+    compute_source_index_and_lambda): returns idx0, idx1, lambda1 (weight of idx1), computed in ``dtype``."""
+    dst = np.arange(n_out, dtype=dtype)
+    if align_corners:
+        scale = dtype((n_in - 1) / (n_out - 1)) if n_out > 1 else dtype(0)
+        src = dst * scale
+    else:
+        scale = dtype(n_in / n_out)
+        src = np.maximum(scale * (dst + dtype(0.5)) - dtype(0.5), dtype(0))
+    i0 = np.minimum(src.astype(np.int64), n_in - 1)
+    i1 = i0 + (i0 < n_in - 1)
+    lam = np.clip(src - i0.astype(dtype), 0, 1).astype(dtype)
+    return i0, i1, lam
+
+
+def bilinear_resize(x, size, align_corners):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=...) on [B,C,H,W] numpy."""
+    dt = x.dtype.type
+    r0, r1, lr = _axis_taps(x.shape[2], size[0], align_corners, dt)
+    c0, c1, lc = _axis_taps(x.shape[3], size[1], align_corners, dt)
+    one = dt(1)
+    top = x[:, :, r0][:, :, :, c0] * (one - lc) + x[:, :, r0][:, :, :, c1] * lc
+    bot = x[:, :, r1][:, :, :, c0] * (one - lc) + x[:, :, r1][:, :, :, c1] * lc
+    return top * (one - lr)[:, None] + bot * lr[:, None]
+
+
+def ms_image_augment(x, size_offsets, align_corners=False):
+    """tta.py:599-621 (bilinear): offsets are pixel deltas; 0 -> the input itself."""
+    out = []
+    for off in size_offsets:
+        ro, co = _offsets(off)
+        if ro == 0 and co == 0:
+            out.append(x)
+        else:
+            out.append(bilinear_resize(x, (x.shape[2] + ro, x.shape[3] + co), align_corners))
+    return out
+
+
+def ms_image_deaugment(images, size_offsets, reduction="mean", align_corners=True, stride=1):
+    """tta.py:645-689 (bilinear): resize each map back to rows - off//stride (Python floor division, quirk Q3)."""
+    if len(images) != len(size_offsets):
+        raise ValueError("Number of images must be equal to number of size offsets")
+    back = []
+    for fm, off in zip(images, size_offsets):
+        ro, co = _offsets(off)
+        if ro == 0 and co == 0:
+            back.append(fm)
+        else:
+            size = (fm.shape[2] - ro // stride, fm.shape[3] - co // stride)       # tta.py:682
+            back.append(bilinear_resize(fm, size, align_corners))
+    return deaugment_averaging(np.stack(back), reduction)

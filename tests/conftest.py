@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+class Golden:
+    """A tests/golden/*.npz fixture written by oracle/make_golden.py (outputs of the unmodified reference)."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+        self.cases = json.loads(str(self.z["__cases__"]))
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def by_fn(self, *fns):
+        return [c for c in self.cases if c["fn"] in fns]
+
+
+_cache = {}
+
+
+def load_golden(name):
+    if name not in _cache:
+        _cache[name] = Golden(name)
+    return _cache[name]
+
+
+@pytest.fixture(scope="session")
+def golden_tiles():
+    return load_golden("tiles.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_tta():
+    return load_golden("tta.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_losses():
+    return load_golden("losses.npz")
