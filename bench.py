@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: megapixels/s of the tiled + d4-TTA merge on 5000x5000 (BASELINE.json configs[1]).
+
+One *step* = one full pass of the hot path over one 5000x5000x3 image: 361 tiles (512/256, pyramid window) whose
+8 d4-view model outputs (C=4, fp32, 12.1 GB) are already resident in HBM -> fused de-augment + mean + weighted
+accumulation in batches of 8 tiles (46 HIP launches) -> merge (image / norm_mask).  The model forward is excluded
+(the config's "dummy UNet" only produces these tensors).  Accumulators are re-zeroed inside the timed step.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the 361 tiles of ONE image are sharded over the
+ranks by tile rows, neighbouring ranks exchange their 256-row overlap strips point-to-point over xGMI and every
+rank merges its own band (strong scaling: total work per step is fixed).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+IMAGE = (5000, 5000, 3)
+TILE, STEP, CHANNELS, VIEWS, BATCH = 512, 256, 4, 8, 8
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
+    return ap.parse_args()
+
+
+def cpu_baseline(slicer, n_batches=3):
+    """Reference algorithm (numpy oracle: strided stack + mean, then sequential slice accumulation) on the host,
+    timed on a bounded sample of the same workload and extrapolated to one image."""
+    from oracle import tiles_oracle as TO
+    from oracle import tta_oracle as AO
+
+    rng = np.random.default_rng(0)
+    state = TO.merger_new(slicer.target_shape, CHANNELS, slicer.weight)
+    sample = rng.standard_normal((VIEWS * BATCH, CHANNELS, TILE, TILE), dtype=np.float32)
+    t0 = time.perf_counter()
+    for b in range(n_batches):
+        crops = slicer.crops[b * BATCH:(b + 1) * BATCH]
+        TO.merger_integrate(state, AO.image_deaugment(sample, "d4", "mean"), crops)
+    t_tiles = (time.perf_counter() - t0) / (n_batches * BATCH)
+    t0 = time.perf_counter()
+    TO.merger_merge(state)
+    t_merge = time.perf_counter() - t0
+    per_image = t_tiles * len(slicer.crops) + t_merge
+    return {
+        "value": round(IMAGE[0] * IMAGE[1] / 1e6 / per_image, 3),
+        "unit": "MP/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{n_batches} batches of {BATCH} tiles (d4 de-augment+mean+accumulate) + one full merge, numpy oracle, extrapolated to 361 tiles",
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import __graft_entry__ as entry
+
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger, tile_row_partition
+
+    if args.chunk_rows:
+        assert N.load().ptb_set_tunable(0, args.chunk_rows) == 0
+
+    slicer = ImageSlicer(IMAGE, TILE, STEP, weight="pyramid")
+    n_tiles = len(slicer.crops)
+    assert n_tiles == 361 and slicer.target_shape == (5120, 5120)
+
+    # ---- this rank's share of the tiles, and their (synthetic) model outputs resident in HBM -------------------
+    if world == 1:
+        my_tiles = np.arange(n_tiles)
+    else:
+        my_tiles = tile_row_partition(slicer.crops, world)[rank]
+    crops = slicer.crops[my_tiles]
+    batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    outputs = torch.empty((VIEWS * len(crops), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
+    for b0, b1 in batches:  # chunk-major per batch: rows [8*b0, 8*b1) hold view k of tiles b0..b1 at k*nb + j
+        outputs[VIEWS * b0:VIEWS * b1].normal_(generator=gen)
+    batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]
+    batch_crops = [crops[b0:b1] for b0, b1 in batches]
+
+    if world == 1:
+        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
+    else:
+        merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev)
+
+    def step():
+        if world == 1:
+            merger.image.zero_()
+            merger.norm_mask.zero_()
+            for t, c in zip(batch_tensors, batch_crops):
+                merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+            return merger.merge()
+        merger.reset()
+        for t, c in zip(batch_tensors, batch_crops):
+            merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+        return merger.merge()  # this rank's band of the merged image
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- dominant-kernel roofline: HIP events around every fused launch (same stream), full batches only ----------
+    ev = []
+    if world == 1:
+        merger.image.zero_()
+        merger.norm_mask.zero_()
+    else:
+        merger.reset()
+    for t, c in zip(batch_tensors, batch_crops):
+        if len(c) == BATCH:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+            e1.record()
+            ev.append((e0, e1))
+        else:
+            merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+    merger.merge()
+    torch.cuda.synchronize()
+    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+    bytes_per_tile = VIEWS * CHANNELS * TILE * TILE * 4          # 8 views x C x T x 4 B read per tile
+    bytes_per_launch = bytes_per_tile * BATCH
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+
+    mp = IMAGE[0] * IMAGE[1] / 1e6
+    ms_per_step = elapsed / args.steps * 1e3
+    value = mp * args.steps / elapsed  # one image per step for the whole job (strong scaling for N > 1)
+    region_bytes = VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4  # 12 532 580 352 B
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("view_accum_d4_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "megapixels/sec tiled+d4-TTA merge on 5000x5000",
+            "value": round(value, 1),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE cfg2: 5000x5000x3 image, ImageSlicer 512/256 pyramid (361 tiles, target 5120x5120), "
+                            "d4 TTA (8 views) model outputs C=4 fp32 resident in HBM, fused de-augment+mean+integrate_batch in "
+                            "batches of 8 tiles + merge; accumulators re-zeroed each step; model forward excluded",
+                "tiles": n_tiles,
+                "batch_tiles": BATCH,
+                "parallelism": "single GPU" if world == 1 else f"tile rows sharded over {world} ranks, RCCL p2p halo exchange",
+                "region_algorithmic_bytes": region_bytes,
+                "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+            },
+            "roofline": {
+                "kernel": "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate, 8 tiles/launch)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "avg_launch_ms": round(launch_ms, 5),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(slicer)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+"""ctypes binding of libptb_hip.so (the C ABI declared in include/ptb_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or a tensor is not on the MI355X,
+the call fails loudly.  PyTorch is used only for device memory, the current HIP stream and autograd glue.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libptb_hip.so")
+
+# view codes (bit0 transpose, bit1 flip source rows, bit2 flip source cols) -- include/ptb_hip.h
+IDENT, TRANSPOSE, FLIPUD, ROT90_CW, FLIPLR, ROT90_CCW, ROT180, ANTITRANSPOSE = range(8)
+
+RED_SUM, RED_MEAN, RED_GMEAN, RED_HMEAN, RED_HARMONIC1P, RED_LOGODD, RED_LOG1P = range(7)
+
+_ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed", -4: "tile rectangle outside the accumulator"}
+
+_c_int = ctypes.c_int
+_c_f = ctypes.c_float
+_c_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> (restype, argtypes); must list every symbol of include/ptb_hip.h (checked by tests/test_abi.py)
+SIGNATURES = {
+    "ptb_version": (_c_int, []),
+    "ptb_last_hip_error": (ctypes.c_char_p, []),
+    "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
+    "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),
+    "ptb_merge_div_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp]),
+    "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_view_transform": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_f, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_resize_bilinear": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+calls = 0  # number of native entry-point invocations (tests assert the HIP path really ran)
+
+
+def load():
+    """Load libptb_hip.so (built by ``__graft_entry__.build()``); raises ImportError when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} is missing: build the HIP extension first "
+                    "(python -c 'import __graft_entry__ as g; g.build()'). There is no non-HIP fallback."
+                )
+            lib = ctypes.CDLL(LIB_PATH)  # torch (imported above) has already loaded libamdhip64.so.7
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    msg = _ERR.get(rc, f"error {rc}")
+    if rc == -3:
+        msg += ": " + load().ptb_last_hip_error().decode()
+    if rc == -2:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise RuntimeError(f"{what}: {msg}")
+
+
+def require_device(t, what):
+    """The native path runs on the GPU only; CPU tensors are refused instead of silently computed elsewhere."""
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on '{t.device}', but pytorch_toolbelt_amd runs its hot path as HIP kernels on the "
+            "MI355X only (no CPU fallback). Move the tensor to a 'cuda' device."
+        )
+
+
+def stream_ptr(device):
+    return _vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+class on_device:
+    """Make ``device`` current for the duration of a launch (kernels launch on the HIP current device)."""
+
+    __slots__ = ("dev", "prev")
+
+    def __init__(self, device):
+        self.dev = device.index if device.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.dev:
+            self.prev = cur
+            torch.cuda.set_device(self.dev)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*values)
+
+
+def i64_array(values):
+    return (ctypes.c_int64 * len(values))(*values)
+
+
+def bump():
+    global calls
+    calls += 1

@@ -1,0 +1,28 @@
+// Internal helpers shared by the libptb_hip translation units (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ptb_hip.h"
+
+namespace ptb {
+
+// thread-local text of the last failing HIP call (ptb_last_hip_error)
+void set_hip_error(hipError_t e);
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_hip_error(e);
+        return PTB_ELAUNCH;
+    }
+    return PTB_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// tunables (ptb_set_tunable)
+extern int g_chunk_rows;    // 16 | 32 | 64
+extern int g_force_scalar;  // 0 | 1
+
+}  // namespace ptb

@@ -1,0 +1,100 @@
+// ptb_core.hip -- library plumbing (version, error text, tunables) and TileMerger.merge (tiles.py:345-350).
+#include <string>
+
+#include "ptb_common.h"
+
+namespace ptb {
+
+static thread_local std::string g_last_error;
+int g_chunk_rows = 64;
+int g_force_scalar = 0;
+
+void set_hip_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
+
+// out[c][p] = (image[c][p] [+ extra[c][p] for p < extra_n]) / norm[p]; IEEE division, no eps clamp (uncovered pixels
+// give NaN like the reference).  Streaming elementwise: 16 B/lane, grid-stride; the norm float4 is reused across the
+// C channels in registers.  Channel strides let a rank merge a row band of a larger accumulator (parallel.py).
+__global__ __launch_bounds__(256) void merge_div_kernel(const float* __restrict__ image, const float* __restrict__ norm,
+                                                        float* __restrict__ out, int C, long long hw4, long long ics4,
+                                                        long long ocs4, const float* __restrict__ extra, long long ecs4,
+                                                        long long en4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float4* n4 = reinterpret_cast<const float4*>(norm);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += stride) {
+        const float4 n = n4[i];
+        for (int c = 0; c < C; ++c) {
+            float4 v = reinterpret_cast<const float4*>(image)[c * ics4 + i];
+            if (i < en4) {
+                const float4 e = reinterpret_cast<const float4*>(extra)[c * ecs4 + i];
+                v.x = __fadd_rn(v.x, e.x); v.y = __fadd_rn(v.y, e.y); v.z = __fadd_rn(v.z, e.z); v.w = __fadd_rn(v.w, e.w);
+            }
+            float4 o;
+            o.x = __fdiv_rn(v.x, n.x); o.y = __fdiv_rn(v.y, n.y); o.z = __fdiv_rn(v.z, n.z); o.w = __fdiv_rn(v.w, n.w);
+            reinterpret_cast<float4*>(out)[c * ocs4 + i] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void merge_div_scalar_kernel(const float* __restrict__ image, const float* __restrict__ norm,
+                                                               float* __restrict__ out, int C, long long hw, long long ics,
+                                                               long long ocs, const float* __restrict__ extra, long long ecs,
+                                                               long long en) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += stride) {
+        const float n = norm[i];
+        for (int c = 0; c < C; ++c) {
+            float v = image[c * ics + i];
+            if (i < en) v = __fadd_rn(v, extra[c * ecs + i]);
+            out[c * ocs + i] = __fdiv_rn(v, n);
+        }
+    }
+}
+
+}  // namespace ptb
+
+using namespace ptb;
+
+extern "C" int ptb_version(void) { return 100; }
+
+extern "C" const char* ptb_last_hip_error(void) { return g_last_error.c_str(); }
+
+extern "C" int ptb_set_tunable(int key, int value) {
+    if (key == 0) {
+        if (value != 16 && value != 32 && value != 64) return PTB_EINVAL;
+        g_chunk_rows = value;
+        return PTB_OK;
+    }
+    if (key == 1) {
+        g_force_scalar = value ? 1 : 0;
+        return PTB_OK;
+    }
+    return PTB_EINVAL;
+}
+
+extern "C" int ptb_merge_div_ex(const float* image, const float* norm, float* out, int C, int64_t HW, int64_t image_cs,
+                                int64_t out_cs, const float* extra, int64_t extra_cs, int64_t extra_n, ptb_stream_t stream) {
+    if (!image || !norm || !out || C < 1 || HW < 0 || image_cs < HW || out_cs < HW) return PTB_EINVAL;
+    if (extra_n < 0 || extra_n > HW || (extra_n > 0 && (!extra || extra_cs < extra_n))) return PTB_EINVAL;
+    if (HW == 0) return PTB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = !g_force_scalar && HW % 4 == 0 && image_cs % 4 == 0 && out_cs % 4 == 0 && aligned16(image) &&
+                     aligned16(norm) && aligned16(out) &&
+                     (extra_n == 0 || (extra_n % 4 == 0 && extra_cs % 4 == 0 && aligned16(extra)));
+    if (vec) {
+        const long long hw4 = HW / 4;
+        const long long want = (hw4 + 255) / 256;
+        const int blocks = (int)(want < 256 * 16 ? want : 256 * 16);
+        hipLaunchKernelGGL(merge_div_kernel, dim3(blocks), dim3(256), 0, s, image, norm, out, C, hw4, (long long)image_cs / 4,
+                           (long long)out_cs / 4, extra, (long long)extra_cs / 4, (long long)extra_n / 4);
+    } else {
+        const long long want = (HW + 255) / 256;
+        const int blocks = (int)(want < 256 * 16 ? want : 256 * 16);
+        hipLaunchKernelGGL(merge_div_scalar_kernel, dim3(blocks), dim3(256), 0, s, image, norm, out, C, (long long)HW,
+                           (long long)image_cs, (long long)out_cs, extra, (long long)extra_cs, (long long)extra_n);
+    }
+    return check_launch();
+}
+
+extern "C" int ptb_merge_div(const float* image, const float* norm, float* out, int C, int64_t HW, ptb_stream_t stream) {
+    return ptb_merge_div_ex(image, norm, out, C, HW, HW, HW, nullptr, 0, 0, stream);
+}

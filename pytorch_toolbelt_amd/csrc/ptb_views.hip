@@ -1,0 +1,676 @@
+// ptb_views.hip -- view-gather kernels for gfx950 (MI355X):
+//   * TTA de-augment + reduce            (reference inference/tta.py:287-316,344-365,442-467,503-524)
+//   * TTA augment / per-view transform   (reference inference/tta.py:257-284,319-341,385-422,470-484)
+//   * TileMerger.integrate_batch         (reference inference/tiles.py:321-339)
+//   * the fusion of de-augment+reduce with integrate_batch (the reduced tile never reaches HBM)
+//
+// One kernel family serves all four: a 64-column x CH-row *chunk* of the output is produced by one
+// workgroup of CH*16 threads, each thread owning one float4 (16 B/lane: 64-lane waves issue 1 KiB
+// global_load_dwordx4).  A D4 view is (T, fr, fc): row-preserving views (T=0) are read straight from
+// HBM with mirrored addressing (reversed rows are still one contiguous 256 B segment per 16 lanes);
+// transposing views (T=1) read the *source* block coalesced along source rows, scatter it transposed
+// into an XOR-swizzled LDS tile (ds_write_b32, <=2-way = free on CDNA4) and read it back as one
+// conflict-free ds_read_b128 per lane.  These kernels are HBM-bound streaming gathers: no MFMA.
+//
+// Accumulation into the TileMerger image is race-free without atomics: the host splits the batch's
+// tile rectangles into disjoint *cells* (the arrangement of their edges); every cell is owned by
+// exactly one set of workgroups, which walk the (<=4) covering tiles in batch order and read-modify-
+// write each accumulator element exactly once per launch.  Per-XCD L2s are not coherent, so
+// exclusive ownership within a launch (plus the kernel-boundary release/acquire between launches) is
+// what makes this correct on MI355X; it also halves the RMW traffic of 50%-overlap batches and
+// reproduces the reference's sequential fp32 order bit-for-bit (mul and add are not contracted).
+#include <algorithm>
+#include <vector>
+
+#include "ptb_common.h"
+
+namespace ptb {
+
+constexpr int MAX_VIEWS = 8;
+constexpr int MAX_T = 4;       // LDS tiles: at most 4 of 8 D4 views transpose
+constexpr int MAX_CELLS = 64;  // per launch (kernarg budget)
+constexpr int MAX_COVER = 4;   // tiles covering one cell
+constexpr int MAX_GROUP = 64;  // tiles per launch in accumulate mode
+constexpr int CW = 64;         // chunk columns (256 B row segments)
+
+// number of LDS transpose tiles a kernel instantiation needs (CODES < 0: view codes known only at run time)
+constexpr int lds_tiles(int nv, int codes) {
+    if (codes < 0) return nv < MAX_T ? nv : MAX_T;
+    int n = 0;
+    for (int k = 0; k < nv; ++k) n += (codes >> (3 * k)) & 1;
+    return n;
+}
+
+struct Cell {
+    int ox, oy, w, h;     // rectangle in accumulator coordinates
+    int chunk_end;        // exclusive prefix of chunk counts (cells sorted heavy-first)
+    int ntiles;
+    int tile[MAX_COVER];  // group-local tile indices, ascending batch order
+};
+
+struct CellArgs {
+    Cell cells[MAX_CELLS];
+    int tile_x[MAX_GROUP];
+    int tile_y[MAX_GROUP];
+    int tile_id[MAX_GROUP];  // index into the batch (source tile)
+};
+
+struct ViewArgs {
+    const float* src;
+    float* dst;           // plain output, or the accumulator image
+    float* norm;          // accumulate mode
+    const float* weight;  // accumulate mode, [H, W] of the tile
+    int H, W, C;          // output-tile rows / cols, channels
+    long long src_view_stride;  // elements between consecutive views of one tile (B*C*H*W)
+    long long src_tile_stride;  // C*H*W
+    long long dst_tile_stride;
+    long long dst_chan_stride;
+    int dst_row_stride;
+    int nviews;
+    int codes;           // 3 bits per view
+    int tiles_per_view;  // per-view mode: out tile t uses view t / tiles_per_view ...
+    int src_tile_mod;    // ... and source tile t % src_tile_mod
+    int op;              // PTB_RED_*
+    float divisor;       // linear ops: out = sum / divisor (1 for sum); non-linear: mean divisor
+    float scale;         // per-view mode multiplier
+    int chunks_x, chunks_y;  // plain modes: chunks per tile
+    int ncells, total_chunks;
+};
+
+enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
+
+// ------------------------------------------------------------------------------------------------ reductions
+constexpr float kEps = 1e-6f;
+constexpr float kOneMinusEps = (float)(1.0 - 1e-6);
+
+template <int OPK>
+__device__ __forceinline__ float red_pre(float x, int op) {
+    if (OPK == 0) return x;
+    switch (op) {
+        case PTB_RED_GMEAN: return logf(x);                                   // functional.py:261
+        case PTB_RED_HMEAN: return 1.0f / (x < kEps ? kEps : x);              // functional.py:275
+        case PTB_RED_HARMONIC1P: return 1.0f / (x + 1.0f);                    // functional.py:292
+        case PTB_RED_LOGODD: {                                               // functional.py:311-312
+            float p = x < kEps ? kEps : (x > kOneMinusEps ? kOneMinusEps : x);
+            return logf(p / (1.0f - p));
+        }
+        case PTB_RED_LOG1P: return log1pf(x);                                 // functional.py:330
+        default: return x;
+    }
+}
+
+template <int OPK>
+__device__ __forceinline__ float red_post(float s, int op, float divisor) {
+    if (OPK == 0) return divisor == 1.0f ? s : s / divisor;
+    const float m = s / divisor;
+    switch (op) {
+        case PTB_RED_GMEAN: return expf(m);
+        case PTB_RED_HMEAN: return 1.0f / (m < kEps ? kEps : m);
+        case PTB_RED_HARMONIC1P: return 1.0f / m - 1.0f;
+        case PTB_RED_LOGODD: { const float e = expf(m); return e / (1.0f + e); }
+        case PTB_RED_LOG1P: return expf(m) - 1.0f;
+        default: return m;
+    }
+}
+
+// XOR-swizzled [CH][64] fp32 LDS tile: 16-byte slots of a row are permuted by (row/4) so that the transposing
+// scatter (lanes walk rows) spreads over banks and the b128 gather (16 lanes per row) stays conflict-free.
+__device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + (j & 3); }
+
+__device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }
+
+// Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
+// tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
+template <int CH, int NV, int CODES, int OPK>
+__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane, long long view_stride, int nv_rt,
+                                                int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
+                                                float divisor, float* lds, int tid, bool more_entries) {
+    constexpr int QPR = CH / 4;  // float4 per source row of a transposed block
+    const int q = tid & 15, r = tid >> 4;
+    const int rr = tid / QPR, qq = tid % QPR;
+    const bool act = (r < ch) && (4 * q < cw);
+    const bool tact = (rr < cw) && (4 * qq < ch);
+    const int nv = CODES >= 0 ? NV : nv_rt;
+    const int codes = CODES >= 0 ? CODES : codes_rt;
+
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (k < nv) {
+            const int code = (codes >> (3 * k)) & 7;
+            const float* p = plane + (long long)k * view_stride;
+            if (!(code & 1)) {
+                if (act) {
+                    const int i = ly + r, j = lx + 4 * q;
+                    const int row = (code & 2) ? H - 1 - i : i;
+                    const int col = (code & 4) ? W - 4 - j : j;
+                    const float4 t = *reinterpret_cast<const float4*>(p + (long long)row * W + col);
+                    v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
+                }
+            } else if (tact) {
+                const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
+                const int C0 = (code & 4) ? W - ly - ch : ly;
+                v[k] = *reinterpret_cast<const float4*>(p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+            }
+        }
+    }
+
+    int tb = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (k < nv && ((codes >> (3 * k)) & 1)) {
+            const int code = (codes >> (3 * k)) & 7;
+            float* buf = lds + tb * (CW * CH);
+            ++tb;
+            if (tact) {
+                const int jl = (code & 2) ? cw - 1 - rr : rr;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int cc = 4 * qq + m;
+                    const int il = (code & 4) ? ch - 1 - cc : cc;
+                    buf[swz(il, jl)] = comp(v[k], m);
+                }
+            }
+        }
+    }
+    if (tb) {
+        __syncthreads();
+        tb = 0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (k < nv && ((codes >> (3 * k)) & 1)) {
+                const float* buf = lds + tb * (CW * CH);
+                ++tb;
+                v[k] = act ? *reinterpret_cast<const float4*>(buf + swz(r, 4 * q)) : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
+        if (more_entries) __syncthreads();  // LDS tiles are reused by the next covering tile
+    }
+
+    float4 s = make_float4(red_pre<OPK>(v[0].x, op), red_pre<OPK>(v[0].y, op), red_pre<OPK>(v[0].z, op), red_pre<OPK>(v[0].w, op));
+#pragma unroll
+    for (int k = 1; k < NV; ++k) {
+        if (k < nv) {
+            s.x = __fadd_rn(s.x, red_pre<OPK>(v[k].x, op));
+            s.y = __fadd_rn(s.y, red_pre<OPK>(v[k].y, op));
+            s.z = __fadd_rn(s.z, red_pre<OPK>(v[k].z, op));
+            s.w = __fadd_rn(s.w, red_pre<OPK>(v[k].w, op));
+        }
+    }
+    return make_float4(red_post<OPK>(s.x, op, divisor), red_post<OPK>(s.y, op, divisor), red_post<OPK>(s.z, op, divisor),
+                       red_post<OPK>(s.w, op, divisor));
+}
+
+// ------------------------------------------------------------------------------------------------ fast kernels
+template <int CH, int NV, int CODES, int OPK, int MODE>
+__global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
+    const int tid = threadIdx.x;
+    const int cpt = a.chunks_x * a.chunks_y;
+    int bid = blockIdx.x;
+    const int chunk = bid % cpt;
+    bid /= cpt;
+    const int c = bid % a.C;
+    const int t = bid / a.C;
+    const int cx0 = (chunk % a.chunks_x) * CW, cy0 = (chunk / a.chunks_x) * CH;
+    const int cw = min(CW, a.W - cx0), ch = min(CH, a.H - cy0);
+
+    int codes = a.codes, nv = a.nviews;
+    long long src_tile = t;
+    if (MODE == MODE_PERVIEW) {
+        codes = (a.codes >> (3 * (t / a.tiles_per_view))) & 7;
+        nv = 1;
+        src_tile = t % a.src_tile_mod;
+    }
+    const float* plane = a.src + src_tile * a.src_tile_stride + (long long)c * a.H * a.W;
+    float4 val = gather_reduce<CH, NV, CODES, OPK>(plane, a.src_view_stride, nv, codes, a.H, a.W, cx0, cy0, cw, ch, a.op,
+                                                  a.divisor, lds, tid, false);
+    if (MODE == MODE_PERVIEW && a.scale != 1.0f) {
+        val.x *= a.scale; val.y *= a.scale; val.z *= a.scale; val.w *= a.scale;
+    }
+    const int q = tid & 15, r = tid >> 4;
+    if (r < ch && 4 * q < cw) {
+        float* o = a.dst + (long long)t * a.dst_tile_stride + (long long)c * a.dst_chan_stride +
+                   (long long)(cy0 + r) * a.dst_row_stride + cx0 + 4 * q;
+        *reinterpret_cast<float4*>(o) = val;
+    }
+}
+
+template <int CH, int NV, int CODES, int OPK>
+__global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, const CellArgs g) {
+    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x % a.C;
+    const int chunk = blockIdx.x / a.C;
+    int ci = 0;
+    while (ci < a.ncells - 1 && chunk >= g.cells[ci].chunk_end) ++ci;
+    const Cell& cell = g.cells[ci];
+    const int first = ci ? g.cells[ci - 1].chunk_end : 0;
+    const int ncx = (cell.w + CW - 1) / CW;
+    const int lc = chunk - first;
+    const int cx0 = (lc % ncx) * CW, cy0 = (lc / ncx) * CH;
+    const int cw = min(CW, cell.w - cx0), ch = min(CH, cell.h - cy0);
+    const int q = tid & 15, r = tid >> 4;
+    const bool act = (r < ch) && (4 * q < cw);
+    const int ax = cell.ox + cx0, ay = cell.oy + cy0;  // chunk origin in the accumulator
+
+    float* ip = a.dst + (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+    float* np = a.norm + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), nacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) {
+        acc = *reinterpret_cast<const float4*>(ip);
+        if (c == 0) nacc = *reinterpret_cast<const float4*>(np);
+    }
+    const int nt = cell.ntiles;
+    for (int e = 0; e < nt; ++e) {
+        const int gt = cell.tile[e];
+        const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
+        const float* plane = a.src + (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
+        const float4 val = gather_reduce<CH, NV, CODES, OPK>(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
+                                                        ch, a.op, a.divisor, lds, tid, e + 1 < nt);
+        if (act) {
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
+            // tile*weight rounded, then added: the reference's two torch ops (tiles.py:338), no FMA contraction
+            acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));
+            acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, w4.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, w4.z));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(val.w, w4.w));
+            if (c == 0) {
+                nacc.x = __fadd_rn(nacc.x, w4.x); nacc.y = __fadd_rn(nacc.y, w4.y);
+                nacc.z = __fadd_rn(nacc.z, w4.z); nacc.w = __fadd_rn(nacc.w, w4.w);
+            }
+        }
+    }
+    if (act) {
+        *reinterpret_cast<float4*>(ip) = acc;
+        if (c == 0) *reinterpret_cast<float4*>(np) = nacc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scalar kernels
+// Any shape / alignment (odd tile sizes such as the reference's 51/26 test): one element per thread, 64x4 threads
+// sweeping a 64x64 chunk.  Same cell ownership and the same arithmetic order as the fast kernels.
+__device__ __forceinline__ float scalar_reduce(const float* __restrict__ plane, long long view_stride, int nv, int codes,
+                                               int H, int W, int i, int j, int op, float divisor, bool nonlinear) {
+    float s = 0.f;
+    for (int k = 0; k < nv; ++k) {
+        const int code = (codes >> (3 * k)) & 7;
+        int rr = (code & 1) ? j : i, cc = (code & 1) ? i : j;
+        const int rows = (code & 1) ? W : H, cols = (code & 1) ? H : W;
+        if (code & 2) rr = rows - 1 - rr;
+        if (code & 4) cc = cols - 1 - cc;
+        float x = plane[(long long)k * view_stride + (long long)rr * cols + cc];
+        x = nonlinear ? red_pre<1>(x, op) : x;
+        s = k ? __fadd_rn(s, x) : x;
+    }
+    return nonlinear ? red_post<1>(s, op, divisor) : red_post<0>(s, op, divisor);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void view_plain_scalar_kernel(const ViewArgs a) {
+    const int cpt = a.chunks_x * a.chunks_y;
+    int bid = blockIdx.x;
+    const int chunk = bid % cpt;
+    bid /= cpt;
+    const int c = bid % a.C;
+    const int t = bid / a.C;
+    const int cx0 = (chunk % a.chunks_x) * CW, cy0 = (chunk / a.chunks_x) * 64;
+    const int cw = min(CW, a.W - cx0), ch = min(64, a.H - cy0);
+    int codes = a.codes, nv = a.nviews;
+    long long src_tile = t;
+    if (MODE == MODE_PERVIEW) {
+        codes = (a.codes >> (3 * (t / a.tiles_per_view))) & 7;
+        nv = 1;
+        src_tile = t % a.src_tile_mod;
+    }
+    const float* plane = a.src + src_tile * a.src_tile_stride + (long long)c * a.H * a.W;
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (tx >= cw) return;
+    for (int r = ty; r < ch; r += 4) {
+        float val = scalar_reduce(plane, a.src_view_stride, nv, codes, a.H, a.W, cy0 + r, cx0 + tx, a.op, a.divisor, nonlinear);
+        if (MODE == MODE_PERVIEW && a.scale != 1.0f) val *= a.scale;
+        a.dst[(long long)t * a.dst_tile_stride + (long long)c * a.dst_chan_stride + (long long)(cy0 + r) * a.dst_row_stride + cx0 + tx] = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a, const CellArgs g) {
+    const int c = blockIdx.x % a.C;
+    const int chunk = blockIdx.x / a.C;
+    int ci = 0;
+    while (ci < a.ncells - 1 && chunk >= g.cells[ci].chunk_end) ++ci;
+    const Cell& cell = g.cells[ci];
+    const int first = ci ? g.cells[ci - 1].chunk_end : 0;
+    const int ncx = (cell.w + CW - 1) / CW;
+    const int lc = chunk - first;
+    const int cx0 = (lc % ncx) * CW, cy0 = (lc / ncx) * 64;
+    const int cw = min(CW, cell.w - cx0), ch = min(64, cell.h - cy0);
+    const int ax = cell.ox + cx0, ay = cell.oy + cy0;
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (tx >= cw) return;
+    for (int r = ty; r < ch; r += 4) {
+        const long long off = (long long)(ay + r) * a.dst_row_stride + ax + tx;
+        float acc = a.dst[(long long)c * a.dst_chan_stride + off];
+        float nacc = c == 0 ? a.norm[off] : 0.f;
+        for (int e = 0; e < cell.ntiles; ++e) {
+            const int gt = cell.tile[e];
+            const int lx = ax - g.tile_x[gt] + tx, ly = ay - g.tile_y[gt] + r;
+            const float* plane = a.src + (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
+            const float val = scalar_reduce(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, ly, lx, a.op, a.divisor, nonlinear);
+            const float w = a.weight[(long long)ly * a.W + lx];
+            acc = __fadd_rn(acc, __fmul_rn(val, w));
+            nacc = __fadd_rn(nacc, w);
+        }
+        a.dst[(long long)c * a.dst_chan_stride + off] = acc;
+        if (c == 0) a.norm[off] = nacc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host: cells
+// Split the tile rectangles of one launch group into disjoint cells (arrangement of their edges), each with the
+// ascending list of covering tiles.  Returns false when the group needs more than MAX_CELLS / MAX_COVER.
+static bool decompose(const int* xs, const int* ys, const int* ids, int n, int tw, int th, int chunk_rows, CellArgs& out,
+                      int& ncells, int& total_chunks) {
+    if (n > MAX_GROUP) return false;
+    std::vector<int> ye;
+    ye.reserve(2 * n);
+    for (int t = 0; t < n; ++t) { ye.push_back(ys[t]); ye.push_back(ys[t] + th); }
+    std::sort(ye.begin(), ye.end());
+    ye.erase(std::unique(ye.begin(), ye.end()), ye.end());
+    std::vector<Cell> cells;
+    std::vector<int> active, xe;
+    for (size_t yi = 0; yi + 1 < ye.size(); ++yi) {
+        const int y0 = ye[yi], y1 = ye[yi + 1];
+        active.clear();
+        for (int t = 0; t < n; ++t) if (ys[t] <= y0 && y0 < ys[t] + th) active.push_back(t);
+        if (active.empty()) continue;
+        xe.clear();
+        for (int t : active) { xe.push_back(xs[t]); xe.push_back(xs[t] + tw); }
+        std::sort(xe.begin(), xe.end());
+        xe.erase(std::unique(xe.begin(), xe.end()), xe.end());
+        for (size_t xi = 0; xi + 1 < xe.size(); ++xi) {
+            const int x0 = xe[xi], x1 = xe[xi + 1];
+            Cell c{};
+            for (int t : active) {
+                if (xs[t] <= x0 && x0 < xs[t] + tw) {
+                    if (c.ntiles == MAX_COVER) return false;
+                    c.tile[c.ntiles++] = t;
+                }
+            }
+            if (!c.ntiles) continue;
+            c.ox = x0; c.oy = y0; c.w = x1 - x0; c.h = y1 - y0;
+            // merge with the cell directly above when it has the same x-range and cover (fewer, taller cells)
+            bool merged = false;
+            for (auto it = cells.rbegin(); it != cells.rend(); ++it) {
+                if (it->oy + it->h == y0 && it->ox == x0 && it->w == c.w && it->ntiles == c.ntiles &&
+                    std::equal(c.tile, c.tile + c.ntiles, it->tile)) {
+                    it->h += c.h;
+                    merged = true;
+                    break;
+                }
+            }
+            if (!merged) cells.push_back(c);
+        }
+    }
+    if ((int)cells.size() > MAX_CELLS) return false;
+    std::stable_sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) { return a.ntiles > b.ntiles; });
+    int run = 0;
+    for (size_t i = 0; i < cells.size(); ++i) {
+        run += ((cells[i].w + CW - 1) / CW) * ((cells[i].h + chunk_rows - 1) / chunk_rows);
+        cells[i].chunk_end = run;
+        out.cells[i] = cells[i];
+    }
+    for (int t = 0; t < n; ++t) { out.tile_x[t] = xs[t]; out.tile_y[t] = ys[t]; out.tile_id[t] = ids[t]; }
+    ncells = (int)cells.size();
+    total_chunks = run;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ dispatch
+constexpr int pack_codes(std::initializer_list<int> l) {
+    int v = 0, k = 0;
+    for (int c : l) v |= c << (3 * k++);
+    return v;
+}
+constexpr int CODES_ID = 0;
+constexpr int CODES_FLIPLR = pack_codes({0, 4});
+constexpr int CODES_FLIPUD = pack_codes({0, 2});
+constexpr int CODES_FLIPS = pack_codes({0, 4, 2});
+constexpr int CODES_D2 = pack_codes({0, 4, 2, 6});
+constexpr int CODES_D4 = pack_codes({0, 5, 6, 3, 1, 4, 7, 2});  // inverse views of d4_image_deaugment, tta.py:455-466
+
+static int pack_runtime(int V, const int* views) {
+    int v = 0;
+    for (int k = 0; k < V; ++k) v |= (views[k] & 7) << (3 * k);
+    return v;
+}
+
+template <int CH, int MODE>
+static void launch_plain_ch(const ViewArgs& a, int blocks, hipStream_t s, bool nonlinear) {
+    const dim3 grid(blocks), block(CH * 16);
+#define PTB_PLAIN(NV, CODES)                                                                                      \
+    do {                                                                                                          \
+        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE>), grid, block, 0, s, a);     \
+        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE>), grid, block, 0, s, a);               \
+    } while (0)
+    if constexpr (MODE == MODE_PERVIEW) {
+        hipLaunchKernelGGL((view_plain_kernel<CH, 1, -1, 0, MODE_PERVIEW>), grid, block, 0, s, a);
+    } else {
+        if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_PLAIN(2, CODES_FLIPLR);
+        else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_PLAIN(2, CODES_FLIPUD);
+        else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_PLAIN(3, CODES_FLIPS);
+        else if (a.nviews == 4 && a.codes == CODES_D2) PTB_PLAIN(4, CODES_D2);
+        else if (a.nviews == 8 && a.codes == CODES_D4) PTB_PLAIN(8, CODES_D4);
+        else PTB_PLAIN(8, -1);
+    }
+#undef PTB_PLAIN
+}
+
+template <int CH>
+static void launch_accum_ch(const ViewArgs& a, const CellArgs& g, int blocks, hipStream_t s, bool nonlinear) {
+    const dim3 grid(blocks), block(CH * 16);
+#define PTB_ACCUM(NV, CODES)                                                                                      \
+    do {                                                                                                          \
+        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1>), grid, block, 0, s, a, g);        \
+        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0>), grid, block, 0, s, a, g);                  \
+    } while (0)
+    if (a.nviews == 1 && a.codes == CODES_ID && !nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, 1, CODES_ID, 0>), grid, block, 0, s, a, g);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_ACCUM(2, CODES_FLIPLR);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_ACCUM(2, CODES_FLIPUD);
+    else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_ACCUM(3, CODES_FLIPS);
+    else if (a.nviews == 4 && a.codes == CODES_D2) PTB_ACCUM(4, CODES_D2);
+    else if (a.nviews == 8 && a.codes == CODES_D4) PTB_ACCUM(8, CODES_D4);
+    else PTB_ACCUM(8, -1);
+#undef PTB_ACCUM
+}
+
+static bool has_transpose(int V, int codes) {
+    for (int k = 0; k < V; ++k) if ((codes >> (3 * k)) & 1) return true;
+    return false;
+}
+static int count_transpose(int V, int codes) {
+    int n = 0;
+    for (int k = 0; k < V; ++k) n += (codes >> (3 * k)) & 1;
+    return n;
+}
+
+static int validate_views(int V, const int* views, int H, int W) {
+    if (V < 1 || V > MAX_VIEWS || !views) return PTB_EINVAL;
+    int nt = 0;
+    for (int k = 0; k < V; ++k) {
+        if (views[k] < 0 || views[k] > 7) return PTB_EINVAL;
+        nt += views[k] & 1;
+    }
+    if (nt && H != W) return PTB_EINVAL;
+    return PTB_OK;
+}
+
+static void fill_reduction(ViewArgs& a, int reduction, int V) {
+    a.op = reduction;
+    a.divisor = reduction == PTB_RED_SUM ? 1.0f : (float)V;
+}
+
+static int run_plain(ViewArgs& a, int ntiles_out, int mode, hipStream_t s) {
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+    const int nT = mode == MODE_PERVIEW ? 1 : count_transpose(a.nviews, a.codes);
+    const bool tr = mode == MODE_PERVIEW ? has_transpose(a.nviews, a.codes) : nT > 0;
+    bool fast = !g_force_scalar && (a.W % 4 == 0) && (a.dst_row_stride % 4 == 0) && (a.dst_chan_stride % 4 == 0) &&
+                (a.dst_tile_stride % 4 == 0) && aligned16(a.src) && aligned16(a.dst) && nT <= MAX_T;
+    if (tr && a.H % 4 != 0) fast = false;
+    if ((long long)a.H * a.W % 4 != 0) fast = false;
+    const int ch = fast ? g_chunk_rows : 64;
+    a.chunks_x = (a.W + CW - 1) / CW;
+    a.chunks_y = (a.H + ch - 1) / ch;
+    const long long blocks = (long long)ntiles_out * a.C * a.chunks_x * a.chunks_y;
+    if (blocks <= 0) return PTB_OK;
+    if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    if (!fast) {
+        if (mode == MODE_PERVIEW) hipLaunchKernelGGL(view_plain_scalar_kernel<MODE_PERVIEW>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(view_plain_scalar_kernel<MODE_REDUCE>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        return check_launch();
+    }
+    if (mode == MODE_PERVIEW) {
+        if (ch == 64) launch_plain_ch<64, MODE_PERVIEW>(a, (int)blocks, s, false);
+        else if (ch == 32) launch_plain_ch<32, MODE_PERVIEW>(a, (int)blocks, s, false);
+        else launch_plain_ch<16, MODE_PERVIEW>(a, (int)blocks, s, false);
+    } else {
+        if (ch == 64) launch_plain_ch<64, MODE_REDUCE>(a, (int)blocks, s, nonlinear);
+        else if (ch == 32) launch_plain_ch<32, MODE_REDUCE>(a, (int)blocks, s, nonlinear);
+        else launch_plain_ch<16, MODE_REDUCE>(a, (int)blocks, s, nonlinear);
+    }
+    return check_launch();
+}
+
+// Accumulate a run of tiles [lo, hi) of the batch; splits recursively until each launch group decomposes.
+static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, bool fast, int ch, hipStream_t s) {
+    if (lo >= hi) return PTB_OK;
+    CellArgs g;
+    int ids[MAX_GROUP];
+    const int n = hi - lo;
+    bool ok = n <= MAX_GROUP;
+    if (ok) {
+        for (int t = 0; t < n; ++t) ids[t] = lo + t;
+        ok = decompose(xs + lo, ys + lo, ids, n, a.W, a.H, ch, g, a.ncells, a.total_chunks);
+    }
+    if (!ok) {
+        if (n == 1) return PTB_EUNSUPPORTED;  // cannot happen: one tile is one cell
+        const int mid = lo + n / 2;
+        const int rc = run_accum(a, xs, ys, lo, mid, fast, ch, s);
+        return rc ? rc : run_accum(a, xs, ys, mid, hi, fast, ch, s);
+    }
+    const long long blocks = (long long)a.total_chunks * a.C;
+    if (blocks <= 0) return PTB_OK;
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+    if (!fast) {
+        hipLaunchKernelGGL(view_accum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
+    } else if (ch == 64) {
+        launch_accum_ch<64>(a, g, (int)blocks, s, nonlinear);
+    } else if (ch == 32) {
+        launch_accum_ch<32>(a, g, (int)blocks, s, nonlinear);
+    } else {
+        launch_accum_ch<16>(a, g, (int)blocks, s, nonlinear);
+    }
+    return check_launch();
+}
+
+static int accumulate_impl(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
+                           int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th, int tw, int H, int W,
+                           hipStream_t s) {
+    if (!image || !norm || !weight || !in || !xs64 || !ys64) return PTB_EINVAL;
+    if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, th, tw)) return rc;
+    if (B == 0) return PTB_OK;
+    std::vector<int> xs(B), ys(B);
+    bool aligned = true;
+    for (int b = 0; b < B; ++b) {
+        if (xs64[b] < 0 || ys64[b] < 0 || xs64[b] + tw > W || ys64[b] + th > H) return PTB_EBOUNDS;
+        xs[b] = (int)xs64[b];
+        ys[b] = (int)ys64[b];
+        if (xs[b] % 4) aligned = false;
+    }
+    ViewArgs a{};
+    a.src = in; a.dst = image; a.norm = norm; a.weight = weight;
+    a.H = th; a.W = tw; a.C = C;
+    a.src_view_stride = (long long)B * C * th * tw;
+    a.src_tile_stride = (long long)C * th * tw;
+    a.dst_tile_stride = 0;
+    a.dst_chan_stride = (long long)H * W;
+    a.dst_row_stride = W;
+    a.nviews = V;
+    a.codes = pack_runtime(V, views);
+    a.scale = 1.0f;
+    fill_reduction(a, reduction, V);
+    const int nT = count_transpose(V, a.codes);
+    bool fast = !g_force_scalar && aligned && (tw % 4 == 0) && (W % 4 == 0) && ((long long)H * W % 4 == 0) &&
+                ((long long)th * tw % 4 == 0) && aligned16(in) && aligned16(image) && aligned16(norm) && aligned16(weight) &&
+                nT <= MAX_T;
+    if (nT) {  // transposed source blocks are addressed by tile-local rows: need 4-aligned row offsets too
+        if (th % 4) fast = false;
+        for (int b = 0; b < B && fast; ++b) if ((ys[b] - ys[0]) % 4) fast = false;
+    }
+    const int ch = fast ? g_chunk_rows : 64;
+    return run_accum(a, xs.data(), ys.data(), 0, B, fast, ch, s);
+}
+
+}  // namespace ptb
+
+using namespace ptb;
+
+extern "C" int ptb_tile_accumulate(float* image, float* norm, const float* weight, const float* tiles, const int64_t* xs,
+                                   const int64_t* ys, int B, int C, int th, int tw, int H, int W, ptb_stream_t stream) {
+    const int ident = PTB_VIEW_IDENT;
+    return accumulate_impl(image, norm, weight, tiles, 1, &ident, PTB_RED_SUM, xs, ys, B, C, th, tw, H, W, (hipStream_t)stream);
+}
+
+extern "C" int ptb_deaug_accumulate(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
+                                    int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw, int H,
+                                    int W, ptb_stream_t stream) {
+    return accumulate_impl(image, norm, weight, in, V, views, reduction, xs, ys, B, C, th, tw, H, W, (hipStream_t)stream);
+}
+
+extern "C" int ptb_deaug_reduce(const float* in, float* out, int V, const int* views, int reduction, int B, int C, int H, int W,
+                                ptb_stream_t stream) {
+    if (!in || !out || B < 0 || C < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, H, W)) return rc;
+    if (B == 0) return PTB_OK;
+    ViewArgs a{};
+    a.src = in; a.dst = out;
+    a.H = H; a.W = W; a.C = C;
+    a.src_view_stride = (long long)B * C * H * W;
+    a.src_tile_stride = (long long)C * H * W;
+    a.dst_tile_stride = (long long)C * H * W;
+    a.dst_chan_stride = (long long)H * W;
+    a.dst_row_stride = W;
+    a.nviews = V;
+    a.codes = pack_runtime(V, views);
+    a.scale = 1.0f;
+    fill_reduction(a, reduction, V);
+    return run_plain(a, B, MODE_REDUCE, (hipStream_t)stream);
+}
+
+extern "C" int ptb_view_transform(const float* in, float* out, int V, const int* views, int in_is_batch, float scale, int B,
+                                  int C, int H, int W, ptb_stream_t stream) {
+    if (!in || !out || B < 0 || C < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, H, W)) return rc;
+    if (B == 0) return PTB_OK;
+    ViewArgs a{};
+    a.src = in; a.dst = out;
+    a.H = H; a.W = W; a.C = C;
+    a.src_view_stride = 0;
+    a.src_tile_stride = (long long)C * H * W;
+    a.dst_tile_stride = (long long)C * H * W;
+    a.dst_chan_stride = (long long)H * W;
+    a.dst_row_stride = W;
+    a.nviews = V;
+    a.codes = pack_runtime(V, views);
+    a.tiles_per_view = B;
+    a.src_tile_mod = in_is_batch ? B : V * B;
+    a.scale = scale;
+    a.op = PTB_RED_SUM;
+    a.divisor = 1.0f;
+    return run_plain(a, V * B, MODE_PERVIEW, (hipStream_t)stream);
+}

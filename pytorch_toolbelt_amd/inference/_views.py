@@ -1,0 +1,173 @@
+"""Autograd-aware Python front of the view kernels (ptb_view_transform / ptb_deaug_reduce).
+
+A *view code* is 3 bits (transpose, flip source rows, flip source cols) -- see include/ptb_hip.h.  Everything here
+launches hand-written HIP kernels on the current stream; tensors must be float32 and live on the GPU.
+"""
+from typing import Sequence
+
+import torch
+
+from .. import _native as N
+
+# inverse of each D4 element: the two quarter turns swap, everything else is an involution
+INVERSE = {
+    N.IDENT: N.IDENT,
+    N.TRANSPOSE: N.TRANSPOSE,
+    N.FLIPUD: N.FLIPUD,
+    N.FLIPLR: N.FLIPLR,
+    N.ROT180: N.ROT180,
+    N.ANTITRANSPOSE: N.ANTITRANSPOSE,
+    N.ROT90_CW: N.ROT90_CCW,
+    N.ROT90_CCW: N.ROT90_CW,
+}
+
+REDUCTION_CODES = {
+    "sum": N.RED_SUM,
+    "mean": N.RED_MEAN,
+    "gmean": N.RED_GMEAN,
+    "geometric_mean": N.RED_GMEAN,
+    "hmean": N.RED_HMEAN,
+    "harmonic_mean": N.RED_HMEAN,
+    "harmonic1p": N.RED_HARMONIC1P,
+    "logodd": N.RED_LOGODD,
+    "log1p": N.RED_LOG1P,
+}
+
+
+def _check_image(x, what):
+    N.require_device(x, what)
+    if x.dim() != 4:
+        raise NotImplementedError(f"{what}: expected a [B, C, H, W] tensor, got shape {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"{what}: the native path is float32, got {x.dtype}")
+
+
+def _raw_view_transform(x, views: Sequence[int], in_is_batch: bool, scale: float):
+    """out[k*B + b] = scale * view_k(x[b or k*B+b]); x contiguous fp32 [*, C, H, W] on the GPU."""
+    V = len(views)
+    n, C, H, W = x.shape
+    B = n if in_is_batch else n // V
+    if any(v & 1 for v in views) and H != W:
+        raise ValueError(f"Input tensor must have number of rows equal to number of cols. Got input tensor of shape {x.size()}")
+    out = torch.empty((V * B, C, H, W), device=x.device, dtype=x.dtype)
+    lib = N.load()
+    with N.on_device(x.device):
+        rc = lib.ptb_view_transform(x.data_ptr(), out.data_ptr(), V, N.int_array(views), 1 if in_is_batch else 0, float(scale),
+                                    B, C, H, W, N.stream_ptr(x.device))
+    N.bump()
+    N.check(rc, "ptb_view_transform")
+    return out
+
+
+def _raw_deaug_reduce(x, views: Sequence[int], code: int):
+    """out[b] = reduce_k view_k(x[k*B + b]); x contiguous fp32 [V*B, C, H, W] on the GPU."""
+    V = len(views)
+    n, C, H, W = x.shape
+    B = n // V
+    if any(v & 1 for v in views) and H != W:
+        raise ValueError(f"Transposing views need square inputs, got {tuple(x.shape)}")
+    out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
+    lib = N.load()
+    with N.on_device(x.device):
+        rc = lib.ptb_deaug_reduce(x.data_ptr(), out.data_ptr(), V, N.int_array(views), code, B, C, H, W, N.stream_ptr(x.device))
+    N.bump()
+    N.check(rc, "ptb_deaug_reduce")
+    return out
+
+
+class _ViewTransform(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, views, in_is_batch, scale):
+        ctx.views, ctx.in_is_batch, ctx.scale = tuple(views), in_is_batch, scale
+        return _raw_view_transform(x.contiguous(), views, in_is_batch, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        inv = [INVERSE[v] for v in ctx.views]
+        if ctx.in_is_batch:  # every input element fans out to V outputs: gather them back and sum
+            gx = _raw_deaug_reduce(g, inv, N.RED_SUM)
+            if ctx.scale != 1.0:
+                gx = gx * ctx.scale
+        else:
+            gx = _raw_view_transform(g, inv, False, ctx.scale)
+        return gx, None, None, None
+
+
+class _DeaugReduce(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, views, code):
+        ctx.views, ctx.code = tuple(views), code
+        return _raw_deaug_reduce(x.contiguous(), views, code)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.code not in (N.RED_SUM, N.RED_MEAN):
+            raise NotImplementedError("backward of non-linear TTA reductions (gmean/hmean/logodd/...) is not implemented natively yet")
+        inv = [INVERSE[v] for v in ctx.views]
+        scale = 1.0 if ctx.code == N.RED_SUM else 1.0 / len(inv)
+        return _raw_view_transform(g.contiguous(), inv, True, scale), None, None
+
+
+def view_transform(x, views, in_is_batch=True, scale=1.0):
+    _check_image(x, "view transform")
+    return _ViewTransform.apply(x, list(views), in_is_batch, scale)
+
+
+def deaug_reduce(x, views, code):
+    _check_image(x, "de-augment")
+    if x.shape[0] % len(views) != 0:
+        raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
+    return _DeaugReduce.apply(x, list(views), code)
+
+
+def _plane_shape(numel):
+    """Factor a flat length into [H, W] with W a multiple of 4 when possible (vector kernels), else one long row."""
+    for w in (256, 128, 64, 32, 16, 8, 4):
+        if numel % w == 0:
+            return numel // w, w
+    return 1, numel
+
+
+class _StackReduce(torch.autograd.Function):
+    """reduce dim 0 of a [T, ...] tensor: identity views of a flat plane."""
+
+    @staticmethod
+    def forward(ctx, x, code):
+        ctx.code, ctx.T = code, x.shape[0]
+        T = x.shape[0]
+        rest = x.shape[1:]
+        numel = 1
+        for s in rest:
+            numel *= int(s)
+        if numel == 0:
+            return x.new_empty(rest)
+        H, W = _plane_shape(numel)
+        flat = x.contiguous().view(T, 1, H, W)
+        return _raw_deaug_reduce(flat, [N.IDENT] * T, code).view(rest)
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.code == N.RED_SUM:
+            return g.unsqueeze(0).expand(ctx.T, *g.shape), None
+        if ctx.code == N.RED_MEAN:
+            return (g / ctx.T).unsqueeze(0).expand(ctx.T, *g.shape), None
+        raise NotImplementedError("backward of non-linear TTA reductions is not implemented natively yet")
+
+
+def stack_reduce(x, code):
+    """Reduce dim 0 of ``x [T, ...]`` (float32, GPU) with the HIP reduction ``code``; T <= 8."""
+    N.require_device(x, "TTA reduction")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"TTA reduction: the native path is float32, got {x.dtype}")
+    T = x.shape[0]
+    if T < 1:
+        raise RuntimeError("cannot reduce an empty stack")
+    if T > 8:
+        # chain groups of <= 8: only valid for the linear reductions (sum; mean = sum / T)
+        if code not in (N.RED_SUM, N.RED_MEAN):
+            raise NotImplementedError("non-linear reductions over more than 8 stacked predictions")
+        parts = [_StackReduce.apply(x[i:i + 8], N.RED_SUM) for i in range(0, T, 8)]
+        total = stack_reduce(torch.stack(parts), N.RED_SUM)
+        return total / T if code == N.RED_MEAN else total
+    return _StackReduce.apply(x, code)

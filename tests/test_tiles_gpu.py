@@ -1,0 +1,252 @@
+"""GPU parity: TileMerger (HIP) vs the reference's golden vectors and the numpy oracle.
+
+Tolerances: integrate_batch / merge are bit-exact (same fp32 op order as the reference, no FMA contraction);
+the fused TTA path is held to 1e-5 absolute on O(1)-scale inputs (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import tiles_oracle as TO
+from oracle import tta_oracle as AO
+
+pytestmark = pytest.mark.gpu
+
+GT = load_golden("tiles.npz")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def native():
+    from pytorch_toolbelt_amd import _native as N
+
+    lib = N.load()
+    yield N
+    lib.ptb_set_tunable(0, 64)
+    lib.ptb_set_tunable(1, 0)
+
+
+def _merger(shape, C, weight, dev):
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    return TileMerger(shape, C, weight, device=dev)
+
+
+def _window(kw):
+    return TO.pyramid_window(*kw["tile_size"])[0] if kw["weight"] == "pyramid" else TO.mean_window(*kw["tile_size"])
+
+
+@pytest.mark.parametrize("case", GT.by_fn("tile_merger"), ids=lambda c: c["name"])
+def test_golden_tile_merger_bit_exact(case, dev, native):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    kw, n = case["kwargs"], case["name"]
+    s = ImageSlicer(kw["image_shape"], kw["tile_size"], kw["tile_step"], weight=kw["weight"])
+    m = _merger(s.target_shape, kw["channels"], s.weight, dev)
+    pred = torch.from_numpy(GT[f"{n}_pred"]).to(dev)
+    calls = native.calls
+    for b0 in range(0, len(pred), kw["batch"]):
+        m.integrate_batch(pred[b0:b0 + kw["batch"]], s.crops[b0:b0 + kw["batch"]])
+    assert native.calls > calls
+    assert np.array_equal(m.image.cpu().numpy(), GT[f"{n}_image"])
+    assert np.array_equal(m.norm_mask.cpu().numpy(), GT[f"{n}_norm"])
+    assert np.array_equal(m.merge().cpu().numpy(), GT[f"{n}_merged"])
+
+
+def _oracle_merge(geom, C, weight, pred, batch):
+    st = TO.merger_new(geom["target_shape"], C, weight)
+    for b0 in range(0, len(pred), batch):
+        TO.merger_integrate(st, pred[b0:b0 + batch], geom["crops"][b0:b0 + batch])
+    return st
+
+
+@pytest.mark.parametrize("chunk_rows,scalar", [(64, 0), (32, 0), (16, 0), (64, 1)])
+@pytest.mark.parametrize(
+    "shape,tile,step,C,batch",
+    [
+        ((300, 420), (128, 128), (64, 64), 3, 8),     # 50% overlap, vector path
+        ((256, 256), (64, 64), (16, 16), 2, 7),       # 16-fold cover -> launch groups are split
+        ((200, 330), (96, 72), (96, 72), 1, 40),      # no overlap, many tiles per batch
+        ((130, 170), (52, 36), (20, 12), 2, 9),       # multiples of 4 but ragged chunks
+        ((77, 91), (25, 31), (11, 17), 2, 6),         # odd sizes -> scalar kernels
+    ],
+)
+def test_integrate_batch_matches_oracle_bit_exact(shape, tile, step, C, batch, chunk_rows, scalar, dev, native):
+    lib = native.load()
+    lib.ptb_set_tunable(0, chunk_rows)
+    lib.ptb_set_tunable(1, scalar)
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile)[0]
+    rng = np.random.default_rng(1)
+    pred = rng.standard_normal((len(geom["crops"]), C, *tile)).astype(np.float32)
+    st = _oracle_merge(geom, C, w, pred, batch)
+    m = _merger(geom["target_shape"], C, w, dev)
+    tp = torch.from_numpy(pred).to(dev)
+    for b0 in range(0, len(pred), batch):
+        m.integrate_batch(tp[b0:b0 + batch], geom["crops"][b0:b0 + batch])
+    assert np.array_equal(m.image.cpu().numpy(), st["image"])
+    assert np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"])
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st), equal_nan=True)
+
+
+def test_coords_formats_errors_and_inplace(dev):
+    geom = TO.slicer_geometry((128, 128), 64, 32)
+    w = TO.pyramid_window(64, 64)[0]
+    rng = np.random.default_rng(2)
+    pred = rng.standard_normal((len(geom["crops"]), 2, 64, 64)).astype(np.float32)
+    want = _oracle_merge(geom, 2, w, pred, 3)
+    tp = torch.from_numpy(pred).to(dev)
+    crops = geom["crops"]
+    for fmt in (lambda c: c, lambda c: [tuple(int(v) for v in r) for r in c], lambda c: torch.from_numpy(c), lambda c: [torch.tensor(r) for r in c]):
+        m = _merger(geom["target_shape"], 2, w, dev)
+        for b0 in range(0, len(pred), 3):
+            m.integrate_batch(tp[b0:b0 + 3], fmt(crops[b0:b0 + 3]))
+        assert np.array_equal(m.image.cpu().numpy(), want["image"])
+    # accumulate_single == batch of one; CPU / fp16 inputs are moved + cast like the reference
+    m = _merger(geom["target_shape"], 2, w, dev)
+    for t, c in zip(pred, crops):
+        m.accumulate_single(torch.from_numpy(t), c)
+    st1 = _oracle_merge(geom, 2, w, pred, 1)
+    assert np.array_equal(m.image.cpu().numpy(), st1["image"])
+    # merge_ is in place and aliases image
+    merged = m.merge().cpu().numpy()
+    out = m.merge_()
+    assert out.data_ptr() == m.image.data_ptr() and np.array_equal(out.cpu().numpy(), merged)
+    assert m.device == m.image.device
+    with pytest.raises(ValueError):
+        m.integrate_batch(tp[:2], crops[:3])
+    with pytest.raises(RuntimeError):
+        m.integrate_batch(tp[:1], np.array([[100, 100, 64, 64]]))  # leaves the accumulator
+    with pytest.raises(RuntimeError):
+        m.integrate_batch(tp[:1, :, :32], crops[:1])
+    # half-precision predictions are cast to the fp32 accumulator (reference tiles.py:334-335)
+    m2 = _merger(geom["target_shape"], 2, w, dev)
+    m2.integrate_batch(tp[:4].half(), crops[:4])
+    st = TO.merger_new(geom["target_shape"], 2, w)
+    TO.merger_integrate(st, pred[:4].astype(np.float16).astype(np.float32), crops[:4])
+    assert np.array_equal(m2.image.cpu().numpy(), st["image"])
+
+
+def test_uncovered_pixels_are_nan(dev):
+    m = _merger((64, 64), 1, np.ones((32, 32), np.float32), dev)
+    m.integrate_batch(torch.ones((1, 1, 32, 32), device=dev), [(0, 0, 32, 32)])
+    out = m.merge().cpu().numpy()
+    assert out[0, 0, 0] == 1.0 and np.isnan(out[0, 40, 40])
+
+
+def test_readme_loop_with_dataloader(dev):
+    """The reference's canonical loop (README.md:208-226 == tests/test_tiles.py:58-85) on a NON-zero image."""
+    from torch.utils.data import DataLoader
+
+    from pytorch_toolbelt_amd.inference.tiles import CudaTileMerger, ImageSlicer
+    from pytorch_toolbelt_amd.utils.torch_utils import image_to_tensor, to_numpy
+
+    image = np.random.default_rng(0).integers(0, 256, (500, 620, 3), dtype=np.uint8)
+    tiler = ImageSlicer(image.shape, tile_size=(128, 128), tile_step=(64, 64), weight="pyramid")
+    tiles = [image_to_tensor(t) for t in tiler.split(image)]
+    merger = CudaTileMerger(tiler.target_shape, 1, tiler.weight)
+    for tiles_batch, coords_batch in DataLoader(list(zip(tiles, tiler.crops)), batch_size=8, pin_memory=True):
+        pred = tiles_batch.float().to(dev).max(dim=1, keepdim=True)[0]
+        merger.integrate_batch(pred, coords_batch)
+    merged = np.moveaxis(to_numpy(merger.merge()), 0, -1)
+    merged = tiler.crop_to_orignal_size(merged)
+    np.testing.assert_array_equal(np.rint(merged).astype(np.uint8), image.max(axis=2, keepdims=True))
+
+
+GROUPS = {"fliplr": 2, "flipud": 2, "flips": 3, "d2": 4, "d4": 8}
+
+
+@pytest.mark.parametrize("chunk_rows,scalar", [(64, 0), (32, 0), (16, 0), (64, 1)])
+@pytest.mark.parametrize("group", list(GROUPS))
+def test_fused_deaugment_accumulate(group, chunk_rows, scalar, dev, native):
+    lib = native.load()
+    lib.ptb_set_tunable(0, chunk_rows)
+    lib.ptb_set_tunable(1, scalar)
+    V = GROUPS[group]
+    shape, tile, step, C, batch = (300, 300), (128, 128), (64, 64), 3, 5
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile)[0]
+    n = len(geom["crops"])
+    rng = np.random.default_rng(4)
+    outs = rng.standard_normal((V, n, C, *tile)).astype(np.float32)  # [view][tile]
+    st = TO.merger_new(geom["target_shape"], C, w)
+    m = _merger(geom["target_shape"], C, w, dev)
+    for b0 in range(0, n, batch):
+        b1 = min(n, b0 + batch)
+        chunk_major = np.concatenate([outs[k, b0:b1] for k in range(V)])
+        TO.merger_integrate(st, AO.image_deaugment(chunk_major, group, "mean"), geom["crops"][b0:b1])
+        m.integrate_batch_deaugment(torch.from_numpy(chunk_major).to(dev), geom["crops"][b0:b1], group=group, reduction="mean")
+    assert np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"])
+    np.testing.assert_allclose(m.image.cpu().numpy(), st["image"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(m.merge().cpu().numpy(), TO.merger_merge(st), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("reduction", ["sum", "gmean", "hmean", "harmonic1p", "logodd", "log1p"])
+def test_fused_reductions(reduction, dev):
+    geom = TO.slicer_geometry((192, 192), (64, 64), (32, 32))
+    w = TO.pyramid_window(64, 64)[0]
+    n = len(geom["crops"])
+    rng = np.random.default_rng(5)
+    outs = (rng.random((8 * n, 2, 64, 64)) * 0.98 + 0.01).astype(np.float32)
+    st = TO.merger_new(geom["target_shape"], 2, w)
+    TO.merger_integrate(st, AO.image_deaugment(outs, "d4", reduction), geom["crops"])
+    m = _merger(geom["target_shape"], 2, w, dev)
+    m.integrate_batch_deaugment(torch.from_numpy(outs).to(dev), geom["crops"], group="d4", reduction=reduction)
+    np.testing.assert_allclose(m.merge().cpu().numpy(), TO.merger_merge(st), rtol=1e-5, atol=1e-5)
+
+
+def test_fused_equals_unfused_pipeline(dev):
+    """integrate_batch(tta.d4_image_deaugment(y)) and the fused call give the same accumulator (same op order)."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    geom = TO.slicer_geometry((256, 256), (128, 128), (64, 64))
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(geom["crops"])
+    y = torch.randn((8 * n, 2, 128, 128), device=dev)
+    a = _merger(geom["target_shape"], 2, w, dev)
+    b = _merger(geom["target_shape"], 2, w, dev)
+    a.integrate_batch(tta.d4_image_deaugment(y), geom["crops"])
+    b.integrate_batch_deaugment(y, geom["crops"], group="d4")
+    assert torch.equal(a.image, b.image) and torch.equal(a.norm_mask, b.norm_mask)
+
+
+def test_full_size_cfg2_properties(dev):
+    """BASELINE cfg2 geometry (5000x5000, 512/256 pyramid, d4, C=4) through size-independent properties:
+    a constant prediction merges to that constant everywhere (the window is a partition of unity after
+    normalisation), and the merge is linear in the predictions."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    s = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+    assert len(s.crops) == 361 and s.target_shape == (5120, 5120)
+    C, bs = 4, 8
+    g = torch.Generator(device=dev).manual_seed(0)
+    base = torch.randn((8 * bs, C, 512, 512), device=dev, generator=g)
+
+    def run(batch_fn):
+        m = _merger(s.target_shape, C, s.weight, dev)
+        for b0 in range(0, 361, bs):
+            b1 = min(361, b0 + bs)
+            m.integrate_batch_deaugment(batch_fn(b0, b1), s.crops[b0:b1], group="d4")
+        return m
+
+    const = run(lambda b0, b1: torch.full((8 * (b1 - b0), C, 512, 512), 0.75, device=dev))
+    out = const.merge()
+    assert float((out - 0.75).abs().max()) <= 1e-6
+    assert float(const.norm_mask.min()) > 0.0
+
+    def tiles(b0, b1, scale):
+        nb = b1 - b0
+        return (base.view(8, bs, C, 512, 512)[:, :nb] * scale + 0.01 * b0).reshape(8 * nb, C, 512, 512)
+
+    m1 = run(lambda b0, b1: tiles(b0, b1, 1.0)).merge()
+    m2 = run(lambda b0, b1: tiles(b0, b1, 2.0)).merge()
+    m3 = run(lambda b0, b1: tiles(b0, b1, 3.0)).merge()
+    # linearity: f(3x) - f(2x) == f(2x) - f(x)
+    assert float(((m3 - m2) - (m2 - m1)).abs().max()) <= 2e-5
+    crop = s.crop_to_orignal_size(np.moveaxis(m1.cpu().numpy(), 0, -1))
+    assert crop.shape == (5000, 5000, C) and np.isfinite(crop).all()

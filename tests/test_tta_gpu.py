@@ -1,0 +1,226 @@
+"""GPU parity: TTA augment / de-augment / reductions (HIP) vs golden vectors of the reference and the numpy oracle.
+
+Pure permutations (augment, reduction=None, flips) are bit-exact; reductions are held to 1e-5 (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import tta_oracle as AO
+
+pytestmark = pytest.mark.gpu
+
+GA = load_golden("tta.npz")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def native():
+    from pytorch_toolbelt_amd import _native as N
+
+    lib = N.load()
+    yield N
+    lib.ptb_set_tunable(0, 64)
+    lib.ptb_set_tunable(1, 0)
+
+
+def _tta():
+    from pytorch_toolbelt_amd.inference import tta
+
+    return tta
+
+
+@pytest.mark.parametrize("case", GA.by_fn("image_augment"), ids=lambda c: c["name"])
+def test_golden_augment(case, dev):
+    fn = getattr(_tta(), f"{case['kwargs']['group']}_image_augment")
+    out = fn(torch.from_numpy(GA[case["inputs"][0]]).to(dev))
+    assert np.array_equal(out.cpu().numpy(), GA[case["output"]])
+
+
+@pytest.mark.parametrize("case", GA.by_fn("image_deaugment"), ids=lambda c: c["name"])
+def test_golden_deaugment(case, dev):
+    kw = case["kwargs"]
+    fn = getattr(_tta(), f"{kw['group']}_image_deaugment")
+    out = fn(torch.from_numpy(GA[case["inputs"][0]]).to(dev), reduction=kw["reduction"]).cpu().numpy()
+    ref = GA[case["output"]]
+    assert out.shape == ref.shape
+    if kw["reduction"] is None:
+        assert np.array_equal(out, ref)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5, equal_nan=True)
+
+
+@pytest.mark.parametrize("case", GA.by_fn("labels_deaugment"), ids=lambda c: c["name"])
+def test_golden_labels(case, dev):
+    kw = case["kwargs"]
+    tta = _tta()
+    fn = tta.fivecrop_label_deaugment if kw["group"] == "fivecrop" else getattr(tta, f"{kw['group']}_labels_deaugment")
+    out = fn(torch.from_numpy(GA[case["inputs"][0]]).to(dev), reduction=kw["reduction"]).cpu().numpy()
+    np.testing.assert_allclose(out, GA[case["output"]], rtol=1e-5, atol=1e-6)
+
+
+def test_golden_fivecrop_ms_reductions(dev):
+    tta = _tta()
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    x = torch.from_numpy(GA["x_sq"]).to(dev)
+    assert np.array_equal(tta.fivecrop_image_augment(x, (8, 10)).cpu().numpy(), GA["fivecrop_aug"])
+    xm = torch.from_numpy(GA["x_ms"]).to(dev)
+    for c in GA.by_fn("ms_image_augment"):
+        outs = tta.ms_image_augment(xm, c["kwargs"]["size_offsets"], mode="bilinear", align_corners=c["kwargs"]["align_corners"])
+        assert outs[1] is xm  # offset 0 returns the input itself
+        for o, k in zip(outs, c["output"]):
+            np.testing.assert_allclose(o.cpu().numpy(), GA[k], rtol=1e-5, atol=1e-6)
+    for c in GA.by_fn("ms_image_deaugment"):
+        kw = c["kwargs"]
+        fmaps = [torch.from_numpy(GA[k]).to(dev) for k in c["inputs"]]
+        out = tta.ms_image_deaugment(fmaps, kw["size_offsets"], reduction=kw["reduction"], mode="bilinear", align_corners=kw["align_corners"], stride=kw["stride"])
+        np.testing.assert_allclose(out.cpu().numpy(), GA[c["output"]], rtol=1e-5, atol=1e-6)
+    st = torch.from_numpy(GA["red_stack"]).to(dev)
+    for c in GA.by_fn("reduction"):
+        out = getattr(F, c["kwargs"]["which"])(st, dim=0)
+        np.testing.assert_allclose(out.cpu().numpy(), GA[c["output"]], rtol=1e-5, atol=1e-6)
+    # reduction along another dim == oracle on the moved axis
+    out = F.geometric_mean(st, dim=1).cpu().numpy()
+    np.testing.assert_allclose(out, AO.geometric_mean(np.moveaxis(GA["red_stack"], 1, 0)), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("chunk_rows,scalar", [(64, 0), (32, 0), (16, 0), (64, 1)])
+@pytest.mark.parametrize("group,shape", [("d4", (3, 2, 200, 200)), ("d4", (2, 3, 75, 75)), ("d2", (2, 2, 136, 68)), ("flips", (2, 2, 37, 53)), ("fliplr", (1, 5, 64, 260)), ("flipud", (3, 1, 130, 4))])
+def test_roundtrip_and_oracle(group, shape, chunk_rows, scalar, dev, native):
+    """reference tests/test_tta.py:31-68 (deaugment(augment(x)) == x) on ragged shapes + oracle comparison."""
+    lib = native.load()
+    lib.ptb_set_tunable(0, chunk_rows)
+    lib.ptb_set_tunable(1, scalar)
+    tta = _tta()
+    rng = np.random.default_rng(7)
+    x = rng.random(shape, dtype=np.float32)
+    tx = torch.from_numpy(x).to(dev)
+    aug = getattr(tta, f"{group}_image_augment")(tx)
+    assert np.array_equal(aug.cpu().numpy(), AO.image_augment(x, group))
+    back = getattr(tta, f"{group}_image_deaugment")(aug)
+    np.testing.assert_allclose(back.cpu().numpy(), x, atol=1e-6, rtol=1e-6)
+    V = aug.shape[0] // shape[0]
+    y = (rng.random((V * shape[0],) + shape[1:], dtype=np.float32) * 0.9 + 0.05)
+    ty = torch.from_numpy(y).to(dev)
+    for red in ("mean", "sum", "gmean", "logodd", None):
+        out = getattr(tta, f"{group}_image_deaugment")(ty, reduction=red).cpu().numpy()
+        np.testing.assert_allclose(out, AO.image_deaugment(y, group, red), rtol=1e-5, atol=1e-5)
+    # callable reduction receives the [V, B, ...] stack
+    out = getattr(tta, f"{group}_image_deaugment")(ty, reduction=lambda t, dim: t.max(dim=dim)[0]).cpu().numpy()
+    assert np.array_equal(out, AO.image_deaugment(y, group, None).max(axis=0))
+
+
+def test_reference_kat_labels_and_wrappers(dev):
+    """reference tests/test_tta.py:71-108 with the SumAll model, plus d4/fliplr image2mask with an identity model."""
+    tta = _tta()
+    x = torch.tensor([[1, 2, 3, 4], [5, 6, 7, 8], [9, 0, 1, 2], [3, 4, 5, 6]], device=dev).unsqueeze(0).unsqueeze(0).float()
+    model = lambda t: t.sum(dim=[1, 2, 3])
+    assert int(tta.d4_image2label(model, x)) == int(x.sum())
+    assert int(tta.fliplr_image2label(model, x)) == int(x.sum())
+    assert int(tta.fivecrop_image2label(model, x, (2, 2))) == ((1 + 2 + 5 + 6) + (3 + 4 + 7 + 8) + (9 + 0 + 3 + 4) + (1 + 2 + 5 + 6) + (6 + 7 + 0 + 1)) / 5
+    assert int(tta.tencrop_image2label(model, x, (2, 2))) == (2 * ((1 + 2 + 5 + 6) + (3 + 4 + 7 + 8) + (9 + 0 + 3 + 4) + (1 + 2 + 5 + 6) + (6 + 7 + 0 + 1))) / 10
+    img = torch.rand((4, 3, 224, 224), device=dev)
+    ident = lambda t: t
+    np.testing.assert_allclose(tta.d4_image2mask(ident, img).cpu().numpy(), img.cpu().numpy(), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(tta.fliplr_image2mask(ident, img).cpu().numpy(), img.cpu().numpy(), atol=1e-6, rtol=1e-6)
+    # d4_labels_deaugment reference quirk: chunk 6 dropped, chunk 7 twice -> mean of 0..7 is 3.625
+    v = torch.arange(8, device=dev, dtype=torch.float32).view(8, 1)
+    assert float(tta.d4_labels_deaugment(v)) == pytest.approx(3.625)
+
+
+def test_errors(dev):
+    tta = _tta()
+    with pytest.raises(ValueError):
+        tta.d4_image_augment(torch.rand((1, 1, 8, 12), device=dev))
+    with pytest.raises(RuntimeError):
+        tta.d4_image_deaugment(torch.rand((7, 1, 8, 8), device=dev))
+    with pytest.raises(KeyError):
+        tta.d4_image_deaugment(torch.rand((8, 1, 8, 8), device=dev), reduction="median")
+    with pytest.raises(RuntimeError):
+        tta.flips_labels_deaugment(torch.rand((4, 3), device=dev))
+    with pytest.raises(ValueError):
+        tta.ms_image_deaugment([torch.rand((1, 1, 8, 8), device=dev)], [0, 2])
+    with pytest.raises(ValueError):
+        tta.fivecrop_image_augment(torch.rand((1, 1, 8, 8), device=dev), (9, 4))
+
+
+def test_functional_view_ops(dev):
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    x = np.random.default_rng(9).random((2, 3, 20, 20), dtype=np.float32)
+    t = torch.from_numpy(x).to(dev)
+    table = {
+        "torch_fliplr": x[..., :, ::-1], "torch_flipud": x[..., ::-1, :], "torch_rot180": x[..., ::-1, ::-1],
+        "torch_transpose": np.swapaxes(x, 2, 3), "torch_transpose2": np.swapaxes(x, 2, 3),
+        "torch_rot90_ccw": np.rot90(x, 1, axes=(2, 3)), "torch_rot90_cw": np.rot90(x, -1, axes=(2, 3)),
+        "torch_rot90_ccw_transpose": np.swapaxes(np.rot90(x, 1, axes=(2, 3)), 2, 3),
+        "torch_rot90_cw_transpose": np.swapaxes(np.rot90(x, -1, axes=(2, 3)), 2, 3),
+        "torch_rot180_transpose": np.swapaxes(np.rot90(x, 2, axes=(2, 3)), 2, 3),
+        "torch_transpose_rot90_ccw": np.rot90(np.swapaxes(x, 2, 3), 1, axes=(2, 3)),
+        "torch_transpose_rot90_cw": np.rot90(np.swapaxes(x, 2, 3), -1, axes=(2, 3)),
+        "torch_transpose_rot180": np.rot90(np.swapaxes(x, 2, 3), 2, axes=(2, 3)),
+    }
+    for name, want in table.items():
+        assert np.array_equal(getattr(F, name)(t).cpu().numpy(), want), name
+    assert F.torch_none(t) is t
+    with pytest.warns(DeprecationWarning):
+        assert np.array_equal(F.torch_rot90(t).cpu().numpy(), table["torch_rot90_ccw"])
+    # non-square flips
+    r = torch.rand((1, 2, 12, 40), device=dev)
+    assert torch.equal(F.torch_fliplr(r), r.flip(3)) and torch.equal(F.torch_flipud(r), r.flip(2))
+    # pad helpers are exact shape arithmetic (reference tests/test_utils_functional.py)
+    p, pad = F.pad_image_tensor(r, 32)
+    assert p.shape == (1, 2, 32, 64) and torch.equal(F.unpad_image_tensor(p, pad), r)
+    p2, crop = F.pad_tensor_to_size(r, (16, 41))
+    assert p2.shape == (1, 2, 16, 41) and torch.equal(p2[crop], r)
+
+
+def test_autograd_adjoint(dev):
+    """TTA functions respect gradient flow (reference tta.py:3-4): check <L x, g> == <x, L^T g> for the linear maps."""
+    tta = _tta()
+    for group in ("fliplr", "flips", "d2", "d4"):
+        x = torch.randn((2, 3, 32, 32), device=dev, requires_grad=True)
+        aug = getattr(tta, f"{group}_image_augment")(x)
+        g = torch.randn_like(aug)
+        aug.backward(g)
+        # adjoint of augment = de-augment with sum
+        want = getattr(tta, f"{group}_image_deaugment")(g, reduction="sum")
+        torch.testing.assert_close(x.grad, want, rtol=1e-6, atol=1e-6)
+        y = torch.randn_like(aug, requires_grad=True)
+        out = getattr(tta, f"{group}_image_deaugment")(y)  # mean
+        go = torch.randn_like(out)
+        out.backward(go)
+        V = aug.shape[0] // 2
+        want = getattr(tta, f"{group}_image_augment")(go) / V
+        torch.testing.assert_close(y.grad, want, rtol=1e-6, atol=1e-6)
+    lg = torch.randn((16, 5), device=dev, requires_grad=True)
+    tta.d2_labels_deaugment(lg).sum().backward()
+    torch.testing.assert_close(lg.grad, torch.full_like(lg, 0.25))
+
+
+def test_generalized_and_multiscale_wrappers(dev):
+    tta = _tta()
+    x = torch.rand((2, 3, 64, 64), device=dev)
+    m = tta.GeneralizedTTA(torch.nn.Identity(), tta.d4_image_augment, tta.d4_image_deaugment)
+    np.testing.assert_allclose(m(x).cpu().numpy(), x.cpu().numpy(), atol=1e-6)
+
+    class TwoHeads(torch.nn.Module):
+        def forward(self, image):
+            return {"mask": image * 2, "edge": image + 1}
+
+    m = tta.GeneralizedTTA(TwoHeads(), {"image": tta.d2_image_augment}, {"mask": tta.d2_image_deaugment, "edge": tta.d2_image_deaugment})
+    out = m(image=x)
+    np.testing.assert_allclose(out["mask"].cpu().numpy(), (x * 2).cpu().numpy(), atol=1e-6)
+    with pytest.raises(ValueError):
+        m(x)
+    ms = tta.MultiscaleTTA(torch.nn.Identity(), size_offsets=[-16, 0, 16])
+    y = ms(x)
+    assert y.shape == x.shape
+    want = AO.ms_image_deaugment(AO.ms_image_augment(x.cpu().numpy(), [-16, 0, 16], False), [-16, 0, 16], "mean", True)  # quirk Q2
+    np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
