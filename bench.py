@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
+    ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
     return ap.parse_args()
 
 
@@ -93,6 +94,9 @@ def main():
 
     if args.chunk_rows:
         assert N.load().ptb_set_tunable(0, args.chunk_rows) == 0
+    for kv in args.tunable:
+        k, v = kv.split("=")
+        assert N.load().ptb_set_tunable(int(k), int(v)) == 0
 
     slicer = ImageSlicer(IMAGE, TILE, STEP, weight="pyramid")
     n_tiles = len(slicer.crops)

@@ -117,11 +117,22 @@ __device__ __forceinline__ float red_post(float s, int op, float divisor) {
 // scatter (lanes walk rows) spreads over banks and the b128 gather (16 lanes per row) stays conflict-free.
 __device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + (j & 3); }
 
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// 16-byte global load; NT = non-temporal (streamed once: do not keep the line in L2 / Infinity Cache, which is left to
+// the accumulator read-modify-writes).  On MI355X nt streaming reads measured +8..15 % HBM bandwidth (tools/bw_probe).
+template <bool NT>
+__device__ __forceinline__ float4 ld16(const float* p) {
+    const v4f* q = reinterpret_cast<const v4f*>(p);
+    const v4f v = NT ? __builtin_nontemporal_load(q) : *q;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }
 
 // Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
 // tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
-template <int CH, int NV, int CODES, int OPK>
+template <int CH, int NV, int CODES, int OPK, bool NT>
 __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane, long long view_stride, int nv_rt,
                                                 int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
                                                 float divisor, float* lds, int tid, bool more_entries) {
@@ -145,13 +156,13 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane,
                     const int i = ly + r, j = lx + 4 * q;
                     const int row = (code & 2) ? H - 1 - i : i;
                     const int col = (code & 4) ? W - 4 - j : j;
-                    const float4 t = *reinterpret_cast<const float4*>(p + (long long)row * W + col);
+                    const float4 t = ld16<NT>(p + (long long)row * W + col);
                     v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
                 }
             } else if (tact) {
                 const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
                 const int C0 = (code & 4) ? W - ly - ch : ly;
-                v[k] = *reinterpret_cast<const float4*>(p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+                v[k] = ld16<NT>(p + (long long)(R0 + rr) * W + C0 + 4 * qq);
             }
         }
     }
@@ -203,7 +214,7 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane,
 }
 
 // ------------------------------------------------------------------------------------------------ fast kernels
-template <int CH, int NV, int CODES, int OPK, int MODE>
+template <int CH, int NV, int CODES, int OPK, int MODE, bool NT>
 __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
         src_tile = t % a.src_tile_mod;
     }
     const float* plane = a.src + src_tile * a.src_tile_stride + (long long)c * a.H * a.W;
-    float4 val = gather_reduce<CH, NV, CODES, OPK>(plane, a.src_view_stride, nv, codes, a.H, a.W, cx0, cy0, cw, ch, a.op,
+    float4 val = gather_reduce<CH, NV, CODES, OPK, NT>(plane, a.src_view_stride, nv, codes, a.H, a.W, cx0, cy0, cw, ch, a.op,
                                                   a.divisor, lds, tid, false);
     if (MODE == MODE_PERVIEW && a.scale != 1.0f) {
         val.x *= a.scale; val.y *= a.scale; val.z *= a.scale; val.w *= a.scale;
@@ -237,7 +248,7 @@ __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
     }
 }
 
-template <int CH, int NV, int CODES, int OPK>
+template <int CH, int NV, int CODES, int OPK, bool NT>
 __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, const CellArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
         const int gt = cell.tile[e];
         const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
         const float* plane = a.src + (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
-        const float4 val = gather_reduce<CH, NV, CODES, OPK>(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
+        const float4 val = gather_reduce<CH, NV, CODES, OPK, NT>(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
                                                         ch, a.op, a.divisor, lds, tid, e + 1 < nt);
         if (act) {
             const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
@@ -452,11 +463,12 @@ static void launch_plain_ch(const ViewArgs& a, int blocks, hipStream_t s, bool n
     const dim3 grid(blocks), block(CH * 16);
 #define PTB_PLAIN(NV, CODES)                                                                                      \
     do {                                                                                                          \
-        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE>), grid, block, 0, s, a);     \
-        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE>), grid, block, 0, s, a);               \
+        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE, true>), grid, block, 0, s, a);     \
+        else if (g_nt_loads) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, true>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, false>), grid, block, 0, s, a);        \
     } while (0)
     if constexpr (MODE == MODE_PERVIEW) {
-        hipLaunchKernelGGL((view_plain_kernel<CH, 1, -1, 0, MODE_PERVIEW>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((view_plain_kernel<CH, 1, -1, 0, MODE_PERVIEW, true>), grid, block, 0, s, a);
     } else {
         if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_PLAIN(2, CODES_FLIPLR);
         else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_PLAIN(2, CODES_FLIPUD);
@@ -473,10 +485,11 @@ static void launch_accum_ch(const ViewArgs& a, const CellArgs& g, int blocks, hi
     const dim3 grid(blocks), block(CH * 16);
 #define PTB_ACCUM(NV, CODES)                                                                                      \
     do {                                                                                                          \
-        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1>), grid, block, 0, s, a, g);        \
-        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0>), grid, block, 0, s, a, g);                  \
+        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1, true>), grid, block, 0, s, a, g);        \
+        else if (g_nt_loads) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, true>), grid, block, 0, s, a, g);  \
+        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, false>), grid, block, 0, s, a, g);           \
     } while (0)
-    if (a.nviews == 1 && a.codes == CODES_ID && !nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, 1, CODES_ID, 0>), grid, block, 0, s, a, g);
+    if (a.nviews == 1 && a.codes == CODES_ID && !nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, 1, CODES_ID, 0, true>), grid, block, 0, s, a, g);
     else if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_ACCUM(2, CODES_FLIPLR);
     else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_ACCUM(2, CODES_FLIPUD);
     else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_ACCUM(3, CODES_FLIPS);

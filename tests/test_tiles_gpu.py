@@ -27,7 +27,7 @@ def native():
 
     lib = N.load()
     yield N
-    lib.ptb_set_tunable(0, 64)
+    lib.ptb_set_tunable(0, 32)
     lib.ptb_set_tunable(1, 0)
 
 
