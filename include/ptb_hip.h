@@ -101,6 +101,72 @@ int ptb_deaug_accumulate(float* image, float* norm, const float* weight, const f
 int ptb_resize_bilinear(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout,
                         int align_corners, ptb_stream_t stream);
 
+/* ================================= segmentation losses (pytorch_toolbelt.losses) =================================
+ * logits [B, C, HW] fp32; targets are either labels int64 [B, HW] (one-hot is formed on the fly, never materialised)
+ * or dense fp32 [B, C, HW]; exactly one of `labels` / `dense` is non-NULL.  Scalars are accumulated in fp64.
+ * flags: */
+#define PTB_SEG_FOCAL 1            /* accumulate sigmoid focal sums: sums[0] = sum loss, sums[1] = sum focal_term */
+#define PTB_SEG_STATS 2            /* accumulate region statistics: sums[2 + k*C + c], k = 0: I=sum p*t, 1: P=sum p, 2: T=sum t */
+#define PTB_SEG_HAS_IGNORE 4       /* ignore_label (labels) / ignore_value (dense) is active */
+#define PTB_SEG_HAS_ALPHA 8
+#define PTB_SEG_REDUCED 16         /* reduced focal loss with `threshold` */
+#define PTB_SEG_MASK_FOCAL_TERM 32 /* normalized focal: ignored elements add 0 to sums[1] (functional.py:90-98) */
+#define PTB_SEG_ELEMWISE 64        /* also write the unreduced focal loss to elem_out [B, C, HW] */
+/* prob (activation used for the region statistics): */
+#define PTB_PROB_SOFTMAX 0         /* log_softmax(dim=1).exp()  (dice.py:68-72 multiclass) */
+#define PTB_PROB_SIGMOID 1         /* logsigmoid.exp()          (dice.py:73-75 binary / multilabel) */
+#define PTB_PROB_IDENTITY 2        /* from_logits=False: `logits` already holds probabilities */
+
+/* One pass over logits+targets for focal_loss_with_logits (losses/functional.py:19-107, sigmoid activation),
+ * BinaryFocalLoss (losses/focal.py:77-105) and the sums of soft_dice_score / soft_jaccard_score with dims=(0,2)
+ * (losses/functional.py:188-247; DiceLoss losses/dice.py:59-131, JaccardLoss losses/jaccard.py:48-103).
+ * sums: double[2 + 3*C], must be zeroed by the caller; error_flag: int, set to 1 when a label is outside [0, C)
+ * and not ignore_label (the reference's F.one_hot raises).  class_weights [C] fp32 or NULL. */
+int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                     double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags, int prob,
+                     float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
+                     ptb_stream_t stream);
+
+/* Gradient of the sigmoid focal loss w.r.t. logits: grad[i] = coef[0] * (grad_elem ? grad_elem[i] : 1) * dL_i/dx_i
+ * + coef[1] * dF_i/dx_i, coef = DEVICE float[2] (reduction / normalisation factors times the upstream gradient). */
+int ptb_focal_bwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                  const float* coef, const float* grad_elem, float* grad, int B, int C, int64_t HW, int flags,
+                  float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
+                  ptb_stream_t stream);
+
+/* Gradient of any function of the region statistics w.r.t. logits, given DEVICE arrays gI[C] = dLoss/dI_c and
+ * gP[C] = dLoss/dP_c (T does not depend on the logits). */
+int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, const float* dense, const float* gI, const float* gP,
+                      float* grad, int B, int C, int64_t HW, int flags, int prob, int64_t ignore_label,
+                      float ignore_value, ptb_stream_t stream);
+
+/* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
+ * sums double[2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
+int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,
+                          float* pixel_out, int* error_flag, int B, int C, int64_t HW, int reduced, float gamma,
+                          float threshold, int64_t ignore_label, ptb_stream_t stream);
+int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const float* class_weights, const float* coef,
+                          const float* grad_pix, float* grad, int B, int C, int64_t HW, int reduced, float gamma,
+                          float threshold, int64_t ignore_label, ptb_stream_t stream);
+
+/* ---- Lovasz hinge / Lovasz-softmax (losses/lovasz.py:23-184) ---------------------------------------------------
+ * mode 0 (softmax): pred = probabilities [B, C, HW], labels int64 [B, HW]; mode 1 (hinge): pred = logits [B, HW],
+ * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the
+ * whole batch; S = groups*C segments of P = (per_image ? HW : B*HW) elements, n = S*P < 2^31.
+ * seg_loss[s] (double, zeroed by the caller) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
+ * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward).
+ * Workspaces are caller-provided device buffers: keys_a/keys_b float[n], vals_a/vals_b u32[n], offsets u32[S+1] holding
+ * s*P, chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (rocPRIM segmented radix sort). */
+int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments);
+int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, float* keys_a, float* keys_b,
+                   unsigned* vals_a, unsigned* vals_b, unsigned* offsets, unsigned* chunk, unsigned* fg_total,
+                   double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream);
+/* grad[pred layout] = coef[s] * grad_at_pixel * d(error)/d(pred); coef = DEVICE float[S]. */
+int ptb_lovasz_bwd(const float* pred, const int64_t* labels, const float* flabels, const float* coef,
+                   const float* grad_at_pixel, float* grad, int B, int C, int64_t HW, int mode, int per_image,
+                   int has_ignore, int64_t ignore_label, float ignore_value, ptb_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,1 +1,6 @@
-"""Segmentation losses (focal / Dice / Jaccard / Lovasz) on HIP kernels -- populated in losses/*.py."""
+"""Segmentation losses on fused HIP reductions (drop-in for the hot-path part of ``pytorch_toolbelt.losses``)."""
+from .dice import *  # noqa: F401,F403
+from .focal import *  # noqa: F401,F403
+from .functional import *  # noqa: F401,F403
+from .jaccard import *  # noqa: F401,F403
+from .lovasz import *  # noqa: F401,F403

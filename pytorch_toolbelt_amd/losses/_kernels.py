@@ -1,0 +1,169 @@
+"""Autograd functions over the fused loss kernels of libptb_hip.so (ptb_seg_loss_fwd & friends).
+
+Each function returns the *sums* the loss needs as a small float64 tensor; the remaining scalar algebra (normalise,
+clamp, 1 - score, log, mean over classes) is ordinary differentiable torch code on [C]-sized tensors, so the backward
+kernels only need d(loss)/d(sum) -- delivered as device arrays, without a host synchronisation.
+"""
+import os
+
+import torch
+
+from .. import _native as N
+
+SEG_FOCAL, SEG_STATS, SEG_HAS_IGNORE, SEG_HAS_ALPHA, SEG_REDUCED, SEG_MASK_FOCAL_TERM, SEG_ELEMWISE = 1, 2, 4, 8, 16, 32, 64
+PROB_SOFTMAX, PROB_SIGMOID, PROB_IDENTITY = 0, 1, 2
+
+_CHECK_LABELS = os.environ.get("PTB_SKIP_LABEL_CHECK", "0") != "1"
+
+
+def _f32c(t, what):
+    N.require_device(t, what)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def check_labels(flag):
+    """F.one_hot raises on labels outside [0, C); the kernels record that in a device flag (one sync, like one_hot)."""
+    if _CHECK_LABELS and int(flag.item()) != 0:
+        raise RuntimeError("Class values must be smaller than num_classes.")
+
+
+class SigmoidFocalSums(torch.autograd.Function):
+    """sums[0] = sum_i L_i, sums[1] = sum_i F_i (focal terms), optionally the unreduced L map.
+
+    x: [B, C, HW] fp32 logits; labels int64 [B, HW] or dense fp32 [B, C, HW]."""
+
+    @staticmethod
+    def forward(ctx, x, labels, dense, class_weights, flags, gamma, alpha, threshold, ignore_label, ignore_value):
+        B, C, HW = x.shape
+        sums = torch.zeros(2, dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        elem = torch.empty_like(x) if flags & SEG_ELEMWISE else None
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), sums.data_ptr(), _ptr(elem),
+                                      flag.data_ptr(), B, C, HW, flags | SEG_FOCAL, PROB_SIGMOID, gamma, alpha, threshold,
+                                      ignore_label, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_seg_loss_fwd")
+        if labels is not None:
+            check_labels(flag)
+        ctx.save_for_backward(x, labels, dense, class_weights)
+        ctx.cfg = (flags, gamma, alpha, threshold, ignore_label, ignore_value)
+        if elem is None:
+            elem = x.new_empty(0)
+            ctx.has_elem = False
+        else:
+            ctx.has_elem = True
+        return sums, elem
+
+    @staticmethod
+    def backward(ctx, g_sums, g_elem):
+        x, labels, dense, class_weights = ctx.saved_tensors
+        flags, gamma, alpha, threshold, ignore_label, ignore_value = ctx.cfg
+        B, C, HW = x.shape
+        coef = g_sums.to(torch.float32).contiguous() if g_sums is not None else torch.zeros(2, device=x.device)
+        grad_elem = None
+        if ctx.has_elem and g_elem is not None:
+            # grad = (g_sums[0] + g_elem) * dL + g_sums[1] * dF: fold the scalar into the map, multiplier 1
+            grad_elem = (g_elem.to(torch.float32) + coef[0]).contiguous()
+            coef = torch.stack([torch.ones((), device=x.device), coef[1]])
+        grad = torch.empty_like(x)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_focal_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), coef.data_ptr(), _ptr(grad_elem),
+                                   grad.data_ptr(), B, C, HW, flags, gamma, alpha, threshold, ignore_label, ignore_value,
+                                   N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_focal_bwd")
+        return grad, None, None, None, None, None, None, None, None, None
+
+
+class RegionStats(torch.autograd.Function):
+    """stats [3, C] float64: I_c = sum p t, P_c = sum p, T_c = sum t over batch and pixels (masked), p = activation(x)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, dense, prob, has_ignore, ignore_label, ignore_value):
+        B, C, HW = x.shape
+        sums = torch.zeros(2 + 3 * C, dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        flags = SEG_STATS | (SEG_HAS_IGNORE if has_ignore else 0)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), None, sums.data_ptr(), None, flag.data_ptr(), B, C, HW,
+                                      flags, prob, 0.0, 0.0, 0.0, ignore_label, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_seg_loss_fwd")
+        if labels is not None:
+            check_labels(flag)
+        ctx.save_for_backward(x, labels, dense)
+        ctx.cfg = (flags, prob, ignore_label, ignore_value)
+        return sums[2:].view(3, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, labels, dense = ctx.saved_tensors
+        flags, prob, ignore_label, ignore_value = ctx.cfg
+        B, C, HW = x.shape
+        g = g.to(torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_stats_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), g[0].data_ptr(), g[1].data_ptr(), grad.data_ptr(),
+                                       B, C, HW, flags, prob, ignore_label, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_seg_stats_bwd")
+        return grad, None, None, None, None, None, None
+
+
+class SoftmaxFocalSums(torch.autograd.Function):
+    """sums[0] = sum of per-pixel softmax-focal losses, sums[1] = sum of all focal terms; optional [B, HW] map."""
+
+    @staticmethod
+    def forward(ctx, x, labels, class_weights, reduced, gamma, threshold, ignore_label, want_map):
+        B, C, HW = x.shape
+        sums = torch.zeros(2, dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        pix = torch.empty((B, HW), dtype=torch.float32, device=x.device) if want_map else None
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_softmax_focal_fwd(x.data_ptr(), labels.data_ptr(), _ptr(class_weights), sums.data_ptr(), _ptr(pix),
+                                           flag.data_ptr(), B, C, HW, reduced, gamma, threshold, ignore_label, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_softmax_focal_fwd")
+        check_labels(flag)
+        ctx.save_for_backward(x, labels, class_weights)
+        ctx.cfg = (reduced, gamma, threshold, ignore_label)
+        ctx.has_map = want_map
+        return sums, (pix if want_map else x.new_empty(0))
+
+    @staticmethod
+    def backward(ctx, g_sums, g_pix):
+        x, labels, class_weights = ctx.saved_tensors
+        reduced, gamma, threshold, ignore_label = ctx.cfg
+        B, C, HW = x.shape
+        coef = g_sums.to(torch.float32).contiguous()
+        grad_pix = None
+        if ctx.has_map and g_pix is not None:
+            grad_pix = (g_pix.to(torch.float32) + coef[0]).contiguous()
+            coef = torch.stack([torch.ones((), device=x.device), coef[1]])
+        grad = torch.empty_like(x)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_softmax_focal_bwd(x.data_ptr(), labels.data_ptr(), _ptr(class_weights), coef.data_ptr(), _ptr(grad_pix),
+                                           grad.data_ptr(), B, C, HW, reduced, gamma, threshold, ignore_label, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_softmax_focal_bwd")
+        return grad, None, None, None, None, None, None, None
+
+
+def as_bchw(t):
+    """View an [N, C, *] (or lower-rank) tensor as [B, C, HW]."""
+    if t.dim() >= 2:
+        return t.reshape(t.shape[0], t.shape[1], -1)
+    return t.reshape(1, 1, -1)

@@ -1,0 +1,50 @@
+"""Shared body of DiceLoss / JaccardLoss: fused region statistics + a [C]-sized scalar epilogue."""
+import torch
+
+from ..utils.torch_utils import to_tensor
+from . import _kernels as K
+
+BINARY_MODE = "binary"
+MULTICLASS_MODE = "multiclass"
+MULTILABEL_MODE = "multilabel"
+
+
+def prepare_classes(mode, classes):
+    if classes is None:
+        return None
+    assert mode != BINARY_MODE, "Masking classes is not supported with mode=binary"
+    return to_tensor(classes, dtype=torch.long)
+
+
+def region_statistics(y_pred, y_true, mode, from_logits, ignore_index):
+    """(I, P, T) per class over batch and pixels: one HIP pass over the logits; the softmax / sigmoid probabilities, the
+    one-hot targets and the ignore mask are formed in registers (reference losses/dice.py:68-111)."""
+    assert y_true.size(0) == y_pred.size(0)
+    bs = y_true.size(0)
+    x = K._f32c(y_pred, "region loss")
+    if mode == MULTICLASS_MODE:
+        x = x.reshape(bs, x.size(1), -1)
+        labels = y_true.to(device=x.device).reshape(bs, -1)
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        labels = labels.contiguous()
+        if labels.size(1) != x.size(2):
+            raise RuntimeError(f"target shape {tuple(y_true.shape)} does not match prediction shape {tuple(y_pred.shape)}")
+        prob = K.PROB_SOFTMAX if from_logits else K.PROB_IDENTITY
+        stats = K.RegionStats.apply(x, labels, None, prob, ignore_index is not None, int(ignore_index) if ignore_index is not None else 0, 0.0)
+    else:
+        C = 1 if mode == BINARY_MODE else x.size(1)
+        x = x.reshape(bs, C, -1)
+        dense = K._f32c(y_true.to(device=x.device), "region loss").reshape(bs, C, -1)
+        prob = K.PROB_SIGMOID if from_logits else K.PROB_IDENTITY
+        stats = K.RegionStats.apply(x, None, dense, prob, ignore_index is not None, 0, float(ignore_index) if ignore_index is not None else 0.0)
+    return stats[0].float(), stats[1].float(), stats[2].float()
+
+
+def finish(scores, true_mass, log_loss, eps, classes):
+    """1 - score (or -log score), zero for classes without positives, optional class subset, mean (dice.py:115-131)."""
+    loss = -torch.log(scores.clamp_min(eps)) if log_loss else 1.0 - scores
+    loss = loss * (true_mass > 0).to(loss.dtype)
+    if classes is not None:
+        loss = loss[classes.to(loss.device)]
+    return loss.mean()

@@ -1,0 +1,205 @@
+"""Loss functionals (drop-in for ``pytorch_toolbelt.losses.functional``).
+
+``focal_loss_with_logits``, ``softmax_focal_loss_with_logits``, ``soft_dice_score`` and ``soft_jaccard_score`` run as
+single-pass HIP reductions (csrc/ptb_losses.hip); their scalar epilogues are torch ops on tiny tensors.  The wing and
+log-cosh losses are not on the hot path and stay plain torch.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from ..utils.support import pytorch_toolbelt_deprecated
+from . import _kernels as K
+
+__all__ = [
+    "focal_loss_with_logits",
+    "softmax_focal_loss_with_logits",
+    "sigmoid_focal_loss",
+    "soft_jaccard_score",
+    "soft_dice_score",
+    "wing_loss",
+    "log_cosh_loss",
+]
+
+
+def focal_loss_with_logits(
+    output: torch.Tensor,
+    target: torch.Tensor,
+    gamma: float = 2.0,
+    alpha: Optional[float] = 0.25,
+    reduction: str = "mean",
+    normalized: bool = False,
+    reduced_threshold: Optional[float] = None,
+    eps: float = 1e-6,
+    ignore_index=None,
+    activation: str = "sigmoid",
+    softmax_dim: Optional[int] = None,
+    class_weights: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Binary focal loss between logits and a same-shaped (0/1 or soft) target, always evaluated in float32.
+
+    ``loss_i = (1 - pt_i)^gamma * BCE_i`` (optionally alpha-balanced, class-weighted, reduced-threshold variant,
+    normalised by the sum of focal terms); elements whose target equals ``ignore_index`` contribute 0.
+    reduction: "mean" (over all elements, ignored ones included) | "sum" | "batchwise_mean" (a sum over dim 0, as in
+    the reference) | anything else -> unreduced tensor.
+    """
+    if activation != "sigmoid":
+        raise NotImplementedError("focal_loss_with_logits: only activation='sigmoid' has a native kernel")
+    return _sigmoid_focal(output, None, target, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights)
+
+
+def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights):
+    shape = output.shape
+    x = K.as_bchw(K._f32c(output, "focal loss"))
+    flags = 0
+    if alpha is not None:
+        flags |= K.SEG_HAS_ALPHA
+    if reduced_threshold is not None:
+        flags |= K.SEG_REDUCED
+    if ignore_index is not None:
+        flags |= K.SEG_HAS_IGNORE
+        if normalized:
+            flags |= K.SEG_MASK_FOCAL_TERM
+    want_map = reduction not in ("mean", "sum")
+    if want_map:
+        flags |= K.SEG_ELEMWISE
+    if dense is not None:
+        if dense.shape != shape:
+            raise RuntimeError(f"target shape {tuple(dense.shape)} does not match output shape {tuple(shape)}")
+        dense = K.as_bchw(K._f32c(dense, "focal loss"))
+    else:
+        labels = labels.to(device=x.device, dtype=torch.int64).reshape(x.shape[0], -1).contiguous()
+    cw = None
+    if class_weights is not None:
+        cw = class_weights.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if cw.numel() != x.shape[1]:
+            raise RuntimeError("class_weights must have one entry per channel")
+    sums, elem = K.SigmoidFocalSums.apply(
+        x, labels, dense, cw, flags, float(gamma), float(alpha if alpha is not None else 0.0),
+        float(reduced_threshold if reduced_threshold is not None else 0.0),
+        int(ignore_index) if (ignore_index is not None and labels is not None) else 0,
+        float(ignore_index) if ignore_index is not None else 0.0,
+    )
+    norm = sums[1].clamp_min(eps) if normalized else None
+    if want_map:
+        loss = elem.view(shape)
+        if normalized:
+            loss = loss / norm.float()
+        if reduction == "batchwise_mean":
+            loss = loss.sum(dim=0)
+        return loss
+    total = sums[0] / norm if normalized else sums[0]
+    if reduction == "mean":
+        total = total / x.numel()
+    return total.float()
+
+
+def softmax_focal_loss_with_logits(
+    output: torch.Tensor,
+    target: torch.Tensor,
+    class_weights: Optional[torch.Tensor] = None,
+    gamma: float = 2.0,
+    reduction: str = "mean",
+    normalized: bool = False,
+    reduced_threshold: Optional[float] = None,
+    eps: float = 1e-6,
+    ignore_index: int = -100,
+) -> torch.Tensor:
+    """Softmax flavour of the focal loss for ``output [B, C, *]`` / ``target [B, *]`` (like nn.CrossEntropyLoss):
+    per pixel ``sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c`` with ``pt`` from the softmax probabilities; pixels whose
+    label equals ``ignore_index`` give 0 but still count in the "mean" denominator."""
+    x = K.as_bchw(K._f32c(output, "softmax focal loss"))
+    labels = target.to(device=x.device, dtype=torch.int64).reshape(x.shape[0], -1).contiguous()
+    if labels.shape[1] != x.shape[2]:
+        raise RuntimeError(f"target shape {tuple(target.shape)} does not match output shape {tuple(output.shape)}")
+    cw = None
+    if class_weights is not None:
+        cw = class_weights.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+    want_map = reduction not in ("mean", "sum")
+    sums, pix = K.SoftmaxFocalSums.apply(x, labels, cw, 1 if reduced_threshold is not None else 0, float(gamma),
+                                         float(reduced_threshold if reduced_threshold is not None else 0.0), int(ignore_index), want_map)
+    norm = sums[1].clamp_min(eps) if normalized else None
+    if want_map:
+        loss = pix.view(target.shape)
+        if normalized:
+            loss = loss / norm.float()
+        if reduction == "batchwise_mean":
+            loss = loss.sum(0)
+        return loss
+    total = sums[0] / norm if normalized else sums[0]
+    if reduction == "mean":
+        total = total / labels.numel()
+    return total.float()
+
+
+@pytorch_toolbelt_deprecated("Function sigmoid_focal_loss is deprecated. Please use focal_loss_with_logits instead.")
+def sigmoid_focal_loss(*input, **kwargs):
+    return focal_loss_with_logits(*input, **kwargs)
+
+
+@pytorch_toolbelt_deprecated("Function reduced_focal_loss is deprecated. Please use focal_loss_with_logits instead.")
+def reduced_focal_loss(output: torch.Tensor, target: torch.Tensor, threshold=0.5, gamma=2.0, reduction="mean"):
+    return focal_loss_with_logits(output, target, alpha=None, gamma=gamma, reduction=reduction, reduced_threshold=threshold)
+
+
+def _region_sums(output: torch.Tensor, target: torch.Tensor, dims):
+    """(intersection, cardinality) = (sum o*t, sum o+t) over ``dims`` via the fused statistics kernel."""
+    assert output.size() == target.size()
+    nd = output.dim()
+    if dims is None:
+        kept = None
+        o3 = output.reshape(1, 1, -1)
+    else:
+        red = sorted({d % nd for d in (dims if isinstance(dims, (list, tuple)) else [dims])})
+        keep = [d for d in range(nd) if d not in red]
+        if len(keep) > 1:
+            raise NotImplementedError("soft scores: the native kernel keeps at most one dimension")
+        if not keep:
+            kept = None
+            o3 = output.reshape(1, 1, -1)
+        else:
+            kept = keep[0]
+            lead = 1
+            for s in output.shape[:kept]:
+                lead *= int(s)
+            o3 = output.reshape(lead, output.shape[kept], -1)
+    x = K._f32c(o3, "soft score")
+    t = K._f32c(target.reshape(o3.shape), "soft score")
+    stats = K.RegionStats.apply(x, None, t, K.PROB_IDENTITY, False, 0, 0.0)
+    inter, card = stats[0], stats[0 + 1] + stats[2]
+    if kept is None:
+        inter, card = inter[0], card[0]
+    return inter.float(), card.float()
+
+
+def soft_jaccard_score(output: torch.Tensor, target: torch.Tensor, smooth: float = 0.0, eps: float = 1e-7, dims=None) -> torch.Tensor:
+    """(I + smooth) / max(U + smooth, eps) with I = sum(output*target), U = sum(output+target) - I over ``dims``."""
+    inter, card = _region_sums(output, target, dims)
+    union = card - inter
+    return (inter + smooth) / (union + smooth).clamp_min(eps)
+
+
+def soft_dice_score(output: torch.Tensor, target: torch.Tensor, smooth: float = 0.0, eps: float = 1e-7, dims=None) -> torch.Tensor:
+    """(2 I + smooth) / max(S + smooth, eps) with I = sum(output*target), S = sum(output+target) over ``dims``."""
+    inter, card = _region_sums(output, target, dims)
+    return (2.0 * inter + smooth) / (card + smooth).clamp_min(eps)
+
+
+def wing_loss(output: torch.Tensor, target: torch.Tensor, width=5, curvature=0.5, reduction="mean"):
+    """Wing loss for landmark regression (https://arxiv.org/pdf/1711.06753.pdf): log-shaped near zero, L1 beyond."""
+    diff = (target - output).abs()
+    c = width - width * math.log(1 + width / curvature)
+    loss = torch.where(diff < width, width * torch.log(1 + diff / curvature), diff - c)
+    if reduction == "sum":
+        return loss.sum()
+    if reduction == "mean":
+        return loss.mean()
+    return loss
+
+
+def log_cosh_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
+    """mean(log(cosh(y_pred - y_true))), evaluated as d + softplus(-2d) - log 2 for stability."""
+    d = y_pred - y_true
+    return torch.mean(d + F.softplus(-2.0 * d) - math.log(2.0))

@@ -1,0 +1,134 @@
+"""Lovasz hinge / Lovasz-softmax losses (drop-in for ``pytorch_toolbelt.losses.lovasz``).
+
+Algorithm of Berman et al. 2018 as used by the reference (losses/lovasz.py): sort the per-pixel errors of one class in
+decreasing order, weight them by the discrete gradient of the Jaccard index along that order, sum.  Here all classes
+(and all images when ``per_image``) are segments of ONE segmented radix sort followed by one fused scan/dot kernel,
+with no host synchronisation (the reference syncs once per class to test ``fg.sum() == 0``).
+"""
+from typing import Optional, Union
+
+import torch
+from torch.nn.modules.loss import _Loss
+
+from .. import _native as N
+from . import _kernels as K
+
+__all__ = ["BinaryLovaszLoss", "LovaszLoss"]
+
+_SOFTMAX, _HINGE = 0, 1
+_CHUNK = 2048
+
+
+class _LovaszSegments(torch.autograd.Function):
+    """Per-segment Lovasz dot products [S] (float64) and per-segment foreground counts [S] (int32)."""
+
+    @staticmethod
+    def forward(ctx, pred, labels, flabels, mode, per_image, has_ignore, ignore_label, ignore_value):
+        if mode == _SOFTMAX:
+            B, C, HW = pred.shape
+        else:
+            (B, HW), C = pred.shape, 1
+        groups = B if per_image else 1
+        P = HW if per_image else B * HW
+        S = groups * C
+        n = P * S
+        dev = pred.device
+        seg_loss = torch.zeros(S, dtype=torch.float64, device=dev)
+        fg_total = torch.zeros(S, dtype=torch.int32, device=dev)
+        gpix = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        if n > 0:
+            lib = N.load()
+            keys = torch.empty((2, n), dtype=torch.float32, device=dev)
+            vals = torch.empty((2, n), dtype=torch.int32, device=dev)
+            offsets = (torch.arange(S + 1, device=dev, dtype=torch.int64) * P).to(torch.int32)
+            chunk = torch.empty(S * ((P + _CHUNK - 1) // _CHUNK), dtype=torch.int32, device=dev)
+            with N.on_device(dev):
+                tb = lib.ptb_lovasz_temp_bytes(P, S)
+                if tb < 0:
+                    raise RuntimeError("ptb_lovasz_temp_bytes failed")
+                temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
+                rc = lib.ptb_lovasz_fwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
+                                        1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
+                                        vals[0].data_ptr(), vals[1].data_ptr(), offsets.data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
+                                        seg_loss.data_ptr(), gpix.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
+            N.bump()
+            N.check(rc, "ptb_lovasz_fwd")
+        ctx.save_for_backward(pred, labels, flabels, gpix)
+        ctx.cfg = (B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)
+        ctx.mark_non_differentiable(fg_total)
+        return seg_loss, fg_total
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_fg):
+        pred, labels, flabels, gpix = ctx.saved_tensors
+        B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value = ctx.cfg
+        grad = torch.zeros_like(pred)
+        if pred.numel():
+            coef = g_loss.to(torch.float32).contiguous()
+            lib = N.load()
+            with N.on_device(pred.device):
+                rc = lib.ptb_lovasz_bwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), gpix.data_ptr(), grad.data_ptr(),
+                                        B, C, HW, mode, 1 if per_image else 0, 1 if has_ignore else 0, ignore_label, ignore_value,
+                                        N.stream_ptr(pred.device))
+            N.bump()
+            N.check(rc, "ptb_lovasz_bwd")
+        return grad, None, None, None, None, None, None, None
+
+
+def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
+    """Binary Lovasz hinge loss: logits [B, H, W] (any real), labels [B, H, W] in {0, 1}; ``ignore_index`` marks void pixels.
+    per_image averages the per-image losses; an image with only void pixels contributes 0."""
+    x = K._f32c(logits, "BinaryLovaszLoss")
+    B = x.shape[0]
+    x = x.reshape(B, -1)
+    y = labels.to(device=x.device, dtype=torch.float32).reshape(B, -1).contiguous()
+    seg_loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
+                                          float(ignore_index) if ignore_index is not None else 0.0)
+    return seg_loss.mean().float() if per_image else seg_loss[0].float()
+
+
+def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_index=None):
+    """Multi-class Lovasz-softmax: ``probas`` [B, C, H, W] are class PROBABILITIES (no softmax is applied, as in the
+    reference); labels [B, H, W] in [0, C).  classes: "present" (average over classes that occur), "all", or a list."""
+    if probas.dim() == 3:
+        probas = probas.unsqueeze(1)
+    x = K._f32c(probas, "LovaszLoss")
+    B, C = x.shape[0], x.shape[1]
+    if C == 1 and len(classes) > 1:
+        raise ValueError("Sigmoid output possible only with 1 class")   # reference lovasz.py:129-131 (always hit for C == 1)
+    x = x.reshape(B, C, -1)
+    lab = labels.to(device=x.device, dtype=torch.int64).reshape(B, -1).contiguous()
+    seg_loss, fg = _LovaszSegments.apply(x, lab, None, _SOFTMAX, bool(per_image), ignore_index is not None,
+                                         int(ignore_index) if ignore_index is not None else 0, 0.0)
+    groups = B if per_image else 1
+    seg_loss = seg_loss.view(groups, C)
+    if classes == "present":
+        use = (fg.view(groups, C) > 0).to(seg_loss.dtype)
+    elif classes == "all":
+        use = torch.ones_like(seg_loss)
+    else:
+        use = torch.zeros_like(seg_loss)
+        use[:, list(classes)] = 1.0
+    count = use.sum(dim=1)
+    per_group = (seg_loss * use).sum(dim=1) / count.clamp_min(1.0)   # mean over the selected classes; 0 when none
+    return per_group.mean().float() if per_image else per_group[0].float()
+
+
+class BinaryLovaszLoss(_Loss):
+    def __init__(self, per_image: bool = False, ignore_index: Optional[Union[int, float]] = None):
+        super().__init__()
+        self.ignore_index = ignore_index
+        self.per_image = per_image
+
+    def forward(self, logits, target):
+        return _lovasz_hinge(logits, target, per_image=self.per_image, ignore_index=self.ignore_index)
+
+
+class LovaszLoss(_Loss):
+    def __init__(self, per_image=False, ignore=None):
+        super().__init__()
+        self.ignore = ignore
+        self.per_image = per_image
+
+    def forward(self, logits, target):
+        return _lovasz_softmax(logits, target, per_image=self.per_image, ignore_index=self.ignore)

@@ -1,0 +1,349 @@
+"""GPU parity: fused loss kernels (HIP) vs golden vectors of the reference, the fp64 numpy oracle, and (for gradients)
+a plain torch fp32 restatement differentiated by autograd.  Loss scalars: |diff| <= 1e-5 absolute (north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import losses_oracle as LO
+
+pytestmark = pytest.mark.gpu
+
+GL = load_golden("losses.npz")
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _L():
+    from pytorch_toolbelt_amd import losses as L
+
+    return L
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _kw(case, dev):
+    kw = dict(case["kwargs"])
+    if kw.pop("class_weights", None):
+        kw["class_weights"] = _t(GL["class_weights"], dev)
+    return kw
+
+
+@pytest.mark.parametrize("case", GL.by_fn("focal_loss_with_logits"), ids=lambda c: c["name"])
+def test_golden_focal_functional(case, dev):
+    kw = _kw(case, dev)
+    if kw.get("activation") == "softmax":
+        with pytest.raises(NotImplementedError):
+            _L().focal_loss_with_logits(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev), **kw)
+        return
+    from pytorch_toolbelt_amd import _native as N
+
+    before = N.calls
+    out = _L().focal_loss_with_logits(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev), **kw)
+    assert N.calls > before
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+@pytest.mark.parametrize("case", GL.by_fn("binary_focal_loss"), ids=lambda c: c["name"])
+def test_golden_binary_focal_module(case, dev):
+    out = _L().BinaryFocalLoss(**_kw(case, dev)).to(dev)(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+@pytest.mark.parametrize("case", GL.by_fn("softmax_focal_loss_with_logits"), ids=lambda c: c["name"])
+def test_golden_softmax_focal(case, dev):
+    out = _L().softmax_focal_loss_with_logits(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev), **_kw(case, dev))
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+    kw = _kw(case, dev)
+    mod = _L().CrossEntropyFocalLoss(**kw).to(dev)(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev))
+    np.testing.assert_allclose(mod.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+@pytest.mark.parametrize("case", GL.by_fn("soft_dice_score", "soft_jaccard_score"), ids=lambda c: c["name"])
+def test_golden_soft_scores(case, dev):
+    fn = getattr(_L(), case["fn"])
+    out = fn(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev), **case["kwargs"])
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+@pytest.mark.parametrize("case", GL.by_fn("dice_loss", "jaccard_loss"), ids=lambda c: c["name"])
+def test_golden_region_losses(case, dev):
+    cls = _L().DiceLoss if case["fn"] == "dice_loss" else _L().JaccardLoss
+    kw = dict(case["kwargs"])
+    out = cls(**kw)(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+    if "classes" in kw:  # a tensor of classes behaves the same (the only form that works in the reference, quirk Q17)
+        kw["classes"] = torch.tensor(kw["classes"])
+        out = cls(**kw)(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev))
+        np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+@pytest.mark.parametrize("case", GL.by_fn("lovasz_softmax", "lovasz_hinge"), ids=lambda c: c["name"])
+def test_golden_lovasz(case, dev):
+    cls = _L().LovaszLoss if case["fn"] == "lovasz_softmax" else _L().BinaryLovaszLoss
+    out = cls(**case["kwargs"])(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), GL[case["output"]], **TOL)
+
+
+GRAD_CASES = {
+    "grad_binary_focal": lambda L, kw: L.BinaryFocalLoss(**kw),
+    "grad_softmax_focal": lambda L, kw: L.CrossEntropyFocalLoss(**kw),
+    "grad_dice": lambda L, kw: L.DiceLoss(**kw),
+    "grad_jaccard": lambda L, kw: L.JaccardLoss(**kw),
+}
+
+
+@pytest.mark.parametrize("case", GL.by_fn(*GRAD_CASES), ids=lambda c: c["name"])
+def test_golden_gradients(case, dev):
+    """d(loss)/d(logits) vs the reference's autograd result."""
+    crit = GRAD_CASES[case["fn"]](_L(), dict(case["kwargs"]))
+    x = _t(GL[case["inputs"][0]], dev).requires_grad_(True)
+    crit(x, _t(GL[case["inputs"][1]], dev)).backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), GL[case["output"]], rtol=1e-4, atol=1e-7)
+
+
+# --------------------------------------------------------------------------------------- larger shapes vs the oracle
+def _cfg4_like(seed=0, B=4, C=16, H=96, W=128):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn((B, C, H, W), generator=g) * 2.5
+    logits[1] += 1.0
+    logits[2] *= 0.2
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels[0, :20] = 3
+    return logits, labels
+
+
+@pytest.mark.parametrize("hw", [(96, 128), (33, 37)])  # 16-byte vector path and the scalar (HW % 4 != 0) path
+def test_cfg4_fused_losses_match_oracle(hw, dev):
+    """BASELINE configs[3] pattern (BinaryFocal + Dice + Jaccard on [B,16,H,W] logits + int64 labels), reduced size."""
+    logits, labels = _cfg4_like(H=hw[0], W=hw[1])
+    xl, ll = logits.to(dev), labels.to(dev)
+    L = _L()
+    x64, l64 = logits.numpy(), labels.numpy()
+    np.testing.assert_allclose(float(L.BinaryFocalLoss()(xl, ll)), LO.binary_focal_loss(x64, l64), **TOL)
+    np.testing.assert_allclose(float(L.BinaryFocalLoss(alpha=0.3, gamma=1.7, normalized=True)(xl, ll)), LO.binary_focal_loss(x64, l64, alpha=0.3, gamma=1.7, normalized=True), **TOL)
+    np.testing.assert_allclose(float(L.DiceLoss("multiclass")(xl, ll)), LO.dice_loss(x64, l64, "multiclass"), **TOL)
+    np.testing.assert_allclose(float(L.JaccardLoss("multiclass")(xl, ll)), LO.jaccard_loss(x64, l64, "multiclass"), **TOL)
+    np.testing.assert_allclose(float(L.CrossEntropyFocalLoss()(xl, ll)), LO.softmax_focal_loss_with_logits(x64, l64), **TOL)
+    oh = torch.nn.functional.one_hot(labels, 16).permute(0, 3, 1, 2).float()
+    np.testing.assert_allclose(float(L.DiceLoss("multilabel")(xl, oh.to(dev))), LO.dice_loss(x64, oh.numpy(), "multilabel"), **TOL)
+    np.testing.assert_allclose(float(L.JaccardLoss("multilabel", log_loss=True, smooth=1.0)(xl, oh.to(dev))), LO.jaccard_loss(x64, oh.numpy(), "multilabel", log_loss=True, smooth=1.0), **TOL)
+    probs = torch.softmax(logits[:2], dim=1)
+    np.testing.assert_allclose(float(L.LovaszLoss()(probs.to(dev), ll[:2])), LO.lovasz_softmax(probs.numpy(), l64[:2]), **TOL)
+    np.testing.assert_allclose(float(L.LovaszLoss(per_image=True)(probs.to(dev), ll[:2])), LO.lovasz_softmax(probs.numpy(), l64[:2], per_image=True), **TOL)
+    bl, bt = logits[:, 0], (labels == 3).float()
+    np.testing.assert_allclose(float(L.BinaryLovaszLoss()(bl.contiguous().to(dev), bt.to(dev))), LO.lovasz_hinge(bl.numpy(), bt.numpy()), **TOL)
+    np.testing.assert_allclose(float(L.BinaryLovaszLoss(per_image=True)(bl.contiguous().to(dev), bt.to(dev))), LO.lovasz_hinge(bl.numpy(), bt.numpy(), per_image=True), **TOL)
+
+
+def test_reference_kats(dev):
+    """reference tests/test_losses.py:11-209 on the GPU."""
+    L = _L()
+    f = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+    t = torch.tensor([1, 0, 1], device=dev)
+    assert L.focal_loss_with_logits(f([10, -10, 10]), t) < L.focal_loss_with_logits(f([-1, 2, 0]), t)
+    assert L.BinaryFocalLoss()(f([10, -10, 10]), t) < L.BinaryFocalLoss()(f([-1, 2, 0]), t)
+    good, bad, lab = f([[0, 10, 0], [10, 0, 0], [0, 0, 10]]), f([[0, -10, 0], [0, 10, 0], [0, 0, 10]]), torch.tensor([1, 0, 2], device=dev)
+    assert L.softmax_focal_loss_with_logits(good, lab) < L.softmax_focal_loss_with_logits(bad, lab)
+    assert L.CrossEntropyFocalLoss()(good, lab) < L.CrossEntropyFocalLoss()(bad, lab)
+    for yt, yp, want in [([1, 1, 1, 1], [1, 1, 1, 1], 1.0), ([0, 1, 1, 0], [0, 1, 1, 0], 1.0), ([1, 1, 1, 1], [1, 1, 0, 0], 0.5)]:
+        assert float(L.soft_jaccard_score(f(yp), f(yt), eps=1e-5)) == pytest.approx(want, 1e-5)
+    for yt, yp, want in [([1, 1, 1, 1], [1, 1, 1, 1], 1.0), ([0, 1, 1, 0], [0, 1, 1, 0], 1.0), ([1, 1, 1, 1], [1, 1, 0, 0], 2 / 3)]:
+        assert float(L.soft_dice_score(f(yp), f(yt), eps=1e-5)) == pytest.approx(want, 1e-5)
+    yt, yp = f([[1, 1, 0, 0], [0, 0, 0, 1]]), f([[1, 1, 0, 0], [0, 0, 0, 0]])
+    assert float(L.soft_jaccard_score(yp, yt, dims=[1], eps=1e-5).mean()) == pytest.approx(0.5, 1e-5)
+    eps = 1e-5
+    for cls in (L.DiceLoss, L.JaccardLoss):
+        crit = cls(mode="binary", from_logits=False)
+        assert float(crit(f([1, 1, 1]).view(1, 1, 1, -1), torch.tensor([1, 1, 1], device=dev).view(1, 1, 1, -1))) == pytest.approx(0, abs=eps)
+        assert float(crit(f([1, 0, 1]).view(1, 1, 1, -1), torch.tensor([1, 0, 1], device=dev).view(1, 1, 1, -1))) == pytest.approx(0, abs=eps)
+        assert float(crit(f([0, 0, 0]).view(1, 1, 1, -1), torch.tensor([0, 0, 0], device=dev).view(1, 1, 1, -1))) == pytest.approx(0, abs=eps)
+        assert float(crit(f([1, 1, 1]).view(1, 1, -1), torch.tensor([0, 0, 0], device=dev).view(1, 1, 1, -1))) == pytest.approx(0, abs=eps)
+        assert float(crit(f([1, 0, 1]).view(1, 1, -1), torch.tensor([0, 1, 0], device=dev).view(1, 1, 1, -1))) == pytest.approx(1, abs=eps)
+        assert float(crit(f([0, 0, 0]).view(1, 1, -1), torch.tensor([1, 1, 1], device=dev).view(1, 1, 1, -1))) == pytest.approx(1, abs=eps)
+    crit = L.JaccardLoss(mode="multiclass", from_logits=False)
+    assert float(crit(f([[[1, 1, 0, 0], [0, 0, 1, 1]]]), torch.tensor([[0, 0, 1, 1]], device=dev))) == pytest.approx(0, abs=eps)
+    assert float(crit(f([[[1, 1, 0, 0], [0, 0, 1, 1]]]), torch.tensor([[1, 1, 0, 0]], device=dev))) == pytest.approx(1, abs=eps)
+    assert float(crit(f([[[1, 0, 1, 0], [0, 1, 0, 1]]]), torch.tensor([[1, 1, 0, 0]], device=dev))) == pytest.approx(1 - 1 / 3, abs=eps)
+    crit = L.JaccardLoss(mode="multilabel", from_logits=False)
+    yp = f([[[1, 1, 0, 0], [0, 0, 1, 1]]])
+    assert float(crit(yp, yp.clone())) == pytest.approx(0, abs=eps)
+    assert float(crit(yp, 1 - yp)) == pytest.approx(1, abs=eps)
+    assert float(crit(f([[[0, 1, 1, 0], [0, 1, 1, 0]]]), f([[[1, 1, 0, 0], [1, 1, 0, 0]]]))) == pytest.approx(1 - 1 / 3, abs=eps)
+
+
+def test_label_errors_and_modes(dev):
+    L = _L()
+    x = torch.randn((2, 3, 8, 8), device=dev)
+    bad = torch.full((2, 8, 8), 7, device=dev)
+    for crit in (L.DiceLoss("multiclass"), L.JaccardLoss("multiclass"), L.BinaryFocalLoss(), L.CrossEntropyFocalLoss()):
+        with pytest.raises(RuntimeError):
+            crit(x, bad)
+    with pytest.raises(AssertionError):
+        L.DiceLoss("nonsense")
+    with pytest.raises(AssertionError):
+        L.JaccardLoss("binary", classes=[0])
+    with pytest.raises(ValueError):
+        L.LovaszLoss()(torch.rand((2, 8, 8), device=dev), torch.zeros((2, 8, 8), dtype=torch.long, device=dev))
+    assert "class_weights=None" in repr(L.BinaryFocalLoss())
+    # the reference's list handling of `classes` yields NaN (quirk Q17); here lists and tensors agree
+    lab = torch.randint(0, 3, (2, 8, 8), device=dev)
+    assert float(L.DiceLoss("multiclass", classes=[0, 2])(x, lab)) == pytest.approx(float(L.DiceLoss("multiclass", classes=torch.tensor([0, 2]))(x, lab)))
+    # fp16 logits are evaluated in float32 (functional.py:58-59)
+    a = L.BinaryFocalLoss()(x.half(), lab)
+    b = L.BinaryFocalLoss()(x.half().float(), lab)
+    assert float(a) == pytest.approx(float(b), abs=1e-6)
+
+
+# --------------------------------------------------------------------------------------- gradients vs torch autograd
+def _torch_focal(x, t, gamma, alpha, normalized, thr, ignore):
+    p = torch.sigmoid(x)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
+    pt = p * t + (1 - p) * (1 - t)
+    f = (1 - pt).pow(gamma) if thr is None else torch.where(pt < thr, torch.ones_like(pt), ((1 - pt) / (1 - thr)).pow(gamma))
+    loss = f * ce
+    if alpha is not None:
+        loss = loss * (alpha * t + (1 - alpha) * (1 - t))
+    if ignore is not None:
+        m = t == ignore
+        loss = loss.masked_fill(m, 0)
+        f = f.masked_fill(m, 0)
+    if normalized:
+        loss = loss / f.sum().clamp_min(1e-6)
+    return loss
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(alpha=0.25), dict(gamma=1.5, alpha=0.6), dict(normalized=True), dict(reduced_threshold=0.5),
+                                dict(ignore_index=255, normalized=True), dict(reduction="sum", gamma=0.0), dict(reduction="none"),
+                                dict(reduction="batchwise_mean", alpha=0.4)])
+def test_focal_gradient(kw, dev):
+    L = _L()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn((3, 4, 10, 12), generator=g) * 2).to(dev)
+    t = (torch.rand((3, 4, 10, 12), generator=g) < 0.3).float().to(dev)
+    if kw.get("ignore_index") is not None:
+        t[torch.rand(t.shape, generator=g).to(dev) < 0.2] = 255
+    red = kw.get("reduction", "mean")
+    x1 = x.clone().requires_grad_(True)
+    out = L.focal_loss_with_logits(x1, t, **{"alpha": None, **kw})
+    x2 = x.clone().requires_grad_(True)
+    ref = _torch_focal(x2, t, kw.get("gamma", 2.0), kw.get("alpha"), kw.get("normalized", False), kw.get("reduced_threshold"), kw.get("ignore_index"))
+    ref = {"mean": ref.mean, "sum": ref.sum, "batchwise_mean": lambda: ref.sum(0), "none": lambda: ref}[red]()
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    w = torch.rand_like(ref)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-7)
+
+
+def _torch_region(x, t_onehot, kind, log_loss, smooth, prob):
+    p = x.log_softmax(1).exp() if prob == "softmax" else (torch.nn.functional.logsigmoid(x).exp() if prob == "sigmoid" else x)
+    p = p.flatten(2)
+    t = t_onehot.flatten(2)
+    inter, card = (p * t).sum((0, 2)), (p + t).sum((0, 2))
+    score = (2 * inter + smooth) / (card + smooth).clamp_min(1e-7) if kind == "dice" else (inter + smooth) / (card - inter + smooth).clamp_min(1e-7)
+    loss = -torch.log(score.clamp_min(1e-7)) if log_loss else 1 - score
+    return (loss * (t.sum((0, 2)) > 0)).mean()
+
+
+@pytest.mark.parametrize("kind", ["dice", "jaccard"])
+@pytest.mark.parametrize("mode,log_loss,smooth", [("multiclass", False, 0.0), ("multiclass", True, 1.0), ("multilabel", False, 0.5), ("binary", True, 0.0)])
+def test_region_loss_gradient(kind, mode, log_loss, smooth, dev):
+    L = _L()
+    g = torch.Generator().manual_seed(6)
+    C = 1 if mode == "binary" else 5
+    x = (torch.randn((3, C, 9, 11), generator=g) * 2).to(dev)
+    if mode == "multiclass":
+        lab = torch.randint(0, C, (3, 9, 11), generator=g).to(dev)
+        target, onehot, prob = lab, torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float(), "softmax"
+    else:
+        target = (torch.rand((3, C, 9, 11), generator=g) < 0.4).float().to(dev)
+        onehot, prob = target, "sigmoid"
+    cls = L.DiceLoss if kind == "dice" else L.JaccardLoss
+    x1 = x.clone().requires_grad_(True)
+    out = cls(mode, log_loss=log_loss, smooth=smooth)(x1, target)
+    x2 = x.clone().requires_grad_(True)
+    ref = _torch_region(x2, onehot, kind, log_loss, smooth, prob)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    out.backward()
+    ref.backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-8)
+
+
+def test_softmax_focal_and_lovasz_gradients(dev):
+    L = _L()
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn((2, 6, 8, 9), generator=g) * 2).to(dev)
+    lab = torch.randint(0, 6, (2, 8, 9), generator=g).to(dev)
+    lab[0, 0, :4] = -100
+    for kw in (dict(), dict(gamma=1.0, reduction="sum"), dict(normalized=True), dict(reduced_threshold=0.5), dict(reduction="none")):
+        x1 = x.clone().requires_grad_(True)
+        out = L.softmax_focal_loss_with_logits(x1, lab, **kw)
+        x2 = x.clone().requires_grad_(True)
+        valid = lab != -100
+        oh = torch.nn.functional.one_hot(lab.masked_fill(~valid, 0), 6).permute(0, 3, 1, 2).float()
+        p = torch.softmax(x2, 1)
+        pt = (1 - oh) * p + oh * (1 - p)
+        thr = kw.get("reduced_threshold")
+        f = pt.pow(kw.get("gamma", 2.0)) if thr is None else torch.where(pt < thr, torch.ones_like(pt), (pt / thr).pow(kw.get("gamma", 2.0)))
+        ref = (f * torch.nn.functional.binary_cross_entropy_with_logits(x2, oh, reduction="none")).sum(1) * valid
+        if kw.get("normalized"):
+            ref = ref / f.sum().clamp_min(1e-6)
+        red = kw.get("reduction", "mean")
+        ref = ref.mean() if red == "mean" else (ref.sum() if red == "sum" else ref)
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+        w = torch.rand_like(ref)
+        (out * w).sum().backward()
+        (ref * w).sum().backward()
+        torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-7)
+    # Lovasz: gradient equals the Lovasz gradient at each pixel's rank times d(error)/d(pred); check against the
+    # directional finite difference of the (piecewise linear) loss
+    probs = torch.softmax(x, 1).clone().requires_grad_(True)
+    lab2 = lab.masked_fill(lab == -100, 0)
+    loss = L.LovaszLoss()(probs, lab2)
+    loss.backward()
+    d = torch.randn_like(probs) * 1e-4
+    with torch.no_grad():
+        l2 = L.LovaszLoss()(probs + d, lab2)
+    assert float(l2 - loss) == pytest.approx(float((probs.grad * d).sum()), rel=2e-2, abs=1e-7)
+    xl = x[:, 0].contiguous().clone().requires_grad_(True)
+    bt = (lab2 == 1).float()
+    loss = L.BinaryLovaszLoss(per_image=True)(xl, bt)
+    loss.backward()
+    d = torch.randn_like(xl) * 1e-4
+    with torch.no_grad():
+        l2 = L.BinaryLovaszLoss(per_image=True)(xl + d, bt)
+    assert float(l2 - loss) == pytest.approx(float((xl.grad * d).sum()), rel=2e-2, abs=1e-7)
+
+
+def test_cfg4_full_size_properties(dev):
+    """BASELINE configs[3] at full size ([32,16,512,512] logits, int64 labels): size-independent properties."""
+    L = _L()
+    B, C, H, W = 32, 16, 512, 512
+    g = torch.Generator(device=dev).manual_seed(0)
+    labels = torch.randint(0, C, (B, H, W), device=dev, generator=g)
+    # (1) perfect prediction: huge logit on the labelled class -> every loss ~ 0
+    perfect = torch.full((B, C, H, W), -30.0, device=dev)
+    perfect.scatter_(1, labels.unsqueeze(1), 30.0)
+    assert float(L.DiceLoss("multiclass")(perfect, labels)) == pytest.approx(0.0, abs=1e-5)
+    assert float(L.JaccardLoss("multiclass")(perfect, labels)) == pytest.approx(0.0, abs=1e-5)
+    assert float(L.BinaryFocalLoss()(perfect, labels)) == pytest.approx(0.0, abs=1e-6)
+    # (2) all-zero logits: closed forms.  sigmoid focal: p = 0.5 -> 0.25 * ln 2 per element; uniform softmax: p = 1/C
+    zeros = torch.zeros((B, C, H, W), device=dev)
+    assert float(L.BinaryFocalLoss()(zeros, labels)) == pytest.approx(0.25 * np.log(2.0), rel=1e-5)
+    counts = torch.bincount(labels.flatten(), minlength=C).double().cpu().numpy()
+    n = B * H * W
+    dice = np.mean(1 - 2 * (counts / C) / (n / C + counts))
+    assert float(L.DiceLoss("multiclass")(zeros, labels)) == pytest.approx(dice, abs=1e-5)
+    # (3) batch linearity of the sums: loss(sum reduction) over the batch == sum of the two half batches
+    x = torch.randn((B, C, H, W), device=dev, generator=g)
+    full = L.BinaryFocalLoss(reduction="sum")(x, labels)
+    halves = L.BinaryFocalLoss(reduction="sum")(x[:16], labels[:16]) + L.BinaryFocalLoss(reduction="sum")(x[16:], labels[16:])
+    assert float(full) == pytest.approx(float(halves), rel=1e-6)
