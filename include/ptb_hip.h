@@ -117,10 +117,14 @@ int ptb_resize_bilinear(const float* in, float* out, int64_t planes, int hin, in
 #define PTB_PROB_SIGMOID 1         /* logsigmoid.exp()          (dice.py:73-75 binary / multilabel) */
 #define PTB_PROB_IDENTITY 2        /* from_logits=False: `logits` already holds probabilities */
 
+/* Scalars are accumulated into PTB_SUM_SLOTS interleaved copies (same-address atomics serialise on the device); the
+ * caller zeroes the whole buffer and adds the slots: total[k] = sum_s sums[s * n + k]. */
+#define PTB_SUM_SLOTS 64
+
 /* One pass over logits+targets for focal_loss_with_logits (losses/functional.py:19-107, sigmoid activation),
  * BinaryFocalLoss (losses/focal.py:77-105) and the sums of soft_dice_score / soft_jaccard_score with dims=(0,2)
  * (losses/functional.py:188-247; DiceLoss losses/dice.py:59-131, JaccardLoss losses/jaccard.py:48-103).
- * sums: double[2 + 3*C], must be zeroed by the caller; error_flag: int, set to 1 when a label is outside [0, C)
+ * sums: double[PTB_SUM_SLOTS][2 + 3*C], must be zeroed by the caller; error_flag: int, set to 1 when a label is outside [0, C)
  * and not ignore_label (the reference's F.one_hot raises).  class_weights [C] fp32 or NULL. */
 int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
                      double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags, int prob,
@@ -141,7 +145,7 @@ int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, const float* d
                       float ignore_value, ptb_stream_t stream);
 
 /* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
- * sums double[2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
+ * sums double[PTB_SUM_SLOTS][2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
 int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,
                           float* pixel_out, int* error_flag, int B, int C, int64_t HW, int reduced, float gamma,
                           float threshold, int64_t ignore_label, ptb_stream_t stream);
@@ -155,12 +159,12 @@ int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const floa
  * whole batch; S = groups*C segments of P = (per_image ? HW : B*HW) elements, n = S*P < 2^31.
  * seg_loss[s] (double, zeroed by the caller) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
  * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward).
- * Workspaces are caller-provided device buffers: keys_a/keys_b float[n], vals_a/vals_b u32[n], offsets u32[S+1] holding
- * s*P, chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (rocPRIM segmented radix sort). */
+ * Workspaces are caller-provided device buffers: keys_a/keys_b u64[n] (segment rank << 32 | ordered error bits),
+ * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (rocPRIM radix sort). */
 int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments);
 int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
-                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, float* keys_a, float* keys_b,
-                   unsigned* vals_a, unsigned* vals_b, unsigned* offsets, unsigned* chunk, unsigned* fg_total,
+                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint64_t* keys_a, uint64_t* keys_b,
+                   unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                    double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream);
 /* grad[pred layout] = coef[s] * grad_at_pixel * d(error)/d(pred); coef = DEVICE float[S]. */
 int ptb_lovasz_bwd(const float* pred, const int64_t* labels, const float* flabels, const float* coef,

@@ -9,33 +9,39 @@
 // from which Dice, Jaccard and their log variants are [C]-sized scalar algebra.  Backward kernels recompute the
 // activations from the logits (one more read, one gradient write) instead of storing any intermediate.
 //
-// Layout: logits [B, C, HW] fp32.  A wave owns 64*PIX consecutive pixels of one image (lane = PIX pixels, 16 B loads
-// when PIX = 4) and walks the C planes, so every global access is a coalesced 256 B..1 KiB row segment.  Per-class
-// sums are reduced across the 64 lanes with shuffles, accumulated per wave in LDS, and leave the workgroup as one fp64
-// atomic per (statistic, class).  Memory/transcendental-bound elementwise work: no MFMA.
+// Layout: logits [B, C, HW] fp32.  A wave owns 64*PIX consecutive pixels of one image (lane = PIX pixels, one 16 B load
+// per class plane when PIX = 4).  For C <= CREG the lane first issues the loads of ALL class planes (CREG x 16 B in
+// flight per lane -- this is what hides HBM latency), keeps them in registers, and does softmax with one exp per
+// element.  Per-class sums are kept per lane across the wave's groups and reduced across lanes once, at the end;
+// they leave the workgroup as one fp64 atomic per (statistic, class).  Streaming + transcendental work: no MFMA.
+#include <initializer_list>
+
 #include "ptb_common.h"
+
+// the losses are tolerance-checked (1e-5), not bit-exact: let the compiler fuse multiply-adds in this file
+#pragma clang fp contract(fast)
 
 namespace ptb {
 
 enum {
-    SEG_FOCAL = 1,         // accumulate sigmoid-focal sums
-    SEG_STATS = 2,         // accumulate per-class region statistics
+    SEG_FOCAL = 1,             // accumulate sigmoid-focal sums
+    SEG_STATS = 2,             // accumulate per-class region statistics
     SEG_HAS_IGNORE = 4,
     SEG_HAS_ALPHA = 8,
-    SEG_REDUCED = 16,      // reduced focal loss (threshold)
+    SEG_REDUCED = 16,          // reduced focal loss (threshold)
     SEG_MASK_FOCAL_TERM = 32,  // normalised focal: ignored elements contribute 0 to sums[1]
-    SEG_ELEMWISE = 64,     // also write the per-element focal loss
+    SEG_ELEMWISE = 64,         // also write the per-element focal loss
 };
 enum { PROB_SOFTMAX = 0, PROB_SIGMOID = 1, PROB_IDENTITY = 2 };
 
 struct SegArgs {
     const float* logits;
-    const long long* labels;   // [B, HW] or null
-    const float* dense;        // [B, C, HW] or null
+    const long long* labels;     // [B, HW] or null
+    const float* dense;          // [B, C, HW] or null
     const float* class_weights;  // [C] or null
-    double* sums;              // [2 + 3*C]: focal loss, focal term, I[C], P[C], T[C]
-    float* elem_out;           // [B, C, HW] when SEG_ELEMWISE
-    int* error_flag;           // set to 1 on a label outside [0, C) that is not ignore_index
+    double* sums;                // [2 + 3*C]: focal loss, focal term, I[C], P[C], T[C]
+    float* elem_out;             // [B, C, HW] when SEG_ELEMWISE
+    int* error_flag;             // set to 1 on a label outside [0, C) that is not ignore_index
     int B, C;
     long long HW;
     int flags, prob;
@@ -43,7 +49,7 @@ struct SegArgs {
     long long ignore_label;
 };
 
-// PIX consecutive floats of one lane: one 16-byte load when PIX == 4 (the host guarantees 16 B alignment then)
+// ------------------------------------------------------------------------------------------------ small helpers
 template <int PIX>
 __device__ __forceinline__ void load_px(const float* __restrict__ p, float (&x)[PIX], bool ok) {
     if (!ok) return;
@@ -71,276 +77,585 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-
-__device__ __forceinline__ float powf_pos(float base, float g) {  // base >= 0
-    if (g == 2.0f) return base * base;
-    if (g == 1.0f) return base;
-    if (g == 0.0f) return 1.0f;
-    return base > 0.f ? __expf(g * __logf(base)) : 0.f;
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
 }
 
-// sigmoid focal term and loss of one element (functional.py:61-94).  hard = target is exactly 0 or 1.
-__device__ __forceinline__ void focal_elem(float x, float t, const SegArgs& a, float cw, float& loss, float& term) {
-    const float e = __expf(-fabsf(x));
-    const float inv = 1.0f / (1.0f + e);
-    const float p = x >= 0.f ? inv : e * inv;                    // sigmoid(x)
-    const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);          // BCE with logits
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32 (2^x), no range fix-ups
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (log2 x)
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fexp(float x) { return ex2(x * kLog2e); }
+
+// x^g for x >= 0 without branches: 2^(g log2 x); x = 0 gives 0 for g > 0 (g == 0 is patched by the caller)
+__device__ __forceinline__ float pow_pos(float base, float g) { return ex2(g * lg2(base)); }
+
+// sigmoid(x) and log(1 + exp(-|x|)) from one exp (absolute error ~1e-7, far inside the 1e-5 loss tolerance)
+struct Sig { float p, log1pe; };
+__device__ __forceinline__ Sig sigmoid_parts(float x) {
+    const float e = fexp(-fabsf(x));
+    const float s1 = 1.0f + e;
+    const float inv = rcp(s1);
+    Sig s;
+    s.p = x >= 0.f ? inv : e * inv;
+    s.log1pe = lg2(s1) * kLn2;
+    return s;
+}
+
+// Wave-uniform focal configuration, built once per kernel so the per-element math has no branches.
+struct FocalCfg {
+    float gamma, gm1;      // gamma, gamma - 1
+    float a1, a0;          // alpha weight = a1 * t + a0 (a1 = 0, a0 = 1 when alpha is None)
+    float thr, sc;         // reduced focal: f = 1 where pt < thr, base scaled by sc = 1 / (1 - thr); (-inf, 1) otherwise
+    float f_when_g0;       // 1 if gamma == 0 (x^0 = 1 even at x = 0) else NaN marker unused
+    float term_mask;       // multiplier of the focal term of ignored elements (0 when normalised, else 1)
+    bool g0, g1;
+};
+__device__ __forceinline__ FocalCfg focal_cfg(const SegArgs& a) {
+    FocalCfg c;
+    c.gamma = a.gamma; c.gm1 = a.gamma - 1.0f;
+    const bool ha = a.flags & SEG_HAS_ALPHA;
+    c.a1 = ha ? 2.0f * a.alpha - 1.0f : 0.0f;
+    c.a0 = ha ? 1.0f - a.alpha : 1.0f;
+    const bool red = a.flags & SEG_REDUCED;
+    c.thr = red ? a.threshold : -INFINITY;
+    c.sc = red ? 1.0f / (1.0f - a.threshold) : 1.0f;
+    c.f_when_g0 = 1.0f;
+    c.term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
+    c.g0 = a.gamma == 0.0f; c.g1 = a.gamma == 1.0f;
+    return c;
+}
+
+// BCE, focal term f, d f / d x and sigmoid of one element (functional.py:61-94).  G2 = gamma is exactly 2.
+template <bool G2, bool GRAD>
+__device__ __forceinline__ void focal_parts(float x, float t, const FocalCfg& c, float& ce, float& f, float& df, float& p) {
+    const Sig s = sigmoid_parts(x);
+    p = s.p;
+    ce = fmaxf(x, 0.f) - x * t + s.log1pe;                 // BCE with logits
     const float pt = p * t + (1.f - p) * (1.f - t);
-    float f;
-    if (a.flags & SEG_REDUCED) {
-        f = pt < a.threshold ? 1.0f : powf_pos((1.f - pt) / (1.f - a.threshold), a.gamma);
-    } else {
-        f = powf_pos(fmaxf(1.f - pt, 0.f), a.gamma);
+    const float base = fmaxf(1.f - pt, 0.f) * c.sc;
+    const bool below = pt < c.thr;
+    if (G2) f = base * base;
+    else { f = pow_pos(base, c.gamma); f = c.g0 ? 1.0f : f; }
+    f = below ? 1.0f : f;
+    df = 0.f;
+    if (GRAD) {
+        const float dpt = p * (1.f - p) * (2.f * t - 1.f);
+        float pw;                                           // base^(gamma-1)
+        if (G2) pw = base;
+        else { pw = pow_pos(base, c.gm1); pw = c.g1 ? 1.0f : pw; }
+        df = -c.gamma * pw * c.sc * dpt;
+        df = (below || (!G2 && c.g0)) ? 0.f : df;
     }
-    float l = f * ce;
-    if (a.flags & SEG_HAS_ALPHA) l *= a.alpha * t + (1.f - a.alpha) * (1.f - t);
-    l *= cw;
-    loss = l;
-    term = f;
 }
+
+// Same-address device atomics serialise (~12 ns each): 8192 waves adding into ONE double costs more than the whole
+// streaming pass.  So each workgroup reduces its 4 waves in LDS first and adds into one of PTB_SUM_SLOTS copies of the
+// sums (slot = blockIdx % PTB_SUM_SLOTS); the caller adds the slots up (a [64, n] -> [n] sum).
+constexpr int SUM_SLOTS = 64;
+
+__device__ __forceinline__ void block_add2(double v0, double v1, double* dst /* slot base */, int lane, int wave) {
+    __shared__ double red[2][4];
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&dst[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&dst[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// One wave-group: image b, first pixel i0 of this lane, validity; labels of the lane's PIX pixels.
+template <int PIX>
+struct Group {
+    int b;
+    long long i0;
+    bool ok;                // PIX == 4: all-or-nothing (HW % 4 == 0); PIX == 1: the single pixel
+    long long lab[PIX];
+    bool ign[PIX];
+};
 
 template <int PIX>
-__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
+__device__ __forceinline__ Group<PIX> make_group(long long g, long long per_img, int lane, long long HW, const long long* __restrict__ labels,
+                                                 bool has_ignore, long long ignore_label, int C, int* error_flag) {
+    Group<PIX> G;
+    G.b = (int)(g / per_img);
+    G.i0 = (g - (long long)G.b * per_img) * 64 * PIX + (long long)lane * PIX;
+    G.ok = G.i0 < HW;
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) { G.lab[k] = -1; G.ign[k] = false; }
+    if (labels && G.ok) {
+        const long long* lp = labels + (long long)G.b * HW + G.i0;
+        if constexpr (PIX == 4) {
+            const longlong2 a = *reinterpret_cast<const longlong2*>(lp);
+            const longlong2 b2 = *reinterpret_cast<const longlong2*>(lp + 2);
+            G.lab[0] = a.x; G.lab[1] = a.y; G.lab[2] = b2.x; G.lab[3] = b2.y;
+        } else {
+            G.lab[0] = lp[0];
+        }
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            G.ign[k] = has_ignore && G.lab[k] == ignore_label;
+            if (error_flag && !G.ign[k] && (G.lab[k] < 0 || G.lab[k] >= C)) *error_flag = 1;
+        }
+    }
+    return G;
+}
+
+// focal contribution of one element; returns the (weighted) loss, adds the focal term to fsum
+template <bool G2>
+__device__ __forceinline__ float focal_one(float x, float t, bool ig, float cw, const FocalCfg& c, float& fsum) {
+    float ce, f, df, p;
+    focal_parts<G2, false>(x, ig ? 0.f : t, c, ce, f, df, p);
+    float l = f * ce * (c.a1 * t + c.a0) * cw;
+    l = ig ? 0.f : l;
+    f = ig ? f * c.term_mask : f;
+    fsum += f;
+    return l;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// Opaque register barrier: stops the compiler from keeping exp()/sigmoid() results of one pass alive for the next
+// (recomputing is cheaper than 64 extra VGPRs per lane, which would halve occupancy).
+__device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
+
+// Register-resident variant: C <= CREG, the lane issues the loads of ALL class planes first (CREG x 16 B in flight).
+// WHAT = SEG_FOCAL | SEG_STATS bits (compile time), DENSE = dense fp32 targets instead of int64 labels.
+template <int PIX, int CREG, int WHAT, bool DENSE, bool G2>
+__global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) {
+    const FocalCfg cfg = focal_cfg(a);
     extern __shared__ float lds[];  // [4 waves][3][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
     float* wl = lds + wave * 3 * C;
-    if (a.flags & SEG_STATS) for (int k = lane; k < 3 * C; k += 64) wl[k] = 0.f;
+    constexpr bool stats = WHAT & SEG_STATS, focal = WHAT & SEG_FOCAL;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
+    double f_loss = 0.0, f_term = 0.0;
+    float aI[CREG], aP[CREG], aT[CREG];
+#pragma unroll
+    for (int c = 0; c < CREG; ++c) { aI[c] = 0.f; aP[c] = 0.f; aT[c] = 0.f; }
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, DENSE ? nullptr : a.labels, ignf, a.ignore_label, C, a.error_flag);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        int lab[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) lab[k] = (int)G.lab[k];
+        float lsum = 0.f, fsum = 0.f;
+        float xv[CREG][PIX];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) xv[c][k] = 0.f;
+            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], G.ok);
+        }
+        float mx[PIX], inv[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) { mx[k] = 0.f; inv[k] = 0.f; }
+        if (stats && a.prob == PROB_SOFTMAX) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xv[c][k]);
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) {
+                    const float e = fexp(xv[c][k] - m);
+                    d += e;
+                    if (!focal) xv[c][k] = e;          // statistics only: keep exp(x - m), one exp per element
+                }
+                mx[k] = m;
+                inv[k] = rcp(d);
+                if (focal) { opaque(mx[k]); }          // both: recompute exp in the class loop instead of caching 64 values
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            if (c < C) {
+                const float cw = (focal && a.class_weights) ? a.class_weights[c] : 1.0f;
+                float tv[PIX], lv[PIX];
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) { tv[k] = 0.f; lv[k] = 0.f; }
+                if (DENSE) load_px<PIX>(a.dense + base + (long long)c * a.HW, tv, G.ok);
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    if (!G.ok) continue;
+                    const float x = xv[c][k];
+                    float t;
+                    bool ig = G.ign[k];
+                    if (!DENSE) t = lab[k] == c ? 1.f : 0.f;
+                    else { t = tv[k]; if (ignf && t == a.ignore_value) ig = true; }
+                    if (focal) { lv[k] = focal_one<G2>(x, t, ig, cw, cfg, fsum); lsum += lv[k]; }
+                    if (stats) {
+                        float p;
+                        if (a.prob == PROB_SOFTMAX) p = focal ? fexp(x - mx[k]) * inv[k] : x * inv[k];
+                        else if (a.prob == PROB_SIGMOID) p = sigmoid_parts(x).p;
+                        else p = x;
+                        if (ig) { p = 0.f; t = 0.f; }   // p*mask, t*mask (dice.py:85-111)
+                        aI[c] += p * t; aP[c] += p; aT[c] += t;
+                    }
+                }
+                if (focal && (a.flags & SEG_ELEMWISE)) store_px<PIX>(a.elem_out + base + (long long)c * a.HW, lv, G.ok);
+            }
+        }
+        if (focal) { f_loss += (double)lsum; f_term += (double)fsum; }
+    }
+    double* slot = a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C);
+    if (focal) block_add2(f_loss, f_term, slot, lane, wave);
+    if (stats) {
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            if (c < C) {
+                const float sI = wave_sum(aI[c]), sP = wave_sum(aP[c]), sT = wave_sum(aT[c]);
+                if (lane == 0) { wl[c] = sI; wl[C + c] = sP; wl[2 * C + c] = sT; }
+            }
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < 3 * C; k += 256) {
+            const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
+            if (v != 0.0) atomicAdd(&slot[2 + k], v);
+        }
+    }
+}
+
+// Generic variant: any C, class planes are streamed (softmax: one extra pass for the log-sum-exp), everything run time.
+template <int PIX>
+__global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
+    const FocalCfg cfg = focal_cfg(a);
+    extern __shared__ float lds[];  // [4 waves][3][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    float* wl = lds + wave * 3 * C;
+    const bool stats = a.flags & SEG_STATS, focal = a.flags & SEG_FOCAL;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
+    if (stats) for (int k = lane; k < 3 * C; k += 64) wl[k] = 0.f;
     double f_loss = 0.0, f_term = 0.0;
     const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
     const long long groups = per_img * a.B;
-    const bool ign = a.flags & SEG_HAS_IGNORE;
     for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
-        const int b = (int)(g / per_img);
-        const long long i0 = (g % per_img) * 64 * PIX + (long long)lane * PIX;
-        bool valid[PIX];
-        long long lab[PIX];
-        bool ignored[PIX];
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, ignf, a.ignore_label, C, a.error_flag);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        float lsum = 0.f, fsum = 0.f;
+        float mx[PIX], inv[PIX];
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) {
-            valid[k] = i0 + k < a.HW;
-            lab[k] = -1;
-            ignored[k] = false;
-        }
-        if (a.labels) {
-#pragma unroll
-            for (int k = 0; k < PIX; ++k) {
-                if (valid[k]) {
-                    lab[k] = a.labels[(long long)b * a.HW + i0 + k];
-                    ignored[k] = ign && lab[k] == a.ignore_label;
-                    if (!ignored[k] && (lab[k] < 0 || lab[k] >= C)) *a.error_flag = 1;
-                }
-            }
-        }
-        // softmax statistics need the per-pixel log-sum-exp first
-        float mx[PIX], den[PIX];
-        if ((a.flags & SEG_STATS) && a.prob == PROB_SOFTMAX) {
-#pragma unroll
-            for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; den[k] = 0.f; }
+        for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; inv[k] = 0.f; }
+        if (stats && a.prob == PROB_SOFTMAX) {
             for (int c = 0; c < C; ++c) {
                 float xv[PIX];
-                load_px<PIX>(a.logits + ((long long)b * C + c) * a.HW + i0, xv, valid[0]);
+                load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
 #pragma unroll
-                for (int k = 0; k < PIX; ++k) {
-                    if (valid[k]) {
-                        const float x = xv[k];
-                        const float m2 = fmaxf(mx[k], x);
-                        den[k] = den[k] * __expf(mx[k] - m2) + __expf(x - m2);
-                        mx[k] = m2;
-                    }
+                for (int k = 0; k < PIX; ++k) if (G.ok) {
+                    const float m2 = fmaxf(mx[k], xv[k]);
+                    inv[k] = inv[k] * fexp(mx[k] - m2) + fexp(xv[k] - m2);
+                    mx[k] = m2;
                 }
             }
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) inv[k] = rcp(inv[k]);
         }
         for (int c = 0; c < C; ++c) {
-            const long long off = ((long long)b * C + c) * a.HW + i0;
-            float sI = 0.f, sP = 0.f, sT = 0.f;
+            const long long off = base + (long long)c * a.HW;
             const float cw = a.class_weights ? a.class_weights[c] : 1.0f;
             float xv[PIX], tv[PIX], lv[PIX];
-            load_px<PIX>(a.logits + off, xv, valid[0]);
-            if (!a.labels) load_px<PIX>(a.dense + off, tv, valid[0]);
+            float sI = 0.f, sP = 0.f, sT = 0.f;
+            load_px<PIX>(a.logits + off, xv, G.ok);
+            if (!a.labels) load_px<PIX>(a.dense + off, tv, G.ok);
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
                 lv[k] = 0.f;
-                if (!valid[k]) continue;
+                if (!G.ok) continue;
                 const float x = xv[k];
                 float t;
-                bool ig = ignored[k];
-                if (a.labels) {
-                    t = lab[k] == c ? 1.f : 0.f;
-                } else {
-                    t = tv[k];
-                    if (ign && t == a.ignore_value) ig = true;
-                }
-                if (a.flags & SEG_FOCAL) {
-                    float l, f;
-                    focal_elem(x, ig ? 0.f : t, a, cw, l, f);
-                    if (ig) { l = 0.f; if (a.flags & SEG_MASK_FOCAL_TERM) f = 0.f; }
-                    f_loss += (double)l;
-                    f_term += (double)f;
-                    lv[k] = l;
-                }
-                if (a.flags & SEG_STATS) {
+                bool ig = G.ign[k];
+                if (a.labels) t = G.lab[k] == c ? 1.f : 0.f;
+                else { t = tv[k]; if (ignf && t == a.ignore_value) ig = true; }
+                if (focal) { lv[k] = focal_one<false>(x, t, ig, cw, cfg, fsum); lsum += lv[k]; }
+                if (stats) {
                     float p;
-                    if (a.prob == PROB_SOFTMAX) p = __expf(x - mx[k]) / den[k];
-                    else if (a.prob == PROB_SIGMOID) { const float e = __expf(-fabsf(x)); p = (x >= 0.f ? 1.f : e) / (1.f + e); }
+                    if (a.prob == PROB_SOFTMAX) p = fexp(x - mx[k]) * inv[k];
+                    else if (a.prob == PROB_SIGMOID) p = sigmoid_parts(x).p;
                     else p = x;
-                    if (ig) { p = 0.f; t = 0.f; }   // p*mask, t*mask (dice.py:85-111)
+                    if (ig) { p = 0.f; t = 0.f; }
                     sI += p * t; sP += p; sT += t;
                 }
             }
-            if (a.flags & SEG_ELEMWISE) store_px<PIX>(a.elem_out + off, lv, valid[0]);
-            if (a.flags & SEG_STATS) {
+            if (a.flags & SEG_ELEMWISE) store_px<PIX>(a.elem_out + off, lv, G.ok);
+            if (stats) {
                 sI = wave_sum(sI); sP = wave_sum(sP); sT = wave_sum(sT);
                 if (lane == 0) { wl[c] += sI; wl[C + c] += sP; wl[2 * C + c] += sT; }
             }
         }
+        f_loss += (double)lsum;
+        f_term += (double)fsum;
     }
-    // workgroup -> global: fp64 atomics, one per statistic per class per workgroup
-    if (a.flags & SEG_FOCAL) {
-        double l = f_loss, f = f_term;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); f += __shfl_xor(f, o); }
-        if (lane == 0) { atomicAdd(&a.sums[0], l); atomicAdd(&a.sums[1], f); }
-    }
-    if (a.flags & SEG_STATS) {
+    double* slot = a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C);
+    if (focal) block_add2(f_loss, f_term, slot, lane, wave);
+    if (stats) {
         __syncthreads();
         for (int k = threadIdx.x; k < 3 * C; k += 256) {
             const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
-            if (v != 0.0) atomicAdd(&a.sums[2 + k], v);
+            if (v != 0.0) atomicAdd(&slot[2 + k], v);
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------- focal backward
-// d(loss)/dx for the sigmoid focal loss.  coef[0] multiplies dL_j/dx_j, coef[1] multiplies dF_j/dx_j (normalised
-// variant: -sum(L)/N^2), both already scaled by the upstream gradient and the reduction's 1/numel; coef lives on the
-// device so no host synchronisation is needed.  grad_elem (optional) is a per-element upstream gradient (reduction none).
+// ------------------------------------------------------------------------------------------------ focal-only forward
+// No cross-class dependency: class planes are streamed 4 at a time (4 x 16 B in flight per lane, ~100 VGPRs).
+template <int PIX, bool DENSE, bool G2>
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const SegArgs a) {
+    const FocalCfg cfg = focal_cfg(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
+    const bool elem = a.flags & SEG_ELEMWISE;
+    double f_loss = 0.0, f_term = 0.0;
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, DENSE ? nullptr : a.labels, ignf, a.ignore_label, C, a.error_flag);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        float lsum = 0.f, fsum = 0.f;
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            float xv[4][PIX], tv[DENSE ? 4 : 1][PIX];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) xv[u][k] = 0.f;
+                const bool on = G.ok && c0 + u < C;
+                const long long off = base + (long long)(c0 + u) * a.HW;
+                load_px<PIX>(a.logits + off, xv[u], on);
+                if constexpr (DENSE) {
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) tv[u][k] = 0.f;
+                    load_px<PIX>(a.dense + off, tv[u], on);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u;
+                if (c < C) {
+                    const float cw = a.class_weights ? a.class_weights[c] : 1.f;
+                    float lv[PIX];
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) {
+                        lv[k] = 0.f;
+                        if (!G.ok) continue;
+                        float t;
+                        bool ig = G.ign[k];
+                        if constexpr (!DENSE) t = G.lab[k] == c ? 1.f : 0.f;
+                        else { t = tv[u][k]; if (ignf && t == a.ignore_value) ig = true; }
+                        lv[k] = focal_one<G2>(xv[u][k], t, ig, cw, cfg, fsum);
+                        lsum += lv[k];
+                    }
+                    if (elem) store_px<PIX>(a.elem_out + base + (long long)c * a.HW, lv, G.ok);
+                }
+            }
+        }
+        f_loss += (double)lsum;
+        f_term += (double)fsum;
+    }
+    block_add2(f_loss, f_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C), lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------ focal backward
+// grad[i] = coef[0] * (grad_elem ? grad_elem[i] : 1) * dL_i/dx_i + coef[1] * dF_i/dx_i  (coef on the device: no host sync).
+// Same wave-group walk as the forward; class planes are processed 4 at a time so 4+ loads are in flight per lane.
+template <int PIX, bool DENSE, bool GELEM, bool G2>
 __global__ __launch_bounds__(256) void focal_bwd_kernel(const SegArgs a, const float* __restrict__ coef,
                                                         const float* __restrict__ grad_elem, float* __restrict__ grad) {
-    const long long n = (long long)a.B * a.C * a.HW;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const bool ign = a.flags & SEG_HAS_IGNORE;
+    const FocalCfg cfg = focal_cfg(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
     const float k1 = coef[0], k2 = coef[1];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const long long plane = i / a.HW;
-        const int c = (int)(plane % a.C);
-        const long long b = plane / a.C;
-        const float x = a.logits[i];
-        float t;
-        bool ig = false;
-        if (a.labels) {
-            const long long lab = a.labels[b * a.HW + (i - plane * a.HW)];
-            ig = ign && lab == a.ignore_label;
-            t = lab == c ? 1.f : 0.f;
-        } else {
-            t = a.dense[i];
-            ig = ign && t == a.ignore_value;
-        }
-        float gx = 0.f;
-        if (!ig) {
-            const float e = __expf(-fabsf(x));
-            const float inv = 1.0f / (1.0f + e);
-            const float p = x >= 0.f ? inv : e * inv;
-            const float ce = fmaxf(x, 0.f) - x * t + log1pf(e);
-            const float pt = p * t + (1.f - p) * (1.f - t);
-            const float dpt = p * (1.f - p) * (2.f * t - 1.f);
-            float f, df;
-            if (a.flags & SEG_REDUCED) {
-                if (pt < a.threshold) { f = 1.f; df = 0.f; }
-                else {
-                    const float s = 1.f / (1.f - a.threshold);
-                    const float base = (1.f - pt) * s;
-                    f = powf_pos(base, a.gamma);
-                    df = a.gamma == 0.f ? 0.f : -a.gamma * powf_pos(base, a.gamma - 1.f) * s * dpt;
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, DENSE ? nullptr : a.labels, ignf, a.ignore_label, C, nullptr);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        for (int c0 = 0; c0 < C; c0 += 4) {
+            float xv[4][PIX], tv[DENSE ? 4 : 1][PIX], gv[GELEM ? 4 : 1][PIX];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) xv[u][k] = 0.f;
+                const bool on = G.ok && c0 + u < C;
+                const long long off = base + (long long)(c0 + u) * a.HW;
+                load_px<PIX>(a.logits + off, xv[u], on);
+                if constexpr (DENSE) {
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) tv[u][k] = 0.f;
+                    load_px<PIX>(a.dense + off, tv[u], on);
                 }
-            } else {
-                const float base = fmaxf(1.f - pt, 0.f);
-                f = powf_pos(base, a.gamma);
-                df = a.gamma == 0.f ? 0.f : -a.gamma * (a.gamma == 1.f ? 1.f : powf_pos(base, a.gamma - 1.f)) * dpt;
+                if constexpr (GELEM) {
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) gv[u][k] = 0.f;
+                    load_px<PIX>(grad_elem + off, gv[u], on);
+                }
             }
-            float w = a.class_weights ? a.class_weights[c] : 1.f;
-            if (a.flags & SEG_HAS_ALPHA) w *= a.alpha * t + (1.f - a.alpha) * (1.f - t);
-            const float dL = w * (df * ce + f * (p - t));
-            const float g1 = grad_elem ? k1 * grad_elem[i] : k1;
-            gx = g1 * dL + k2 * df;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u;
+                if (c < C) {
+                    const float w0 = a.class_weights ? a.class_weights[c] : 1.f;
+                    float out[PIX];
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) {
+                        out[k] = 0.f;
+                        if (!G.ok) continue;
+                        float t;
+                        bool ig = G.ign[k];
+                        if constexpr (!DENSE) t = G.lab[k] == c ? 1.f : 0.f;
+                        else { t = tv[u][k]; if (ignf && t == a.ignore_value) ig = true; }
+                        if (!ig) {
+                            float ce, f, df, p;
+                            focal_parts<G2, true>(xv[u][k], t, cfg, ce, f, df, p);
+                            const float w = w0 * (cfg.a1 * t + cfg.a0);
+                            const float dL = w * (df * ce + f * (p - t));
+                            float g1 = k1;
+                            if constexpr (GELEM) g1 = k1 * gv[u][k];
+                            out[k] = g1 * dL + k2 * df;
+                        }
+                    }
+                    store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                }
+            }
         }
-        grad[i] = gx;
     }
 }
 
-// ---------------------------------------------------------------------------------------------- region-stat backward
-// Given dLoss/dI_c = gI[c] and dLoss/dP_c = gP[c] (device arrays, from the [C]-sized scalar epilogue), write
-// dLoss/dlogits.  With G_c = (gI[c]*t_c + gP[c]) * mask:  softmax: p_k (G_k - sum_c G_c p_c);  sigmoid: G p (1-p);
-// identity: G.
-template <int PIX>
+// ------------------------------------------------------------------------------------------------ region-stat backward
+// With G_c = (gI[c]*t_c + gP[c]) * mask:  softmax: p_k (G_k - sum_c G_c p_c);  sigmoid: G p (1-p);  identity: G.
+template <int PIX, int CREG, bool DENSE>
 __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, const float* __restrict__ gI,
                                                             const float* __restrict__ gP, float* __restrict__ grad) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int C = a.C;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
     const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
     const long long groups = per_img * a.B;
-    const bool ign = a.flags & SEG_HAS_IGNORE;
     for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
-        const int b = (int)(g / per_img);
-        const long long i0 = (g % per_img) * 64 * PIX + (long long)lane * PIX;
-        bool valid[PIX], ignored[PIX];
-        long long lab[PIX];
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, ignf, a.ignore_label, C, nullptr);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        if constexpr (CREG > 0) {
+            float xv[CREG][PIX], tv[DENSE ? CREG : 1][PIX];
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) {
-            valid[k] = i0 + k < a.HW;
-            lab[k] = -1;
-            ignored[k] = false;
-            if (valid[k] && a.labels) {
-                lab[k] = a.labels[(long long)b * a.HW + i0 + k];
-                ignored[k] = ign && lab[k] == a.ignore_label;
+            for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) xv[c][k] = 0.f;
+                if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], G.ok);
             }
-        }
-        float mx[PIX], den[PIX], dot[PIX];
-        if (a.prob == PROB_SOFTMAX) {
+            if constexpr (DENSE) {
 #pragma unroll
-            for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; den[k] = 0.f; dot[k] = 0.f; }
+                for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) tv[c][k] = 0.f;
+                    if (c < C) load_px<PIX>(a.dense + base + (long long)c * a.HW, tv[c], G.ok);
+                }
+            }
+            float dot[PIX];
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) dot[k] = 0.f;
+            if (a.prob == PROB_SOFTMAX) {
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xv[c][k]);
+                    float d = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CREG; ++c) if (c < C) { xv[c][k] = fexp(xv[c][k] - m); d += xv[c][k]; }
+                    const float inv = rcp(d);
+                    float dd = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CREG; ++c) if (c < C) {
+                        xv[c][k] *= inv;  // p_c
+                        const float t = !DENSE ? (G.lab[k] == c ? 1.f : 0.f) : tv[DENSE ? c : 0][k];
+                        dd += (gI[c] * t + gP[c]) * xv[c][k];
+                    }
+                    dot[k] = dd;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+                if (c < C) {
+                    float out[PIX];
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) {
+                        out[k] = 0.f;
+                        if (!G.ok) continue;
+                        const float t = !DENSE ? (G.lab[k] == c ? 1.f : 0.f) : tv[DENSE ? c : 0][k];
+                        bool ig = G.ign[k];
+                        if (DENSE && ignf && t == a.ignore_value) ig = true;
+                        if (!ig) {
+                            const float Gc = gI[c] * t + gP[c];
+                            if (a.prob == PROB_SOFTMAX) out[k] = xv[c][k] * (Gc - dot[k]);
+                            else if (a.prob == PROB_SIGMOID) { const float p = sigmoid_parts(xv[c][k]).p; out[k] = Gc * p * (1.f - p); }
+                            else out[k] = Gc;
+                        }
+                    }
+                    store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                }
+            }
+        } else {
+            float mx[PIX], inv[PIX], dot[PIX];
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; inv[k] = 0.f; dot[k] = 0.f; }
+            if (a.prob == PROB_SOFTMAX) {
+                for (int c = 0; c < C; ++c) {
+                    float xv[PIX];
+                    load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) if (G.ok) {
+                        const float m2 = fmaxf(mx[k], xv[k]);
+                        inv[k] = inv[k] * fexp(mx[k] - m2) + fexp(xv[k] - m2);
+                        mx[k] = m2;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) inv[k] = rcp(inv[k]);
+                for (int c = 0; c < C; ++c) {
+                    float xv[PIX], tv[PIX];
+                    load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+                    if (!a.labels) load_px<PIX>(a.dense + base + (long long)c * a.HW, tv, G.ok);
+#pragma unroll
+                    for (int k = 0; k < PIX; ++k) if (G.ok && !G.ign[k]) {
+                        const float p = fexp(xv[k] - mx[k]) * inv[k];
+                        const float t = a.labels ? (G.lab[k] == c ? 1.f : 0.f) : tv[k];
+                        dot[k] += (gI[c] * t + gP[c]) * p;
+                    }
+                }
+            }
             for (int c = 0; c < C; ++c) {
-                const float* row = a.logits + ((long long)b * C + c) * a.HW + i0;
+                float xv[PIX], tv[PIX], out[PIX];
+                load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+                if (!a.labels) load_px<PIX>(a.dense + base + (long long)c * a.HW, tv, G.ok);
 #pragma unroll
-                for (int k = 0; k < PIX; ++k) if (valid[k]) {
-                    const float x = row[k];
-                    const float m2 = fmaxf(mx[k], x);
-                    den[k] = den[k] * __expf(mx[k] - m2) + __expf(x - m2);
-                    mx[k] = m2;
+                for (int k = 0; k < PIX; ++k) {
+                    out[k] = 0.f;
+                    if (!G.ok) continue;
+                    const float t = a.labels ? (G.lab[k] == c ? 1.f : 0.f) : tv[k];
+                    bool ig = G.ign[k];
+                    if (!a.labels && ignf && t == a.ignore_value) ig = true;
+                    if (!ig) {
+                        const float Gc = gI[c] * t + gP[c];
+                        if (a.prob == PROB_SOFTMAX) out[k] = fexp(xv[k] - mx[k]) * inv[k] * (Gc - dot[k]);
+                        else if (a.prob == PROB_SIGMOID) { const float p = sigmoid_parts(xv[k]).p; out[k] = Gc * p * (1.f - p); }
+                        else out[k] = Gc;
+                    }
                 }
-            }
-            for (int c = 0; c < C; ++c) {  // dot = sum_c G_c p_c
-                const long long off = ((long long)b * C + c) * a.HW + i0;
-#pragma unroll
-                for (int k = 0; k < PIX; ++k) if (valid[k] && !ignored[k]) {
-                    const float p = __expf(a.logits[off + k] - mx[k]) / den[k];
-                    const float t = a.labels ? (lab[k] == c ? 1.f : 0.f) : a.dense[off + k];
-                    dot[k] += (gI[c] * t + gP[c]) * p;
-                }
-            }
-        }
-        for (int c = 0; c < C; ++c) {
-            const long long off = ((long long)b * C + c) * a.HW + i0;
-#pragma unroll
-            for (int k = 0; k < PIX; ++k) if (valid[k]) {
-                const float x = a.logits[off + k];
-                float t = a.labels ? (lab[k] == c ? 1.f : 0.f) : a.dense[off + k];
-                bool ig = ignored[k];
-                if (!a.labels && ign && t == a.ignore_value) ig = true;
-                float gx = 0.f;
-                if (!ig) {
-                    const float G = gI[c] * t + gP[c];
-                    if (a.prob == PROB_SOFTMAX) { const float p = __expf(x - mx[k]) / den[k]; gx = p * (G - dot[k]); }
-                    else if (a.prob == PROB_SIGMOID) { const float e = __expf(-fabsf(x)); const float p = (x >= 0.f ? 1.f : e) / (1.f + e); gx = G * p * (1.f - p); }
-                    else gx = G;
-                }
-                grad[off + k] = gx;
+                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             }
         }
     }
 }
 
-// ---------------------------------------------------------------------------------------------- softmax focal
+// ------------------------------------------------------------------------------------------------ softmax focal
 // softmax_focal_loss_with_logits (functional.py:110-173): per pixel sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c, masked by
 // label != ignore_index.  sums[0] = sum of pixel losses, sums[1] = sum of ALL focal terms (the reference does not
 // mask them, functional.py:161-164).  pixel_out (optional) receives the unreduced [B, HW] map.
@@ -351,108 +666,164 @@ struct SmfArgs {
     int reduced; float gamma, threshold; long long ignore_label;
 };
 
-__device__ __forceinline__ float smf_term(float pt, const SmfArgs& a) {
-    if (a.reduced) return pt < a.threshold ? 1.0f : powf_pos(pt / a.threshold, a.gamma);
-    return powf_pos(pt, a.gamma);
+// f(pt) = pt^gamma, or the reduced variant (pt/thr)^gamma with f = 1 below thr; branch-free, G2 = gamma is exactly 2
+template <bool G2>
+__device__ __forceinline__ float smf_term(float pt, const SmfArgs& a, float sc, float thr) {
+    const float base = pt * sc;
+    float f = G2 ? base * base : (a.gamma == 0.f ? 1.0f : pow_pos(base, a.gamma));
+    return pt < thr ? 1.0f : f;
+}
+template <bool G2>
+__device__ __forceinline__ float smf_dterm(float pt, float t, const SmfArgs& a, float sc, float thr) {  // d f / d p
+    const float base = pt * sc;
+    float pw = G2 ? base : (a.gamma == 1.f ? 1.0f : pow_pos(base, a.gamma - 1.f));
+    float df = a.gamma * pw * sc;
+    df = (pt < thr || a.gamma == 0.f) ? 0.f : df;
+    return df * (1.f - 2.f * t);
 }
 
-__global__ __launch_bounds__(256) void softmax_focal_fwd_kernel(const SmfArgs a) {
-    const long long n = (long long)a.B * a.HW;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+// MODE 0: forward.  MODE 1: backward,
+//   grad_k = g1 * [p_k (h_k - sum_c h_c p_c) + w_k f_k (sigmoid(x_k) - t_k)] + k2 * p_k (d_k - sum_c d_c p_c),
+//   h_c = w_c * bce_c * df_c/dp_c, d_c = df_c/dp_c; g1 = coef[0] (x per-pixel upstream gradient), k2 = coef[1].
+template <int PIX, int CREG, int MODE, bool G2>
+__global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, const float* __restrict__ coef,
+                                                            const float* __restrict__ grad_pix, float* __restrict__ grad) {
+    const float thr = a.reduced ? a.threshold : -INFINITY, sc = a.reduced ? 1.0f / a.threshold : 1.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
     double s_loss = 0.0, s_term = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const long long b = i / a.HW, px = i - b * a.HW;
-        const long long lab = a.labels[i];
-        const bool ig = lab == a.ignore_label;
-        if (!ig && (lab < 0 || lab >= a.C)) *a.error_flag = 1;
-        const long long tgt = ig ? 0 : lab;   // masked_fill(target, ignore, 0), functional.py:139
-        const float* row = a.logits + b * a.C * a.HW + px;
-        float mx = -INFINITY, den = 0.f;
-        for (int c = 0; c < a.C; ++c) {
-            const float x = row[(long long)c * a.HW];
-            const float m2 = fmaxf(mx, x);
-            den = den * __expf(mx - m2) + __expf(x - m2);
-            mx = m2;
-        }
-        float loss = 0.f, term = 0.f;
-        for (int c = 0; c < a.C; ++c) {
-            const float x = row[(long long)c * a.HW];
-            const float p = __expf(x - mx) / den;
-            const float t = c == tgt ? 1.f : 0.f;
-            const float pt = (1.f - t) * p + t * (1.f - p);
-            const float f = smf_term(pt, a);
-            const float bce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
-            loss += f * bce * (a.class_weights ? a.class_weights[c] : 1.f);
-            term += f;
-        }
-        if (ig) loss = 0.f;
-        if (a.pixel_out) a.pixel_out[i] = loss;
-        s_loss += (double)loss;
-        s_term += (double)term;
-    }
+    const float k1 = MODE ? coef[0] : 0.f, k2 = MODE ? coef[1] : 0.f;
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, true, a.ignore_label, C, MODE ? nullptr : a.error_flag);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        float mx[PIX], inv[PIX], loss[PIX], dh[PIX], dd[PIX], gp[PIX];
+        float tsum = 0.f;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s_loss += __shfl_xor(s_loss, o); s_term += __shfl_xor(s_term, o); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&a.sums[0], s_loss); atomicAdd(&a.sums[1], s_term); }
-}
-
-// grad_k = k1 * g_i * [ p_k (h_k - sum_c h_c p_c) + w_k f_k (sigmoid(x_k) - t_k) ] + k2 * p_k (d_k - sum_c d_c p_c)
-// with h_c = w_c * bce_c * df_c/dp_c, d_c = df_c/dp_c; k1 (x per-pixel upstream g_i, optional) and k2 as in focal_bwd.
-__global__ __launch_bounds__(256) void softmax_focal_bwd_kernel(const SmfArgs a, const float* __restrict__ coef,
-                                                                const float* __restrict__ grad_pix, float* __restrict__ grad) {
-    const long long n = (long long)a.B * a.HW;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    const float k1 = coef[0], k2 = coef[1];
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const long long b = i / a.HW, px = i - b * a.HW;
-        const long long lab = a.labels[i];
-        const bool ig = lab == a.ignore_label;
-        const long long tgt = ig ? 0 : lab;
-        const float* row = a.logits + b * a.C * a.HW + px;
-        float* grow = grad + b * a.C * a.HW + px;
-        float mx = -INFINITY, den = 0.f;
-        for (int c = 0; c < a.C; ++c) {
-            const float x = row[(long long)c * a.HW];
-            const float m2 = fmaxf(mx, x);
-            den = den * __expf(mx - m2) + __expf(x - m2);
-            mx = m2;
+        for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; inv[k] = 0.f; loss[k] = 0.f; dh[k] = 0.f; dd[k] = 0.f; gp[k] = 1.f; }
+        if (MODE && grad_pix) load_px<PIX>(grad_pix + (long long)G.b * a.HW + G.i0, gp, G.ok);
+        constexpr int NR = CREG > 0 ? CREG : 1;
+        float xr[NR][PIX];
+        if constexpr (CREG > 0) {
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) xr[c][k] = 0.f;
+                if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xr[c], G.ok);
+            }
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xr[c][k]);
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) d += fexp(xr[c][k] - m);
+                mx[k] = m; inv[k] = rcp(d);
+                opaque(mx[k]);  // recompute exp(x - m) per pass instead of keeping 64 values alive
+            }
+        } else {
+            for (int c = 0; c < C; ++c) {
+                float xv[PIX];
+                load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) if (G.ok) {
+                    const float m2 = fmaxf(mx[k], xv[k]);
+                    inv[k] = inv[k] * fexp(mx[k] - m2) + fexp(xv[k] - m2);
+                    mx[k] = m2;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) inv[k] = rcp(inv[k]);
         }
-        const float g1 = ig ? 0.f : (grad_pix ? k1 * grad_pix[i] : k1);
-        float dot_h = 0.f, dot_d = 0.f;
-        for (int c = 0; c < a.C; ++c) {
-            const float x = row[(long long)c * a.HW];
-            const float p = __expf(x - mx) / den;
-            const float t = c == tgt ? 1.f : 0.f;
-            const float pt = (1.f - t) * p + t * (1.f - p);
-            float df;  // d f / d p
-            if (a.reduced) df = pt < a.threshold ? 0.f : a.gamma * powf_pos(pt / a.threshold, a.gamma - 1.f) / a.threshold * (1.f - 2.f * t);
-            else df = a.gamma == 0.f ? 0.f : a.gamma * (a.gamma == 1.f ? 1.f : powf_pos(pt, a.gamma - 1.f)) * (1.f - 2.f * t);
-            const float bce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+        // pass 1: losses (forward) or the two softmax-Jacobian dot products (backward)
+        auto pass1 = [&](int c, const float (&xv)[PIX]) {
             const float w = a.class_weights ? a.class_weights[c] : 1.f;
-            dot_h += w * bce * df * p;
-            dot_d += df * p;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                if (!G.ok) continue;
+                const long long tgt = G.ign[k] ? 0 : G.lab[k];   // masked_fill(target, ignore, 0), functional.py:139
+                const float x = xv[k];
+                const float p = fexp(x - mx[k]) * inv[k];
+                const float t = c == tgt ? 1.f : 0.f;
+                const float pt = (1.f - t) * p + t * (1.f - p);
+                const float bce = fmaxf(x, 0.f) - x * t + sigmoid_parts(x).log1pe;
+                if (MODE == 0) {
+                    const float f = smf_term<G2>(pt, a, sc, thr);
+                    loss[k] += f * bce * w;
+                    tsum += f;
+                } else {
+                    const float df = smf_dterm<G2>(pt, t, a, sc, thr);
+                    dh[k] += w * bce * df * p;
+                    dd[k] += df * p;
+                }
+            }
+        };
+        if constexpr (CREG > 0) {
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) if (c < C) pass1(c, xr[c]);
+        } else {
+            for (int c = 0; c < C; ++c) {
+                float xv[PIX];
+                load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+                pass1(c, xv);
+            }
         }
-        for (int c = 0; c < a.C; ++c) {
-            const float x = row[(long long)c * a.HW];
-            const float p = __expf(x - mx) / den;
-            const float t = c == tgt ? 1.f : 0.f;
-            const float pt = (1.f - t) * p + t * (1.f - p);
-            float df;
-            if (a.reduced) df = pt < a.threshold ? 0.f : a.gamma * powf_pos(pt / a.threshold, a.gamma - 1.f) / a.threshold * (1.f - 2.f * t);
-            else df = a.gamma == 0.f ? 0.f : a.gamma * (a.gamma == 1.f ? 1.f : powf_pos(pt, a.gamma - 1.f)) * (1.f - 2.f * t);
-            const float f = smf_term(pt, a);
-            const float e = __expf(-fabsf(x));
-            const float sg = (x >= 0.f ? 1.f : e) / (1.f + e);
-            const float bce = fmaxf(x, 0.f) - x * t + log1pf(e);
-            const float w = a.class_weights ? a.class_weights[c] : 1.f;
-            const float gl = p * (w * bce * df - dot_h) + w * f * (sg - t);
-            const float gf = p * (df - dot_d);
-            grow[(long long)c * a.HW] = g1 * gl + k2 * gf;
+        if (MODE == 0) {
+            float ls = 0.f;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                if (G.ign[k] || !G.ok) loss[k] = 0.f;
+                ls += loss[k];
+            }
+            s_loss += (double)ls;
+            s_term += (double)tsum;
+            if (a.pixel_out) store_px<PIX>(a.pixel_out + (long long)G.b * a.HW + G.i0, loss, G.ok);
+        } else {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) { opaque(mx[k]); opaque(inv[k]); }  // pass 2 recomputes p, bce, df
+            auto pass2 = [&](int c, const float (&xv)[PIX]) {
+                const float w = a.class_weights ? a.class_weights[c] : 1.f;
+                float out[PIX];
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    out[k] = 0.f;
+                    if (!G.ok) continue;
+                    const long long tgt = G.ign[k] ? 0 : G.lab[k];
+                    const float x = xv[k];
+                    const float p = fexp(x - mx[k]) * inv[k];
+                    const float t = c == tgt ? 1.f : 0.f;
+                    const float pt = (1.f - t) * p + t * (1.f - p);
+                    const Sig sg = sigmoid_parts(x);
+                    const float bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
+                    const float df = smf_dterm<G2>(pt, t, a, sc, thr);
+                    const float f = smf_term<G2>(pt, a, sc, thr);
+                    const float g1 = G.ign[k] ? 0.f : (grad_pix ? k1 * gp[k] : k1);
+                    const float gl = p * (w * bce * df - dh[k]) + w * f * (sg.p - t);
+                    const float gf = p * (df - dd[k]);
+                    out[k] = g1 * gl + k2 * gf;
+                }
+                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+            };
+            if constexpr (CREG > 0) {
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) pass2(c, xr[c]);
+            } else {
+                for (int c = 0; c < C; ++c) {
+                    float xv[PIX];
+                    load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
+                    pass2(c, xv);
+                }
+            }
         }
     }
+    if (MODE == 0) block_add2(s_loss, s_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * 2, lane, wave);
 }
 
-static int grid_for(long long work_items, int per_block) {
-    const long long want = (work_items + per_block - 1) / per_block;
+// ------------------------------------------------------------------------------------------------ host side
+static int grid_for_groups(long long groups) {
+    const long long want = (groups + 3) / 4;
     const long long cap = 256LL * 8;
     return (int)(want < 1 ? 1 : (want < cap ? want : cap));
 }
@@ -466,6 +837,12 @@ static int fill_seg(SegArgs& a, const float* logits, const int64_t* labels, cons
     a.B = B; a.C = C; a.HW = HW; a.flags = flags; a.prob = prob;
     a.gamma = gamma; a.alpha = alpha; a.threshold = threshold; a.ignore_label = ignore_label; a.ignore_value = ignore_value;
     return PTB_OK;
+}
+
+static bool vec_ok(int64_t HW, std::initializer_list<const void*> ptrs) {
+    if (HW % 4 != 0 || g_force_scalar) return false;
+    for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+    return true;
 }
 
 }  // namespace ptb
@@ -484,12 +861,27 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     if ((long long)B * HW == 0) return PTB_OK;
     const size_t shmem = (size_t)4 * 3 * C * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
-    if (HW % 4 == 0 && aligned16(logits) && (!dense || aligned16(dense)) && (!elem_out || aligned16(elem_out))) {
-        const long long groups = (HW + 255) / 256 * B;
-        hipLaunchKernelGGL(seg_loss_fwd_kernel<4>, dim3(grid_for(groups, 4)), dim3(256), shmem, s, a);
+    const int what = flags & (SEG_FOCAL | SEG_STATS);
+    if (!what) return PTB_EINVAL;
+    const bool g2 = gamma == 2.0f;
+    const bool vec = vec_ok(HW, {logits, dense, elem_out, labels});
+    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B) : grid_for_groups((HW + 63) / 64 * B)), block(256);
+    if (what == SEG_FOCAL) {
+#define PTB_FF(P, D) do { if (g2) hipLaunchKernelGGL((focal_fwd_kernel<P, D, true>), grid, block, 0, s, a); \
+                          else hipLaunchKernelGGL((focal_fwd_kernel<P, D, false>), grid, block, 0, s, a); } while (0)
+        if (vec) { if (labels) PTB_FF(4, false); else PTB_FF(4, true); }
+        else { if (labels) PTB_FF(1, false); else PTB_FF(1, true); }
+#undef PTB_FF
+    } else if (vec && C <= 16) {
+#define PTB_FWD(W, D) do { if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, true>), grid, block, shmem, s, a); \
+                           else hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, false>), grid, block, shmem, s, a); } while (0)
+        if (labels) { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, false, true>), grid, block, shmem, s, a); else PTB_FWD(3, false); }
+        else { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, true, true>), grid, block, shmem, s, a); else PTB_FWD(3, true); }
+#undef PTB_FWD
+    } else if (vec) {
+        hipLaunchKernelGGL((seg_loss_fwd_kernel<4>), grid, block, shmem, s, a);
     } else {
-        const long long groups = (HW + 63) / 64 * B;
-        hipLaunchKernelGGL(seg_loss_fwd_kernel<1>, dim3(grid_for(groups, 4)), dim3(256), shmem, s, a);
+        hipLaunchKernelGGL((seg_loss_fwd_kernel<1>), grid, block, shmem, s, a);
     }
     return check_launch();
 }
@@ -501,9 +893,21 @@ extern "C" int ptb_focal_bwd(const float* logits, const int64_t* labels, const f
     SegArgs a{};
     if (int rc = fill_seg(a, logits, labels, dense, class_weights, B, C, HW, flags, PROB_SIGMOID, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
     if (!coef || !grad) return PTB_EINVAL;
-    const long long n = (long long)B * C * HW;
-    if (n == 0) return PTB_OK;
-    hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(n, 256 * 4)), dim3(256), 0, (hipStream_t)stream, a, coef, grad_elem, grad);
+    if ((long long)B * HW == 0) return PTB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = vec_ok(HW, {logits, dense, grad_elem, grad, labels});
+    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B) : grid_for_groups((HW + 63) / 64 * B)), block(256);
+    const bool g2 = gamma == 2.0f;
+#define PTB_FBWD(P, D, G) do { if (g2) hipLaunchKernelGGL((focal_bwd_kernel<P, D, G, true>), grid, block, 0, s, a, coef, grad_elem, grad); \
+                               else hipLaunchKernelGGL((focal_bwd_kernel<P, D, G, false>), grid, block, 0, s, a, coef, grad_elem, grad); } while (0)
+    if (vec) {
+        if (labels) { if (grad_elem) PTB_FBWD(4, false, true); else PTB_FBWD(4, false, false); }
+        else { if (grad_elem) PTB_FBWD(4, true, true); else PTB_FBWD(4, true, false); }
+    } else {
+        if (labels) { if (grad_elem) PTB_FBWD(1, false, true); else PTB_FBWD(1, false, false); }
+        else { if (grad_elem) PTB_FBWD(1, true, true); else PTB_FBWD(1, true, false); }
+    }
+#undef PTB_FBWD
     return check_launch();
 }
 
@@ -515,12 +919,25 @@ extern "C" int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, con
     if (!gI || !gP || !grad) return PTB_EINVAL;
     if ((long long)B * HW == 0) return PTB_OK;
     hipStream_t s = (hipStream_t)stream;
-    if (HW % 4 == 0) {
-        const long long groups = (HW + 255) / 256 * B;
-        hipLaunchKernelGGL(seg_stats_bwd_kernel<4>, dim3(grid_for(groups, 4)), dim3(256), 0, s, a, gI, gP, grad);
+    if (vec_ok(HW, {logits, dense, grad, labels})) {
+        const int grid = grid_for_groups((HW + 255) / 256 * B);
+        if (C <= 16 && labels) hipLaunchKernelGGL((seg_stats_bwd_kernel<4, 16, false>), dim3(grid), dim3(256), 0, s, a, gI, gP, grad);
+        else hipLaunchKernelGGL((seg_stats_bwd_kernel<4, 0, false>), dim3(grid), dim3(256), 0, s, a, gI, gP, grad);
     } else {
-        const long long groups = (HW + 63) / 64 * B;
-        hipLaunchKernelGGL(seg_stats_bwd_kernel<1>, dim3(grid_for(groups, 4)), dim3(256), 0, s, a, gI, gP, grad);
+        hipLaunchKernelGGL((seg_stats_bwd_kernel<1, 0, false>), dim3(grid_for_groups((HW + 63) / 64 * B)), dim3(256), 0, s, a, gI, gP, grad);
+    }
+    return check_launch();
+}
+
+template <int MODE>
+static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix, float* grad, hipStream_t s) {
+    if (vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
+        const int grid = grid_for_groups((a.HW + 255) / 256 * a.B);
+        if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
+        else if (a.C <= 16) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
+        else hipLaunchKernelGGL((softmax_focal_kernel<4, 0, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
+    } else {
+        hipLaunchKernelGGL((softmax_focal_kernel<1, 0, MODE, false>), dim3(grid_for_groups((a.HW + 63) / 64 * a.B)), dim3(256), 0, s, a, coef, grad_pix, grad);
     }
     return check_launch();
 }
@@ -531,8 +948,7 @@ extern "C" int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels,
     if (!logits || !labels || !sums || !error_flag || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
     if ((long long)B * HW == 0) return PTB_OK;
     SmfArgs a{logits, (const long long*)labels, class_weights, sums, pixel_out, error_flag, B, C, HW, reduced, gamma, threshold, ignore_label};
-    hipLaunchKernelGGL(softmax_focal_fwd_kernel, dim3(grid_for((long long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch();
+    return launch_smf<0>(a, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const float* class_weights, const float* coef,
@@ -541,6 +957,5 @@ extern "C" int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels,
     if (!logits || !labels || !coef || !grad || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
     if ((long long)B * HW == 0) return PTB_OK;
     SmfArgs a{logits, (const long long*)labels, class_weights, nullptr, nullptr, nullptr, B, C, HW, reduced, gamma, threshold, ignore_label};
-    hipLaunchKernelGGL(softmax_focal_bwd_kernel, dim3(grid_for((long long)B * HW, 256)), dim3(256), 0, (hipStream_t)stream, a, coef, grad_pix, grad);
-    return check_launch();
+    return launch_smf<1>(a, coef, grad_pix, grad, (hipStream_t)stream);
 }

@@ -12,6 +12,7 @@ from .. import _native as N
 
 SEG_FOCAL, SEG_STATS, SEG_HAS_IGNORE, SEG_HAS_ALPHA, SEG_REDUCED, SEG_MASK_FOCAL_TERM, SEG_ELEMWISE = 1, 2, 4, 8, 16, 32, 64
 PROB_SOFTMAX, PROB_SIGMOID, PROB_IDENTITY = 0, 1, 2
+SUM_SLOTS = 64  # PTB_SUM_SLOTS: the kernels spread their fp64 atomics over this many copies of the sums
 
 _CHECK_LABELS = os.environ.get("PTB_SKIP_LABEL_CHECK", "0") != "1"
 
@@ -41,7 +42,7 @@ class SigmoidFocalSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, dense, class_weights, flags, gamma, alpha, threshold, ignore_label, ignore_value):
         B, C, HW = x.shape
-        sums = torch.zeros(2, dtype=torch.float64, device=x.device)
+        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
         flag = torch.zeros(1, dtype=torch.int32, device=x.device)
         elem = torch.empty_like(x) if flags & SEG_ELEMWISE else None
         lib = N.load()
@@ -60,7 +61,7 @@ class SigmoidFocalSums(torch.autograd.Function):
             ctx.has_elem = False
         else:
             ctx.has_elem = True
-        return sums, elem
+        return sums.sum(dim=0)[:2], elem
 
     @staticmethod
     def backward(ctx, g_sums, g_elem):
@@ -90,7 +91,7 @@ class RegionStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, dense, prob, has_ignore, ignore_label, ignore_value):
         B, C, HW = x.shape
-        sums = torch.zeros(2 + 3 * C, dtype=torch.float64, device=x.device)
+        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
         flag = torch.zeros(1, dtype=torch.int32, device=x.device)
         flags = SEG_STATS | (SEG_HAS_IGNORE if has_ignore else 0)
         lib = N.load()
@@ -103,7 +104,7 @@ class RegionStats(torch.autograd.Function):
             check_labels(flag)
         ctx.save_for_backward(x, labels, dense)
         ctx.cfg = (flags, prob, ignore_label, ignore_value)
-        return sums[2:].view(3, C)
+        return sums.sum(dim=0)[2:].view(3, C)
 
     @staticmethod
     def backward(ctx, g):
@@ -127,7 +128,7 @@ class SoftmaxFocalSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, class_weights, reduced, gamma, threshold, ignore_label, want_map):
         B, C, HW = x.shape
-        sums = torch.zeros(2, dtype=torch.float64, device=x.device)
+        sums = torch.zeros((SUM_SLOTS, 2), dtype=torch.float64, device=x.device)
         flag = torch.zeros(1, dtype=torch.int32, device=x.device)
         pix = torch.empty((B, HW), dtype=torch.float32, device=x.device) if want_map else None
         lib = N.load()
@@ -140,7 +141,7 @@ class SoftmaxFocalSums(torch.autograd.Function):
         ctx.save_for_backward(x, labels, class_weights)
         ctx.cfg = (reduced, gamma, threshold, ignore_label)
         ctx.has_map = want_map
-        return sums, (pix if want_map else x.new_empty(0))
+        return sums.sum(dim=0), (pix if want_map else x.new_empty(0))
 
     @staticmethod
     def backward(ctx, g_sums, g_pix):

@@ -38,9 +38,8 @@ class _LovaszSegments(torch.autograd.Function):
         gpix = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
         if n > 0:
             lib = N.load()
-            keys = torch.empty((2, n), dtype=torch.float32, device=dev)
+            keys = torch.empty((2, n), dtype=torch.int64, device=dev)
             vals = torch.empty((2, n), dtype=torch.int32, device=dev)
-            offsets = (torch.arange(S + 1, device=dev, dtype=torch.int64) * P).to(torch.int32)
             chunk = torch.empty(S * ((P + _CHUNK - 1) // _CHUNK), dtype=torch.int32, device=dev)
             with N.on_device(dev):
                 tb = lib.ptb_lovasz_temp_bytes(P, S)
@@ -49,7 +48,7 @@ class _LovaszSegments(torch.autograd.Function):
                 temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
                 rc = lib.ptb_lovasz_fwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
                                         1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
-                                        vals[0].data_ptr(), vals[1].data_ptr(), offsets.data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
+                                        vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
                                         seg_loss.data_ptr(), gpix.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
             N.bump()
             N.check(rc, "ptb_lovasz_fwd")
