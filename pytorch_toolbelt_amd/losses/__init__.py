@@ -2,5 +2,6 @@
 from .dice import *  # noqa: F401,F403
 from .focal import *  # noqa: F401,F403
 from .functional import *  # noqa: F401,F403
+from .fused import *  # noqa: F401,F403
 from .jaccard import *  # noqa: F401,F403
 from .lovasz import *  # noqa: F401,F403

@@ -168,3 +168,48 @@ def as_bchw(t):
     if t.dim() >= 2:
         return t.reshape(t.shape[0], t.shape[1], -1)
     return t.reshape(1, 1, -1)
+
+
+class FusedSegSums(torch.autograd.Function):
+    """One forward pass over logits + labels for BOTH the sigmoid focal sums [2] and the region statistics [3, C]
+    (BASELINE configs[3]: BinaryFocal + SoftDice + SoftJaccard fused).  Backward = focal and region gradient kernels."""
+
+    @staticmethod
+    def forward(ctx, x, labels, dense, class_weights, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value):
+        B, C, HW = x.shape
+        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), sums.data_ptr(), None,
+                                      flag.data_ptr(), B, C, HW, flags | SEG_FOCAL | SEG_STATS, prob, gamma, alpha, threshold,
+                                      ignore_label, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_seg_loss_fwd")
+        if labels is not None:
+            check_labels(flag)
+        ctx.save_for_backward(x, labels, dense, class_weights)
+        ctx.cfg = (flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)
+        total = sums.sum(dim=0)
+        return total[:2], total[2:].view(3, C)
+
+    @staticmethod
+    def backward(ctx, g_focal, g_stats):
+        x, labels, dense, class_weights = ctx.saved_tensors
+        flags, prob, gamma, alpha, threshold, ignore_label, ignore_value = ctx.cfg
+        B, C, HW = x.shape
+        lib = N.load()
+        grad = torch.empty_like(x)
+        grad2 = torch.empty_like(x)
+        coef = g_focal.to(torch.float32).contiguous()
+        gs = g_stats.to(torch.float32).contiguous()
+        with N.on_device(x.device):
+            rc = lib.ptb_focal_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), coef.data_ptr(), None, grad.data_ptr(),
+                                   B, C, HW, flags, gamma, alpha, threshold, ignore_label, ignore_value, N.stream_ptr(x.device))
+            N.check(rc, "ptb_focal_bwd")
+            sflags = flags & SEG_HAS_IGNORE
+            rc = lib.ptb_seg_stats_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), gs[0].data_ptr(), gs[1].data_ptr(), grad2.data_ptr(),
+                                       B, C, HW, SEG_STATS | sflags, prob, ignore_label, ignore_value, N.stream_ptr(x.device))
+            N.check(rc, "ptb_seg_stats_bwd")
+        N.bump()
+        return grad.add_(grad2), None, None, None, None, None, None, None, None, None, None

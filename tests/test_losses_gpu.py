@@ -347,3 +347,24 @@ def test_cfg4_full_size_properties(dev):
     full = L.BinaryFocalLoss(reduction="sum")(x, labels)
     halves = L.BinaryFocalLoss(reduction="sum")(x[:16], labels[:16]) + L.BinaryFocalLoss(reduction="sum")(x[16:], labels[16:])
     assert float(full) == pytest.approx(float(halves), rel=1e-6)
+
+
+def test_fused_focal_dice_jaccard(dev):
+    """BASELINE configs[3]: the fused loss equals the sum of the three modules (value and gradient), and the oracle."""
+    L = _L()
+    logits, labels = _cfg4_like(B=3, C=16, H=64, W=80)
+    xl, ll = logits.to(dev), labels.to(dev)
+    x1 = xl.clone().requires_grad_(True)
+    fused = L.FocalDiceJaccardLoss("multiclass", focal_weight=1.0, dice_weight=0.5, jaccard_weight=2.0, alpha=0.25)(x1, ll)
+    x2 = xl.clone().requires_grad_(True)
+    parts = L.BinaryFocalLoss(alpha=0.25)(x2, ll) + 0.5 * L.DiceLoss("multiclass")(x2, ll) + 2.0 * L.JaccardLoss("multiclass")(x2, ll)
+    torch.testing.assert_close(fused, parts, rtol=1e-6, atol=1e-6)
+    fused.backward()
+    parts.backward()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=1e-5, atol=1e-8)
+    want = LO.binary_focal_loss(logits.numpy(), labels.numpy(), alpha=0.25) + 0.5 * LO.dice_loss(logits.numpy(), labels.numpy(), "multiclass") + 2.0 * LO.jaccard_loss(logits.numpy(), labels.numpy(), "multiclass")
+    assert float(fused) == pytest.approx(float(want), abs=1e-5)
+    ml = (torch.rand((3, 16, 64, 80)) < 0.3).float()
+    f2 = L.FocalDiceJaccardLoss("multilabel")(xl, ml.to(dev))
+    w2 = LO.focal_loss_with_logits(logits.numpy(), ml.numpy(), alpha=None) + LO.dice_loss(logits.numpy(), ml.numpy(), "multilabel") + LO.jaccard_loss(logits.numpy(), ml.numpy(), "multilabel")
+    assert float(f2) == pytest.approx(float(w2), abs=1e-5)

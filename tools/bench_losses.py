@@ -55,6 +55,7 @@ def main():
         "DiceLoss(multiclass)": L.DiceLoss("multiclass"),
         "JaccardLoss(multiclass)": L.JaccardLoss("multiclass"),
         "CrossEntropyFocalLoss": L.CrossEntropyFocalLoss(),
+        "FocalDiceJaccardLoss (fused)": L.FocalDiceJaccardLoss("multiclass"),
     }
     print(f"{'loss':34s} {'fwd ms':>8s} {'fwd GB/s':>9s} {'fwd+bwd ms':>11s} {'GB/s':>8s}")
     for name, crit in crits.items():
