@@ -28,6 +28,8 @@ extern "C" {
 #define PTB_EUNSUPPORTED (-2) /* legal for the reference but not implemented natively (caller must raise) */
 #define PTB_ELAUNCH (-3)     /* HIP launch failed; see ptb_last_hip_error() */
 #define PTB_EBOUNDS (-4)     /* tile rectangle leaves the accumulator */
+#define PTB_EFRESH (-5)      /* first-touch bitmap cannot be honoured for this batch: zero-fill the fresh blocks, then call
+                                again with fresh = NULL */
 
 typedef void* ptb_stream_t; /* hipStream_t */
 
@@ -62,9 +64,15 @@ int ptb_set_tunable(int key, int value);
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------
  * for b in 0..B-1 (in order):  image[:, y:y+th, x:x+tw] += tiles[b] * weight ;  norm[0, y:y+th, x:x+tw] += weight
  * image [C,H,W], norm [H,W], weight [th,tw], tiles [B,C,th,tw]; xs/ys HOST int64[B] (top-left corner of each tile).
- * Overlapping tiles of one batch are handled race-free and in batch order: bit-identical to the sequential loop. */
+ * Overlapping tiles of one batch are handled race-free and in batch order: bit-identical to the sequential loop.
+ * First-touch stores (optional): `fresh` is a HOST bitmap owned by the caller, one byte per accumulator block of
+ * 64 columns x fresh_rows rows (row-major, ceil(H/fresh_rows) x ceil(W/64)); 1 = the block was never written since the
+ * accumulators were (logically) zeroed.  Cells made only of fresh blocks are written with plain stores -- the
+ * accumulators then never need a memset and are not read on first touch -- and the library clears the bits it wrote.
+ * NULL = plain read-modify-write everywhere.  PTB_EFRESH: see above. */
 int ptb_tile_accumulate(float* image, float* norm, const float* weight, const float* tiles, const int64_t* xs,
-                        const int64_t* ys, int B, int C, int th, int tw, int H, int W, ptb_stream_t stream);
+                        const int64_t* ys, int B, int C, int th, int tw, int H, int W, uint8_t* fresh, int fresh_rows,
+                        ptb_stream_t stream);
 
 /* ---- TileMerger.merge / merge_ (inference/tiles.py:345-350): out[c] = image[c] / norm (no eps clamp) -----------
  * out may alias image (merge_). */
@@ -91,10 +99,10 @@ int ptb_view_transform(const float* in, float* out, int V, const int* views, int
 
 /* ---- fused: de-augment + reduce + TileMerger.integrate_batch (tta.py:442-467 feeding tiles.py:321-339) ----------
  * image[:, y:y+th, x:x+tw] += reduce_k view_k(in[k*B+b]) * weight ; norm += weight.  The reduced tile never goes
- * to HBM.  Same tensors as ptb_deaug_reduce (H=th, W=tw) and ptb_tile_accumulate. */
+ * to HBM.  Same tensors as ptb_deaug_reduce (H=th, W=tw) and ptb_tile_accumulate (incl. the first-touch bitmap). */
 int ptb_deaug_accumulate(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                          int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw, int H,
-                         int W, ptb_stream_t stream);
+                         int W, uint8_t* fresh, int fresh_rows, ptb_stream_t stream);
 
 /* ---- bilinear resize of ms_image_augment / ms_image_deaugment (inference/tta.py:599-621, 645-689) ----------------
  * = torch.nn.functional.interpolate(in, size=(hout,wout), mode="bilinear", align_corners=...) on `planes` = B*C maps. */

@@ -17,6 +17,7 @@ IDENT, TRANSPOSE, FLIPUD, ROT90_CW, FLIPLR, ROT90_CCW, ROT180, ANTITRANSPOSE = r
 
 RED_SUM, RED_MEAN, RED_GMEAN, RED_HMEAN, RED_HARMONIC1P, RED_LOGODD, RED_LOG1P = range(7)
 
+EFRESH = -5
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed", -4: "tile rectangle outside the accumulator"}
 
 _c_int = ctypes.c_int
@@ -31,7 +32,7 @@ SIGNATURES = {
     "ptb_version": (_c_int, []),
     "ptb_last_hip_error": (ctypes.c_char_p, []),
     "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
-    "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),
     "ptb_merge_div_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp]),
     "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
@@ -45,7 +46,7 @@ SIGNATURES = {
     "ptb_lovasz_temp_bytes": (_c_i64, [_c_i64, _c_int]),
     "ptb_lovasz_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
     "ptb_lovasz_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _vp]),
-    "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
 }
 
 _lib = None

@@ -45,6 +45,7 @@ struct Cell {
     int ox, oy, w, h;     // rectangle in accumulator coordinates
     int chunk_end;        // exclusive prefix of chunk counts (cells sorted heavy-first)
     int ntiles;
+    int fresh;            // 1: no element of this cell was ever written -> store instead of read-modify-write
     int tile[MAX_COVER];  // group-local tile indices, ascending batch order
 };
 
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
     float* ip = a.dst + (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
     float* np = a.norm + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), nacc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) {
+    if (act && !cell.fresh) {  // first touch: the accumulator is logically zero, nothing to read (and it was never memset)
         acc = *reinterpret_cast<const float4*>(ip);
         if (c == 0) nacc = *reinterpret_cast<const float4*>(np);
     }
@@ -363,8 +364,8 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
     if (tx >= cw) return;
     for (int r = ty; r < ch; r += 4) {
         const long long off = (long long)(ay + r) * a.dst_row_stride + ax + tx;
-        float acc = a.dst[(long long)c * a.dst_chan_stride + off];
-        float nacc = c == 0 ? a.norm[off] : 0.f;
+        float acc = cell.fresh ? 0.f : a.dst[(long long)c * a.dst_chan_stride + off];
+        float nacc = (c == 0 && !cell.fresh) ? a.norm[off] : 0.f;
         for (int e = 0; e < cell.ntiles; ++e) {
             const int gt = cell.tile[e];
             const int lx = ax - g.tile_x[gt] + tx, ly = ay - g.tile_y[gt] + r;
@@ -382,15 +383,80 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
 // ------------------------------------------------------------------------------------------------ host: cells
 // Split the tile rectangles of one launch group into disjoint cells (arrangement of their edges), each with the
 // ascending list of covering tiles.  Returns false when the group needs more than MAX_CELLS / MAX_COVER.
-static bool decompose(const int* xs, const int* ys, const int* ids, int n, int tw, int th, int chunk_rows, CellArgs& out,
-                      int& ncells, int& total_chunks) {
-    if (n > MAX_GROUP) return false;
+// Host-side freshness bitmap of the accumulator (owned by the caller): one byte per block of 64 columns x `rows` rows,
+// 1 = never written since the last reset.  A cell whose blocks are all fresh is written with plain stores.
+struct Fresh {
+    uint8_t* map;  // may be null: everything is read-modify-write
+    int rows;      // block rows (must equal the chunk rows of the launch)
+    int H, W;      // accumulator size
+    int nbx() const { return (W + CW - 1) / CW; }
+    int nby() const { return (H + rows - 1) / rows; }
+};
+
+enum { DECOMP_OK = 0, DECOMP_SPLIT = 1, DECOMP_NEEDS_ZERO = 2 };
+
+// Tag cells with their freshness, splitting a cell into row runs of uniform freshness.  Cells that are not aligned to
+// the block grid, or block rows that are partly fresh, cannot use first-touch stores: if they touch any fresh block the
+// caller has to zero-fill first (DECOMP_NEEDS_ZERO).
+static int apply_freshness(std::vector<Cell>& cells, const Fresh& fr) {
+    if (!fr.map) return DECOMP_OK;
+    std::vector<Cell> out;
+    const int nbx = fr.nbx();
+    for (const Cell& c : cells) {
+        const bool aligned = c.ox % CW == 0 && c.oy % fr.rows == 0 && (c.w % CW == 0 || c.ox + c.w == fr.W) &&
+                             (c.h % fr.rows == 0 || c.oy + c.h == fr.H);
+        const int bx0 = c.ox / CW, bx1 = (c.ox + c.w - 1) / CW, by0 = c.oy / fr.rows, by1 = (c.oy + c.h - 1) / fr.rows;
+        if (!aligned) {
+            for (int by = by0; by <= by1; ++by)
+                for (int bx = bx0; bx <= bx1; ++bx)
+                    if (fr.map[by * nbx + bx]) return DECOMP_NEEDS_ZERO;
+            out.push_back(c);
+            continue;
+        }
+        int run_start = by0, run_state = -1;
+        for (int by = by0; by <= by1 + 1; ++by) {
+            int state = -1;
+            if (by <= by1) {
+                int nf = 0;
+                for (int bx = bx0; bx <= bx1; ++bx) nf += fr.map[by * nbx + bx] ? 1 : 0;
+                if (nf != 0 && nf != bx1 - bx0 + 1) return DECOMP_NEEDS_ZERO;
+                state = nf ? 1 : 0;
+            }
+            if (state != run_state) {
+                if (run_state >= 0) {
+                    Cell piece = c;
+                    piece.oy = run_start * fr.rows;
+                    const int y_end = std::min(by * fr.rows, c.oy + c.h);
+                    piece.h = y_end - piece.oy;
+                    piece.fresh = run_state;
+                    out.push_back(piece);
+                }
+                run_start = by;
+                run_state = state;
+            }
+        }
+    }
+    cells.swap(out);
+    return DECOMP_OK;
+}
+
+static void mark_written(const std::vector<Cell>& cells, const Fresh& fr) {
+    if (!fr.map) return;
+    const int nbx = fr.nbx();
+    for (const Cell& c : cells)
+        for (int by = c.oy / fr.rows; by <= (c.oy + c.h - 1) / fr.rows; ++by)
+            for (int bx = c.ox / CW; bx <= (c.ox + c.w - 1) / CW; ++bx) fr.map[by * nbx + bx] = 0;
+}
+
+static int decompose(const int* xs, const int* ys, const int* ids, int n, int tw, int th, int chunk_rows, const Fresh& fr,
+                     CellArgs& out, int& ncells, int& total_chunks, std::vector<Cell>& cells) {
+    if (n > MAX_GROUP) return DECOMP_SPLIT;
     std::vector<int> ye;
     ye.reserve(2 * n);
     for (int t = 0; t < n; ++t) { ye.push_back(ys[t]); ye.push_back(ys[t] + th); }
     std::sort(ye.begin(), ye.end());
     ye.erase(std::unique(ye.begin(), ye.end()), ye.end());
-    std::vector<Cell> cells;
+    cells.clear();
     std::vector<int> active, xe;
     for (size_t yi = 0; yi + 1 < ye.size(); ++yi) {
         const int y0 = ye[yi], y1 = ye[yi + 1];
@@ -406,7 +472,7 @@ static bool decompose(const int* xs, const int* ys, const int* ids, int n, int t
             Cell c{};
             for (int t : active) {
                 if (xs[t] <= x0 && x0 < xs[t] + tw) {
-                    if (c.ntiles == MAX_COVER) return false;
+                    if (c.ntiles == MAX_COVER) return DECOMP_SPLIT;
                     c.tile[c.ntiles++] = t;
                 }
             }
@@ -425,7 +491,8 @@ static bool decompose(const int* xs, const int* ys, const int* ids, int n, int t
             if (!merged) cells.push_back(c);
         }
     }
-    if ((int)cells.size() > MAX_CELLS) return false;
+    if (int rc = apply_freshness(cells, fr)) return rc;
+    if ((int)cells.size() > MAX_CELLS) return DECOMP_SPLIT;
     std::stable_sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) { return a.ntiles > b.ntiles; });
     int run = 0;
     for (size_t i = 0; i < cells.size(); ++i) {
@@ -436,7 +503,7 @@ static bool decompose(const int* xs, const int* ys, const int* ids, int n, int t
     for (int t = 0; t < n; ++t) { out.tile_x[t] = xs[t]; out.tile_y[t] = ys[t]; out.tile_id[t] = ids[t]; }
     ncells = (int)cells.size();
     total_chunks = run;
-    return true;
+    return DECOMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
@@ -557,21 +624,23 @@ static int run_plain(ViewArgs& a, int ntiles_out, int mode, hipStream_t s) {
 }
 
 // Accumulate a run of tiles [lo, hi) of the batch; splits recursively until each launch group decomposes.
-static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, bool fast, int ch, hipStream_t s) {
+static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, bool fast, int ch, const Fresh& fr, hipStream_t s) {
     if (lo >= hi) return PTB_OK;
     CellArgs g;
     int ids[MAX_GROUP];
+    std::vector<Cell> cells;
     const int n = hi - lo;
-    bool ok = n <= MAX_GROUP;
-    if (ok) {
+    int st = n <= MAX_GROUP ? DECOMP_OK : DECOMP_SPLIT;
+    if (st == DECOMP_OK) {
         for (int t = 0; t < n; ++t) ids[t] = lo + t;
-        ok = decompose(xs + lo, ys + lo, ids, n, a.W, a.H, ch, g, a.ncells, a.total_chunks);
+        st = decompose(xs + lo, ys + lo, ids, n, a.W, a.H, ch, fr, g, a.ncells, a.total_chunks, cells);
     }
-    if (!ok) {
+    if (st == DECOMP_NEEDS_ZERO) return PTB_EFRESH;
+    if (st == DECOMP_SPLIT) {
         if (n == 1) return PTB_EUNSUPPORTED;  // cannot happen: one tile is one cell
         const int mid = lo + n / 2;
-        const int rc = run_accum(a, xs, ys, lo, mid, fast, ch, s);
-        return rc ? rc : run_accum(a, xs, ys, mid, hi, fast, ch, s);
+        const int rc = run_accum(a, xs, ys, lo, mid, fast, ch, fr, s);
+        return rc ? rc : run_accum(a, xs, ys, mid, hi, fast, ch, fr, s);
     }
     const long long blocks = (long long)a.total_chunks * a.C;
     if (blocks <= 0) return PTB_OK;
@@ -585,12 +654,38 @@ static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, 
     } else {
         launch_accum_ch<16>(a, g, (int)blocks, s, nonlinear);
     }
-    return check_launch();
+    const int rc = check_launch();
+    if (rc == PTB_OK) mark_written(cells, fr);
+    return rc;
+}
+
+// Dry run of run_accum's grouping on a scratch bitmap: PTB_EFRESH if any launch group would need a zero-fill.
+static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int th, int ch, Fresh& fr) {
+    if (lo >= hi) return PTB_OK;
+    CellArgs g;
+    int ids[MAX_GROUP];
+    std::vector<Cell> cells;
+    const int n = hi - lo;
+    int nc = 0, tc = 0;
+    int st = n <= MAX_GROUP ? DECOMP_OK : DECOMP_SPLIT;
+    if (st == DECOMP_OK) {
+        for (int t = 0; t < n; ++t) ids[t] = lo + t;
+        st = decompose(xs + lo, ys + lo, ids, n, tw, th, ch, fr, g, nc, tc, cells);
+    }
+    if (st == DECOMP_NEEDS_ZERO) return PTB_EFRESH;
+    if (st == DECOMP_SPLIT) {
+        if (n == 1) return PTB_EUNSUPPORTED;
+        const int mid = lo + n / 2;
+        const int rc = probe_accum(xs, ys, lo, mid, tw, th, ch, fr);
+        return rc ? rc : probe_accum(xs, ys, mid, hi, tw, th, ch, fr);
+    }
+    mark_written(cells, fr);
+    return PTB_OK;
 }
 
 static int accumulate_impl(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                            int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th, int tw, int H, int W,
-                           hipStream_t s) {
+                           uint8_t* fresh, int fresh_rows, hipStream_t s) {
     if (!image || !norm || !weight || !in || !xs64 || !ys64) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
@@ -625,7 +720,18 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
         for (int b = 0; b < B && fast; ++b) if ((ys[b] - ys[0]) % 4) fast = false;
     }
     const int ch = fast ? g_chunk_rows : 64;
-    return run_accum(a, xs.data(), ys.data(), 0, B, fast, ch, s);
+    Fresh fr{fresh, fresh_rows, H, W};
+    if (fresh) {
+        if (fresh_rows < 1) return PTB_EINVAL;
+        if (fresh_rows != ch) return PTB_EFRESH;  // bitmap granularity differs from this launch's chunk rows
+        // a batch that is split into several launches may have been partly applied when a later part needs zeroing:
+        // decide on a scratch copy of the bitmap first
+        std::vector<uint8_t> probe(fresh, fresh + (size_t)fr.nbx() * fr.nby());
+        Fresh pf{probe.data(), fresh_rows, H, W};
+        const int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, ch, pf);
+        if (rc) return rc;
+    }
+    return run_accum(a, xs.data(), ys.data(), 0, B, fast, ch, fr, s);
 }
 
 }  // namespace ptb
@@ -633,15 +739,18 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
 using namespace ptb;
 
 extern "C" int ptb_tile_accumulate(float* image, float* norm, const float* weight, const float* tiles, const int64_t* xs,
-                                   const int64_t* ys, int B, int C, int th, int tw, int H, int W, ptb_stream_t stream) {
+                                   const int64_t* ys, int B, int C, int th, int tw, int H, int W, uint8_t* fresh, int fresh_rows,
+                                   ptb_stream_t stream) {
     const int ident = PTB_VIEW_IDENT;
-    return accumulate_impl(image, norm, weight, tiles, 1, &ident, PTB_RED_SUM, xs, ys, B, C, th, tw, H, W, (hipStream_t)stream);
+    return accumulate_impl(image, norm, weight, tiles, 1, &ident, PTB_RED_SUM, xs, ys, B, C, th, tw, H, W, fresh, fresh_rows,
+                           (hipStream_t)stream);
 }
 
 extern "C" int ptb_deaug_accumulate(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                                     int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw, int H,
-                                    int W, ptb_stream_t stream) {
-    return accumulate_impl(image, norm, weight, in, V, views, reduction, xs, ys, B, C, th, tw, H, W, (hipStream_t)stream);
+                                    int W, uint8_t* fresh, int fresh_rows, ptb_stream_t stream) {
+    return accumulate_impl(image, norm, weight, in, V, views, reduction, xs, ys, B, C, th, tw, H, W, fresh, fresh_rows,
+                           (hipStream_t)stream);
 }
 
 extern "C" int ptb_deaug_reduce(const float* in, float* out, int V, const int* views, int reduction, int B, int C, int H, int W,

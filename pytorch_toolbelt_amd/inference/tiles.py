@@ -19,6 +19,7 @@ __all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "compute_pyramid_patch
 # inference/tiles.py:161,182,220).  Only constant padding is pinned by the oracle; the others map to the numpy
 # mode with OpenCV's documented semantics.
 BORDER_CONSTANT = 0
+_FRESH_ROWS = 32  # rows of a first-touch block = default chunk rows of the view kernels (64 columns wide)
 _NP_PAD_MODE = {1: "edge", 2: "symmetric", 3: "wrap", 4: "reflect"}
 
 
@@ -202,7 +203,7 @@ class TileMerger:
     """Blend tile predictions into a full-size map that lives in HBM (reference inference/tiles.py:290-350).
 
     ``image`` ``[C, H', W']``, ``norm_mask`` ``[1, H', W']`` and ``weight`` ``[1, h, w]`` are public fp32 tensors on the
-    GPU.  ``integrate_batch`` is one HIP launch per batch: overlapping tiles are accumulated race-free in batch order,
+    GPU (``image`` / ``norm_mask`` are properties: blocks no kernel has written yet are zero-filled on first read).  ``integrate_batch`` is one HIP launch per batch: overlapping tiles are accumulated race-free in batch order,
     bit-identical to the reference's sequential ``+=`` loop.  ``integrate_batch_deaugment`` additionally fuses the TTA
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
@@ -221,19 +222,79 @@ class TileMerger:
         self.image_width = image_shape[1]
         self.channels = channels
         self.weight = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=dtype).contiguous()
-        self.image = torch.zeros((channels, self.image_height, self.image_width), device=device, dtype=dtype)
-        self.norm_mask = torch.zeros((1, self.image_height, self.image_width), device=device, dtype=dtype)
+        # First-touch accumulators: allocated uninitialised; `_fresh` (host, one byte per 64x32 block) records which
+        # blocks were never written.  The kernels STORE into fresh blocks instead of read-modify-write, so no memset and
+        # no read of zeros is ever paid; reading `image` / `norm_mask` zero-fills whatever is still fresh first.
+        self._image = torch.empty((channels, self.image_height, self.image_width), device=device, dtype=dtype)
+        self._norm = torch.empty((1, self.image_height, self.image_width), device=device, dtype=dtype)
+        self._fresh = np.ones(((self.image_height + _FRESH_ROWS - 1) // _FRESH_ROWS, (self.image_width + 63) // 64), dtype=np.uint8)
+
+    # ------------------------------------------------------------------ first-touch state
+    @property
+    def image(self) -> torch.Tensor:
+        """``[C, H', W']`` accumulator (zeros where nothing was integrated yet)."""
+        self._materialize()
+        return self._image
+
+    @image.setter
+    def image(self, value: torch.Tensor):
+        self._materialize()
+        self._image = value
+
+    @property
+    def norm_mask(self) -> torch.Tensor:
+        """``[1, H', W']`` sum of the blending windows."""
+        self._materialize()
+        return self._norm
+
+    @norm_mask.setter
+    def norm_mask(self, value: torch.Tensor):
+        self._materialize()
+        self._norm = value
+
+    def reset(self):
+        """Start a new image: the accumulators become logically zero again (no memset: O(1) on the host)."""
+        self._fresh[:] = 1
+
+    def _materialize(self):
+        """Zero-fill the blocks no kernel has written yet, so the tensors read as plain zero-initialised accumulators."""
+        fresh = self._fresh
+        if not fresh.any():
+            return
+        if fresh.all():
+            self._image.zero_()
+            self._norm.zero_()
+        else:
+            rows = np.nonzero(fresh.any(axis=1))[0]
+            i = 0
+            while i < len(rows):  # group consecutive block rows with identical column patterns into rectangles
+                j = i
+                while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and np.array_equal(fresh[rows[j + 1]], fresh[rows[i]]):
+                    j += 1
+                y0, y1 = int(rows[i]) * _FRESH_ROWS, min(self.image_height, (int(rows[j]) + 1) * _FRESH_ROWS)
+                cols = np.nonzero(fresh[rows[i]])[0]
+                k = 0
+                while k < len(cols):
+                    m = k
+                    while m + 1 < len(cols) and cols[m + 1] == cols[m] + 1:
+                        m += 1
+                    x0, x1 = int(cols[k]) * 64, min(self.image_width, (int(cols[m]) + 1) * 64)
+                    self._image[:, y0:y1, x0:x1] = 0
+                    self._norm[:, y0:y1, x0:x1] = 0
+                    k = m + 1
+                i = j + 1
+        fresh[:] = 0
 
     # ------------------------------------------------------------------ helpers
     def _prep(self, batch):
-        if batch.device != self.image.device:
-            batch = batch.to(device=self.image.device)
-        if batch.dtype != self.image.dtype:
-            batch = batch.type_as(self.image)
+        if batch.device != self._image.device:
+            batch = batch.to(device=self._image.device)
+        if batch.dtype != self._image.dtype:
+            batch = batch.type_as(self._image)
         return batch.detach().contiguous()
 
     def _check_state(self):
-        for t in (self.image, self.norm_mask, self.weight):
+        for t in (self._image, self._norm, self.weight):
             N.require_device(t, "TileMerger")
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("TileMerger accumulators must be contiguous float32 tensors")
@@ -253,17 +314,24 @@ class TileMerger:
         xs = N.i64_array(coords[:, 0].tolist())
         ys = N.i64_array(coords[:, 1].tolist())
         lib = N.load()
-        dev = self.image.device
-        with N.on_device(dev):
+        dev = self._image.device
+        varr = N.int_array(views) if views is not None else None
+
+        def launch(fresh_ptr):
             if views is None:
-                rc = lib.ptb_tile_accumulate(
-                    self.image.data_ptr(), self.norm_mask.data_ptr(), self.weight.data_ptr(), batch.data_ptr(), xs, ys,
-                    B, self.channels, th, tw, self.image_height, self.image_width, N.stream_ptr(dev))
-            else:
-                rc = lib.ptb_deaug_accumulate(
-                    self.image.data_ptr(), self.norm_mask.data_ptr(), self.weight.data_ptr(), batch.data_ptr(),
-                    n_views, N.int_array(views), reduction, xs, ys, B, self.channels, th, tw,
-                    self.image_height, self.image_width, N.stream_ptr(dev))
+                return lib.ptb_tile_accumulate(
+                    self._image.data_ptr(), self._norm.data_ptr(), self.weight.data_ptr(), batch.data_ptr(), xs, ys,
+                    B, self.channels, th, tw, self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
+            return lib.ptb_deaug_accumulate(
+                self._image.data_ptr(), self._norm.data_ptr(), self.weight.data_ptr(), batch.data_ptr(),
+                n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
+                self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
+
+        with N.on_device(dev):
+            rc = launch(self._fresh.ctypes.data if self._fresh.any() else None)
+            if rc == N.EFRESH:  # geometry not block aligned (or a non-default chunk size): zero-fill once, then plain RMW
+                self._materialize()
+                rc = launch(None)
         N.bump()
         N.check(rc, "TileMerger.integrate_batch")
 
@@ -296,14 +364,15 @@ class TileMerger:
 
     @property
     def device(self) -> torch.device:
-        return self.image.device
+        return self._image.device
 
     def _merge_into(self, out):
+        self._materialize()
         self._check_state()
         lib = N.load()
-        dev = self.image.device
+        dev = self._image.device
         with N.on_device(dev):
-            rc = lib.ptb_merge_div(self.image.data_ptr(), self.norm_mask.data_ptr(), out.data_ptr(), self.channels,
+            rc = lib.ptb_merge_div(self._image.data_ptr(), self._norm.data_ptr(), out.data_ptr(), self.channels,
                                    self.image_height * self.image_width, N.stream_ptr(dev))
         N.bump()
         N.check(rc, "TileMerger.merge")
@@ -311,11 +380,12 @@ class TileMerger:
 
     def merge(self) -> torch.Tensor:
         """``image / norm_mask`` as a new tensor (no eps clamp: never-covered pixels are NaN, like the reference)."""
-        return self._merge_into(torch.empty_like(self.image))
+        return self._merge_into(torch.empty_like(self._image))
 
     def merge_(self) -> torch.Tensor:
         """In-place ``image /= norm_mask``; returns ``image``."""
-        return self._merge_into(self.image)
+        self._materialize()
+        return self._merge_into(self._image)
 
 
 class CudaTileMerger(TileMerger):

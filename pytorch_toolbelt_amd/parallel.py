@@ -167,8 +167,11 @@ class ShardedTileMerger:
         self._exchanged = False
         if self.local is None:
             return
-        self.local.image.zero_()
-        self.local.norm_mask.zero_()
+        if hasattr(self.local, "reset"):
+            self.local.reset()          # first-touch accumulators: no memset
+        else:
+            self.local.image.zero_()
+            self.local.norm_mask.zero_()
         self._remaining = {y: self._tiles_per_y[y] for y in self._send_rows_y}
 
     def _shift(self, crop_coords):
@@ -208,12 +211,17 @@ class ShardedTileMerger:
         dist = self.dist
         ops = []
         for buf, (dst, r0, r1) in zip(self._send_buf, self.sends):
-            buf.copy_(self.local.image[:, r0 - self.top:r1 - self.top])  # pack the strided strip
+            # pack the strided strip; its rows are complete (all tiles of the boundary row are in), so read the raw
+            # accumulator and leave the still-untouched interior rows in their first-touch state
+            buf.copy_(self._raw_image()[:, r0 - self.top:r1 - self.top])
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
         for buf, (src, _r0, _r1) in zip(self._recv_buf, self.recvs):
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
         if ops:
             self._pending = dist.batch_isend_irecv(ops)
+
+    def _raw_image(self):
+        return getattr(self.local, "_image", None) if hasattr(self.local, "_image") else self.local.image
 
     def _global_rank(self, r):
         if self.group is None:
@@ -233,7 +241,7 @@ class ShardedTileMerger:
             self._start_exchange()
         self._wait_pending()
         o0, o1 = self.owned_rows
-        img = self.local.image[:, o0 - self.top:o1 - self.top]
+        img = self.local.image[:, o0 - self.top:o1 - self.top]  # (property: zero-fills anything never written)
         out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
         extra, extra_rows = None, 0
         if self.recvs:

@@ -250,3 +250,86 @@ def test_full_size_cfg2_properties(dev):
     assert float(((m3 - m2) - (m2 - m1)).abs().max()) <= 2e-5
     crop = s.crop_to_orignal_size(np.moveaxis(m1.cpu().numpy(), 0, -1))
     assert crop.shape == (5000, 5000, C) and np.isfinite(crop).all()
+
+
+class _SoloDist:
+    """Single-rank stand-in for torch.distributed: exercises the sharded merger's HIP paths (band accumulators, local
+    normaliser, strided band merge) on one GPU; the exchange itself is covered over gloo in tests/test_sharded_cpu.py."""
+
+    def __init__(self, rank=0, world=1):
+        self.rank, self.world = rank, world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_merger_bands_on_gpu(world, dev):
+    """Every rank of a `world`-way tile-row sharding is played in turn on one GPU; strips are handed over by hand.
+    The assembled result must equal the single-device TileMerger (same HIP kernels, different accumulation order)."""
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger, tile_row_partition
+
+    geom = TO.slicer_geometry((700, 520), (128, 128), (64, 64))
+    w = TO.pyramid_window(128, 128)[0]
+    crops, C = geom["crops"], 3
+    n = len(crops)
+    y = torch.randn((8, n, C, 128, 128), device=dev)
+    single = _merger(geom["target_shape"], C, w, dev)
+    for b0 in range(0, n, 8):
+        idx = list(range(b0, min(n, b0 + 8)))
+        single.integrate_batch_deaugment(y[:, idx].reshape(-1, C, 128, 128), crops[idx], group="d4")
+    want = single.merge()
+
+    ranks = []
+    for r in range(world):
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_SoloDist(r, world))
+        m._start_exchange = lambda: None  # no process group here: strips are moved below
+        mine = tile_row_partition(crops, world)[r]
+        m.reset()
+        for b0 in range(0, len(mine), 8):
+            idx = mine[b0:b0 + 8]
+            m.integrate_batch_deaugment(y[:, idx].reshape(-1, C, 128, 128), crops[idx], group="d4")
+        ranks.append(m)
+    full = torch.empty_like(want)
+    for r, m in enumerate(ranks):
+        for buf, (src, r0, r1) in zip(m._recv_buf, m.recvs):  # what rank `src` would have sent
+            s = ranks[src]
+            buf.copy_(s.local.image[:, r0 - s.top:r1 - s.top])
+        m._exchanged = True
+        band = m.merge()
+        o0, o1 = m.owned_rows
+        full[:, o0:o1] = band
+    torch.testing.assert_close(full, want, rtol=0, atol=2e-6)
+
+
+def test_first_touch_reset_and_reuse(dev):
+    """`reset()` re-arms the first-touch bitmap: a reused merger must give the same bits as a new one, stale data from
+    the previous image must never leak (also where the second image covers less), and mid-way reads see zeros."""
+    geom = TO.slicer_geometry((512, 768), (256, 256), (128, 128))
+    w = TO.pyramid_window(256, 256)[0]
+    crops = geom["crops"]
+    n = len(crops)
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal((n, 2, 256, 256)).astype(np.float32)
+    b = rng.standard_normal((n, 2, 256, 256)).astype(np.float32)
+    m = _merger(geom["target_shape"], 2, w, dev)
+    m.integrate_batch(torch.from_numpy(a).to(dev), crops)
+    first = m.merge().cpu().numpy()
+    assert np.array_equal(first, TO.merger_merge(_oracle_merge(geom, 2, w, a, n)))
+    m.reset()
+    half = n // 2
+    m.integrate_batch(torch.from_numpy(b[:half]).to(dev), crops[:half])
+    st = TO.merger_new(geom["target_shape"], 2, w)
+    TO.merger_integrate(st, b[:half], crops[:half])
+    # mid-way read: untouched blocks read as zeros (not the previous image), touched ones hold the partial sums
+    assert np.array_equal(m.image.cpu().numpy(), st["image"]) and np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"])
+    m.integrate_batch(torch.from_numpy(b[half:]).to(dev), crops[half:])
+    TO.merger_integrate(st, b[half:], crops[half:])
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    # the attributes stay assignable like plain tensors
+    m.image = torch.ones_like(m.image)
+    m.norm_mask = torch.full_like(m.norm_mask, 2.0)
+    assert float(m.merge().max()) == 0.5
