@@ -1,0 +1,3 @@
+from .functional import *  # noqa: F401,F403
+from .tiles import *  # noqa: F401,F403
+from .tta import *  # noqa: F401,F403

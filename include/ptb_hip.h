@@ -109,6 +109,12 @@ int ptb_deaug_accumulate(float* image, float* norm, const float* weight, const f
 int ptb_resize_bilinear(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout,
                         int align_corners, ptb_stream_t stream);
 
+/* ---- fused ms_image_deaugment (inference/tta.py:645-689): out = reduce_s resize(inputs[s] -> (hout,wout)) -----------
+ * inputs: HOST array of n (<= 8) device pointers, map s is [planes, hs[s], ws[s]]; maps that already have the output
+ * size are taken as they are (the reference skips F.interpolate for offset 0).  The resized maps never go to HBM. */
+int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, float* out, int64_t planes, int hout,
+                        int wout, int align_corners, int reduction, ptb_stream_t stream);
+
 /* ================================= segmentation losses (pytorch_toolbelt.losses) =================================
  * logits [B, C, HW] fp32; targets are either labels int64 [B, HW] (one-hot is formed on the fly, never materialised)
  * or dense fp32 [B, C, HW]; exactly one of `labels` / `dense` is non-NULL.  Scalars are accumulated in fp64.

@@ -60,6 +60,94 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused multiscale
+// ms_image_deaugment (tta.py:645-689) in ONE pass: every scale's prediction is sampled at the output grid (4-tap
+// bilinear, or a straight 16 B load when the sizes already match) and reduced in registers -- the reference resizes
+// each map to full size (write + read), stacks them (another copy) and reduces in further passes.
+constexpr int MS_MAX = 8;
+struct MsArgs {
+    const float* in[MS_MAX];
+    int h[MS_MAX], w[MS_MAX];
+    float sh[MS_MAX], sw[MS_MAX];
+    int n;           // number of scales
+    int planes, hout, wout, align_corners, op;
+};
+
+constexpr float kMsEps = 1e-6f;
+constexpr float kMsOneMinusEps = (float)(1.0 - 1e-6);
+
+__device__ __forceinline__ float ms_pre(float x, int op) {
+    switch (op) {
+        case PTB_RED_GMEAN: return logf(x);
+        case PTB_RED_HMEAN: return 1.0f / (x < kMsEps ? kMsEps : x);
+        case PTB_RED_HARMONIC1P: return 1.0f / (x + 1.0f);
+        case PTB_RED_LOGODD: { const float p = x < kMsEps ? kMsEps : (x > kMsOneMinusEps ? kMsOneMinusEps : x); return logf(p / (1.0f - p)); }
+        case PTB_RED_LOG1P: return log1pf(x);
+        default: return x;
+    }
+}
+__device__ __forceinline__ float ms_post(float s, int op, float n) {
+    if (op == PTB_RED_SUM) return s;
+    const float m = s / n;
+    switch (op) {
+        case PTB_RED_GMEAN: return expf(m);
+        case PTB_RED_HMEAN: return 1.0f / (m < kMsEps ? kMsEps : m);
+        case PTB_RED_HARMONIC1P: return 1.0f / m - 1.0f;
+        case PTB_RED_LOGODD: { const float e = expf(m); return e / (1.0f + e); }
+        case PTB_RED_LOG1P: return expf(m) - 1.0f;
+        default: return m;
+    }
+}
+
+__global__ __launch_bounds__(256) void ms_reduce_kernel(const MsArgs a, float* __restrict__ out) {
+    const int wq = (a.wout + 3) / 4;
+    const long long total = (long long)a.planes * a.hout * wq;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool vec_out = (a.wout & 3) == 0;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int q = (int)(idx % wq);
+        const long long rest = idx / wq;
+        const int oy = (int)(rest % a.hout);
+        const long long p = rest / a.hout;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < a.n; ++s) {
+            float v[4];
+            const int hin = a.h[s], win = a.w[s];
+            if (hin == a.hout && win == a.wout) {  // same size: F.interpolate is skipped by the reference (offset 0)
+                const float* r = a.in[s] + (p * hin + oy) * (long long)win + 4 * q;
+                if (vec_out) { const float4 t = *reinterpret_cast<const float4*>(r); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+                else { for (int m = 0; m < 4; ++m) v[m] = 4 * q + m < a.wout ? r[m] : 1.f; }
+            } else {
+                const Taps ty = taps(oy, a.sh[s], hin, a.align_corners);
+                const float* r0 = a.in[s] + (p * hin + ty.i0) * (long long)win;
+                const float* r1 = a.in[s] + (p * hin + ty.i1) * (long long)win;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int ox = 4 * q + m;
+                    v[m] = 1.f;
+                    if (ox < a.wout) {
+                        const Taps tx = taps(ox, a.sw[s], win, a.align_corners);
+                        const float top = tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1];
+                        const float bot = tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1];
+                        v[m] = ty.l0 * top + ty.l1 * bot;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float t = a.op >= PTB_RED_GMEAN ? ms_pre(v[m], a.op) : v[m];
+                acc[m] = s ? acc[m] + t : t;
+            }
+        }
+        float res[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) res[m] = ms_post(acc[m], a.op, (float)a.n);
+        float* o = out + (p * a.hout + oy) * (long long)a.wout + 4 * q;
+        if (vec_out) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+        else for (int m = 0; m < 4; ++m) if (4 * q + m < a.wout) o[m] = res[m];
+    }
+}
+
 }  // namespace ptb
 
 using namespace ptb;
@@ -82,5 +170,32 @@ extern "C" int ptb_resize_bilinear(const float* in, float* out, int64_t planes, 
     const int blocks = (int)(want < 256 * 32 ? want : 256 * 32);
     hipLaunchKernelGGL(resize_bilinear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, (int)planes, hin, win,
                        hout, wout, sh, sw, align_corners);
+    return check_launch();
+}
+
+extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, float* out, int64_t planes,
+                                   int hout, int wout, int align_corners, int reduction, ptb_stream_t stream) {
+    if (!inputs || !hs || !ws || !out || n < 1 || n > MS_MAX || planes < 0 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    MsArgs a{};
+    for (int s = 0; s < n; ++s) {
+        if (!inputs[s] || hs[s] < 1 || ws[s] < 1) return PTB_EINVAL;
+        a.in[s] = inputs[s]; a.h[s] = hs[s]; a.w[s] = ws[s];
+        if (hs[s] == hout && ws[s] == wout && (wout % 4 == 0) && !aligned16(inputs[s])) return PTB_EUNSUPPORTED;
+        if (align_corners) {
+            a.sh[s] = hout > 1 ? (float)(hs[s] - 1) / (float)(hout - 1) : 0.f;
+            a.sw[s] = wout > 1 ? (float)(ws[s] - 1) / (float)(wout - 1) : 0.f;
+        } else {
+            a.sh[s] = (float)hs[s] / (float)hout;
+            a.sw[s] = (float)ws[s] / (float)wout;
+        }
+    }
+    a.n = n; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners; a.op = reduction;
+    const long long total = planes * hout * ((wout + 3) / 4);
+    const long long want = (total + 255) / 256;
+    const int blocks = (int)(want < 256 * 32 ? want : 256 * 32);
+    hipLaunchKernelGGL(ms_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, out);
     return check_launch();
 }

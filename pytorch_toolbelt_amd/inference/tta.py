@@ -329,6 +329,17 @@ def ms_image_deaugment(images: List[Tensor], size_offsets: List[Union[int, Tuple
     """Resize every scale's prediction back to ``rows - offset // stride`` (floor division, like the reference) and reduce."""
     if len(images) != len(size_offsets):
         raise ValueError("Number of images must be equal to number of size offsets")
+    code = _reduction_code(reduction)
+    if code is not None and mode == "bilinear" and 1 <= len(images) <= 8:
+        # fused path: every scale is sampled at the target grid and reduced in registers (one HIP launch)
+        sizes = set()
+        for fmap, offset in zip(images, size_offsets):
+            dr, dc = _offset_pair(offset)
+            sizes.add((fmap.size(2) - dr // stride, fmap.size(3) - dc // stride) if (dr != 0 or dc != 0) else (fmap.size(2), fmap.size(3)))
+        if len(sizes) == 1 and not any(t.requires_grad for t in images):
+            from . import _resample
+
+            return _resample.ms_reduce(list(images), sizes.pop(), align_corners, code)
     restored = []
     for fmap, offset in zip(images, size_offsets):
         dr, dc = _offset_pair(offset)

@@ -224,3 +224,30 @@ def test_generalized_and_multiscale_wrappers(dev):
     assert y.shape == x.shape
     want = AO.ms_image_deaugment(AO.ms_image_augment(x.cpu().numpy(), [-16, 0, 16], False), [-16, 0, 16], "mean", True)  # quirk Q2
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_cfg5_multiscale_fliplr_gmean(dev):
+    """BASELINE configs[4] pattern: scales 0.75/1.0/1.25 (pixel offsets -N/4, 0, +N/4), each wrapped in fliplr TTA,
+    gmean merge -- reduced to 384x384 for the oracle, plus size-independent properties at 4096x4096."""
+    tta = _tta()
+    N_ = 384
+    offs = [-N_ // 4, 0, N_ // 4]
+    rng = np.random.default_rng(12)
+    outs = [(rng.random((2 * 1, 3, N_ + o, N_ + o), dtype=np.float32) * 0.9 + 0.05) for o in offs]   # fliplr-augmented model outputs
+    per_scale = [tta.fliplr_image_deaugment(torch.from_numpy(o).to(dev)) for o in outs]
+    got = tta.ms_image_deaugment(per_scale, offs, reduction="gmean", mode="bilinear", align_corners=False)
+    want = AO.ms_image_deaugment([AO.image_deaugment(o, "fliplr", "mean") for o in outs], offs, "gmean", False)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    for red in ("mean", "sum", "hmean", "logodd"):
+        got = tta.ms_image_deaugment(per_scale, offs, reduction=red, align_corners=True)
+        want = AO.ms_image_deaugment([AO.image_deaugment(o, "fliplr", "mean") for o in outs], offs, red, True)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # full size: a constant map at every scale merges to that constant (bilinear and gmean both reproduce constants);
+    # a horizontal ramp stays a ramp under align_corners=True resampling
+    big = [torch.full((1, 4, 4096 + o, 4096 + o), 0.37, device=dev) for o in (-1024, 0, 1024)]
+    out = tta.ms_image_deaugment(big, [-1024, 0, 1024], reduction="gmean", align_corners=False)
+    assert out.shape == (1, 4, 4096, 4096) and float((out - 0.37).abs().max()) <= 1e-6
+    ramps = [torch.linspace(0, 1, 4096 + o, device=dev).view(1, 1, 1, -1).expand(1, 4, 4096 + o, 4096 + o).contiguous() for o in (-1024, 0, 1024)]
+    out = tta.ms_image_deaugment(ramps, [-1024, 0, 1024], reduction="mean", align_corners=True)
+    ref = torch.linspace(0, 1, 4096, device=dev).view(1, 1, 1, -1).expand_as(out)
+    assert float((out - ref).abs().max()) <= 2e-6

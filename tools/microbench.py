@@ -93,5 +93,26 @@ def main():
         print(f"{name:70s} {gbs:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+
+
+def cfg5():
+    """BASELINE configs[4]: multiscale (3072/4096/5120) de-augment + gmean to 4096x4096, C=4 (after per-scale fliplr)."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    dev = torch.device("cuda:0")
+    maps = [torch.rand((1, 4, 4096 + o, 4096 + o), device=dev) * 0.9 + 0.05 for o in (-1024, 0, 1024)]
+    flips = [torch.rand((2, 4, 4096 + o, 4096 + o), device=dev) * 0.9 + 0.05 for o in (-1024, 0, 1024)]
+    alg = sum(m.numel() for m in maps) * 4 + 4 * 4096 * 4096 * 4
+    t = timeit(lambda i: tta.ms_image_deaugment(maps, [-1024, 0, 1024], reduction="gmean", align_corners=False), 10, 1)
+    print(f"{'cfg5 fused ms_image_deaugment gmean (3 scales -> 4096^2, C=4)':70s} {alg / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+    alg2 = sum(m.numel() for m in flips) * 4 + 4 * 4096 * 4096 * 4
+    t = timeit(lambda i: tta.ms_image_deaugment([tta.fliplr_image_deaugment(f) for f in flips], [-1024, 0, 1024], reduction="gmean"), 10, 1)
+    print(f"{'cfg5 fliplr de-augment per scale + fused ms gmean (SURVEY 8d bytes)':70s} {alg2 / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "cfg5":
+    cfg5()
+    sys.exit(0)
+
 if __name__ == "__main__":
     main()
