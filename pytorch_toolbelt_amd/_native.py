@@ -52,6 +52,7 @@ SIGNATURES = {
 
 _lib = None
 _lock = threading.Lock()
+fresh_fallbacks = 0  # times a first-touch bitmap could not be honoured (diagnostics)
 calls = 0  # number of native entry-point invocations (tests assert the HIP path really ran)
 
 

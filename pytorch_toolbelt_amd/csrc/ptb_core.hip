@@ -15,23 +15,29 @@ void set_hip_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
 // out[c][p] = (image[c][p] [+ extra[c][p] for p < extra_n]) / norm[p]; IEEE division, no eps clamp (uncovered pixels
 // give NaN like the reference).  Streaming elementwise: 16 B/lane, grid-stride; the norm float4 is reused across the
 // C channels in registers.  Channel strides let a rank merge a row band of a larger accumulator (parallel.py).
+template <bool NT>
 __global__ __launch_bounds__(256) void merge_div_kernel(const float* __restrict__ image, const float* __restrict__ norm,
                                                         float* __restrict__ out, int C, long long hw4, long long ics4,
                                                         long long ocs4, const float* __restrict__ extra, long long ecs4,
                                                         long long en4) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const float4* n4 = reinterpret_cast<const float4*>(norm);
+    const v4f* n4 = reinterpret_cast<const v4f*>(norm);
+    const v4f* im4 = reinterpret_cast<const v4f*>(image);
+    const v4f* ex4 = reinterpret_cast<const v4f*>(extra);
+    v4f* o4 = reinterpret_cast<v4f*>(out);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw4; i += stride) {
-        const float4 n = n4[i];
+        // everything here is touched exactly once: non-temporal loads (g_nt_loads) keep the streams out of L2 / MALL
+        const v4f n = NT ? __builtin_nontemporal_load(&n4[i]) : n4[i];
         for (int c = 0; c < C; ++c) {
-            float4 v = reinterpret_cast<const float4*>(image)[c * ics4 + i];
+            v4f v = NT ? __builtin_nontemporal_load(&im4[c * ics4 + i]) : im4[c * ics4 + i];
             if (i < en4) {
-                const float4 e = reinterpret_cast<const float4*>(extra)[c * ecs4 + i];
+                const v4f e = NT ? __builtin_nontemporal_load(&ex4[c * ecs4 + i]) : ex4[c * ecs4 + i];
                 v.x = __fadd_rn(v.x, e.x); v.y = __fadd_rn(v.y, e.y); v.z = __fadd_rn(v.z, e.z); v.w = __fadd_rn(v.w, e.w);
             }
-            float4 o;
+            v4f o;
             o.x = __fdiv_rn(v.x, n.x); o.y = __fdiv_rn(v.y, n.y); o.z = __fdiv_rn(v.z, n.z); o.w = __fdiv_rn(v.w, n.w);
-            reinterpret_cast<float4*>(out)[c * ocs4 + i] = o;
+            o4[c * ocs4 + i] = o;
         }
     }
 }
@@ -89,8 +95,9 @@ extern "C" int ptb_merge_div_ex(const float* image, const float* norm, float* ou
         const long long hw4 = HW / 4;
         const long long want = (hw4 + 255) / 256;
         const int blocks = (int)(want < 256 * 16 ? want : 256 * 16);
-        hipLaunchKernelGGL(merge_div_kernel, dim3(blocks), dim3(256), 0, s, image, norm, out, C, hw4, (long long)image_cs / 4,
-                           (long long)out_cs / 4, extra, (long long)extra_cs / 4, (long long)extra_n / 4);
+        // (non-temporal loads were measured here too: no gain for this 1:1 read/write stream, so the default policy stays)
+        hipLaunchKernelGGL(merge_div_kernel<false>, dim3(blocks), dim3(256), 0, s, image, norm, out, C, hw4, (long long)image_cs / 4,
+                                (long long)out_cs / 4, extra, (long long)extra_cs / 4, (long long)extra_n / 4);
     } else {
         const long long want = (HW + 255) / 256;
         const int blocks = (int)(want < 256 * 16 ? want : 256 * 16);

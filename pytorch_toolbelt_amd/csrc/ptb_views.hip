@@ -300,6 +300,64 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------ augment (scatter)
+// *_image_augment: every source chunk is read ONCE and written to all V views (the gather formulation above would read
+// it V times).  Row-preserving views are stored straight from the registers at mirrored addresses; the transposing
+// views share one transposed, XOR-swizzled LDS copy of the chunk (ST[c][r] = S[r][c]) read back with ds_read_b128.
+template <int CH>
+__global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a, int B) {
+    constexpr int SL = CH / 4;  // 16-byte slots per LDS row
+    __shared__ __attribute__((aligned(16))) float st[CW * CH];
+    const int tid = threadIdx.x;
+    const int cpt = a.chunks_x * a.chunks_y;
+    int bid = blockIdx.x;
+    const int chunk = bid % cpt;
+    bid /= cpt;
+    const int c = bid % a.C;
+    const int b = bid / a.C;
+    const int x0 = (chunk % a.chunks_x) * CW, y0 = (chunk / a.chunks_x) * CH;
+    const int cw = min(CW, a.W - x0), ch = min(CH, a.H - y0);
+    const int q = tid & 15, r = tid >> 4;
+    const bool act = r < ch && 4 * q < cw;
+    const long long plane = (long long)a.H * a.W;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (act) v = ld16<true>(a.src + ((long long)b * a.C + c) * plane + (long long)(y0 + r) * a.W + x0 + 4 * q);
+    if (a.scale != 1.0f) { v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale; }
+    bool any_t = false;
+    for (int k = 0; k < a.nviews; ++k) {
+        const int code = (a.codes >> (3 * k)) & 7;
+        if (code & 1) { any_t = true; continue; }
+        if (act) {   // out[i][j] = src[fr ? H-1-i : i][fc ? W-1-j : j]  <=>  src (R, Cc) lands at i = R or H-1-R, j = Cc or W-1-Cc
+            const int i = (code & 2) ? a.H - 1 - (y0 + r) : y0 + r;
+            const int j = (code & 4) ? a.W - 4 - (x0 + 4 * q) : x0 + 4 * q;
+            float* o = a.dst + (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
+            *reinterpret_cast<float4*>(o) = (code & 4) ? make_float4(v.w, v.z, v.y, v.x) : v;
+        }
+    }
+    if (!any_t) return;
+    if (act) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int col = 4 * q + m;  // source column -> LDS row
+            st[col * CH + ((((r >> 2) ^ (col >> 2)) & (SL - 1)) << 2) + (r & 3)] = comp(v, m);
+        }
+    }
+    __syncthreads();
+    const int ii = tid / SL, qq = tid % SL;  // LDS row (source column) and slot (4 source rows)
+    if (ii < cw && 4 * qq < ch) {
+        const float4 t = *reinterpret_cast<const float4*>(&st[ii * CH + (((qq ^ (ii >> 2)) & (SL - 1)) << 2)]);
+        for (int k = 0; k < a.nviews; ++k) {
+            const int code = (a.codes >> (3 * k)) & 7;
+            if (!(code & 1)) continue;
+            // out[i][j] = src[fr ? N-1-j : j][fc ? N-1-i : i]: source column Cc = x0+ii gives the out row, source rows give out cols
+            const int i = (code & 4) ? a.W - 1 - (x0 + ii) : x0 + ii;
+            const int j = (code & 2) ? a.H - 4 - (y0 + 4 * qq) : y0 + 4 * qq;
+            float* o = a.dst + (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
+            *reinterpret_cast<float4*>(o) = (code & 2) ? make_float4(t.w, t.z, t.y, t.x) : t;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scalar kernels
 // Any shape / alignment (odd tile sizes such as the reference's 51/26 test): one element per thread, 64x4 threads
 // sweeping a 64x64 chunk.  Same cell ownership and the same arithmetic order as the fast kernels.
@@ -794,5 +852,18 @@ extern "C" int ptb_view_transform(const float* in, float* out, int V, const int*
     a.scale = scale;
     a.op = PTB_RED_SUM;
     a.divisor = 1.0f;
+    const bool tr = has_transpose(V, a.codes);
+    if (in_is_batch && V > 1 && !g_force_scalar && W % 4 == 0 && (!tr || H % 4 == 0) && aligned16(in) && aligned16(out)) {
+        const int ch = g_chunk_rows;
+        a.chunks_x = (W + CW - 1) / CW;
+        a.chunks_y = (H + ch - 1) / ch;
+        const long long blocks = (long long)B * C * a.chunks_x * a.chunks_y;
+        if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+        hipStream_t s = (hipStream_t)stream;
+        if (ch == 64) hipLaunchKernelGGL(view_scatter_kernel<64>, dim3((unsigned)blocks), dim3(1024), 0, s, a, B);
+        else if (ch == 32) hipLaunchKernelGGL(view_scatter_kernel<32>, dim3((unsigned)blocks), dim3(512), 0, s, a, B);
+        else hipLaunchKernelGGL(view_scatter_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, a, B);
+        return check_launch();
+    }
     return run_plain(a, V * B, MODE_PERVIEW, (hipStream_t)stream);
 }

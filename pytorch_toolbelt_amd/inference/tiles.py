@@ -330,6 +330,7 @@ class TileMerger:
         with N.on_device(dev):
             rc = launch(self._fresh.ctypes.data if self._fresh.any() else None)
             if rc == N.EFRESH:  # geometry not block aligned (or a non-default chunk size): zero-fill once, then plain RMW
+                N.fresh_fallbacks += 1
                 self._materialize()
                 rc = launch(None)
         N.bump()

@@ -84,9 +84,18 @@ def main():
         rows.append((f"CH={ch} fused d4 accumulate, 8 disjoint tiles", nbytes / t / 1e9, t))
         t = timeit(lambda i: merger.integrate_batch(bufs[i][:8], crops_row), args.reps, nbuf)
         rows.append((f"CH={ch} integrate_batch (1 view) row of 8", nbytes / 8 / t / 1e9, t))
-    lib.ptb_set_tunable(0, 64)
-    t = timeit(lambda i: merger.merge(), args.reps, nbuf)
-    rows.append(("merge 4x5120x5120 (r image+norm, w out)", (2 * merger.image.numel() + merger.norm_mask.numel()) * 4 / t / 1e9, t))
+    lib.ptb_set_tunable(0, 32)
+    for nt in (0, 1):
+        lib.ptb_set_tunable(2, nt)
+        t = timeit(lambda i: merger.merge(), args.reps, nbuf)
+        rows.append((f"merge 4x5120x5120 (r image+norm, w out) nt={nt}", (2 * merger.image.numel() + merger.norm_mask.numel()) * 4 / t / 1e9, t))
+    # d4 augment [8,3,512,512] -> [64,3,512,512]: read 25 MB, write 201 MB
+    from pytorch_toolbelt_amd.inference import tta
+    xa = [torch.randn((8, 3, T, T), device=dev) for _ in range(nbuf)]
+    t = timeit(lambda i: tta.d4_image_augment(xa[i]), args.reps, nbuf)
+    rows.append(("d4_image_augment [8,3,512,512] -> [64,...] (r+w bytes)", 9 * xa[0].numel() * 4 / t / 1e9, t))
+    t = timeit(lambda i: tta.d4_image_deaugment(bufs[i]), args.reps, nbuf)
+    rows.append(("d4_image_deaugment [64,4,512,512] -> [8,...] via public API (read bytes)", nbytes / t / 1e9, t))
     t = timeit(lambda i: (merger.image.zero_(), merger.norm_mask.zero_()), args.reps, nbuf)
     rows.append(("zero accumulators (w bytes)", (merger.image.numel() + merger.norm_mask.numel()) * 4 / t / 1e9, t))
     for name, gbs, t in rows:
