@@ -160,21 +160,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # ---- dominant-kernel roofline: HIP events around every fused launch (same stream), full batches only ----------
-    ev = []
-    merger.reset()
-    for t, c in zip(batch_tensors, batch_crops):
-        if len(c) == BATCH:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+    # ---- dominant-kernel roofline: ONE HIP-event pair (same stream) around the back-to-back run of full 8-tile launches
+    # of a step (per-launch event pairs would insert a marker packet between kernels and inflate every launch by a few
+    # microseconds); averaged over several steps.  The trailing partial batch and the merge are outside the bracket.
+    n_full = sum(1 for c in batch_crops if len(c) == BATCH)
+    assert all(len(c) == BATCH for c in batch_crops[:n_full])
+    spans = []
+    for _ in range(max(3, min(10, args.steps))):
+        merger.reset()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t, c in zip(batch_tensors[:n_full], batch_crops[:n_full]):
             merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
-            e1.record()
-            ev.append((e0, e1))
-        else:
+        e1.record()
+        for t, c in zip(batch_tensors[n_full:], batch_crops[n_full:]):
             merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
-    merger.merge()
-    torch.cuda.synchronize()
-    launch_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+        merger.merge()
+        torch.cuda.synchronize()
+        spans.append(e0.elapsed_time(e1))
+    launch_ms = float(np.median(spans)) / max(n_full, 1) if n_full else float("nan")
     bytes_per_tile = VIEWS * CHANNELS * TILE * TILE * 4          # 8 views x C x T x 4 B read per tile
     bytes_per_launch = bytes_per_tile * BATCH
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
