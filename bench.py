@@ -77,10 +77,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_sharded = os.environ.get("PTB_BENCH_FORCE_SHARDED", "0") == "1"  # exercise the RCCL path with any world size
+    use_dist = world > 1 or force_sharded
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -88,7 +93,7 @@ def main():
 
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from pytorch_toolbelt_amd import _native as N
     from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
@@ -105,7 +110,8 @@ def main():
     assert n_tiles == 361 and slicer.target_shape == (5120, 5120)
 
     # ---- this rank's share of the tiles, and their (synthetic) model outputs resident in HBM -------------------
-    if world == 1:
+    sharded = use_dist
+    if not sharded:
         my_tiles = np.arange(n_tiles)
     else:
         my_tiles = tile_row_partition(slicer.crops, world)[rank]
@@ -118,13 +124,13 @@ def main():
     batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
 
-    if world == 1:
+    if not sharded:
         merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
     else:
         merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev)
 
     def step():
-        if world == 1:
+        if not sharded:
             if args.memset_accumulators:
                 merger.image.zero_()      # (property access materialises -> every later write is a read-modify-write)
                 merger.norm_mask.zero_()
@@ -139,7 +145,7 @@ def main():
         return merger.merge()  # this rank's band of the merged image
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -155,7 +161,7 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -236,7 +242,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(slicer)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -74,6 +74,12 @@ int ptb_tile_accumulate(float* image, float* norm, const float* weight, const fl
                         const int64_t* ys, int B, int C, int th, int tw, int H, int W, uint8_t* fresh, int fresh_rows,
                         ptb_stream_t stream);
 
+/* Test hook, host only (no device work): the launch plan of the two calls above for one batch.  out: up to `cap`
+ * records of 12 ints {launch group, ox, oy, w, h, fresh, chunk_end, ntiles, tile[4] (batch indices, -1 padded)}.
+ * Returns the number of cells or a PTB_E* code. */
+int ptb_debug_plan(const int64_t* xs, const int64_t* ys, int B, int th, int tw, int H, int W, int chunk_rows,
+                   uint8_t* fresh, int fresh_rows, int* out, int cap);
+
 /* ---- TileMerger.merge / merge_ (inference/tiles.py:345-350): out[c] = image[c] / norm (no eps clamp) -----------
  * out may alias image (merge_). */
 int ptb_merge_div(const float* image, const float* norm, float* out, int C, int64_t HW, ptb_stream_t stream);

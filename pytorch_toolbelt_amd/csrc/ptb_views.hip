@@ -718,7 +718,8 @@ static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, 
 }
 
 // Dry run of run_accum's grouping on a scratch bitmap: PTB_EFRESH if any launch group would need a zero-fill.
-static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int th, int ch, Fresh& fr) {
+static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int th, int ch, Fresh& fr,
+                       std::vector<Cell>* record = nullptr, std::vector<int>* record_group = nullptr, int* group_counter = nullptr) {
     if (lo >= hi) return PTB_OK;
     CellArgs g;
     int ids[MAX_GROUP];
@@ -734,8 +735,17 @@ static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int
     if (st == DECOMP_SPLIT) {
         if (n == 1) return PTB_EUNSUPPORTED;
         const int mid = lo + n / 2;
-        const int rc = probe_accum(xs, ys, lo, mid, tw, th, ch, fr);
-        return rc ? rc : probe_accum(xs, ys, mid, hi, tw, th, ch, fr);
+        const int rc = probe_accum(xs, ys, lo, mid, tw, th, ch, fr, record, record_group, group_counter);
+        return rc ? rc : probe_accum(xs, ys, mid, hi, tw, th, ch, fr, record, record_group, group_counter);
+    }
+    if (record) {
+        for (int i = 0; i < nc; ++i) {
+            Cell c = g.cells[i];
+            for (int e = 0; e < c.ntiles; ++e) c.tile[e] = g.tile_id[c.tile[e]];  // batch indices
+            record->push_back(c);
+            record_group->push_back(*group_counter);
+        }
+        ++*group_counter;
     }
     mark_written(cells, fr);
     return PTB_OK;
@@ -866,4 +876,39 @@ extern "C" int ptb_view_transform(const float* in, float* out, int V, const int*
         return check_launch();
     }
     return run_plain(a, V * B, MODE_PERVIEW, (hipStream_t)stream);
+}
+
+// Test hook (no device work): the launch plan ptb_tile_accumulate / ptb_deaug_accumulate would use for this batch.
+// out receives up to `cap` records of 12 ints: group, ox, oy, w, h, fresh, chunk_end, ntiles, tile[4] (batch indices).
+// Returns the number of cells (>= 0) or a PTB_E* code; `fresh` (optional) is updated exactly as a real call would.
+extern "C" int ptb_debug_plan(const int64_t* xs64, const int64_t* ys64, int B, int th, int tw, int H, int W, int chunk_rows,
+                              uint8_t* fresh, int fresh_rows, int* out, int cap) {
+    if (!xs64 || !ys64 || B < 0 || th < 1 || tw < 1 || H < 1 || W < 1 || chunk_rows < 1 || !out) return PTB_EINVAL;
+    std::vector<int> xs(B), ys(B);
+    for (int b = 0; b < B; ++b) {
+        if (xs64[b] < 0 || ys64[b] < 0 || xs64[b] + tw > W || ys64[b] + th > H) return PTB_EBOUNDS;
+        xs[b] = (int)xs64[b];
+        ys[b] = (int)ys64[b];
+    }
+    Fresh fr{fresh, fresh_rows, H, W};
+    if (fresh && fresh_rows != chunk_rows) return PTB_EFRESH;
+    std::vector<uint8_t> probe;
+    Fresh pf = fr;
+    if (fresh) {  // decide on a scratch copy first, like accumulate_impl
+        probe.assign(fresh, fresh + (size_t)fr.nbx() * fr.nby());
+        pf.map = probe.data();
+        if (int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, chunk_rows, pf)) return rc;
+    }
+    std::vector<Cell> cells;
+    std::vector<int> groups;
+    int counter = 0;
+    if (int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, chunk_rows, fr, &cells, &groups, &counter)) return rc;
+    const int n = (int)cells.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        int* o = out + 12 * i;
+        const Cell& c = cells[i];
+        o[0] = groups[i]; o[1] = c.ox; o[2] = c.oy; o[3] = c.w; o[4] = c.h; o[5] = c.fresh; o[6] = c.chunk_end; o[7] = c.ntiles;
+        for (int e = 0; e < MAX_COVER; ++e) o[8 + e] = e < c.ntiles ? c.tile[e] : -1;
+    }
+    return n;
 }

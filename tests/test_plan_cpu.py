@@ -1,0 +1,123 @@
+"""CPU: the host-side launch planner of the accumulate kernels (cell decomposition + first-touch bitmap), exercised
+through the ptb_debug_plan test hook with random tile layouts.  Invariants: within a launch group cells are disjoint,
+their union is the union of the group's tiles, every cell lists exactly the tiles covering it in ascending batch order;
+groups cover the batch in order; freshness flags agree with a pixel-level simulation."""
+import ctypes
+
+import numpy as np
+import pytest
+from hypothesis import given, settings
+from hypothesis import strategies as st
+
+from pytorch_toolbelt_amd import _native as N
+
+
+def plan(xs, ys, th, tw, H, W, chunk_rows=32, fresh=None, fresh_rows=32):
+    lib = N.load()
+    cap = 4096
+    out = (ctypes.c_int * (12 * cap))()
+    rc = lib.ptb_debug_plan(N.i64_array(list(xs)), N.i64_array(list(ys)), len(xs), th, tw, H, W, chunk_rows,
+                            fresh.ctypes.data if fresh is not None else None, fresh_rows, out, cap)
+    if rc < 0:
+        return rc, None
+    arr = np.frombuffer(out, dtype=np.int32)[:12 * rc].reshape(rc, 12).copy()
+    return rc, arr
+
+
+def check_plan(xs, ys, th, tw, H, W, cells):
+    B = len(xs)
+    seen_tiles = []
+    for g in np.unique(cells[:, 0]):
+        grp = cells[cells[:, 0] == g]
+        tiles = sorted({t for row in grp for t in row[8:8 + row[7]]})
+        seen_tiles.append(tiles)
+        cover = np.zeros((H, W), dtype=np.int32)   # how many cells of this group claim each pixel
+        for t in tiles:
+            assert 0 <= t < B
+        tile_mask = np.zeros((H, W), dtype=bool)
+        for t in tiles:
+            tile_mask[ys[t]:ys[t] + th, xs[t]:xs[t] + tw] = True
+        for row in grp:
+            _, ox, oy, w, h, _fresh, _ce, nt = row[:8]
+            assert w > 0 and h > 0 and 1 <= nt <= 4
+            cover[oy:oy + h, ox:ox + w] += 1
+            lst = list(row[8:8 + nt])
+            assert lst == sorted(lst)
+            # the cell's cover list == tiles of the group that contain the cell (checked at its corners: cells never
+            # straddle a tile edge, so all pixels of a cell share one cover set)
+            for (py, px) in ((oy, ox), (oy + h - 1, ox + w - 1)):
+                want = [t for t in tiles if xs[t] <= px < xs[t] + tw and ys[t] <= py < ys[t] + th]
+                assert lst == want
+        assert cover.max() <= 1, "cells of one launch overlap"
+        assert np.array_equal(cover.astype(bool), tile_mask), "cells do not tile the union of the group's tiles"
+    flat = [t for g in seen_tiles for t in g]
+    assert flat == list(range(B)), "launch groups must partition the batch in order"
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.data())
+def test_random_layouts(data):
+    th = data.draw(st.sampled_from([8, 12, 16, 24, 31]))
+    tw = data.draw(st.sampled_from([8, 16, 20, 28, 33]))
+    H = data.draw(st.integers(th, 96))
+    W = data.draw(st.integers(tw, 96))
+    B = data.draw(st.integers(1, 24))
+    xs = [data.draw(st.integers(0, W - tw)) for _ in range(B)]
+    ys = [data.draw(st.integers(0, H - th)) for _ in range(B)]
+    n, cells = plan(xs, ys, th, tw, H, W)
+    assert n > 0
+    check_plan(xs, ys, th, tw, H, W, cells)
+
+
+def test_slicer_row_of_eight_and_wraparound():
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    s = ImageSlicer((5000, 5000, 3), 512, 256, weight="mean")
+    xs, ys = s.crops[:8, 0], s.crops[:8, 1]
+    n, cells = plan(xs, ys, 512, 512, 5120, 5120)
+    assert n == 9 and sorted(cells[:, 7].tolist()) == [1, 1] + [2] * 7          # 9 cells: 7 two-tile, 2 one-tile
+    assert (cells[:-1, 7] >= cells[1:, 7]).all()                                 # heavy cells first
+    assert cells[-1, 6] == 9 * (256 // 64) * (512 // 32)                         # chunk prefix = total 64x32 chunks
+    xs, ys = s.crops[16:24, 0], s.crops[16:24, 1]                                # batch wrapping from tile row 0 to row 1
+    n, cells = plan(xs, ys, 512, 512, 5120, 5120)
+    check_plan(list(xs), list(ys), 512, 512, 5120, 5120, cells)
+    # 16-fold cover (step = size / 4) cannot go into one launch: the planner splits the batch
+    d = ImageSlicer((64, 64), 32, 8, weight="mean")
+    n, cells = plan(d.crops[:, 0], d.crops[:, 1], 32, 32, *d.target_shape)
+    assert len(np.unique(cells[:, 0])) > 1
+    check_plan(list(d.crops[:, 0]), list(d.crops[:, 1]), 32, 32, *d.target_shape, cells)
+
+
+def test_first_touch_bitmap():
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    s = ImageSlicer((1000, 1500, 3), 512, 256, weight="mean")
+    H, W = s.target_shape
+    fresh = np.ones(((H + 31) // 32, (W + 63) // 64), dtype=np.uint8)
+    written = np.zeros((H, W), dtype=bool)
+    row_len = len(np.unique(s.crops[:, 0]))
+    for b0 in range(0, len(s.crops) - 1, row_len):          # one tile row per batch (the last single tile is done below)
+        idx = range(b0, min(b0 + row_len, len(s.crops)))
+        xs, ys = s.crops[idx, 0], s.crops[idx, 1]
+        n, cells = plan(xs, ys, 512, 512, H, W, 32, fresh, 32)
+        assert n > 0
+        for row in cells:
+            _, ox, oy, w, h, fr = row[:6]
+            region = written[oy:oy + h, ox:ox + w]
+            assert region.all() or not region.any(), "a cell must be uniformly fresh or uniformly written"
+            assert fr == (0 if region.any() else 1)
+            written[oy:oy + h, ox:ox + w] = True
+    assert not fresh.any() and written.all()
+    # a tile whose footprint is partly written cannot be stored blindly: the planner asks for a zero-fill
+    fresh = np.ones_like(fresh)
+    fresh[:8, :4] = 0                                   # left half of the first tile already written
+    rc, _ = plan([0], [0], 512, 512, H, W, 32, fresh, 32)
+    assert rc == N.EFRESH
+    # unaligned tiles never use first-touch stores
+    fresh = np.ones_like(fresh)
+    rc, _ = plan([4], [0], 512, 512, H, W, 32, fresh, 32)
+    assert rc == N.EFRESH
+    rc, _ = plan([0], [0], 512, 512, H, W, 64, fresh, 32)   # bitmap granularity != chunk rows
+    assert rc == N.EFRESH
+    rc, _ = plan([W], [0], 512, 512, H, W)
+    assert rc == -4
