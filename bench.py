@@ -212,7 +212,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",  # one image per step for the whole job, whatever N
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",

@@ -73,6 +73,18 @@ def main():
         with torch.no_grad():
             tf = timeit(lambda: fn(x, labels), reps=3)
         print(f"{name:34s} {tf:8.3f} {fwd_bytes / tf / 1e6:9.1f}")
+    # CPU reference point: the numpy oracle (one core) on a 1/16 sample of the batch, extrapolated
+    import time
+    import numpy as np
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import losses_oracle as LO
+    xs, ls = x[:2].cpu().numpy(), labels[:2].cpu().numpy()
+    for name, fn in (("numpy oracle BinaryFocal (1 core)", lambda: LO.binary_focal_loss(xs, ls)),
+                     ("numpy oracle Dice multiclass (1 core)", lambda: LO.dice_loss(xs, ls, "multiclass"))):
+        t0 = time.perf_counter()
+        fn()
+        dt = (time.perf_counter() - t0) * 16 * 1e3
+        print(f"{name:34s} {dt:8.1f}   (2 of 32 images timed, x16)")
     probs = torch.softmax(x[:4], 1)
     with torch.no_grad():
         t = timeit(lambda: L.LovaszLoss()(probs, labels[:4]), reps=5)
