@@ -9,6 +9,7 @@ static thread_local std::string g_last_error;
 int g_chunk_rows = 32;  // 32x64 chunks (512-thread workgroups) measured best on MI355X (profiles/)
 int g_force_scalar = 0;
 int g_nt_loads = 1;
+int g_ms_tiled = 1;
 
 void set_hip_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
 
@@ -77,6 +78,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
     }
     if (key == 2) {
         g_nt_loads = value ? 1 : 0;
+        return PTB_OK;
+    }
+    if (key == 3) {
+        g_ms_tiled = value ? 1 : 0;
         return PTB_OK;
     }
     return PTB_EINVAL;

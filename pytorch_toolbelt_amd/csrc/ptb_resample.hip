@@ -76,9 +76,14 @@ struct MsArgs {
 constexpr float kMsEps = 1e-6f;
 constexpr float kMsOneMinusEps = (float)(1.0 - 1e-6);
 
+// v_log_f32 / v_exp_f32 based log/exp (absolute error ~1e-7 on the [0,1] probability range this path is used for, far
+// inside the 1e-5 tolerance); the full-precision libm versions made this kernel ALU-bound.
+__device__ __forceinline__ float ms_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float ms_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __device__ __forceinline__ float ms_pre(float x, int op) {
     switch (op) {
-        case PTB_RED_GMEAN: return logf(x);
+        case PTB_RED_GMEAN: return ms_log(x);
         case PTB_RED_HMEAN: return 1.0f / (x < kMsEps ? kMsEps : x);
         case PTB_RED_HARMONIC1P: return 1.0f / (x + 1.0f);
         case PTB_RED_LOGODD: { const float p = x < kMsEps ? kMsEps : (x > kMsOneMinusEps ? kMsOneMinusEps : x); return logf(p / (1.0f - p)); }
@@ -90,7 +95,7 @@ __device__ __forceinline__ float ms_post(float s, int op, float n) {
     if (op == PTB_RED_SUM) return s;
     const float m = s / n;
     switch (op) {
-        case PTB_RED_GMEAN: return expf(m);
+        case PTB_RED_GMEAN: return ms_exp(m);
         case PTB_RED_HMEAN: return 1.0f / (m < kMsEps ? kMsEps : m);
         case PTB_RED_HARMONIC1P: return 1.0f / m - 1.0f;
         case PTB_RED_LOGODD: { const float e = expf(m); return e / (1.0f + e); }
@@ -148,6 +153,91 @@ __global__ __launch_bounds__(256) void ms_reduce_kernel(const MsArgs a, float* _
     }
 }
 
+// Tiled variant: a workgroup owns a 64 x 16 output tile; for every resized scale it first copies the source window the
+// tile's taps fall into (<= 24 x 96 floats for ratios up to 1.25) into LDS with coalesced 16-byte loads, then all
+// 4-tap gathers hit LDS instead of issuing 16 scattered 4-byte global loads per lane and scale.  Windows that do not
+// fit (strong down-sampling) fall back to direct global gathers for that scale.
+constexpr int MS_TW = 64, MS_TH = 16, MS_LR = 24, MS_LC = 96;
+
+__global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[MS_LR * MS_LC];
+    const int tiles_x = (a.wout + MS_TW - 1) / MS_TW, tiles_y = (a.hout + MS_TH - 1) / MS_TH;
+    int bid = blockIdx.x;
+    const int txi = bid % tiles_x;
+    bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const long long p = bid / tiles_y;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ox0 = txi * MS_TW, oy0 = tyi * MS_TH;
+    const int oy = oy0 + ly, ox = ox0 + 4 * lx;
+    const bool row_ok = oy < a.hout;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < a.n; ++s) {
+        float v[4] = {1.f, 1.f, 1.f, 1.f};
+        const int hin = a.h[s], win = a.w[s];
+        const float* src = a.in[s] + p * (long long)hin * win;
+        if (hin == a.hout && win == a.wout) {
+            if (row_ok && ox + 3 < a.wout) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (long long)oy * win + ox);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else if (row_ok) {
+                for (int m = 0; m < 4; ++m) if (ox + m < a.wout) v[m] = src[(long long)oy * win + ox + m];
+            }
+        } else {
+            // workgroup-uniform source window of this tile
+            const int oy_last = min(oy0 + MS_TH, a.hout) - 1, ox_last = min(ox0 + MS_TW, a.wout) - 1;
+            const int r_lo = taps(oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps(oy_last, a.sh[s], hin, a.align_corners).i1;
+            const int c_lo = taps(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps(ox_last, a.sw[s], win, a.align_corners).i1;
+            const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
+            const bool staged = nr <= MS_LR && nc <= MS_LC && (win & 3) == 0;
+            if (staged) {
+                const int q_per_row = (nc + 3) / 4;
+                for (int idx = tid; idx < nr * q_per_row; idx += 256) {
+                    const int rr = idx / q_per_row, q4 = idx - rr * q_per_row;
+                    const int col = c_lo + 4 * q4;
+                    if (col < win)  // win % 4 == 0 and col % 4 == 0: the whole float4 is inside the row
+                        *reinterpret_cast<float4*>(&lds[rr * MS_LC + 4 * q4]) =
+                            *reinterpret_cast<const float4*>(src + (long long)(r_lo + rr) * win + col);
+                }
+                __syncthreads();
+            }
+            if (row_ok) {
+                const Taps ty = taps(oy, a.sh[s], hin, a.align_corners);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (ox + m < a.wout) {
+                        const Taps tx = taps(ox + m, a.sw[s], win, a.align_corners);
+                        float t00, t01, t10, t11;
+                        if (staged) {
+                            const float* l0 = lds + (ty.i0 - r_lo) * MS_LC - c_lo;
+                            const float* l1 = lds + (ty.i1 - r_lo) * MS_LC - c_lo;
+                            t00 = l0[tx.i0]; t01 = l0[tx.i1]; t10 = l1[tx.i0]; t11 = l1[tx.i1];
+                        } else {
+                            const float* g0 = src + (long long)ty.i0 * win;
+                            const float* g1 = src + (long long)ty.i1 * win;
+                            t00 = g0[tx.i0]; t01 = g0[tx.i1]; t10 = g1[tx.i0]; t11 = g1[tx.i1];
+                        }
+                        v[m] = ty.l0 * (tx.l0 * t00 + tx.l1 * t01) + ty.l1 * (tx.l0 * t10 + tx.l1 * t11);
+                    }
+                }
+            }
+            if (staged) __syncthreads();  // the next scale reuses the LDS window
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float t = a.op >= PTB_RED_GMEAN ? ms_pre(v[m], a.op) : v[m];
+            acc[m] = s ? acc[m] + t : t;
+        }
+    }
+    if (!row_ok) return;
+    float res[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) res[m] = ms_post(acc[m], a.op, (float)a.n);
+    float* o = out + (p * a.hout + oy) * (long long)a.wout + ox;
+    if ((a.wout & 3) == 0 && ox + 3 < a.wout) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+    else for (int m = 0; m < 4; ++m) if (ox + m < a.wout) o[m] = res[m];
+}
+
 }  // namespace ptb
 
 using namespace ptb;
@@ -193,6 +283,11 @@ extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, co
         }
     }
     a.n = n; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners; a.op = reduction;
+    const long long tiles = planes * ((hout + MS_TH - 1) / MS_TH) * ((wout + MS_TW - 1) / MS_TW);
+    if (g_ms_tiled && tiles <= 0x7fffffffLL) {
+        hipLaunchKernelGGL(ms_reduce_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a, out);
+        return check_launch();
+    }
     const long long total = planes * hout * ((wout + 3) / 4);
     const long long want = (total + 255) / 256;
     const int blocks = (int)(want < 256 * 32 ? want : 256 * 32);

@@ -34,12 +34,21 @@ REDUCTION_CODES = {
 }
 
 
+_LOW_PRECISION = (torch.float16, torch.bfloat16)
+
+
 def _check_image(x, what):
+    """Validate and return (float32 tensor, dtype to cast the result back to or None).  Half / bfloat16 inputs are
+    evaluated in float32 by the kernels and the result is cast back (at least as accurate as the reference's
+    half-precision op chain)."""
     N.require_device(x, what)
     if x.dim() != 4:
         raise NotImplementedError(f"{what}: expected a [B, C, H, W] tensor, got shape {tuple(x.shape)}")
+    if x.dtype in _LOW_PRECISION:
+        return x.float(), x.dtype
     if x.dtype != torch.float32:
-        raise NotImplementedError(f"{what}: the native path is float32, got {x.dtype}")
+        raise NotImplementedError(f"{what}: the native path is float32 (half / bfloat16 are converted), got {x.dtype}")
+    return x, None
 
 
 def _raw_view_transform(x, views: Sequence[int], in_is_batch: bool, scale: float):
@@ -110,15 +119,17 @@ class _DeaugReduce(torch.autograd.Function):
 
 
 def view_transform(x, views, in_is_batch=True, scale=1.0):
-    _check_image(x, "view transform")
-    return _ViewTransform.apply(x, list(views), in_is_batch, scale)
+    x, back = _check_image(x, "view transform")
+    out = _ViewTransform.apply(x, list(views), in_is_batch, scale)
+    return out.to(back) if back is not None else out
 
 
 def deaug_reduce(x, views, code):
-    _check_image(x, "de-augment")
+    x, back = _check_image(x, "de-augment")
     if x.shape[0] % len(views) != 0:
         raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
-    return _DeaugReduce.apply(x, list(views), code)
+    out = _DeaugReduce.apply(x, list(views), code)
+    return out.to(back) if back is not None else out
 
 
 def _plane_shape(numel):
@@ -158,8 +169,10 @@ class _StackReduce(torch.autograd.Function):
 def stack_reduce(x, code):
     """Reduce dim 0 of ``x [T, ...]`` (float32, GPU) with the HIP reduction ``code``; T <= 8."""
     N.require_device(x, "TTA reduction")
+    if x.dtype in _LOW_PRECISION:
+        return stack_reduce(x.float(), code).to(x.dtype)
     if x.dtype != torch.float32:
-        raise NotImplementedError(f"TTA reduction: the native path is float32, got {x.dtype}")
+        raise NotImplementedError(f"TTA reduction: the native path is float32 (half / bfloat16 are converted), got {x.dtype}")
     T = x.shape[0]
     if T < 1:
         raise RuntimeError("cannot reduce an empty stack")

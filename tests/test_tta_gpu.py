@@ -251,3 +251,21 @@ def test_cfg5_multiscale_fliplr_gmean(dev):
     out = tta.ms_image_deaugment(ramps, [-1024, 0, 1024], reduction="mean", align_corners=True)
     ref = torch.linspace(0, 1, 4096, device=dev).view(1, 1, 1, -1).expand_as(out)
     assert float((out - ref).abs().max()) <= 2e-6
+
+
+def test_half_precision_inputs(dev):
+    """fp16 / bf16 tensors (AMP inference) are accepted: evaluated in fp32, returned in the input dtype."""
+    tta = _tta()
+    x = torch.rand((2, 3, 64, 64), device=dev)
+    for dt, tol in ((torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)):
+        xa = tta.d4_image_augment(x.to(dt))
+        assert xa.dtype == dt and torch.equal(xa, tta.d4_image_augment(x).to(dt))
+        y = torch.rand((16, 3, 64, 64), device=dev).to(dt)
+        out = tta.d4_image_deaugment(y)
+        assert out.dtype == dt
+        want = AO.image_deaugment(y.float().cpu().numpy(), "d4", "mean")
+        np.testing.assert_allclose(out.float().cpu().numpy(), want, atol=tol, rtol=tol)
+        lab = tta.d2_labels_deaugment(torch.rand((8, 5), device=dev).to(dt))
+        assert lab.dtype == dt
+    with pytest.raises(NotImplementedError):
+        tta.d4_image_augment(torch.zeros((1, 1, 8, 8), device=dev, dtype=torch.int32))

@@ -112,8 +112,10 @@ def cfg5():
     maps = [torch.rand((1, 4, 4096 + o, 4096 + o), device=dev) * 0.9 + 0.05 for o in (-1024, 0, 1024)]
     flips = [torch.rand((2, 4, 4096 + o, 4096 + o), device=dev) * 0.9 + 0.05 for o in (-1024, 0, 1024)]
     alg = sum(m.numel() for m in maps) * 4 + 4 * 4096 * 4096 * 4
-    t = timeit(lambda i: tta.ms_image_deaugment(maps, [-1024, 0, 1024], reduction="gmean", align_corners=False), 10, 1)
-    print(f"{'cfg5 fused ms_image_deaugment gmean (3 scales -> 4096^2, C=4)':70s} {alg / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+    for tiled in (0, 1):
+        N.load().ptb_set_tunable(3, tiled)
+        t = timeit(lambda i: tta.ms_image_deaugment(maps, [-1024, 0, 1024], reduction="gmean", align_corners=False), 10, 1)
+        print(f"{'cfg5 fused ms_image_deaugment gmean (3 scales -> 4096^2, C=4) tiled=%d' % tiled:70s} {alg / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
     alg2 = sum(m.numel() for m in flips) * 4 + 4 * 4096 * 4096 * 4
     t = timeit(lambda i: tta.ms_image_deaugment([tta.fliplr_image_deaugment(f) for f in flips], [-1024, 0, 1024], reduction="gmean"), 10, 1)
     print(f"{'cfg5 fliplr de-augment per scale + fused ms gmean (SURVEY 8d bytes)':70s} {alg2 / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
