@@ -63,7 +63,7 @@ def main():
 
     rows = ["| kernel | counter | dispatches | avg per dispatch |", "|---|---|---|---|"]
     agg = {}
-    for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "SQ_WAVES"):
+    for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
         db = os.path.join(PROF, sub, "run_results.db")
         if not os.path.exists(db):
             continue
