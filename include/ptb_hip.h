@@ -96,6 +96,12 @@ int ptb_merge_div_ex(const float* image, const float* norm, float* out, int C, i
 int ptb_deaug_reduce(const float* in, float* out, int V, const int* views, int reduction, int B, int C, int H, int W,
                      ptb_stream_t stream);
 
+/* Backward of ptb_deaug_reduce for the NON-linear reductions (the TTA functions "respect gradients flow",
+ * inference/tta.py:3-4); `in` / `out` are the forward input / output, `views` the forward views.  The linear reductions
+ * (sum, mean) are differentiated with ptb_view_transform. */
+int ptb_deaug_reduce_bwd(const float* in, const float* out, const float* grad_out, float* grad_in, int V, const int* views,
+                         int reduction, int B, int C, int H, int W, ptb_stream_t stream);
+
 /* ---- per-view transform without reduction ----------------------------------------------------------------------
  * out[k*B + b] = scale * view_k(in[src]) with src = b (in_is_batch = 1: *_image_augment, inference/tta.py:257-284,
  * 319-341,385-422,470-484; in [B,C,H,W]) or src = k*B + b (in_is_batch = 0: de-augment with reduction=None).

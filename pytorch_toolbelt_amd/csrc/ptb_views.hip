@@ -114,6 +114,28 @@ __device__ __forceinline__ float red_post(float s, int op, float divisor) {
     }
 }
 
+// d post / d m expressed through the forward output, and d pre / d x, for the backward of the non-linear reductions
+__device__ __forceinline__ float red_dpost(float out, int op) {
+    switch (op) {
+        case PTB_RED_GMEAN: return out;                                         // out = exp(m)
+        case PTB_RED_HMEAN: return out >= 1.0f / kEps ? 0.f : -out * out;        // out = 1 / max(m, eps)
+        case PTB_RED_HARMONIC1P: return -(out + 1.0f) * (out + 1.0f);           // out = 1/m - 1
+        case PTB_RED_LOGODD: return out * (1.0f - out);                         // out = sigmoid(m)
+        case PTB_RED_LOG1P: return out + 1.0f;                                  // out = exp(m) - 1
+        default: return 1.0f;
+    }
+}
+__device__ __forceinline__ float red_dpre(float x, int op) {
+    switch (op) {
+        case PTB_RED_GMEAN: return 1.0f / x;
+        case PTB_RED_HMEAN: return x < kEps ? 0.f : -1.0f / (x * x);
+        case PTB_RED_HARMONIC1P: return -1.0f / ((x + 1.0f) * (x + 1.0f));
+        case PTB_RED_LOGODD: return (x < kEps || x > kOneMinusEps) ? 0.f : 1.0f / (x * (1.0f - x));
+        case PTB_RED_LOG1P: return 1.0f / (1.0f + x);
+        default: return 1.0f;
+    }
+}
+
 // XOR-swizzled [CH][64] fp32 LDS tile: 16-byte slots of a row are permuted by (row/4) so that the transposing
 // scatter (lanes walk rows) spreads over banks and the b128 gather (16 lanes per row) stays conflict-free.
 __device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + (j & 3); }
@@ -304,7 +326,9 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
 // *_image_augment: every source chunk is read ONCE and written to all V views (the gather formulation above would read
 // it V times).  Row-preserving views are stored straight from the registers at mirrored addresses; the transposing
 // views share one transposed, XOR-swizzled LDS copy of the chunk (ST[c][r] = S[r][c]) read back with ds_read_b128.
-template <int CH>
+// NONLIN = backward of a non-linear reduction: the scattered value is u = g * post'(out) / V (a.norm = forward output,
+// a.divisor = V) and every destination is multiplied by pre'(x_k) read at the destination (a.weight = forward input).
+template <int CH, bool NONLIN>
 __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a, int B) {
     constexpr int SL = CH / 4;  // 16-byte slots per LDS row
     __shared__ __attribute__((aligned(16))) float st[CW * CH];
@@ -321,8 +345,14 @@ __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a,
     const bool act = r < ch && 4 * q < cw;
     const long long plane = (long long)a.H * a.W;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (act) v = ld16<true>(a.src + ((long long)b * a.C + c) * plane + (long long)(y0 + r) * a.W + x0 + 4 * q);
+    const long long src_off = ((long long)b * a.C + c) * plane + (long long)(y0 + r) * a.W + x0 + 4 * q;
+    if (act) v = ld16<true>(a.src + src_off);
     if (a.scale != 1.0f) { v.x *= a.scale; v.y *= a.scale; v.z *= a.scale; v.w *= a.scale; }
+    if (NONLIN && act) {
+        const float4 o4 = ld16<true>(a.norm + src_off);
+        v.x *= red_dpost(o4.x, a.op) / a.divisor; v.y *= red_dpost(o4.y, a.op) / a.divisor;
+        v.z *= red_dpost(o4.z, a.op) / a.divisor; v.w *= red_dpost(o4.w, a.op) / a.divisor;
+    }
     bool any_t = false;
     for (int k = 0; k < a.nviews; ++k) {
         const int code = (a.codes >> (3 * k)) & 7;
@@ -330,8 +360,13 @@ __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a,
         if (act) {   // out[i][j] = src[fr ? H-1-i : i][fc ? W-1-j : j]  <=>  src (R, Cc) lands at i = R or H-1-R, j = Cc or W-1-Cc
             const int i = (code & 2) ? a.H - 1 - (y0 + r) : y0 + r;
             const int j = (code & 4) ? a.W - 4 - (x0 + 4 * q) : x0 + 4 * q;
-            float* o = a.dst + (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
-            *reinterpret_cast<float4*>(o) = (code & 4) ? make_float4(v.w, v.z, v.y, v.x) : v;
+            const long long off = (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
+            float4 w = (code & 4) ? make_float4(v.w, v.z, v.y, v.x) : v;
+            if (NONLIN) {
+                const float4 x4 = ld16<true>(a.weight + off);
+                w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
+            }
+            *reinterpret_cast<float4*>(a.dst + off) = w;
         }
     }
     if (!any_t) return;
@@ -352,8 +387,34 @@ __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a,
             // out[i][j] = src[fr ? N-1-j : j][fc ? N-1-i : i]: source column Cc = x0+ii gives the out row, source rows give out cols
             const int i = (code & 4) ? a.W - 1 - (x0 + ii) : x0 + ii;
             const int j = (code & 2) ? a.H - 4 - (y0 + 4 * qq) : y0 + 4 * qq;
-            float* o = a.dst + (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
-            *reinterpret_cast<float4*>(o) = (code & 2) ? make_float4(t.w, t.z, t.y, t.x) : t;
+            const long long off = (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
+            float4 w = (code & 2) ? make_float4(t.w, t.z, t.y, t.x) : t;
+            if (NONLIN) {
+                const float4 x4 = ld16<true>(a.weight + off);
+                w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
+            }
+            *reinterpret_cast<float4*>(a.dst + off) = w;
+        }
+    }
+}
+
+// scalar fallback of the non-linear backward (any shape): one thread per element of the reduced tensor
+__global__ __launch_bounds__(256) void deaug_bwd_scalar_kernel(const ViewArgs a, int B) {
+    const long long plane = (long long)a.H * a.W;
+    const long long n = (long long)B * a.C * plane;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
+        const long long bc = t / plane, px = t - bc * plane;
+        const int R = (int)(px / a.W), Cc = (int)(px - (long long)R * a.W);
+        const float u = a.src[t] * red_dpost(a.norm[t], a.op) / a.divisor;
+        for (int k = 0; k < a.nviews; ++k) {
+            const int code = (a.codes >> (3 * k)) & 7;  // scatter view (inverse of the forward de-augment view)
+            int i, j;
+            if (code & 1) { i = (code & 4) ? a.W - 1 - Cc : Cc; j = (code & 2) ? a.H - 1 - R : R; }
+            else { i = (code & 2) ? a.H - 1 - R : R; j = (code & 4) ? a.W - 1 - Cc : Cc; }
+            const long long b = bc / a.C, c = bc - b * a.C;
+            const long long off = (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
+            a.dst[off] = u * red_dpre(a.weight[off], a.op);
         }
     }
 }
@@ -870,9 +931,9 @@ extern "C" int ptb_view_transform(const float* in, float* out, int V, const int*
         const long long blocks = (long long)B * C * a.chunks_x * a.chunks_y;
         if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
         hipStream_t s = (hipStream_t)stream;
-        if (ch == 64) hipLaunchKernelGGL(view_scatter_kernel<64>, dim3((unsigned)blocks), dim3(1024), 0, s, a, B);
-        else if (ch == 32) hipLaunchKernelGGL(view_scatter_kernel<32>, dim3((unsigned)blocks), dim3(512), 0, s, a, B);
-        else hipLaunchKernelGGL(view_scatter_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, a, B);
+        if (ch == 64) hipLaunchKernelGGL((view_scatter_kernel<64, false>), dim3((unsigned)blocks), dim3(1024), 0, s, a, B);
+        else if (ch == 32) hipLaunchKernelGGL((view_scatter_kernel<32, false>), dim3((unsigned)blocks), dim3(512), 0, s, a, B);
+        else hipLaunchKernelGGL((view_scatter_kernel<16, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, B);
         return check_launch();
     }
     return run_plain(a, V * B, MODE_PERVIEW, (hipStream_t)stream);
@@ -911,4 +972,44 @@ extern "C" int ptb_debug_plan(const int64_t* xs64, const int64_t* ys64, int B, i
         for (int e = 0; e < MAX_COVER; ++e) o[8 + e] = e < c.ntiles ? c.tile[e] : -1;
     }
     return n;
+}
+
+// Backward of ptb_deaug_reduce for the non-linear reductions (gmean, hmean, harmonic1p, logodd, log1p):
+//   grad_in[k*B+b] = view_k^-1( grad_out * post'(m) / V ) * pre'(in[k*B+b])
+extern "C" int ptb_deaug_reduce_bwd(const float* in, const float* out, const float* grad_out, float* grad_in, int V, const int* views,
+                                    int reduction, int B, int C, int H, int W, ptb_stream_t stream) {
+    if (!in || !out || !grad_out || !grad_in || B < 0 || C < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_GMEAN || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, H, W)) return rc;
+    if (B == 0) return PTB_OK;
+    static const int inverse[8] = {0, 1, 2, 5, 4, 3, 6, 7};  // the two quarter turns swap, the rest are involutions
+    int inv[MAX_VIEWS];
+    for (int k = 0; k < V; ++k) inv[k] = inverse[views[k]];
+    ViewArgs a{};
+    a.src = grad_out; a.dst = grad_in; a.norm = const_cast<float*>(out); a.weight = in;
+    a.H = H; a.W = W; a.C = C;
+    a.nviews = V;
+    a.codes = pack_runtime(V, inv);
+    a.scale = 1.0f;
+    a.op = reduction;
+    a.divisor = (float)V;
+    hipStream_t s = (hipStream_t)stream;
+    const bool tr = has_transpose(V, a.codes);
+    const bool fast = !g_force_scalar && W % 4 == 0 && (!tr || H % 4 == 0) && aligned16(in) && aligned16(out) &&
+                      aligned16(grad_out) && aligned16(grad_in);
+    if (fast) {
+        const int ch = g_chunk_rows;
+        a.chunks_x = (W + CW - 1) / CW;
+        a.chunks_y = (H + ch - 1) / ch;
+        const long long blocks = (long long)B * C * a.chunks_x * a.chunks_y;
+        if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+        if (ch == 64) hipLaunchKernelGGL((view_scatter_kernel<64, true>), dim3((unsigned)blocks), dim3(1024), 0, s, a, B);
+        else if (ch == 32) hipLaunchKernelGGL((view_scatter_kernel<32, true>), dim3((unsigned)blocks), dim3(512), 0, s, a, B);
+        else hipLaunchKernelGGL((view_scatter_kernel<16, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, B);
+    } else {
+        const long long n = (long long)B * C * H * W;
+        const long long want = (n + 255) / 256;
+        hipLaunchKernelGGL(deaug_bwd_scalar_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, a, B);
+    }
+    return check_launch();
 }

@@ -103,16 +103,35 @@ class _ViewTransform(torch.autograd.Function):
         return gx, None, None, None
 
 
+def _raw_deaug_reduce_bwd(x, out, g, views, code):
+    """grad wrt x of the non-linear reductions: view_k^-1(g * post'(m) / V) * pre'(x_k), one HIP scatter launch."""
+    V = len(views)
+    n, C, H, W = x.shape
+    grad = torch.empty_like(x)
+    lib = N.load()
+    with N.on_device(x.device):
+        rc = lib.ptb_deaug_reduce_bwd(x.data_ptr(), out.data_ptr(), g.data_ptr(), grad.data_ptr(), V, N.int_array(views), code,
+                                      n // V, C, H, W, N.stream_ptr(x.device))
+    N.bump()
+    N.check(rc, "ptb_deaug_reduce_bwd")
+    return grad
+
+
 class _DeaugReduce(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, views, code):
         ctx.views, ctx.code = tuple(views), code
-        return _raw_deaug_reduce(x.contiguous(), views, code)
+        x = x.contiguous()
+        out = _raw_deaug_reduce(x, views, code)
+        if code not in (N.RED_SUM, N.RED_MEAN):
+            ctx.save_for_backward(x, out)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         if ctx.code not in (N.RED_SUM, N.RED_MEAN):
-            raise NotImplementedError("backward of non-linear TTA reductions (gmean/hmean/logodd/...) is not implemented natively yet")
+            x, out = ctx.saved_tensors
+            return _raw_deaug_reduce_bwd(x, out, g.contiguous(), list(ctx.views), ctx.code), None, None
         inv = [INVERSE[v] for v in ctx.views]
         scale = 1.0 if ctx.code == N.RED_SUM else 1.0 / len(inv)
         return _raw_view_transform(g.contiguous(), inv, True, scale), None, None
@@ -155,7 +174,10 @@ class _StackReduce(torch.autograd.Function):
             return x.new_empty(rest)
         H, W = _plane_shape(numel)
         flat = x.contiguous().view(T, 1, H, W)
-        return _raw_deaug_reduce(flat, [N.IDENT] * T, code).view(rest)
+        out = _raw_deaug_reduce(flat, [N.IDENT] * T, code)
+        if code not in (N.RED_SUM, N.RED_MEAN):
+            ctx.save_for_backward(flat, out)
+        return out.view(rest)
 
     @staticmethod
     def backward(ctx, g):
@@ -163,7 +185,9 @@ class _StackReduce(torch.autograd.Function):
             return g.unsqueeze(0).expand(ctx.T, *g.shape), None
         if ctx.code == N.RED_MEAN:
             return (g / ctx.T).unsqueeze(0).expand(ctx.T, *g.shape), None
-        raise NotImplementedError("backward of non-linear TTA reductions is not implemented natively yet")
+        flat, out = ctx.saved_tensors
+        grad = _raw_deaug_reduce_bwd(flat, out, g.contiguous().view(out.shape), [N.IDENT] * ctx.T, ctx.code)
+        return grad.view(ctx.T, *g.shape), None
 
 
 def stack_reduce(x, code):

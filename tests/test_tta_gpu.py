@@ -269,3 +269,39 @@ def test_half_precision_inputs(dev):
         assert lab.dtype == dt
     with pytest.raises(NotImplementedError):
         tta.d4_image_augment(torch.zeros((1, 1, 8, 8), device=dev, dtype=torch.int32))
+
+
+@pytest.mark.parametrize("reduction", ["gmean", "hmean", "harmonic1p", "logodd", "log1p"])
+@pytest.mark.parametrize("group,shape", [("d4", (16, 2, 48, 48)), ("d2", (8, 3, 20, 36)), ("flips", (6, 1, 15, 22))])
+def test_nonlinear_reduction_gradients(reduction, group, shape, dev):
+    """TTA "respects gradient flow" (reference tta.py:3-4) also through the non-linear reductions: compare the HIP
+    backward with torch autograd of the reference formula (inference/functional.py:250-333) on the de-augmented stack."""
+    tta = _tta()
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(shape, generator=g) * 0.9 + 0.05).to(dev)
+    y1 = y.clone().requires_grad_(True)
+    out = getattr(tta, f"{group}_image_deaugment")(y1, reduction=reduction)
+    y2 = y.clone().requires_grad_(True)
+    stack = getattr(tta, f"{group}_image_deaugment")(y2, reduction=None)   # [V, B, ...], differentiable permutation
+    ref = {
+        "gmean": lambda t: t.log().mean(0).exp(),
+        "hmean": lambda t: torch.reciprocal(torch.reciprocal(t.clamp_min(1e-6)).mean(0).clamp_min(1e-6)),
+        "harmonic1p": lambda t: torch.reciprocal(torch.reciprocal(t + 1).mean(0)) - 1,
+        "logodd": lambda t: torch.sigmoid(torch.log(t.clamp(1e-6, 1 - 1e-6) / (1 - t.clamp(1e-6, 1 - 1e-6))).mean(0)),
+        "log1p": lambda t: torch.log1p(t).mean(0).exp() - 1,
+    }[reduction](stack)
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+    w = torch.rand_like(out)
+    (out * w).sum().backward()
+    (ref * w).sum().backward()
+    torch.testing.assert_close(y1.grad, y2.grad, rtol=1e-4, atol=1e-6)
+    # generic [T, B, ...] stacks (labels, ensembling) go through the same kernel
+    lg = (torch.rand((4 * 3, 7), generator=g) * 0.9 + 0.05).to(dev)
+    l1 = lg.clone().requires_grad_(True)
+    tta.d2_labels_deaugment(l1, reduction=reduction).sum().backward()
+    l2 = lg.clone().requires_grad_(True)
+    st = l2.view(4, 3, 7)
+    {"gmean": lambda t: t.log().mean(0).exp(), "hmean": lambda t: 1 / (1 / t.clamp_min(1e-6)).mean(0).clamp_min(1e-6),
+     "harmonic1p": lambda t: 1 / (1 / (t + 1)).mean(0) - 1,
+     "logodd": lambda t: torch.sigmoid(torch.log(t / (1 - t)).mean(0)), "log1p": lambda t: torch.log1p(t).mean(0).exp() - 1}[reduction](st).sum().backward()
+    torch.testing.assert_close(l1.grad, l2.grad, rtol=1e-4, atol=1e-6)
