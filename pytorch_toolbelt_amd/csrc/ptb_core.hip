@@ -84,6 +84,11 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_ms_tiled = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 4) {
+        if (value < 0) return PTB_EINVAL;
+        g_loss_grid_cap = value;
+        return PTB_OK;
+    }
     return PTB_EINVAL;
 }
 

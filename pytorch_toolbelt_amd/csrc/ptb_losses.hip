@@ -822,9 +822,14 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int grid_for_groups(long long groups) {
+int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
+// Measured on MI355X (tools/ab_losses.py): the streaming kernels (focal fwd/bwd, softmax focal) gain ~10 % from an
+// oversubscribed grid (32 workgroups per CU, one pixel group per wave), the statistics kernels lose from it (more
+// per-workgroup LDS reductions + atomics), so they keep 8 per CU.
+constexpr int kGridStream = 256 * 32, kGridStats = 256 * 8;
+static int grid_for_groups(long long groups, int dflt) {
     const long long want = (groups + 3) / 4;
-    const long long cap = 256LL * 8;
+    const long long cap = g_loss_grid_cap > 0 ? g_loss_grid_cap : dflt;
     return (int)(want < 1 ? 1 : (want < cap ? want : cap));
 }
 
@@ -865,7 +870,8 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     if (!what) return PTB_EINVAL;
     const bool g2 = gamma == 2.0f;
     const bool vec = vec_ok(HW, {logits, dense, elem_out, labels});
-    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B) : grid_for_groups((HW + 63) / 64 * B)), block(256);
+    const int gcap = what == SEG_FOCAL ? kGridStream : kGridStats;
+    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B, gcap) : grid_for_groups((HW + 63) / 64 * B, gcap)), block(256);
     if (what == SEG_FOCAL) {
 #define PTB_FF(P, D) do { if (g2) hipLaunchKernelGGL((focal_fwd_kernel<P, D, true>), grid, block, 0, s, a); \
                           else hipLaunchKernelGGL((focal_fwd_kernel<P, D, false>), grid, block, 0, s, a); } while (0)
@@ -896,7 +902,7 @@ extern "C" int ptb_focal_bwd(const float* logits, const int64_t* labels, const f
     if ((long long)B * HW == 0) return PTB_OK;
     hipStream_t s = (hipStream_t)stream;
     const bool vec = vec_ok(HW, {logits, dense, grad_elem, grad, labels});
-    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B) : grid_for_groups((HW + 63) / 64 * B)), block(256);
+    const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B, kGridStream) : grid_for_groups((HW + 63) / 64 * B, kGridStream)), block(256);
     const bool g2 = gamma == 2.0f;
 #define PTB_FBWD(P, D, G) do { if (g2) hipLaunchKernelGGL((focal_bwd_kernel<P, D, G, true>), grid, block, 0, s, a, coef, grad_elem, grad); \
                                else hipLaunchKernelGGL((focal_bwd_kernel<P, D, G, false>), grid, block, 0, s, a, coef, grad_elem, grad); } while (0)
@@ -920,11 +926,11 @@ extern "C" int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, con
     if ((long long)B * HW == 0) return PTB_OK;
     hipStream_t s = (hipStream_t)stream;
     if (vec_ok(HW, {logits, dense, grad, labels})) {
-        const int grid = grid_for_groups((HW + 255) / 256 * B);
+        const int grid = grid_for_groups((HW + 255) / 256 * B, kGridStats);
         if (C <= 16 && labels) hipLaunchKernelGGL((seg_stats_bwd_kernel<4, 16, false>), dim3(grid), dim3(256), 0, s, a, gI, gP, grad);
         else hipLaunchKernelGGL((seg_stats_bwd_kernel<4, 0, false>), dim3(grid), dim3(256), 0, s, a, gI, gP, grad);
     } else {
-        hipLaunchKernelGGL((seg_stats_bwd_kernel<1, 0, false>), dim3(grid_for_groups((HW + 63) / 64 * B)), dim3(256), 0, s, a, gI, gP, grad);
+        hipLaunchKernelGGL((seg_stats_bwd_kernel<1, 0, false>), dim3(grid_for_groups((HW + 63) / 64 * B, kGridStats)), dim3(256), 0, s, a, gI, gP, grad);
     }
     return check_launch();
 }
@@ -932,12 +938,12 @@ extern "C" int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, con
 template <int MODE>
 static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix, float* grad, hipStream_t s) {
     if (vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
-        const int grid = grid_for_groups((a.HW + 255) / 256 * a.B);
+        const int grid = grid_for_groups((a.HW + 255) / 256 * a.B, kGridStream);
         if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else if (a.C <= 16) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else hipLaunchKernelGGL((softmax_focal_kernel<4, 0, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
     } else {
-        hipLaunchKernelGGL((softmax_focal_kernel<1, 0, MODE, false>), dim3(grid_for_groups((a.HW + 63) / 64 * a.B)), dim3(256), 0, s, a, coef, grad_pix, grad);
+        hipLaunchKernelGGL((softmax_focal_kernel<1, 0, MODE, false>), dim3(grid_for_groups((a.HW + 63) / 64 * a.B, kGridStream)), dim3(256), 0, s, a, coef, grad_pix, grad);
     }
     return check_launch();
 }

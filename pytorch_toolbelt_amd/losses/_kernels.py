@@ -14,7 +14,16 @@ SEG_FOCAL, SEG_STATS, SEG_HAS_IGNORE, SEG_HAS_ALPHA, SEG_REDUCED, SEG_MASK_FOCAL
 PROB_SOFTMAX, PROB_SIGMOID, PROB_IDENTITY = 0, 1, 2
 SUM_SLOTS = 64  # PTB_SUM_SLOTS: the kernels spread their fp64 atomics over this many copies of the sums
 
+# Labels outside [0, C): the reference's F.one_hot raises on CPU and trips a device-side assert on GPU (no host sync).
+# The kernels record the condition in a device flag.  By default the flag is checked WITHOUT synchronising: it is copied
+# to pinned host memory asynchronously and examined at the next loss call (or by ``flush_label_check()``), so a bad
+# label surfaces one call late -- the same asynchronous error model as a device assert, minus the dead context.
+# PTB_SYNC_LABEL_CHECK=1 (or ``SYNC_LABEL_CHECK = True``) checks immediately at the price of one host sync per call;
+# PTB_SKIP_LABEL_CHECK=1 disables the check.
 _CHECK_LABELS = os.environ.get("PTB_SKIP_LABEL_CHECK", "0") != "1"
+SYNC_LABEL_CHECK = os.environ.get("PTB_SYNC_LABEL_CHECK", "0") == "1"
+_LABEL_MSG = "Class values must be smaller than num_classes."
+_pending = []  # (pinned host int32 tensor, event)
 
 
 def _f32c(t, what):
@@ -28,10 +37,39 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _poll(block: bool):
+    global _pending
+    keep, bad = [], False
+    for host, ev in _pending:
+        if block:
+            ev.synchronize()
+        if block or ev.query():
+            bad = bad or int(host[0]) != 0
+        else:
+            keep.append((host, ev))
+    _pending = keep
+    if bad:
+        raise RuntimeError(_LABEL_MSG + " (reported asynchronously by an earlier loss call)")
+
+
+def flush_label_check():
+    """Wait for the outstanding label checks and raise if any loss call saw a label outside [0, C)."""
+    _poll(block=True)
+
+
 def check_labels(flag):
-    """F.one_hot raises on labels outside [0, C); the kernels record that in a device flag (one sync, like one_hot)."""
-    if _CHECK_LABELS and int(flag.item()) != 0:
-        raise RuntimeError("Class values must be smaller than num_classes.")
+    if not _CHECK_LABELS:
+        return
+    if SYNC_LABEL_CHECK:
+        if int(flag.item()) != 0:
+            raise RuntimeError(_LABEL_MSG)
+        return
+    _poll(block=False)
+    host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+    host.copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(flag.device))
+    _pending.append((host, ev))
 
 
 class SigmoidFocalSums(torch.autograd.Function):

@@ -179,10 +179,22 @@ def test_reference_kats(dev):
     assert float(crit(f([[[0, 1, 1, 0], [0, 1, 1, 0]]]), f([[[1, 1, 0, 0], [1, 1, 0, 0]]]))) == pytest.approx(1 - 1 / 3, abs=eps)
 
 
-def test_label_errors_and_modes(dev):
+def test_label_errors_and_modes(dev, monkeypatch):
     L = _L()
+    from pytorch_toolbelt_amd.losses import _kernels as K
+
     x = torch.randn((2, 3, 8, 8), device=dev)
     bad = torch.full((2, 8, 8), 7, device=dev)
+    good = torch.zeros((2, 8, 8), dtype=torch.long, device=dev)
+    # default: asynchronous report (no host sync per call) -- the error surfaces at flush / a later call
+    K.flush_label_check()
+    L.DiceLoss("multiclass")(x, bad)
+    with pytest.raises(RuntimeError, match="asynchronously"):
+        K.flush_label_check()
+    L.DiceLoss("multiclass")(x, good)
+    K.flush_label_check()
+    # synchronous mode: immediate error like the reference's F.one_hot on CPU
+    monkeypatch.setattr(K, "SYNC_LABEL_CHECK", True)
     for crit in (L.DiceLoss("multiclass"), L.JaccardLoss("multiclass"), L.BinaryFocalLoss(), L.CrossEntropyFocalLoss()):
         with pytest.raises(RuntimeError):
             crit(x, bad)
