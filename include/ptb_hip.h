@@ -171,6 +171,13 @@ int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, const float* d
                       float* grad, int B, int C, int64_t HW, int flags, int prob, int64_t ignore_label,
                       float ignore_value, ptb_stream_t stream);
 
+/* Both of the above in one pass (backward of a ptb_seg_loss_fwd call with PTB_SEG_FOCAL | PTB_SEG_STATS);
+ * PTB_EUNSUPPORTED when the fused kernel does not apply (C > 16, HW % 4 != 0, ...): use the two kernels above. */
+int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                      const float* coef, const float* gI, const float* gP, float* grad, int B, int C, int64_t HW, int flags,
+                      int prob, float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
+                      ptb_stream_t stream);
+
 /* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
  * sums double[PTB_SUM_SLOTS][2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
 int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,

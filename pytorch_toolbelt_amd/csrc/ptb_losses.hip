@@ -655,6 +655,88 @@ __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, con
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward
+// d/dlogits of (sigmoid focal sums, region statistics) in ONE pass (FocalDiceJaccardLoss): the class planes are read
+// once and the gradient is written once, instead of two backward kernels plus an add (3.4x the traffic).
+//   grad = coef[0] * dL/dx + coef[1] * dF/dx            (focal, see focal_bwd_kernel)
+//        + p_k (G_k - sum_c G_c p_c) | G p (1 - p)       (region statistics with softmax | sigmoid probabilities)
+template <int PIX, int CREG, bool DENSE, bool G2>
+__global__ __launch_bounds__(256) void seg_fused_bwd_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
+                                                            const float* __restrict__ gP, float* __restrict__ grad) {
+    const FocalCfg cfg = focal_cfg(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
+    const float k1 = coef[0], k2 = coef[1];
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, DENSE ? nullptr : a.labels, ignf, a.ignore_label, C, nullptr);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        float xv[CREG][PIX];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) xv[c][k] = 0.f;
+            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], G.ok);
+        }
+        float mx[PIX], inv[PIX], dot[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) { mx[k] = 0.f; inv[k] = 0.f; dot[k] = 0.f; }
+        if (a.prob == PROB_SOFTMAX && !DENSE) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                float m = -INFINITY;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xv[c][k]);
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) d += fexp(xv[c][k] - m);
+                const float iv = rcp(d);
+                opaque(m);  // recompute the exponentials below instead of keeping 64 of them alive
+                float dd = 0.f;
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) {
+                    const float t = G.lab[k] == c ? 1.f : 0.f;
+                    dd += (gI[c] * t + gP[c]) * fexp(xv[c][k] - m) * iv;
+                }
+                opaque(m);
+                mx[k] = m; inv[k] = iv; dot[k] = G.ign[k] ? 0.f : dd;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            if (c < C) {
+                const float w0 = a.class_weights ? a.class_weights[c] : 1.f;
+                float tv[PIX], out[PIX];
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) { tv[k] = 0.f; out[k] = 0.f; }
+                if (DENSE) load_px<PIX>(a.dense + base + (long long)c * a.HW, tv, G.ok);
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    if (!G.ok) continue;
+                    const float x = xv[c][k];
+                    float t;
+                    bool ig = G.ign[k];
+                    if (!DENSE) t = G.lab[k] == c ? 1.f : 0.f;
+                    else { t = tv[k]; if (ignf && t == a.ignore_value) ig = true; }
+                    if (ig) continue;
+                    float ce, f, df, p;
+                    focal_parts<G2, true>(x, t, cfg, ce, f, df, p);   // p = sigmoid(x)
+                    const float w = w0 * (cfg.a1 * t + cfg.a0);
+                    float gx = k1 * w * (df * ce + f * (p - t)) + k2 * df;
+                    const float Gc = gI[c] * t + gP[c];
+                    if (!DENSE && a.prob == PROB_SOFTMAX) gx += fexp(x - mx[k]) * inv[k] * (Gc - dot[k]);
+                    else if (a.prob == PROB_SIGMOID) gx += Gc * p * (1.f - p);
+                    else gx += Gc;
+                    out[k] = gx;
+                }
+                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ softmax focal
 // softmax_focal_loss_with_logits (functional.py:110-173): per pixel sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c, masked by
 // label != ignore_index.  sums[0] = sum of pixel losses, sums[1] = sum of ALL focal terms (the reference does not
@@ -964,4 +1046,25 @@ extern "C" int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels,
     if ((long long)B * HW == 0) return PTB_OK;
     SmfArgs a{logits, (const long long*)labels, class_weights, nullptr, nullptr, nullptr, B, C, HW, reduced, gamma, threshold, ignore_label};
     return launch_smf<1>(a, coef, grad_pix, grad, (hipStream_t)stream);
+}
+
+// Fused backward of ptb_seg_loss_fwd(PTB_SEG_FOCAL | PTB_SEG_STATS): returns PTB_EUNSUPPORTED when the fused kernel does
+// not apply (C > 16, unaligned, dense targets with softmax), in which case the caller uses the two separate kernels.
+extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                                 const float* coef, const float* gI, const float* gP, float* grad, int B, int C, int64_t HW, int flags,
+                                 int prob, float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
+                                 ptb_stream_t stream) {
+    SegArgs a{};
+    if (int rc = fill_seg(a, logits, labels, dense, class_weights, B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
+    if (!coef || !gI || !gP || !grad) return PTB_EINVAL;
+    if ((long long)B * HW == 0) return PTB_OK;
+    if (C > 16 || !vec_ok(HW, {logits, dense, grad, labels}) || (dense && prob == PROB_SOFTMAX)) return PTB_EUNSUPPORTED;
+    const dim3 grid(grid_for_groups((HW + 255) / 256 * B, kGridStats)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool g2 = gamma == 2.0f;
+#define PTB_FUSED(D) do { if (g2) hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, true>), grid, block, 0, s, a, coef, gI, gP, grad); \
+                          else hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, false>), grid, block, 0, s, a, coef, gI, gP, grad); } while (0)
+    if (labels) PTB_FUSED(false); else PTB_FUSED(true);
+#undef PTB_FUSED
+    return check_launch();
 }

@@ -238,9 +238,18 @@ class FusedSegSums(torch.autograd.Function):
         B, C, HW = x.shape
         lib = N.load()
         grad = torch.empty_like(x)
-        grad2 = torch.empty_like(x)
         coef = g_focal.to(torch.float32).contiguous()
         gs = g_stats.to(torch.float32).contiguous()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_fused_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), coef.data_ptr(), gs[0].data_ptr(),
+                                       gs[1].data_ptr(), grad.data_ptr(), B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label,
+                                       ignore_value, N.stream_ptr(x.device))
+        if rc == 0:
+            N.bump()
+            return grad, None, None, None, None, None, None, None, None, None, None
+        if rc != -2:
+            N.check(rc, "ptb_seg_fused_bwd")
+        grad2 = torch.empty_like(x)
         with N.on_device(x.device):
             rc = lib.ptb_focal_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), coef.data_ptr(), None, grad.data_ptr(),
                                    B, C, HW, flags, gamma, alpha, threshold, ignore_label, ignore_value, N.stream_ptr(x.device))

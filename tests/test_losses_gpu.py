@@ -377,6 +377,14 @@ def test_fused_focal_dice_jaccard(dev):
     want = LO.binary_focal_loss(logits.numpy(), labels.numpy(), alpha=0.25) + 0.5 * LO.dice_loss(logits.numpy(), labels.numpy(), "multiclass") + 2.0 * LO.jaccard_loss(logits.numpy(), labels.numpy(), "multiclass")
     assert float(fused) == pytest.approx(float(want), abs=1e-5)
     ml = (torch.rand((3, 16, 64, 80)) < 0.3).float()
+    xa = xl.clone().requires_grad_(True)
+    fa = L.FocalDiceJaccardLoss("multilabel", gamma=1.5, ignore_index=None)(xa, ml.to(dev))
+    xb = xl.clone().requires_grad_(True)
+    fb = L.BinaryFocalLoss(gamma=1.5)(xb, ml.to(dev)) + L.DiceLoss("multilabel")(xb, ml.to(dev)) + L.JaccardLoss("multilabel")(xb, ml.to(dev))
+    torch.testing.assert_close(fa, fb, rtol=1e-6, atol=1e-6)
+    fa.backward()
+    fb.backward()
+    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-5, atol=1e-8)
     f2 = L.FocalDiceJaccardLoss("multilabel")(xl, ml.to(dev))
     w2 = LO.focal_loss_with_logits(logits.numpy(), ml.numpy(), alpha=None) + LO.dice_loss(logits.numpy(), ml.numpy(), "multilabel") + LO.jaccard_loss(logits.numpy(), ml.numpy(), "multilabel")
     assert float(f2) == pytest.approx(float(w2), abs=1e-5)
