@@ -561,6 +561,9 @@ __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, con
             float dot[PIX];
 #pragma unroll
             for (int k = 0; k < PIX; ++k) dot[k] = 0.f;
+            float mx[PIX], inv[PIX];
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) { mx[k] = 0.f; inv[k] = 0.f; }
             if (a.prob == PROB_SOFTMAX) {
 #pragma unroll
                 for (int k = 0; k < PIX; ++k) {
@@ -569,16 +572,17 @@ __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, con
                     for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xv[c][k]);
                     float d = 0.f;
 #pragma unroll
-                    for (int c = 0; c < CREG; ++c) if (c < C) { xv[c][k] = fexp(xv[c][k] - m); d += xv[c][k]; }
-                    const float inv = rcp(d);
+                    for (int c = 0; c < CREG; ++c) if (c < C) d += fexp(xv[c][k] - m);
+                    const float iv = rcp(d);
+                    opaque(m);  // recompute exp(x - m) in each pass: cheaper than 64 live values (occupancy 2 -> 4)
                     float dd = 0.f;
 #pragma unroll
                     for (int c = 0; c < CREG; ++c) if (c < C) {
-                        xv[c][k] *= inv;  // p_c
                         const float t = !DENSE ? (G.lab[k] == c ? 1.f : 0.f) : tv[DENSE ? c : 0][k];
-                        dd += (gI[c] * t + gP[c]) * xv[c][k];
+                        dd += (gI[c] * t + gP[c]) * fexp(xv[c][k] - m) * iv;
                     }
-                    dot[k] = dd;
+                    opaque(m);
+                    mx[k] = m; inv[k] = iv; dot[k] = dd;
                 }
             }
 #pragma unroll
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, con
                         if (DENSE && ignf && t == a.ignore_value) ig = true;
                         if (!ig) {
                             const float Gc = gI[c] * t + gP[c];
-                            if (a.prob == PROB_SOFTMAX) out[k] = xv[c][k] * (Gc - dot[k]);
+                            if (a.prob == PROB_SOFTMAX) out[k] = fexp(xv[c][k] - mx[k]) * inv[k] * (Gc - dot[k]);
                             else if (a.prob == PROB_SIGMOID) { const float p = sigmoid_parts(xv[c][k]).p; out[k] = Gc * p * (1.f - p); }
                             else out[k] = Gc;
                         }
