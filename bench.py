@@ -14,6 +14,7 @@ ranks by tile rows, neighbouring ranks exchange their 256-row overlap strips poi
 rank merges its own band (strong scaling: total work per step is fixed).  Rank 0 prints one JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -39,6 +40,7 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
     ap.add_argument("--memset-accumulators", action="store_true", help="A/B: zero the accumulators with a memset each step instead of first-touch stores")
     ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
+    ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
 
@@ -149,6 +151,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Host hygiene: a generation-2 Python GC pass over the ~10^5 objects torch leaves behind takes 30-45 ms (ten
+    # steps' worth) and used to land inside the timed region; collect once and freeze the survivors, as a serving loop
+    # would after start-up.
+    gc.collect()
+    gc.freeze()
+    if args.diag and rank == 0:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
+        sync()
+        tt = time.perf_counter()
+        ev[0].record()
+        hs = []
+        for i in range(40):
+            step()
+            ev[i + 1].record()
+            hs.append(round((time.perf_counter() - tt) * 1e3, 2))
+        sync()
+        print(f"[diag] cold start: gpu ms per step {[round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(40)]}", file=sys.stderr)
+        print(f"[diag] cold start: host issue done at ms {hs}", file=sys.stderr)
     for _ in range(args.warmup):
         step()
     sync()
@@ -165,6 +185,39 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    if args.diag and rank == 0:
+        per_step = []
+        for _ in range(10):
+            sync()
+            t1 = time.perf_counter()
+            step()
+            th = time.perf_counter() - t1
+            sync()
+            per_step.append((round(th * 1e3, 3), round((time.perf_counter() - t1) * 1e3, 3)))
+        depth = {}
+        for k in (1, 2, 4, 8, 16, 32):
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k):
+                step()
+            sync()
+            depth[k] = round((time.perf_counter() - t1) * 1e3 / k, 3)
+        print(f"[diag] ms/step for k unsynced steps: {depth}", file=sys.stderr)
+        calls = []
+        sync()
+        for _ in range(3):
+            merger.reset()
+            for t, c in zip(batch_tensors, batch_crops):
+                t1 = time.perf_counter()
+                merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+                calls.append((time.perf_counter() - t1) * 1e6)
+            merger.merge()
+        sync()
+        calls = np.array(calls)
+        print(f"[diag] cpus={os.cpu_count()} loadavg={os.getloadavg()} (host issue ms, step ms) per synced step: {per_step}", file=sys.stderr)
+        print(f"[diag] integrate host us: min {calls.min():.1f} median {np.median(calls):.1f} p90 {np.percentile(calls, 90):.1f} max {calls.max():.1f}", file=sys.stderr)
+        print(f"[diag] allocator: allocated {torch.cuda.memory_allocated() / 1e9:.2f} GB reserved {torch.cuda.memory_reserved() / 1e9:.2f} GB", file=sys.stderr)
 
     # ---- dominant-kernel roofline: ONE HIP-event pair (same stream) around the back-to-back run of full 8-tile launches
     # of a step (per-launch event pairs would insert a marker packet between kernels and inflate every launch by a few

@@ -742,6 +742,26 @@ static int run_plain(ViewArgs& a, int ntiles_out, int mode, hipStream_t s) {
     return check_launch();
 }
 
+static int launch_group(const ViewArgs& a, const CellArgs& g, const std::vector<Cell>& cells, const Fresh& fr, bool fast, int ch,
+                        hipStream_t s) {
+    const long long blocks = (long long)a.total_chunks * a.C;
+    if (blocks <= 0) return PTB_OK;
+    if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+    if (!fast) {
+        hipLaunchKernelGGL(view_accum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
+    } else if (ch == 64) {
+        launch_accum_ch<64>(a, g, (int)blocks, s, nonlinear);
+    } else if (ch == 32) {
+        launch_accum_ch<32>(a, g, (int)blocks, s, nonlinear);
+    } else {
+        launch_accum_ch<16>(a, g, (int)blocks, s, nonlinear);
+    }
+    const int rc = check_launch();
+    if (rc == PTB_OK) mark_written(cells, fr);
+    return rc;
+}
+
 // Accumulate a run of tiles [lo, hi) of the batch; splits recursively until each launch group decomposes.
 static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, bool fast, int ch, const Fresh& fr, hipStream_t s) {
     if (lo >= hi) return PTB_OK;
@@ -761,21 +781,7 @@ static int run_accum(ViewArgs& a, const int* xs, const int* ys, int lo, int hi, 
         const int rc = run_accum(a, xs, ys, lo, mid, fast, ch, fr, s);
         return rc ? rc : run_accum(a, xs, ys, mid, hi, fast, ch, fr, s);
     }
-    const long long blocks = (long long)a.total_chunks * a.C;
-    if (blocks <= 0) return PTB_OK;
-    const bool nonlinear = a.op >= PTB_RED_GMEAN;
-    if (!fast) {
-        hipLaunchKernelGGL(view_accum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
-    } else if (ch == 64) {
-        launch_accum_ch<64>(a, g, (int)blocks, s, nonlinear);
-    } else if (ch == 32) {
-        launch_accum_ch<32>(a, g, (int)blocks, s, nonlinear);
-    } else {
-        launch_accum_ch<16>(a, g, (int)blocks, s, nonlinear);
-    }
-    const int rc = check_launch();
-    if (rc == PTB_OK) mark_written(cells, fr);
-    return rc;
+    return launch_group(a, g, cells, fr, fast, ch, s);
 }
 
 // Dry run of run_accum's grouping on a scratch bitmap: PTB_EFRESH if any launch group would need a zero-fill.
@@ -854,11 +860,30 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
         if (fresh_rows < 1) return PTB_EINVAL;
         if (fresh_rows != ch) return PTB_EFRESH;  // bitmap granularity differs from this launch's chunk rows
         // a batch that is split into several launches may have been partly applied when a later part needs zeroing:
-        // decide on a scratch copy of the bitmap first
-        std::vector<uint8_t> probe(fresh, fresh + (size_t)fr.nbx() * fr.nby());
-        Fresh pf{probe.data(), fresh_rows, H, W};
-        const int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, ch, pf);
-        if (rc) return rc;
+        // decide on a scratch copy of the bitmap first (skipped in the common case of a batch that is one launch group,
+        // where run_accum itself reports PTB_EFRESH before anything is launched)
+        if (B > MAX_GROUP || B > 16) {
+            std::vector<uint8_t> probe(fresh, fresh + (size_t)fr.nbx() * fr.nby());
+            Fresh pf{probe.data(), fresh_rows, H, W};
+            const int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, ch, pf);
+            if (rc) return rc;
+        } else {
+            CellArgs g;
+            int ids[MAX_GROUP], nc = 0, tc = 0;
+            std::vector<Cell> cells;
+            for (int t = 0; t < B; ++t) ids[t] = t;
+            const int st = decompose(xs.data(), ys.data(), ids, B, tw, th, ch, fr, g, nc, tc, cells);
+            if (st == DECOMP_NEEDS_ZERO) return PTB_EFRESH;
+            if (st == DECOMP_SPLIT) {  // rare: several groups after all -> full dry run
+                std::vector<uint8_t> probe(fresh, fresh + (size_t)fr.nbx() * fr.nby());
+                Fresh pf{probe.data(), fresh_rows, H, W};
+                const int rc = probe_accum(xs.data(), ys.data(), 0, B, tw, th, ch, pf);
+                if (rc) return rc;
+            } else {  // one group: launch it right away with the plan we already have
+                a.ncells = nc; a.total_chunks = tc;
+                return launch_group(a, g, cells, fr, fast, ch, s);
+            }
+        }
     }
     return run_accum(a, xs.data(), ys.data(), 0, B, fast, ch, fr, s);
 }

@@ -311,8 +311,9 @@ class TileMerger:
             )
         if B and (np.any(coords[:, 2] != tw) or np.any(coords[:, 3] != th)):
             raise RuntimeError("crop size in crop_coords does not match the tile / weight size")
-        xs = N.i64_array(coords[:, 0].tolist())
-        ys = N.i64_array(coords[:, 1].tolist())
+        xy = np.ascontiguousarray(coords[:, :2].T)          # [2, B] int64: xs row, ys row (host arrays for the C ABI)
+        xs = xy[0].ctypes.data_as(N._i64p)
+        ys = xy[1].ctypes.data_as(N._i64p)
         lib = N.load()
         dev = self._image.device
         varr = N.int_array(views) if views is not None else None
