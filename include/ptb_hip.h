@@ -91,6 +91,23 @@ int ptb_merge_div(const float* image, const float* norm, float* out, int C, int6
 int ptb_merge_div_ex(const float* image, const float* norm, float* out, int C, int64_t HW, int64_t image_cs, int64_t out_cs,
                      const float* extra, int64_t extra_cs, int64_t extra_n, ptb_stream_t stream);
 
+/* ---- Loop edges on the device (compositions of reference functions, no single counterpart) ---------
+ * ptb_split_tiles_u8 == ImageSlicer.split (inference/tiles.py:177-204, BORDER_CONSTANT only) -> image_to_tensor
+ * (utils/torch_utils.py:204-231, HWC->CHW) -> .float() [-> * scale[c] + bias[c]] [-> *_image_augment, tta.py:385-422]:
+ * image DEVICE uint8 [IH, IW, IC] contiguous; xs/ys HOST int64[B] = tile origins in IMAGE coordinates (the slicer's
+ * bbox_crops: negative / overhanging parts read pad_value); views HOST int[V] (augment view codes; {PTB_VIEW_IDENT} for
+ * none); scale/bias HOST float[IC] or both NULL; out DEVICE fp32 [V*B, IC, th, tw] chunk-major.  IC <= 16, V <= 8. */
+int ptb_split_tiles_u8(const uint8_t* image, int IH, int IW, int IC, const int64_t* xs, const int64_t* ys, int B, int th, int tw,
+                       int V, const int* views, const float* scale, const float* bias, int pad_value, float* out,
+                       ptb_stream_t stream);
+/* ptb_merge_crop == TileMerger.merge (tiles.py:345-346) -> np.moveaxis(.., 0, -1) -> .astype(uint8) | argmax
+ * -> ImageSlicer.crop_to_orignal_size (tiles.py:271-280; README.md:225-226): window [top, top+OH) x [left, left+OW) of
+ * image[C,H,W] / norm[H,W].  layout 0: out [C, OH, OW], 1: out [OH, OW, C].  kind 0: float32; 1: uint8 by truncating
+ * cast (numpy .astype on x86-64: low byte of the int32 truncation, 0 for NaN / out of int32 range); 2 / 3: argmax over
+ * channels as uint8 / int64 [OH, OW] (first maximum, NaN counts as maximum; layout ignored). */
+int ptb_merge_crop(const float* image, const float* norm, int C, int H, int W, int top, int left, int OH, int OW, int layout,
+                   int kind, void* out, ptb_stream_t stream);
+
 /* ---- {fliplr,flipud,flips,d2,d4}_image_deaugment (inference/tta.py:287-316,344-365,442-467,503-524) -------------
  * in [V*B, C, H, W] (chunk-major: rows [k*B,(k+1)*B) are view k), views HOST int[V] = inverse transform of each chunk.
  * out [B, C, H, W] = reduce_k view_k(in[k*B + b]).  V <= 8.  Transposing views require H == W. */

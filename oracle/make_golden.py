@@ -339,7 +339,68 @@ def gen_losses():
     save("losses.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- loop edges (8f-1)
+def gen_edges():
+    """The compositions at both ends of the README loop (README.md:196-227), run with the reference's own functions."""
+    from pytorch_toolbelt.utils import torch_utils as rtu
+
+    A, cases = {}, []
+    rng = np.random.default_rng(7)
+    aug_fns = {"d4": rtta.d4_image_augment, "d2": rtta.d2_image_augment, "fliplr": rtta.fliplr_image_augment,
+               "flipud": rtta.flipud_image_augment, "flips": rtta.flips_image_augment, None: lambda t: t}
+    front = [
+        dict(image_shape=[75, 83, 3], tile_size=[32, 32], tile_step=[16, 16], augment="d4"),
+        dict(image_shape=[64, 50, 2], tile_size=[32, 24], tile_step=[16, 12], augment="d2", affine=True),
+        dict(image_shape=[50, 47], tile_size=[16, 16], tile_step=[16, 16], augment="fliplr"),
+        dict(image_shape=[100, 130, 1], tile_size=[48, 64], tile_step=[24, 64], image_margin=[3, 5, 7, 9], augment="flips", affine=True, value=7),
+        dict(image_shape=[40, 40, 3], tile_size=64, tile_step=32, augment="d4"),
+        dict(image_shape=[97, 61, 4], tile_size=[17, 13], tile_step=[5, 13], augment="flipud", indices=[3, 4, 5, 40, 2]),
+        dict(image_shape=[97, 61, 4], tile_size=[17, 13], tile_step=[5, 13], augment=None),
+        dict(image_shape=[45, 45, 3], tile_size=[15, 15], tile_step=[10, 10], augment="d4", affine=True),
+    ]
+    for k, g in enumerate(front):
+        img = rng.integers(0, 256, g["image_shape"], dtype=np.uint8)
+        s = rt.ImageSlicer(img.shape, g["tile_size"], g["tile_step"], image_margin=g.get("image_margin", 0))
+        tiles = [rtu.tensor_from_rgb_image(t) for t in s.split(img, value=g.get("value", 0))]      # README.md:209
+        idx = g.get("indices") or list(range(len(tiles)))
+        batch = torch.stack([tiles[i] for i in idx]).float()                                       # README.md:216
+        C = batch.shape[1]
+        if g.get("affine"):
+            scale = (1.0 / (255.0 * rng.uniform(0.2, 0.3, C))).astype(np.float32)
+            bias = (-rng.uniform(0.4, 0.5, C) / rng.uniform(0.2, 0.3, C)).astype(np.float32)
+            batch = batch * torch.from_numpy(scale).view(1, C, 1, 1) + torch.from_numpy(bias).view(1, C, 1, 1)
+            A[f"front{k}_scale"], A[f"front{k}_bias"] = scale, bias
+        out = aug_fns[g["augment"]](batch)
+        A[f"front{k}_image"] = img
+        A[f"front{k}_out"] = t2n(out)
+        cases.append(dict(name=f"front{k}", fn="tiles_to_batch", kwargs=g))
+
+    gt = torch.Generator().manual_seed(11)
+    back = [
+        dict(image_shape=[96, 80, 3], tile_size=[32, 32], tile_step=[16, 16], weight="pyramid", channels=3, batch=4),
+        dict(image_shape=[75, 83, 3], tile_size=[32, 24], tile_step=[16, 12], weight="pyramid", channels=2, batch=5),
+        dict(image_shape=[50, 70, 3], tile_size=[20, 28], tile_step=[7, 9], weight="pyramid", channels=4, batch=8),
+        dict(image_shape=[61, 33, 3], tile_size=[16, 16], tile_step=[16, 16], weight="mean", channels=1, batch=3),
+    ]
+    for k, g in enumerate(back):
+        s = rt.ImageSlicer(g["image_shape"], g["tile_size"], g["tile_step"], weight=g["weight"])
+        n, C = len(s.crops), g["channels"]
+        pred = torch.rand((n, C, *s.tile_size), generator=gt) * 255.0
+        m = rt.TileMerger(s.target_shape, C, s.weight)
+        for b0 in range(0, n, g["batch"]):
+            m.integrate_batch(pred[b0:b0 + g["batch"]], s.crops[b0:b0 + g["batch"]])
+        merged = m.merge()
+        hwc = np.moveaxis(rtu.to_numpy(merged), 0, -1)                                             # README.md:225
+        A[f"back{k}_pred"] = t2n(pred)
+        A[f"back{k}_hwc_f32"] = s.crop_to_orignal_size(hwc)
+        A[f"back{k}_hwc_u8"] = s.crop_to_orignal_size(hwc.astype(np.uint8))                        # README.md:225-226
+        A[f"back{k}_argmax"] = s.crop_to_orignal_size(rtu.to_numpy(merged.argmax(dim=0)))
+        cases.append(dict(name=f"back{k}", fn="merge_crop", kwargs=g))
+    save("edges.npz", A, cases)
+
+
 if __name__ == "__main__":
     gen_tiles()
     gen_tta()
     gen_losses()
+    gen_edges()

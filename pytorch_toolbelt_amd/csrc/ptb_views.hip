@@ -22,136 +22,9 @@
 #include <algorithm>
 #include <vector>
 
-#include "ptb_common.h"
+#include "ptb_view_device.h"
 
 namespace ptb {
-
-constexpr int MAX_VIEWS = 8;
-constexpr int MAX_T = 4;       // LDS tiles: at most 4 of 8 D4 views transpose
-constexpr int MAX_CELLS = 64;  // per launch (kernarg budget)
-constexpr int MAX_COVER = 4;   // tiles covering one cell
-constexpr int MAX_GROUP = 64;  // tiles per launch in accumulate mode
-constexpr int CW = 64;         // chunk columns (256 B row segments)
-
-// number of LDS transpose tiles a kernel instantiation needs (CODES < 0: view codes known only at run time)
-constexpr int lds_tiles(int nv, int codes) {
-    if (codes < 0) return nv < MAX_T ? nv : MAX_T;
-    int n = 0;
-    for (int k = 0; k < nv; ++k) n += (codes >> (3 * k)) & 1;
-    return n;
-}
-
-struct Cell {
-    int ox, oy, w, h;     // rectangle in accumulator coordinates
-    int chunk_end;        // exclusive prefix of chunk counts (cells sorted heavy-first)
-    int ntiles;
-    int fresh;            // 1: no element of this cell was ever written -> store instead of read-modify-write
-    int tile[MAX_COVER];  // group-local tile indices, ascending batch order
-};
-
-struct CellArgs {
-    Cell cells[MAX_CELLS];
-    int tile_x[MAX_GROUP];
-    int tile_y[MAX_GROUP];
-    int tile_id[MAX_GROUP];  // index into the batch (source tile)
-};
-
-struct ViewArgs {
-    const float* src;
-    float* dst;           // plain output, or the accumulator image
-    float* norm;          // accumulate mode
-    const float* weight;  // accumulate mode, [H, W] of the tile
-    int H, W, C;          // output-tile rows / cols, channels
-    long long src_view_stride;  // elements between consecutive views of one tile (B*C*H*W)
-    long long src_tile_stride;  // C*H*W
-    long long dst_tile_stride;
-    long long dst_chan_stride;
-    int dst_row_stride;
-    int nviews;
-    int codes;           // 3 bits per view
-    int tiles_per_view;  // per-view mode: out tile t uses view t / tiles_per_view ...
-    int src_tile_mod;    // ... and source tile t % src_tile_mod
-    int op;              // PTB_RED_*
-    float divisor;       // linear ops: out = sum / divisor (1 for sum); non-linear: mean divisor
-    float scale;         // per-view mode multiplier
-    int chunks_x, chunks_y;  // plain modes: chunks per tile
-    int ncells, total_chunks;
-};
-
-enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
-
-// ------------------------------------------------------------------------------------------------ reductions
-constexpr float kEps = 1e-6f;
-constexpr float kOneMinusEps = (float)(1.0 - 1e-6);
-
-template <int OPK>
-__device__ __forceinline__ float red_pre(float x, int op) {
-    if (OPK == 0) return x;
-    switch (op) {
-        case PTB_RED_GMEAN: return logf(x);                                   // functional.py:261
-        case PTB_RED_HMEAN: return 1.0f / (x < kEps ? kEps : x);              // functional.py:275
-        case PTB_RED_HARMONIC1P: return 1.0f / (x + 1.0f);                    // functional.py:292
-        case PTB_RED_LOGODD: {                                               // functional.py:311-312
-            float p = x < kEps ? kEps : (x > kOneMinusEps ? kOneMinusEps : x);
-            return logf(p / (1.0f - p));
-        }
-        case PTB_RED_LOG1P: return log1pf(x);                                 // functional.py:330
-        default: return x;
-    }
-}
-
-template <int OPK>
-__device__ __forceinline__ float red_post(float s, int op, float divisor) {
-    if (OPK == 0) return divisor == 1.0f ? s : s / divisor;
-    const float m = s / divisor;
-    switch (op) {
-        case PTB_RED_GMEAN: return expf(m);
-        case PTB_RED_HMEAN: return 1.0f / (m < kEps ? kEps : m);
-        case PTB_RED_HARMONIC1P: return 1.0f / m - 1.0f;
-        case PTB_RED_LOGODD: { const float e = expf(m); return e / (1.0f + e); }
-        case PTB_RED_LOG1P: return expf(m) - 1.0f;
-        default: return m;
-    }
-}
-
-// d post / d m expressed through the forward output, and d pre / d x, for the backward of the non-linear reductions
-__device__ __forceinline__ float red_dpost(float out, int op) {
-    switch (op) {
-        case PTB_RED_GMEAN: return out;                                         // out = exp(m)
-        case PTB_RED_HMEAN: return out >= 1.0f / kEps ? 0.f : -out * out;        // out = 1 / max(m, eps)
-        case PTB_RED_HARMONIC1P: return -(out + 1.0f) * (out + 1.0f);           // out = 1/m - 1
-        case PTB_RED_LOGODD: return out * (1.0f - out);                         // out = sigmoid(m)
-        case PTB_RED_LOG1P: return out + 1.0f;                                  // out = exp(m) - 1
-        default: return 1.0f;
-    }
-}
-__device__ __forceinline__ float red_dpre(float x, int op) {
-    switch (op) {
-        case PTB_RED_GMEAN: return 1.0f / x;
-        case PTB_RED_HMEAN: return x < kEps ? 0.f : -1.0f / (x * x);
-        case PTB_RED_HARMONIC1P: return -1.0f / ((x + 1.0f) * (x + 1.0f));
-        case PTB_RED_LOGODD: return (x < kEps || x > kOneMinusEps) ? 0.f : 1.0f / (x * (1.0f - x));
-        case PTB_RED_LOG1P: return 1.0f / (1.0f + x);
-        default: return 1.0f;
-    }
-}
-
-// XOR-swizzled [CH][64] fp32 LDS tile: 16-byte slots of a row are permuted by (row/4) so that the transposing
-// scatter (lanes walk rows) spreads over banks and the b128 gather (16 lanes per row) stays conflict-free.
-__device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + (j & 3); }
-
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-// 16-byte global load; NT = non-temporal (streamed once: do not keep the line in L2 / Infinity Cache, which is left to
-// the accumulator read-modify-writes).  On MI355X nt streaming reads measured +8..15 % HBM bandwidth (tools/bw_probe).
-template <bool NT>
-__device__ __forceinline__ float4 ld16(const float* p) {
-    const v4f* q = reinterpret_cast<const v4f*>(p);
-    const v4f v = NT ? __builtin_nontemporal_load(q) : *q;
-    return make_float4(v.x, v.y, v.z, v.w);
-}
-
-__device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }
 
 // Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
 // tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
@@ -330,7 +203,6 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
 // a.divisor = V) and every destination is multiplied by pre'(x_k) read at the destination (a.weight = forward input).
 template <int CH, bool NONLIN>
 __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a, int B) {
-    constexpr int SL = CH / 4;  // 16-byte slots per LDS row
     __shared__ __attribute__((aligned(16))) float st[CW * CH];
     const int tid = threadIdx.x;
     const int cpt = a.chunks_x * a.chunks_y;
@@ -353,49 +225,7 @@ __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a,
         v.x *= red_dpost(o4.x, a.op) / a.divisor; v.y *= red_dpost(o4.y, a.op) / a.divisor;
         v.z *= red_dpost(o4.z, a.op) / a.divisor; v.w *= red_dpost(o4.w, a.op) / a.divisor;
     }
-    bool any_t = false;
-    for (int k = 0; k < a.nviews; ++k) {
-        const int code = (a.codes >> (3 * k)) & 7;
-        if (code & 1) { any_t = true; continue; }
-        if (act) {   // out[i][j] = src[fr ? H-1-i : i][fc ? W-1-j : j]  <=>  src (R, Cc) lands at i = R or H-1-R, j = Cc or W-1-Cc
-            const int i = (code & 2) ? a.H - 1 - (y0 + r) : y0 + r;
-            const int j = (code & 4) ? a.W - 4 - (x0 + 4 * q) : x0 + 4 * q;
-            const long long off = (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
-            float4 w = (code & 4) ? make_float4(v.w, v.z, v.y, v.x) : v;
-            if (NONLIN) {
-                const float4 x4 = ld16<true>(a.weight + off);
-                w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
-            }
-            *reinterpret_cast<float4*>(a.dst + off) = w;
-        }
-    }
-    if (!any_t) return;
-    if (act) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int col = 4 * q + m;  // source column -> LDS row
-            st[col * CH + ((((r >> 2) ^ (col >> 2)) & (SL - 1)) << 2) + (r & 3)] = comp(v, m);
-        }
-    }
-    __syncthreads();
-    const int ii = tid / SL, qq = tid % SL;  // LDS row (source column) and slot (4 source rows)
-    if (ii < cw && 4 * qq < ch) {
-        const float4 t = *reinterpret_cast<const float4*>(&st[ii * CH + (((qq ^ (ii >> 2)) & (SL - 1)) << 2)]);
-        for (int k = 0; k < a.nviews; ++k) {
-            const int code = (a.codes >> (3 * k)) & 7;
-            if (!(code & 1)) continue;
-            // out[i][j] = src[fr ? N-1-j : j][fc ? N-1-i : i]: source column Cc = x0+ii gives the out row, source rows give out cols
-            const int i = (code & 4) ? a.W - 1 - (x0 + ii) : x0 + ii;
-            const int j = (code & 2) ? a.H - 4 - (y0 + 4 * qq) : y0 + 4 * qq;
-            const long long off = (((long long)k * B + b) * a.C + c) * plane + (long long)i * a.W + j;
-            float4 w = (code & 2) ? make_float4(t.w, t.z, t.y, t.x) : t;
-            if (NONLIN) {
-                const float4 x4 = ld16<true>(a.weight + off);
-                w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
-            }
-            *reinterpret_cast<float4*>(a.dst + off) = w;
-        }
-    }
+    scatter_chunk<CH, NONLIN>(a, B, b, c, x0, y0, cw, ch, v, st, tid);
 }
 
 // scalar fallback of the non-linear backward (any shape): one thread per element of the reduced tensor

@@ -182,6 +182,61 @@ class ImageSlicer:
         assert crop.shape[1] == self.image_width
         return crop
 
+    # ------------------------------------------------------------------ device-side split
+    def split_device(self, image: torch.Tensor, indices=None, augment=None, scale=None, bias=None, value: int = 0) -> torch.Tensor:
+        """Model input for the tiles ``indices`` straight from a uint8 image that already lives in HBM.
+
+        Equals ``torch.stack([image_to_tensor(t) for t in self.split(image)][indices]).float()`` (optionally
+        ``* scale[c] + bias[c]`` and then ``tta.<augment>_image_augment``) -- the front of the reference's loop
+        (README.md:209-216; tiles.py:177-204; utils/torch_utils.py:204-231) -- but as ONE HIP launch: no padded copy,
+        no per-tile HWC->CHW copies, no fp32 upload.  ``image``: CUDA uint8 ``[H, W, C]`` or ``[H, W]``;
+        ``indices``: None (all tiles), a slice, or a sequence of tile indices; ``augment``: None | "fliplr" | "flipud" |
+        "flips" | "d2" | "d4"; ``scale`` / ``bias``: per-channel sequences (both or neither); ``value``: constant border.
+        Returns fp32 ``[V*n, C, tile_h, tile_w]``, chunk-major like the augment functions.
+        """
+        from .tta import AUGMENT_VIEWS
+
+        N.require_device(image, "ImageSlicer.split_device")
+        if image.dtype != torch.uint8:
+            raise NotImplementedError(f"split_device takes a uint8 image, got {image.dtype}")
+        if image.dim() not in (2, 3) or image.shape[0] != self.image_height or image.shape[1] != self.image_width:
+            raise ValueError(f"image of shape {tuple(image.shape)} does not match the slicer ({self.image_height}, {self.image_width})")
+        if augment is not None and augment not in AUGMENT_VIEWS:
+            raise KeyError(augment)
+        views = list(AUGMENT_VIEWS[augment]) if augment is not None else [N.IDENT]
+        th, tw = int(self.tile_size[0]), int(self.tile_size[1])
+        if any(v & 1 for v in views) and th != tw:
+            raise ValueError(f"Input tensor must have number of rows equal to number of cols. Got tiles of {th}x{tw}")
+        channels = 1 if image.dim() == 2 else int(image.shape[2])
+        if (scale is None) != (bias is None):
+            raise ValueError("scale and bias go together")
+        if indices is None:
+            boxes = self.bbox_crops
+        elif isinstance(indices, slice):
+            boxes = self.bbox_crops[indices]
+        else:
+            boxes = self.bbox_crops[np.asarray(indices, dtype=np.int64).reshape(-1)]
+        n = len(boxes)
+        image = image.contiguous()
+        out = torch.empty((len(views) * n, channels, th, tw), device=image.device, dtype=torch.float32)
+        if n == 0:
+            return out
+        xy = np.ascontiguousarray(np.asarray(boxes, dtype=np.int64)[:, :2].T)
+        fa = None
+        if scale is not None:
+            sc = np.ascontiguousarray(np.broadcast_to(np.asarray(scale, dtype=np.float32).reshape(-1), (channels,)))
+            bi = np.ascontiguousarray(np.broadcast_to(np.asarray(bias, dtype=np.float32).reshape(-1), (channels,)))
+            fa = (sc.ctypes.data_as(N._fp), bi.ctypes.data_as(N._fp))
+        lib = N.load()
+        with N.on_device(image.device):
+            rc = lib.ptb_split_tiles_u8(image.data_ptr(), self.image_height, self.image_width, channels,
+                                        xy[0].ctypes.data_as(N._i64p), xy[1].ctypes.data_as(N._i64p), n, th, tw,
+                                        len(views), N.int_array(views), fa[0] if fa else None, fa[1] if fa else None,
+                                        int(value), out.data_ptr(), N.stream_ptr(image.device))
+        N.bump()
+        N.check(rc, "ImageSlicer.split_device")
+        return out
+
     def _mean(self, tile_size):
         return np.ones((tile_size[0], tile_size[1]), dtype=np.float32)
 
@@ -388,6 +443,49 @@ class TileMerger:
         """In-place ``image /= norm_mask``; returns ``image``."""
         self._materialize()
         return self._merge_into(self._image)
+
+    _CROP_KINDS = {"float32": (0, torch.float32), "uint8": (1, torch.uint8), "argmax_u8": (2, torch.uint8), "argmax_i64": (3, torch.int64)}
+
+    def merge_crop(self, crop, layout: str = "hwc", dtype=torch.float32, argmax: bool = False) -> torch.Tensor:
+        """``merge()`` + channel-last + cast + ``crop_to_orignal_size`` in one pass over the cropped window only.
+
+        Equals ``tiler.crop_to_orignal_size(np.moveaxis(to_numpy(merger.merge()), 0, -1).astype(dtype))`` -- the tail
+        of the reference's loop (README.md:225-226; tiles.py:345-346, 271-280) -- as a device tensor, so 25-100 MB
+        travel to the host instead of the 419 MB padded fp32 map.  ``crop``: the ``ImageSlicer`` (its margins and
+        image size are used) or ``(top, left, height, width)``; ``layout``: "hwc" | "chw"; ``dtype``: torch.float32 |
+        torch.uint8 (truncating cast, like ``ndarray.astype``); ``argmax=True`` returns ``[H, W]`` class indices
+        (``dtype`` uint8 or int64) instead.
+        """
+        if isinstance(crop, ImageSlicer):
+            top, left, oh, ow = crop.margin_top, crop.margin_left, crop.image_height, crop.image_width
+        else:
+            top, left, oh, ow = (int(v) for v in crop)
+        if layout not in ("hwc", "chw"):
+            raise ValueError(f"layout must be 'hwc' or 'chw', got {layout!r}")
+        if argmax:
+            key = {torch.uint8: "argmax_u8", torch.int64: "argmax_i64", torch.float32: "argmax_i64"}.get(dtype)
+        else:
+            key = {torch.float32: "float32", torch.uint8: "uint8"}.get(dtype)
+        if key is None:
+            raise NotImplementedError(f"merge_crop: dtype {dtype} is not supported")
+        kind, out_dtype = self._CROP_KINDS[key]
+        if top < 0 or left < 0 or oh < 0 or ow < 0 or top + oh > self.image_height or left + ow > self.image_width:
+            raise ValueError("crop window is outside the accumulator")
+        self._materialize()
+        self._check_state()
+        shape = (oh, ow) if argmax else ((oh, ow, self.channels) if layout == "hwc" else (self.channels, oh, ow))
+        out = torch.empty(shape, device=self._image.device, dtype=out_dtype)
+        if out.numel() == 0:
+            return out
+        lib = N.load()
+        dev = self._image.device
+        with N.on_device(dev):
+            rc = lib.ptb_merge_crop(self._image.data_ptr(), self._norm.data_ptr(), self.channels, self.image_height,
+                                    self.image_width, top, left, oh, ow, 1 if layout == "hwc" else 0, kind, out.data_ptr(),
+                                    N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger.merge_crop")
+        return out
 
 
 class CudaTileMerger(TileMerger):

@@ -1,0 +1,209 @@
+"""GPU parity of the device-side loop edges: ImageSlicer.split_device and TileMerger.merge_crop (HIP,
+through the C ABI) vs the golden vectors produced by the reference's own functions (tests/golden/edges.npz) and vs the
+numpy oracle.  Everything here is bit-exact: uint8 -> float is exact, the affine is two fp32 roundings, the merge is an
+IEEE division of bit-exact accumulators, casts and argmax are integer work."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import edges_oracle as EO
+from oracle import tiles_oracle as TO
+
+pytestmark = pytest.mark.gpu
+
+GE = load_golden("edges.npz")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def native():
+    from pytorch_toolbelt_amd import _native as N
+
+    lib = N.load()
+    yield N
+    lib.ptb_set_tunable(0, 32)
+    lib.ptb_set_tunable(1, 0)
+
+
+def _slicer(kw, weight="mean"):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    return ImageSlicer(kw["image_shape"], kw["tile_size"], kw["tile_step"], weight=kw.get("weight", weight),
+                       image_margin=kw.get("image_margin", 0))
+
+
+@pytest.mark.parametrize("scalar", [0, 1])
+@pytest.mark.parametrize("case", GE.by_fn("tiles_to_batch"), ids=lambda c: c["name"])
+def test_golden_split_device_bit_exact(case, scalar, dev, native):
+    kw, n = case["kwargs"], case["name"]
+    native.load().ptb_set_tunable(1, scalar)
+    s = _slicer(kw)
+    img = torch.from_numpy(GE[f"{n}_image"]).to(dev)
+    scale = GE[f"{n}_scale"] if kw.get("affine") else None
+    bias = GE[f"{n}_bias"] if kw.get("affine") else None
+    before = native.calls
+    out = s.split_device(img, kw.get("indices"), augment=kw.get("augment"), scale=scale, bias=bias, value=kw.get("value", 0))
+    assert native.calls > before
+    want = GE[f"{n}_out"]
+    assert out.dtype == torch.float32 and tuple(out.shape) == want.shape
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("chunk_rows", [16, 32, 64])
+@pytest.mark.parametrize("shape,tile,step,margin,augment", [
+    ((300, 420, 3), (128, 128), (64, 64), 0, "d4"),
+    ((257, 190, 4), (64, 96), (32, 48), (5, 9, 3, 20), "d2"),
+    ((130, 131), (64, 64), (64, 64), 0, "d4"),
+    ((100, 90, 1), (40, 36), (20, 12), 7, "flips"),
+    ((90, 75, 3), (36, 36), (18, 18), 0, "d4"),     # 36 % 4 == 0 but not a multiple of the chunk width
+])
+def test_split_device_matches_oracle(shape, tile, step, margin, augment, chunk_rows, dev, native):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    native.load().ptb_set_tunable(0, chunk_rows)
+    rng = np.random.default_rng(hash((shape, tile)) & 0xFFFF)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    s = ImageSlicer(img.shape, tile, step, image_margin=margin)
+    g = TO.slicer_geometry(img.shape, tile, step, margin)
+    C = 1 if img.ndim == 2 else img.shape[2]
+    scale = rng.uniform(0.001, 0.02, C).astype(np.float32)
+    bias = rng.uniform(-2, 2, C).astype(np.float32)
+    dimg = torch.from_numpy(img).to(dev)
+    n = len(s.crops)
+    for idx in (None, slice(1, n, 2), [n - 1, 0, n // 2]):
+        ids = range(n)[idx] if isinstance(idx, slice) else idx
+        want = EO.tiles_to_batch(img, g, ids, scale, bias, 3, augment)
+        got = s.split_device(dimg, idx, augment=augment, scale=scale, bias=bias, value=3)
+        assert np.array_equal(got.cpu().numpy(), want)
+    # identity view, no affine == the host split of this package (and of the reference)
+    host = np.stack([t[None] if t.ndim == 2 else np.moveaxis(t, -1, 0) for t in s.split(img)]).astype(np.float32)
+    assert np.array_equal(s.split_device(dimg).cpu().numpy(), host)
+
+
+def test_split_device_more_tiles_than_one_launch_group(dev):
+    """> 64 tiles: the C ABI splits the batch into launch groups; chunk-major rows must still be k*n + tile."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (200, 264, 3), dtype=np.uint8)
+    s = ImageSlicer(img.shape, 32, 16)
+    assert len(s.crops) > 128
+    g = TO.slicer_geometry(img.shape, 32, 16)
+    got = s.split_device(torch.from_numpy(img).to(dev), augment="d4")
+    assert np.array_equal(got.cpu().numpy(), EO.tiles_to_batch(img, g, None, None, None, 0, "d4"))
+
+
+def test_split_device_errors(dev):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+    s = ImageSlicer((64, 48, 3), (32, 16), (16, 16))
+    img = torch.zeros((64, 48, 3), dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        s.split_device(img.cpu())
+    with pytest.raises(NotImplementedError):
+        s.split_device(img.float())
+    with pytest.raises(ValueError):
+        s.split_device(img[:32])
+    with pytest.raises(ValueError):
+        s.split_device(img, augment="d4")          # non-square tiles cannot take transposing views
+    with pytest.raises(KeyError):
+        s.split_device(img, augment="d8")
+    with pytest.raises(ValueError):
+        s.split_device(img, scale=[1, 1, 1])
+    assert s.split_device(img, []).shape == (0, 3, 32, 16)
+
+
+@pytest.mark.parametrize("case", GE.by_fn("merge_crop"), ids=lambda c: c["name"])
+def test_golden_merge_crop_bit_exact(case, dev, native):
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    kw, n = case["kwargs"], case["name"]
+    s = _slicer(kw)
+    m = TileMerger(s.target_shape, kw["channels"], s.weight, device=dev)
+    pred = torch.from_numpy(GE[f"{n}_pred"]).to(dev)
+    for b0 in range(0, len(pred), kw["batch"]):
+        m.integrate_batch(pred[b0:b0 + kw["batch"]], s.crops[b0:b0 + kw["batch"]])
+    f32 = m.merge_crop(s)
+    assert f32.dtype == torch.float32 and np.array_equal(f32.cpu().numpy(), GE[f"{n}_hwc_f32"])
+    u8 = m.merge_crop(s, dtype=torch.uint8)
+    assert u8.dtype == torch.uint8 and np.array_equal(u8.cpu().numpy(), GE[f"{n}_hwc_u8"])
+    am = m.merge_crop(s, argmax=True, dtype=torch.int64)
+    assert am.dtype == torch.int64 and np.array_equal(am.cpu().numpy(), GE[f"{n}_argmax"])
+    am8 = m.merge_crop(s, argmax=True, dtype=torch.uint8)
+    assert np.array_equal(am8.cpu().numpy(), GE[f"{n}_argmax"].astype(np.uint8))
+    chw = m.merge_crop(s, layout="chw")
+    assert np.array_equal(np.moveaxis(chw.cpu().numpy(), 0, -1), GE[f"{n}_hwc_f32"])
+    # the composition it replaces, computed with this package's own reference-shaped API
+    assert np.array_equal(s.crop_to_orignal_size(np.moveaxis(m.merge().cpu().numpy(), 0, -1)), GE[f"{n}_hwc_f32"])
+
+
+def test_merge_crop_casts_nan_and_windows(dev):
+    """uint8 cast outside [0, 256), NaN (uncovered pixels) handling in cast and argmax, arbitrary windows."""
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    C, H, W = 3, 40, 52
+    m = TileMerger((H, W), C, np.ones((8, 8), dtype=np.float32), device=dev)
+    vals = np.array([-300.2, -1.5, -0.5, 0.0, 0.99, 127.5, 255.99, 256.0, 300.7, 65536.5, 1e10, -1e10, np.inf], dtype=np.float32)
+    rng = np.random.default_rng(0)
+    image = rng.choice(vals, size=(C, H, W)).astype(np.float32)
+    norm = np.ones((1, H, W), dtype=np.float32)
+    norm[0, 5:9, 7:30] = 0.0                      # 0/0 -> NaN, x/0 -> inf like the reference's merge (no eps clamp)
+    m.image = torch.from_numpy(image).to(dev)
+    m.norm_mask = torch.from_numpy(norm).to(dev)
+    state = dict(image=image, norm_mask=norm)
+    geom = dict(margins=(3, 0, 2, 0))
+    for (top, left, oh, ow) in [(2, 3, 30, 41), (0, 0, H, W), (7, 1, 1, 5), (0, 0, 0, 0)]:
+        geom = dict(margins=(left, 0, top, 0))
+        for layout in ("hwc", "chw"):
+            for kind, dt in (("float32", torch.float32), ("uint8", torch.uint8)):
+                want = EO.merge_crop(state, geom, (oh, ow), layout, kind)
+                got = m.merge_crop((top, left, oh, ow), layout=layout, dtype=dt).cpu().numpy()
+                assert got.shape == want.shape
+                assert np.array_equal(got, want, equal_nan=True), (top, left, oh, ow, layout, kind)
+        for kind, dt in (("argmax_u8", torch.uint8), ("argmax_i64", torch.int64)):
+            want = EO.merge_crop(state, geom, (oh, ow), "hwc", kind)
+            got = m.merge_crop((top, left, oh, ow), argmax=True, dtype=dt).cpu().numpy()
+            assert np.array_equal(got, want), (top, left, oh, ow, kind)
+    with pytest.raises(ValueError):
+        m.merge_crop((0, 0, H + 1, W))
+    with pytest.raises(ValueError):
+        m.merge_crop((0, 0, H, W), layout="nhwc")
+    with pytest.raises(NotImplementedError):
+        m.merge_crop((0, 0, H, W), dtype=torch.float16)
+
+
+def test_full_size_cfg2_edges(dev):
+    """BASELINE cfg2 geometry end to end through the device edges: uint8 5000x5000x3 in HBM -> split_device(d4) ->
+    (identity 'model') -> fused de-augment merge -> merge_crop uint8 == the input image (round trip, size independent);
+    and the identity-view batch equals the host split."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (5000, 5000, 3), dtype=np.uint8)
+    s = ImageSlicer(img.shape, 512, 256, weight="pyramid")
+    dimg = torch.from_numpy(img).to(dev)
+    m = TileMerger(s.target_shape, 3, s.weight, device=dev)
+    host_tiles = s.split(img)
+    for b0 in range(0, len(s.crops), 8):
+        idx = slice(b0, min(b0 + 8, len(s.crops)))
+        x = s.split_device(dimg, idx, augment="d4")
+        nb = idx.stop - idx.start
+        assert x.shape == (8 * nb, 3, 512, 512)
+        if b0 in (0, 176, 360):   # first view of the batch == host split, HWC -> CHW, float
+            want = np.stack([np.moveaxis(t, -1, 0) for t in host_tiles[idx]]).astype(np.float32)
+            assert np.array_equal(x[:nb].cpu().numpy(), want)
+        m.integrate_batch_deaugment(x, s.crops[idx], group="d4", reduction="mean")
+    f32 = m.merge_crop(s)
+    assert f32.shape == (5000, 5000, 3)
+    assert torch.allclose(f32, dimg.float(), atol=1e-3, rtol=0)       # weighted mean of identical values
+    back = m.merge_crop(s, dtype=torch.uint8)
+    # truncation (quirk Q6) can land one below when the fp32 blend is a hair under the integer: compare after rounding
+    assert np.array_equal(np.rint(f32.cpu().numpy()).astype(np.uint8), img)
+    assert int((back.cpu().numpy().astype(np.int16) - img.astype(np.int16)).min()) >= -1
+    assert int((back.cpu().numpy().astype(np.int16) - img.astype(np.int16)).max()) <= 0

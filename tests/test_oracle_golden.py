@@ -238,3 +238,55 @@ def test_reference_kat_focal_ordering():
     bad = np.float32([[0, -10, 0], [0, 10, 0], [0, 0, 10]])
     lab = np.array([1, 0, 2])
     assert LO.softmax_focal_loss_with_logits(good, lab) < LO.softmax_focal_loss_with_logits(bad, lab)
+
+
+# ------------------------------------------------------------------ loop edges
+from oracle import edges_oracle as EO  # noqa: E402
+
+GE = load_golden("edges.npz")
+
+
+def _edge_geom(kw):
+    return TO.slicer_geometry(kw["image_shape"], kw["tile_size"], kw["tile_step"], kw.get("image_margin", 0))
+
+
+@pytest.mark.parametrize("case", GE.by_fn("tiles_to_batch"), ids=lambda c: c["name"])
+def test_edges_front_bit_exact(case):
+    kw, n = case["kwargs"], case["name"]
+    img = GE[f"{n}_image"]
+    scale = GE[f"{n}_scale"] if kw.get("affine") else None
+    bias = GE[f"{n}_bias"] if kw.get("affine") else None
+    got = EO.tiles_to_batch(img, _edge_geom(kw), kw.get("indices"), scale, bias, kw.get("value", 0), kw.get("augment"))
+    want = GE[f"{n}_out"]
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", GE.by_fn("merge_crop"), ids=lambda c: c["name"])
+def test_edges_back_bit_exact(case):
+    kw, n = case["kwargs"], case["name"]
+    g = _edge_geom(kw)
+    w = TO.pyramid_window(*g["tile_size"])[0] if kw["weight"] == "pyramid" else TO.mean_window(*g["tile_size"])
+    st = TO.merger_new(g["target_shape"], kw["channels"], w)
+    pred = GE[f"{n}_pred"]
+    for b0 in range(0, len(pred), kw["batch"]):
+        TO.merger_integrate(st, pred[b0:b0 + kw["batch"]], g["crops"][b0:b0 + kw["batch"]])
+    assert np.array_equal(EO.merge_crop(st, g, kw["image_shape"], "hwc", "float32"), GE[f"{n}_hwc_f32"])
+    assert np.array_equal(EO.merge_crop(st, g, kw["image_shape"], "hwc", "uint8"), GE[f"{n}_hwc_u8"])
+    assert np.array_equal(EO.merge_crop(st, g, kw["image_shape"], "hwc", "argmax_i64"), GE[f"{n}_argmax"])
+    chw = EO.merge_crop(st, g, kw["image_shape"], "chw", "float32")
+    assert np.array_equal(np.moveaxis(chw, 0, -1), GE[f"{n}_hwc_f32"])
+
+
+def test_cast_u8_matches_numpy_astype():
+    import warnings
+
+    v = np.array([-300.2, -1.5, -0.5, 0.0, 0.99, 1.0, 127.5, 255.99, 256.0, 300.7, 65536.5, 1e10, -1e10, np.nan, np.inf, -np.inf],
+                 dtype=np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = v.astype(np.uint8)
+    got = EO.cast_u8(v)
+    inside = np.abs(v) < 2147483648.0
+    assert np.array_equal(got[inside], want[inside])   # outside int32 the C cast is undefined; the oracle pins 0
+    assert (got[~inside] == 0).all()

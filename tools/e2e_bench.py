@@ -6,7 +6,11 @@
     -> merge (HIP) -> D2H -> crop_to_orignal_size
 
 Reports MP/s for the whole loop and a per-stage breakdown (SURVEY.md 8d "secondary" region; not a roofline figure:
-the model and PCIe dominate).  `--tiny` uses a 1024x1024 image."""
+the model and PCIe dominate).  `--tiny` uses a 1024x1024 image.
+
+`--device-edges` runs the same loop with the device-side edges: the uint8 image is uploaded once (75 MB),
+`ImageSlicer.split_device(..., augment="d4", scale, bias)` builds each model batch in one HIP launch, and
+`TileMerger.merge_crop(tiler, dtype=uint8, argmax=True)` downloads 25 MB of class indices instead of 419 MB of fp32."""
 import argparse
 import os
 import sys
@@ -50,6 +54,7 @@ class DummyUNet(nn.Module):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--device-edges", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     side = 1024 if args.tiny else 5000
@@ -79,6 +84,41 @@ def main():
         merged = tiler.crop_to_orignal_size(np.moveaxis(to_numpy(merger.merge()), 0, -1))
         stages["merge_d2h"] += time.perf_counter() - t
         return merged
+
+    def run_device():
+        t = time.perf_counter()
+        tiler = ImageSlicer(image.shape, tile_size=(512, 512), tile_step=(256, 256), weight="pyramid")
+        stages["split"] += time.perf_counter() - t; t = time.perf_counter()
+        dimg = torch.from_numpy(image).to(dev, non_blocking=True)
+        torch.cuda.synchronize(); stages["h2d"] += time.perf_counter() - t
+        merger = CudaTileMerger(tiler.target_shape, 4, tiler.weight)
+        inv255 = [1.0 / 255.0] * 3
+        with torch.no_grad():
+            for b0 in range(0, len(tiler.crops), 8):
+                t = time.perf_counter()
+                aug = tiler.split_device(dimg, slice(b0, b0 + 8), augment="d4", scale=inv255, bias=[0.0] * 3)
+                torch.cuda.synchronize(); stages["augment"] += time.perf_counter() - t; t = time.perf_counter()
+                pred = model(aug)
+                torch.cuda.synchronize(); stages["model"] += time.perf_counter() - t; t = time.perf_counter()
+                merger.integrate_batch_deaugment(pred, tiler.crops[b0:b0 + 8], group="d4")
+                torch.cuda.synchronize(); stages["integrate"] += time.perf_counter() - t
+        t = time.perf_counter()
+        labels = merger.merge_crop(tiler, argmax=True, dtype=torch.uint8).cpu().numpy()
+        stages["merge_d2h"] += time.perf_counter() - t
+        return labels
+
+    if args.device_edges:
+        run_device()
+        for k in stages:
+            stages[k] = 0.0
+        t0 = time.perf_counter()
+        out = run_device()
+        total = time.perf_counter() - t0
+        assert out.shape == (side, side) and out.max() < 4
+        print(f"end-to-end (device edges) {side}x{side}: {total * 1e3:.1f} ms -> {side * side / 1e6 / total:.1f} MP/s")
+        for k, v in stages.items():
+            print(f"  {k:10s} {v * 1e3:9.1f} ms  ({100 * v / total:4.1f} %)")
+        return
 
     run()  # warm-up (MIOpen find, allocator)
     for k in stages:

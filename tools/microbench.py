@@ -121,8 +121,36 @@ def cfg5():
     print(f"{'cfg5 fliplr de-augment per scale + fused ms gmean (SURVEY 8d bytes)':70s} {alg2 / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+def edges():
+    """Device-side loop edges at the cfg2 geometry: split_device of 8 tiles (d4, affine) and merge_crop."""
+    dev = torch.device("cuda:0")
+    slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+    img = torch.randint(0, 256, (5000, 5000, 3), dtype=torch.uint8, device=dev)
+    sc, bi = [1 / 255.0] * 3, [0.0] * 3
+    starts = [0, 40, 96, 176, 240, 300]
+    for aug, V_ in ((None, 1), ("d4", 8)):
+        for affine in (False, True):
+            t = timeit(lambda i: slicer.split_device(img, slice(starts[i], starts[i] + 8), augment=aug, scale=sc if affine else None,
+                                                     bias=bi if affine else None), 20, len(starts))
+            by = 8 * 3 * 512 * 512 * (1 + 4 * V_)
+            print(f"{'split_device 8 tiles augment=%s affine=%d (r u8 + w fp32 bytes)' % (aug, affine):70s} {by / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+    merger = TileMerger(slicer.target_shape, 4, slicer.weight, device=dev)
+    merger.image.normal_()
+    merger.norm_mask.fill_(1.5)
+    rd = 5 * 5000 * 5000 * 4
+    for name, kw, wr in (("f32 hwc", dict(), 4 * 4), ("f32 chw", dict(layout="chw"), 4 * 4), ("u8 hwc", dict(dtype=torch.uint8), 4),
+                         ("argmax u8", dict(argmax=True, dtype=torch.uint8), 1), ("argmax i64", dict(argmax=True, dtype=torch.int64), 8)):
+        t = timeit(lambda i: merger.merge_crop(slicer, **kw), 20, 1)
+        print(f"{'merge_crop 5000x5000 C=4 -> ' + name + ' (r+w bytes)':70s} {(rd + 5000 * 5000 * wr) / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+    t = timeit(lambda i: merger.merge(), 20, 1)
+    print(f"{'merge (padded fp32 CHW, for comparison)':70s} {(9 * 5120 * 5120 * 4) / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+
+
 if len(sys.argv) > 1 and sys.argv[1] == "cfg5":
     cfg5()
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "edges":
+    edges()
     sys.exit(0)
 
 if __name__ == "__main__":
