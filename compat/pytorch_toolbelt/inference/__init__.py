@@ -1,3 +1,4 @@
+from .ensembling import *  # noqa: F401,F403
 from .functional import *  # noqa: F401,F403
 from .tiles import *  # noqa: F401,F403
 from .tta import *  # noqa: F401,F403

@@ -108,6 +108,13 @@ int ptb_split_tiles_u8(const uint8_t* image, int IH, int IW, int IC, const int64
 int ptb_merge_crop(const float* image, const float* norm, int C, int H, int W, int top, int left, int OH, int OW, int layout,
                    int kind, void* out, ptb_stream_t stream);
 
+/* ---- Ensembler (+ ApplySigmoidTo / ApplySoftmaxTo) (inference/ensembling.py:12-123) ---------------
+ * out = reduce_t act(inputs[t]) over T model outputs read in place (the reference stacks them first, :111,:117):
+ * inputs HOST array of T DEVICE pointers, each [B, C, HW] contiguous fp32; reduction = PTB_RED_*; activation 0: none,
+ * 1: sigmoid(x * temperature) (:65), 2: softmax over C of x * temperature (:41).  Summation in list order.  T <= 16. */
+int ptb_ensemble_reduce(const float* const* inputs, int T, int reduction, int activation, float temperature, int B, int C,
+                        int64_t HW, float* out, ptb_stream_t stream);
+
 /* ---- {fliplr,flipud,flips,d2,d4}_image_deaugment (inference/tta.py:287-316,344-365,442-467,503-524) -------------
  * in [V*B, C, H, W] (chunk-major: rows [k*B,(k+1)*B) are view k), views HOST int[V] = inverse transform of each chunk.
  * out [B, C, H, W] = reduce_k view_k(in[k*B + b]).  V <= 8.  Transposing views require H == W. */

@@ -399,8 +399,72 @@ def gen_edges():
     save("edges.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- ensembling (8f-2)
+class _Affine(torch.nn.Module):
+    """Deterministic stand-in model: every output is ``x * k + b`` (so the tests can rebuild it without weights)."""
+
+    def __init__(self, k, b, kind):
+        super().__init__()
+        self.k, self.b, self.kind = k, b, kind
+
+    def forward(self, x):
+        y = x * self.k + self.b
+        if self.kind == "tensor":
+            return y
+        if self.kind == "list":
+            return [y, y * 0.5 - 0.25]
+        return {"logits": y, "aux": y * 0.5 - 0.25}
+
+
+def gen_ensembling():
+    from pytorch_toolbelt.inference import ensembling as re_
+
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn((2, 5, 12, 16), generator=g)
+    xpos = torch.rand((2, 5, 12, 16), generator=g) * 0.9 + 0.05
+    A["x"], A["xpos"] = t2n(x), t2n(xpos)
+    coeffs = [(1.0, 0.0), (0.7, 0.3), (1.3, -0.2), (0.5, 0.1), (0.9, -0.4)]
+    k = 0
+    for kind in ("tensor", "dict", "list"):
+        for wrap in (None, "sigmoid", "softmax"):
+            if wrap is not None and kind == "tensor":
+                continue
+            for reduction in ("mean", "sum", "gmean", "hmean", "harmonic1p", "logodd", "log1p"):
+                nm = 3 if reduction in ("sum", "logodd") else 5
+                positive = wrap is None and reduction not in ("mean", "sum")
+                inp = xpos if positive else x
+                cs = [(1.0, 0.0), (0.9, 0.02), (0.8, 0.05), (0.95, 0.01), (0.85, 0.03)] if positive else coeffs
+                models = [_Affine(a, b, kind) for a, b in cs[:nm]]
+                temp = 1.0 if k % 2 else 0.5
+                if wrap == "sigmoid":
+                    models = [re_.ApplySigmoidTo(m, output_key=("logits" if kind == "dict" else 0), temperature=temp) for m in models]
+                elif wrap == "softmax":
+                    models = [re_.ApplySoftmaxTo(m, output_key=("logits" if kind == "dict" else 0), dim=1, temperature=temp) for m in models]
+                outputs = ["logits"] if (kind == "dict" and k % 3 == 0) else None
+                ens = re_.Ensembler(models, reduction=reduction, outputs=outputs)
+                out = ens(inp)
+                name = f"ens{k}"
+                if kind == "tensor":
+                    A[f"{name}_out"] = t2n(out)
+                    keys = None
+                elif kind == "dict":
+                    keys = list(out.keys())
+                    for kk in keys:
+                        A[f"{name}_out_{kk}"] = t2n(out[kk])
+                else:
+                    keys = list(range(len(out)))
+                    for kk in keys:
+                        A[f"{name}_out_{kk}"] = t2n(out[kk])
+                cases.append(dict(name=name, fn="ensembler", kwargs=dict(kind=kind, wrap=wrap, reduction=reduction, coeffs=cs[:nm], temperature=temp,
+                                                                         input="xpos" if positive else "x", outputs=outputs, keys=keys)))
+                k += 1
+    save("ensembling.npz", A, cases)
+
+
 if __name__ == "__main__":
     gen_tiles()
     gen_tta()
     gen_losses()
     gen_edges()
+    gen_ensembling()

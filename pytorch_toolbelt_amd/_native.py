@@ -27,6 +27,7 @@ _vp = ctypes.c_void_p
 _i64p = ctypes.POINTER(ctypes.c_int64)
 _ip = ctypes.POINTER(ctypes.c_int)
 _fp = ctypes.POINTER(ctypes.c_float)
+_vpp = ctypes.POINTER(ctypes.c_void_p)
 
 # name -> (restype, argtypes); must list every symbol of include/ptb_hip.h (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -53,6 +54,7 @@ SIGNATURES = {
     "ptb_lovasz_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _vp]),
     "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_split_tiles_u8": (_c_int, [_vp, _c_int, _c_int, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _ip, _fp, _fp, _c_int, _vp, _vp]),
+    "ptb_ensemble_reduce": (_c_int, [_vpp, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _c_i64, _vp, _vp]),
     "ptb_merge_crop": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
 }
 

@@ -1,3 +1,4 @@
 from .functional import *  # noqa: F401,F403
 from .tiles import *  # noqa: F401,F403
+from .ensembling import *
 from .tta import *  # noqa: F401,F403

@@ -14,6 +14,11 @@ def test_alias_surface():
         from pytorch_toolbelt.utils.torch_utils import image_to_tensor, rgb_image_from_tensor, tensor_from_rgb_image, to_numpy  # noqa: F401
     finally:
         sys.path.pop(0)
+    from pytorch_toolbelt.inference import ensembling
+    import pytorch_toolbelt.inference as inf
+
+    for n in ("ApplySoftmaxTo", "ApplySigmoidTo", "Ensembler", "PickModelOutput", "SelectByIndex", "average_checkpoints"):
+        assert hasattr(ensembling, n) and hasattr(inf, n)
     for n in ("ImageSlicer", "TileMerger", "compute_pyramid_patch_weight_loss"):
         assert hasattr(tiles, n)
     ref_tta = ["GeneralizedTTA", "MultiscaleTTA", "d2_image_augment", "d2_labels_augment", "d2_image_deaugment", "d2_labels_deaugment",

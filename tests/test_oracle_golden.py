@@ -290,3 +290,38 @@ def test_cast_u8_matches_numpy_astype():
     inside = np.abs(v) < 2147483648.0
     assert np.array_equal(got[inside], want[inside])   # outside int32 the C cast is undefined; the oracle pins 0
     assert (got[~inside] == 0).all()
+
+
+# ------------------------------------------------------------------ ensembling
+from oracle import ensembling_oracle as NO  # noqa: E402
+
+GN = load_golden("ensembling.npz")
+
+
+def affine_outputs(x, k, b, kind):
+    """The golden generator's stand-in model (oracle/make_golden.py:_Affine) in float32 numpy."""
+    y = (x * np.float32(k)).astype(np.float32) + np.float32(b)
+    aux = (y * np.float32(0.5)).astype(np.float32) - np.float32(0.25)
+    return y if kind == "tensor" else ({"logits": y, "aux": aux} if kind == "dict" else [y, aux])
+
+
+@pytest.mark.parametrize("case", GN.by_fn("ensembler"), ids=lambda c: f"{c['name']}-{c['kwargs']['kind']}-{c['kwargs']['wrap']}-{c['kwargs']['reduction']}")
+def test_ensembling_oracle(case):
+    kw, n = case["kwargs"], case["name"]
+    x = GN[kw["input"]]
+    outs = [affine_outputs(x, k, b, kw["kind"]) for k, b in kw["coeffs"]]
+    act_key = None if kw["wrap"] is None else ("logits" if kw["kind"] == "dict" else 0)
+
+    def activated(o, key):
+        v = o if key is None else o[key]
+        if kw["wrap"] is not None and key == act_key:
+            return NO.sigmoid_to(v, kw["temperature"]) if kw["wrap"] == "sigmoid" else NO.softmax_to(v, kw["temperature"], 1)
+        return v
+
+    if kw["keys"] is None:
+        got = NO.ensemble([activated(o, None) for o in outs], kw["reduction"])
+        np.testing.assert_allclose(got, GN[f"{n}_out"], rtol=2e-6, atol=2e-6)
+    else:
+        for key in kw["keys"]:
+            got = NO.ensemble([activated(o, key) for o in outs], kw["reduction"])
+            np.testing.assert_allclose(got, GN[f"{n}_out_{key}"], rtol=2e-6, atol=2e-6)

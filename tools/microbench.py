@@ -149,6 +149,27 @@ def edges():
 if len(sys.argv) > 1 and sys.argv[1] == "cfg5":
     cfg5()
     sys.exit(0)
+def ensemble():
+    """Ensembler over T = 4 model outputs [8, 16, 512, 512]: fused activation + reduce vs torch ops."""
+    from pytorch_toolbelt_amd.inference import ensembling as E
+
+    dev = torch.device("cuda:0")
+    T = 4
+    sets = [[torch.randn((8, 16, 512, 512), device=dev) for _ in range(T)] for _ in range(3)]
+    by = (T + 1) * sets[0][0].numel() * 4
+    for act, name in ((0, "none"), (1, "sigmoid"), (2, "softmax")):
+        for code, red in ((N.RED_MEAN, "mean"), (N.RED_GMEAN, "gmean")):
+            if act == 0 and red == "gmean":
+                continue
+            t = timeit(lambda i: E._ensemble_native(sets[i], code, act, 0.5, 1), 10, 3)
+            print(f"{'ensemble T=4 [8,16,512,512] act=%s reduction=%s (T reads + 1 write)' % (name, red):70s} {by / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+    t = timeit(lambda i: torch.stack([x.mul(0.5).softmax(dim=1) for x in sets[i]]).log().mean(0).exp(), 5, 3)
+    print(f"{'same (softmax, gmean) as the reference op chain in eager torch':70s} {by / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "ensemble":
+    ensemble()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "edges":
     edges()
     sys.exit(0)
