@@ -211,6 +211,33 @@ int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const floa
                           const float* grad_pix, float* grad, int B, int C, int64_t HW, int reduced, float gamma,
                           float threshold, int64_t ignore_label, ptb_stream_t stream);
 
+/* ---- Remaining elementwise + reduce losses -------------------------------------------------------
+ * kind: 0 SoftBCEWithLogitsLoss (losses/soft_bce.py:29-46; p0 = smooth factor when flags & 2, chan_w / chan_pw = DEVICE
+ * per-channel weight / pos_weight [C] or NULL with element channel = (i / HW) % C), 1 balanced BCE (losses/
+ * balanced_bce.py:27-40), 2 QualityFocalLoss (losses/quality_focal_loss.py:33-35; p0 = beta), 3 wing_loss (losses/
+ * functional.py:260-269; p0 = width, p1 = curvature, p2 = width - width*log(1 + width/curvature)), 4 log_cosh_loss
+ * (losses/functional.py:338-341).  flags: 1 = elements whose target == ignore_value contribute 0; 2 = label smoothing.
+ * x, t: DEVICE fp32 [n].  sums: DEVICE double [PTB_SUM_SLOTS][4], zeroed by the caller, slot-wise partial sums of
+ *   kind 0,3,4: {loss};  kind 1: {sum t*logsigmoid(x), sum (1-t)*logsigmoid(-x), #(t == 1), #(t == 0)};  kind 2: {loss, focal}.
+ * elem_out (optional, not for kind 1): per-element loss. */
+int ptb_pointwise_loss_fwd(int kind, const float* x, const float* t, const float* chan_w, const float* chan_pw, double* sums,
+                           float* elem_out, int64_t n, int C, int64_t HW, int flags, float p0, float p1, float p2,
+                           float ignore_value, ptb_stream_t stream);
+/* out[i] = coef[0] * (grad_elem ? grad_elem[i] : 1) * dloss_i/dx_i (+ coef[1] * dfocal_i/dx_i for kind 2); kind 1: coef =
+ * {pos class weight, neg class weight} (each already multiplied by the upstream gradient); emit_loss = 1 (kind 1 only)
+ * writes the per-element loss -(coef[0]*t*logsigmoid(x) + coef[1]*(1-t)*logsigmoid(-x)) instead.  coef: DEVICE float[2]. */
+int ptb_pointwise_loss_apply(int kind, int emit_loss, const float* x, const float* t, const float* chan_w, const float* chan_pw,
+                             const float* coef, const float* grad_elem, float* out, int64_t n, int C, int64_t HW, int flags,
+                             float p0, float p1, float p2, float ignore_value, ptb_stream_t stream);
+/* SoftCrossEntropyLoss = label_smoothed_nll_loss(log_softmax(x, 1)) (losses/soft_ce.py:24-33, losses/functional.py:280-323):
+ * logits [B, C, HW], labels int64 [B, HW]; sums double [PTB_SUM_SLOTS][4]: {sum nll, sum smooth} over non-ignored pixels;
+ * pixel_out (optional) [B, HW] = (1-eps)*nll + eps/C*smooth; error_flag set to 1 on a label outside [0, C) that is not ignored.
+ * bwd: grad[b,c,i] = coef[0] * (grad_pix ? grad_pix[b,i] : 1) * d pixel_loss / d x[b,c,i]; coef DEVICE float[1]. */
+int ptb_soft_ce_fwd(const float* logits, const int64_t* labels, double* sums, float* pixel_out, int* error_flag, int B, int C,
+                    int64_t HW, float eps, int has_ignore, int64_t ignore_label, ptb_stream_t stream);
+int ptb_soft_ce_bwd(const float* logits, const int64_t* labels, const float* coef, const float* grad_pix, float* grad, int B, int C,
+                    int64_t HW, float eps, int has_ignore, int64_t ignore_label, ptb_stream_t stream);
+
 /* ---- Lovasz hinge / Lovasz-softmax (losses/lovasz.py:23-184) ---------------------------------------------------
  * mode 0 (softmax): pred = probabilities [B, C, HW], labels int64 [B, HW]; mode 1 (hinge): pred = logits [B, HW],
  * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the

@@ -462,9 +462,90 @@ def gen_ensembling():
     save("ensembling.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- more losses (8f-3)
+def gen_losses2():
+    """SoftBCE / balanced BCE / QualityFocal / wing / log-cosh / SoftCrossEntropy: values and input gradients."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 3, 5, 12, 10
+    logits = torch.randn((B, C, H, W), generator=g) * 3.0
+    logits[1] += 1.0
+    hard = (torch.rand((B, C, H, W), generator=g) < 0.3).float()
+    hard_ign = hard.clone()
+    hard_ign[torch.rand((B, C, H, W), generator=g) < 0.1] = -100.0
+    soft = torch.rand((B, C, H, W), generator=g)
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels_ign = labels.clone()
+    labels_ign[torch.rand((B, H, W), generator=g) < 0.15] = -100
+    reg_pred = torch.randn((4, 6, 7), generator=g) * 4.0
+    reg_true = torch.randn((4, 6, 7), generator=g) * 4.0
+    wvec = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.25])
+    pwvec = torch.tensor([1.0, 3.0, 0.5, 2.0, 1.0])
+    odd_logits = torch.randn((2, 3, 7, 5), generator=g) * 2.0          # HW % 4 != 0 -> scalar kernels
+    odd_hard = (torch.rand((2, 3, 7, 5), generator=g) < 0.4).float()
+    odd_labels = torch.randint(0, 3, (2, 7, 5), generator=g)
+    big_logits = torch.randn((2, 20, 6, 6), generator=g) * 2.0         # C > 16 -> generic soft-CE kernel
+    big_labels = torch.randint(0, 20, (2, 6, 6), generator=g)
+    flat_logits = torch.randn((9, 7), generator=g) * 2.0               # [N, C] classification input
+    flat_labels = torch.randint(0, 7, (9,), generator=g)
+    for k, v in dict(logits=logits, hard=hard, hard_ign=hard_ign, soft=soft, labels=labels, labels_ign=labels_ign, reg_pred=reg_pred,
+                     reg_true=reg_true, wvec=wvec, pwvec=pwvec, odd_logits=odd_logits, odd_hard=odd_hard, odd_labels=odd_labels,
+                     big_logits=big_logits, big_labels=big_labels, flat_logits=flat_logits, flat_labels=flat_labels).items():
+        A[k] = t2n(v)
+
+    def add(name, fn, kwargs, inputs, make):
+        """value and d value.sum() / d first input, both from the reference's autograd"""
+        x = torch.from_numpy(A[inputs[0]]).clone().requires_grad_(True)
+        val = make(x, *[torch.from_numpy(A[i]) for i in inputs[1:]])
+        A[name] = t2n(val)
+        val.sum().backward()
+        A[name + "_grad"] = t2n(x.grad)
+        cases.append(dict(name=name, fn=fn, kwargs=kwargs, inputs=inputs, output=name))
+
+    def tensors(kw):
+        k2 = dict(kw)
+        for key, vec in (("weight", wvec), ("pos_weight", pwvec)):
+            if k2.get(key) == "chan":
+                k2[key] = vec.view(C, 1, 1)
+            elif k2.get(key) == "scalar":
+                k2[key] = torch.tensor(1.7)
+        return k2
+
+    bce_opts = [
+        (dict(ignore_index=None), "logits", "hard"), (dict(), "logits", "hard_ign"), (dict(smooth_factor=0.1), "logits", "hard_ign"),
+        (dict(reduction="sum", smooth_factor=0.2, ignore_index=None), "logits", "soft"), (dict(reduction="none"), "logits", "hard_ign"),
+        (dict(weight="chan", ignore_index=None), "logits", "hard"), (dict(pos_weight="chan", smooth_factor=0.05), "logits", "hard_ign"),
+        (dict(weight="chan", pos_weight="chan", reduction="sum"), "logits", "hard_ign"), (dict(weight="scalar", ignore_index=None), "logits", "soft"),
+        (dict(ignore_index=None), "odd_logits", "odd_hard"),
+    ]
+    for i, (kw, a, b) in enumerate(bce_opts):
+        add(f"soft_bce_{i}", "soft_bce", kw, [a, b], lambda x, t, kw=kw: rl.SoftBCEWithLogitsLoss(**tensors(kw))(x, t))
+    bal_opts = [(dict(), "logits", "hard"), (dict(gamma=2.0), "logits", "hard"), (dict(ignore_index=-100), "logits", "hard_ign"),
+                (dict(reduction="sum", gamma=0.5), "logits", "hard"), (dict(reduction="none", ignore_index=-100), "logits", "hard_ign"),
+                (dict(), "odd_logits", "odd_hard")]
+    for i, (kw, a, b) in enumerate(bal_opts):
+        add(f"balanced_bce_{i}", "balanced_bce", kw, [a, b], lambda x, t, kw=kw: rl.balanced_binary_cross_entropy_with_logits(x, t, **kw))
+    qfl_opts = [(dict(), "logits", "soft"), (dict(beta=1.0), "logits", "soft"), (dict(beta=3.0, reduction="sum"), "logits", "hard"),
+                (dict(reduction="normalized"), "logits", "soft"), (dict(reduction="none", beta=1.5), "logits", "soft"), (dict(), "odd_logits", "odd_hard")]
+    for i, (kw, a, b) in enumerate(qfl_opts):
+        add(f"qfl_{i}", "qfl", kw, [a, b], lambda x, t, kw=kw: rl.QualityFocalLoss(**kw)(x, t))
+    for i, kw in enumerate([dict(), dict(width=2.0, curvature=1.0), dict(reduction="sum"), dict(reduction="none", width=3.0)]):
+        add(f"wing_{i}", "wing", kw, ["reg_pred", "reg_true"], lambda x, t, kw=kw: rlf.wing_loss(x, t, **kw))
+    add("logcosh_0", "logcosh", dict(), ["reg_pred", "reg_true"], lambda x, t: rlf.log_cosh_loss(x, t))
+    add("logcosh_1", "logcosh", dict(), ["logits", "soft"], lambda x, t: rl.LogCoshLoss()(x, t))
+    sce_opts = [(dict(), "logits", "labels"), (dict(smooth_factor=0.1), "logits", "labels_ign"), (dict(smooth_factor=0.2, reduction="sum"), "logits", "labels_ign"),
+                (dict(reduction="none", smooth_factor=0.1), "logits", "labels_ign"), (dict(reduction="none", ignore_index=None, smooth_factor=0.3), "logits", "labels"),
+                (dict(ignore_index=None), "odd_logits", "odd_labels"), (dict(smooth_factor=0.1), "big_logits", "big_labels"),
+                (dict(smooth_factor=0.1), "flat_logits", "flat_labels"), (dict(smooth_factor=1.0), "logits", "labels")]
+    for i, (kw, a, b) in enumerate(sce_opts):
+        add(f"soft_ce_{i}", "soft_ce", kw, [a, b], lambda x, t, kw=kw: rl.SoftCrossEntropyLoss(**kw)(x, t))
+    save("losses2.npz", A, cases)
+
+
 if __name__ == "__main__":
     gen_tiles()
     gen_tta()
     gen_losses()
     gen_edges()
     gen_ensembling()
+    gen_losses2()

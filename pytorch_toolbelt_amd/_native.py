@@ -54,6 +54,10 @@ SIGNATURES = {
     "ptb_lovasz_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _vp]),
     "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_split_tiles_u8": (_c_int, [_vp, _c_int, _c_int, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _ip, _fp, _fp, _c_int, _vp, _vp]),
+    "ptb_pointwise_loss_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_f, _vp]),
+    "ptb_pointwise_loss_apply": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_f, _vp]),
+    "ptb_soft_ce_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_f, _c_int, _c_i64, _vp]),
+    "ptb_soft_ce_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_f, _c_int, _c_i64, _vp]),
     "ptb_ensemble_reduce": (_c_int, [_vpp, _c_int, _c_int, _c_int, _c_f, _c_int, _c_int, _c_i64, _vp, _vp]),
     "ptb_merge_crop": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
 }

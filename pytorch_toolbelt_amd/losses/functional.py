@@ -1,8 +1,8 @@
 """Loss functionals (drop-in for ``pytorch_toolbelt.losses.functional``).
 
 ``focal_loss_with_logits``, ``softmax_focal_loss_with_logits``, ``soft_dice_score`` and ``soft_jaccard_score`` run as
-single-pass HIP reductions (csrc/ptb_losses.hip); their scalar epilogues are torch ops on tiny tensors.  The wing and
-log-cosh losses are not on the hot path and stay plain torch.
+single-pass HIP reductions (csrc/ptb_losses.hip), ``wing_loss`` and ``log_cosh_loss`` as fused elementwise + reduce
+passes (csrc/ptb_pointwise.hip); the scalar epilogues are torch ops on tiny tensors.
 """
 import math
 from typing import Optional
@@ -21,6 +21,7 @@ __all__ = [
     "soft_dice_score",
     "wing_loss",
     "log_cosh_loss",
+    "label_smoothed_nll_loss",
 ]
 
 
@@ -188,18 +189,55 @@ def soft_dice_score(output: torch.Tensor, target: torch.Tensor, smooth: float = 
 
 
 def wing_loss(output: torch.Tensor, target: torch.Tensor, width=5, curvature=0.5, reduction="mean"):
-    """Wing loss for landmark regression (https://arxiv.org/pdf/1711.06753.pdf): log-shaped near zero, L1 beyond."""
-    diff = (target - output).abs()
+    """Wing loss for landmark regression (https://arxiv.org/pdf/1711.06753.pdf): ``width * log(1 + d / curvature)`` for
+    ``d = |target - output| < width``, ``d - C`` beyond (C makes it continuous); "sum" | "mean" | unreduced.  One fused
+    HIP pass (reference losses/functional.py:250-277)."""
+    from . import _pointwise as P
+
+    x = P.as_f32(output, "wing_loss")
+    t = P.as_f32(target.detach(), "wing_loss")
+    if x.shape != t.shape:
+        x, t = (v.contiguous() for v in torch.broadcast_tensors(x, t))
     c = width - width * math.log(1 + width / curvature)
-    loss = torch.where(diff < width, width * torch.log(1 + diff / curvature), diff - c)
+    reduce = reduction in ("mean", "sum")
+    sums, elem = P.PointwiseSums.apply(x, t, None, None, P.WING, 0, float(width), float(curvature), float(c), 0.0, 1, 1, not reduce)
     if reduction == "sum":
-        return loss.sum()
+        return sums[0].to(output.dtype)
     if reduction == "mean":
-        return loss.mean()
-    return loss
+        return (sums[0] / max(x.numel(), 1)).to(output.dtype)
+    return elem.view(x.shape).to(output.dtype)
 
 
 def log_cosh_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
-    """mean(log(cosh(y_pred - y_true))), evaluated as d + softplus(-2d) - log 2 for stability."""
-    d = y_pred - y_true
-    return torch.mean(d + F.softplus(-2.0 * d) - math.log(2.0))
+    """``mean(log(cosh(y_pred - y_true)))`` evaluated as ``d + softplus(-2 d) - log 2`` (reference
+    losses/functional.py:326-342), one fused HIP pass."""
+    from . import _pointwise as P
+
+    x = P.as_f32(y_pred, "log_cosh_loss")
+    t = P.as_f32(y_true.detach(), "log_cosh_loss")
+    if x.shape != t.shape:
+        x, t = (v.contiguous() for v in torch.broadcast_tensors(x, t))
+    sums, _ = P.PointwiseSums.apply(x, t, None, None, P.LOGCOSH, 0, 0.0, 0.0, 0.0, 0.0, 1, 1, False)
+    return (sums[0] / max(x.numel(), 1)).to(y_pred.dtype)
+
+
+def label_smoothed_nll_loss(lprobs: torch.Tensor, target: torch.Tensor, epsilon: float, ignore_index=None, reduction="mean", dim=-1) -> torch.Tensor:
+    """Label-smoothed negative log-likelihood of LOG-PROBABILITIES (reference losses/functional.py:280-323):
+    ``(1 - eps) * nll + eps / C * smooth`` with ``nll = -lprobs[target]`` and ``smooth = -sum_c lprobs``; positions whose
+    target equals ``ignore_index`` contribute 0 (and keep the gathered dim in the unreduced output).  Plain torch on
+    purpose: it consumes log-probabilities somebody already computed; ``SoftCrossEntropyLoss`` is the fused path."""
+    if target.dim() == lprobs.dim() - 1:
+        target = target.unsqueeze(dim)
+    if ignore_index is not None:
+        pad = target.eq(ignore_index)
+        nll = -lprobs.gather(dim=dim, index=target.masked_fill(pad, 0))
+        smooth = -lprobs.sum(dim=dim, keepdim=True)
+        nll, smooth = nll.masked_fill(pad, 0.0), smooth.masked_fill(pad, 0.0)
+    else:
+        nll = -lprobs.gather(dim=dim, index=target).squeeze(dim)
+        smooth = -lprobs.sum(dim=dim, keepdim=True).squeeze(dim)
+    if reduction == "sum":
+        nll, smooth = nll.sum(), smooth.sum()
+    if reduction == "mean":
+        nll, smooth = nll.mean(), smooth.mean()
+    return (1.0 - epsilon) * nll + (epsilon / lprobs.size(dim)) * smooth

@@ -325,3 +325,34 @@ def test_ensembling_oracle(case):
         for key in kw["keys"]:
             got = NO.ensemble([activated(o, key) for o in outs], kw["reduction"])
             np.testing.assert_allclose(got, GN[f"{n}_out_{key}"], rtol=2e-6, atol=2e-6)
+
+
+# ------------------------------------------------------------------ remaining elementwise losses
+from oracle import pointwise_oracle as PO  # noqa: E402
+
+GL2 = load_golden("losses2.npz")
+
+
+def pointwise_kwargs(kw, C):
+    """Materialise the 'chan' / 'scalar' weight markers of oracle/make_golden.py:gen_losses2."""
+    k2 = dict(kw)
+    for key, vec in (("weight", "wvec"), ("pos_weight", "pwvec")):
+        if k2.get(key) == "chan":
+            k2[key] = GL2[vec].reshape(C, 1, 1)
+        elif k2.get(key) == "scalar":
+            k2[key] = np.float32(1.7)
+    return k2
+
+
+POINTWISE_ORACLES = {"soft_bce": PO.soft_bce, "balanced_bce": PO.balanced_bce, "qfl": PO.quality_focal, "wing": PO.wing,
+                     "logcosh": PO.log_cosh, "soft_ce": PO.soft_ce}
+
+
+@pytest.mark.parametrize("case", GL2.cases, ids=lambda c: c["name"])
+def test_pointwise_loss_oracle(case):
+    a, b = GL2[case["inputs"][0]], GL2[case["inputs"][1]]
+    kw = pointwise_kwargs(case["kwargs"], a.shape[1] if a.ndim > 1 else 1)
+    got = POINTWISE_ORACLES[case["fn"]](a, b, **kw)
+    want = GL2[case["name"]]
+    assert np.shape(got) == want.shape
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)

@@ -69,6 +69,34 @@ def main():
 
         tb = timeit(fb)
         print(f"{name:34s} {tf:8.3f} {fwd_bytes / tf / 1e6:9.1f} {tb:11.3f} {bwd_bytes / tb / 1e6:8.1f}")
+    # SURVEY 8f-3 losses: dense float targets of the logits' shape (2 reads forward; +1 read, +1 write backward),
+    # SoftCrossEntropy on int64 labels
+    dense = (torch.rand((B, C, H, W), device=dev, generator=g) < 0.3).float()
+    dense_fwd = 2 * x.numel() * 4
+    extra = {
+        "SoftBCEWithLogitsLoss(smooth 0.1)": (L.SoftBCEWithLogitsLoss(smooth_factor=0.1), dense, dense_fwd),
+        "BalancedBCEWithLogitsLoss": (L.BalancedBCEWithLogitsLoss(), dense, dense_fwd),
+        "QualityFocalLoss": (L.QualityFocalLoss(), dense, dense_fwd),
+        "WingLoss": (L.WingLoss(), dense, dense_fwd),
+        "LogCoshLoss": (L.LogCoshLoss(), dense, dense_fwd),
+        "SoftCrossEntropyLoss(smooth 0.1)": (L.SoftCrossEntropyLoss(smooth_factor=0.1), labels, fwd_bytes),
+    }
+    for name, (crit, tgt, fb_) in extra.items():
+        with torch.no_grad():
+            tf = timeit(lambda: crit(x, tgt))
+        xg = x.clone().requires_grad_(True)
+
+        def fb2():
+            xg.grad = None
+            crit(xg, tgt).backward()
+
+        tb = timeit(fb2)
+        print(f"{name:34s} {tf:8.3f} {fb_ / tf / 1e6:9.1f} {tb:11.3f} {(2 * fb_ + x.numel() * 4) / tb / 1e6:8.1f}")
+    with torch.no_grad():
+        tf = timeit(lambda: torch.nn.functional.binary_cross_entropy_with_logits(x, dense), reps=3)
+        print(f"{'torch F.bce_with_logits (eager)':34s} {tf:8.3f} {dense_fwd / tf / 1e6:9.1f}")
+        tf = timeit(lambda: torch.nn.functional.cross_entropy(x, labels, label_smoothing=0.1), reps=3)
+        print(f"{'torch F.cross_entropy ls=0.1 (eager)':34s} {tf:8.3f} {fwd_bytes / tf / 1e6:9.1f}")
     for name, fn in (("eager torch focal (reference math)", eager_focal), ("eager torch dice (reference math)", eager_dice)):
         with torch.no_grad():
             tf = timeit(lambda: fn(x, labels), reps=3)
