@@ -542,6 +542,42 @@ def gen_losses2():
     save("losses2.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- classification-shaped losses
+def gen_losses3():
+    """Bi-tempered, soft-F1 and focal-cosine losses (device-agnostic torch algebra in both implementations)."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((12, 6), generator=g) * 2.0
+    y = torch.randint(0, 6, (12,), generator=g)
+    xb = torch.randn((3, 1, 6, 5), generator=g) * 2.0
+    tb = (torch.rand((3, 1, 6, 5), generator=g) < 0.4).float()
+    tbi = tb.clone()
+    tbi[torch.rand((3, 1, 6, 5), generator=g) < 0.15] = 255
+    for k, v in dict(x=x, y=y, xb=xb, tb=tb, tbi=tbi).items():
+        A[k] = t2n(v)
+
+    def add(name, fn, kwargs, inputs, make):
+        xin = torch.from_numpy(A[inputs[0]]).clone().requires_grad_(True)
+        val = make(xin, torch.from_numpy(A[inputs[1]]))
+        A[name] = t2n(val)
+        val.sum().backward()
+        A[name + "_grad"] = t2n(xin.grad)
+        cases.append(dict(name=name, fn=fn, kwargs=kwargs, inputs=inputs, output=name))
+
+    for i, kw in enumerate([dict(t1=0.8, t2=1.2), dict(t1=0.7, t2=0.6), dict(t1=1.0, t2=1.0), dict(t1=0.9, t2=2.0, smoothing=0.1),
+                            dict(t1=0.5, t2=1.5, reduction="sum"), dict(t1=0.8, t2=1.4, reduction="none")]):
+        add(f"bitempered_{i}", "bitempered", kw, ["x", "y"], lambda a, b, kw=kw: rl.BiTemperedLogisticLoss(**kw)(a, b))
+    for i, (kw, t) in enumerate([(dict(t1=0.8, t2=1.3), "tb"), (dict(t1=0.8, t2=1.3, smoothing=0.05, ignore_index=255), "tbi"),
+                                 (dict(t1=0.6, t2=0.8, reduction="none"), "tb")]):
+        add(f"binary_bitempered_{i}", "binary_bitempered", kw, ["xb", t], lambda a, b, kw=kw: rl.BinaryBiTemperedLogisticLoss(**kw)(a, b))
+    add("binary_soft_f1_0", "binary_soft_f1", dict(), ["xb", "tb"], lambda a, b: rl.BinarySoftF1Loss()(a, b))
+    add("binary_soft_f1_1", "binary_soft_f1", dict(ignore_index=255), ["xb", "tbi"], lambda a, b: rl.BinarySoftF1Loss(ignore_index=255)(a, b))
+    add("soft_f1_0", "soft_f1", dict(), ["x", "y"], lambda a, b: rl.SoftF1Loss()(a, b))
+    add("focal_cosine_0", "focal_cosine", dict(), ["x", "y"], lambda a, b: rl.FocalCosineLoss()(a, b))
+    add("focal_cosine_1", "focal_cosine", dict(alpha=0.5, gamma=1.5, xent=0.3), ["x", "y"], lambda a, b: rl.FocalCosineLoss(alpha=0.5, gamma=1.5, xent=0.3)(a, b))
+    save("losses3.npz", A, cases)
+
+
 if __name__ == "__main__":
     gen_tiles()
     gen_tta()
@@ -549,3 +585,4 @@ if __name__ == "__main__":
     gen_edges()
     gen_ensembling()
     gen_losses2()
+    gen_losses3()

@@ -37,5 +37,8 @@ def test_alias_surface():
     assert all(hasattr(F, n) for n in ref_fn)
     ref_losses = ["BinaryFocalLoss", "CrossEntropyFocalLoss", "FocalLoss", "DiceLoss", "JaccardLoss", "BinaryLovaszLoss", "LovaszLoss",
                   "BINARY_MODE", "MULTICLASS_MODE", "MULTILABEL_MODE", "focal_loss_with_logits", "softmax_focal_loss_with_logits",
-                  "sigmoid_focal_loss", "soft_dice_score", "soft_jaccard_score", "wing_loss", "log_cosh_loss"]
+                  "sigmoid_focal_loss", "soft_dice_score", "soft_jaccard_score", "wing_loss", "log_cosh_loss",
+                  "BalancedBCEWithLogitsLoss", "balanced_binary_cross_entropy_with_logits", "BiTemperedLogisticLoss",
+                  "BinaryBiTemperedLogisticLoss", "FocalCosineLoss", "SoftBCEWithLogitsLoss", "SoftCrossEntropyLoss", "soft_micro_f1",
+                  "BinarySoftF1Loss", "SoftF1Loss", "WingLoss", "LogCoshLoss", "QualityFocalLoss", "label_smoothed_nll_loss"]
     assert all(hasattr(L, n) for n in ref_losses)
