@@ -115,6 +115,13 @@ int ptb_merge_crop(const float* image, const float* norm, int C, int H, int W, i
 int ptb_ensemble_reduce(const float* const* inputs, int T, int reduction, int activation, float temperature, int B, int C,
                         int64_t HW, float* out, ptb_stream_t stream);
 
+/* ---- VolumeMerger.integrate_batch (inference/tiles_3d.py:195-208) -----------------------------------
+ * volume [C, D, H, W], norm [D, H, W], weight [d, h, w], tiles [B, C, d, h, w] DEVICE fp32; zs/ys/xs HOST int64[B] = tile
+ * origin (roi start) per axis.  For b = 0..B-1 in order: volume[:, roi] += tiles[b] * weight (product rounded, then
+ * added); norm[roi] += weight.  Out-of-range rois -> PTB_EBOUNDS.  merge = ptb_merge_div with HW = D*H*W. */
+int ptb_volume_accumulate(float* volume, float* norm, const float* weight, const float* tiles, const int64_t* zs, const int64_t* ys,
+                          const int64_t* xs, int B, int C, int d, int h, int w, int D, int H, int W, ptb_stream_t stream);
+
 /* ---- {fliplr,flipud,flips,d2,d4}_image_deaugment (inference/tta.py:287-316,344-365,442-467,503-524) -------------
  * in [V*B, C, H, W] (chunk-major: rows [k*B,(k+1)*B) are view k), views HOST int[V] = inverse transform of each chunk.
  * out [B, C, H, W] = reduce_k view_k(in[k*B + b]).  V <= 8.  Transposing views require H == W. */

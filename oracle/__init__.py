@@ -16,4 +16,4 @@ vectors to ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every
 oracle function against those vectors and against the reference's own
 known-answer tests (tests/test_tta.py:31-108, tests/test_losses.py:37-209).
 """
-from . import tiles_oracle, tta_oracle, losses_oracle, edges_oracle, ensembling_oracle, pointwise_oracle  # noqa: F401
+from . import tiles_oracle, tta_oracle, losses_oracle, edges_oracle, ensembling_oracle, pointwise_oracle, volumes_oracle  # noqa: F401

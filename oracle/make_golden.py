@@ -578,6 +578,49 @@ def gen_losses3():
     save("losses3.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- 3-D tiles (8f-4)
+def gen_volumes():
+    from pytorch_toolbelt.inference import tiles_3d as rt3
+
+    A, cases = {}, []
+    rng = np.random.default_rng(13)
+    g = torch.Generator().manual_seed(13)
+    geoms = [dict(volume_shape=[20, 33, 17], voxel_size=[8, 16, 8], voxel_step=[4, 8, 8]),
+             dict(volume_shape=[16, 16, 16], voxel_size=8, voxel_step=8),
+             dict(volume_shape=[9, 21, 30], voxel_size=[4, 8, 12], voxel_step=[3, 5, 12]),
+             dict(volume_shape=[5, 6, 7], voxel_size=[8, 8, 8], voxel_step=[4, 4, 4]),      # volume smaller than a tile
+             dict(volume_shape=[64, 96, 80, 2], voxel_size=[32, 32, 32], voxel_step=[16, 16, 16])]
+    for k, kw in enumerate(geoms):
+        s = rt3.VolumeSlicer(kw["volume_shape"], kw["voxel_size"], kw["voxel_step"])
+        A[f"vgeom{k}_starts"] = np.array([[r.start for r in roi] for roi in s.crops], dtype=np.int64)
+        A[f"vgeom{k}_stops"] = np.array([[r.stop for r in roi] for roi in s.crops], dtype=np.int64)
+        A[f"vgeom{k}_bbox_starts"] = np.array([[r.start for r in roi] for roi in s.bbox_crops], dtype=np.int64)
+        A[f"vgeom{k}_meta"] = np.array([*s.pad_before, *s.pad_after, *s.target_shape, *s.num_tiles], dtype=np.int64)
+        cases.append(dict(name=f"vgeom{k}", fn="vgeometry", kwargs=kw))
+    for k, kw in enumerate(geoms[:4]):
+        vol = rng.integers(0, 256, kw["volume_shape"], dtype=np.uint8)
+        s = rt3.VolumeSlicer(vol.shape, kw["voxel_size"], kw["voxel_step"])
+        tiles = s.split(vol, value=5)
+        A[f"vsplit{k}_volume"] = vol
+        A[f"vsplit{k}_tiles"] = np.stack(tiles)
+        it = list(s.iter_split(vol, value=5))
+        assert all(np.array_equal(a, b) for (a, _), b in zip(it, tiles))
+        A[f"vsplit{k}_crop"] = s.crop_to_orignal_size(np.pad(vol, np.stack([s.pad_before, s.pad_after], -1)))
+        cases.append(dict(name=f"vsplit{k}", fn="vsplit", kwargs=kw))
+    for k, (kw, C, bs) in enumerate([(geoms[0], 2, 5), (geoms[2], 1, 4), (geoms[1], 3, 8), (geoms[3], 2, 1)]):
+        s = rt3.VolumeSlicer(kw["volume_shape"], kw["voxel_size"], kw["voxel_step"])
+        ts = tuple(int(v) for v in s.tile_size)
+        weight = (rng.random(ts) + 0.25).astype(np.float32)
+        pred = torch.randn((len(s.crops), C, *ts), generator=g)
+        m = rt3.VolumeMerger(s.target_shape, C, weight)
+        for b0 in range(0, len(s.crops), bs):
+            m.integrate_batch(pred[b0:b0 + bs], s.crops[b0:b0 + bs])
+        A[f"vmerger{k}_weight"], A[f"vmerger{k}_pred"] = weight, t2n(pred)
+        A[f"vmerger{k}_volume"], A[f"vmerger{k}_norm"], A[f"vmerger{k}_merged"] = t2n(m.volume), t2n(m.norm_mask), t2n(m.merge())
+        cases.append(dict(name=f"vmerger{k}", fn="vmerger", kwargs=dict(kw, channels=C, batch=bs)))
+    save("volumes.npz", A, cases)
+
+
 if __name__ == "__main__":
     gen_tiles()
     gen_tta()
@@ -586,3 +629,4 @@ if __name__ == "__main__":
     gen_ensembling()
     gen_losses2()
     gen_losses3()
+    gen_volumes()

@@ -316,3 +316,84 @@ extern "C" int ptb_merge_crop(const float* image, const float* norm, int C, int 
     else hipLaunchKernelGGL(merge_crop_hwc_generic_kernel, grid, block, 0, s, a);
     return check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------ 3-D tiles
+// VolumeMerger.integrate_batch (reference inference/tiles_3d.py:195-208): volume[:, z:z+d, y:y+h, x:x+w] += tile * weight,
+// norm_mask[...] += weight, tile after tile.  One launch per tile: a tile never overlaps itself, so every launch owns
+// its accumulator region exclusively (race-free without atomics) and the stream order reproduces the reference's
+// sequential fp32 order bit for bit.  A 3-D tile is megabytes, so a launch per tile is not launch-bound.
+namespace ptb {
+
+struct VolArgs {
+    float* volume;        // [C, D, H, W]
+    float* norm;          // [D, H, W]
+    const float* weight;  // [d, h, w]
+    const float* tile;    // [C, d, h, w]
+    int C, d, h, w, D, H, W;
+    int z0, y0, x0;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void volume_accumulate_kernel(const VolArgs a) {
+    constexpr int PIX = VEC ? 4 : 1;
+    const int wq = (a.w + PIX - 1) / PIX;
+    const long long per_chan = (long long)a.d * a.h * wq;
+    const long long total = per_chan * a.C;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long tplane = (long long)a.d * a.h * a.w, vplane = (long long)a.D * a.H * a.W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i / per_chan);
+        long long r = i - (long long)c * per_chan;
+        const int q = (int)(r % wq);
+        r /= wq;
+        const int y = (int)(r % a.h), z = (int)(r / a.h);
+        const long long toff = ((long long)z * a.h + y) * a.w + (long long)q * PIX;
+        const long long voff = ((long long)(a.z0 + z) * a.H + (a.y0 + y)) * a.W + a.x0 + (long long)q * PIX;
+        if (VEC) {
+            const float4 t = *reinterpret_cast<const float4*>(a.tile + c * tplane + toff);
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + toff);
+            float4* vp = reinterpret_cast<float4*>(a.volume + c * vplane + voff);
+            float4 v = *vp;
+            v.x = __fadd_rn(v.x, __fmul_rn(t.x, w4.x)); v.y = __fadd_rn(v.y, __fmul_rn(t.y, w4.y));
+            v.z = __fadd_rn(v.z, __fmul_rn(t.z, w4.z)); v.w = __fadd_rn(v.w, __fmul_rn(t.w, w4.w));
+            *vp = v;
+            if (c == 0) {
+                float4* np = reinterpret_cast<float4*>(a.norm + voff);
+                float4 n = *np;
+                n.x = __fadd_rn(n.x, w4.x); n.y = __fadd_rn(n.y, w4.y); n.z = __fadd_rn(n.z, w4.z); n.w = __fadd_rn(n.w, w4.w);
+                *np = n;
+            }
+        } else {
+            const float wv = a.weight[toff];
+            a.volume[c * vplane + voff] = __fadd_rn(a.volume[c * vplane + voff], __fmul_rn(a.tile[c * tplane + toff], wv));
+            if (c == 0) a.norm[voff] = __fadd_rn(a.norm[voff], wv);
+        }
+    }
+}
+
+}  // namespace ptb
+
+extern "C" int ptb_volume_accumulate(float* volume, float* norm, const float* weight, const float* tiles, const int64_t* zs,
+                                     const int64_t* ys, const int64_t* xs, int B, int C, int d, int h, int w, int D, int H, int W,
+                                     ptb_stream_t stream) {
+    if (!volume || !norm || !weight || !tiles || !zs || !ys || !xs) return PTB_EINVAL;
+    if (B < 0 || C < 1 || d < 1 || h < 1 || w < 1 || D < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    for (int b = 0; b < B; ++b)
+        if (zs[b] < 0 || ys[b] < 0 || xs[b] < 0 || zs[b] + d > D || ys[b] + h > H || xs[b] + w > W) return PTB_EBOUNDS;
+    VolArgs a{volume, norm, weight, nullptr, C, d, h, w, D, H, W, 0, 0, 0};
+    const long long tile_elems = (long long)C * d * h * w;
+    const bool base_vec = !g_force_scalar && w % 4 == 0 && W % 4 == 0 && aligned16(volume) && aligned16(norm) && aligned16(weight) &&
+                          aligned16(tiles) && tile_elems % 4 == 0;
+    for (int b = 0; b < B; ++b) {
+        a.tile = tiles + (long long)b * tile_elems;
+        a.z0 = (int)zs[b]; a.y0 = (int)ys[b]; a.x0 = (int)xs[b];
+        const bool vec = base_vec && a.x0 % 4 == 0;
+        const long long items = (long long)C * d * h * (vec ? w / 4 : w);
+        const long long want = (items + 255) / 256;
+        const dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
+        if (vec) hipLaunchKernelGGL(ptb::volume_accumulate_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(ptb::volume_accumulate_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+        if (int rc = ptb::check_launch()) return rc;
+    }
+    return PTB_OK;
+}
