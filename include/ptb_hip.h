@@ -70,10 +70,17 @@ int ptb_set_tunable(int key, int value);
  * 64 columns x fresh_rows rows (row-major, ceil(H/fresh_rows) x ceil(W/64)); 1 = the block was never written since the
  * accumulators were (logically) zeroed.  Cells made only of fresh blocks are written with plain stores -- the
  * accumulators then never need a memset and are not read on first touch -- and the library clears the bits it wrote.
- * NULL = plain read-modify-write everywhere.  PTB_EFRESH: see above. */
+ * NULL = plain read-modify-write everywhere.  PTB_EFRESH: see above.
+ * norm may be NULL: the normaliser depends only on the crop list and the window, never on the predictions, so a caller
+ * can keep the crop list and materialise it later (ptb_norm_accumulate) -- or reuse the one of the previous image. */
 int ptb_tile_accumulate(float* image, float* norm, const float* weight, const float* tiles, const int64_t* xs,
                         const int64_t* ys, int B, int C, int th, int tw, int H, int W, uint8_t* fresh, int fresh_rows,
                         ptb_stream_t stream);
+
+/* norm[0, y:y+th, x:x+tw] += weight for b in 0..B-1, in order (the norm_mask half of integrate_batch: same race-free cell
+ * ownership, same summation order, same optional first-touch bitmap -- a SEPARATE bitmap from the image's). */
+int ptb_norm_accumulate(float* norm, const float* weight, const int64_t* xs, const int64_t* ys, int B, int th, int tw, int H,
+                        int W, uint8_t* fresh, int fresh_rows, ptb_stream_t stream);
 
 /* Test hook, host only (no device work): the launch plan of the two calls above for one batch.  out: up to `cap`
  * records of 12 ints {launch group, ox, oy, w, h, fresh, chunk_end, ntiles, tile[4] (batch indices, -1 padded)}.

@@ -164,10 +164,11 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
 
     float* ip = a.dst + (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
     float* np = a.norm + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+    const bool do_norm = c == 0 && a.norm != nullptr;  // norm == NULL: the caller keeps the (data independent) normaliser itself
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), nacc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (act && !cell.fresh) {  // first touch: the accumulator is logically zero, nothing to read (and it was never memset)
         acc = *reinterpret_cast<const float4*>(ip);
-        if (c == 0) nacc = *reinterpret_cast<const float4*>(np);
+        if (do_norm) nacc = *reinterpret_cast<const float4*>(np);
     }
     const int nt = cell.ntiles;
     for (int e = 0; e < nt; ++e) {
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
             acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, w4.y));
             acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, w4.z));
             acc.w = __fadd_rn(acc.w, __fmul_rn(val.w, w4.w));
-            if (c == 0) {
+            if (do_norm) {
                 nacc.x = __fadd_rn(nacc.x, w4.x); nacc.y = __fadd_rn(nacc.y, w4.y);
                 nacc.z = __fadd_rn(nacc.z, w4.z); nacc.w = __fadd_rn(nacc.w, w4.w);
             }
@@ -191,8 +192,37 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
     }
     if (act) {
         *reinterpret_cast<float4*>(ip) = acc;
-        if (c == 0) *reinterpret_cast<float4*>(np) = nacc;
+        if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
     }
+}
+
+// norm_mask only (a.dst == NULL): the same cell walk without any tile data -- used to materialise the normaliser that
+// the accumulate calls skipped (it depends on the crop list and the window only, never on the predictions).
+template <int CH>
+__global__ __launch_bounds__(CH * 16) void norm_accum_kernel(const ViewArgs a, const CellArgs g) {
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x;
+    int ci = 0;
+    while (ci < a.ncells - 1 && chunk >= g.cells[ci].chunk_end) ++ci;
+    const Cell& cell = g.cells[ci];
+    const int first = ci ? g.cells[ci - 1].chunk_end : 0;
+    const int ncx = (cell.w + CW - 1) / CW;
+    const int lc = chunk - first;
+    const int cx0 = (lc % ncx) * CW, cy0 = (lc / ncx) * CH;
+    const int cw = min(CW, cell.w - cx0), ch = min(CH, cell.h - cy0);
+    const int q = tid & 15, r = tid >> 4;
+    if (!((r < ch) && (4 * q < cw))) return;
+    const int ax = cell.ox + cx0, ay = cell.oy + cy0;
+    float* np = a.norm + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+    float4 nacc = cell.fresh ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(np);
+    for (int e = 0; e < cell.ntiles; ++e) {
+        const int gt = cell.tile[e];
+        const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
+        const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
+        nacc.x = __fadd_rn(nacc.x, w4.x); nacc.y = __fadd_rn(nacc.y, w4.y);
+        nacc.z = __fadd_rn(nacc.z, w4.z); nacc.w = __fadd_rn(nacc.w, w4.w);
+    }
+    *reinterpret_cast<float4*>(np) = nacc;
 }
 
 // ------------------------------------------------------------------------------------------------ augment (scatter)
@@ -314,7 +344,8 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
     for (int r = ty; r < ch; r += 4) {
         const long long off = (long long)(ay + r) * a.dst_row_stride + ax + tx;
         float acc = cell.fresh ? 0.f : a.dst[(long long)c * a.dst_chan_stride + off];
-        float nacc = (c == 0 && !cell.fresh) ? a.norm[off] : 0.f;
+        const bool do_norm = c == 0 && a.norm != nullptr;
+        float nacc = (do_norm && !cell.fresh) ? a.norm[off] : 0.f;
         for (int e = 0; e < cell.ntiles; ++e) {
             const int gt = cell.tile[e];
             const int lx = ax - g.tile_x[gt] + tx, ly = ay - g.tile_y[gt] + r;
@@ -325,7 +356,31 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
             nacc = __fadd_rn(nacc, w);
         }
         a.dst[(long long)c * a.dst_chan_stride + off] = acc;
-        if (c == 0) a.norm[off] = nacc;
+        if (do_norm) a.norm[off] = nacc;
+    }
+}
+
+__global__ __launch_bounds__(256) void norm_accum_scalar_kernel(const ViewArgs a, const CellArgs g) {
+    const int chunk = blockIdx.x;
+    int ci = 0;
+    while (ci < a.ncells - 1 && chunk >= g.cells[ci].chunk_end) ++ci;
+    const Cell& cell = g.cells[ci];
+    const int first = ci ? g.cells[ci - 1].chunk_end : 0;
+    const int ncx = (cell.w + CW - 1) / CW;
+    const int lc = chunk - first;
+    const int cx0 = (lc % ncx) * CW, cy0 = (lc / ncx) * 64;
+    const int cw = min(CW, cell.w - cx0), ch = min(64, cell.h - cy0);
+    const int ax = cell.ox + cx0, ay = cell.oy + cy0;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    if (tx >= cw) return;
+    for (int r = ty; r < ch; r += 4) {
+        const long long off = (long long)(ay + r) * a.dst_row_stride + ax + tx;
+        float nacc = cell.fresh ? 0.f : a.norm[off];
+        for (int e = 0; e < cell.ntiles; ++e) {
+            const int gt = cell.tile[e];
+            nacc = __fadd_rn(nacc, a.weight[(long long)(ay - g.tile_y[gt] + r) * a.W + ax - g.tile_x[gt] + tx]);
+        }
+        a.norm[off] = nacc;
     }
 }
 
@@ -578,7 +633,12 @@ static int launch_group(const ViewArgs& a, const CellArgs& g, const std::vector<
     if (blocks <= 0) return PTB_OK;
     if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     const bool nonlinear = a.op >= PTB_RED_GMEAN;
-    if (!fast) {
+    if (!a.dst) {  // norm only (C == 1)
+        if (!fast) hipLaunchKernelGGL(norm_accum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
+        else if (ch == 64) hipLaunchKernelGGL(norm_accum_kernel<64>, dim3((unsigned)blocks), dim3(1024), 0, s, a, g);
+        else if (ch == 32) hipLaunchKernelGGL(norm_accum_kernel<32>, dim3((unsigned)blocks), dim3(512), 0, s, a, g);
+        else hipLaunchKernelGGL(norm_accum_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
+    } else if (!fast) {
         hipLaunchKernelGGL(view_accum_scalar_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, g);
     } else if (ch == 64) {
         launch_accum_ch<64>(a, g, (int)blocks, s, nonlinear);
@@ -651,7 +711,8 @@ static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int
 static int accumulate_impl(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                            int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th, int tw, int H, int W,
                            uint8_t* fresh, int fresh_rows, hipStream_t s) {
-    if (!image || !norm || !weight || !in || !xs64 || !ys64) return PTB_EINVAL;
+    const bool norm_only = !image && !in;  // ptb_norm_accumulate
+    if ((!norm_only && (!image || !in)) || (norm_only && !norm) || !weight || !xs64 || !ys64) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
     if (int rc = validate_views(V, views, th, tw)) return rc;
@@ -678,8 +739,8 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
     fill_reduction(a, reduction, V);
     const int nT = count_transpose(V, a.codes);
     bool fast = !g_force_scalar && aligned && (tw % 4 == 0) && (W % 4 == 0) && ((long long)H * W % 4 == 0) &&
-                ((long long)th * tw % 4 == 0) && aligned16(in) && aligned16(image) && aligned16(norm) && aligned16(weight) &&
-                nT <= MAX_T;
+                ((long long)th * tw % 4 == 0) && (norm_only || (aligned16(in) && aligned16(image))) && aligned16(norm) &&
+                aligned16(weight) && nT <= MAX_T;
     if (nT) {  // transposed source blocks are addressed by tile-local rows: need 4-aligned row offsets too
         if (th % 4) fast = false;
         for (int b = 0; b < B && fast; ++b) if ((ys[b] - ys[0]) % 4) fast = false;
@@ -727,6 +788,13 @@ extern "C" int ptb_tile_accumulate(float* image, float* norm, const float* weigh
                                    ptb_stream_t stream) {
     const int ident = PTB_VIEW_IDENT;
     return accumulate_impl(image, norm, weight, tiles, 1, &ident, PTB_RED_SUM, xs, ys, B, C, th, tw, H, W, fresh, fresh_rows,
+                           (hipStream_t)stream);
+}
+
+extern "C" int ptb_norm_accumulate(float* norm, const float* weight, const int64_t* xs, const int64_t* ys, int B, int th, int tw,
+                                   int H, int W, uint8_t* fresh, int fresh_rows, ptb_stream_t stream) {
+    const int ident = PTB_VIEW_IDENT;
+    return accumulate_impl(nullptr, norm, weight, nullptr, 1, &ident, PTB_RED_SUM, xs, ys, B, 1, th, tw, H, W, fresh, fresh_rows,
                            (hipStream_t)stream);
 }
 

@@ -283,6 +283,16 @@ class TileMerger:
         self._image = torch.empty((channels, self.image_height, self.image_width), device=device, dtype=dtype)
         self._norm = torch.empty((1, self.image_height, self.image_width), device=device, dtype=dtype)
         self._fresh = np.ones(((self.image_height + _FRESH_ROWS - 1) // _FRESH_ROWS, (self.image_width + 63) // 64), dtype=np.uint8)
+        # Lazy normaliser: `norm_mask` depends only on the crop list and the window, never on the predictions.  The
+        # accumulate kernels therefore skip it (norm = NULL); the crops are logged on the host and the normaliser is
+        # materialised when somebody needs it (`merge`, or a read of `norm_mask`) -- and when the log of an image equals
+        # the log the buffer was last built from (every image of one slicer), it is simply reused.
+        self._log = []            # [2, B] int64 origin arrays of the integrate calls since the last reset
+        self._applied = 0         # log entries already summed into _norm
+        self._norm_zero = True    # _norm is logically zero (its buffer may hold the cached normaliser of _norm_key)
+        self._norm_key = None     # crop log the buffer content was built from, start to end, by this object alone
+        self._norm_pure = False   # this cycle's _norm was built from zero by _norm_ready only
+        self._eager_norm = False  # norm_mask was handed out: keep it up to date inside the accumulate kernels
 
     # ------------------------------------------------------------------ first-touch state
     @property
@@ -298,27 +308,65 @@ class TileMerger:
 
     @property
     def norm_mask(self) -> torch.Tensor:
-        """``[1, H', W']`` sum of the blending windows."""
+        """``[1, H', W']`` sum of the blending windows (materialised on first access; from then on the accumulate
+        kernels keep this tensor up to date, exactly like the reference's attribute)."""
+        self._norm_ready()
         self._materialize()
+        self._eager_norm, self._norm_pure, self._norm_key = True, False, None
         return self._norm
 
     @norm_mask.setter
     def norm_mask(self, value: torch.Tensor):
+        self._norm_ready()
         self._materialize()
+        self._eager_norm, self._norm_pure, self._norm_key = True, False, None
         self._norm = value
 
     def reset(self):
         """Start a new image: the accumulators become logically zero again (no memset: O(1) on the host)."""
         self._fresh[:] = 1
+        self._log, self._applied = [], 0
+        self._norm_zero, self._norm_pure, self._eager_norm = True, False, False
+
+    def _log_key(self):
+        return (self.weight.data_ptr(), self.weight._version, b"".join(a.tobytes() for a in self._log))
+
+    def _norm_ready(self):
+        """Bring ``_norm`` up to date with the crop log (a no-op in eager mode, where the kernels maintain it)."""
+        if self._eager_norm:
+            return
+        if self._norm_zero:
+            if self._applied == 0 and self._norm_key is not None and self._norm_key == self._log_key():
+                self._applied, self._norm_zero, self._norm_pure = len(self._log), False, True   # same crops as last image
+                return
+            self._norm.zero_()
+            self._norm_zero, self._norm_pure, self._norm_key = False, True, None
+        pending = self._log[self._applied:]
+        if pending:
+            xy = np.ascontiguousarray(np.concatenate(pending, axis=1))
+            th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
+            lib = N.load()
+            dev = self._norm.device
+            with N.on_device(dev):
+                rc = lib.ptb_norm_accumulate(self._norm.data_ptr(), self.weight.data_ptr(), xy[0].ctypes.data_as(N._i64p),
+                                             xy[1].ctypes.data_as(N._i64p), xy.shape[1], th, tw, self.image_height,
+                                             self.image_width, None, 0, N.stream_ptr(dev))
+            N.bump()
+            N.check(rc, "TileMerger.norm_mask")
+            self._applied = len(self._log)
+        if self._norm_pure:
+            self._norm_key = self._log_key()
 
     def _materialize(self):
         """Zero-fill the blocks no kernel has written yet, so the tensors read as plain zero-initialised accumulators."""
         fresh = self._fresh
         if not fresh.any():
             return
+        eager = self._eager_norm   # lazy mode: the normaliser is not tied to the image's first-touch bitmap
         if fresh.all():
             self._image.zero_()
-            self._norm.zero_()
+            if eager:
+                self._norm.zero_()
         else:
             rows = np.nonzero(fresh.any(axis=1))[0]
             i = 0
@@ -335,7 +383,8 @@ class TileMerger:
                         m += 1
                     x0, x1 = int(cols[k]) * 64, min(self.image_width, (int(cols[m]) + 1) * 64)
                     self._image[:, y0:y1, x0:x1] = 0
-                    self._norm[:, y0:y1, x0:x1] = 0
+                    if eager:
+                        self._norm[:, y0:y1, x0:x1] = 0
                     k = m + 1
                 i = j + 1
         fresh[:] = 0
@@ -372,14 +421,15 @@ class TileMerger:
         lib = N.load()
         dev = self._image.device
         varr = N.int_array(views) if views is not None else None
+        norm_ptr = self._norm.data_ptr() if self._eager_norm else None
 
         def launch(fresh_ptr):
             if views is None:
                 return lib.ptb_tile_accumulate(
-                    self._image.data_ptr(), self._norm.data_ptr(), self.weight.data_ptr(), batch.data_ptr(), xs, ys,
+                    self._image.data_ptr(), norm_ptr, self.weight.data_ptr(), batch.data_ptr(), xs, ys,
                     B, self.channels, th, tw, self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
             return lib.ptb_deaug_accumulate(
-                self._image.data_ptr(), self._norm.data_ptr(), self.weight.data_ptr(), batch.data_ptr(),
+                self._image.data_ptr(), norm_ptr, self.weight.data_ptr(), batch.data_ptr(),
                 n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
                 self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
 
@@ -391,6 +441,8 @@ class TileMerger:
                 rc = launch(None)
         N.bump()
         N.check(rc, "TileMerger.integrate_batch")
+        if not self._eager_norm and B:
+            self._log.append(xy)
 
     # ------------------------------------------------------------------ reference API
     def accumulate_single(self, tile: torch.Tensor, coords):
@@ -424,6 +476,7 @@ class TileMerger:
         return self._image.device
 
     def _merge_into(self, out):
+        self._norm_ready()
         self._materialize()
         self._check_state()
         lib = N.load()
@@ -471,6 +524,7 @@ class TileMerger:
         kind, out_dtype = self._CROP_KINDS[key]
         if top < 0 or left < 0 or oh < 0 or ow < 0 or top + oh > self.image_height or left + ow > self.image_width:
             raise ValueError("crop window is outside the accumulator")
+        self._norm_ready()
         self._materialize()
         self._check_state()
         shape = (oh, ow) if argmax else ((oh, ow, self.channels) if layout == "hwc" else (self.channels, oh, ow))

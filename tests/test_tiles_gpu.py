@@ -333,3 +333,66 @@ def test_first_touch_reset_and_reuse(dev):
     m.image = torch.ones_like(m.image)
     m.norm_mask = torch.full_like(m.norm_mask, 2.0)
     assert float(m.merge().max()) == 0.5
+
+
+def test_lazy_norm_mask_cache_and_eager_switch(dev, native):
+    """``norm_mask`` is data independent: the accumulate kernels skip it, ``merge`` materialises it from the crop log and
+    reuses the buffer when the next image brings the same crops.  Every observable value stays the reference's."""
+    geom = TO.slicer_geometry((512, 768), (256, 256), (128, 128))
+    w = TO.pyramid_window(256, 256)[0]
+    crops, n = geom["crops"], len(geom["crops"])
+    rng = np.random.default_rng(11)
+    imgs = [rng.standard_normal((n, 2, 256, 256)).astype(np.float32) for _ in range(3)]
+    m = _merger(geom["target_shape"], 2, w, dev)
+
+    def run(pred, order=None, batch=5):
+        idx = np.arange(n) if order is None else order
+        st = TO.merger_new(geom["target_shape"], 2, w)
+        for b0 in range(0, n, batch):
+            sel = idx[b0:b0 + batch]
+            m.integrate_batch(torch.from_numpy(pred[sel]).to(dev), crops[sel])
+            TO.merger_integrate(st, pred[sel], crops[sel])
+        return st
+
+    st = run(imgs[0])
+    c0 = native.calls
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    first_merge_calls = native.calls - c0           # norm accumulate + merge
+    m.reset()
+    st = run(imgs[1])
+    c0 = native.calls
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    assert native.calls - c0 == first_merge_calls - 1, "the normaliser of an identical crop log must be reused"
+    # a different tile order is a different log (fp32 sums depend on the order): rebuilt, still bit exact
+    m.reset()
+    order = rng.permutation(n)
+    st = run(imgs[2], order)
+    c0 = native.calls
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    assert native.calls - c0 == first_merge_calls
+    assert np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"])
+    # partial merge, more tiles, merge again; then a read of norm_mask switches to the kernel-maintained mode
+    m.reset()
+    st = TO.merger_new(geom["target_shape"], 2, w)
+    for lo, hi in ((0, 4), (4, 9)):
+        m.integrate_batch(torch.from_numpy(imgs[0][lo:hi]).to(dev), crops[lo:hi])
+        TO.merger_integrate(st, imgs[0][lo:hi], crops[lo:hi])
+        assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st), equal_nan=True)
+    held = m.norm_mask
+    assert np.array_equal(held.cpu().numpy(), st["norm_mask"])
+    m.integrate_batch(torch.from_numpy(imgs[0][9:]).to(dev), crops[9:])
+    TO.merger_integrate(st, imgs[0][9:], crops[9:])
+    assert np.array_equal(held.cpu().numpy(), st["norm_mask"]), "a handed-out norm_mask must keep tracking the integrate calls"
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    # after such a cycle nothing stale is reused
+    m.reset()
+    st = run(imgs[1])
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    # a new window invalidates the cached normaliser
+    m.reset()
+    w2 = (w * 0.5 + 0.1).astype(w.dtype)
+    m.weight = torch.from_numpy(w2[None]).to(dev, torch.float32)
+    st = TO.merger_new(geom["target_shape"], 2, w2)
+    m.integrate_batch(torch.from_numpy(imgs[1]).to(dev), crops)
+    TO.merger_integrate(st, imgs[1], crops)
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
