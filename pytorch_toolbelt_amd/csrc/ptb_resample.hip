@@ -157,10 +157,17 @@ __global__ __launch_bounds__(256) void ms_reduce_kernel(const MsArgs a, float* _
 // tile's taps fall into (<= 24 x 96 floats for ratios up to 1.25) into LDS with coalesced 16-byte loads, then all
 // 4-tap gathers hit LDS instead of issuing 16 scattered 4-byte global loads per lane and scale.  Windows that do not
 // fit (strong down-sampling) fall back to direct global gathers for that scale.
-constexpr int MS_TW = 64, MS_TH = 16, MS_LR = 24, MS_LC = 96;
+// LDS row pitch MS_LP = 112 floats (= 16 mod 32 banks): the 2 x 16 lanes a ds_read serves per cycle belong to two
+// output rows; with a pitch of 96 (= 0 mod 32) both rows hit the same banks (rocprof: 54 % of the LDS cycles were bank
+// conflicts), with 16 mod 32 the two rows' stride-3 / stride-5 lane patterns (scale 0.75 / 1.25) interleave exactly.
+constexpr int MS_TW = 64, MS_TH = 16, MS_LR = 24, MS_LC = 96, MS_LP = 112;
 
+// OPK: 0 = sum / mean, 2 = gmean (branch-free: the run-time switch over all reductions costs more than the gathers),
+// 1 = any other reduction
+template <int OPK>
 __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float lds[MS_LR * MS_LC];
+    __shared__ __attribute__((aligned(16))) float lds[MS_LR * MS_LP];
+    __shared__ __attribute__((aligned(16))) Taps ctap[MS_TW];  // the tile's 64 column taps, computed once per scale
     const int tiles_x = (a.wout + MS_TW - 1) / MS_TW, tiles_y = (a.hout + MS_TH - 1) / MS_TH;
     int bid = blockIdx.x;
     const int txi = bid % tiles_x;
@@ -191,48 +198,54 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
             const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
             const bool staged = nr <= MS_LR && nc <= MS_LC && (win & 3) == 0;
             if (staged) {
+                // 32 lanes x 16 B cover a window row (<= 24 float4), 8 rows per pass: no integer division per element
                 const int q_per_row = (nc + 3) / 4;
-                for (int idx = tid; idx < nr * q_per_row; idx += 256) {
-                    const int rr = idx / q_per_row, q4 = idx - rr * q_per_row;
-                    const int col = c_lo + 4 * q4;
-                    if (col < win)  // win % 4 == 0 and col % 4 == 0: the whole float4 is inside the row
-                        *reinterpret_cast<float4*>(&lds[rr * MS_LC + 4 * q4]) =
+                const int q4 = tid & 31, col = c_lo + 4 * q4;
+                if (q4 < q_per_row && col < win) {  // win % 4 == 0 and col % 4 == 0: the whole float4 is inside the row
+                    for (int rr = tid >> 5; rr < nr; rr += 8)
+                        *reinterpret_cast<float4*>(&lds[rr * MS_LP + 4 * q4]) =
                             *reinterpret_cast<const float4*>(src + (long long)(r_lo + rr) * win + col);
                 }
+                if (tid < MS_TW) ctap[tid] = taps(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
                 __syncthreads();
             }
             if (row_ok) {
+                // branch-free: columns past the right edge use the clamped tap of the last column (computed, never
+                // stored), so all 16 gathers of the lane are issued back to back instead of one pixel at a time
                 const Taps ty = taps(oy, a.sh[s], hin, a.align_corners);
+                Taps tx[4];
+                float t[4][4];
+                if (staged) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (ox + m < a.wout) {
-                        const Taps tx = taps(ox + m, a.sw[s], win, a.align_corners);
-                        float t00, t01, t10, t11;
-                        if (staged) {
-                            const float* l0 = lds + (ty.i0 - r_lo) * MS_LC - c_lo;
-                            const float* l1 = lds + (ty.i1 - r_lo) * MS_LC - c_lo;
-                            t00 = l0[tx.i0]; t01 = l0[tx.i1]; t10 = l1[tx.i0]; t11 = l1[tx.i1];
-                        } else {
-                            const float* g0 = src + (long long)ty.i0 * win;
-                            const float* g1 = src + (long long)ty.i1 * win;
-                            t00 = g0[tx.i0]; t01 = g0[tx.i1]; t10 = g1[tx.i0]; t11 = g1[tx.i1];
-                        }
-                        v[m] = ty.l0 * (tx.l0 * t00 + tx.l1 * t01) + ty.l1 * (tx.l0 * t10 + tx.l1 * t11);
-                    }
+                    for (int m = 0; m < 4; ++m) tx[m] = ctap[4 * lx + m];
+                    const float* l0 = lds + (ty.i0 - r_lo) * MS_LP - c_lo;
+                    const float* l1 = lds + (ty.i1 - r_lo) * MS_LP - c_lo;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { t[m][0] = l0[tx[m].i0]; t[m][1] = l0[tx[m].i1]; t[m][2] = l1[tx[m].i0]; t[m][3] = l1[tx[m].i1]; }
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) tx[m] = taps(min(ox + m, a.wout - 1), a.sw[s], win, a.align_corners);
+                    const float* g0 = src + (long long)ty.i0 * win;
+                    const float* g1 = src + (long long)ty.i1 * win;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { t[m][0] = g0[tx[m].i0]; t[m][1] = g0[tx[m].i1]; t[m][2] = g1[tx[m].i0]; t[m][3] = g1[tx[m].i1]; }
                 }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    v[m] = ty.l0 * (tx[m].l0 * t[m][0] + tx[m].l1 * t[m][1]) + ty.l1 * (tx[m].l0 * t[m][2] + tx[m].l1 * t[m][3]);
             }
             if (staged) __syncthreads();  // the next scale reuses the LDS window
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const float t = a.op >= PTB_RED_GMEAN ? ms_pre(v[m], a.op) : v[m];
+            const float t = OPK == 0 ? v[m] : (OPK == 2 ? ms_log(v[m]) : ms_pre(v[m], a.op));
             acc[m] = s ? acc[m] + t : t;
         }
     }
     if (!row_ok) return;
     float res[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) res[m] = ms_post(acc[m], a.op, (float)a.n);
+    for (int m = 0; m < 4; ++m) res[m] = OPK == 2 ? ms_exp(acc[m] / (float)a.n) : ms_post(acc[m], a.op, (float)a.n);
     float* o = out + (p * a.hout + oy) * (long long)a.wout + ox;
     if ((a.wout & 3) == 0 && ox + 3 < a.wout) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
     else for (int m = 0; m < 4; ++m) if (ox + m < a.wout) o[m] = res[m];
@@ -285,7 +298,11 @@ extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, co
     a.n = n; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners; a.op = reduction;
     const long long tiles = planes * ((hout + MS_TH - 1) / MS_TH) * ((wout + MS_TW - 1) / MS_TW);
     if (g_ms_tiled && tiles <= 0x7fffffffLL) {
-        hipLaunchKernelGGL(ms_reduce_tiled_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a, out);
+        const dim3 grid((unsigned)tiles), block(256);
+        hipStream_t st = (hipStream_t)stream;
+        if (reduction == PTB_RED_GMEAN) hipLaunchKernelGGL(ms_reduce_tiled_kernel<2>, grid, block, 0, st, a, out);
+        else if (reduction >= PTB_RED_GMEAN) hipLaunchKernelGGL(ms_reduce_tiled_kernel<1>, grid, block, 0, st, a, out);
+        else hipLaunchKernelGGL(ms_reduce_tiled_kernel<0>, grid, block, 0, st, a, out);
         return check_launch();
     }
     const long long total = planes * hout * ((wout + 3) / 4);
