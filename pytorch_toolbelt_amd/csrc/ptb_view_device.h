@@ -63,18 +63,25 @@ enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
 constexpr float kEps = 1e-6f;
 constexpr float kOneMinusEps = (float)(1.0 - 1e-6);
 
+// v_log_f32 / v_exp_f32 / v_rcp_f32 (1 ulp each) instead of libm: on probabilities and their logs the results stay within
+// ~1e-7 (relative for the reciprocal forms) of the libm values, far inside the 1e-5 parity tolerance, while the libm
+// versions made the non-linear reductions ALU-bound (log1p: 213 us instead of 52 us per 8-tile d4 batch).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 template <int OPK>
 __device__ __forceinline__ float red_pre(float x, int op) {
     if (OPK == 0) return x;
     switch (op) {
-        case PTB_RED_GMEAN: return logf(x);                                   // functional.py:261
-        case PTB_RED_HMEAN: return 1.0f / (x < kEps ? kEps : x);              // functional.py:275
-        case PTB_RED_HARMONIC1P: return 1.0f / (x + 1.0f);                    // functional.py:292
-        case PTB_RED_LOGODD: {                                               // functional.py:311-312
+        case PTB_RED_GMEAN: return fast_log(x);                                  // functional.py:261
+        case PTB_RED_HMEAN: return fast_rcp(x < kEps ? kEps : x);                // functional.py:275
+        case PTB_RED_HARMONIC1P: return fast_rcp(x + 1.0f);                      // functional.py:292
+        case PTB_RED_LOGODD: {                                                   // functional.py:311-312
             float p = x < kEps ? kEps : (x > kOneMinusEps ? kOneMinusEps : x);
-            return logf(p / (1.0f - p));
+            return fast_log(p * fast_rcp(1.0f - p));
         }
-        case PTB_RED_LOG1P: return log1pf(x);                                 // functional.py:330
+        case PTB_RED_LOG1P: return fast_log(1.0f + x);                           // functional.py:330
         default: return x;
     }
 }
@@ -84,11 +91,11 @@ __device__ __forceinline__ float red_post(float s, int op, float divisor) {
     if (OPK == 0) return divisor == 1.0f ? s : s / divisor;
     const float m = s / divisor;
     switch (op) {
-        case PTB_RED_GMEAN: return expf(m);
-        case PTB_RED_HMEAN: return 1.0f / (m < kEps ? kEps : m);
-        case PTB_RED_HARMONIC1P: return 1.0f / m - 1.0f;
-        case PTB_RED_LOGODD: { const float e = expf(m); return e / (1.0f + e); }
-        case PTB_RED_LOG1P: return expf(m) - 1.0f;
+        case PTB_RED_GMEAN: return fast_exp(m);
+        case PTB_RED_HMEAN: return fast_rcp(m < kEps ? kEps : m);
+        case PTB_RED_HARMONIC1P: return fast_rcp(m) - 1.0f;
+        case PTB_RED_LOGODD: { const float e = fast_exp(m); return e * fast_rcp(1.0f + e); }
+        case PTB_RED_LOG1P: return fast_exp(m) - 1.0f;
         default: return m;
     }
 }

@@ -121,6 +121,23 @@ def cfg5():
     print(f"{'cfg5 fliplr de-augment per scale + fused ms gmean (SURVEY 8d bytes)':70s} {alg2 / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+def nonlinear():
+    """Non-linear TTA reductions through the view kernels (probability inputs): d4 de-augment and the fused merge."""
+    dev = torch.device("cuda:0")
+    B, C, T = 8, 4, 512
+    bufs = [torch.rand((8 * B, C, T, T), device=dev) * 0.9 + 0.05 for _ in range(6)]
+    nbytes = bufs[0].numel() * 4
+    slicer = ImageSlicer((5000, 5000, 3), T, 256, weight="pyramid")
+    merger = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    crops_row = slicer.crops[:8]
+    for red in ("mean", "gmean", "hmean", "logodd", "log1p", "harmonic1p"):
+        code = V.REDUCTION_CODES[red]
+        t = timeit(lambda i: V._raw_deaug_reduce(bufs[i], list(DEAUGMENT_VIEWS["d4"]), code), 20, 6)
+        print(f"{'d4 de-augment reduction=%s (read bytes)' % red:70s} {nbytes / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+        t = timeit(lambda i: merger.integrate_batch_deaugment(bufs[i], crops_row, group="d4", reduction=red), 20, 6)
+        print(f"{'fused d4 accumulate reduction=%s (read bytes)' % red:70s} {nbytes / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+
+
 def edges():
     """Device-side loop edges at the cfg2 geometry: split_device of 8 tiles (d4, affine) and merge_crop."""
     dev = torch.device("cuda:0")
@@ -167,6 +184,9 @@ def ensemble():
     print(f"{'same (softmax, gmean) as the reference op chain in eager torch':70s} {by / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "nonlinear":
+    nonlinear()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "ensemble":
     ensemble()
     sys.exit(0)
