@@ -6,9 +6,11 @@ One *step* = one full pass of the hot path over one 5000x5000x3 image: 361 tiles
 accumulation in batches of 8 tiles (46 HIP launches) -> merge (image / norm_mask).  The model forward is excluded
 (the config's "dummy UNet" only produces these tensors).  Every step starts from (logically) zero accumulators:
 `reset()` re-arms the first-touch bitmap, so the first write of each block is a store and no memset is needed.  The
-normaliser `norm_mask` depends only on the crop list and the window: the accumulate kernels skip it, `merge()` builds
-it from the logged crops and keeps it while the following images bring the same crops (SURVEY 8d counts it as
-precomputable, not compulsory, traffic); `--memset-accumulators` restores the kernel-maintained normaliser for A/B.
+normaliser `norm_mask` depends only on the crop list and the window (SURVEY 8d counts it as precomputable, not
+compulsory, traffic): the accumulate kernels skip it, `merge()` builds it from the logged crops and keeps it while the
+following images bring the same crops.  A/B switches: `--planned` (merger constructed with the crop list: every block is
+divided in the launch that brings its last tile, no merge pass), `--memset-accumulators` (kernel-maintained normaliser,
+memset accumulators: the reference's literal data flow).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -43,6 +45,7 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
     ap.add_argument("--memset-accumulators", action="store_true", help="A/B: zero the accumulators with a memset each step instead of first-touch stores")
     ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
+    ap.add_argument("--planned", action="store_true", help="A/B: TileMerger(crops=tiler.crops): blocks are normalised in the launch of their last tile, no merge pass")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
@@ -138,7 +141,10 @@ def main():
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
 
     if not sharded:
-        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
+        # --planned: TileMerger(crops=...) divides each block in the launch that brings its last tile (no merge pass);
+        # measured +1..2 % end to end, at the price of 3 us more per accumulate launch -- not the default
+        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev,
+                            crops=slicer.crops if (args.planned and not args.memset_accumulators) else None)
     else:
         merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev)
 

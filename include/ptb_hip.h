@@ -77,6 +77,24 @@ int ptb_tile_accumulate(float* image, float* norm, const float* weight, const fl
                         const int64_t* ys, int B, int C, int th, int tw, int H, int W, uint8_t* fresh, int fresh_rows,
                         ptb_stream_t stream);
 
+/* Planned accumulation (no reference counterpart; the result must equal integrate_batch(...) followed by merge()): the
+ * caller knows the complete crop list of the image up front.  `remaining` / `done` are HOST byte maps on the block grid of
+ * the first-touch bitmap (64 columns x fresh_rows rows): remaining[b] = planned tiles that have not yet touched block b
+ * (initialised by the caller from the crop list), done[b] = the merged value of b has been written.  The call works like
+ * ptb_deaug_accumulate (V = 1, views = {PTB_VIEW_IDENT}, PTB_RED_SUM for plain tiles) except that cells whose blocks
+ * receive their last planned tile in this launch are written as (sum / norm_full) into `merged` [C,H,W] instead of into
+ * `image` -- the separate merge pass disappears for them -- and no norm is accumulated (norm_full [H,W] = the complete,
+ * data-independent normaliser in integration order).  The library updates both maps.  One launch group per call:
+ * PTB_EUNSUPPORTED (nothing launched) if the batch needs several groups, is not block aligned, or does not fit the plan;
+ * PTB_EFRESH as above.  Blocks with done == 0 at the end are merged by ptb_merge_div_masked. */
+int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const float* in, int V,
+                           const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw,
+                           int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, ptb_stream_t stream);
+/* out[c] = image[c] / norm on the blocks (64 columns x rows rows, row-major grid) whose byte in the DEVICE map `mask` is
+ * non-zero; other blocks of `out` are left untouched. */
+int ptb_merge_div_masked(const float* image, const float* norm, float* out, int C, int H, int W, const uint8_t* mask, int rows,
+                         ptb_stream_t stream);
+
 /* norm[0, y:y+th, x:x+tw] += weight for b in 0..B-1, in order (the norm_mask half of integrate_batch: same race-free cell
  * ownership, same summation order, same optional first-touch bitmap -- a SEPARATE bitmap from the image's). */
 int ptb_norm_accumulate(float* norm, const float* weight, const int64_t* xs, const int64_t* ys, int B, int th, int tw, int H,
@@ -109,7 +127,7 @@ int ptb_split_tiles_u8(const uint8_t* image, int IH, int IW, int IC, const int64
                        ptb_stream_t stream);
 /* ptb_merge_crop == TileMerger.merge (tiles.py:345-346) -> np.moveaxis(.., 0, -1) -> .astype(uint8) | argmax
  * -> ImageSlicer.crop_to_orignal_size (tiles.py:271-280; README.md:225-226): window [top, top+OH) x [left, left+OW) of
- * image[C,H,W] / norm[H,W].  layout 0: out [C, OH, OW], 1: out [OH, OW, C].  kind 0: float32; 1: uint8 by truncating
+ * image[C,H,W] / norm[H,W] (norm == NULL: image is already normalised).  layout 0: out [C, OH, OW], 1: out [OH, OW, C].  kind 0: float32; 1: uint8 by truncating
  * cast (numpy .astype on x86-64: low byte of the int32 truncation, 0 for NaN / out of int32 range); 2 / 3: argmax over
  * channels as uint8 / int64 [OH, OW] (first maximum, NaN counts as maximum; layout ignored). */
 int ptb_merge_crop(const float* image, const float* norm, int C, int H, int W, int top, int left, int OH, int OW, int layout,

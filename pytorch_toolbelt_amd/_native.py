@@ -35,6 +35,9 @@ SIGNATURES = {
     "ptb_last_hip_error": (ctypes.c_char_p, []),
     "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
     "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
+    "ptb_accumulate_planned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                        _vp, _c_int, _vp, _vp, _vp]),
+    "ptb_merge_div_masked": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_norm_accumulate": (_c_int, [_vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_debug_plan": (_c_int, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _ip, _c_int]),
     "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),

@@ -58,9 +58,38 @@ __global__ __launch_bounds__(256) void merge_div_scalar_kernel(const float* __re
     }
 }
 
+// merge restricted to the accumulator blocks (64 columns x `rows` rows) whose byte in `mask` is non-zero: the blocks a
+// planned accumulation has not finalised itself.  One workgroup per block, 16 B per lane.
+__global__ __launch_bounds__(256) void merge_div_masked_kernel(const float* __restrict__ image, const float* __restrict__ norm,
+                                                               float* __restrict__ out, int C, int H, int W,
+                                                               const uint8_t* __restrict__ mask, int rows) {
+    const int nbx = (W + 63) / 64;
+    const int bx = blockIdx.x % nbx, by = blockIdx.x / nbx;
+    if (!mask[blockIdx.x]) return;
+    const long long plane = (long long)H * W;
+    const int x0 = bx * 64, y0 = by * rows;
+    const int cw = min(64, W - x0), ch = min(rows, H - y0);
+    for (int e = threadIdx.x; e < ch * cw; e += blockDim.x) {
+        const int r = e / cw, cc = e - r * cw;
+        const long long off = (long long)(y0 + r) * W + x0 + cc;
+        const float n = norm[off];
+        for (int c = 0; c < C; ++c) out[c * plane + off] = __fdiv_rn(image[c * plane + off], n);
+    }
+}
+
 }  // namespace ptb
 
 using namespace ptb;
+
+extern "C" int ptb_merge_div_masked(const float* image, const float* norm, float* out, int C, int H, int W, const uint8_t* mask,
+                                    int rows, ptb_stream_t stream) {
+    if (!image || !norm || !out || !mask || C < 1 || H < 1 || W < 1 || rows < 1) return PTB_EINVAL;
+    const long long blocks = (long long)((W + 63) / 64) * ((H + rows - 1) / rows);
+    if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    hipLaunchKernelGGL(merge_div_masked_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, norm, out, C, H, W,
+                       mask, rows);
+    return check_launch();
+}
 
 extern "C" int ptb_version(void) { return 100; }
 

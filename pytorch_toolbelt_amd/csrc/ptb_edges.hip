@@ -105,6 +105,7 @@ __device__ __forceinline__ uint8_t cast_u8(float v) {
 
 // 4 consecutive source floats of one row; `vec` (uniform): the window is 16 B aligned in the accumulator
 __device__ __forceinline__ void load_px4(const float* p, int nv, bool vec, float* o) {
+    if (!p) { o[0] = o[1] = o[2] = o[3] = 1.0f; return; }  // norm == NULL: the image is already normalised
     if (vec && nv == 4) {
         const float4 t = ld16<true>(p);
         o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
@@ -136,11 +137,13 @@ __global__ __launch_bounds__(256) void merge_crop_planar_kernel(const CropArgs a
         const long long dpx = (long long)y * a.OW + x;
         float n[4], v[4], best[4];
         int arg[4];
-        load_px4(a.norm + src, nv, vec, n);
+        load_px4(a.norm ? a.norm + src : nullptr, nv, vec, n);
         for (int c = 0; c < a.C; ++c) {
             load_px4(a.image + c * iplane + src, nv, vec, v);
+            if (a.norm) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) v[m] = __fdiv_rn(v[m], n[m]);  // tiles.py:346: no eps clamp
+                for (int m = 0; m < 4; ++m) v[m] = __fdiv_rn(v[m], n[m]);  // tiles.py:346: no eps clamp
+            }
             if (a.kind >= OUT_ARGMAX_U8) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)  // first maximum wins; NaN counts as the maximum (numpy / torch argmax)
@@ -180,12 +183,14 @@ __global__ __launch_bounds__(256) void merge_crop_hwc_kernel(const CropArgs a, b
         const long long src = (long long)(y + a.top) * a.W + a.left + x;
         const long long dpx = (long long)y * a.OW + x;
         float n[4], v[CT][4];
-        load_px4(a.norm + src, nv, vec, n);
+        load_px4(a.norm ? a.norm + src : nullptr, nv, vec, n);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
             load_px4(a.image + c * iplane + src, nv, vec, v[c]);
+            if (a.norm) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) v[c][m] = __fdiv_rn(v[c][m], n[m]);
+                for (int m = 0; m < 4; ++m) v[c][m] = __fdiv_rn(v[c][m], n[m]);
+            }
         }
         // element e = m * CT + c of the thread's contiguous run; group g = elements 4g .. 4g+3
         if (a.kind == OUT_U8) {
@@ -224,10 +229,10 @@ __global__ __launch_bounds__(256) void merge_crop_hwc_generic_kernel(const CropA
         const long long src = (long long)(y + a.top) * a.W + a.left + x;
         const long long dpx = (long long)y * a.OW + x;
         float n[4];
-        for (int m = 0; m < nv; ++m) n[m] = a.norm[src + m];
+        for (int m = 0; m < nv; ++m) n[m] = a.norm ? a.norm[src + m] : 1.0f;
         for (int c = 0; c < a.C; ++c) {
             for (int m = 0; m < nv; ++m) {
-                const float v = __fdiv_rn(a.image[c * iplane + src + m], n[m]);
+                const float v = a.norm ? __fdiv_rn(a.image[c * iplane + src + m], n[m]) : a.image[c * iplane + src + m];
                 const long long o = (dpx + m) * a.C + c;
                 if (a.kind == OUT_U8) static_cast<uint8_t*>(a.out)[o] = cast_u8(v);
                 else static_cast<float*>(a.out)[o] = v;
@@ -297,7 +302,7 @@ extern "C" int ptb_split_tiles_u8(const uint8_t* image, int IH, int IW, int IC, 
 
 extern "C" int ptb_merge_crop(const float* image, const float* norm, int C, int H, int W, int top, int left, int OH, int OW,
                               int layout, int kind, void* out, ptb_stream_t stream) {
-    if (!image || !norm || !out || C < 1 || H < 1 || W < 1 || OH < 0 || OW < 0) return PTB_EINVAL;
+    if (!image || !out || C < 1 || H < 1 || W < 1 || OH < 0 || OW < 0) return PTB_EINVAL;
     if (top < 0 || left < 0 || (long long)top + OH > H || (long long)left + OW > W) return PTB_EBOUNDS;
     if (layout < 0 || layout > 1 || kind < OUT_F32 || kind > OUT_ARGMAX_I64) return PTB_EINVAL;
     if (kind == OUT_ARGMAX_U8 && C > 256) return PTB_EUNSUPPORTED;

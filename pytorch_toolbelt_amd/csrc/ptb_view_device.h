@@ -25,6 +25,7 @@ struct Cell {
     int chunk_end;        // exclusive prefix of chunk counts (cells sorted heavy-first)
     int ntiles;
     int fresh;            // 1: no element of this cell was ever written -> store instead of read-modify-write
+    int final_;           // 1: every planned tile of this cell is in after this launch -> write (sum / norm) to `merged`
     int tile[MAX_COVER];  // group-local tile indices, ascending batch order
 };
 
@@ -40,6 +41,8 @@ struct ViewArgs {
     float* dst;           // plain output, or the accumulator image
     float* norm;          // accumulate mode
     const float* weight;  // accumulate mode, [H, W] of the tile
+    float* merged;            // planned accumulate: the merge result [C, H, W] (same strides as dst) ...
+    const float* norm_full;   // ... and the complete normaliser [H, W] it is divided by
     int H, W, C;          // output-tile rows / cols, channels
     long long src_view_stride;  // elements between consecutive views of one tile (B*C*H*W)
     long long src_tile_stride;  // C*H*W

@@ -191,8 +191,17 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
         }
     }
     if (act) {
-        *reinterpret_cast<float4*>(ip) = acc;
-        if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
+        if (cell.final_) {
+            // last touch of a planned cell: the weighted sum is complete, so the merged value (tiles.py:346) is written
+            // right away and the accumulator is never stored -- the separate merge pass over this cell disappears
+            const long long off = (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+            const float4 n4 = *reinterpret_cast<const float4*>(a.norm_full + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q);
+            *reinterpret_cast<float4*>(a.merged + off) =
+                make_float4(__fdiv_rn(acc.x, n4.x), __fdiv_rn(acc.y, n4.y), __fdiv_rn(acc.z, n4.z), __fdiv_rn(acc.w, n4.w));
+        } else {
+            *reinterpret_cast<float4*>(ip) = acc;
+            if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
+        }
     }
 }
 
@@ -355,8 +364,12 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
             acc = __fadd_rn(acc, __fmul_rn(val, w));
             nacc = __fadd_rn(nacc, w);
         }
-        a.dst[(long long)c * a.dst_chan_stride + off] = acc;
-        if (do_norm) a.norm[off] = nacc;
+        if (cell.final_) {
+            a.merged[(long long)c * a.dst_chan_stride + off] = __fdiv_rn(acc, a.norm_full[off]);
+        } else {
+            a.dst[(long long)c * a.dst_chan_stride + off] = acc;
+            if (do_norm) a.norm[off] = nacc;
+        }
     }
 }
 
@@ -452,8 +465,76 @@ static void mark_written(const std::vector<Cell>& cells, const Fresh& fr) {
             for (int bx = c.ox / CW; bx <= (c.ox + c.w - 1) / CW; ++bx) fr.map[by * nbx + bx] = 0;
 }
 
+// Planned accumulation (the caller knows every tile the image will receive): `rem` counts, per accumulator block, the
+// planned tiles that have not touched it yet; `done` marks blocks whose merged value has been written.  Same block grid
+// as Fresh.  A cell whose block rows all drop to zero in this launch is final.  The planned geometry is block aligned
+// (checked by the caller), so every block lies inside exactly one cell of a launch.
+struct Plan {
+    uint8_t* rem;   // null: not planned
+    uint8_t* done;
+    int rows, H, W;
+    int nbx() const { return (W + CW - 1) / CW; }
+};
+
+enum { DECOMP_PLAN_MISMATCH = 3 };
+
+static int apply_plan(std::vector<Cell>& cells, const Plan& pl) {
+    if (!pl.rem) return DECOMP_OK;
+    std::vector<Cell> out;
+    std::vector<uint8_t> fin;
+    const int nbx = pl.nbx();
+    for (const Cell& c : cells) {
+        const bool aligned = c.ox % CW == 0 && c.oy % pl.rows == 0 && (c.w % CW == 0 || c.ox + c.w == pl.W) &&
+                             (c.h % pl.rows == 0 || c.oy + c.h == pl.H);
+        if (!aligned) return DECOMP_PLAN_MISMATCH;
+        const int bx0 = c.ox / CW, bx1 = (c.ox + c.w - 1) / CW, by0 = c.oy / pl.rows, by1 = (c.oy + c.h - 1) / pl.rows;
+        const int nx = bx1 - bx0 + 1, ny = by1 - by0 + 1;
+        fin.assign((size_t)nx * ny, 0);
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) {
+                const int left = (int)pl.rem[by * nbx + bx] - c.ntiles;
+                if (left < 0 || pl.done[by * nbx + bx]) return DECOMP_PLAN_MISMATCH;  // more tiles than planned here
+                fin[(size_t)(by - by0) * nx + (bx - bx0)] = left == 0;
+            }
+        // any sub-rectangle of a cell is a cell with the same cover: cut into column strips wherever two neighbouring
+        // block columns differ in some row, then into row runs of uniform finality inside each strip
+        int sx0 = 0;
+        for (int sx = 1; sx <= nx; ++sx) {
+            bool cut = sx == nx;
+            for (int y = 0; y < ny && !cut; ++y) cut = fin[(size_t)y * nx + sx] != fin[(size_t)y * nx + sx - 1];
+            if (!cut) continue;
+            int run_start = 0;
+            for (int y = 1; y <= ny; ++y) {
+                if (y < ny && fin[(size_t)y * nx + sx0] == fin[(size_t)run_start * nx + sx0]) continue;
+                Cell piece = c;
+                piece.ox = (bx0 + sx0) * CW;
+                piece.w = std::min((bx0 + sx) * CW, c.ox + c.w) - piece.ox;
+                piece.oy = (by0 + run_start) * pl.rows;
+                piece.h = std::min((by0 + y) * pl.rows, c.oy + c.h) - piece.oy;
+                piece.final_ = fin[(size_t)run_start * nx + sx0];
+                out.push_back(piece);
+                run_start = y;
+            }
+            sx0 = sx;
+        }
+    }
+    cells.swap(out);
+    return DECOMP_OK;
+}
+
+static void commit_plan(const std::vector<Cell>& cells, const Plan& pl) {
+    if (!pl.rem) return;
+    const int nbx = pl.nbx();
+    for (const Cell& c : cells)
+        for (int by = c.oy / pl.rows; by <= (c.oy + c.h - 1) / pl.rows; ++by)
+            for (int bx = c.ox / CW; bx <= (c.ox + c.w - 1) / CW; ++bx) {
+                pl.rem[by * nbx + bx] = (uint8_t)(pl.rem[by * nbx + bx] - c.ntiles);
+                if (c.final_) pl.done[by * nbx + bx] = 1;
+            }
+}
+
 static int decompose(const int* xs, const int* ys, const int* ids, int n, int tw, int th, int chunk_rows, const Fresh& fr,
-                     CellArgs& out, int& ncells, int& total_chunks, std::vector<Cell>& cells) {
+                     CellArgs& out, int& ncells, int& total_chunks, std::vector<Cell>& cells, const Plan* plan = nullptr) {
     if (n > MAX_GROUP) return DECOMP_SPLIT;
     std::vector<int> ye;
     ye.reserve(2 * n);
@@ -496,6 +577,7 @@ static int decompose(const int* xs, const int* ys, const int* ids, int n, int tw
         }
     }
     if (int rc = apply_freshness(cells, fr)) return rc;
+    if (plan) if (int rc = apply_plan(cells, *plan)) return rc;
     if ((int)cells.size() > MAX_CELLS) return DECOMP_SPLIT;
     std::stable_sort(cells.begin(), cells.end(), [](const Cell& a, const Cell& b) { return a.ntiles > b.ntiles; });
     int run = 0;
@@ -789,6 +871,52 @@ extern "C" int ptb_tile_accumulate(float* image, float* norm, const float* weigh
     const int ident = PTB_VIEW_IDENT;
     return accumulate_impl(image, norm, weight, tiles, 1, &ident, PTB_RED_SUM, xs, ys, B, C, th, tw, H, W, fresh, fresh_rows,
                            (hipStream_t)stream);
+}
+
+// Planned variant of ptb_tile_accumulate / ptb_deaug_accumulate: one launch group per call, see the header.
+extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const float* in, int V,
+                                      const int* views, int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th,
+                                      int tw, int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done,
+                                      ptb_stream_t stream) {
+    if (!image || !norm_full || !merged || !weight || !in || !xs64 || !ys64 || !remaining || !done) return PTB_EINVAL;
+    if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || fresh_rows < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, th, tw)) return rc;
+    if (B == 0) return PTB_OK;
+    if (B > 16) return PTB_EUNSUPPORTED;
+    int xs[16], ys[16], ids[16];
+    for (int b = 0; b < B; ++b) {
+        if (xs64[b] < 0 || ys64[b] < 0 || xs64[b] + tw > W || ys64[b] + th > H) return PTB_EBOUNDS;
+        xs[b] = (int)xs64[b]; ys[b] = (int)ys64[b]; ids[b] = b;
+        if (xs[b] % CW || ys[b] % fresh_rows) return PTB_EUNSUPPORTED;
+    }
+    ViewArgs a{};
+    a.src = in; a.dst = image; a.norm = nullptr; a.weight = weight; a.merged = merged; a.norm_full = norm_full;
+    a.H = th; a.W = tw; a.C = C;
+    a.src_view_stride = (long long)B * C * th * tw;
+    a.src_tile_stride = (long long)C * th * tw;
+    a.dst_chan_stride = (long long)H * W;
+    a.dst_row_stride = W;
+    a.nviews = V;
+    a.codes = pack_runtime(V, views);
+    a.scale = 1.0f;
+    fill_reduction(a, reduction, V);
+    const int nT = count_transpose(V, a.codes);
+    const bool fast = !g_force_scalar && (tw % 4 == 0) && (W % 4 == 0) && ((long long)H * W % 4 == 0) && ((long long)th * tw % 4 == 0) &&
+                      aligned16(in) && aligned16(image) && aligned16(merged) && aligned16(norm_full) && aligned16(weight) &&
+                      nT <= MAX_T && (!nT || th % 4 == 0);
+    const int ch = fast ? g_chunk_rows : 64;
+    if (fresh_rows != ch) return PTB_EUNSUPPORTED;  // plan / first-touch block rows must equal this launch's chunk rows
+    Fresh fr{fresh, fresh_rows, H, W};
+    Plan pl{remaining, done, fresh_rows, H, W};
+    CellArgs g;
+    std::vector<Cell> cells;
+    const int st = decompose(xs, ys, ids, B, tw, th, ch, fr, g, a.ncells, a.total_chunks, cells, &pl);
+    if (st == DECOMP_NEEDS_ZERO) return PTB_EFRESH;
+    if (st != DECOMP_OK) return PTB_EUNSUPPORTED;   // several launch groups, or the batch does not fit the plan
+    const int rc = launch_group(a, g, cells, fr, fast, ch, (hipStream_t)stream);
+    if (rc == PTB_OK) commit_plan(cells, pl);
+    return rc;
 }
 
 extern "C" int ptb_norm_accumulate(float* norm, const float* weight, const int64_t* xs, const int64_t* ys, int B, int th, int tw,

@@ -254,6 +254,66 @@ def _coords_xy(crop_coords, n_expected=None):
     return arr
 
 
+class _Plan:
+    """State of a *planned* TileMerger (constructed with the complete ``crops`` of the image).
+
+    ``remaining[b]`` = planned tiles that have not touched accumulator block ``b`` (64 columns x 32 rows) yet,
+    ``done[b]`` = the block has been written to the merge result.  Finalisation is only performed while the integrate
+    calls follow the planned sequence exactly (then every partial sum, including the normaliser's, has the reference's
+    order of additions); the first deviating batch switches it off for the rest of the image and everything not yet
+    finalised goes through the ordinary accumulate + merge.  Restrictions while planned blocks are finalised: a tile
+    that touches a finished block raises, ``merger.image`` is not readable (the accumulators of finished blocks are
+    never stored) and ``merge_()`` is unavailable."""
+
+    def __init__(self, xy, remaining0, norm_full):
+        self.xy = xy                    # [2, N] int64 origins in integration order
+        self.remaining0 = remaining0
+        self.norm_full = norm_full      # [1, H, W] complete normaliser (device)
+        self.remaining = remaining0.copy()
+        self.done = np.zeros_like(remaining0)
+        self.pos = 0
+        self.active = True
+
+    @staticmethod
+    def build(merger, crops):
+        crops = _coords_xy(crops)
+        th, tw = int(merger.weight.shape[1]), int(merger.weight.shape[2])
+        H, W = merger.image_height, merger.image_width
+        if len(crops) == 0 or np.any(crops[:, 2] != tw) or np.any(crops[:, 3] != th):
+            return None
+        aligned = (tw % 64 == 0 and th % _FRESH_ROWS == 0 and not np.any(crops[:, 0] % 64) and not np.any(crops[:, 1] % _FRESH_ROWS)
+                   and np.all(crops[:, 0] >= 0) and np.all(crops[:, 1] >= 0) and np.all(crops[:, 0] + tw <= W) and np.all(crops[:, 1] + th <= H))
+        if not aligned:
+            return None   # geometry off the block grid: the ordinary path is used
+        remaining = np.zeros(((H + _FRESH_ROWS - 1) // _FRESH_ROWS, (W + 63) // 64), dtype=np.int32)
+        for x, y in crops[:, :2]:
+            remaining[y // _FRESH_ROWS:(y + th) // _FRESH_ROWS, x // 64:(x + tw) // 64] += 1
+        if remaining.max() > 255:
+            return None
+        xy = np.ascontiguousarray(crops[:, :2].T)
+        norm_full = torch.zeros((1, H, W), device=merger.weight.device, dtype=torch.float32)
+        lib = N.load()
+        dev = norm_full.device
+        with N.on_device(dev):
+            rc = lib.ptb_norm_accumulate(norm_full.data_ptr(), merger.weight.data_ptr(), xy[0].ctypes.data_as(N._i64p),
+                                         xy[1].ctypes.data_as(N._i64p), xy.shape[1], th, tw, H, W, None, 0, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger(crops=...)")
+        return _Plan(xy, remaining.astype(np.uint8), norm_full)
+
+    def restart(self):
+        self.remaining = self.remaining0.copy()
+        self.done[:] = 0
+        self.pos = 0
+        self.active = True
+
+    def touches_done(self, xy, th, tw):
+        for x, y in xy.T:
+            if self.done[y // _FRESH_ROWS:(y + th + _FRESH_ROWS - 1) // _FRESH_ROWS, x // 64:(x + tw + 63) // 64].any():
+                return True
+        return False
+
+
 class TileMerger:
     """Blend tile predictions into a full-size map that lives in HBM (reference inference/tiles.py:290-350).
 
@@ -263,7 +323,11 @@ class TileMerger:
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
 
-    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32):
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None):
+        """``crops`` (extension, optional): the complete crop list the image will receive (``tiler.crops``), in the
+        order it will be integrated.  With it the merger runs *planned*: the normaliser is known up front and every
+        block of the image is divided by it in the very launch that brings its last tile, so ``merge()`` has nothing
+        left to do.  Results are bit-identical; see ``_Plan`` for what a planned merger restricts."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(
@@ -293,16 +357,28 @@ class TileMerger:
         self._norm_key = None     # crop log the buffer content was built from, start to end, by this object alone
         self._norm_pure = False   # this cycle's _norm was built from zero by _norm_ready only
         self._eager_norm = False  # norm_mask was handed out: keep it up to date inside the accumulate kernels
+        self._merged = None       # planned mode: the merge result the accumulate launches fill in
+        self._plan = _Plan.build(self, crops) if crops is not None else None
 
     # ------------------------------------------------------------------ first-touch state
+    def _plan_off(self, what):
+        """Leave planned mode; impossible once blocks were finalised (their accumulators were never stored)."""
+        if self._plan is not None:
+            if self._plan.done.any():
+                raise RuntimeError(f"TileMerger(crops=...): {what} is not available after planned blocks were finalised; "
+                                   "call merge(), or construct the merger without crops=")
+            self._plan.active = False
+
     @property
     def image(self) -> torch.Tensor:
         """``[C, H', W']`` accumulator (zeros where nothing was integrated yet)."""
+        self._plan_off("reading .image")
         self._materialize()
         return self._image
 
     @image.setter
     def image(self, value: torch.Tensor):
+        self._plan_off("assigning .image")
         self._materialize()
         self._image = value
 
@@ -310,6 +386,8 @@ class TileMerger:
     def norm_mask(self) -> torch.Tensor:
         """``[1, H', W']`` sum of the blending windows (materialised on first access; from then on the accumulate
         kernels keep this tensor up to date, exactly like the reference's attribute)."""
+        if self._plan is not None:
+            self._plan.active = False   # (finalised blocks keep their results; the rest accumulates with this norm)
         self._norm_ready()
         self._materialize()
         self._eager_norm, self._norm_pure, self._norm_key = True, False, None
@@ -317,6 +395,8 @@ class TileMerger:
 
     @norm_mask.setter
     def norm_mask(self, value: torch.Tensor):
+        if self._plan is not None:
+            self._plan.active = False
         self._norm_ready()
         self._materialize()
         self._eager_norm, self._norm_pure, self._norm_key = True, False, None
@@ -327,6 +407,9 @@ class TileMerger:
         self._fresh[:] = 1
         self._log, self._applied = [], 0
         self._norm_zero, self._norm_pure, self._eager_norm = True, False, False
+        self._merged = None
+        if self._plan is not None:
+            self._plan.restart()
 
     def _log_key(self):
         return (self.weight.data_ptr(), self.weight._version, b"".join(a.tobytes() for a in self._log))
@@ -433,6 +516,40 @@ class TileMerger:
                 n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
                 self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
 
+        plan = self._plan
+        if plan is not None and B:
+            planned = (plan.active and not self._eager_norm and plan.pos + B <= plan.xy.shape[1]
+                       and np.array_equal(plan.xy[:, plan.pos:plan.pos + B], xy))
+            if planned:
+                if self._merged is None:
+                    self._merged = torch.empty_like(self._image)
+                ident = N.int_array([N.IDENT])
+
+                def launch_planned(fresh_ptr):
+                    return lib.ptb_accumulate_planned(
+                        self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
+                        batch.data_ptr(), n_views, varr if views is not None else ident, reduction, xs, ys, B, self.channels, th, tw,
+                        self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS,
+                        plan.remaining.ctypes.data, plan.done.ctypes.data, N.stream_ptr(dev))
+
+                with N.on_device(dev):
+                    rc = launch_planned(self._fresh.ctypes.data if self._fresh.any() else None)
+                    if rc == N.EFRESH:  # a cell straddles written and never-written blocks: zero-fill once, then plain RMW
+                        N.fresh_fallbacks += 1
+                        self._materialize()
+                        rc = launch_planned(None)
+                N.bump()
+                if rc == 0:
+                    plan.pos += B
+                    self._log.append(xy)
+                    return
+                if rc != -2:
+                    N.check(rc, "TileMerger.integrate_batch")
+                # nothing was launched: this batch (and the rest of the image) takes the ordinary path
+            plan.active = False
+            if plan.done.any() and plan.touches_done(xy, th, tw):
+                raise RuntimeError("TileMerger(crops=...): a tile touches pixels that were already finalised -- every planned "
+                                   "tile may be integrated once; construct the merger without crops= for free-form accumulation")
         with N.on_device(dev):
             rc = launch(self._fresh.ctypes.data if self._fresh.any() else None)
             if rc == N.EFRESH:  # geometry not block aligned (or a non-default chunk size): zero-fill once, then plain RMW
@@ -475,6 +592,24 @@ class TileMerger:
     def device(self) -> torch.device:
         return self._image.device
 
+    def _finish_planned(self):
+        """Planned mode: divide whatever the accumulate launches have not finalised themselves; returns the result."""
+        plan, out = self._plan, self._merged
+        pending = plan.done == 0
+        if pending.any():
+            self._norm_ready()
+            self._materialize()
+            self._check_state()
+            mask = torch.from_numpy(pending.astype(np.uint8)).to(self._image.device)
+            lib = N.load()
+            dev = self._image.device
+            with N.on_device(dev):
+                rc = lib.ptb_merge_div_masked(self._image.data_ptr(), self._norm.data_ptr(), out.data_ptr(), self.channels,
+                                              self.image_height, self.image_width, mask.data_ptr(), _FRESH_ROWS, N.stream_ptr(dev))
+            N.bump()
+            N.check(rc, "TileMerger.merge")
+        return out
+
     def _merge_into(self, out):
         self._norm_ready()
         self._materialize()
@@ -490,10 +625,15 @@ class TileMerger:
 
     def merge(self) -> torch.Tensor:
         """``image / norm_mask`` as a new tensor (no eps clamp: never-covered pixels are NaN, like the reference)."""
+        if self._merged is not None:
+            # planned: the accumulate launches have been writing the result block by block.  The buffer belongs to this
+            # image (reset() lets go of it); a second merge() of the same image returns the same, updated tensor.
+            return self._finish_planned()
         return self._merge_into(torch.empty_like(self._image))
 
     def merge_(self) -> torch.Tensor:
         """In-place ``image /= norm_mask``; returns ``image``."""
+        self._plan_off("merge_()")
         self._materialize()
         return self._merge_into(self._image)
 
@@ -524,9 +664,14 @@ class TileMerger:
         kind, out_dtype = self._CROP_KINDS[key]
         if top < 0 or left < 0 or oh < 0 or ow < 0 or top + oh > self.image_height or left + ow > self.image_width:
             raise ValueError("crop window is outside the accumulator")
-        self._norm_ready()
-        self._materialize()
-        self._check_state()
+        planned = self._merged is not None
+        if planned:
+            src, norm_ptr = self._finish_planned(), None     # already normalised
+        else:
+            self._norm_ready()
+            self._materialize()
+            self._check_state()
+            src, norm_ptr = self._image, self._norm.data_ptr()
         shape = (oh, ow) if argmax else ((oh, ow, self.channels) if layout == "hwc" else (self.channels, oh, ow))
         out = torch.empty(shape, device=self._image.device, dtype=out_dtype)
         if out.numel() == 0:
@@ -534,7 +679,7 @@ class TileMerger:
         lib = N.load()
         dev = self._image.device
         with N.on_device(dev):
-            rc = lib.ptb_merge_crop(self._image.data_ptr(), self._norm.data_ptr(), self.channels, self.image_height,
+            rc = lib.ptb_merge_crop(src.data_ptr(), norm_ptr, self.channels, self.image_height,
                                     self.image_width, top, left, oh, ow, 1 if layout == "hwc" else 0, kind, out.data_ptr(),
                                     N.stream_ptr(dev))
         N.bump()
@@ -545,5 +690,5 @@ class TileMerger:
 class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
 
-    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32):
-        super().__init__(image_shape, channels, weight, device=device, dtype=dtype)
+    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None):
+        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops)

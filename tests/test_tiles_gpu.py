@@ -396,3 +396,110 @@ def test_lazy_norm_mask_cache_and_eager_switch(dev, native):
     m.integrate_batch(torch.from_numpy(imgs[1]).to(dev), crops)
     TO.merger_integrate(st, imgs[1], crops)
     assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+
+
+def _planned_run(m, pred, crops, order, batch, dev, fused=None):
+    st = TO.merger_new((m.image_height, m.image_width), m.channels, m.weight[0].cpu().numpy())
+    for b0 in range(0, len(order), batch):
+        sel = order[b0:b0 + batch]
+        if fused is None:
+            m.integrate_batch(torch.from_numpy(pred[sel]).to(dev), crops[sel])
+            TO.merger_integrate(st, pred[sel], crops[sel])
+        else:
+            V = pred.shape[1]
+            x = np.ascontiguousarray(np.moveaxis(pred[sel], 1, 0)).reshape(V * len(sel), *pred.shape[2:])   # chunk-major views
+            m.integrate_batch_deaugment(torch.from_numpy(x).to(dev), crops[sel], group=fused, reduction="mean")
+            TO.merger_integrate(st, AO.image_deaugment(x, fused, "mean"), crops[sel])
+    return st
+
+
+@pytest.mark.parametrize("shape,tile,step,C,batch,all_final", [
+    ((1000, 1400), (256, 256), (128, 128), 3, 8, True),   # margins -> 1024 x 1536 target, everything block aligned
+    ((512, 768), (256, 256), (128, 128), 2, 5, True),
+    # step < size / 2 on x: up to 6 tiles per pixel, so a batch of 7 needs several launch groups -> that batch (and the
+    # rest of the image) falls back to the ordinary path; the result must not change
+    ((700, 640), (128, 192), (64, 64), 1, 7, False),
+    ((700, 640), (128, 192), (64, 64), 1, 2, True),
+    ((640, 640), (320, 320), (320, 320), 2, 3, True),     # no overlap: every cell is final at once
+])
+def test_planned_merger_bit_exact(shape, tile, step, C, batch, all_final, dev, native):
+    """TileMerger(crops=...): blocks are divided by the precomputed normaliser in the launch that brings their last tile;
+    merge() must equal the ordinary integrate + merge bit for bit, image after image."""
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile)[0]
+    crops, n = geom["crops"], len(geom["crops"])
+    rng = np.random.default_rng(n)
+    m = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops)
+    assert m._plan is not None
+    for rep in range(3):
+        pred = rng.standard_normal((n, C, *tile)).astype(np.float32)
+        st = _planned_run(m, pred, crops, np.arange(n), batch, dev)
+        c0 = native.calls
+        got = m.merge()
+        if all_final:
+            assert m._plan.done.all() and not m._plan.remaining.any(), "every block must have been finalised in-launch"
+            assert native.calls == c0, "nothing is left for merge() to do"
+        assert np.array_equal(got.cpu().numpy(), TO.merger_merge(st))
+        keep = got
+        m.reset()
+    assert np.array_equal(keep.cpu().numpy(), TO.merger_merge(st)), "a returned result must survive reset()"
+    # merge_crop reads the planned result
+    st = _planned_run(m, pred, crops, np.arange(n), batch, dev)
+    want = TO.merger_merge(st)[:, 3:3 + 200, 5:5 + 300]
+    assert np.array_equal(m.merge_crop((3, 5, 200, 300), layout="chw").cpu().numpy(), want)
+
+
+def test_planned_merger_fused_d4_and_deviations(dev, native):
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    geom = TO.slicer_geometry((768, 1024), (256, 256), (128, 128))
+    w = TO.pyramid_window(256, 256)[0]
+    crops, n = geom["crops"], len(geom["crops"])
+    rng = np.random.default_rng(5)
+    views = rng.standard_normal((n, 8, 2, 256, 256)).astype(np.float32)
+    m = TileMerger(geom["target_shape"], 2, w, device=dev, crops=crops)
+    st = _planned_run(m, views, crops, np.arange(n), 8, dev, fused="d4")
+    assert m._plan.done.all()
+    assert np.allclose(m.merge().cpu().numpy(), TO.merger_merge(st), atol=1e-5)
+    # same data through an unplanned merger: identical bits (the fused reduction itself is order-identical)
+    u = TileMerger(geom["target_shape"], 2, w, device=dev)
+    _planned_run(u, views, crops, np.arange(n), 8, dev, fused="d4")
+    assert torch.equal(m.merge(), u.merge())
+    # a different batch size than planned is still the planned sequence
+    m.reset()
+    pred = rng.standard_normal((n, 2, 256, 256)).astype(np.float32)
+    st = _planned_run(m, pred, crops, np.arange(n), 3, dev)
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    # deviation: the second half arrives in reverse order -> finalisation stops, the rest is merged the ordinary way
+    m.reset()
+    order = np.concatenate([np.arange(n // 2), np.arange(n // 2, n)[::-1]])
+    st = _planned_run(m, pred, crops, order, 4, dev)
+    assert not m._plan.active and not m._plan.done.all()
+    c0 = native.calls
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))
+    assert native.calls > c0
+    # partial image: merge mid-way (NaN where nothing arrived), continue, merge again
+    m.reset()
+    st = TO.merger_new(geom["target_shape"], 2, w)
+    for lo, hi in ((0, 8), (8, n)):
+        m.integrate_batch(torch.from_numpy(pred[lo:hi]).to(dev), crops[lo:hi])
+        TO.merger_integrate(st, pred[lo:hi], crops[lo:hi])
+        assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st), equal_nan=True)
+    # restrictions once blocks are final
+    with pytest.raises(RuntimeError, match="finalised"):
+        m.image
+    with pytest.raises(RuntimeError, match="finalised"):
+        m.merge_()
+    with pytest.raises(RuntimeError, match="already finalised"):
+        m.integrate_batch(torch.from_numpy(pred[:1]).to(dev), crops[:1])
+    # ...but before anything is final the plan can be dropped silently
+    m.reset()
+    m.integrate_batch(torch.from_numpy(pred[:1]).to(dev), crops[:1])       # a corner tile alone finalises its outer quarter
+    m.reset()
+    assert m.image.abs().sum() == 0 and not m._plan.active
+    # geometry off the block grid: no plan, ordinary behaviour
+    g2 = TO.slicer_geometry((500, 500), (51, 51), (26, 26))
+    m2 = TileMerger(g2["target_shape"], 1, TO.pyramid_window(51, 51)[0], device=dev, crops=g2["crops"])
+    assert m2._plan is None
