@@ -7,10 +7,12 @@ accumulation in batches of 8 tiles (46 HIP launches) -> merge (image / norm_mask
 (the config's "dummy UNet" only produces these tensors).  Every step starts from (logically) zero accumulators:
 `reset()` re-arms the first-touch bitmap, so the first write of each block is a store and no memset is needed.  The
 normaliser `norm_mask` depends only on the crop list and the window (SURVEY 8d counts it as precomputable, not
-compulsory, traffic): the accumulate kernels skip it, `merge()` builds it from the logged crops and keeps it while the
-following images bring the same crops.  A/B switches: `--planned` (merger constructed with the crop list: every block is
-divided in the launch that brings its last tile, no merge pass), `--memset-accumulators` (kernel-maintained normaliser,
-memset accumulators: the reference's literal data flow).
+compulsory, traffic): the merger is constructed with the slicer's crop list (`TileMerger(..., crops=tiler.crops)`),
+precomputes it, and divides every block in the launch that brings its last tile -- `merge()` then returns the finished
+map, so the accumulate kernel does the whole region.  A/B switches: `--unplanned` (no crop list: the accumulate kernels
+skip the normaliser, `merge()` builds it from the logged crops, reuses it while the log repeats, and runs the separate
+division pass), `--memset-accumulators` (kernel-maintained normaliser, memset accumulators: the reference's literal
+data flow).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -45,7 +47,7 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
     ap.add_argument("--memset-accumulators", action="store_true", help="A/B: zero the accumulators with a memset each step instead of first-touch stores")
     ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
-    ap.add_argument("--planned", action="store_true", help="A/B: TileMerger(crops=tiler.crops): blocks are normalised in the launch of their last tile, no merge pass")
+    ap.add_argument("--unplanned", action="store_true", help="A/B: TileMerger without crops= (lazily built norm_mask + separate merge pass)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
@@ -141,10 +143,11 @@ def main():
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
 
     if not sharded:
-        # --planned: TileMerger(crops=...) divides each block in the launch that brings its last tile (no merge pass);
-        # measured +1..2 % end to end, at the price of 3 us more per accumulate launch -- not the default
-        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev,
-                            crops=slicer.crops if (args.planned and not args.memset_accumulators) else None)
+        # planned merger: the slicer's crop list is known before the first batch (the README loop has it), so every
+        # block is divided by the precomputed normaliser in the launch that brings its last tile and merge() returns the
+        # finished map (+3 % per image; --unplanned: lazily built normaliser + separate merge pass)
+        planned = not (args.unplanned or args.memset_accumulators)
+        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None)
     else:
         merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev)
 
@@ -257,6 +260,10 @@ def main():
     launch_ms = float(np.median(spans)) / max(n_full, 1) if n_full else float("nan")
     bytes_per_tile = VIEWS * CHANNELS * TILE * TILE * 4          # 8 views x C x T x 4 B read per tile
     bytes_per_launch = bytes_per_tile * BATCH
+    if not sharded and planned:
+        # the planned kernel also writes the region's output (+ C x 5120 x 5120 x 4 B per image): the launch's
+        # share of the whole region's algorithmic bytes, 12 532 580 352 B x 8 / 361
+        bytes_per_launch += CHANNELS * 5120 * 5120 * 4 * BATCH // n_tiles
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
 
     mp = IMAGE[0] * IMAGE[1] / 1e6
@@ -289,9 +296,10 @@ def main():
             "config": {
                 "workload": "BASELINE cfg2: 5000x5000x3 image, ImageSlicer 512/256 pyramid (361 tiles, target 5120x5120), "
                             "d4 TTA (8 views) model outputs C=4 fp32 resident in HBM, fused de-augment+mean+integrate_batch in "
-                            "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; the data-independent "
-                            "norm_mask is built from the crop list once and reused while the crop list repeats (SURVEY 8d: not "
-                            "compulsory traffic); model forward excluded",
+                            "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; TileMerger(crops=tiler.crops): the "
+                            "data-independent norm_mask is precomputed from the crop list (SURVEY 8d: not compulsory traffic) and every "
+                            "block is divided by it in the launch that brings its last tile, so merge() returns the finished "
+                            "[C,H',W'] map; model forward excluded",
                 "tiles": n_tiles,
                 "batch_tiles": BATCH,
                 "parallelism": "single GPU" if world == 1 else f"tile rows sharded over {world} ranks, RCCL p2p halo exchange",
@@ -300,7 +308,8 @@ def main():
                 "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "roofline": {
-                "kernel": "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate, 8 tiles/launch)",
+                "kernel": "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
+                          "normalisation, 8 tiles/launch)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(256) void merge_crop_planar_kernel(const CropArgs a
         const int nv = min(4, a.OW - x);
         const long long src = (long long)(y + a.top) * a.W + a.left + x;
         const long long dpx = (long long)y * a.OW + x;
-        float n[4], v[4], best[4];
-        int arg[4];
+        float n[4], v[4];
+        float best[4] = {0.f, 0.f, 0.f, 0.f};
+        int arg[4] = {0, 0, 0, 0};
         load_px4(a.norm ? a.norm + src : nullptr, nv, vec, n);
         for (int c = 0; c < a.C; ++c) {
             load_px4(a.image + c * iplane + src, nv, vec, v);
@@ -146,8 +147,11 @@ __global__ __launch_bounds__(256) void merge_crop_planar_kernel(const CropArgs a
             }
             if (a.kind >= OUT_ARGMAX_U8) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)  // first maximum wins; NaN counts as the maximum (numpy / torch argmax)
-                    if (c == 0 || v[m] > best[m] || (v[m] != v[m] && best[m] == best[m])) { best[m] = v[m]; arg[m] = c; }
+                for (int m = 0; m < 4; ++m) {  // first maximum wins; NaN counts as the maximum (numpy / torch argmax)
+                    const bool take = c == 0 ? true : (v[m] > best[m] || (v[m] != v[m] && best[m] == best[m]));
+                    best[m] = take ? v[m] : best[m];
+                    arg[m] = take ? c : arg[m];
+                }
             } else if (a.kind == OUT_U8) {
                 uint8_t b[4];
 #pragma unroll

@@ -170,6 +170,9 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
         acc = *reinterpret_cast<const float4*>(ip);
         if (do_norm) nacc = *reinterpret_cast<const float4*>(np);
     }
+    float4 nfull = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act && cell.final_)  // issued with the first loads: at the end it would add one exposed memory latency per workgroup
+        nfull = *reinterpret_cast<const float4*>(a.norm_full + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q);
     const int nt = cell.ntiles;
     for (int e = 0; e < nt; ++e) {
         const int gt = cell.tile[e];
@@ -195,9 +198,8 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
             // last touch of a planned cell: the weighted sum is complete, so the merged value (tiles.py:346) is written
             // right away and the accumulator is never stored -- the separate merge pass over this cell disappears
             const long long off = (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
-            const float4 n4 = *reinterpret_cast<const float4*>(a.norm_full + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q);
             *reinterpret_cast<float4*>(a.merged + off) =
-                make_float4(__fdiv_rn(acc.x, n4.x), __fdiv_rn(acc.y, n4.y), __fdiv_rn(acc.z, n4.z), __fdiv_rn(acc.w, n4.w));
+                make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w));
         } else {
             *reinterpret_cast<float4*>(ip) = acc;
             if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
