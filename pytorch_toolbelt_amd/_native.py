@@ -10,7 +10,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libptb_hip.so")
+# PTB_HIP_LIB: load another build of the library (A/B experiments, an integrator's own build location)
+LIB_PATH = os.environ.get("PTB_HIP_LIB") or os.path.join(_HERE, "lib", "libptb_hip.so")
 
 # view codes (bit0 transpose, bit1 flip source rows, bit2 flip source cols) -- include/ptb_hip.h
 IDENT, TRANSPOSE, FLIPUD, ROT90_CW, FLIPLR, ROT90_CCW, ROT180, ANTITRANSPOSE = range(8)

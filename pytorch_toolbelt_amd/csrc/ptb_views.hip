@@ -181,6 +181,8 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
         const float4 val = gather_reduce<CH, NV, CODES, OPK, NT>(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
                                                         ch, a.op, a.divisor, lds, tid, e + 1 < nt);
         if (act) {
+            // (requesting the window value before the gather was A/B-tested on one box: no gain, and 6 more VGPRs cost a wave
+            // of occupancy -- the other resident workgroups already hide this L2 latency)
             const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             // tile*weight rounded, then added: the reference's two torch ops (tiles.py:338), no FMA contraction
             acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));
