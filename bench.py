@@ -189,6 +189,18 @@ def main():
         sync()
         print(f"[diag] cold start: gpu ms per step {[round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(40)]}", file=sys.stderr)
         print(f"[diag] cold start: host issue done at ms {hs}", file=sys.stderr)
+    if not sharded and planned:
+        # one untimed step that is also checked: should the planned path ever misbehave on this box, the benchmark falls
+        # back to the ordinary merger (and says so in the JSON) instead of dying
+        try:
+            probe = step()
+            ok = bool(torch.isfinite(probe).all()) and merger._plan is not None and bool(merger._plan.done.all())
+        except Exception as exc:  # noqa: BLE001
+            print(f"[bench] planned merger failed ({exc!r}); using the unplanned merger", file=sys.stderr)
+            ok = False
+        if not ok:
+            planned = False
+            merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
     for _ in range(args.warmup):
         step()
     sync()
@@ -302,6 +314,8 @@ def main():
                             "[C,H',W'] map; model forward excluded",
                 "tiles": n_tiles,
                 "batch_tiles": BATCH,
+                "merger": ("planned (crops= given, no merge pass)" if (not sharded and planned) else
+                           ("sharded, unplanned" if sharded else "unplanned (lazy norm_mask + merge pass)")),
                 "parallelism": "single GPU" if world == 1 else f"tile rows sharded over {world} ranks, RCCL p2p halo exchange",
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "region_algorithmic_bytes": region_bytes,
