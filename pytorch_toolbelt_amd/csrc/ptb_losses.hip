@@ -54,7 +54,9 @@ template <int PIX>
 __device__ __forceinline__ void load_px(const float* __restrict__ p, float (&x)[PIX], bool ok) {
     if (!ok) return;
     if constexpr (PIX == 4) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
+        // streamed once: non-temporal (leaves L2 / Infinity Cache to the labels and class weights); +2..3 % measured
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
     } else {
 #pragma unroll
