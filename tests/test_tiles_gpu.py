@@ -503,3 +503,49 @@ def test_planned_merger_fused_d4_and_deviations(dev, native):
     g2 = TO.slicer_geometry((500, 500), (51, 51), (26, 26))
     m2 = TileMerger(g2["target_shape"], 1, TO.pyramid_window(51, 51)[0], device=dev, crops=g2["crops"])
     assert m2._plan is None
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_geometries_all_merger_modes(seed, dev, native):
+    """Seeded differential test: random slicer geometries (block aligned and not), batch sizes, channel counts and tile
+    orders through the three TileMerger modes -- lazy normaliser (default), kernel-maintained normaliser (norm_mask read
+    up front) and planned (crops= given) -- all bit-identical to the oracle's sequential loop, image after image."""
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    rng = np.random.default_rng(1000 + seed)
+    aligned = seed % 3 != 0
+    if aligned:
+        tile = (int(rng.choice([64, 128, 192])), int(rng.choice([64, 128, 192, 256])))
+        step = (int(rng.choice([s for s in (32, 64, 96, 128, 192) if s <= tile[0]])), int(rng.choice([s for s in (64, 128, 192, 256) if s <= tile[1]])))
+    else:
+        tile = (int(rng.integers(9, 70)), int(rng.integers(9, 70)))
+        step = (int(rng.integers(max(1, tile[0] // 3), tile[0] + 1)), int(rng.integers(max(1, tile[1] // 3), tile[1] + 1)))
+    shape = (int(rng.integers(tile[0], 4 * tile[0] + 40)), int(rng.integers(tile[1], 4 * tile[1] + 40)))
+    C = int(rng.integers(1, 5))
+    batch = int(rng.integers(1, 12))
+    geom = TO.slicer_geometry(shape, tile, step)
+    crops, n = geom["crops"], len(geom["crops"])
+    w = TO.pyramid_window(*tile)[0] if seed % 2 else TO.mean_window(*tile)
+    mergers = {
+        "lazy": TileMerger(geom["target_shape"], C, w, device=dev),
+        "eager": TileMerger(geom["target_shape"], C, w, device=dev),
+        "planned": TileMerger(geom["target_shape"], C, w, device=dev, crops=crops),
+    }
+    for image in range(2):
+        pred = rng.standard_normal((n, C, *tile)).astype(np.float32)
+        order = np.arange(n) if (image == 0 or seed % 4) else rng.permutation(n)
+        st = TO.merger_new(geom["target_shape"], C, w)
+        for b0 in range(0, n, batch):
+            TO.merger_integrate(st, pred[order[b0:b0 + batch]], crops[order[b0:b0 + batch]])
+        want = TO.merger_merge(st)
+        for name, m in mergers.items():
+            m.reset()
+            if name == "eager":
+                m.norm_mask  # noqa: B018  (handing the tensor out switches to the kernel-maintained normaliser)
+            for b0 in range(0, n, batch):
+                sel = order[b0:b0 + batch]
+                m.integrate_batch(torch.from_numpy(pred[sel]).to(dev), crops[sel])
+            got = m.merge().cpu().numpy()
+            assert np.array_equal(got, want, equal_nan=True), (name, image, shape, tile, step, C, batch)
+            if name != "planned" or not m._plan or not m._plan.done.any():
+                assert np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"]), (name, image)
