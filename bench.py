@@ -27,8 +27,11 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+# the host driver only supports dmabuf IPC: without this RCCL / cross-process tensor sharing fails (hipIpcGetMemHandle)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
