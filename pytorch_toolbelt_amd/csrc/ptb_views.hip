@@ -416,12 +416,38 @@ struct Fresh {
 
 enum { DECOMP_OK = 0, DECOMP_SPLIT = 1, DECOMP_NEEDS_ZERO = 2 };
 
-// Tag cells with their freshness, splitting a cell into row runs of uniform freshness.  Cells that are not aligned to
-// the block grid, or block rows that are partly fresh, cannot use first-touch stores: if they touch any fresh block the
-// caller has to zero-fill first (DECOMP_NEEDS_ZERO).
+// Cut a block-aligned cell into rectangles on which a per-block 0/1 state is uniform: column strips wherever two
+// neighbouring block columns differ in some row, then row runs inside each strip.  Any sub-rectangle of a cell is a cell
+// with the same cover list, so this never changes the result -- only which stores are first-touch / final.
+template <typename Emit>
+static void split_by_state(const Cell& c, const std::vector<uint8_t>& state, int nx, int ny, int bx0, int by0, int rows, Emit emit) {
+    int sx0 = 0;
+    for (int sx = 1; sx <= nx; ++sx) {
+        bool cut = sx == nx;
+        for (int y = 0; y < ny && !cut; ++y) cut = state[(size_t)y * nx + sx] != state[(size_t)y * nx + sx - 1];
+        if (!cut) continue;
+        int run_start = 0;
+        for (int y = 1; y <= ny; ++y) {
+            if (y < ny && state[(size_t)y * nx + sx0] == state[(size_t)run_start * nx + sx0]) continue;
+            Cell piece = c;
+            piece.ox = (bx0 + sx0) * CW;
+            piece.w = std::min((bx0 + sx) * CW, c.ox + c.w) - piece.ox;
+            piece.oy = (by0 + run_start) * rows;
+            piece.h = std::min((by0 + y) * rows, c.oy + c.h) - piece.oy;
+            emit(piece, state[(size_t)run_start * nx + sx0]);
+            run_start = y;
+        }
+        sx0 = sx;
+    }
+}
+
+// Tag cells with their freshness, splitting a cell into rectangles of uniform freshness.  Cells that are not aligned to
+// the block grid cannot use first-touch stores: if they touch any fresh block the caller has to zero-fill first
+// (DECOMP_NEEDS_ZERO).
 static int apply_freshness(std::vector<Cell>& cells, const Fresh& fr) {
     if (!fr.map) return DECOMP_OK;
     std::vector<Cell> out;
+    std::vector<uint8_t> state;
     const int nbx = fr.nbx();
     for (const Cell& c : cells) {
         const bool aligned = c.ox % CW == 0 && c.oy % fr.rows == 0 && (c.w % CW == 0 || c.ox + c.w == fr.W) &&
@@ -434,28 +460,11 @@ static int apply_freshness(std::vector<Cell>& cells, const Fresh& fr) {
             out.push_back(c);
             continue;
         }
-        int run_start = by0, run_state = -1;
-        for (int by = by0; by <= by1 + 1; ++by) {
-            int state = -1;
-            if (by <= by1) {
-                int nf = 0;
-                for (int bx = bx0; bx <= bx1; ++bx) nf += fr.map[by * nbx + bx] ? 1 : 0;
-                if (nf != 0 && nf != bx1 - bx0 + 1) return DECOMP_NEEDS_ZERO;
-                state = nf ? 1 : 0;
-            }
-            if (state != run_state) {
-                if (run_state >= 0) {
-                    Cell piece = c;
-                    piece.oy = run_start * fr.rows;
-                    const int y_end = std::min(by * fr.rows, c.oy + c.h);
-                    piece.h = y_end - piece.oy;
-                    piece.fresh = run_state;
-                    out.push_back(piece);
-                }
-                run_start = by;
-                run_state = state;
-            }
-        }
+        const int nx = bx1 - bx0 + 1, ny = by1 - by0 + 1;
+        state.assign((size_t)nx * ny, 0);
+        for (int by = by0; by <= by1; ++by)
+            for (int bx = bx0; bx <= bx1; ++bx) state[(size_t)(by - by0) * nx + (bx - bx0)] = fr.map[by * nbx + bx] ? 1 : 0;
+        split_by_state(c, state, nx, ny, bx0, by0, fr.rows, [&](Cell piece, uint8_t st) { piece.fresh = st; out.push_back(piece); });
     }
     cells.swap(out);
     return DECOMP_OK;
@@ -500,27 +509,7 @@ static int apply_plan(std::vector<Cell>& cells, const Plan& pl) {
                 if (left < 0 || pl.done[by * nbx + bx]) return DECOMP_PLAN_MISMATCH;  // more tiles than planned here
                 fin[(size_t)(by - by0) * nx + (bx - bx0)] = left == 0;
             }
-        // any sub-rectangle of a cell is a cell with the same cover: cut into column strips wherever two neighbouring
-        // block columns differ in some row, then into row runs of uniform finality inside each strip
-        int sx0 = 0;
-        for (int sx = 1; sx <= nx; ++sx) {
-            bool cut = sx == nx;
-            for (int y = 0; y < ny && !cut; ++y) cut = fin[(size_t)y * nx + sx] != fin[(size_t)y * nx + sx - 1];
-            if (!cut) continue;
-            int run_start = 0;
-            for (int y = 1; y <= ny; ++y) {
-                if (y < ny && fin[(size_t)y * nx + sx0] == fin[(size_t)run_start * nx + sx0]) continue;
-                Cell piece = c;
-                piece.ox = (bx0 + sx0) * CW;
-                piece.w = std::min((bx0 + sx) * CW, c.ox + c.w) - piece.ox;
-                piece.oy = (by0 + run_start) * pl.rows;
-                piece.h = std::min((by0 + y) * pl.rows, c.oy + c.h) - piece.oy;
-                piece.final_ = fin[(size_t)run_start * nx + sx0];
-                out.push_back(piece);
-                run_start = y;
-            }
-            sx0 = sx;
-        }
+        split_by_state(c, fin, nx, ny, bx0, by0, pl.rows, [&](Cell piece, uint8_t st) { piece.final_ = st; out.push_back(piece); });
     }
     cells.swap(out);
     return DECOMP_OK;

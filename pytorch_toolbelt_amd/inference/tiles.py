@@ -496,7 +496,7 @@ class TileMerger:
                 f"tile batch of shape {tuple(batch.shape)} does not match {B} tiles x {n_views} views of "
                 f"[{self.channels}, {th}, {tw}]"
             )
-        if B and (np.any(coords[:, 2] != tw) or np.any(coords[:, 3] != th)):
+        if B and not (coords[:, 2:] == (tw, th)).all():
             raise RuntimeError("crop size in crop_coords does not match the tile / weight size")
         xy = np.ascontiguousarray(coords[:, :2].T)          # [2, B] int64: xs row, ys row (host arrays for the C ABI)
         xs = xy[0].ctypes.data_as(N._i64p)
@@ -519,7 +519,7 @@ class TileMerger:
         plan = self._plan
         if plan is not None and B:
             planned = (plan.active and not self._eager_norm and plan.pos + B <= plan.xy.shape[1]
-                       and np.array_equal(plan.xy[:, plan.pos:plan.pos + B], xy))
+                       and xy[0].data == plan.xy[0, plan.pos:plan.pos + B].data and xy[1].data == plan.xy[1, plan.pos:plan.pos + B].data)
             if planned:
                 if self._merged is None:
                     self._merged = torch.empty_like(self._image)

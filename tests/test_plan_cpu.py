@@ -108,11 +108,19 @@ def test_first_touch_bitmap():
             assert fr == (0 if region.any() else 1)
             written[oy:oy + h, ox:ox + w] = True
     assert not fresh.any() and written.all()
-    # a tile whose footprint is partly written cannot be stored blindly: the planner asks for a zero-fill
+    # a tile whose footprint is partly written is cut into rectangles of uniform freshness (no zero-fill needed)
     fresh = np.ones_like(fresh)
-    fresh[:8, :4] = 0                                   # left half of the first tile already written
-    rc, _ = plan([0], [0], 512, 512, H, W, 32, fresh, 32)
-    assert rc == N.EFRESH
+    fresh[:8, :4] = 0                                   # upper-left quarter of the first tile already written
+    before = fresh.copy()
+    n, cells = plan([0], [0], 512, 512, H, W, 32, fresh, 32)
+    assert n == 3
+    area = 0
+    for row in cells:
+        _, ox, oy, w, h, fr = row[:6]
+        blocks = before[oy // 32:(oy + h + 31) // 32, ox // 64:(ox + w + 63) // 64]
+        assert blocks.all() if fr else not blocks.any()
+        area += w * h
+    assert area == 512 * 512 and not fresh[:16, :8].any()
     # unaligned tiles never use first-touch stores
     fresh = np.ones_like(fresh)
     rc, _ = plan([4], [0], 512, 512, H, W, 32, fresh, 32)
