@@ -54,6 +54,11 @@ typedef void* ptb_stream_t; /* hipStream_t */
 #define PTB_RED_LOGODD 5
 #define PTB_RED_LOG1P 6
 
+/* element type of the model outputs a `_t` entry point reads (accumulators and results are always fp32) */
+#define PTB_F32 0
+#define PTB_F16 1
+#define PTB_BF16 2
+
 int ptb_version(void);
 /* hipGetErrorString of the last failing HIP call made by this library on this thread ("" if none). */
 const char* ptb_last_hip_error(void);
@@ -87,8 +92,8 @@ int ptb_tile_accumulate(float* image, float* norm, const float* weight, const fl
  * data-independent normaliser in integration order).  The library updates both maps.  One launch group per call:
  * PTB_EUNSUPPORTED (nothing launched) if the batch needs several groups, is not block aligned, or does not fit the plan;
  * PTB_EFRESH as above.  Blocks with done == 0 at the end are merged by ptb_merge_div_masked. */
-int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const float* in, int V,
-                           const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw,
+int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const void* in, int in_dtype,
+                           int V, const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw,
                            int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, ptb_stream_t stream);
 /* out[c] = image[c] / norm on the blocks (64 columns x rows rows, row-major grid) whose byte in the DEVICE map `mask` is
  * non-zero; other blocks of `out` are left untouched. */
@@ -158,6 +163,17 @@ int ptb_deaug_reduce(const float* in, float* out, int V, const int* views, int r
  * (sum, mean) are differentiated with ptb_view_transform. */
 int ptb_deaug_reduce_bwd(const float* in, const float* out, const float* grad_out, float* grad_in, int V, const int* views,
                          int reduction, int B, int C, int H, int W, ptb_stream_t stream);
+
+/* Half-precision sources: the same as ptb_deaug_reduce / ptb_deaug_accumulate (and ptb_tile_accumulate with V = 1,
+ * views = {PTB_VIEW_IDENT}, PTB_RED_SUM) with `in` holding in_dtype elements -- what the reference does with
+ * `batch.type_as(self.image)` (inference/tiles.py:334-335) / its dtype-agnostic TTA ops, minus the fp32 copy: fp16 / bf16
+ * values are widened in registers (exact), so the result equals the fp32 entry point on in.float() bit for bit.
+ * PTB_EUNSUPPORTED (nothing launched) when the shape needs the scalar kernels or a non-default chunk size. */
+int ptb_deaug_reduce_t(const void* in, int in_dtype, float* out, int V, const int* views, int reduction, int B, int C, int H,
+                       int W, ptb_stream_t stream);
+int ptb_deaug_accumulate_t(float* image, float* norm, const float* weight, const void* in, int in_dtype, int V, const int* views,
+                           int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw, int H, int W,
+                           uint8_t* fresh, int fresh_rows, ptb_stream_t stream);
 
 /* ---- per-view transform without reduction ----------------------------------------------------------------------
  * out[k*B + b] = scale * view_k(in[src]) with src = b (in_is_batch = 1: *_image_augment, inference/tta.py:257-284,

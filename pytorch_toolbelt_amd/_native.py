@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("PTB_HIP_LIB") or os.path.join(_HERE, "lib", "libptb_h
 IDENT, TRANSPOSE, FLIPUD, ROT90_CW, FLIPLR, ROT90_CCW, ROT180, ANTITRANSPOSE = range(8)
 
 RED_SUM, RED_MEAN, RED_GMEAN, RED_HMEAN, RED_HARMONIC1P, RED_LOGODD, RED_LOG1P = range(7)
+F32, F16, BF16 = range(3)   # PTB_F32 / PTB_F16 / PTB_BF16: element type of the model outputs a `_t` entry point reads
+DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 EFRESH = -5
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed", -4: "tile rectangle outside the accumulator"}
@@ -36,7 +38,9 @@ SIGNATURES = {
     "ptb_last_hip_error": (ctypes.c_char_p, []),
     "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
     "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
-    "ptb_accumulate_planned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+    "ptb_deaug_reduce_t": (_c_int, [_vp, _c_int, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_deaug_accumulate_t": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
+    "ptb_accumulate_planned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _vp, _c_int, _vp, _vp, _vp]),
     "ptb_merge_div_masked": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_norm_accumulate": (_c_int, [_vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),

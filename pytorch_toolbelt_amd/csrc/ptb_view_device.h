@@ -58,6 +58,7 @@ struct ViewArgs {
     float scale;         // per-view mode multiplier
     int chunks_x, chunks_y;  // plain modes: chunks per tile
     int ncells, total_chunks;
+    int in_dtype;        // element type of src: PTB_F32 | PTB_F16 | PTB_BF16 (reduce / accumulate kernels)
 };
 
 enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
@@ -138,6 +139,25 @@ __device__ __forceinline__ float4 ld16(const float* p) {
     const v4f* q = reinterpret_cast<const v4f*>(p);
     const v4f v = NT ? __builtin_nontemporal_load(q) : *q;
     return make_float4(v.x, v.y, v.z, v.w);
+}
+
+// 4 consecutive source elements at element offset `off` of `base`, as fp32.  LD: 0 = fp32, 1 = fp32 non-temporal,
+// 2 = fp16, 3 = bf16 (both non-temporal, 8 B per lane; the conversions are exact, so a half-precision model output gives
+// bit for bit what its .float() copy would -- without that copy ever being written to HBM).
+template <int LD>
+__device__ __forceinline__ float4 ld4(const float* base, long long off) {
+    if constexpr (LD <= 1) {
+        return ld16<LD == 1>(base + off);
+    } else if constexpr (LD == 2) {
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 v = __builtin_nontemporal_load(reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + off));
+        return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    } else {
+        typedef unsigned short u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load(reinterpret_cast<const u4*>(reinterpret_cast<const unsigned short*>(base) + off));
+        return make_float4(__uint_as_float((unsigned)v.x << 16), __uint_as_float((unsigned)v.y << 16),
+                           __uint_as_float((unsigned)v.z << 16), __uint_as_float((unsigned)v.w << 16));
+    }
 }
 
 __device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }

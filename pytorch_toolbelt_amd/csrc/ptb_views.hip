@@ -28,8 +28,8 @@ namespace ptb {
 
 // Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
 // tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
-template <int CH, int NV, int CODES, int OPK, bool NT>
-__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane, long long view_stride, int nv_rt,
+template <int CH, int NV, int CODES, int OPK, int LD>
+__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt,
                                                 int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
                                                 float divisor, float* lds, int tid, bool more_entries) {
     constexpr int QPR = CH / 4;  // float4 per source row of a transposed block
@@ -46,19 +46,19 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane,
         v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
         if (k < nv) {
             const int code = (codes >> (3 * k)) & 7;
-            const float* p = plane + (long long)k * view_stride;
+            const long long p = plane + (long long)k * view_stride;   // element offset of view k
             if (!(code & 1)) {
                 if (act) {
                     const int i = ly + r, j = lx + 4 * q;
                     const int row = (code & 2) ? H - 1 - i : i;
                     const int col = (code & 4) ? W - 4 - j : j;
-                    const float4 t = ld16<NT>(p + (long long)row * W + col);
+                    const float4 t = ld4<LD>(src, p + (long long)row * W + col);
                     v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
                 }
             } else if (tact) {
                 const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
                 const int C0 = (code & 4) ? W - ly - ch : ly;
-                v[k] = ld16<NT>(p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+                v[k] = ld4<LD>(src, p + (long long)(R0 + rr) * W + C0 + 4 * qq);
             }
         }
     }
@@ -110,7 +110,7 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ plane,
 }
 
 // ------------------------------------------------------------------------------------------------ fast kernels
-template <int CH, int NV, int CODES, int OPK, int MODE, bool NT>
+template <int CH, int NV, int CODES, int OPK, int MODE, int LD>
 __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
         nv = 1;
         src_tile = t % a.src_tile_mod;
     }
-    const float* plane = a.src + src_tile * a.src_tile_stride + (long long)c * a.H * a.W;
-    float4 val = gather_reduce<CH, NV, CODES, OPK, NT>(plane, a.src_view_stride, nv, codes, a.H, a.W, cx0, cy0, cw, ch, a.op,
+    const long long plane = src_tile * a.src_tile_stride + (long long)c * a.H * a.W;
+    float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(a.src, plane, a.src_view_stride, nv, codes, a.H, a.W, cx0, cy0, cw, ch, a.op,
                                                   a.divisor, lds, tid, false);
     if (MODE == MODE_PERVIEW && a.scale != 1.0f) {
         val.x *= a.scale; val.y *= a.scale; val.z *= a.scale; val.w *= a.scale;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
     }
 }
 
-template <int CH, int NV, int CODES, int OPK, bool NT>
+template <int CH, int NV, int CODES, int OPK, int LD>
 __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, const CellArgs g) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
     for (int e = 0; e < nt; ++e) {
         const int gt = cell.tile[e];
         const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
-        const float* plane = a.src + (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
-        const float4 val = gather_reduce<CH, NV, CODES, OPK, NT>(plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
+        const long long plane = (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
+        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(a.src, plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
                                                         ch, a.op, a.divisor, lds, tid, e + 1 < nt);
         if (act) {
             // (requesting the window value before the gather was A/B-tested on one box: no gain, and 6 more VGPRs cost a wave
@@ -607,14 +607,24 @@ static int pack_runtime(int V, const int* views) {
 template <int CH, int MODE>
 static void launch_plain_ch(const ViewArgs& a, int blocks, hipStream_t s, bool nonlinear) {
     const dim3 grid(blocks), block(CH * 16);
+    // half-precision sources (in_dtype != PTB_F32) are compiled for the default chunk rows only (callers check)
+#define PTB_PLAIN_LD(NV, CODES, LD)                                                                               \
+    do {                                                                                                          \
+        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE, LD>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, LD>), grid, block, 0, s, a);           \
+    } while (0)
 #define PTB_PLAIN(NV, CODES)                                                                                      \
     do {                                                                                                          \
-        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE, true>), grid, block, 0, s, a);     \
-        else if (g_nt_loads) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, true>), grid, block, 0, s, a); \
-        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, false>), grid, block, 0, s, a);        \
+        if constexpr (CH == 32) {                                                                                 \
+            if (a.in_dtype == PTB_F16) { PTB_PLAIN_LD(NV, CODES, 2); break; }                                     \
+            if (a.in_dtype == PTB_BF16) { PTB_PLAIN_LD(NV, CODES, 3); break; }                                    \
+        }                                                                                                         \
+        if (nonlinear) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 1, MODE, 1>), grid, block, 0, s, a);  \
+        else if (g_nt_loads) hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, 1>), grid, block, 0, s, a); \
+        else hipLaunchKernelGGL((view_plain_kernel<CH, NV, CODES, 0, MODE, 0>), grid, block, 0, s, a);            \
     } while (0)
     if constexpr (MODE == MODE_PERVIEW) {
-        hipLaunchKernelGGL((view_plain_kernel<CH, 1, -1, 0, MODE_PERVIEW, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((view_plain_kernel<CH, 1, -1, 0, MODE_PERVIEW, 1>), grid, block, 0, s, a);
     } else {
         if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_PLAIN(2, CODES_FLIPLR);
         else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_PLAIN(2, CODES_FLIPUD);
@@ -624,18 +634,28 @@ static void launch_plain_ch(const ViewArgs& a, int blocks, hipStream_t s, bool n
         else PTB_PLAIN(8, -1);
     }
 #undef PTB_PLAIN
+#undef PTB_PLAIN_LD
 }
 
 template <int CH>
 static void launch_accum_ch(const ViewArgs& a, const CellArgs& g, int blocks, hipStream_t s, bool nonlinear) {
     const dim3 grid(blocks), block(CH * 16);
+#define PTB_ACCUM_LD(NV, CODES, LD)                                                                               \
+    do {                                                                                                          \
+        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1, LD>), grid, block, 0, s, a, g);    \
+        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, LD>), grid, block, 0, s, a, g);              \
+    } while (0)
 #define PTB_ACCUM(NV, CODES)                                                                                      \
     do {                                                                                                          \
-        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1, true>), grid, block, 0, s, a, g);        \
-        else if (g_nt_loads) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, true>), grid, block, 0, s, a, g);  \
-        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, false>), grid, block, 0, s, a, g);           \
+        if constexpr (CH == 32) {                                                                                 \
+            if (a.in_dtype == PTB_F16) { PTB_ACCUM_LD(NV, CODES, 2); break; }                                     \
+            if (a.in_dtype == PTB_BF16) { PTB_ACCUM_LD(NV, CODES, 3); break; }                                    \
+        }                                                                                                         \
+        if (nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 1, 1>), grid, block, 0, s, a, g);     \
+        else if (g_nt_loads) hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, 1>), grid, block, 0, s, a, g); \
+        else hipLaunchKernelGGL((view_accum_kernel<CH, NV, CODES, 0, 0>), grid, block, 0, s, a, g);               \
     } while (0)
-    if (a.nviews == 1 && a.codes == CODES_ID && !nonlinear) hipLaunchKernelGGL((view_accum_kernel<CH, 1, CODES_ID, 0, true>), grid, block, 0, s, a, g);
+    if (a.nviews == 1 && a.codes == CODES_ID) PTB_ACCUM(1, CODES_ID);
     else if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_ACCUM(2, CODES_FLIPLR);
     else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_ACCUM(2, CODES_FLIPUD);
     else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_ACCUM(3, CODES_FLIPS);
@@ -643,6 +663,7 @@ static void launch_accum_ch(const ViewArgs& a, const CellArgs& g, int blocks, hi
     else if (a.nviews == 8 && a.codes == CODES_D4) PTB_ACCUM(8, CODES_D4);
     else PTB_ACCUM(8, -1);
 #undef PTB_ACCUM
+#undef PTB_ACCUM_LD
 }
 
 static bool has_transpose(int V, int codes) {
@@ -671,15 +692,20 @@ static void fill_reduction(ViewArgs& a, int reduction, int V) {
     a.divisor = reduction == PTB_RED_SUM ? 1.0f : (float)V;
 }
 
+static bool aligned_elems(const void* p, int dtype) {  // 4 source elements per lane: 16 B of fp32, 8 B of fp16 / bf16
+    return (reinterpret_cast<uintptr_t>(p) & (dtype == PTB_F32 ? 15u : 7u)) == 0;
+}
+
 static int run_plain(ViewArgs& a, int ntiles_out, int mode, hipStream_t s) {
     const bool nonlinear = a.op >= PTB_RED_GMEAN;
     const int nT = mode == MODE_PERVIEW ? 1 : count_transpose(a.nviews, a.codes);
     const bool tr = mode == MODE_PERVIEW ? has_transpose(a.nviews, a.codes) : nT > 0;
     bool fast = !g_force_scalar && (a.W % 4 == 0) && (a.dst_row_stride % 4 == 0) && (a.dst_chan_stride % 4 == 0) &&
-                (a.dst_tile_stride % 4 == 0) && aligned16(a.src) && aligned16(a.dst) && nT <= MAX_T;
+                (a.dst_tile_stride % 4 == 0) && aligned_elems(a.src, a.in_dtype) && aligned16(a.dst) && nT <= MAX_T;
     if (tr && a.H % 4 != 0) fast = false;
     if ((long long)a.H * a.W % 4 != 0) fast = false;
     const int ch = fast ? g_chunk_rows : 64;
+    if (a.in_dtype != PTB_F32 && (!fast || ch != 32 || mode != MODE_REDUCE)) return PTB_EUNSUPPORTED;
     a.chunks_x = (a.W + CW - 1) / CW;
     a.chunks_y = (a.H + ch - 1) / ch;
     const long long blocks = (long long)ntiles_out * a.C * a.chunks_x * a.chunks_y;
@@ -785,7 +811,8 @@ static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int
 
 static int accumulate_impl(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                            int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th, int tw, int H, int W,
-                           uint8_t* fresh, int fresh_rows, hipStream_t s) {
+                           uint8_t* fresh, int fresh_rows, hipStream_t s, int in_dtype = PTB_F32) {
+    if (in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
     const bool norm_only = !image && !in;  // ptb_norm_accumulate
     if ((!norm_only && (!image || !in)) || (norm_only && !norm) || !weight || !xs64 || !ys64) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
@@ -802,6 +829,7 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
     }
     ViewArgs a{};
     a.src = in; a.dst = image; a.norm = norm; a.weight = weight;
+    a.in_dtype = in_dtype;
     a.H = th; a.W = tw; a.C = C;
     a.src_view_stride = (long long)B * C * th * tw;
     a.src_tile_stride = (long long)C * th * tw;
@@ -814,13 +842,14 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
     fill_reduction(a, reduction, V);
     const int nT = count_transpose(V, a.codes);
     bool fast = !g_force_scalar && aligned && (tw % 4 == 0) && (W % 4 == 0) && ((long long)H * W % 4 == 0) &&
-                ((long long)th * tw % 4 == 0) && (norm_only || (aligned16(in) && aligned16(image))) && aligned16(norm) &&
+                ((long long)th * tw % 4 == 0) && (norm_only || (aligned_elems(in, in_dtype) && aligned16(image))) && aligned16(norm) &&
                 aligned16(weight) && nT <= MAX_T;
     if (nT) {  // transposed source blocks are addressed by tile-local rows: need 4-aligned row offsets too
         if (th % 4) fast = false;
         for (int b = 0; b < B && fast; ++b) if ((ys[b] - ys[0]) % 4) fast = false;
     }
     const int ch = fast ? g_chunk_rows : 64;
+    if (in_dtype != PTB_F32 && (!fast || ch != 32)) return PTB_EUNSUPPORTED;  // half sources: default vector kernels only
     Fresh fr{fresh, fresh_rows, H, W};
     if (fresh) {
         if (fresh_rows < 1) return PTB_EINVAL;
@@ -867,13 +896,13 @@ extern "C" int ptb_tile_accumulate(float* image, float* norm, const float* weigh
 }
 
 // Planned variant of ptb_tile_accumulate / ptb_deaug_accumulate: one launch group per call, see the header.
-extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const float* in, int V,
-                                      const int* views, int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th,
+extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const void* in,
+                                      int in_dtype, int V, const int* views, int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th,
                                       int tw, int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done,
                                       ptb_stream_t stream) {
     if (!image || !norm_full || !merged || !weight || !in || !xs64 || !ys64 || !remaining || !done) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || fresh_rows < 1) return PTB_EINVAL;
-    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
     if (int rc = validate_views(V, views, th, tw)) return rc;
     if (B == 0) return PTB_OK;
     if (B > 16) return PTB_EUNSUPPORTED;
@@ -884,7 +913,8 @@ extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, floa
         if (xs[b] % CW || ys[b] % fresh_rows) return PTB_EUNSUPPORTED;
     }
     ViewArgs a{};
-    a.src = in; a.dst = image; a.norm = nullptr; a.weight = weight; a.merged = merged; a.norm_full = norm_full;
+    a.src = static_cast<const float*>(in); a.dst = image; a.norm = nullptr; a.weight = weight; a.merged = merged; a.norm_full = norm_full;
+    a.in_dtype = in_dtype;
     a.H = th; a.W = tw; a.C = C;
     a.src_view_stride = (long long)B * C * th * tw;
     a.src_tile_stride = (long long)C * th * tw;
@@ -896,9 +926,10 @@ extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, floa
     fill_reduction(a, reduction, V);
     const int nT = count_transpose(V, a.codes);
     const bool fast = !g_force_scalar && (tw % 4 == 0) && (W % 4 == 0) && ((long long)H * W % 4 == 0) && ((long long)th * tw % 4 == 0) &&
-                      aligned16(in) && aligned16(image) && aligned16(merged) && aligned16(norm_full) && aligned16(weight) &&
+                      aligned_elems(in, in_dtype) && aligned16(image) && aligned16(merged) && aligned16(norm_full) && aligned16(weight) &&
                       nT <= MAX_T && (!nT || th % 4 == 0);
     const int ch = fast ? g_chunk_rows : 64;
+    if (in_dtype != PTB_F32 && (!fast || ch != 32)) return PTB_EUNSUPPORTED;
     if (fresh_rows != ch) return PTB_EUNSUPPORTED;  // plan / first-touch block rows must equal this launch's chunk rows
     Fresh fr{fresh, fresh_rows, H, W};
     Plan pl{remaining, done, fresh_rows, H, W};
@@ -926,14 +957,36 @@ extern "C" int ptb_deaug_accumulate(float* image, float* norm, const float* weig
                            (hipStream_t)stream);
 }
 
+extern "C" int ptb_deaug_accumulate_t(float* image, float* norm, const float* weight, const void* in, int in_dtype, int V,
+                                      const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th,
+                                      int tw, int H, int W, uint8_t* fresh, int fresh_rows, ptb_stream_t stream) {
+    return accumulate_impl(image, norm, weight, static_cast<const float*>(in), V, views, reduction, xs, ys, B, C, th, tw, H, W, fresh,
+                           fresh_rows, (hipStream_t)stream, in_dtype);
+}
+
+static int deaug_reduce_impl(const float* in, int in_dtype, float* out, int V, const int* views, int reduction, int B, int C, int H,
+                             int W, ptb_stream_t stream);
+
 extern "C" int ptb_deaug_reduce(const float* in, float* out, int V, const int* views, int reduction, int B, int C, int H, int W,
                                 ptb_stream_t stream) {
+    return deaug_reduce_impl(in, PTB_F32, out, V, views, reduction, B, C, H, W, stream);
+}
+
+extern "C" int ptb_deaug_reduce_t(const void* in, int in_dtype, float* out, int V, const int* views, int reduction, int B, int C,
+                                  int H, int W, ptb_stream_t stream) {
+    if (in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
+    return deaug_reduce_impl(static_cast<const float*>(in), in_dtype, out, V, views, reduction, B, C, H, W, stream);
+}
+
+static int deaug_reduce_impl(const float* in, int in_dtype, float* out, int V, const int* views, int reduction, int B, int C, int H,
+                             int W, ptb_stream_t stream) {
     if (!in || !out || B < 0 || C < 1 || H < 1 || W < 1) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
     if (int rc = validate_views(V, views, H, W)) return rc;
     if (B == 0) return PTB_OK;
     ViewArgs a{};
     a.src = in; a.dst = out;
+    a.in_dtype = in_dtype;
     a.H = H; a.W = W; a.C = C;
     a.src_view_stride = (long long)B * C * H * W;
     a.src_tile_stride = (long long)C * H * W;

@@ -69,17 +69,21 @@ def _raw_view_transform(x, views: Sequence[int], in_is_batch: bool, scale: float
 
 
 def _raw_deaug_reduce(x, views: Sequence[int], code: int):
-    """out[b] = reduce_k view_k(x[k*B + b]); x contiguous fp32 [V*B, C, H, W] on the GPU."""
+    """out[b] = reduce_k view_k(x[k*B + b]); x contiguous [V*B, C, H, W] on the GPU, fp32 -- or fp16 / bf16, which the
+    kernel widens in registers (the fp32 copy the reference's `.float()` would write never exists).  out is fp32."""
     V = len(views)
     n, C, H, W = x.shape
     B = n // V
     if any(v & 1 for v in views) and H != W:
         raise ValueError(f"Transposing views need square inputs, got {tuple(x.shape)}")
-    out = torch.empty((B, C, H, W), device=x.device, dtype=x.dtype)
+    out = torch.empty((B, C, H, W), device=x.device, dtype=torch.float32)
     lib = N.load()
+    dcode = N.DTYPE_CODES[x.dtype]
     with N.on_device(x.device):
-        rc = lib.ptb_deaug_reduce(x.data_ptr(), out.data_ptr(), V, N.int_array(views), code, B, C, H, W, N.stream_ptr(x.device))
+        rc = lib.ptb_deaug_reduce_t(x.data_ptr(), dcode, out.data_ptr(), V, N.int_array(views), code, B, C, H, W, N.stream_ptr(x.device))
     N.bump()
+    if rc == -2 and dcode != N.F32:   # shape needs the scalar kernels
+        return _raw_deaug_reduce(x.float(), views, code)
     N.check(rc, "ptb_deaug_reduce")
     return out
 
@@ -144,6 +148,11 @@ def view_transform(x, views, in_is_batch=True, scale=1.0):
 
 
 def deaug_reduce(x, views, code):
+    if x.dtype in _LOW_PRECISION and x.is_cuda and x.dim() == 4 and not (x.requires_grad and torch.is_grad_enabled()):
+        # inference on half-precision model outputs: read them as they are
+        if x.shape[0] % len(views) != 0:
+            raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
+        return _raw_deaug_reduce(x.contiguous(), list(views), code).to(x.dtype)
     x, back = _check_image(x, "de-augment")
     if x.shape[0] % len(views) != 0:
         raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")

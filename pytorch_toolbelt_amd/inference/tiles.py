@@ -476,7 +476,7 @@ class TileMerger:
     def _prep(self, batch):
         if batch.device != self._image.device:
             batch = batch.to(device=self._image.device)
-        if batch.dtype != self._image.dtype:
+        if batch.dtype not in N.DTYPE_CODES:   # fp16 / bf16 model outputs are widened inside the kernel, not copied
             batch = batch.type_as(self._image)
         return batch.detach().contiguous()
 
@@ -503,16 +503,13 @@ class TileMerger:
         ys = xy[1].ctypes.data_as(N._i64p)
         lib = N.load()
         dev = self._image.device
-        varr = N.int_array(views) if views is not None else None
+        varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
         norm_ptr = self._norm.data_ptr() if self._eager_norm else None
+        dcode = N.DTYPE_CODES[batch.dtype]
 
         def launch(fresh_ptr):
-            if views is None:
-                return lib.ptb_tile_accumulate(
-                    self._image.data_ptr(), norm_ptr, self.weight.data_ptr(), batch.data_ptr(), xs, ys,
-                    B, self.channels, th, tw, self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
-            return lib.ptb_deaug_accumulate(
-                self._image.data_ptr(), norm_ptr, self.weight.data_ptr(), batch.data_ptr(),
+            return lib.ptb_deaug_accumulate_t(
+                self._image.data_ptr(), norm_ptr, self.weight.data_ptr(), batch.data_ptr(), dcode,
                 n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
                 self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS, N.stream_ptr(dev))
 
@@ -523,12 +520,10 @@ class TileMerger:
             if planned:
                 if self._merged is None:
                     self._merged = torch.empty_like(self._image)
-                ident = N.int_array([N.IDENT])
-
                 def launch_planned(fresh_ptr):
                     return lib.ptb_accumulate_planned(
                         self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
-                        batch.data_ptr(), n_views, varr if views is not None else ident, reduction, xs, ys, B, self.channels, th, tw,
+                        batch.data_ptr(), dcode, n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
                         self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS,
                         plan.remaining.ctypes.data, plan.done.ctypes.data, N.stream_ptr(dev))
 
@@ -557,6 +552,8 @@ class TileMerger:
                 self._materialize()
                 rc = launch(None)
         N.bump()
+        if rc == -2 and dcode != N.F32:   # shape needs the scalar kernels: take the reference's route (cast, then accumulate)
+            return self._accumulate(batch.float(), coords, views, reduction)
         N.check(rc, "TileMerger.integrate_batch")
         if not self._eager_norm and B:
             self._log.append(xy)

@@ -549,3 +549,40 @@ def test_random_geometries_all_merger_modes(seed, dev, native):
             assert np.array_equal(got, want, equal_nan=True), (name, image, shape, tile, step, C, batch)
             if name != "planned" or not m._plan or not m._plan.done.any():
                 assert np.array_equal(m.norm_mask.cpu().numpy(), st["norm_mask"]), (name, image)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_half_precision_model_outputs_are_read_natively(dtype, dev, native):
+    """fp16 / bf16 predictions (autocast inference): the kernels widen them in registers, so every result equals what the
+    reference's `batch.type_as(self.image)` copy would give -- bit for bit -- in all merger modes, fused or not, and for
+    shapes that need the scalar kernels (where the cast fallback is taken)."""
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    rng = np.random.default_rng(3)
+    for shape, tile, step, C in (((512, 768), (256, 256), (128, 128), 3), ((200, 230), (50, 50), (25, 30), 2)):
+        geom = TO.slicer_geometry(shape, tile, step)
+        crops, n = geom["crops"], len(geom["crops"])
+        w = TO.pyramid_window(*tile)[0]
+        pred = torch.from_numpy(rng.standard_normal((n, 8, C, *tile)).astype(np.float32)).to(dev).to(dtype)   # [n, views, C, h, w]
+        for planned in (False, True):
+            a = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops if planned else None)
+            b = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops if planned else None)
+            for b0 in range(0, n, 6):
+                sel = slice(b0, min(n, b0 + 6))
+                a.integrate_batch(pred[sel, 0], crops[sel])
+                b.integrate_batch(pred[sel, 0].float(), crops[sel])
+            assert torch.equal(a.merge(), b.merge())
+            a.reset(); b.reset()
+            for b0 in range(0, n, 6):
+                sel = slice(b0, min(n, b0 + 6))
+                x = pred[sel].transpose(0, 1).reshape(-1, C, *tile).contiguous()      # chunk-major views
+                a.integrate_batch_deaugment(x, crops[sel], group="d4", reduction="mean")
+                b.integrate_batch_deaugment(x.float(), crops[sel], group="d4", reduction="mean")
+            assert torch.equal(a.merge(), b.merge())
+        x = pred[:4].transpose(0, 1).reshape(-1, C, *tile).contiguous()
+        for red in ("mean", "gmean", "sum"):
+            xin = x.abs() + 0.1 if red == "gmean" else x
+            got = tta.d4_image_deaugment(xin, reduction=red)
+            assert got.dtype == dtype
+            assert torch.equal(got, tta.d4_image_deaugment(xin.float(), reduction=red).to(dtype))

@@ -138,6 +138,25 @@ def nonlinear():
         print(f"{'fused d4 accumulate reduction=%s (read bytes)' % red:70s} {nbytes / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+def half():
+    """Half-precision model outputs read natively (no fp32 copy): fused d4 accumulate and d4 de-augment, 8 tiles."""
+    dev = torch.device("cuda:0")
+    B, C, T = 8, 4, 512
+    slicer = ImageSlicer((5000, 5000, 3), T, 256, weight="pyramid")
+    merger = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    crops_row = slicer.crops[:8]
+    for dt in (torch.float32, torch.float16, torch.bfloat16):
+        bufs = [torch.randn((8 * B, C, T, T), device=dev).to(dt) for _ in range(6)]
+        nbytes = bufs[0].numel() * bufs[0].element_size()
+        t = timeit(lambda i: merger.integrate_batch_deaugment(bufs[i], crops_row, group="d4"), 20, 6)
+        print(f"{'fused d4 accumulate, 8 tiles, input %s (read bytes)' % str(dt).replace('torch.', ''):70s} {nbytes / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+        t = timeit(lambda i: V._raw_deaug_reduce(bufs[i], list(DEAUGMENT_VIEWS["d4"]), N.RED_MEAN), 20, 6)
+        print(f"{'d4 de-augment mean, input %s (read bytes)' % str(dt).replace('torch.', ''):70s} {nbytes / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
+        if dt != torch.float32:
+            t = timeit(lambda i: merger.integrate_batch_deaugment(bufs[i].float(), crops_row, group="d4"), 20, 6)
+            print(f"{'  the same through a .float() copy first (reference route)':70s} {'':9s}        {t * 1e6:9.1f} us")
+
+
 def edges():
     """Device-side loop edges at the cfg2 geometry: split_device of 8 tiles (d4, affine) and merge_crop."""
     dev = torch.device("cuda:0")
@@ -184,6 +203,9 @@ def ensemble():
     print(f"{'same (softmax, gmean) as the reference op chain in eager torch':70s} {by / t / 1e9:9.1f} GB/s   {t * 1e6:9.1f} us")
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "half":
+    half()
+    sys.exit(0)
 if len(sys.argv) > 1 and sys.argv[1] == "nonlinear":
     nonlinear()
     sys.exit(0)
