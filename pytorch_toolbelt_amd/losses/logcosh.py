@@ -1,12 +1,12 @@
-"""``LogCoshLoss`` module (reference losses/logcosh.py) over :func:`functional.log_cosh_loss`."""
-import torch
-from torch import nn
+"""Module form of :func:`pytorch_toolbelt_amd.losses.functional.log_cosh_loss` (mean log-cosh of the residual, one
+fused HIP pass)."""
+from torch import Tensor, nn
 
-from .functional import log_cosh_loss
+from . import functional as LF
 
 __all__ = ["LogCoshLoss"]
 
 
 class LogCoshLoss(nn.Module):
-    def forward(self, y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
-        return log_cosh_loss(y_pred, y_true)
+    def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        return LF.log_cosh_loss(y_pred, y_true)

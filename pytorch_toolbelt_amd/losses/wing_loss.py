@@ -1,16 +1,19 @@
-"""``WingLoss`` module (reference losses/wing_loss.py) over :func:`functional.wing_loss`."""
+"""Module form of the wing loss (landmark regression, https://arxiv.org/abs/1711.06753); the math is the fused HIP pass of
+:func:`pytorch_toolbelt_amd.losses.functional.wing_loss`."""
 from torch.nn.modules.loss import _Loss
 
-from . import functional as F
+from .functional import wing_loss
 
 __all__ = ["WingLoss"]
 
 
 class WingLoss(_Loss):
+    """``width * log(1 + |d| / curvature)`` below ``width``, linear beyond; ``reduction``: "mean" | "sum" | anything else
+    for the unreduced map."""
+
     def __init__(self, width=5, curvature=0.5, reduction="mean"):
         super().__init__(reduction=reduction)
-        self.width = width
-        self.curvature = curvature
+        self.width, self.curvature = width, curvature
 
     def forward(self, prediction, target):
-        return F.wing_loss(prediction, target, self.width, self.curvature, self.reduction)
+        return wing_loss(prediction, target, width=self.width, curvature=self.curvature, reduction=self.reduction)
