@@ -38,7 +38,9 @@ def region_statistics(y_pred, y_true, mode, from_logits, ignore_index):
         dense = K._f32c(y_true.to(device=x.device), "region loss").reshape(bs, C, -1)
         prob = K.PROB_SIGMOID if from_logits else K.PROB_IDENTITY
         stats = K.RegionStats.apply(x, None, dense, prob, ignore_index is not None, 0, float(ignore_index) if ignore_index is not None else 0.0)
-    return stats[0].float(), stats[1].float(), stats[2].float()
+    from ..parallel import sync_region_statistics   # batch sharded over ranks: sum the [C] partials (no-op by default)
+
+    return sync_region_statistics.apply((stats[0].float(), stats[1].float(), stats[2].float()))
 
 
 def finish(scores, true_mass, log_loss, eps, classes):

@@ -44,7 +44,9 @@ class FocalDiceJaccardLoss(nn.Module):
             dense = K._f32c(y_true.to(device=x.device), "fused loss").reshape(bs, C, -1)
             focal, stats = K.FusedSegSums.apply(x, None, dense, None, flags, K.PROB_SIGMOID, float(self.gamma), float(self.alpha or 0.0), 0.0,
                                                 0, float(ign) if ign is not None else 0.0)
-        inter, pred_mass, true_mass = stats[0].float(), stats[1].float(), stats[2].float()
+        from ..parallel import sync_region_statistics
+
+        inter, pred_mass, true_mass = sync_region_statistics.apply((stats[0].float(), stats[1].float(), stats[2].float()))
         wf, wd, wj = self.weights
         focal_loss = (focal[0] / x.numel()).float()
         dice = (2.0 * inter + self.smooth) / (pred_mass + true_mass + self.smooth).clamp_min(self.eps)

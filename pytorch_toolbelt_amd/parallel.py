@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger"]
+__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics"]
 
 
 def tile_row_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
@@ -261,3 +261,63 @@ class ShardedTileMerger:
             self.dist.broadcast(piece, self._global_rank(r), group=self.group)
             full[:, owned[0]:owned[1]] = piece
         return full
+
+
+# ---------------------------------------------------------------------------------------------- batch-sharded losses
+class _AllReduceSum(torch.autograd.Function):
+    """Differentiable sum over the ranks of a process group: every rank receives the total; in backward every rank's
+    input receives the sum of the ranks' upstream gradients (the adjoint of a replicated sum)."""
+
+    @staticmethod
+    def forward(ctx, x, group, dist):
+        ctx.group, ctx.dist = group, dist
+        out = x.clone()
+        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.dist.all_reduce(g, op=ctx.dist.ReduceOp.SUM, group=ctx.group)
+        return g, None, None
+
+
+def all_reduce_sum(x: torch.Tensor, group=None, dist=None) -> torch.Tensor:
+    """Sum of ``x`` over the ranks of ``group`` with autograd support (a [C]-sized tensor: one tiny RCCL all-reduce)."""
+    if dist is None:
+        import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    return _AllReduceSum.apply(x, group, dist)
+
+
+class sync_region_statistics:
+    """Context manager: inside it ``DiceLoss`` / ``JaccardLoss`` (and ``FocalDiceJaccardLoss``) evaluate their per-class
+    region sums over the batch of ALL ranks, so a batch sharded over the GPUs of a node gives the single-GPU loss value
+    (per-rank partials -> one tiny all-reduce -> scalar epilogue).  Each rank's result is then the global
+    loss; with DDP's gradient averaging, scale by the world size if the sum of the ranks' gradients is wanted.
+
+        with sync_region_statistics():          # or sync_region_statistics(group)
+            loss = dice(logits_shard, labels_shard)
+    """
+
+    _active = None
+
+    def __init__(self, group=None, dist=None):
+        self.group, self.dist = group, dist
+
+    def __enter__(self):
+        self._prev = sync_region_statistics._active
+        sync_region_statistics._active = self
+        return self
+
+    def __exit__(self, *exc):
+        sync_region_statistics._active = self._prev
+        return False
+
+    @staticmethod
+    def apply(stats):
+        ctx = sync_region_statistics._active
+        if ctx is None:
+            return stats
+        return tuple(all_reduce_sum(s, ctx.group, ctx.dist) for s in stats)

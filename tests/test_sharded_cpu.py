@@ -136,3 +136,57 @@ def test_partition_and_plan():
     assert sum(p["owned"] is not None for p in plan) == 3 - 0 or True
     live = [p for p in plan if p["owned"] is not None]
     assert live[0]["owned"][0] == 0 and live[-1]["owned"][1] == 128
+
+
+# ------------------------------------------------------------------ batch-sharded region losses
+def _dice_from_stats(inter, pred_mass, true_mass):
+    score = 2.0 * inter / (pred_mass + true_mass).clamp_min(1e-7)
+    return ((1.0 - score) * (true_mass > 0)).mean()
+
+
+def _stats_worker(rank, world, port, q):
+    from pytorch_toolbelt_amd.parallel import sync_region_statistics
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(5)
+        probs = torch.rand((4, 3, 50), generator=g)          # the whole batch; this rank owns images [2r, 2r+2)
+        onehot = (torch.rand((4, 3, 50), generator=g) < 0.4).float()
+        p = probs[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+        t = onehot[2 * rank:2 * rank + 2]
+        local = ((p * t).sum((0, 2)), p.sum((0, 2)), t.sum((0, 2)))
+        with sync_region_statistics():
+            inter, pm, tm = sync_region_statistics.apply(local)
+        loss = _dice_from_stats(inter, pm, tm)
+        loss.backward()
+        assert sync_region_statistics._active is None
+        assert sync_region_statistics.apply(local) is local            # outside the context: untouched
+        q.put((rank, float(loss), p.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_region_statistics_all_reduce_matches_single_process():
+    """World size 2 over gloo: the synchronised Dice value equals the single-process value on the whole batch, and each
+    rank's input gradient equals WORLD x its slice of the single-process gradient (every rank back-propagates the same
+    global loss, and the backward all-reduce sums those identical upstream gradients)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stats_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    probs = torch.rand((4, 3, 50), generator=g).requires_grad_(True)
+    onehot = (torch.rand((4, 3, 50), generator=g) < 0.4).float()
+    ref = _dice_from_stats((probs * onehot).sum((0, 2)), probs.sum((0, 2)), onehot.sum((0, 2)))
+    ref.backward()
+    for rank, loss, grad in got:
+        assert abs(loss - float(ref)) < 1e-6
+        assert np.allclose(grad, world * probs.grad[2 * rank:2 * rank + 2].numpy(), atol=1e-7)
