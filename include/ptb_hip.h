@@ -199,6 +199,14 @@ int ptb_resize_bilinear(const float* in, float* out, int64_t planes, int hin, in
  * size are taken as they are (the reference skips F.interpolate for offset 0).  The resized maps never go to HBM. */
 int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, float* out, int64_t planes, int hout,
                         int wout, int align_corners, int reduction, ptb_stream_t stream);
+/* Row-strip variant (cfg5 over several GPUs, no collective: every rank reduces its own strip of output rows): computes
+ * output rows [out_row0, out_row0 + out_rows) of the hout_full x wout result into out [planes, out_rows, wout].  Map s has
+ * hs_full[s] rows in total, of which inputs[s] holds src_rows[s] rows starting at global row src_row0[s] ([planes,
+ * src_rows[s], ws[s]]); the strip must contain every source row the 4-tap footprints of the output rows touch
+ * (pytorch_toolbelt_amd.parallel.ms_strip_plan computes the ranges).  Same arithmetic as the full call. */
+int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* hs_full, const int* ws, const int* src_row0,
+                              const int* src_rows, int n, float* out, int64_t planes, int hout_full, int wout, int out_row0,
+                              int out_rows, int align_corners, int reduction, ptb_stream_t stream);
 
 /* ================================= segmentation losses (pytorch_toolbelt.losses) =================================
  * logits [B, C, HW] fp32; targets are either labels int64 [B, HW] (one-hot is formed on the fly, never materialised)

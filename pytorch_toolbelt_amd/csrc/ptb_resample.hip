@@ -71,7 +71,15 @@ struct MsArgs {
     float sh[MS_MAX], sw[MS_MAX];
     int n;           // number of scales
     int planes, hout, wout, align_corners, op;
+    // row strips (one rank of a multi-GPU job computes output rows [row0, row0 + hout) of a hout_full-row result from
+    // source row strips): hfull[s] = full source height (tap arithmetic), src0[s] = global index of the first source row
+    // held in in[s] (which has h[s] rows).  Single GPU: row0 = 0, hout_full = hout, hfull = h, src0 = 0.
+    int row0, hout_full;
+    int hfull[MS_MAX], src0[MS_MAX];
 };
+
+// local row of global source row i inside the strip held for scale s (clamped: the caller provides every row the taps need)
+__device__ __forceinline__ int ms_local(const MsArgs& a, int s, int i) { return min(max(i - a.src0[s], 0), a.h[s] - 1); }
 
 constexpr float kMsEps = 1e-6f;
 constexpr float kMsOneMinusEps = (float)(1.0 - 1e-6);
@@ -118,14 +126,15 @@ __global__ __launch_bounds__(256) void ms_reduce_kernel(const MsArgs a, float* _
         for (int s = 0; s < a.n; ++s) {
             float v[4];
             const int hin = a.h[s], win = a.w[s];
-            if (hin == a.hout && win == a.wout) {  // same size: F.interpolate is skipped by the reference (offset 0)
-                const float* r = a.in[s] + (p * hin + oy) * (long long)win + 4 * q;
+            const int gy = oy + a.row0;
+            if (a.hfull[s] == a.hout_full && win == a.wout) {  // same size: F.interpolate is skipped by the reference (offset 0)
+                const float* r = a.in[s] + (p * hin + ms_local(a, s, gy)) * (long long)win + 4 * q;
                 if (vec_out) { const float4 t = *reinterpret_cast<const float4*>(r); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
                 else { for (int m = 0; m < 4; ++m) v[m] = 4 * q + m < a.wout ? r[m] : 1.f; }
             } else {
-                const Taps ty = taps(oy, a.sh[s], hin, a.align_corners);
-                const float* r0 = a.in[s] + (p * hin + ty.i0) * (long long)win;
-                const float* r1 = a.in[s] + (p * hin + ty.i1) * (long long)win;
+                const Taps ty = taps(gy, a.sh[s], a.hfull[s], a.align_corners);
+                const float* r0 = a.in[s] + (p * hin + ms_local(a, s, ty.i0)) * (long long)win;
+                const float* r1 = a.in[s] + (p * hin + ms_local(a, s, ty.i1)) * (long long)win;
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const int ox = 4 * q + m;
@@ -181,19 +190,22 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.n; ++s) {
         float v[4] = {1.f, 1.f, 1.f, 1.f};
-        const int hin = a.h[s], win = a.w[s];
+        const int hin = a.h[s], win = a.w[s], hfull = a.hfull[s];
         const float* src = a.in[s] + p * (long long)hin * win;
-        if (hin == a.hout && win == a.wout) {
+        const int gy = oy + a.row0, gy0 = oy0 + a.row0;
+        if (hfull == a.hout_full && win == a.wout) {
+            const int ry = ms_local(a, s, gy);
             if (row_ok && ox + 3 < a.wout) {
-                const float4 t = *reinterpret_cast<const float4*>(src + (long long)oy * win + ox);
+                const float4 t = *reinterpret_cast<const float4*>(src + (long long)ry * win + ox);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
             } else if (row_ok) {
-                for (int m = 0; m < 4; ++m) if (ox + m < a.wout) v[m] = src[(long long)oy * win + ox + m];
+                for (int m = 0; m < 4; ++m) if (ox + m < a.wout) v[m] = src[(long long)ry * win + ox + m];
             }
         } else {
             // workgroup-uniform source window of this tile
             const int oy_last = min(oy0 + MS_TH, a.hout) - 1, ox_last = min(ox0 + MS_TW, a.wout) - 1;
-            const int r_lo = taps(oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps(oy_last, a.sh[s], hin, a.align_corners).i1;
+            // window rows in GLOBAL source coordinates, then shifted into the strip this rank holds
+            const int r_lo = taps(gy0, a.sh[s], hfull, a.align_corners).i0, r_hi = taps(oy_last + a.row0, a.sh[s], hfull, a.align_corners).i1;
             const int c_lo = taps(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps(ox_last, a.sw[s], win, a.align_corners).i1;
             const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
             const bool staged = nr <= MS_LR && nc <= MS_LC && (win & 3) == 0;
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
                 if (q4 < q_per_row && col < win) {  // win % 4 == 0 and col % 4 == 0: the whole float4 is inside the row
                     for (int rr = tid >> 5; rr < nr; rr += 8)
                         *reinterpret_cast<float4*>(&lds[rr * MS_LP + 4 * q4]) =
-                            *reinterpret_cast<const float4*>(src + (long long)(r_lo + rr) * win + col);
+                            *reinterpret_cast<const float4*>(src + (long long)ms_local(a, s, r_lo + rr) * win + col);
                 }
                 if (tid < MS_TW) ctap[tid] = taps(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
                 __syncthreads();
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
             if (row_ok) {
                 // branch-free: columns past the right edge use the clamped tap of the last column (computed, never
                 // stored), so all 16 gathers of the lane are issued back to back instead of one pixel at a time
-                const Taps ty = taps(oy, a.sh[s], hin, a.align_corners);
+                Taps ty = taps(gy, a.sh[s], hfull, a.align_corners);
                 Taps tx[4];
                 float t[4][4];
                 if (staged) {
@@ -225,8 +237,8 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
                 } else {
 #pragma unroll
                     for (int m = 0; m < 4; ++m) tx[m] = taps(min(ox + m, a.wout - 1), a.sw[s], win, a.align_corners);
-                    const float* g0 = src + (long long)ty.i0 * win;
-                    const float* g1 = src + (long long)ty.i1 * win;
+                    const float* g0 = src + (long long)ms_local(a, s, ty.i0) * win;
+                    const float* g1 = src + (long long)ms_local(a, s, ty.i1) * win;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { t[m][0] = g0[tx[m].i0]; t[m][1] = g0[tx[m].i1]; t[m][2] = g1[tx[m].i0]; t[m][3] = g1[tx[m].i1]; }
                 }
@@ -276,26 +288,31 @@ extern "C" int ptb_resize_bilinear(const float* in, float* out, int64_t planes, 
     return check_launch();
 }
 
-extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, float* out, int64_t planes,
-                                   int hout, int wout, int align_corners, int reduction, ptb_stream_t stream) {
-    if (!inputs || !hs || !ws || !out || n < 1 || n > MS_MAX || planes < 0 || hout < 1 || wout < 1) return PTB_EINVAL;
+static int ms_reduce_impl(const float* const* inputs, const int* hs_full, const int* ws, const int* src_row0, const int* src_rows,
+                          int n, float* out, int64_t planes, int hout_full, int wout, int out_row0, int out_rows, int align_corners,
+                          int reduction, ptb_stream_t stream) {
+    if (!inputs || !hs_full || !ws || !out || n < 1 || n > MS_MAX || planes < 0 || hout_full < 1 || wout < 1) return PTB_EINVAL;
+    if (out_row0 < 0 || out_rows < 0 || out_row0 + out_rows > hout_full) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
-    if (planes == 0) return PTB_OK;
+    if (planes == 0 || out_rows == 0) return PTB_OK;
     if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     MsArgs a{};
     for (int s = 0; s < n; ++s) {
-        if (!inputs[s] || hs[s] < 1 || ws[s] < 1) return PTB_EINVAL;
-        a.in[s] = inputs[s]; a.h[s] = hs[s]; a.w[s] = ws[s];
-        if (hs[s] == hout && ws[s] == wout && (wout % 4 == 0) && !aligned16(inputs[s])) return PTB_EUNSUPPORTED;
+        const int r0 = src_row0 ? src_row0[s] : 0, nr = src_rows ? src_rows[s] : hs_full[s];
+        if (!inputs[s] || hs_full[s] < 1 || ws[s] < 1 || r0 < 0 || nr < 1 || r0 + nr > hs_full[s]) return PTB_EINVAL;
+        a.in[s] = inputs[s]; a.h[s] = nr; a.w[s] = ws[s]; a.hfull[s] = hs_full[s]; a.src0[s] = r0;
+        if (hs_full[s] == hout_full && ws[s] == wout && (wout % 4 == 0) && !aligned16(inputs[s])) return PTB_EUNSUPPORTED;
         if (align_corners) {
-            a.sh[s] = hout > 1 ? (float)(hs[s] - 1) / (float)(hout - 1) : 0.f;
+            a.sh[s] = hout_full > 1 ? (float)(hs_full[s] - 1) / (float)(hout_full - 1) : 0.f;
             a.sw[s] = wout > 1 ? (float)(ws[s] - 1) / (float)(wout - 1) : 0.f;
         } else {
-            a.sh[s] = (float)hs[s] / (float)hout;
+            a.sh[s] = (float)hs_full[s] / (float)hout_full;
             a.sw[s] = (float)ws[s] / (float)wout;
         }
     }
+    const int hout = out_rows;
     a.n = n; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners; a.op = reduction;
+    a.row0 = out_row0; a.hout_full = hout_full;
     const long long tiles = planes * ((hout + MS_TH - 1) / MS_TH) * ((wout + MS_TW - 1) / MS_TW);
     if (g_ms_tiled && tiles <= 0x7fffffffLL) {
         const dim3 grid((unsigned)tiles), block(256);
@@ -310,4 +327,18 @@ extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, co
     const int blocks = (int)(want < 256 * 32 ? want : 256 * 32);
     hipLaunchKernelGGL(ms_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, out);
     return check_launch();
+}
+
+extern "C" int ptb_ms_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, float* out, int64_t planes,
+                                   int hout, int wout, int align_corners, int reduction, ptb_stream_t stream) {
+    if (hout < 1) return PTB_EINVAL;
+    return ms_reduce_impl(inputs, hs, ws, nullptr, nullptr, n, out, planes, hout, wout, 0, hout, align_corners, reduction, stream);
+}
+
+extern "C" int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* hs_full, const int* ws, const int* src_row0,
+                                         const int* src_rows, int n, float* out, int64_t planes, int hout_full, int wout,
+                                         int out_row0, int out_rows, int align_corners, int reduction, ptb_stream_t stream) {
+    if (!src_row0 || !src_rows) return PTB_EINVAL;
+    return ms_reduce_impl(inputs, hs_full, ws, src_row0, src_rows, n, out, planes, hout_full, wout, out_row0, out_rows, align_corners,
+                          reduction, stream);
 }

@@ -19,7 +19,8 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics"]
+__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
+           "ms_image_deaugment_strip"]
 
 
 def tile_row_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
@@ -321,3 +322,70 @@ class sync_region_statistics:
         if ctx is None:
             return stats
         return tuple(all_reduce_sum(s, ctx.group, ctx.dist) for s in stats)
+
+
+# ---------------------------------------------------------------------------------------------- multiscale TTA over ranks
+def _source_rows(out_r0: int, out_r1: int, h_in: int, h_out: int, align_corners: bool):
+    """Source rows [s0, s1) the bilinear taps of output rows [out_r0, out_r1) touch (one row of slack on both sides:
+    the device evaluates the tap positions in fp32)."""
+    if h_in == h_out:
+        return out_r0, out_r1
+    if align_corners:
+        scale = (h_in - 1) / (h_out - 1) if h_out > 1 else 0.0
+        lo, hi = scale * out_r0, scale * (out_r1 - 1)
+    else:
+        scale = h_in / h_out
+        lo, hi = max(scale * (out_r0 + 0.5) - 0.5, 0.0), max(scale * (out_r1 - 1 + 0.5) - 0.5, 0.0)
+    return max(int(np.floor(lo)) - 1, 0), min(int(np.floor(hi)) + 3, h_in)
+
+
+def ms_strip_plan(source_heights: Sequence[int], out_height: int, world: int, align_corners: bool = True):
+    """Row-strip decomposition of ``ms_image_deaugment`` over ``world`` ranks (BASELINE cfg5 "4 x MI355X"):
+    rank r produces output rows ``out[r] = (r0, r1)`` (``np.linspace`` cuts) and needs, of scale s, source rows
+    ``src[r][s] = (s0, s1)``.  No collective is involved: when the model runs on row strips with that halo, every rank
+    already holds what it needs; the strips of the result are simply concatenated (or stay sharded)."""
+    cuts = np.linspace(0, out_height, world + 1, dtype=int)
+    plan = []
+    for r in range(world):
+        r0, r1 = int(cuts[r]), int(cuts[r + 1])
+        plan.append(dict(rank=r, out=(r0, r1), src=[_source_rows(r0, r1, int(h), out_height, align_corners) if r1 > r0 else (0, 0)
+                                                     for h in source_heights]))
+    return plan
+
+
+def ms_image_deaugment_strip(strips, source_heights, src_rows, out_rows, out_size, reduction="mean", align_corners: bool = True):
+    """This rank's rows ``out_rows = (r0, r1)`` of ``tta.ms_image_deaugment`` (bilinear, stride 1): ``strips[s]`` holds rows
+    ``src_rows[s] = (s0, s1)`` of scale s's ``[B, C, source_heights[s], w_s]`` prediction.  One HIP launch; same
+    arithmetic as the full-size call, so the concatenated strips equal it bit for bit."""
+    import ctypes
+
+    from . import _native as N
+    from .inference.tta import _reduction_code
+
+    code = _reduction_code(reduction)
+    if code is None:
+        raise NotImplementedError(f"reduction={reduction!r} has no fused multiscale kernel")
+    first = strips[0]
+    N.require_device(first, "multiscale TTA")
+    B, C = int(first.shape[0]), int(first.shape[1])
+    ms = []
+    for m, (s0, s1) in zip(strips, src_rows):
+        N.require_device(m, "multiscale TTA")
+        if m.dim() != 4 or m.dtype != torch.float32 or m.shape[0] != B or m.shape[1] != C or m.shape[2] != s1 - s0:
+            raise ValueError("every strip must be float32 [B, C, s1 - s0, w_s]")
+        ms.append(m.contiguous())
+    r0, r1 = int(out_rows[0]), int(out_rows[1])
+    ho, wo = int(out_size[0]), int(out_size[1])
+    out = torch.empty((B, C, r1 - r0, wo), device=first.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
+    ptrs = (ctypes.c_void_p * len(ms))(*[m.data_ptr() for m in ms])
+    lib = N.load()
+    with N.on_device(first.device):
+        rc = lib.ptb_ms_deaug_reduce_strip(ptrs, N.int_array([int(h) for h in source_heights]), N.int_array([int(m.shape[3]) for m in ms]),
+                                           N.int_array([int(s0) for s0, _ in src_rows]), N.int_array([int(s1 - s0) for s0, s1 in src_rows]),
+                                           len(ms), out.data_ptr(), B * C, ho, wo, r0, r1 - r0, 1 if align_corners else 0, code,
+                                           N.stream_ptr(first.device))
+    N.bump()
+    N.check(rc, "ptb_ms_deaug_reduce_strip")
+    return out

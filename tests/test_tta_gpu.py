@@ -305,3 +305,29 @@ def test_nonlinear_reduction_gradients(reduction, group, shape, dev):
      "harmonic1p": lambda t: 1 / (1 / (t + 1)).mean(0) - 1,
      "logodd": lambda t: torch.sigmoid(torch.log(t / (1 - t)).mean(0)), "log1p": lambda t: torch.log1p(t).mean(0).exp() - 1}[reduction](st).sum().backward()
     torch.testing.assert_close(l1.grad, l2.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("world", [2, 4, 7])
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("reduction", ["mean", "gmean"])
+def test_multiscale_row_strips_equal_the_full_result(world, align_corners, reduction, dev):
+    """cfg5 over several GPUs: every rank reduces its own strip of output rows from source row strips with
+    the halo `ms_strip_plan` prescribes -- no collective; concatenated, the strips equal the single-GPU call bit for bit."""
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.parallel import ms_image_deaugment_strip, ms_strip_plan
+
+    torch.manual_seed(world)
+    H, W = 96, 128
+    offsets = [-24, 0, 32, 13]
+    maps = [torch.rand((2, 3, H + o, W + o), device=dev) * 0.9 + 0.05 for o in offsets]
+    full = tta.ms_image_deaugment(maps, offsets, reduction=reduction, align_corners=align_corners)
+    heights = [m.shape[2] for m in maps]
+    plan = ms_strip_plan(heights, H, world, align_corners)
+    assert plan[0]["out"][0] == 0 and plan[-1]["out"][1] == H
+    pieces = []
+    for entry in plan:
+        strips = [m[:, :, s0:s1].contiguous() for m, (s0, s1) in zip(maps, entry["src"])]
+        for (s0, s1), h in zip(entry["src"], heights):
+            assert 0 <= s0 < s1 <= h and s1 - s0 < h or world == 1 or h <= 40
+        pieces.append(ms_image_deaugment_strip(strips, heights, entry["src"], entry["out"], (H, W), reduction, align_corners))
+    assert torch.equal(torch.cat(pieces, dim=2), full)
