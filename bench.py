@@ -96,6 +96,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if os.environ.get("PTB_BENCH_SAME_GPU", "0") == "1":   # functional test of the N > 1 path on a 1-GPU box (with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_sharded = os.environ.get("PTB_BENCH_FORCE_SHARDED", "0") == "1"  # exercise the RCCL path with any world size
@@ -107,7 +109,11 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("PTB_BENCH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import __graft_entry__ as entry
