@@ -294,6 +294,16 @@ int ptb_soft_ce_fwd(const float* logits, const int64_t* labels, double* sums, fl
 int ptb_soft_ce_bwd(const float* logits, const int64_t* labels, const float* coef, const float* grad_pix, float* grad, int B, int C,
                     int64_t HW, float eps, int has_ignore, int64_t ignore_label, ptb_stream_t stream);
 
+/* BinaryBiTemperedLogisticLoss (losses/bitempered_loss.py:223-284; bi_tempered_logistic_loss :135-180 with the two
+ * activations (-x, x) and targets (1-t, t)): x, t DEVICE fp32 [n]; sums double [PTB_SUM_SLOTS][4] {sum of per-element
+ * losses}; elem_out optional; iters = normalisation iterations (the reference uses 5); elements whose target equals
+ * ignore_value contribute 0.  bwd: grad[i] = coef[0] * (grad_elem ? grad_elem[i] : 1) * dloss_i/dx_i, coef DEVICE float[1]. */
+int ptb_bitempered_binary_fwd(const float* x, const float* t, double* sums, float* elem_out, int64_t n, float t1, float t2,
+                              float smoothing, int iters, int has_ignore, float ignore_value, ptb_stream_t stream);
+int ptb_bitempered_binary_bwd(const float* x, const float* t, const float* coef, const float* grad_elem, float* grad, int64_t n,
+                              float t1, float t2, float smoothing, int iters, int has_ignore, float ignore_value,
+                              ptb_stream_t stream);
+
 /* ---- Lovasz hinge / Lovasz-softmax (losses/lovasz.py:23-184) ---------------------------------------------------
  * mode 0 (softmax): pred = probabilities [B, C, HW], labels int64 [B, HW]; mode 1 (hinge): pred = logits [B, HW],
  * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the

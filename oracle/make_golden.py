@@ -568,7 +568,9 @@ def gen_losses3():
                             dict(t1=0.5, t2=1.5, reduction="sum"), dict(t1=0.8, t2=1.4, reduction="none")]):
         add(f"bitempered_{i}", "bitempered", kw, ["x", "y"], lambda a, b, kw=kw: rl.BiTemperedLogisticLoss(**kw)(a, b))
     for i, (kw, t) in enumerate([(dict(t1=0.8, t2=1.3), "tb"), (dict(t1=0.8, t2=1.3, smoothing=0.05, ignore_index=255), "tbi"),
-                                 (dict(t1=0.6, t2=0.8, reduction="none"), "tb")]):
+                                 (dict(t1=0.6, t2=0.8, reduction="none"), "tb"), (dict(t1=1.0, t2=1.0), "tb"), (dict(t1=0.9, t2=1.0, smoothing=0.1), "tb"),
+                                 (dict(t1=1.0, t2=1.5, reduction="sum"), "tb"), (dict(t1=0.5, t2=4.0, reduction="sum", ignore_index=255), "tbi"),
+                                 (dict(t1=0.2, t2=0.5, smoothing=0.02), "tb"), (dict(t1=0.7, t2=2.0, reduction="none", ignore_index=255), "tbi")]):
         add(f"binary_bitempered_{i}", "binary_bitempered", kw, ["xb", t], lambda a, b, kw=kw: rl.BinaryBiTemperedLogisticLoss(**kw)(a, b))
     add("binary_soft_f1_0", "binary_soft_f1", dict(), ["xb", "tb"], lambda a, b: rl.BinarySoftF1Loss()(a, b))
     add("binary_soft_f1_1", "binary_soft_f1", dict(ignore_index=255), ["xb", "tbi"], lambda a, b: rl.BinarySoftF1Loss(ignore_index=255)(a, b))

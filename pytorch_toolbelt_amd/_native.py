@@ -66,6 +66,8 @@ SIGNATURES = {
     "ptb_split_tiles_u8": (_c_int, [_vp, _c_int, _c_int, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _ip, _fp, _fp, _c_int, _vp, _vp]),
     "ptb_pointwise_loss_fwd": (_c_int, [_c_int, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_f, _vp]),
     "ptb_pointwise_loss_apply": (_c_int, [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_f, _vp]),
+    "ptb_bitempered_binary_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_f, _c_f, _c_f, _c_int, _c_int, _c_f, _vp]),
+    "ptb_bitempered_binary_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_f, _c_f, _c_f, _c_int, _c_int, _c_f, _vp]),
     "ptb_soft_ce_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_f, _c_int, _c_i64, _vp]),
     "ptb_soft_ce_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_f, _c_int, _c_i64, _vp]),
     "ptb_volume_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _i64p] + [_c_int] * 8 + [_vp]),

@@ -383,6 +383,105 @@ __global__ __launch_bounds__(256) void soft_ce_generic_kernel(const SceArgs a, c
     if (MODE == 0) block_add<2>(s, a.sums + (size_t)(blockIdx.x % PW_SLOTS) * 4);
 }
 
+// ------------------------------------------------------------------------------------------------ binary bi-tempered
+// BinaryBiTemperedLogisticLoss (losses/bitempered_loss.py:223-284 over bi_tempered_logistic_loss :135-180): per pixel the two
+// activations (-x, x), the tempered softmax with its iterative normalisation (:25-75, num_iters = 5) and the loss terms, all
+// in registers -- the reference runs ~60 full-tensor torch ops on a [B, H, W, 2] expansion.  Backward uses the closed form
+// of the normalisation's derivative (the escort distribution, :94-104).
+struct BtArgs {
+    const float* x;
+    const float* t;
+    double* sums;
+    float* out;       // forward: optional per-element loss; backward: gradient
+    long long n;
+    float t1, t2, smoothing, ignore_value;
+    int iters, has_ignore;
+};
+
+__device__ __forceinline__ float bt_pow(float u, float e) { return ex2(e * lg2(u)); }          // u >= 0
+__device__ __forceinline__ float bt_log_t(float u, float t) { return t == 1.0f ? flog(u) : (bt_pow(u, 1.0f - t) - 1.0f) / (1.0f - t); }
+__device__ __forceinline__ float bt_exp_t(float u, float t) {
+    return t == 1.0f ? fexp(u) : bt_pow(fmaxf(1.0f + (1.0f - t) * u, 0.0f), 1.0f / (1.0f - t));
+}
+
+// probabilities of the two classes for activations (a0, a1) under temperature t (tempered_softmax, :119-132)
+__device__ __forceinline__ void bt_softmax2(float a0, float a1, float t, int iters, float& p0, float& p1) {
+    const float mu = fmaxf(a0, a1);
+    const float n0 = a0 - mu, n1 = a1 - mu;
+    if (t == 1.0f) {
+        const float e0 = fexp(n0), e1 = fexp(n1), r = rcp(e0 + e1);
+        p0 = e0 * r; p1 = e1 * r;
+        return;
+    }
+    float norm;
+    if (t > 1.0f) {   // fixed point (:25-45)
+        float c0 = n0, c1 = n1;
+        for (int i = 0; i < iters; ++i) {
+            const float z = bt_exp_t(c0, t) + bt_exp_t(c1, t);
+            const float s = bt_pow(z, 1.0f - t);
+            c0 = n0 * s; c1 = n1 * s;
+        }
+        const float z = bt_exp_t(c0, t) + bt_exp_t(c1, t);
+        norm = -bt_log_t(1.0f / z, t);
+    } else {          // bisection (:48-75)
+        const float edge = -1.0f / (1.0f - t);
+        const float dim = (n0 > edge ? 1.0f : 0.0f) + (n1 > edge ? 1.0f : 0.0f);
+        float lo = 0.0f, hi = -bt_log_t(1.0f / dim, t);
+        for (int i = 0; i < iters; ++i) {
+            const float mid = (hi + lo) * 0.5f;
+            const float mass = bt_exp_t(n0 - mid, t) + bt_exp_t(n1 - mid, t);
+            if (mass < 1.0f) hi = mid; else lo = mid;
+        }
+        norm = (hi + lo) * 0.5f;
+    }
+    p0 = bt_exp_t(n0 - norm, t);
+    p1 = bt_exp_t(n1 - norm, t);
+}
+
+template <bool BWD>
+__device__ __forceinline__ float bt_element(float x, float tv, const BtArgs& a, float gi, float k0) {
+    if (a.has_ignore && tv == a.ignore_value) return 0.0f;
+    float y0 = 1.0f - tv, y1 = tv;                                   // onehot of the binary target (:265-266)
+    if (a.smoothing > 0.0f) {                                        // :151-155 with 2 classes
+        y0 = (1.0f - 2.0f * a.smoothing) * y0 + a.smoothing;
+        y1 = (1.0f - 2.0f * a.smoothing) * y1 + a.smoothing;
+    }
+    float p0, p1;
+    bt_softmax2(-x, x, a.t2, a.iters, p0, p1);
+    const float e = 2.0f - a.t1;
+    if (!BWD) {
+        // :159-165 (y * log_t(y + 1e-10) is finite for y = 0: 0 * log_t(1e-10))
+        const float l0 = y0 * bt_log_t(y0 + 1e-10f, a.t1) - y0 * bt_log_t(p0, a.t1) - bt_pow(y0, e) / e + bt_pow(p0, e) / e;
+        const float l1 = y1 * bt_log_t(y1 + 1e-10f, a.t1) - y1 * bt_log_t(p1, a.t1) - bt_pow(y1, e) / e + bt_pow(p1, e) / e;
+        return l0 + l1;
+    }
+    // dL/dp_c = -y_c p_c^(-t1) + p_c^(1 - t1);  dp_c/da_j = p_c^t2 (delta_cj - escort_j), escort = p^t2 / sum p^t2
+    const float g0 = -y0 * bt_pow(p0, -a.t1) + bt_pow(p0, 1.0f - a.t1);
+    const float g1 = -y1 * bt_pow(p1, -a.t1) + bt_pow(p1, 1.0f - a.t1);
+    const float q0 = bt_pow(p0, a.t2), q1 = bt_pow(p1, a.t2);
+    const float rs = rcp(q0 + q1);
+    // a class outside the finite support (t2 < 1, p = 0) passes no gradient: the reference's relu backward zeroes it even
+    // where d log_t / dp is infinite
+    const float w0 = p0 > 0.0f ? g0 * q0 : 0.0f, w1 = p1 > 0.0f ? g1 * q1 : 0.0f;
+    const float dot = w0 + w1;
+    const float da0 = w0 - dot * q0 * rs, da1 = w1 - dot * q1 * rs;
+    return k0 * gi * (da1 - da0);                                    // a0 = -x, a1 = x
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bitempered_binary_kernel(const BtArgs a, const float* __restrict__ coef,
+                                                                const float* __restrict__ grad_elem) {
+    float s[1] = {0.f};
+    const float k0 = BWD ? coef[0] : 0.f;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += stride) {
+        const float v = bt_element<BWD>(a.x[i], a.t[i], a, (BWD && grad_elem) ? grad_elem[i] : 1.0f, k0);
+        if (BWD) a.out[i] = v;
+        else { s[0] += v; if (a.out) a.out[i] = v; }
+    }
+    if (!BWD) block_add<1>(s, a.sums + (size_t)(blockIdx.x % PW_SLOTS) * 4);
+}
+
 static unsigned pw_grid(long long groups) {
     long long want = (groups + 255) / 256;
     const long long cap = g_loss_grid_cap > 0 ? g_loss_grid_cap : 8192;
@@ -505,4 +604,23 @@ extern "C" int ptb_soft_ce_bwd(const float* logits, const int64_t* labels, const
     SceArgs a{logits, reinterpret_cast<const long long*>(labels), nullptr, nullptr, nullptr, B, C, (long long)HW, eps, has_ignore,
               (long long)ignore_label};
     return launch_sce(a, 1, coef, grad_pix, grad, (hipStream_t)stream);
+}
+
+extern "C" int ptb_bitempered_binary_fwd(const float* x, const float* t, double* sums, float* elem_out, int64_t n, float t1, float t2,
+                                         float smoothing, int iters, int has_ignore, float ignore_value, ptb_stream_t stream) {
+    if (!x || !t || !sums || n < 0 || iters < 0 || t1 == 2.0f) return PTB_EINVAL;
+    if (n == 0) return PTB_OK;
+    BtArgs a{x, t, sums, elem_out, (long long)n, t1, t2, smoothing, ignore_value, iters, has_ignore};
+    hipLaunchKernelGGL(bitempered_binary_kernel<false>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, a, nullptr, nullptr);
+    return check_launch();
+}
+
+extern "C" int ptb_bitempered_binary_bwd(const float* x, const float* t, const float* coef, const float* grad_elem, float* grad,
+                                         int64_t n, float t1, float t2, float smoothing, int iters, int has_ignore, float ignore_value,
+                                         ptb_stream_t stream) {
+    if (!x || !t || !coef || !grad || n < 0 || iters < 0 || t1 == 2.0f) return PTB_EINVAL;
+    if (n == 0) return PTB_OK;
+    BtArgs a{x, t, nullptr, grad, (long long)n, t1, t2, smoothing, ignore_value, iters, has_ignore};
+    hipLaunchKernelGGL(bitempered_binary_kernel<true>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, a, coef, grad_elem);
+    return check_launch();
 }

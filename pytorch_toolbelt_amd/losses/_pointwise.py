@@ -137,3 +137,41 @@ class SoftCESums(torch.autograd.Function):
         N.bump()
         N.check(rc, "ptb_soft_ce_bwd")
         return grad, None, None, None, None, None
+
+
+class BiTemperedBinarySums(torch.autograd.Function):
+    """float64 sum of the per-element binary bi-tempered losses (+ optional per-element map) of fp32 x, t [n]."""
+
+    @staticmethod
+    def forward(ctx, x, t, t1, t2, smoothing, iters, has_ignore, ignore_value, want_elem):
+        sums = torch.zeros((SUM_SLOTS, 4), dtype=torch.float64, device=x.device)
+        elem = torch.empty_like(x) if want_elem else None
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_bitempered_binary_fwd(x.data_ptr(), t.data_ptr(), sums.data_ptr(), _ptr(elem), x.numel(), t1, t2, smoothing, iters,
+                                               1 if has_ignore else 0, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_bitempered_binary_fwd")
+        ctx.save_for_backward(x, t)
+        ctx.cfg = (t1, t2, smoothing, iters, has_ignore, ignore_value)
+        ctx.has_elem = want_elem
+        return sums.sum(dim=0)[0], (elem if want_elem else x.new_empty(0))
+
+    @staticmethod
+    def backward(ctx, g_sum, g_elem):
+        x, t = ctx.saved_tensors
+        t1, t2, smoothing, iters, has_ignore, ignore_value = ctx.cfg
+        coef = g_sum.to(torch.float32).reshape(1)
+        grad_elem = None
+        if ctx.has_elem and g_elem is not None and g_elem.numel():
+            grad_elem = (g_elem.to(torch.float32) + coef[0]).contiguous()
+            coef = torch.ones(1, device=x.device)
+        coef = coef.contiguous()
+        grad = torch.empty_like(x)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_bitempered_binary_bwd(x.data_ptr(), t.data_ptr(), coef.data_ptr(), _ptr(grad_elem), grad.data_ptr(), x.numel(),
+                                               t1, t2, smoothing, iters, 1 if has_ignore else 0, ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_bitempered_binary_bwd")
+        return (grad,) + (None,) * 8

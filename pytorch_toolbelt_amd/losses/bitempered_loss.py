@@ -1,7 +1,8 @@
 """Bi-tempered logistic loss (Amid et al., https://arxiv.org/abs/1906.03361; reference losses/bitempered_loss.py).
 
-Classification-shaped (rows of ``num_classes`` activations with an iterative per-row normalisation), not on the
-tiled-inference hot path: written as torch tensor algebra, which runs on the MI355X through ATen.  The tempered
+The general form is classification-shaped (rows of ``num_classes`` activations with an iterative per-row normalisation)
+and written as torch tensor algebra (runs on the MI355X through ATen); the binary form on GPU segmentation maps has a fused
+HIP kernel (``BinaryBiTemperedLogisticLoss._native``).  The tempered
 logarithm / exponential are ``log_t(u) = (u^(1-t) - 1) / (1 - t)`` and ``exp_t(u) = [1 + (1-t) u]_+^(1/(1-t))``.
 """
 from typing import Optional
@@ -134,6 +135,8 @@ class BinaryBiTemperedLogisticLoss(nn.Module):
     def forward(self, predictions: Tensor, targets: Tensor) -> Tensor:
         if predictions.size(1) != 1 or targets.size(1) != 1:
             raise ValueError("Channel dimension for predictions and targets must be equal to 1")
+        if predictions.is_cuda and predictions.shape == targets.shape and not targets.requires_grad and self.t1 != 2.0:
+            return self._native(predictions, targets)
         two = torch.cat([-predictions, predictions], dim=1).moveaxis(1, -1)
         hot = torch.cat([1 - targets, targets], dim=1).moveaxis(1, -1)
         loss = bi_tempered_logistic_loss(two, hot, t1=self.t1, t2=self.t2, label_smoothing=self.smoothing, reduction="none").unsqueeze(dim=1)
@@ -144,3 +147,22 @@ class BinaryBiTemperedLogisticLoss(nn.Module):
         if self.reduction == "sum":
             return loss.sum()
         return loss
+
+    def _native(self, predictions: Tensor, targets: Tensor) -> Tensor:
+        """Segmentation maps on the GPU: one fused HIP pass per direction (csrc/ptb_pointwise.hip) -- the two activations
+        (-x, x), the iterative normalisation (5 iterations, like the reference's default) and the loss terms per pixel in
+        registers, instead of ~60 full-tensor torch ops on a [B, ..., 2] expansion."""
+        from . import _pointwise as P
+
+        x = P.as_f32(predictions, "BinaryBiTemperedLogisticLoss")
+        t = P.as_f32(targets.detach(), "BinaryBiTemperedLogisticLoss")
+        reduce = self.reduction in ("mean", "sum")
+        has_ignore = self.ignore_index is not None
+        total, elem = P.BiTemperedBinarySums.apply(x.view(-1), t.view(-1), float(self.t1), float(self.t2), float(self.smoothing), 5,
+                                                   has_ignore, float(self.ignore_index) if has_ignore else 0.0, not reduce)
+        out_dtype = predictions.dtype if predictions.dtype.is_floating_point else torch.float32
+        if self.reduction == "mean":
+            return (total / max(x.numel(), 1)).to(out_dtype)
+        if self.reduction == "sum":
+            return total.to(out_dtype)
+        return elem.view(predictions.shape).to(out_dtype)
