@@ -8,9 +8,10 @@ namespace ptb {
 
 struct Taps { int i0, i1; float l0, l1; };
 
+template <int ALIGN = -1>   // -1: run-time align_corners; 0 / 1: compile-time (no branch in the unrolled tap code)
 __device__ __forceinline__ Taps taps(int dst, float scale, int n_in, bool align_corners) {
     float src;
-    if (align_corners) {
+    if (ALIGN < 0 ? align_corners : (ALIGN == 1)) {
         src = scale * (float)dst;
     } else {
         src = scale * ((float)dst + 0.5f) - 0.5f;
@@ -173,7 +174,7 @@ constexpr int MS_TW = 64, MS_TH = 16, MS_LR = 24, MS_LC = 96, MS_LP = 112;
 
 // OPK: 0 = sum / mean, 2 = gmean (branch-free: the run-time switch over all reductions costs more than the gathers),
 // 1 = any other reduction
-template <int OPK>
+template <int OPK, int ALIGN>
 __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, float* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) float lds[MS_LR * MS_LP];
     __shared__ __attribute__((aligned(16))) Taps ctap[MS_TW];  // the tile's 64 column taps, computed once per scale
@@ -190,11 +191,12 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < a.n; ++s) {
         float v[4] = {1.f, 1.f, 1.f, 1.f};
-        const int hin = a.h[s], win = a.w[s], hfull = a.hfull[s];
+        const int hin = a.h[s], win = a.w[s], hfull = a.hfull[s], src0 = a.src0[s];
+        auto local_row = [&](int i) { return min(max(i - src0, 0), hin - 1); };   // global source row -> row of this rank's strip
         const float* src = a.in[s] + p * (long long)hin * win;
         const int gy = oy + a.row0, gy0 = oy0 + a.row0;
         if (hfull == a.hout_full && win == a.wout) {
-            const int ry = ms_local(a, s, gy);
+            const int ry = local_row(gy);
             if (row_ok && ox + 3 < a.wout) {
                 const float4 t = *reinterpret_cast<const float4*>(src + (long long)ry * win + ox);
                 v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -205,8 +207,8 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
             // workgroup-uniform source window of this tile
             const int oy_last = min(oy0 + MS_TH, a.hout) - 1, ox_last = min(ox0 + MS_TW, a.wout) - 1;
             // window rows in GLOBAL source coordinates, then shifted into the strip this rank holds
-            const int r_lo = taps(gy0, a.sh[s], hfull, a.align_corners).i0, r_hi = taps(oy_last + a.row0, a.sh[s], hfull, a.align_corners).i1;
-            const int c_lo = taps(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps(ox_last, a.sw[s], win, a.align_corners).i1;
+            const int r_lo = taps<ALIGN>(gy0, a.sh[s], hfull, a.align_corners).i0, r_hi = taps<ALIGN>(oy_last + a.row0, a.sh[s], hfull, a.align_corners).i1;
+            const int c_lo = taps<ALIGN>(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps<ALIGN>(ox_last, a.sw[s], win, a.align_corners).i1;
             const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
             const bool staged = nr <= MS_LR && nc <= MS_LC && (win & 3) == 0;
             if (staged) {
@@ -216,15 +218,15 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
                 if (q4 < q_per_row && col < win) {  // win % 4 == 0 and col % 4 == 0: the whole float4 is inside the row
                     for (int rr = tid >> 5; rr < nr; rr += 8)
                         *reinterpret_cast<float4*>(&lds[rr * MS_LP + 4 * q4]) =
-                            *reinterpret_cast<const float4*>(src + (long long)ms_local(a, s, r_lo + rr) * win + col);
+                            *reinterpret_cast<const float4*>(src + (long long)local_row(r_lo + rr) * win + col);
                 }
-                if (tid < MS_TW) ctap[tid] = taps(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
+                if (tid < MS_TW) ctap[tid] = taps<ALIGN>(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
                 __syncthreads();
             }
             if (row_ok) {
                 // branch-free: columns past the right edge use the clamped tap of the last column (computed, never
                 // stored), so all 16 gathers of the lane are issued back to back instead of one pixel at a time
-                Taps ty = taps(gy, a.sh[s], hfull, a.align_corners);
+                Taps ty = taps<ALIGN>(gy, a.sh[s], hfull, a.align_corners);
                 Taps tx[4];
                 float t[4][4];
                 if (staged) {
@@ -236,9 +238,9 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
                     for (int m = 0; m < 4; ++m) { t[m][0] = l0[tx[m].i0]; t[m][1] = l0[tx[m].i1]; t[m][2] = l1[tx[m].i0]; t[m][3] = l1[tx[m].i1]; }
                 } else {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) tx[m] = taps(min(ox + m, a.wout - 1), a.sw[s], win, a.align_corners);
-                    const float* g0 = src + (long long)ms_local(a, s, ty.i0) * win;
-                    const float* g1 = src + (long long)ms_local(a, s, ty.i1) * win;
+                    for (int m = 0; m < 4; ++m) tx[m] = taps<ALIGN>(min(ox + m, a.wout - 1), a.sw[s], win, a.align_corners);
+                    const float* g0 = src + (long long)local_row(ty.i0) * win;
+                    const float* g1 = src + (long long)local_row(ty.i1) * win;
 #pragma unroll
                     for (int m = 0; m < 4; ++m) { t[m][0] = g0[tx[m].i0]; t[m][1] = g0[tx[m].i1]; t[m][2] = g1[tx[m].i0]; t[m][3] = g1[tx[m].i1]; }
                 }
@@ -317,9 +319,12 @@ static int ms_reduce_impl(const float* const* inputs, const int* hs_full, const 
     if (g_ms_tiled && tiles <= 0x7fffffffLL) {
         const dim3 grid((unsigned)tiles), block(256);
         hipStream_t st = (hipStream_t)stream;
-        if (reduction == PTB_RED_GMEAN) hipLaunchKernelGGL(ms_reduce_tiled_kernel<2>, grid, block, 0, st, a, out);
-        else if (reduction >= PTB_RED_GMEAN) hipLaunchKernelGGL(ms_reduce_tiled_kernel<1>, grid, block, 0, st, a, out);
-        else hipLaunchKernelGGL(ms_reduce_tiled_kernel<0>, grid, block, 0, st, a, out);
+#define PTB_MS(OPK) do { if (align_corners) hipLaunchKernelGGL((ms_reduce_tiled_kernel<OPK, 1>), grid, block, 0, st, a, out); \
+                        else hipLaunchKernelGGL((ms_reduce_tiled_kernel<OPK, 0>), grid, block, 0, st, a, out); } while (0)
+        if (reduction == PTB_RED_GMEAN) PTB_MS(2);
+        else if (reduction >= PTB_RED_GMEAN) PTB_MS(1);
+        else PTB_MS(0);
+#undef PTB_MS
         return check_launch();
     }
     const long long total = planes * hout * ((wout + 3) / 4);
