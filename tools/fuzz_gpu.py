@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Seeded differential fuzzing on an MI355X (beyond the fixed seeds of tests/):
+
+    python tools/fuzz_gpu.py [first_seed] [count]
+
+1. TileMerger in its three modes (lazy / kernel-maintained normaliser / planned) over random slicer geometries, bit-exact
+   against the oracle (the test function of tests/test_tiles_gpu.py with more seeds);
+2. fused de-augment merges over random groups x reductions x input dtypes x planned-or-not, 2e-5 relative;
+3. the elementwise losses and soft cross entropy over random (odd) shapes and options against the float64 oracle.
+Prints one line per failure and a summary; exit code 1 on any failure."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import pointwise_oracle as PO  # noqa: E402
+from oracle import tiles_oracle as TO  # noqa: E402
+from oracle import tta_oracle as AO  # noqa: E402
+from pytorch_toolbelt_amd import _native as N  # noqa: E402
+from pytorch_toolbelt_amd import losses as L  # noqa: E402
+from pytorch_toolbelt_amd.inference.tiles import TileMerger  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def fuzz_merger_modes(seeds):
+    import test_tiles_gpu as T
+
+    bad = 0
+    for seed in seeds:
+        try:
+            T.test_random_geometries_all_merger_modes(seed, dev, N)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("merger modes FAIL seed", seed, repr(e)[:300])
+    return bad
+
+
+def fuzz_fused(seeds):
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        group = ["d4", "d2", "flips", "fliplr", "flipud"][seed % 5]
+        red = ["mean", "sum", "gmean", "hmean", "logodd", "log1p", "harmonic1p"][seed % 7]
+        V = {"d4": 8, "d2": 4, "flips": 3, "fliplr": 2, "flipud": 2}[group]
+        if seed % 3:
+            th = int(rng.choice([64, 128, 192]))
+            tw = th if group == "d4" else int(rng.choice([64, 128, 256]))
+            step = (min(int(rng.choice([32, 64, th])), th), min(int(rng.choice([64, tw])), tw))
+        else:
+            th = int(rng.integers(8, 60))
+            tw = th if group == "d4" else int(rng.integers(8, 60))
+            step = (int(rng.integers(max(1, th // 2), th + 1)), int(rng.integers(max(1, tw // 2), tw + 1)))
+        shape = (int(rng.integers(th, 3 * th + 30)), int(rng.integers(tw, 3 * tw + 30)))
+        C, batch = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+        geom = TO.slicer_geometry(shape, (th, tw), step)
+        crops, n = geom["crops"], len(geom["crops"])
+        w = TO.pyramid_window(th, tw)[0]
+        positive = red not in ("mean", "sum")
+        x = (rng.random((n, V, C, th, tw)) * 0.9 + 0.05 if positive else rng.standard_normal((n, V, C, th, tw))).astype(np.float32)
+        dt = [torch.float32, torch.float16, torch.bfloat16][(seed // 5) % 3]
+        xt = torch.from_numpy(x).to(dev).to(dt)
+        xq = xt.float().cpu().numpy()
+        st = TO.merger_new(geom["target_shape"], C, w)
+        m = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops if seed % 2 else None)
+        try:
+            for b0 in range(0, n, batch):
+                sel = slice(b0, min(n, b0 + batch))
+                nb = sel.stop - sel.start
+                xb = np.ascontiguousarray(np.moveaxis(xq[sel], 1, 0)).reshape(V * nb, C, th, tw)
+                TO.merger_integrate(st, AO.image_deaugment(xb, group, red), crops[sel])
+                m.integrate_batch_deaugment(xt[sel].transpose(0, 1).reshape(V * nb, C, th, tw).contiguous(), crops[sel], group=group, reduction=red)
+            got, want = m.merge().cpu().numpy(), TO.merger_merge(st)
+            err = np.nanmax(np.abs(got - want) / (1 + np.abs(want)))
+            if not (err <= 2e-5) or (np.isnan(got) != np.isnan(want)).any():
+                bad += 1
+                print("fused FAIL", seed, group, red, dt, shape, (th, tw), step, C, batch, err)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("fused ERROR", seed, group, red, dt, repr(e)[:200])
+    return bad
+
+
+def fuzz_losses(seeds):
+    def close(a, b, tol=3e-5):
+        a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+        return a.shape == b.shape and bool(np.all(np.abs(a - b) <= tol * (1 + np.abs(b))))
+
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        B, C, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 22)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if seed % 4 == 0:
+            W = 4 * int(rng.integers(1, 12))
+        x = (rng.standard_normal((B, C, H, W)) * 2).astype(np.float32)
+        t = (rng.random((B, C, H, W)) < 0.4).astype(np.float32)
+        ti = t.copy()
+        ti[rng.random((B, C, H, W)) < 0.1] = -100
+        labi = rng.integers(0, C, (B, H, W))
+        labi[rng.random((B, H, W)) < 0.15] = -100
+        xd, td, tid = (torch.from_numpy(v).to(dev) for v in (x, t, ti))
+        red = ["mean", "sum", "none"][seed % 3]
+        try:
+            wv, pwv = (rng.random(C) + 0.5).astype(np.float32), (rng.random(C) * 2 + 0.5).astype(np.float32)
+            sf = [None, 0.1][seed % 2]
+            ok = close(L.SoftBCEWithLogitsLoss(weight=torch.from_numpy(wv).view(C, 1, 1).to(dev), pos_weight=torch.from_numpy(pwv).view(C, 1, 1).to(dev),
+                                               reduction=red, smooth_factor=sf)(xd, tid).cpu().numpy(),
+                       PO.soft_bce(x, ti, wv.reshape(C, 1, 1), pwv.reshape(C, 1, 1), -100, red, sf))
+            g = 1.0 + seed % 3 * 0.5
+            ok &= close(L.balanced_binary_cross_entropy_with_logits(xd, tid, gamma=g, ignore_index=-100, reduction=red).cpu().numpy(),
+                        PO.balanced_bce(x, ti, g, -100, red))
+            qred, beta = ["mean", "sum", "none", "normalized"][seed % 4], [2.0, 1.0, 1.5][seed % 3]
+            ok &= close(L.QualityFocalLoss(beta=beta, reduction=qred)(xd, td).cpu().numpy(), PO.quality_focal(x, t, beta, qred))
+            ok &= close(L.functional.wing_loss(xd, td, 2.0, 0.7, red).cpu().numpy(), PO.wing(x, t, 2.0, 0.7, red))
+            ok &= close(float(L.functional.log_cosh_loss(xd, td)), PO.log_cosh(x, t))
+            eps = 0.1 * (seed % 3)
+            ok &= close(L.SoftCrossEntropyLoss(reduction=red, smooth_factor=eps)(xd, torch.from_numpy(labi).to(dev)).cpu().numpy(),
+                        PO.soft_ce(x, labi, eps, -100, red))
+            if not ok:
+                bad += 1
+                print("losses FAIL", seed, (B, C, H, W), red)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("losses ERROR", seed, (B, C, H, W), repr(e)[:300])
+    from pytorch_toolbelt_amd.losses import _kernels as K
+
+    K.flush_label_check()
+    return bad
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    seeds = range(first, first + count)
+    total = fuzz_merger_modes(seeds) + fuzz_fused(seeds) + fuzz_losses(seeds)
+    print(f"fuzz: {3 * count} cases, {total} failures")
+    sys.exit(1 if total else 0)
