@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
         const unsigned v = k < chunks_per_seg ? cc[k] : 0u;
         sh[threadIdx.x] = v;
         __syncthreads();
-        for (int o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan in LDS
+        for (unsigned o = 1; o < 256; o <<= 1) {  // Hillis-Steele inclusive scan in LDS
             const unsigned add = threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
             __syncthreads();
             sh[threadIdx.x] += add;

@@ -77,8 +77,6 @@ struct PwArgs {
     float ignore_value;
 };
 
-struct PwElem { float loss, aux; };  // aux: QFL focal term
-
 // ---- per-element forward -------------------------------------------------------------------------------------------
 template <int KIND>
 __device__ __forceinline__ void pw_forward(float x, float t, float w, float pw, const PwArgs& a, float* s, float& loss) {
