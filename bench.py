@@ -17,8 +17,8 @@ data flow).
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the 361 tiles of ONE image are sharded over the
-ranks by tile rows, neighbouring ranks exchange their 256-row overlap strips point-to-point over xGMI and every
-rank merges its own band (strong scaling: total work per step is fixed).  Rank 0 prints one JSON line.
+ranks as contiguous tile ranges (45 / 46 tiles each at N = 8), neighbouring ranks exchange their 256-row halo rectangles
+point-to-point over xGMI and every rank merges its own band (strong scaling: total work per step is fixed).  Rank 0 prints one JSON line.
 """
 import argparse
 import gc
@@ -124,7 +124,7 @@ def main():
         dist.barrier()
     from pytorch_toolbelt_amd import _native as N
     from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
-    from pytorch_toolbelt_amd.parallel import ShardedTileMerger, tile_row_partition
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger
 
     if args.chunk_rows:
         assert N.load().ptb_set_tunable(0, args.chunk_rows) == 0
@@ -138,10 +138,12 @@ def main():
 
     # ---- this rank's share of the tiles, and their (synthetic) model outputs resident in HBM -------------------
     sharded = use_dist
+    partition = os.environ.get("PTB_BENCH_PARTITION", "tiles")   # "tiles": 45 / 46 tiles per rank at N = 8; "rows": whole tile rows
     if not sharded:
         my_tiles = np.arange(n_tiles)
     else:
-        my_tiles = tile_row_partition(slicer.crops, world)[rank]
+        sharded_merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev, partition=partition)
+        my_tiles = sharded_merger.tiles
     crops = slicer.crops[my_tiles]
     batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -158,7 +160,7 @@ def main():
         planned = not (args.unplanned or args.memset_accumulators)
         merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None)
     else:
-        merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev)
+        merger = sharded_merger
 
     def step():
         if not sharded:
@@ -317,15 +319,19 @@ def main():
             "config": {
                 "workload": "BASELINE cfg2: 5000x5000x3 image, ImageSlicer 512/256 pyramid (361 tiles, target 5120x5120), "
                             "d4 TTA (8 views) model outputs C=4 fp32 resident in HBM, fused de-augment+mean+integrate_batch in "
-                            "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; TileMerger(crops=tiler.crops): the "
-                            "data-independent norm_mask is precomputed from the crop list (SURVEY 8d: not compulsory traffic) and every "
-                            "block is divided by it in the launch that brings its last tile, so merge() returns the finished "
-                            "[C,H',W'] map; model forward excluded",
+                            "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; " +
+                            ("TileMerger(crops=tiler.crops): the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: "
+                             "not compulsory traffic) and every block is divided by it in the launch that brings its last tile, so "
+                             "merge() returns the finished [C,H',W'] map; " if (not sharded and planned) else
+                             ("ShardedTileMerger: every rank accumulates its tiles into a band, halo rectangles go point-to-point to "
+                              "the rank owning those rows, each rank divides its rows by the locally computed norm_mask; " if sharded
+                              else "norm_mask built lazily from the crop log, merge() = one division pass; ")) +
+                            "model forward excluded",
                 "tiles": n_tiles,
                 "batch_tiles": BATCH,
                 "merger": ("planned (crops= given, no merge pass)" if (not sharded and planned) else
                            ("sharded, unplanned" if sharded else "unplanned (lazy norm_mask + merge pass)")),
-                "parallelism": "single GPU" if world == 1 else f"tile rows sharded over {world} ranks, RCCL p2p halo exchange",
+                "parallelism": "single GPU" if world == 1 else (f"{'tile ranges' if partition == 'tiles' else 'tile rows'} sharded over {world} ranks, RCCL p2p halo exchange"),
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "region_algorithmic_bytes": region_bytes,
                 "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),

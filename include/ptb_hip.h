@@ -121,6 +121,11 @@ int ptb_merge_div(const float* image, const float* norm, float* out, int C, int6
 int ptb_merge_div_ex(const float* image, const float* norm, float* out, int C, int64_t HW, int64_t image_cs, int64_t out_cs,
                      const float* extra, int64_t extra_cs, int64_t extra_n, ptb_stream_t stream);
 
+/* dst[c][r][x] += src[c][r][x] for a packed src [C, rows, cols] and a rectangle of a larger fp32 accumulator (element
+ * strides dst_cs per channel, dst_rs per row): folds a halo rectangle received from another rank into the band
+ * accumulator (multi-GPU merger; no reference counterpart). */
+int ptb_rect_add(float* dst, const float* src, int C, int rows, int cols, int64_t dst_cs, int64_t dst_rs, ptb_stream_t stream);
+
 /* ---- Loop edges on the device (compositions of reference functions, no single counterpart) ---------
  * ptb_split_tiles_u8 == ImageSlicer.split (inference/tiles.py:177-204, BORDER_CONSTANT only) -> image_to_tensor
  * (utils/torch_utils.py:204-231, HWC->CHW) -> .float() [-> * scale[c] + bias[c]] [-> *_image_augment, tta.py:385-422]:

@@ -146,6 +146,44 @@ extern "C" int ptb_merge_div_ex(const float* image, const float* norm, float* ou
     return check_launch();
 }
 
+// dst[c][r][x] += src[c][r][x] over a [C, rows, cols] rectangle of a larger accumulator (halo rectangles of the multi-GPU
+// merger).  One thread per 4 columns when everything is 16-byte aligned, else one per element; grid.y = channel * rows.
+template <int VEC>
+__global__ __launch_bounds__(256) void rect_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int C, int rows, int cols,
+                                                       long long dst_cs, long long dst_rs) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int x = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (x >= cols) return;
+    for (long long cr = blockIdx.y; cr < (long long)C * rows; cr += gridDim.y) {
+        const int c = (int)(cr / rows), r = (int)(cr - (long long)c * rows);
+        float* d = dst + c * dst_cs + r * dst_rs + x;
+        const float* s = src + cr * cols + x;
+        if (VEC == 4) {
+            const v4f b = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(s));
+            *reinterpret_cast<v4f*>(d) = *reinterpret_cast<v4f*>(d) + b;
+        } else {
+            *d += *s;
+        }
+    }
+}
+
+extern "C" int ptb_rect_add(float* dst, const float* src, int C, int rows, int cols, int64_t dst_cs, int64_t dst_rs,
+                            ptb_stream_t stream) {
+    if (!dst || !src || C < 1 || rows < 0 || cols < 0 || dst_rs < cols || dst_cs < (int64_t)rows * dst_rs) return PTB_EINVAL;
+    if (rows == 0 || cols == 0) return PTB_OK;
+    const long long cr = (long long)C * rows;
+    const int gy = (int)(cr < 65535 ? cr : 65535);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = !g_force_scalar && cols % 4 == 0 && dst_cs % 4 == 0 && dst_rs % 4 == 0 && aligned16(dst) && aligned16(src);
+    if (vec)
+        hipLaunchKernelGGL(rect_add_kernel<4>, dim3((cols / 4 + 255) / 256, gy), dim3(256), 0, s, dst, src, C, rows, cols,
+                           (long long)dst_cs, (long long)dst_rs);
+    else
+        hipLaunchKernelGGL(rect_add_kernel<1>, dim3((cols + 255) / 256, gy), dim3(256), 0, s, dst, src, C, rows, cols,
+                           (long long)dst_cs, (long long)dst_rs);
+    return check_launch();
+}
+
 extern "C" int ptb_merge_div(const float* image, const float* norm, float* out, int C, int64_t HW, ptb_stream_t stream) {
     return ptb_merge_div_ex(image, norm, out, C, HW, HW, HW, nullptr, 0, 0, stream);
 }

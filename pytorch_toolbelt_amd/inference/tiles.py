@@ -445,31 +445,40 @@ class TileMerger:
         fresh = self._fresh
         if not fresh.any():
             return
-        eager = self._eager_norm   # lazy mode: the normaliser is not tied to the image's first-touch bitmap
         if fresh.all():
             self._image.zero_()
-            if eager:
+            if self._eager_norm:   # lazy mode: the normaliser is not tied to the image's first-touch bitmap
                 self._norm.zero_()
+            fresh[:] = 0
         else:
-            rows = np.nonzero(fresh.any(axis=1))[0]
-            i = 0
-            while i < len(rows):  # group consecutive block rows with identical column patterns into rectangles
-                j = i
-                while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and np.array_equal(fresh[rows[j + 1]], fresh[rows[i]]):
-                    j += 1
-                y0, y1 = int(rows[i]) * _FRESH_ROWS, min(self.image_height, (int(rows[j]) + 1) * _FRESH_ROWS)
-                cols = np.nonzero(fresh[rows[i]])[0]
-                k = 0
-                while k < len(cols):
-                    m = k
-                    while m + 1 < len(cols) and cols[m + 1] == cols[m] + 1:
-                        m += 1
-                    x0, x1 = int(cols[k]) * 64, min(self.image_width, (int(cols[m]) + 1) * 64)
-                    self._image[:, y0:y1, x0:x1] = 0
-                    if eager:
-                        self._norm[:, y0:y1, x0:x1] = 0
-                    k = m + 1
-                i = j + 1
+            self._zero_fresh(0, self.image_height, 0, self.image_width)
+
+    def _zero_fresh(self, y0, y1, x0, x1):
+        """Zero-fill the never-written blocks that intersect rows y0:y1, columns x0:x1 (and mark them written)."""
+        fresh = self._fresh[y0 // _FRESH_ROWS:(y1 + _FRESH_ROWS - 1) // _FRESH_ROWS, x0 // 64:(x1 + 63) // 64]
+        if not fresh.any():
+            return
+        by, bx = y0 // _FRESH_ROWS, x0 // 64
+        eager = self._eager_norm
+        rows = np.nonzero(fresh.any(axis=1))[0]
+        i = 0
+        while i < len(rows):  # group consecutive block rows with identical column patterns into rectangles
+            j = i
+            while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1 and np.array_equal(fresh[rows[j + 1]], fresh[rows[i]]):
+                j += 1
+            r0, r1 = (int(rows[i]) + by) * _FRESH_ROWS, min(self.image_height, (int(rows[j]) + by + 1) * _FRESH_ROWS)
+            cols = np.nonzero(fresh[rows[i]])[0]
+            k = 0
+            while k < len(cols):
+                m = k
+                while m + 1 < len(cols) and cols[m + 1] == cols[m] + 1:
+                    m += 1
+                c0, c1 = (int(cols[k]) + bx) * 64, min(self.image_width, (int(cols[m]) + bx + 1) * 64)
+                self._image[:, r0:r1, c0:c1] = 0
+                if eager:
+                    self._norm[:, r0:r1, c0:c1] = 0
+                k = m + 1
+            i = j + 1
         fresh[:] = 0
 
     # ------------------------------------------------------------------ helpers

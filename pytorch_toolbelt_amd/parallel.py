@@ -3,76 +3,104 @@
 The reference has no multi-GPU tile path; the single-device ``TileMerger`` result is the specification
 (SURVEY.md 8e).  Design for MI355X's point-to-point xGMI fabric:
 
-* tiles are partitioned by **tile row** (the reference's ``split_across_nodes`` linspace rule applied to rows,
-  utils/distributed.py:306-309), so each rank's tiles cover one horizontal band of the padded image;
+* tiles are partitioned into contiguous ranges of the row-major tile sequence by the reference's own
+  ``split_across_nodes`` linspace rule (utils/distributed.py:306-309): 361 tiles over 8 ranks = 45 or 46 each (whole
+  tile rows, 19 over 8 ranks, would leave one rank with 3 rows = 57 tiles); a rank's tiles cover a horizontal band;
 * every rank accumulates its band locally with the fused HIP kernels (no communication on the data path);
-* each rank **owns** the pixel rows from the top of its band to the top of the next rank's band.  The only exchange
-  is the strip of its band that hangs into the next owner's rows (tile_size - tile_step rows, 21 MB for the headline
-  config): one point-to-point send to the next rank and one receive from the previous one, all pairs concurrently on
-  distinct xGMI links, overlapped with the accumulation of the remaining tile rows.  Nothing is all-reduced: a ring
-  all-reduce of the 524 MB accumulator would be per-link bound and ~30x slower than the kernels;
+* each rank **owns** a range of pixel rows of the result.  The only exchange is the part of a band that lies in
+  another rank's rows: when the boundary between two ranks coincides with the start of a tile row, one strip of
+  tile_size - tile_step rows travels to the next rank (21 MB for the headline config); when it falls inside a tile row,
+  the two ranks swap two half-height rectangles as wide as their share of that tile row (the same 21 MB in total, but
+  split over the two directions of the link).  All pairs run concurrently on distinct xGMI links as point-to-point
+  send/receive, overlapped with the accumulation of the tiles that do not feed a rectangle.  Nothing is all-reduced: a
+  ring all-reduce of the 524 MB accumulator would be per-link bound and ~30x slower than the kernels;
 * ``norm_mask`` is data independent, so every rank computes the global normaliser of its owned rows once, locally;
-* ``merge()`` adds the received strip and divides in a single HIP kernel, returning this rank's band.
+* ``merge()`` adds what it received and divides (a full-width strip is folded into the division kernel), returning
+  this rank's band.
 """
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
+__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
            "ms_image_deaugment_strip"]
 
 
 def tile_row_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
-    """Tile indices per rank: contiguous groups of tile rows, boundaries at ``np.linspace(0, n_rows, world+1, dtype=int)``.
-    Within a rank the LAST tile row comes first (it produces the strip that must travel to the next rank, so the
-    exchange overlaps the accumulation of the other rows)."""
+    """Tile indices per rank: contiguous groups of whole tile rows, boundaries at
+    ``np.linspace(0, n_rows, world+1, dtype=int)`` (19 rows / 8 ranks -> at most 3 rows: speed-up bound 6.33x)."""
     crops = np.asarray(crops)
     row_y = np.unique(crops[:, 1])
     cuts = np.linspace(0, len(row_y), world + 1, dtype=int)
-    parts = []
-    for r in range(world):
-        ys = row_y[cuts[r]:cuts[r + 1]]
-        order = []
-        for y in list(ys[::-1][:1]) + list(ys[:-1]):
-            order.extend(np.nonzero(crops[:, 1] == y)[0].tolist())
-        parts.append(np.asarray(order, dtype=np.int64))
-    return parts
+    order = np.lexsort((crops[:, 0], crops[:, 1]))
+    return [order[np.isin(crops[order, 1], row_y[cuts[r]:cuts[r + 1]])].astype(np.int64) for r in range(world)]
 
 
-def band_plan(crops: np.ndarray, world: int, image_height: int):
-    """Per rank: band rows [a, b) touched by its tiles, owned rows [o0, o1), and the exchange lists.
-
-    Returns a list of dicts(rank, tiles, band=(a,b), owned=(o0,o1), sends=[(dst, r0, r1)], recvs=[(src, r0, r1)]) with
-    absolute pixel rows.  Ranks without tiles own nothing."""
+def tile_range_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
+    """Tile indices per rank: contiguous ranges of the row-major tile sequence with boundaries at
+    ``np.linspace(0, n_tiles, world+1, dtype=int)`` -- the reference's own ``split_across_nodes`` rule
+    (utils/distributed.py:306-309).  361 tiles / 8 ranks -> 45 or 46 per rank (speed-up bound 7.85x); a rank boundary may
+    fall in the middle of a tile row."""
     crops = np.asarray(crops)
-    parts = tile_row_partition(crops, world)
-    th = int(crops[0, 3])
-    bands = []
-    for p in parts:
-        if len(p) == 0:
-            bands.append(None)
-        else:
-            ys = crops[p, 1]
-            bands.append((int(ys.min()), int(ys.max()) + th))
-    live = [r for r in range(world) if bands[r] is not None]
-    plan = []
-    for r in range(world):
-        plan.append(dict(rank=r, tiles=parts[r], band=bands[r], owned=None, sends=[], recvs=[]))
+    order = np.lexsort((crops[:, 0], crops[:, 1]))
+    cuts = np.linspace(0, len(order), world + 1, dtype=int)
+    return [order[cuts[r]:cuts[r + 1]].astype(np.int64) for r in range(world)]
+
+
+PARTITIONS = {"tiles": tile_range_partition, "rows": tile_row_partition}
+
+
+def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str = "tiles"):
+    """Who accumulates, owns and exchanges what.  Per rank a dict with
+
+    * ``tiles``: its tile indices in ISSUE order -- the tiles feeding an outgoing rectangle first, so that the exchange
+      overlaps the accumulation of the others;
+    * ``band`` = (a, b): pixel rows touched by its tiles;  ``owned`` = (o0, o1): the rows of the result it produces.
+      The cut between consecutive ranks r, s lies at the top of s's first tile when s starts a tile row, and half a tile
+      (at most one tile step) lower when the boundary falls inside a tile row -- then r holds the larger share of the
+      rows above the cut and s of the rows below, and the two halo rectangles travel in opposite directions at once;
+    * ``sends`` = [(dst, r0, r1, c0, c1)], ``recvs`` = [(src, r0, r1, c0, c1)]: absolute pixel rectangles (rows r0:r1,
+      columns c0:c1 = the column extent of the sender's tiles on those rows) of the sender's partial sums that another
+      rank owns.  ``boundary``: the tile indices that must be in before the sends are complete.
+
+    Ranks without tiles have ``band`` = ``owned`` = None."""
+    crops = np.asarray(crops)
+    parts = PARTITIONS[partition](crops, world)
+    tw, th = int(crops[0, 2]), int(crops[0, 3])
+    step = np.diff(np.unique(crops[:, 1]))
+    half = min(th // 2, int(step.min())) if len(step) else 0
+    live = [r for r in range(world) if len(parts[r])]
+    plan = [dict(rank=r, tiles=parts[r], band=None, owned=None, sends=[], recvs=[], boundary=np.zeros(0, dtype=np.int64)) for r in range(world)]
+    for r in live:
+        ys = crops[parts[r], 1]
+        plan[r]["band"] = (int(ys.min()), int(ys.max()) + th)
+    cut = [0]
+    for r, s in zip(live[:-1], live[1:]):
+        y_s = int(crops[parts[s][0], 1])
+        mid_row = int(crops[parts[r][-1], 1]) == y_s
+        cut.append(min(image_height, max(cut[-1], y_s + (half if mid_row else 0))))
+    cut.append(image_height)
     for i, r in enumerate(live):
-        o0 = bands[r][0] if i else 0
-        o1 = bands[live[i + 1]][0] if i + 1 < len(live) else image_height
-        plan[r]["owned"] = (o0, o1)
-    for s in live:  # every part of s's band owned by another rank travels to that owner
-        a, b = bands[s]
+        plan[r]["owned"] = (cut[i], cut[i + 1])
+    for s in live:  # every part of s's band that another rank owns travels to that owner
+        a, b = plan[s]["band"]
+        mine = crops[parts[s]]
+        feeding = np.zeros(len(mine), dtype=bool)
         for d in live:
-            if d == s:
-                continue
             o0, o1 = plan[d]["owned"]
             r0, r1 = max(a, o0), min(b, o1)
-            if r0 < r1:
-                plan[s]["sends"].append((d, r0, r1))
-                plan[d]["recvs"].append((s, r0, r1))
+            if d == s or r0 >= r1:
+                continue
+            hit = (mine[:, 1] < r1) & (mine[:, 1] + th > r0)
+            if not hit.any():
+                continue
+            c0, c1 = int(mine[hit, 0].min()), int(mine[hit, 0].max()) + tw
+            plan[s]["sends"].append((d, r0, r1, c0, c1))
+            plan[d]["recvs"].append((s, r0, r1, c0, c1))
+            feeding |= hit
+        plan[s]["boundary"] = parts[s][feeding]
+        plan[s]["tiles"] = np.concatenate([parts[s][feeding], parts[s][~feeding]])
     return plan
 
 
@@ -102,16 +130,32 @@ class _HipOps:
         return out
 
 
-class ShardedTileMerger:
-    """Drop-in shaped like ``TileMerger`` for one rank of a tile-row sharded merge.
+    @staticmethod
+    def add_rect(image, top, rect, buf):
+        """image [C, h, W] (rows offset by ``top``) += packed ``buf`` [C, r1 - r0, c1 - c0] on the absolute rectangle."""
+        from . import _native as N
 
-    Every rank constructs it with the FULL ``crops`` of the slicer, then feeds only its own tiles
-    (``tile_row_partition(crops, world)[rank]``, boundary row first) in absolute coordinates.  ``merge()`` returns this
-    rank's owned rows ``[C, o1 - o0, W]`` (``owned_rows`` gives the absolute range); ``gather()`` assembles the full
-    map on every rank.
+        r0, r1, c0, c1 = rect
+        dst = image[:, r0 - top:r1 - top, c0:c1]
+        dev = image.device
+        with N.on_device(dev):
+            rc = N.load().ptb_rect_add(dst.data_ptr(), buf.data_ptr(), image.shape[0], r1 - r0, c1 - c0, image.stride(0), image.stride(1),
+                                       N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "ptb_rect_add")
+
+
+class ShardedTileMerger:
+    """Drop-in shaped like ``TileMerger`` for one rank of a sharded merge of ONE image.
+
+    Every rank constructs it with the FULL ``crops`` of the slicer, then feeds only its own tiles -- ``self.tiles``
+    (indices into ``crops``, in the order that lets the exchange overlap the accumulation) -- in absolute coordinates.
+    ``merge()`` returns this rank's owned rows ``[C, o1 - o0, W]`` (``owned_rows`` gives the absolute range);
+    ``gather()`` assembles the full map on every rank.  ``partition``: ``"tiles"`` (contiguous tile ranges, the
+    reference's ``split_across_nodes`` rule; default) or ``"rows"`` (whole tile rows).
     """
 
-    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None):
+    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles"):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -123,8 +167,9 @@ class ShardedTileMerger:
         self.channels = channels
         self.image_height, self.image_width = int(image_shape[0]), int(image_shape[1])
         crops = np.asarray(crops)
-        self.plan = band_plan(crops, self.world, self.image_height)
+        self.plan = band_plan(crops, self.world, self.image_height, partition)
         me = self.plan[self.rank]
+        self.tiles = me["tiles"]
         self.band = me["band"]
         self.owned_rows = me["owned"]
         self.sends, self.recvs = me["sends"], me["recvs"]
@@ -140,25 +185,24 @@ class ShardedTileMerger:
         self.local = self.ops.new_local((self.bottom - self.top, self.image_width), channels, weight, self.device)
         # global normaliser of the owned rows: accumulate the window of EVERY tile touching them (data independent)
         th = int(crops[0, 3])
-        touching = crops[(crops[:, 1] < o1) & (crops[:, 1] + th > o0)]
-        lo = int(min(touching[:, 1].min(), o0))
-        hi = int(max((touching[:, 1] + th).max(), o1))
-        tmp = self.ops.new_local((hi - lo, self.image_width), 1, weight, self.device)
-        zeros = torch.zeros((8, 1, int(crops[0, 3]), int(crops[0, 2])), device=self.device)
-        shifted = touching.copy()
-        shifted[:, 1] -= lo
-        for i in range(0, len(shifted), 8):
-            tmp.integrate_batch(zeros[:len(shifted[i:i + 8])], shifted[i:i + 8])
-        self.norm_owned = tmp.norm_mask[:, o0 - lo:o1 - lo].contiguous()
-        # tiles (by y) whose accumulation must finish before the outgoing strips are complete
-        self._send_rows_y = set()
-        for _d, r0, r1 in self.sends:
-            for y in np.unique(crops[me["tiles"], 1]):
-                if y < r1 and y + th > r0:
-                    self._send_rows_y.add(int(y))
-        self._tiles_per_y = {int(y): int(np.sum(crops[me["tiles"], 1] == y)) for y in np.unique(crops[me["tiles"], 1])}
-        self._send_buf = [torch.empty((channels, r1 - r0, self.image_width), device=self.device) for _d, r0, r1 in self.sends]
-        self._recv_buf = [torch.empty((channels, r1 - r0, self.image_width), device=self.device) for _s, r0, r1 in self.recvs]
+        self.norm_owned = None
+        if o1 > o0:
+            touching = crops[(crops[:, 1] < o1) & (crops[:, 1] + th > o0)]
+            lo = int(min(touching[:, 1].min(), o0)) if len(touching) else o0
+            hi = int(max((touching[:, 1] + th).max(), o1)) if len(touching) else o1
+            tmp = self.ops.new_local((hi - lo, self.image_width), 1, weight, self.device)
+            zeros = torch.zeros((8, 1, int(crops[0, 3]), int(crops[0, 2])), device=self.device)
+            shifted = touching.copy()
+            shifted[:, 1] -= lo
+            for i in range(0, len(shifted), 8):
+                tmp.integrate_batch(zeros[:len(shifted[i:i + 8])], shifted[i:i + 8])
+            self.norm_owned = tmp.norm_mask[:, o0 - lo:o1 - lo].contiguous()
+        # tiles (by origin) whose accumulation must finish before the outgoing rectangles are complete
+        self._boundary = {}
+        for x, y in crops[me["boundary"], :2]:
+            self._boundary[(int(x), int(y))] = self._boundary.get((int(x), int(y)), 0) + 1
+        self._send_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _d, r0, r1, c0, c1 in self.sends]
+        self._recv_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _s, r0, r1, c0, c1 in self.recvs]
         self.reset()
 
     # ------------------------------------------------------------------ per-image cycle
@@ -173,56 +217,66 @@ class ShardedTileMerger:
         else:
             self.local.image.zero_()
             self.local.norm_mask.zero_()
-        self._remaining = {y: self._tiles_per_y[y] for y in self._send_rows_y}
+        self._remaining = dict(self._boundary)
 
     def _shift(self, crop_coords):
         c = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4).copy()
-        ys = c[:, 1].copy()
+        origins = [(int(x), int(y)) for x, y in c[:, :2]]
         c[:, 1] -= self.top
-        return c, ys
+        return c, origins
 
-    def _after_integrate(self, ys):
-        for y in ys:
-            y = int(y)
-            if y in self._remaining:
-                self._remaining[y] -= 1
-                if self._remaining[y] == 0:
-                    del self._remaining[y]
-        if not self._remaining and not self._exchanged:
+    def _after_integrate(self, origins):
+        rem = self._remaining
+        if rem:
+            for o in origins:
+                n = rem.get(o)
+                if n is not None:
+                    if n == 1:
+                        del rem[o]
+                    else:
+                        rem[o] = n - 1
+        if not rem and not self._exchanged:
             self._start_exchange()
 
     def integrate_batch(self, batch, crop_coords):
         if len(batch) != len(crop_coords):
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
-        c, ys = self._shift(crop_coords)
+        c, origins = self._shift(crop_coords)
         self.local.integrate_batch(batch, c)
-        self._after_integrate(ys)
+        self._after_integrate(origins)
 
     def integrate_batch_deaugment(self, batch, crop_coords, group="d4", reduction="mean"):
-        c, ys = self._shift(crop_coords)
+        c, origins = self._shift(crop_coords)
         self.local.integrate_batch_deaugment(batch, c, group=group, reduction=reduction)
-        self._after_integrate(ys)
+        self._after_integrate(origins)
+
+    def _rect(self, r0, r1, c0, c1):
+        """View of the band accumulator on an absolute pixel rectangle, valid to READ now: blocks of the rectangle no
+        kernel has written yet are zero-filled first (only those -- the interior keeps its first-touch state)."""
+        loc = self.local
+        if hasattr(loc, "_zero_fresh"):
+            loc._zero_fresh(r0 - self.top, r1 - self.top, c0, c1)
+            img = loc._image
+        else:
+            img = loc.image
+        return img[:, r0 - self.top:r1 - self.top, c0:c1]
 
     def _start_exchange(self):
-        """Post all strip sends / receives as one batch (one ncclGroup: every pair progresses concurrently, each on
-        its own xGMI link) on RCCL's stream; the caller's stream keeps accumulating the remaining tile rows."""
+        """Post all halo sends / receives as one batch (one ncclGroup: every pair progresses concurrently, each on its
+        own xGMI link, both directions of a link at once) on RCCL's stream; the caller's stream keeps accumulating the
+        remaining tiles."""
         self._exchanged = True
         if self.local is None:
             return
         dist = self.dist
         ops = []
-        for buf, (dst, r0, r1) in zip(self._send_buf, self.sends):
-            # pack the strided strip; its rows are complete (all tiles of the boundary row are in), so read the raw
-            # accumulator and leave the still-untouched interior rows in their first-touch state
-            buf.copy_(self._raw_image()[:, r0 - self.top:r1 - self.top])
+        for buf, (dst, r0, r1, c0, c1) in zip(self._send_buf, self.sends):
+            buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
-        for buf, (src, _r0, _r1) in zip(self._recv_buf, self.recvs):
+        for buf, (src, *_rect) in zip(self._recv_buf, self.recvs):
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
         if ops:
             self._pending = dist.batch_isend_irecv(ops)
-
-    def _raw_image(self):
-        return getattr(self.local, "_image", None) if hasattr(self.local, "_image") else self.local.image
 
     def _global_rank(self, r):
         if self.group is None:
@@ -235,28 +289,31 @@ class ShardedTileMerger:
         self._pending = []
 
     def merge(self):
-        """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank without tiles)."""
+        """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank that owns no rows)."""
         if self.local is None:
             return None
         if not self._exchanged:
             self._start_exchange()
         self._wait_pending()
         o0, o1 = self.owned_rows
-        img = self.local.image[:, o0 - self.top:o1 - self.top]  # (property: zero-fills anything never written)
-        out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
+        if o1 <= o0:
+            return None
+        image = self.local.image                     # (property: zero-fills anything never written)
         extra, extra_rows = None, 0
-        if self.recvs:
-            if len(self.recvs) > 1 or self.recvs[0][1] != o0:
-                raise NotImplementedError("more than one rank overlaps these rows (tile_step < tile_size / 2 with one-row ranks)")
-            extra, extra_rows = self._recv_buf[0], self.recvs[0][2] - self.recvs[0][1]
-        return self.ops.merge_rows(img, self.norm_owned[0], out, extra, extra_rows)
+        for buf, (_src, r0, r1, c0, c1) in zip(self._recv_buf, self.recvs):
+            if extra is None and r0 == o0 and c0 == 0 and c1 == self.image_width:
+                extra, extra_rows = buf, r1 - r0     # a full-width strip at the top of the band: folded into the division
+            else:
+                self.ops.add_rect(image, self.top, (r0, r1, c0, c1), buf)
+        out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
+        return self.ops.merge_rows(image[:, o0 - self.top:o1 - self.top], self.norm_owned[0], out, extra, extra_rows)
 
     def gather(self, band):
         """All-gather the bands into the full ``[C, H, W]`` map on every rank (optional; 52 MB per rank at cfg2)."""
         full = torch.empty((self.channels, self.image_height, self.image_width), device=self.device)
         for r in range(self.world):
             owned = self.plan[r]["owned"]
-            if owned is None:
+            if owned is None or owned[1] <= owned[0]:
                 continue
             piece = band.contiguous() if r == self.rank else torch.empty((self.channels, owned[1] - owned[0], self.image_width), device=self.device)
             self.dist.broadcast(piece, self._global_rank(r), group=self.group)

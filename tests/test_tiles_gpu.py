@@ -266,11 +266,12 @@ class _SoloDist:
         return self.world
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_sharded_merger_bands_on_gpu(world, dev):
-    """Every rank of a `world`-way tile-row sharding is played in turn on one GPU; strips are handed over by hand.
+@pytest.mark.parametrize("partition", ["tiles", "rows"])
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_sharded_merger_bands_on_gpu(world, partition, dev):
+    """Every rank of a `world`-way sharding is played in turn on one GPU; halo rectangles are handed over by hand.
     The assembled result must equal the single-device TileMerger (same HIP kernels, different accumulation order)."""
-    from pytorch_toolbelt_amd.parallel import ShardedTileMerger, tile_row_partition
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger
 
     geom = TO.slicer_geometry((700, 520), (128, 128), (64, 64))
     w = TO.pyramid_window(128, 128)[0]
@@ -285,9 +286,9 @@ def test_sharded_merger_bands_on_gpu(world, dev):
 
     ranks = []
     for r in range(world):
-        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_SoloDist(r, world))
-        m._start_exchange = lambda: None  # no process group here: strips are moved below
-        mine = tile_row_partition(crops, world)[r]
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_SoloDist(r, world), partition=partition)
+        m._start_exchange = lambda: None  # no process group here: rectangles are moved below
+        mine = m.tiles
         m.reset()
         for b0 in range(0, len(mine), 8):
             idx = mine[b0:b0 + 8]
@@ -295,9 +296,8 @@ def test_sharded_merger_bands_on_gpu(world, dev):
         ranks.append(m)
     full = torch.empty_like(want)
     for r, m in enumerate(ranks):
-        for buf, (src, r0, r1) in zip(m._recv_buf, m.recvs):  # what rank `src` would have sent
-            s = ranks[src]
-            buf.copy_(s.local.image[:, r0 - s.top:r1 - s.top])
+        for buf, (src, r0, r1, c0, c1) in zip(m._recv_buf, m.recvs):  # what rank `src` would have sent
+            buf.copy_(ranks[src]._rect(r0, r1, c0, c1))
         m._exchanged = True
         band = m.merge()
         o0, o1 = m.owned_rows
