@@ -226,3 +226,80 @@ def test_region_statistics_all_reduce_matches_single_process():
     for rank, loss, grad in got:
         assert abs(loss - float(ref)) < 1e-6
         assert np.allclose(grad, world * probs.grad[2 * rank:2 * rank + 2].numpy(), atol=1e-7)
+
+
+# ------------------------------------------------------------------ plan fuzzing without processes
+class _FakeDist:
+    """Rank / world stand-in: the ranks are played one after the other and their rectangles are handed over by hand."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+
+def _simulate(shape, tile, step, world, partition, C=1, seed=0):
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*((tile, tile) if isinstance(tile, int) else tile))[0]
+    crops = geom["crops"]
+    rng = np.random.default_rng(seed)
+    th, tw = int(crops[0, 3]), int(crops[0, 2])
+    outs = rng.standard_normal((len(crops), C, th, tw)).astype(np.float32)
+    ranks = []
+    for r in range(world):
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device="cpu", ops=OracleOps, dist=_FakeDist(r, world), partition=partition)
+        m._start_exchange = lambda: None
+        if m.local is not None:
+            m.reset()
+            for b0 in range(0, len(m.tiles), 5):
+                idx = m.tiles[b0:b0 + 5]
+                m.integrate_batch(torch.from_numpy(outs[idx]), crops[idx])
+                # the exchange must not be armed before every boundary tile is in, and must be armed right after
+                done = set(m.tiles[:b0 + 5].tolist())
+                assert (len(m._remaining) == 0) == set(m.plan[r]["boundary"].tolist()).issubset(done)
+        ranks.append(m)
+    H, W = geom["target_shape"]
+    full = torch.full((C, H, W), float("nan"))
+    owned = np.zeros(H, dtype=int)
+    for m in ranks:
+        if m.local is None:
+            continue
+        for buf, (src, r0, r1, c0, c1) in zip(m._recv_buf, m.recvs):
+            buf.copy_(ranks[src]._rect(r0, r1, c0, c1))
+        m._exchanged = True
+        band = m.merge()
+        o0, o1 = m.owned_rows
+        owned[o0:o1] += 1
+        if band is not None:
+            full[:, o0:o1] = band
+    assert (owned == 1).all()
+    st = TO.merger_new(geom["target_shape"], C, w)
+    TO.merger_integrate(st, outs, crops)
+    np.testing.assert_allclose(full.numpy(), TO.merger_merge(st), rtol=0, atol=1e-5)
+    return ranks
+
+
+def test_plan_fuzz_in_process():
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        th, tw = int(rng.choice([16, 24, 32, 48])), int(rng.choice([16, 32, 40]))
+        sh, sw = int(rng.integers(max(1, th // 4), th + 1)), int(rng.integers(max(1, tw // 4), tw + 1))
+        shape = (int(rng.integers(th, 6 * th)), int(rng.integers(tw, 6 * tw)))
+        world = int(rng.integers(1, 9))
+        partition = "tiles" if case % 3 else "rows"
+        try:
+            _simulate(shape, (th, tw), (sh, sw), world, partition, C=int(rng.integers(1, 3)), seed=case)
+        except Exception as e:
+            raise AssertionError(f"case {case}: shape={shape} tile={(th, tw)} step={(sh, sw)} world={world} partition={partition}: {e}") from e
+
+
+def test_headline_geometry_eight_ranks_in_process():
+    """BASELINE cfg3 geometry (5000 x 5000, 512 / 256, 8 ranks), one channel: every rank's band, the bidirectional halo
+    rectangles and the owned-row merge reproduce the single-device result."""
+    ranks = _simulate((5000, 5000), 512, 256, 8, "tiles", C=1, seed=3)
+    assert [len(m.tiles) for m in ranks] == [45, 45, 45, 45, 45, 45, 45, 46]
+    assert max(m.bottom - m.top for m in ranks) <= 1280       # band accumulators: at most 4 tile rows + ownership slack
