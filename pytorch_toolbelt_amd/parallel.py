@@ -298,7 +298,11 @@ class ShardedTileMerger:
         o0, o1 = self.owned_rows
         if o1 <= o0:
             return None
-        image = self.local.image                     # (property: zero-fills anything never written)
+        # the band accumulator, readable on the rows this rank owns and on every received rectangle (blocks there that no
+        # kernel has written are zero-filled; rows owned by other ranks keep their first-touch state: nobody reads them)
+        for _src, r0, r1, c0, c1 in [(None, o0, o1, 0, self.image_width)] + list(self.recvs):
+            self._rect(r0, r1, c0, c1)
+        image = self.local._image if hasattr(self.local, "_zero_fresh") else self.local.image
         extra, extra_rows = None, 0
         for buf, (_src, r0, r1, c0, c1) in zip(self._recv_buf, self.recvs):
             if extra is None and r0 == o0 and c0 == 0 and c1 == self.image_width:
