@@ -175,12 +175,50 @@ __global__ __launch_bounds__(256) void merge_crop_planar_kernel(const CropArgs a
 
 // Channel-last outputs with the CT <= 4 channels of 4 pixels held in registers: the thread's 4*CT output elements are
 // contiguous, so they leave as CT 16-byte (fp32) or CT 4-byte (uint8) stores.
+// fp32 output with OW % 4 == 0 (`repack`): thread t's run starts at element 4 * CT * t of the output, i.e. the 256 threads of a
+// workgroup own 256 * CT consecutive float4 -- but a lane's own CT float4 are adjacent, so storing them directly makes every
+// store instruction hit 64 lanes x 16 B at a stride of 16 * CT B (measured 3.2 TB/s).  The runs are exchanged through LDS
+// instead (lane writes float4 CT * tid + g, reads float4 256 * g + tid), so each store instruction covers 1 KiB contiguous.
 template <int CT>
-__global__ __launch_bounds__(256) void merge_crop_hwc_kernel(const CropArgs a, bool vec) {
+__global__ __launch_bounds__(256) void merge_crop_hwc_kernel(const CropArgs a, bool vec, bool repack) {
+    __shared__ float4 xchg[256 * CT];
     const int groups_x = (a.OW + 3) / 4;
     const long long total = (long long)a.OH * groups_x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const long long iplane = (long long)a.H * a.W;
+    if (repack) {
+        for (long long t0 = (long long)blockIdx.x * blockDim.x; t0 < total; t0 += stride) {   // workgroup-uniform trip count
+            const long long t = t0 + threadIdx.x;
+            if (t < total) {
+                const int y = (int)(t / groups_x), x = (int)(t - (long long)y * groups_x) * 4;
+                const long long src = (long long)(y + a.top) * a.W + a.left + x;
+                float n[4], v[CT][4];
+                load_px4(a.norm ? a.norm + src : nullptr, 4, vec, n);
+#pragma unroll
+                for (int c = 0; c < CT; ++c) {
+                    load_px4(a.image + c * iplane + src, 4, vec, v[c]);
+                    if (a.norm) {
+#pragma unroll
+                        for (int m = 0; m < 4; ++m) v[c][m] = __fdiv_rn(v[c][m], n[m]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < CT; ++g)
+                    xchg[CT * threadIdx.x + g] = make_float4(v[(4 * g) % CT][(4 * g) / CT], v[(4 * g + 1) % CT][(4 * g + 1) / CT],
+                                                             v[(4 * g + 2) % CT][(4 * g + 2) / CT], v[(4 * g + 3) % CT][(4 * g + 3) / CT]);
+            }
+            __syncthreads();
+            const long long live = (total - t0 < 256 ? total - t0 : 256) * CT;   // float4 this workgroup produced
+            float4* o = reinterpret_cast<float4*>(static_cast<float*>(a.out)) + t0 * CT;
+#pragma unroll
+            for (int g = 0; g < CT; ++g) {
+                const int i = 256 * g + threadIdx.x;
+                if (i < live) o[i] = xchg[i];
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
         const int y = (int)(t / groups_x), x = (int)(t - (long long)y * groups_x) * 4;
         const int nv = min(4, a.OW - x);
@@ -317,11 +355,13 @@ extern "C" int ptb_merge_crop(const float* image, const float* norm, int C, int 
     const dim3 grid((unsigned)(want < 16384 ? want : 16384)), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = !g_force_scalar && W % 4 == 0 && left % 4 == 0 && aligned16(image) && aligned16(norm);
+    // fp32 channel-last: exchange the lanes' runs through LDS so that the stores are lane-contiguous (C == 1 already is)
+    const bool repack = !g_force_scalar && kind == OUT_F32 && C > 1 && OW % 4 == 0 && aligned16(out);
     if (layout == 0 || kind >= OUT_ARGMAX_U8) hipLaunchKernelGGL(merge_crop_planar_kernel, grid, block, 0, s, a, vec);
-    else if (C == 1) hipLaunchKernelGGL(merge_crop_hwc_kernel<1>, grid, block, 0, s, a, vec);
-    else if (C == 2) hipLaunchKernelGGL(merge_crop_hwc_kernel<2>, grid, block, 0, s, a, vec);
-    else if (C == 3) hipLaunchKernelGGL(merge_crop_hwc_kernel<3>, grid, block, 0, s, a, vec);
-    else if (C == 4) hipLaunchKernelGGL(merge_crop_hwc_kernel<4>, grid, block, 0, s, a, vec);
+    else if (C == 1) hipLaunchKernelGGL(merge_crop_hwc_kernel<1>, grid, block, 0, s, a, vec, false);
+    else if (C == 2) hipLaunchKernelGGL(merge_crop_hwc_kernel<2>, grid, block, 0, s, a, vec, repack);
+    else if (C == 3) hipLaunchKernelGGL(merge_crop_hwc_kernel<3>, grid, block, 0, s, a, vec, repack);
+    else if (C == 4) hipLaunchKernelGGL(merge_crop_hwc_kernel<4>, grid, block, 0, s, a, vec, repack);
     else hipLaunchKernelGGL(merge_crop_hwc_generic_kernel, grid, block, 0, s, a);
     return check_launch();
 }

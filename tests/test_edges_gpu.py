@@ -207,3 +207,24 @@ def test_full_size_cfg2_edges(dev):
     assert np.array_equal(np.rint(f32.cpu().numpy()).astype(np.uint8), img)
     assert int((back.cpu().numpy().astype(np.int16) - img.astype(np.int16)).min()) >= -1
     assert int((back.cpu().numpy().astype(np.int16) - img.astype(np.int16)).max()) <= 0
+
+
+@pytest.mark.parametrize("C", [2, 3, 4])
+def test_merge_crop_fp32_channel_last_repack(C, dev):
+    """fp32 channel-last output with a width that is a multiple of 4: the lanes' runs are exchanged through LDS before they
+    are stored (csrc/ptb_edges.hip) -- more than one workgroup iteration, a partial last workgroup, aligned and unaligned
+    windows; bit-exact against the oracle."""
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    H, W = 212, 540
+    rng = np.random.default_rng(C)
+    image = rng.standard_normal((C, H, W)).astype(np.float32)
+    norm = (rng.random((1, H, W)) + 0.5).astype(np.float32)
+    m = TileMerger((H, W), C, np.ones((8, 8), dtype=np.float32), device=dev)
+    m.image = torch.from_numpy(image).to(dev)
+    m.norm_mask = torch.from_numpy(norm).to(dev)
+    state = dict(image=image, norm_mask=norm)
+    for (top, left, oh, ow) in [(0, 0, H, W), (4, 8, 200, 512), (3, 5, 77, 36), (1, 2, 9, 4), (0, 4, 211, 532)]:
+        want = EO.merge_crop(state, dict(margins=(left, 0, top, 0)), (oh, ow), "hwc", "float32")
+        got = m.merge_crop((top, left, oh, ow), layout="hwc", dtype=torch.float32).cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (top, left, oh, ow)
