@@ -219,6 +219,23 @@ __device__ __forceinline__ float focal_one(float x, float t, bool ig, float cw, 
     return l;
 }
 
+// Focal contribution of one element with a HARD target from sigmoid(x) = ps and 1 - sigmoid(x) = qs (both already formed,
+// see seg_loss_fwd_reg_kernel): BCE = -log(p_t), 1 - p_t without cancellation.  Same result as focal_one to rounding.
+template <bool G2>
+__device__ __forceinline__ float focal_hard(float ps, float qs, bool t, bool ig, float cw, const FocalCfg& c, float& f) {
+    const bool tt = t && !ig;
+    const float pt = tt ? ps : qs, omp = tt ? qs : ps;
+    const float ce = -lg2(pt) * kLn2;
+    const float base = omp * c.sc;
+    if (G2) f = base * base;
+    else { f = pow_pos(base, c.gamma); f = c.g0 ? 1.0f : f; }
+    f = pt < c.thr ? 1.0f : f;
+    float l = f * ce * (t ? c.a1 + c.a0 : c.a0) * cw;
+    l = ig ? 0.f : l;
+    f = ig ? f * c.term_mask : f;
+    return l;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // Opaque register barrier: stops the compiler from keeping exp()/sigmoid() results of one pass alive for the next
 // (recomputing is cheaper than 64 extra VGPRs per lane, which would halve occupancy).
@@ -226,8 +243,9 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 
 // Register-resident variant: C <= CREG, the lane issues the loads of ALL class planes first (CREG x 16 B in flight).
 // WHAT = SEG_FOCAL | SEG_STATS bits (compile time), DENSE = dense fp32 targets instead of int64 labels.
-template <int PIX, int CREG, int WHAT, bool DENSE, bool G2>
-__global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) {
+// SHARE (focal + softmax statistics on hard labels only): one exp per element, see the comment at `share` below.
+template <int PIX, int CREG, int WHAT, bool DENSE, bool G2, bool SHARE = false>
+__global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(const SegArgs a) {
     const FocalCfg cfg = focal_cfg(a);
     extern __shared__ float lds[];  // [4 waves][3][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -255,9 +273,15 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) 
             for (int k = 0; k < PIX; ++k) xv[c][k] = 0.f;
             if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], G.ok);
         }
-        float mx[PIX], inv[PIX];
+        // Focal + softmax statistics on hard labels share ONE exp per element: with u = exp(x - m) (the softmax numerator)
+        // and em = exp(-m), sigmoid(x) = u / (u + em) and 1 - sigmoid(x) = em / (u + em), so the class loop needs a
+        // reciprocal and a log instead of two more exp and a log.  Pixels with |m| > 60 (em would leave the fp32 range) and label
+        // elements whose sigmoid underflows are masked out of the class loop and redone exactly afterwards (never on sane logits).
+        constexpr bool share = SHARE && focal && stats && !DENSE;   // the dispatcher sets SHARE only with prob == PROB_SOFTMAX
+        float mx[PIX], inv[PIX], em[PIX];
+        bool redo_all[PIX], redo[PIX];
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) { mx[k] = 0.f; inv[k] = 0.f; }
+        for (int k = 0; k < PIX; ++k) { mx[k] = 0.f; inv[k] = 0.f; em[k] = 1.f; redo_all[k] = false; redo[k] = false; }
         if (stats && a.prob == PROB_SOFTMAX) {
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
@@ -269,11 +293,14 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) 
                 for (int c = 0; c < CREG; ++c) if (c < C) {
                     const float e = fexp(xv[c][k] - m);
                     d += e;
-                    if (!focal) xv[c][k] = e;          // statistics only: keep exp(x - m), one exp per element
+                    if (!focal || share) xv[c][k] = e;  // keep exp(x - m): one exp per element
                 }
                 mx[k] = m;
                 inv[k] = rcp(d);
-                if (focal) { opaque(mx[k]); }          // both: recompute exp in the class loop instead of caching 64 values
+                em[k] = fexp(-m);
+                redo_all[k] = share && !(fabsf(m) <= 60.f);
+                redo[k] = redo_all[k];
+                if (focal && !share) { opaque(mx[k]); } // dense targets: recompute exp in the class loop instead of caching 64 values
             }
         }
 #pragma unroll
@@ -292,10 +319,21 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) 
                     bool ig = G.ign[k];
                     if (!DENSE) t = lab[k] == c ? 1.f : 0.f;
                     else { t = tv[k]; if (ignf && t == a.ignore_value) ig = true; }
-                    if (focal) { lv[k] = focal_one<G2>(x, t, ig, cw, cfg, fsum); lsum += lv[k]; }
+                    if (focal && share) {
+                        const float r = rcp(x + em[k]);                 // x holds u = exp(logit - m) here
+                        const float ps = x * r, qs = em[k] * r;
+                        const bool hard = t != 0.f;
+                        float f;
+                        const float l = focal_hard<G2>(ps, qs, hard, ig, cw, cfg, f);
+                        const bool skip = redo_all[k] || (hard && !ig && ps < 1e-36f);
+                        redo[k] = redo[k] || skip;
+                        lv[k] = skip ? 0.f : l;
+                        fsum += skip ? 0.f : f;
+                        lsum += lv[k];
+                    } else if (focal) { lv[k] = focal_one<G2>(x, t, ig, cw, cfg, fsum); lsum += lv[k]; }
                     if (stats) {
                         float p;
-                        if (a.prob == PROB_SOFTMAX) p = focal ? fexp(x - mx[k]) * inv[k] : x * inv[k];
+                        if (a.prob == PROB_SOFTMAX) p = (focal && !share) ? fexp(x - mx[k]) * inv[k] : x * inv[k];
                         else if (a.prob == PROB_SIGMOID) p = sigmoid_parts(x).p;
                         else p = x;
                         if (ig) { p = 0.f; t = 0.f; }   // p*mask, t*mask (dice.py:85-111)
@@ -303,6 +341,17 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_reg_kernel(const SegArgs a) 
                     }
                 }
                 if (focal && (a.flags & SEG_ELEMWISE)) store_px<PIX>(a.elem_out + base + (long long)c * a.HW, lv, G.ok);
+            }
+        }
+        if (share && G.ok) {   // exact redo of what the class loop masked out: the logits are read again (rare)
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                if (!redo[k]) continue;
+                for (int c = 0; c < C; ++c) {
+                    if (!redo_all[k] && c != lab[k]) continue;
+                    const float cw = a.class_weights ? a.class_weights[c] : 1.0f;
+                    lsum += focal_one<G2>(a.logits[base + (long long)c * a.HW + k], lab[k] == c ? 1.f : 0.f, G.ign[k], cw, cfg, fsum);
+                }
             }
         }
         if (focal) { f_loss += (double)lsum; f_term += (double)fsum; }
@@ -743,6 +792,111 @@ __global__ __launch_bounds__(256) void seg_fused_bwd_kernel(const SegArgs a, con
     }
 }
 
+// The same fused backward for hard labels + softmax statistics with ONE exp per element (see `share` in
+// seg_loss_fwd_reg_kernel): u = exp(x - m) replaces the logits in registers, sigmoid(x) = u / (u + em), 1 - sigmoid(x) =
+// em / (u + em) with em = exp(-m); BCE = -log(p_t).  Six transcendentals per element become three.  Pixels with |m| > 60
+// and label elements whose sigmoid underflows are rewritten afterwards from the re-read logits with the exact formulas.
+template <int PIX, int CREG, bool G2>
+__global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegArgs a, const float* __restrict__ coef,
+                                                                      const float* __restrict__ gI, const float* __restrict__ gP,
+                                                                      float* __restrict__ grad) {
+    const FocalCfg cfg = focal_cfg(a);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const bool ignf = a.flags & SEG_HAS_IGNORE;
+    const float k1 = coef[0], k2 = coef[1];
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, ignf, a.ignore_label, C, nullptr);
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        int lab[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) lab[k] = (int)G.lab[k];
+        float xv[CREG][PIX];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) xv[c][k] = 0.f;
+            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], G.ok);
+        }
+        float mx[PIX], inv[PIX], dot[PIX], em[PIX];
+        bool redo_all[PIX], redo[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xv[c][k]);
+            float d = 0.f, dd = 0.f;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) if (c < C) {
+                const float u = fexp(xv[c][k] - m);
+                xv[c][k] = u;
+                d += u;
+                dd += (lab[k] == c ? gI[c] + gP[c] : gP[c]) * u;
+            }
+            const float iv = rcp(d);
+            mx[k] = m; inv[k] = iv; dot[k] = G.ign[k] ? 0.f : dd * iv; em[k] = fexp(-m);
+            redo_all[k] = !(fabsf(m) <= 60.f);
+            redo[k] = redo_all[k];
+        }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            if (c < C) {
+                const float w0 = a.class_weights ? a.class_weights[c] : 1.f;
+                float out[PIX];
+#pragma unroll
+                for (int k = 0; k < PIX; ++k) {
+                    out[k] = 0.f;
+                    if (!G.ok || G.ign[k]) continue;
+                    const float u = xv[c][k];
+                    const bool t = lab[k] == c;
+                    const float r = rcp(u + em[k]);
+                    const float ps = u * r, qs = em[k] * r;              // sigmoid(x), 1 - sigmoid(x)
+                    const float pt = t ? ps : qs, omp = t ? qs : ps;
+                    const float ce = -lg2(pt) * kLn2;
+                    const float base_ = omp * cfg.sc;
+                    const bool below = pt < cfg.thr;
+                    float f, pw;
+                    if (G2) { f = base_ * base_; pw = base_; }
+                    else {
+                        f = pow_pos(base_, cfg.gamma); f = cfg.g0 ? 1.0f : f;
+                        pw = pow_pos(base_, cfg.gm1); pw = cfg.g1 ? 1.0f : pw;
+                    }
+                    f = below ? 1.0f : f;
+                    const float dpt = t ? ps * qs : -(ps * qs);
+                    float df = -cfg.gamma * pw * cfg.sc * dpt;
+                    df = (below || (!G2 && cfg.g0)) ? 0.f : df;
+                    const float w = w0 * (t ? cfg.a1 + cfg.a0 : cfg.a0);
+                    float gx = k1 * w * (df * ce + f * (t ? -qs : ps)) + k2 * df;
+                    const float Gc = t ? gI[c] + gP[c] : gP[c];
+                    gx += u * inv[k] * (Gc - dot[k]);
+                    out[k] = gx;
+                    redo[k] = redo[k] || (t && ps < 1e-36f);
+                }
+                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+            }
+        }
+        if (G.ok) {   // exact rewrite of the elements the fast formulas cannot represent (never on sane logits)
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                if (!redo[k] || G.ign[k]) continue;
+                for (int c = 0; c < C; ++c) {
+                    if (!redo_all[k] && c != lab[k]) continue;
+                    const float x = a.logits[base + (long long)c * a.HW + k];
+                    const float t = lab[k] == c ? 1.f : 0.f;
+                    float ce, f, df, p;
+                    focal_parts<G2, true>(x, t, cfg, ce, f, df, p);
+                    const float w = (a.class_weights ? a.class_weights[c] : 1.f) * (cfg.a1 * t + cfg.a0);
+                    float gx = k1 * w * (df * ce + f * (p - t)) + k2 * df;
+                    gx += fexp(x - mx[k]) * inv[k] * (gI[c] * t + gP[c] - dot[k]);
+                    grad[base + (long long)c * a.HW + k] = gx;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ softmax focal
 // softmax_focal_loss_with_logits (functional.py:110-173): per pixel sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c, masked by
 // label != ignore_index.  sums[0] = sum of pixel losses, sums[1] = sum of ALL focal terms (the reference does not
@@ -969,7 +1123,10 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     } else if (vec && C <= 16) {
 #define PTB_FWD(W, D) do { if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, true>), grid, block, shmem, s, a); \
                            else hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, false>), grid, block, shmem, s, a); } while (0)
-        if (labels) { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, false, true>), grid, block, shmem, s, a); else PTB_FWD(3, false); }
+        if (labels && what != SEG_STATS && prob == PROB_SOFTMAX && !(flags & SEG_ELEMWISE)) {
+            if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, true, true>), grid, block, shmem, s, a);
+            else hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, false, true>), grid, block, shmem, s, a);
+        } else if (labels) { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, false, true>), grid, block, shmem, s, a); else PTB_FWD(3, false); }
         else { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, true, true>), grid, block, shmem, s, a); else PTB_FWD(3, true); }
 #undef PTB_FWD
     } else if (vec) {
@@ -1070,7 +1227,10 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
     const bool g2 = gamma == 2.0f;
 #define PTB_FUSED(D) do { if (g2) hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, true>), grid, block, 0, s, a, coef, gI, gP, grad); \
                           else hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, false>), grid, block, 0, s, a, coef, gI, gP, grad); } while (0)
-    if (labels) PTB_FUSED(false); else PTB_FUSED(true);
+    if (labels && prob == PROB_SOFTMAX) {
+        if (g2) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true>), grid, block, 0, s, a, coef, gI, gP, grad);
+        else hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, false>), grid, block, 0, s, a, coef, gI, gP, grad);
+    } else if (labels) PTB_FUSED(false); else PTB_FUSED(true);
 #undef PTB_FUSED
     return check_launch();
 }

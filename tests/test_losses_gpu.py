@@ -388,3 +388,44 @@ def test_fused_focal_dice_jaccard(dev):
     f2 = L.FocalDiceJaccardLoss("multilabel")(xl, ml.to(dev))
     w2 = LO.focal_loss_with_logits(logits.numpy(), ml.numpy(), alpha=None) + LO.dice_loss(logits.numpy(), ml.numpy(), "multilabel") + LO.jaccard_loss(logits.numpy(), ml.numpy(), "multilabel")
     assert float(f2) == pytest.approx(float(w2), abs=1e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(gamma=1.5, alpha=0.3), dict(gamma=0.0), dict(ignore_index=5), dict(ignore_index=3, gamma=1.0)])
+def test_fused_forward_shared_exp_and_extreme_logits(kw, dev):
+    """The fused multiclass forward forms sigmoid(x) from the softmax numerator (one exp per element, csrc/ptb_losses.hip);
+    elements where that leaves the fp32 range take the exact path: per-pixel maxima beyond +-60, logits 100+ below the
+    maximum with a positive label.  Value against the fp64 oracle and against the sum of the separate modules (JaccardLoss
+    has no ignore_index in the reference, quirk Q11: with ignore_index the Jaccard part is switched off)."""
+    L = _L()
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 2, 16, 32, 48
+    logits = torch.randn((B, C, H, W), generator=g) * 3
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    logits[0, :, :4] += 80.0                   # m > 60
+    logits[0, :, 4:8] -= 90.0                  # m < -60
+    logits[1, 3, :6] = 70.0                    # one dominant class ...
+    labels[1, :3] = 3                          # ... that is the label
+    labels[1, 3:6] = 7                         # ... and that is NOT the label (label logit ~70 below the maximum)
+    logits[1, 9, 10:12] = -150.0
+    labels[1, 10:12] = 9                       # positive label whose sigmoid underflows
+    xl, ll = logits.to(dev), labels.to(dev)
+    fkw = {k: v for k, v in kw.items() if k != "ignore_index"}
+    ign = kw.get("ignore_index")
+    wj = 0.0 if ign is not None else 1.0
+    x1 = xl.clone().requires_grad_(True)
+    fused = L.FocalDiceJaccardLoss("multiclass", ignore_index=ign, jaccard_weight=wj, **fkw)(x1, ll)
+    x2 = xl.clone().requires_grad_(True)
+    parts = L.BinaryFocalLoss(ignore_index=ign, **fkw)(x2, ll) + L.DiceLoss("multiclass", ignore_index=ign)(x2, ll)
+    x64, l64 = logits.numpy(), labels.numpy()
+    want = LO.binary_focal_loss(x64, l64, ignore_index=ign, **fkw) + LO.dice_loss(x64, l64, "multiclass", ignore_index=ign)
+    if ign is None:
+        parts = parts + L.JaccardLoss("multiclass")(x2, ll)
+        want = want + LO.jaccard_loss(x64, l64, "multiclass")
+    assert np.isfinite(float(fused))
+    assert float(fused) == pytest.approx(float(parts), rel=2e-6, abs=1e-6)
+    assert float(fused) == pytest.approx(float(want), rel=1e-5, abs=1e-5)
+    # the fused backward (shared exp + exact rewrite of the extreme elements) against the separate exact backward kernels
+    fused.backward()
+    parts.backward()
+    assert torch.isfinite(x1.grad).all()
+    torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-5, atol=1e-10)
