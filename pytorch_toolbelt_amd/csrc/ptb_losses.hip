@@ -221,8 +221,15 @@ __device__ __forceinline__ float focal_one(float x, float t, bool ig, float cw, 
 
 // Focal contribution of one element with a HARD target from sigmoid(x) = ps and 1 - sigmoid(x) = qs (both already formed,
 // see seg_loss_fwd_reg_kernel): BCE = -log(p_t), 1 - p_t without cancellation.  Same result as focal_one to rounding.
-template <bool G2>
+// PLAIN = gamma 2, no alpha, no reduced threshold, no ignore, no class weights (the default configuration): everything
+// those options cost per element is compiled out.
+template <bool G2, bool PLAIN = false>
 __device__ __forceinline__ float focal_hard(float ps, float qs, bool t, bool ig, float cw, const FocalCfg& c, float& f) {
+    if constexpr (PLAIN) {
+        const float pt = t ? ps : qs, omp = t ? qs : ps;
+        f = omp * omp;
+        return f * (-lg2(pt) * kLn2);
+    }
     const bool tt = t && !ig;
     const float pt = tt ? ps : qs, omp = tt ? qs : ps;
     const float ce = -lg2(pt) * kLn2;
@@ -244,7 +251,7 @@ __device__ __forceinline__ void opaque(float& v) { asm volatile("" : "+v"(v)); }
 // Register-resident variant: C <= CREG, the lane issues the loads of ALL class planes first (CREG x 16 B in flight).
 // WHAT = SEG_FOCAL | SEG_STATS bits (compile time), DENSE = dense fp32 targets instead of int64 labels.
 // SHARE (focal + softmax statistics on hard labels only): one exp per element, see the comment at `share` below.
-template <int PIX, int CREG, int WHAT, bool DENSE, bool G2, bool SHARE = false>
+template <int PIX, int CREG, int WHAT, bool DENSE, bool G2, bool SHARE = false, bool PLAIN = false>
 __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(const SegArgs a) {
     const FocalCfg cfg = focal_cfg(a);
     extern __shared__ float lds[];  // [4 waves][3][C]
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
             if (c < C) {
-                const float cw = (focal && a.class_weights) ? a.class_weights[c] : 1.0f;
+                const float cw = (!PLAIN && focal && a.class_weights) ? a.class_weights[c] : 1.0f;
                 float tv[PIX], lv[PIX];
 #pragma unroll
                 for (int k = 0; k < PIX; ++k) { tv[k] = 0.f; lv[k] = 0.f; }
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
                     if (!G.ok) continue;
                     const float x = xv[c][k];
                     float t;
-                    bool ig = G.ign[k];
+                    bool ig = PLAIN ? false : G.ign[k];
                     if (!DENSE) t = lab[k] == c ? 1.f : 0.f;
                     else { t = tv[k]; if (ignf && t == a.ignore_value) ig = true; }
                     if (focal && share) {
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
                         const float ps = x * r, qs = em[k] * r;
                         const bool hard = t != 0.f;
                         float f;
-                        const float l = focal_hard<G2>(ps, qs, hard, ig, cw, cfg, f);
+                        const float l = focal_hard<G2, PLAIN>(ps, qs, hard, ig, cw, cfg, f);
                         const bool skip = redo_all[k] || (hard && !ig && ps < 1e-36f);
                         redo[k] = redo[k] || skip;
                         lv[k] = skip ? 0.f : l;
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(256) void seg_fused_bwd_kernel(const SegArgs a, con
 // seg_loss_fwd_reg_kernel): u = exp(x - m) replaces the logits in registers, sigmoid(x) = u / (u + em), 1 - sigmoid(x) =
 // em / (u + em) with em = exp(-m); BCE = -log(p_t).  Six transcendentals per element become three.  Pixels with |m| > 60
 // and label elements whose sigmoid underflows are rewritten afterwards from the re-read logits with the exact formulas.
-template <int PIX, int CREG, bool G2>
+template <int PIX, int CREG, bool G2, bool PLAIN = false>
 __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegArgs a, const float* __restrict__ coef,
                                                                       const float* __restrict__ gI, const float* __restrict__ gP,
                                                                       float* __restrict__ grad) {
@@ -843,18 +850,27 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegA
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
             if (c < C) {
-                const float w0 = a.class_weights ? a.class_weights[c] : 1.f;
+                const float w0 = (!PLAIN && a.class_weights) ? a.class_weights[c] : 1.f;
                 float out[PIX];
 #pragma unroll
                 for (int k = 0; k < PIX; ++k) {
                     out[k] = 0.f;
-                    if (!G.ok || G.ign[k]) continue;
+                    if (!G.ok || (!PLAIN && G.ign[k])) continue;
                     const float u = xv[c][k];
                     const bool t = lab[k] == c;
                     const float r = rcp(u + em[k]);
                     const float ps = u * r, qs = em[k] * r;              // sigmoid(x), 1 - sigmoid(x)
                     const float pt = t ? ps : qs, omp = t ? qs : ps;
                     const float ce = -lg2(pt) * kLn2;
+                    if constexpr (PLAIN) {
+                        const float pq = ps * qs;
+                        const float df = -2.0f * omp * (t ? pq : -pq);
+                        float gx = k1 * (df * ce + omp * omp * (t ? -qs : ps)) + k2 * df;
+                        gx += u * inv[k] * ((t ? gI[c] + gP[c] : gP[c]) - dot[k]);
+                        out[k] = gx;
+                        redo[k] = redo[k] || (t && ps < 1e-36f);
+                        continue;
+                    }
                     const float base_ = omp * cfg.sc;
                     const bool below = pt < cfg.thr;
                     float f, pw;
@@ -1123,8 +1139,10 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     } else if (vec && C <= 16) {
 #define PTB_FWD(W, D) do { if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, true>), grid, block, shmem, s, a); \
                            else hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, W, D, false>), grid, block, shmem, s, a); } while (0)
+        const bool plain = g2 && !class_weights && !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
         if (labels && what != SEG_STATS && prob == PROB_SOFTMAX && !(flags & SEG_ELEMWISE)) {
-            if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, true, true>), grid, block, shmem, s, a);
+            if (plain) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, true, true, true>), grid, block, shmem, s, a);
+            else if (g2) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, true, true>), grid, block, shmem, s, a);
             else hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 3, false, false, true>), grid, block, shmem, s, a);
         } else if (labels) { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, false, true>), grid, block, shmem, s, a); else PTB_FWD(3, false); }
         else { if (what == SEG_STATS) hipLaunchKernelGGL((seg_loss_fwd_reg_kernel<4, 16, 2, true, true>), grid, block, shmem, s, a); else PTB_FWD(3, true); }
@@ -1228,7 +1246,9 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
 #define PTB_FUSED(D) do { if (g2) hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, true>), grid, block, 0, s, a, coef, gI, gP, grad); \
                           else hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, false>), grid, block, 0, s, a, coef, gI, gP, grad); } while (0)
     if (labels && prob == PROB_SOFTMAX) {
-        if (g2) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true>), grid, block, 0, s, a, coef, gI, gP, grad);
+        const bool plain = g2 && !class_weights && !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
+        if (plain) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true, true>), grid, block, 0, s, a, coef, gI, gP, grad);
+        else if (g2) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true>), grid, block, 0, s, a, coef, gI, gP, grad);
         else hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, false>), grid, block, 0, s, a, coef, gI, gP, grad);
     } else if (labels) PTB_FUSED(false); else PTB_FUSED(true);
 #undef PTB_FUSED
