@@ -16,6 +16,8 @@
 // they leave the workgroup as one fp64 atomic per (statistic, class).  Streaming + transcendental work: no MFMA.
 #include <initializer_list>
 
+#include <type_traits>
+
 #include "ptb_common.h"
 
 // the losses are tolerance-checked (1e-5), not bit-exact: let the compiler fuse multiply-adds in this file
@@ -956,10 +958,11 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
     for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
         const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, true, a.ignore_label, C, MODE ? nullptr : a.error_flag);
         const long long base = (long long)G.b * C * a.HW + G.i0;
-        float mx[PIX], inv[PIX], loss[PIX], dh[PIX], dd[PIX], gp[PIX];
+        float mx[PIX], inv[PIX], em[PIX], loss[PIX], dh[PIX], dd[PIX], gp[PIX];
         float tsum = 0.f;
+        bool fast = false;
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; inv[k] = 0.f; loss[k] = 0.f; dh[k] = 0.f; dd[k] = 0.f; gp[k] = 1.f; }
+        for (int k = 0; k < PIX; ++k) { mx[k] = -INFINITY; inv[k] = 0.f; em[k] = 1.f; loss[k] = 0.f; dh[k] = 0.f; dd[k] = 0.f; gp[k] = 1.f; }
         if (MODE && grad_pix) load_px<PIX>(grad_pix + (long long)G.b * a.HW + G.i0, gp, G.ok);
         constexpr int NR = CREG > 0 ? CREG : 1;
         float xr[NR][PIX];
@@ -970,16 +973,33 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
                 for (int k = 0; k < PIX; ++k) xr[c][k] = 0.f;
                 if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xr[c], G.ok);
             }
+            // Fast path (wave-uniform): keep u = exp(x - m) in the registers instead of x -- the softmax probability is
+            // u / d, and with em = exp(-m) the sigmoid the BCE term needs is u / (u + em), 1 - sigmoid = em / (u + em), BCE =
+            // -log of one of the two: one exp per element instead of one per element and pass plus a sigmoid.  Needs em and
+            // every u + em inside the fp32 range: |m| <= 60 and x - m >= -80 for all classes, else the wave takes the exact path.
+            bool tame = true;
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
-                float m = -INFINITY;
+                float m = -INFINITY, lo = INFINITY;
 #pragma unroll
-                for (int c = 0; c < CREG; ++c) if (c < C) m = fmaxf(m, xr[c][k]);
+                for (int c = 0; c < CREG; ++c) if (c < C) { m = fmaxf(m, xr[c][k]); lo = fminf(lo, xr[c][k]); }
+                mx[k] = m;
+                tame = tame && (fabsf(m) <= 60.f) && (lo - m >= -80.f);
+            }
+            fast = !__any(!tame);
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                const float m = mx[k];
                 float d = 0.f;
 #pragma unroll
-                for (int c = 0; c < CREG; ++c) if (c < C) d += fexp(xr[c][k] - m);
-                mx[k] = m; inv[k] = rcp(d);
-                opaque(mx[k]);  // recompute exp(x - m) per pass instead of keeping 64 values alive
+                for (int c = 0; c < CREG; ++c) if (c < C) {
+                    const float u = fexp(xr[c][k] - m);
+                    d += u;
+                    if (fast) xr[c][k] = u;
+                }
+                inv[k] = rcp(d);
+                em[k] = fexp(-m);
+                if (!fast) opaque(mx[k]);  // exact path: recompute exp(x - m) per pass instead of keeping 64 values alive
             }
         } else {
             for (int c = 0; c < C; ++c) {
@@ -996,17 +1016,25 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
             for (int k = 0; k < PIX; ++k) inv[k] = rcp(inv[k]);
         }
         // pass 1: losses (forward) or the two softmax-Jacobian dot products (backward)
-        auto pass1 = [&](int c, const float (&xv)[PIX]) {
+        auto pass1 = [&](int c, const float (&xv)[PIX], auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
             const float w = a.class_weights ? a.class_weights[c] : 1.f;
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
                 if (!G.ok) continue;
                 const long long tgt = G.ign[k] ? 0 : G.lab[k];   // masked_fill(target, ignore, 0), functional.py:139
-                const float x = xv[k];
-                const float p = fexp(x - mx[k]) * inv[k];
+                const float x = xv[k];                            // FAST: u = exp(logit - m)
                 const float t = c == tgt ? 1.f : 0.f;
+                float p, bce;
+                if constexpr (FAST) {
+                    p = x * inv[k];
+                    const float r = rcp(x + em[k]);
+                    bce = -lg2((c == tgt ? x : em[k]) * r) * kLn2;
+                } else {
+                    p = fexp(x - mx[k]) * inv[k];
+                    bce = fmaxf(x, 0.f) - x * t + sigmoid_parts(x).log1pe;
+                }
                 const float pt = (1.f - t) * p + t * (1.f - p);
-                const float bce = fmaxf(x, 0.f) - x * t + sigmoid_parts(x).log1pe;
                 if (MODE == 0) {
                     const float f = smf_term<G2>(pt, a, sc, thr);
                     loss[k] += f * bce * w;
@@ -1019,13 +1047,18 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
             }
         };
         if constexpr (CREG > 0) {
+            if (fast) {
 #pragma unroll
-            for (int c = 0; c < CREG; ++c) if (c < C) pass1(c, xr[c]);
+                for (int c = 0; c < CREG; ++c) if (c < C) pass1(c, xr[c], std::true_type{});
+            } else {
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) if (c < C) pass1(c, xr[c], std::false_type{});
+            }
         } else {
             for (int c = 0; c < C; ++c) {
                 float xv[PIX];
                 load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
-                pass1(c, xv);
+                pass1(c, xv, std::false_type{});
             }
         }
         if (MODE == 0) {
@@ -1039,9 +1072,12 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
             s_term += (double)tsum;
             if (a.pixel_out) store_px<PIX>(a.pixel_out + (long long)G.b * a.HW + G.i0, loss, G.ok);
         } else {
+            if (!fast) {
 #pragma unroll
-            for (int k = 0; k < PIX; ++k) { opaque(mx[k]); opaque(inv[k]); }  // pass 2 recomputes p, bce, df
-            auto pass2 = [&](int c, const float (&xv)[PIX]) {
+                for (int k = 0; k < PIX; ++k) { opaque(mx[k]); opaque(inv[k]); }  // pass 2 recomputes p, bce, df
+            }
+            auto pass2 = [&](int c, const float (&xv)[PIX], auto fast_tag) {
+                constexpr bool FAST = decltype(fast_tag)::value;
                 const float w = a.class_weights ? a.class_weights[c] : 1.f;
                 float out[PIX];
 #pragma unroll
@@ -1049,29 +1085,44 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
                     out[k] = 0.f;
                     if (!G.ok) continue;
                     const long long tgt = G.ign[k] ? 0 : G.lab[k];
-                    const float x = xv[k];
-                    const float p = fexp(x - mx[k]) * inv[k];
+                    const float x = xv[k];                        // FAST: u = exp(logit - m)
                     const float t = c == tgt ? 1.f : 0.f;
+                    float p, bce, sig_minus_t;
+                    if constexpr (FAST) {
+                        p = x * inv[k];
+                        const float r = rcp(x + em[k]);
+                        const float ps = x * r, qs = em[k] * r;
+                        bce = -lg2(c == tgt ? ps : qs) * kLn2;
+                        sig_minus_t = c == tgt ? -qs : ps;
+                    } else {
+                        p = fexp(x - mx[k]) * inv[k];
+                        const Sig sg = sigmoid_parts(x);
+                        bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
+                        sig_minus_t = sg.p - t;
+                    }
                     const float pt = (1.f - t) * p + t * (1.f - p);
-                    const Sig sg = sigmoid_parts(x);
-                    const float bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
                     const float df = smf_dterm<G2>(pt, t, a, sc, thr);
                     const float f = smf_term<G2>(pt, a, sc, thr);
                     const float g1 = G.ign[k] ? 0.f : (grad_pix ? k1 * gp[k] : k1);
-                    const float gl = p * (w * bce * df - dh[k]) + w * f * (sg.p - t);
+                    const float gl = p * (w * bce * df - dh[k]) + w * f * sig_minus_t;
                     const float gf = p * (df - dd[k]);
                     out[k] = g1 * gl + k2 * gf;
                 }
                 store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             };
             if constexpr (CREG > 0) {
+                if (fast) {
 #pragma unroll
-                for (int c = 0; c < CREG; ++c) if (c < C) pass2(c, xr[c]);
+                    for (int c = 0; c < CREG; ++c) if (c < C) pass2(c, xr[c], std::true_type{});
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CREG; ++c) if (c < C) pass2(c, xr[c], std::false_type{});
+                }
             } else {
                 for (int c = 0; c < C; ++c) {
                     float xv[PIX];
                     load_px<PIX>(a.logits + base + (long long)c * a.HW, xv, G.ok);
-                    pass2(c, xv);
+                    pass2(c, xv, std::false_type{});
                 }
             }
         }

@@ -429,3 +429,37 @@ def test_fused_forward_shared_exp_and_extreme_logits(kw, dev):
     parts.backward()
     assert torch.isfinite(x1.grad).all()
     torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-5, atol=1e-10)
+
+
+def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev):
+    """softmax_focal_kernel keeps u = exp(x - m) in registers and derives the BCE term's sigmoid from it (wave-uniform fast
+    path); waves holding a pixel with |max| > 60 or a logit 80 below the maximum take the exact path.  Both against an fp64
+    torch restatement of functional.py:110-173, values and gradients, on a map that mixes tame and extreme pixels."""
+    L = _L()
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W = 2, 16, 16, 64                   # one wave = 256 pixels = 4 rows: rows 0-3 of image 0 extreme, the rest tame
+    x = torch.randn((B, C, H, W), generator=g) * 3
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    x[0, :, 0] += 75.0
+    x[0, :, 1] -= 70.0
+    x[0, 5, 2] = -120.0
+    lab[0, 2, :8] = 5
+    lab[1, 3, :5] = -100
+    for kw in (dict(), dict(gamma=1.5), dict(reduced_threshold=0.5)):
+        x1 = x.to(dev).requires_grad_(True)
+        out = L.softmax_focal_loss_with_logits(x1, lab.to(dev), reduction="none", **kw)
+        x2 = x.double().requires_grad_(True)
+        valid = lab != -100
+        oh = torch.nn.functional.one_hot(lab.masked_fill(~valid, 0), C).permute(0, 3, 1, 2).double()
+        p = torch.softmax(x2, 1)
+        pt = (1 - oh) * p + oh * (1 - p)
+        thr = kw.get("reduced_threshold")
+        f = pt.pow(kw.get("gamma", 2.0)) if thr is None else torch.where(pt < thr, torch.ones_like(pt), (pt / thr).pow(kw.get("gamma", 2.0)))
+        ref = (f * torch.nn.functional.binary_cross_entropy_with_logits(x2, oh, reduction="none")).sum(1) * valid
+        assert torch.isfinite(out).all()
+        torch.testing.assert_close(out.cpu().double(), ref, rtol=2e-5, atol=1e-5)
+        w = torch.rand(ref.shape, generator=g).double()
+        (out * w.float().to(dev)).sum().backward()
+        (ref * w).sum().backward()
+        assert torch.isfinite(x1.grad).all()
+        torch.testing.assert_close(x1.grad.cpu().double(), x2.grad, rtol=2e-4, atol=2e-6)
