@@ -263,6 +263,18 @@ int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, const float* d
                       int prob, float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
                       ptb_stream_t stream);
 
+/* Scalar tail of DiceLoss (losses/dice.py:112-131), JaccardLoss (losses/jaccard.py:95-113) and their weighted sum with a
+ * mean focal loss, together with its derivative, from the slot sums a ptb_seg_loss_fwd call produced:
+ *   loss[0] = focal_scale * sum_focal + dice_weight * mean_c dice_loss_c + jaccard_weight * mean_c jaccard_loss_c
+ *   score_c = (2 I + smooth) / max(P + T + smooth, eps)  |  (I + smooth) / max(P + T - I + smooth, eps);
+ *   loss_c = [T_c > 0] * (log_loss ? -log(max(score_c, eps)) : 1 - score_c); the mean runs over the n_selected classes with
+ *   class_mask[c] != 0 (class_mask NULL: all C).  fp32 arithmetic on the fp64 sums rounded to fp32, like the reference.
+ * coef DEVICE float[2 + 2C] receives d loss / d (focal loss sum, focal term sum, I[C], P[C]) -- the arrays
+ * ptb_focal_bwd / ptb_seg_stats_bwd / ptb_seg_fused_bwd take (after scaling by the upstream gradient). */
+int ptb_region_epilogue(const double* sums, int slots, int C, float focal_scale, float dice_weight, float jaccard_weight,
+                        float smooth, float eps, int log_loss, const uint8_t* class_mask, int n_selected, float* loss,
+                        float* coef, ptb_stream_t stream);
+
 /* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
  * sums double[PTB_SUM_SLOTS][2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
 int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,

@@ -1130,6 +1130,93 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
     if (MODE == 0) block_add2(s_loss, s_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * 2, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------ scalar epilogue
+// The [C]-sized tail of DiceLoss / JaccardLoss / the fused focal+Dice+Jaccard loss (dice.py:112-131, jaccard.py:95-113) AND
+// its derivative in one launch: as torch ops the tail is ~25 launches forward and ~40 in autograd's backward, more than the
+// streaming kernels they follow.  One workgroup; fp32 arithmetic in the reference's order (the statistics arrive as fp64
+// slot sums and are rounded to fp32 first, like `.float()`).
+struct EpiArgs {
+    const double* sums;   // [slots][2 + 3C]
+    int slots, C;
+    float focal_scale, dice_w, jacc_w, smooth, eps;
+    int log_loss;
+    const unsigned char* class_mask;  // [C] or null: classes that enter the mean
+    int n_selected;
+    float* loss;          // [1]
+    float* coef;          // [2 + 2C]: d loss / d (focal loss sum, focal term sum, I[C], P[C])
+};
+
+__device__ __forceinline__ void score_loss(float score, bool active, int log_loss, float eps, float& loss, float& dscore) {
+    if (log_loss) {
+        const float cl = fmaxf(score, eps);
+        loss = -logf(cl);
+        dscore = score >= eps ? -1.0f / cl : 0.f;
+    } else {
+        loss = 1.0f - score;
+        dscore = -1.0f;
+    }
+    if (!active) { loss = 0.f; dscore = 0.f; }
+}
+
+__global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
+    __shared__ double red[2][256];
+    const int C = a.C, row = 2 + 3 * C;
+    double dsum = 0.0, jsum = 0.0;
+    const float inv_n = 1.0f / (float)a.n_selected;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double dI = 0.0, dP = 0.0, dT = 0.0;
+        for (int sl = 0; sl < a.slots; ++sl) {
+            const double* r = a.sums + (size_t)sl * row;
+            dI += r[2 + c]; dP += r[2 + C + c]; dT += r[2 + 2 * C + c];
+        }
+        const float I = (float)dI, P = (float)dP, T = (float)dT;
+        const bool sel = !a.class_mask || a.class_mask[c];
+        const bool active = T > 0.f;
+        float gI = 0.f, gP = 0.f;
+        if (a.dice_w != 0.f) {
+            const float num = 2.0f * I + a.smooth, card = P + T + a.smooth, den = fmaxf(card, a.eps);
+            const float score = num / den;
+            float l, ds;
+            score_loss(score, active, a.log_loss, a.eps, l, ds);
+            if (sel) {
+                dsum += (double)l;
+                gI += a.dice_w * ds * (2.0f / den);
+                gP += a.dice_w * ds * (card >= a.eps ? -num / (den * den) : 0.f);
+            }
+        }
+        if (a.jacc_w != 0.f) {
+            const float num = I + a.smooth, uni = P + T - I + a.smooth, den = fmaxf(uni, a.eps);
+            const float score = num / den;
+            float l, ds;
+            score_loss(score, active, a.log_loss, a.eps, l, ds);
+            if (sel) {
+                jsum += (double)l;
+                const float dden = uni >= a.eps ? num / (den * den) : 0.f;
+                gI += a.jacc_w * ds * (1.0f / den + dden);
+                gP += a.jacc_w * ds * (-dden);
+            }
+        }
+        a.coef[2 + c] = gI * inv_n;
+        a.coef[2 + C + c] = gP * inv_n;
+    }
+    red[0][threadIdx.x] = dsum; red[1][threadIdx.x] = jsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double f = 0.0;
+        for (int sl = 0; sl < a.slots; ++sl) f += a.sums[(size_t)sl * row];
+        const float focal = a.focal_scale != 0.f ? a.focal_scale * (float)f : 0.f;
+        const float dice = a.dice_w != 0.f ? a.dice_w * ((float)red[0][0] * inv_n) : 0.f;
+        const float jacc = a.jacc_w != 0.f ? a.jacc_w * ((float)red[1][0] * inv_n) : 0.f;
+        a.loss[0] = focal + dice + jacc;
+        a.coef[0] = a.focal_scale;
+        a.coef[1] = 0.f;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
 // Measured on MI355X (tools/ab_losses.py): the streaming kernels (focal fwd/bwd, softmax focal) gain ~10 % from an
@@ -1303,5 +1390,14 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
         else hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, false>), grid, block, 0, s, a, coef, gI, gP, grad);
     } else if (labels) PTB_FUSED(false); else PTB_FUSED(true);
 #undef PTB_FUSED
+    return check_launch();
+}
+
+extern "C" int ptb_region_epilogue(const double* sums, int slots, int C, float focal_scale, float dice_weight, float jaccard_weight,
+                                   float smooth, float eps, int log_loss, const uint8_t* class_mask, int n_selected, float* loss,
+                                   float* coef, ptb_stream_t stream) {
+    if (!sums || !loss || !coef || slots < 1 || C < 1 || n_selected < 1 || n_selected > C) return PTB_EINVAL;
+    EpiArgs a{sums, slots, C, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected, loss, coef};
+    hipLaunchKernelGGL(region_epilogue_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }

@@ -260,3 +260,70 @@ class FusedSegSums(torch.autograd.Function):
             N.check(rc, "ptb_seg_stats_bwd")
         N.bump()
         return grad.add_(grad2), None, None, None, None, None, None, None, None, None, None
+
+
+class RegionLoss(torch.autograd.Function):
+    """Dice / Jaccard / (mean sigmoid focal + Dice + Jaccard) as ONE differentiable scalar: the streaming kernel that
+    produces the sums, then ``ptb_region_epilogue`` for the [C]-sized tail and its derivative (two launches forward, one
+    multiply + one streaming kernel backward -- as torch ops the tail alone is ~65 launches per forward / backward pair)."""
+
+    @staticmethod
+    def forward(ctx, x, labels, dense, class_weights, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value,
+                with_focal, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected):
+        B, C, HW = x.shape
+        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        coef = torch.empty(2 + 2 * C, dtype=torch.float32, device=x.device)
+        what = SEG_STATS | (SEG_FOCAL if with_focal else 0)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), sums.data_ptr(), None,
+                                      flag.data_ptr(), B, C, HW, flags | what, prob, gamma, alpha, threshold, ignore_label, ignore_value,
+                                      N.stream_ptr(x.device))
+            N.check(rc, "ptb_seg_loss_fwd")
+            rc = lib.ptb_region_epilogue(sums.data_ptr(), SUM_SLOTS, C, focal_scale if with_focal else 0.0, dice_weight, jaccard_weight,
+                                         smooth, eps, 1 if log_loss else 0, _ptr(class_mask), n_selected, loss.data_ptr(),
+                                         coef.data_ptr(), N.stream_ptr(x.device))
+            N.check(rc, "ptb_region_epilogue")
+        N.bump()
+        if labels is not None:
+            check_labels(flag)
+        ctx.save_for_backward(x, labels, dense, class_weights, coef)
+        ctx.cfg = (flags, prob, gamma, alpha, threshold, ignore_label, ignore_value, with_focal)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        x, labels, dense, class_weights, coef = ctx.saved_tensors
+        flags, prob, gamma, alpha, threshold, ignore_label, ignore_value, with_focal = ctx.cfg
+        B, C, HW = x.shape
+        k = coef * g.to(torch.float32)          # upstream gradient folded into the coefficient arrays (device side)
+        kf, gi, gp = k[:2], k[2:2 + C], k[2 + C:]
+        grad = torch.empty_like(x)
+        lib = N.load()
+        none = (None,) * 19
+        with N.on_device(x.device):
+            if with_focal:
+                rc = lib.ptb_seg_fused_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), kf.data_ptr(), gi.data_ptr(),
+                                           gp.data_ptr(), grad.data_ptr(), B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label,
+                                           ignore_value, N.stream_ptr(x.device))
+                if rc == -2:   # the fused kernel does not apply (C > 16, unaligned, ...): two kernels and an add
+                    grad2 = torch.empty_like(x)
+                    rc = lib.ptb_focal_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), kf.data_ptr(), None, grad.data_ptr(),
+                                           B, C, HW, flags, gamma, alpha, threshold, ignore_label, ignore_value, N.stream_ptr(x.device))
+                    N.check(rc, "ptb_focal_bwd")
+                    rc = lib.ptb_seg_stats_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), gi.data_ptr(), gp.data_ptr(), grad2.data_ptr(),
+                                               B, C, HW, SEG_STATS | (flags & SEG_HAS_IGNORE), prob, ignore_label, ignore_value,
+                                               N.stream_ptr(x.device))
+                    N.check(rc, "ptb_seg_stats_bwd")
+                    grad.add_(grad2)
+                else:
+                    N.check(rc, "ptb_seg_fused_bwd")
+            else:
+                rc = lib.ptb_seg_stats_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), gi.data_ptr(), gp.data_ptr(), grad.data_ptr(),
+                                           B, C, HW, SEG_STATS | (flags & SEG_HAS_IGNORE), prob, ignore_label, ignore_value,
+                                           N.stream_ptr(x.device))
+                N.check(rc, "ptb_seg_stats_bwd")
+        N.bump()
+        return (grad,) + none

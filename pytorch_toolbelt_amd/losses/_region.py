@@ -50,3 +50,55 @@ def finish(scores, true_mass, log_loss, eps, classes):
     if classes is not None:
         loss = loss[classes.to(loss.device)]
     return loss.mean()
+
+
+def _inputs(y_pred, y_true, mode, from_logits, ignore_index):
+    """(x [B, C, HW], labels | None, dense | None, prob, has_ignore, ignore_label, ignore_value) for the kernels."""
+    assert y_true.size(0) == y_pred.size(0)
+    bs = y_true.size(0)
+    x = K._f32c(y_pred, "region loss")
+    has_ign = ignore_index is not None
+    if mode == MULTICLASS_MODE:
+        x = x.reshape(bs, x.size(1), -1)
+        labels = y_true.to(device=x.device).reshape(bs, -1)
+        if labels.dtype != torch.int64:
+            labels = labels.long()
+        labels = labels.contiguous()
+        if labels.size(1) != x.size(2):
+            raise RuntimeError(f"target shape {tuple(y_true.shape)} does not match prediction shape {tuple(y_pred.shape)}")
+        return x, labels, None, (K.PROB_SOFTMAX if from_logits else K.PROB_IDENTITY), has_ign, int(ignore_index) if has_ign else 0, 0.0
+    C = 1 if mode == BINARY_MODE else x.size(1)
+    x = x.reshape(bs, C, -1)
+    dense = K._f32c(y_true.to(device=x.device), "region loss").reshape(bs, C, -1)
+    return x, None, dense, (K.PROB_SIGMOID if from_logits else K.PROB_IDENTITY), has_ign, 0, float(ignore_index) if has_ign else 0.0
+
+
+def fused_region_loss(y_pred, y_true, mode, from_logits, ignore_index, dice_weight, jaccard_weight, smooth, eps, log_loss, classes,
+                      focal=None):
+    """The whole loss as one autograd node (kernel + scalar-epilogue kernel), or None when the statistics have to be
+    all-reduced over ranks first (``parallel.sync_region_statistics``) -- the caller then composes the torch tail.
+
+    ``focal`` = None or dict(weight, gamma, alpha): adds ``weight * mean sigmoid focal loss`` from the same pass."""
+    from ..parallel import sync_region_statistics
+
+    if sync_region_statistics._active is not None:
+        return None
+    x, labels, dense, prob, has_ign, ign_label, ign_value = _inputs(y_pred, y_true, mode, from_logits, ignore_index)
+    C = x.size(1)
+    mask, n_sel = None, C
+    if classes is not None:
+        mask = torch.zeros(C, dtype=torch.uint8)
+        mask[classes.cpu()] = 1
+        n_sel = int(classes.numel())            # (the reference indexes loss[classes]: duplicates would count twice)
+        if int(mask.sum()) != n_sel:
+            return None
+        mask = mask.to(x.device)
+    flags = K.SEG_HAS_IGNORE if has_ign else 0
+    gamma = alpha = 0.0
+    scale = 0.0
+    if focal is not None:
+        flags |= K.SEG_HAS_ALPHA if focal["alpha"] is not None else 0
+        gamma, alpha = float(focal["gamma"]), float(focal["alpha"] or 0.0)
+        scale = float(focal["weight"]) / x.numel()
+    return K.RegionLoss.apply(x, labels, dense, None, flags, prob, gamma, alpha, 0.0, ign_label, ign_value, focal is not None, scale,
+                              float(dice_weight), float(jaccard_weight), float(smooth), float(eps), bool(log_loss), mask, n_sel)

@@ -33,6 +33,10 @@ class DiceLoss(_Loss):
         self.log_loss = log_loss
 
     def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        loss = R.fused_region_loss(y_pred, y_true, self.mode, self.from_logits, self.ignore_index, 1.0, 0.0, self.smooth, self.eps,
+                                   self.log_loss, self.classes)
+        if loss is not None:
+            return loss
         inter, pred_mass, true_mass = R.region_statistics(y_pred, y_true, self.mode, self.from_logits, self.ignore_index)
         scores = (2.0 * inter + self.smooth) / (pred_mass + true_mass + self.smooth).clamp_min(self.eps)
         return R.finish(scores, true_mass, self.log_loss, self.eps, self.classes)

@@ -29,6 +29,11 @@ class FocalDiceJaccardLoss(nn.Module):
         self.weights = (focal_weight, dice_weight, jaccard_weight)
 
     def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        wf, wd, wj = self.weights
+        loss = R.fused_region_loss(y_pred, y_true, self.mode, True, self.ignore_index, wd, wj, self.smooth, self.eps, self.log_loss, None,
+                                   focal=dict(weight=wf, gamma=self.gamma, alpha=self.alpha))
+        if loss is not None:
+            return loss
         bs = y_pred.size(0)
         x = K._f32c(y_pred, "fused loss")
         flags = (K.SEG_HAS_ALPHA if self.alpha is not None else 0) | (K.SEG_HAS_IGNORE if self.ignore_index is not None else 0)

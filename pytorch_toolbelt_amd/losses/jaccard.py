@@ -28,6 +28,10 @@ class JaccardLoss(_Loss):
         self.log_loss = log_loss
 
     def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        loss = R.fused_region_loss(y_pred, y_true, self.mode, self.from_logits, None, 0.0, 1.0, self.smooth, self.eps, self.log_loss,
+                                   self.classes)
+        if loss is not None:
+            return loss
         inter, pred_mass, true_mass = R.region_statistics(y_pred, y_true, self.mode, self.from_logits, None)
         union = pred_mass + true_mass - inter
         scores = (inter + self.smooth) / (union + self.smooth).clamp_min(self.eps)
