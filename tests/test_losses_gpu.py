@@ -463,3 +463,56 @@ def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev):
         (ref * w).sum().backward()
         assert torch.isfinite(x1.grad).all()
         torch.testing.assert_close(x1.grad.cpu().double(), x2.grad, rtol=2e-4, atol=2e-6)
+
+
+class _TwoRankEcho:
+    """torch.distributed stand-in: a 2-rank world in which the other rank holds the same shard (all_reduce doubles)."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    @staticmethod
+    def is_available():
+        return True
+
+    @staticmethod
+    def is_initialized():
+        return True
+
+    @staticmethod
+    def get_world_size(group=None):
+        return 2
+
+    @staticmethod
+    def all_reduce(t, op=None, group=None):
+        t.mul_(2.0)
+
+
+@pytest.mark.parametrize("kind", ["dice", "jaccard", "fused"])
+@pytest.mark.parametrize("log_loss,smooth", [(False, 0.0), (True, 1.0)])
+def test_epilogue_kernel_equals_the_torch_tail_and_the_synchronised_path(kind, log_loss, smooth, dev):
+    """The loss as ONE autograd node (streaming kernel + ptb_region_epilogue) against the same modules inside
+    ``sync_region_statistics`` -- there the statistics leave as tensors and the tail is torch ops under autograd.  With the
+    echo world the synchronised statistics are those of the batch repeated twice, so both paths are evaluated on [x; x]."""
+    from pytorch_toolbelt_amd.parallel import sync_region_statistics
+
+    L = _L()
+    logits, labels = _cfg4_like(B=3, C=16, H=48, W=64)
+    xl, ll = logits.to(dev), labels.to(dev)
+    if kind == "dice":
+        crit = L.DiceLoss("multiclass", log_loss=log_loss, smooth=smooth, classes=[0, 3, 5, 9] if log_loss else None)
+    elif kind == "jaccard":
+        crit = L.JaccardLoss("multiclass", log_loss=log_loss, smooth=smooth)
+    else:
+        crit = L.FocalDiceJaccardLoss("multiclass", dice_weight=0.7, jaccard_weight=1.3, focal_weight=0.0, log_loss=log_loss, smooth=smooth)
+    x1 = torch.cat([xl, xl]).requires_grad_(True)
+    one_node = crit(x1, torch.cat([ll, ll]))
+    x2 = xl.clone().requires_grad_(True)
+    with sync_region_statistics(dist=_TwoRankEcho):
+        synced = crit(x2, ll)
+    torch.testing.assert_close(one_node, synced, rtol=2e-6, atol=1e-6)
+    one_node.backward()
+    synced.backward()
+    # every rank back-propagates the global loss and the backward all-reduce doubles again: d/dx2 = 2 * d/dx1[:B]
+    torch.testing.assert_close(2.0 * x1.grad[:3], x2.grad, rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(x1.grad[:3], x1.grad[3:], rtol=0, atol=0)
