@@ -81,23 +81,27 @@ def main():
         for _ in range(5):
             step()
         torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        e0.record()
+        # three timed blocks, the fastest counts: a dev box shows rare 30-70 ms host stalls (allocator / other tenants) that
+        # have nothing to do with the rank being played
+        devms, host = float("inf"), float("inf")
         per = []
-        for _ in range(args.steps):
-            t1 = time.perf_counter()
-            step()
-            per.append((time.perf_counter() - t1) * 1e3)
-        e1.record()
-        host = (time.perf_counter() - t0) / args.steps * 1e3
-        torch.cuda.synchronize()
-        devms = e0.elapsed_time(e1) / args.steps
+        for _blk in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(args.steps):
+                t1 = time.perf_counter()
+                step()
+                per.append((time.perf_counter() - t1) * 1e3)
+            e1.record()
+            host = min(host, (time.perf_counter() - t0) / args.steps * 1e3)
+            torch.cuda.synchronize()
+            devms = min(devms, e0.elapsed_time(e1) / args.steps)
         worst = max(worst, devms)
         halo = sum((r1 - r0) * (c1 - c0) * C * 4 for _d, r0, r1, c0, c1 in m.sends) / 1e6
         print(f"rank {r}/{args.world} [{args.partition}]: {len(crops)} tiles, {len(batches)} launches, boundary tiles {len(m.plan[r]['boundary'])}, "
               f"owned rows {m.owned_rows}, halo out {halo:.1f} MB: {devms:.3f} ms per image (host issue {host:.3f} ms; "
-              f"median {sorted(per)[len(per) // 2]:.3f}, max {max(per):.3f} at step {int(np.argmax(per))})")
+              f"median step {sorted(per)[len(per) // 2]:.3f}, worst step {max(per):.3f})")
         del m, outs
     print(f"slowest rank {worst:.3f} ms per image -> {25.0 / worst * 1e3:.0f} MP/s if the exchange hides completely")
 
