@@ -317,6 +317,7 @@ def test_softmax_focal_and_lovasz_gradients(dev):
         torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-7)
     # Lovasz: gradient equals the Lovasz gradient at each pixel's rank times d(error)/d(pred); check against the
     # directional finite difference of the (piecewise linear) loss
+    torch.manual_seed(1234)    # the directions of the finite differences below (randn_like on the device generator)
     probs = torch.softmax(x, 1).clone().requires_grad_(True)
     lab2 = lab.masked_fill(lab == -100, 0)
     loss = L.LovaszLoss()(probs, lab2)

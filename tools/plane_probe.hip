@@ -1,0 +1,85 @@
+// plane_probe.hip -- what does the class-plane walk of the loss kernels cost by itself?  A wave owns 256 consecutive
+// pixels (lane = 4 pixels) and reads the 16 class planes of image b ([B, 16, HW] fp32, plane stride HW) plus 8 B of label
+// per pixel, adds everything up and writes nothing: the access pattern of focal / statistics / soft-CE forward without
+// their arithmetic.  Variants: planes issued all at once or in two halves, non-temporal or default loads, grid size.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/plane_probe.hip -o tools/build/plane_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <bool NT, int SPLIT, int EXTRA_ALU>
+__global__ __launch_bounds__(256) void plane_kernel(const float* __restrict__ x, const long long* __restrict__ lab, float* sink,
+                                                    int B, long long HW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long per_img = HW / 256, groups = per_img * B;
+    float acc = 0.f;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const int b = (int)(g / per_img);
+        const long long i0 = (g - (long long)b * per_img) * 256 + lane * 4;
+        const float* p = x + (long long)b * 16 * HW + i0;
+        const longlong2 l0 = *reinterpret_cast<const longlong2*>(lab + (long long)b * HW + i0);
+        const longlong2 l1 = *reinterpret_cast<const longlong2*>(lab + (long long)b * HW + i0 + 2);
+        v4f v[16];
+#pragma unroll
+        for (int h = 0; h < SPLIT; ++h) {
+#pragma unroll
+            for (int c = h * (16 / SPLIT); c < (h + 1) * (16 / SPLIT); ++c)
+                v[c] = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + c * HW)) : *reinterpret_cast<const v4f*>(p + c * HW);
+#pragma unroll
+            for (int c = h * (16 / SPLIT); c < (h + 1) * (16 / SPLIT); ++c) {
+                v4f t = v[c];
+#pragma unroll
+                for (int e = 0; e < EXTRA_ALU; ++e) { t.x = __builtin_amdgcn_exp2f(t.x); t.y = __builtin_amdgcn_exp2f(t.y); t.z = __builtin_amdgcn_exp2f(t.z); t.w = __builtin_amdgcn_exp2f(t.w); }
+                acc += t.x + t.y + t.z + t.w;
+            }
+        }
+        acc += (float)(l0.x + l0.y + l1.x + l1.y);
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+template <typename K>
+static void run(const char* name, K kern, int grid, const float* x, const long long* lab, float* sink, int B, long long HW, int shmem = 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, 0, x, lab, sink, B, HW);
+    CK(hipEventRecord(e0));
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, 0, x, lab, sink, B, HW);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)B * HW * (16 * 4 + 8);
+    printf("%-52s grid %6d lds %6d: %7.1f us  %7.1f GB/s\n", name, grid, shmem, ms / reps * 1e3, bytes / (ms / reps * 1e-3) / 1e9);
+}
+
+int main() {
+    const int B = 32;
+    const long long HW = 512 * 512;
+    float* x; long long* lab; float* sink;
+    CK(hipMalloc(&x, (size_t)B * 16 * HW * 4)); CK(hipMalloc(&lab, (size_t)B * HW * 8)); CK(hipMalloc(&sink, 64));
+    CK(hipMemset(x, 0, (size_t)B * 16 * HW * 4)); CK(hipMemset(lab, 0, (size_t)B * HW * 8));
+    const long long groups = HW / 256 * B;
+    for (int grid : {256 * 8, 256 * 16, 256 * 32, (int)(groups / 4)}) {
+        run("16 planes at once, nt", plane_kernel<true, 1, 0>, grid, x, lab, sink, B, HW);
+        run("16 planes at once, default loads", plane_kernel<false, 1, 0>, grid, x, lab, sink, B, HW);
+        run("2 x 8 planes, nt", plane_kernel<true, 2, 0>, grid, x, lab, sink, B, HW);
+        run("4 x 4 planes, nt", plane_kernel<true, 4, 0>, grid, x, lab, sink, B, HW);
+        run("16 planes at once, nt, + 1 exp per element", plane_kernel<true, 1, 1>, grid, x, lab, sink, B, HW);
+        run("16 planes at once, nt, + 3 exp per element", plane_kernel<true, 1, 3>, grid, x, lab, sink, B, HW);
+    }
+    // occupancy: dynamic LDS caps the resident workgroups per CU (4 waves each): 160 KB / lds
+    for (int lds : {0, 20 * 1024, 32 * 1024, 40 * 1024, 53 * 1024, 80 * 1024, 160 * 1024}) {
+        if (lds > 64 * 1024) {
+            CK(hipFuncSetAttribute((const void*)plane_kernel<true, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            CK(hipFuncSetAttribute((const void*)plane_kernel<true, 1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        }
+        run("occupancy sweep: 16 planes, nt", plane_kernel<true, 1, 0>, 256 * 8, x, lab, sink, B, HW, lds);
+        run("occupancy sweep: 16 planes, nt, + 3 exp", plane_kernel<true, 1, 3>, 256 * 8, x, lab, sink, B, HW, lds);
+    }
+    return 0;
+}
