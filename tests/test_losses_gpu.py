@@ -517,3 +517,49 @@ def test_epilogue_kernel_equals_the_torch_tail_and_the_synchronised_path(kind, l
     # every rank back-propagates the global loss and the backward all-reduce doubles again: d/dx2 = 2 * d/dx1[:B]
     torch.testing.assert_close(2.0 * x1.grad[:3], x2.grad, rtol=2e-5, atol=1e-9)
     torch.testing.assert_close(x1.grad[:3], x1.grad[3:], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("C", [2, 3, 5, 8, 11, 16])
+@pytest.mark.parametrize("ignore_index", [None, 0, 255])
+def test_straight_line_forward_kernels_against_oracle_and_generic_kernels(C, ignore_index, dev):
+    """seg_fwd_lean_kernel (hard labels, C <= 16 padded to 4 / 8 / 16, HW % 256 == 0): Dice from logits and from
+    probabilities, with and without ignore_index, and the fused focal + Dice + Jaccard loss -- against the fp64 oracle and
+    against the generic kernels (ptb_set_tunable(1, 1) switches the straight-line and vector paths off)."""
+    from pytorch_toolbelt_amd import _native as N
+
+    L = _L()
+    g = torch.Generator().manual_seed(100 + C)
+    B, H, W = 3, 32, 40                        # HW = 1280 = 5 x 256
+    logits = torch.randn((B, C, H, W), generator=g) * 2.5
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    if ignore_index == 255:
+        labels[0, :5] = 255
+    labels[1, 7:9] = 1
+    xl, ll = logits.to(dev), labels.to(dev)
+    probs = torch.softmax(logits, 1)
+    x64, l64 = logits.numpy(), labels.numpy()
+    lib = N.load()
+    results = []
+    for scalar in (0, 1):
+        lib.ptb_set_tunable(1, scalar)
+        try:
+            d_log = float(L.DiceLoss("multiclass", ignore_index=ignore_index, smooth=0.5)(xl, ll))
+            d_prob = float(L.DiceLoss("multiclass", from_logits=False, ignore_index=ignore_index)(probs.to(dev), ll))
+            fused = float(L.FocalDiceJaccardLoss("multiclass")(xl, ll.clamp(max=C - 1))) if ignore_index is None else 0.0
+        finally:
+            lib.ptb_set_tunable(1, 0)
+        results.append((d_log, d_prob, fused))
+    assert results[0] == pytest.approx(results[1], rel=2e-6, abs=1e-6)
+    assert results[0][0] == pytest.approx(LO.dice_loss(x64, l64, "multiclass", ignore_index=ignore_index, smooth=0.5), abs=1e-5)
+    assert results[0][1] == pytest.approx(LO.dice_loss(probs.numpy(), l64, "multiclass", from_logits=False, ignore_index=ignore_index), abs=1e-5)
+    if ignore_index is None:
+        want = LO.binary_focal_loss(x64, l64) + LO.dice_loss(x64, l64, "multiclass") + LO.jaccard_loss(x64, l64, "multiclass")
+        assert results[0][2] == pytest.approx(want, abs=1e-5)
+    # labels outside [0, C) that are not ignore_index are still reported
+    bad = ll.clone()
+    bad[2, 3, 3] = C + 3
+    with pytest.raises((RuntimeError, ValueError, IndexError)):
+        L.DiceLoss("multiclass", ignore_index=ignore_index)(xl, bad)
+        N.load()
+        from pytorch_toolbelt_amd.losses import _kernels as K
+        K.flush_label_check()
