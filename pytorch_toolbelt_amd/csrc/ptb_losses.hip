@@ -60,6 +60,10 @@ __device__ __forceinline__ void load_px(const float* __restrict__ p, float (&x)[
         typedef float v4f __attribute__((ext_vector_type(4)));
         const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
         x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else if constexpr (PIX == 2) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+        x[0] = v.x; x[1] = v.y;
     } else {
 #pragma unroll
         for (int k = 0; k < PIX; ++k) x[k] = p[k];
@@ -392,9 +396,9 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
 // run-time switches (prob, c < C, ok, ignore) cut the unrolled class loop into hundreds of basic blocks.  Here everything
 // that varies is a template parameter, classes beyond C are padded with -inf / 0 (they contribute exact zeros, so only
 // their loads are guarded), and no control flow diverges: about 8 (statistics) / 20 (+ focal) vector instructions per
-// element.  T_c is a label count: taken per WAVE from the compare mask the class loop needs anyway (s_bcnt1 on the scalar
+// element (2 pixels per lane, 98 VGPRs, measured the same as 4: 105 vs 106 us).  T_c is a label count: taken per WAVE from the compare mask the class loop needs anyway (s_bcnt1 on the scalar
 // unit).  FOCAL shares the exp with the softmax as described at `share` above, with the same exact redo of extreme elements.
-template <int CREG, int PROB, bool FOCAL, bool IGN>
+template <int CREG, int PROB, bool FOCAL, bool IGN, int PIX = 4>
 __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const SegArgs a) {
     static_assert(!FOCAL || PROB == PROB_SOFTMAX, "the shared exp needs the softmax numerators");
     extern __shared__ float lds[];  // [4 waves][3][C]
@@ -406,39 +410,43 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
 #pragma unroll
     for (int c = 0; c < CREG; ++c) { aI[c] = 0.f; aP[c] = 0.f; nT[c] = 0; }
     double f_loss = 0.0, f_term = 0.0;
-    const long long per_img = a.HW / 256;
+    const long long per_img = a.HW / (64 * PIX);
     const long long groups = per_img * a.B;
     for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
         const int b = (int)(g / per_img);
-        const long long i0 = (g - (long long)b * per_img) * 256 + (long long)lane * 4;
+        const long long i0 = (g - (long long)b * per_img) * (64 * PIX) + (long long)lane * PIX;
         const long long base = (long long)b * C * a.HW + i0;
-        int lab[4];
-        bool valid[4];
+        int lab[PIX];
+        bool valid[PIX];
         {
             const long long* lp = a.labels + (long long)b * a.HW + i0;
-            const longlong2 l01 = *reinterpret_cast<const longlong2*>(lp), l23 = *reinterpret_cast<const longlong2*>(lp + 2);
-            const long long l64[4] = {l01.x, l01.y, l23.x, l23.y};
+            long long l64[PIX];
+#pragma unroll
+            for (int k = 0; k < PIX; k += 2) {
+                const longlong2 l2 = *reinterpret_cast<const longlong2*>(lp + k);
+                l64[k] = l2.x; l64[k + 1] = l2.y;
+            }
             bool bad = false;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PIX; ++k) {
                 valid[k] = !IGN || l64[k] != a.ignore_label;
                 bad = bad || (valid[k] && (l64[k] < 0 || l64[k] >= C));
                 lab[k] = valid[k] ? (int)l64[k] : -1;
             }
             if (bad) *a.error_flag = 1;
         }
-        float xv[CREG][4];
+        float xv[CREG][PIX];
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
             const float pad = PROB == PROB_SOFTMAX ? -INFINITY : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xv[c][k] = pad;
-            if (c < C) load_px<4>(a.logits + base + (long long)c * a.HW, xv[c], true);
+            for (int k = 0; k < PIX; ++k) xv[c][k] = pad;
+            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], true);
         }
-        float inv[4], em[4], mx[4];
-        bool redo_all[4], redo[4];
+        float inv[PIX], em[PIX], mx[PIX];
+        bool redo_all[PIX], redo[PIX];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PIX; ++k) {
             inv[k] = 1.0f; em[k] = 1.0f; mx[k] = 0.f; redo_all[k] = false; redo[k] = false;
             if (PROB == PROB_SOFTMAX) {
                 float m = xv[0][k];
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < PIX; ++k) {
                 const float u = xv[c][k];
                 const bool hit = lab[k] == c;
                 if (FOCAL) {
@@ -486,10 +494,13 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
             }
         }
         if (FOCAL) {
-            if (__any(redo[0] || redo[1] || redo[2] || redo[3])) {   // exact redo from re-read logits (never on sane logits)
+            bool any_redo = false;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) any_redo = any_redo || redo[k];
+            if (__any(any_redo)) {   // exact redo from re-read logits (never on sane logits)
                 const FocalCfg cfg = focal_cfg(a);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < PIX; ++k) {
                     if (!redo[k]) continue;
                     for (int c = 0; c < C; ++c) {
                         if (!redo_all[k] && c != lab[k]) continue;
@@ -651,6 +662,72 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const SegArgs a) {
             }
         }
         f_loss += (double)lsum;
+        f_term += (double)fsum;
+    }
+    block_add2(f_loss, f_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C), lane, wave);
+}
+
+// Straight-line variant for hard labels with the default focal configuration (gamma 2; no alpha, threshold or class weights)
+// and HW % 256 == 0.  With y = (label == c) ? -x : x the element is sigmoid(y)^2 * softplus(y): 1 - p_t = sigmoid(y) and
+// BCE = softplus(y), so the target never enters the arithmetic again -- ~13 vector instructions + exp, rcp, log per element.
+// CCH class planes are requested at once (the generic kernel above has 4 in flight); classes beyond C are padded with
+// -inf, whose element is exactly 0.  IGN: ignored pixels add no loss, and their focal terms only count when not normalised.
+template <int CCH, bool IGN>
+__global__ __launch_bounds__(256) void focal_fwd_lean_kernel(const SegArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const float term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
+    double f_loss = 0.0, f_term = 0.0;
+    const long long per_img = a.HW / 256;
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const int b = (int)(g / per_img);
+        const long long i0 = (g - (long long)b * per_img) * 256 + (long long)lane * 4;
+        const long long base = (long long)b * C * a.HW + i0;
+        int lab[4];
+        bool valid[4];
+        {
+            const long long* lp = a.labels + (long long)b * a.HW + i0;
+            const longlong2 l01 = *reinterpret_cast<const longlong2*>(lp), l23 = *reinterpret_cast<const longlong2*>(lp + 2);
+            const long long l64[4] = {l01.x, l01.y, l23.x, l23.y};
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                valid[k] = !IGN || l64[k] != a.ignore_label;
+                bad = bad || (valid[k] && (l64[k] < 0 || l64[k] >= C));
+                lab[k] = valid[k] ? (int)l64[k] : -1;
+            }
+            if (bad) *a.error_flag = 1;
+        }
+        float lrelu = 0.f, llog = 0.f, fsum = 0.f;   // loss = sum f * relu(y) + ln2 * sum f * log2(1 + e)
+        for (int c0 = 0; c0 < C; c0 += CCH) {
+            float xv[CCH][4];
+#pragma unroll
+            for (int u = 0; u < CCH; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xv[u][k] = -INFINITY;
+                if (c0 + u < C) load_px<4>(a.logits + base + (long long)(c0 + u) * a.HW, xv[u], true);
+            }
+#pragma unroll
+            for (int u = 0; u < CCH; ++u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float x = xv[u][k];
+                    const float y = lab[k] == c0 + u ? -x : x;
+                    const float e = ex2(-fabsf(y) * kLog2e);
+                    const float s1 = 1.0f + e;
+                    const float inv = rcp(s1);
+                    const float sg = y >= 0.f ? inv : e * inv;          // sigmoid(y) = 1 - p_t
+                    float f = sg * sg;
+                    const float w = (IGN && !valid[k]) ? 0.f : f;        // weight of this element's loss
+                    lrelu = __builtin_fmaf(w, fmaxf(y, 0.f), lrelu);
+                    llog = __builtin_fmaf(w, lg2(s1), llog);
+                    if (IGN) f = valid[k] ? f : f * term_mask;
+                    fsum += f;
+                }
+            }
+        }
+        f_loss += (double)(lrelu + kLn2 * llog);
         f_term += (double)fsum;
     }
     block_add2(f_loss, f_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C), lane, wave);
@@ -1420,6 +1497,16 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
             return check_launch();
         }
 #undef PTB_LEAN
+    }
+    if (what == SEG_FOCAL && !g_force_scalar && labels && !dense && vec && HW % 256 == 0 && g2 && !class_weights &&
+        !(flags & (SEG_HAS_ALPHA | SEG_REDUCED | SEG_ELEMWISE))) {
+        const bool ign = flags & SEG_HAS_IGNORE;
+        const dim3 lgrid(grid_for_groups(HW / 256 * B, kGridStream));
+#define PTB_FL(CH) do { if (ign) hipLaunchKernelGGL((focal_fwd_lean_kernel<CH, true>), lgrid, block, 0, s, a); \
+                        else hipLaunchKernelGGL((focal_fwd_lean_kernel<CH, false>), lgrid, block, 0, s, a); } while (0)
+        if (C <= 4) PTB_FL(4); else PTB_FL(8);   // 16 at once (139 VGPRs, 3 waves / SIMD) measured 119 us vs 108 us for 2 x 8 at C = 16
+#undef PTB_FL
+        return check_launch();
     }
     if (what == SEG_FOCAL) {
 #define PTB_FF(P, D) do { if (g2) hipLaunchKernelGGL((focal_fwd_kernel<P, D, true>), grid, block, 0, s, a); \

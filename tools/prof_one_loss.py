@@ -14,6 +14,9 @@ labels = torch.randint(0, 16, (32, 512, 512), device=dev, generator=g)
 crit = {"dice": L.DiceLoss("multiclass"), "focal": L.BinaryFocalLoss(), "fused": L.FocalDiceJaccardLoss("multiclass"),
         "cefocal": L.CrossEntropyFocalLoss()}[sys.argv[1]]
 bwd = len(sys.argv) > 2 and sys.argv[2] == "bwd"
+if os.environ.get("PTB_TUNABLE4"):
+    from pytorch_toolbelt_amd import _native as N
+    assert N.load().ptb_set_tunable(4, int(os.environ["PTB_TUNABLE4"])) == 0
 for _ in range(4):
     if bwd:
         xg = x.clone().requires_grad_(True)
