@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--memset-accumulators", action="store_true", help="A/B: zero the accumulators with a memset each step instead of first-touch stores")
     ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
     ap.add_argument("--unplanned", action="store_true", help="A/B: TileMerger without crops= (lazily built norm_mask + separate merge pass)")
+    ap.add_argument("--no-defer", action="store_true", help="A/B: planned merger without deferred band merging (accumulators in HBM)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
@@ -138,6 +139,7 @@ def main():
 
     # ---- this rank's share of the tiles, and their (synthetic) model outputs resident in HBM -------------------
     sharded = use_dist
+    planned = deferred = False
     partition = os.environ.get("PTB_BENCH_PARTITION", "tiles")   # "tiles": 45 / 46 tiles per rank at N = 8; "rows": whole tile rows
     if not sharded:
         my_tiles = np.arange(n_tiles)
@@ -158,7 +160,10 @@ def main():
         # block is divided by the precomputed normaliser in the launch that brings its last tile and merge() returns the
         # finished map (+3 % per image; --unplanned: lazily built normaliser + separate merge pass)
         planned = not (args.unplanned or args.memset_accumulators)
-        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None)
+        # deferred bands (default): the merger keeps references to the batches (they stay resident and unmodified here) and
+        # merges each 256-row band of the image in ONE launch when its last tile has arrived -- no accumulator in HBM
+        deferred = planned and not args.no_defer
+        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None, defer=deferred)
     else:
         merger = sharded_merger
 
@@ -203,13 +208,24 @@ def main():
     if not sharded and planned:
         # one untimed step that is also checked: should the planned path ever misbehave on this box, the benchmark falls
         # back to the ordinary merger (and says so in the JSON) instead of dying
-        try:
-            probe = step()
-            ok = bool(torch.isfinite(probe).all()) and merger._plan is not None and bool(merger._plan.done.all())
-        except Exception as exc:  # noqa: BLE001
-            print(f"[bench] planned merger failed ({exc!r}); using the unplanned merger", file=sys.stderr)
-            ok = False
-        if not ok:
+        def probe_ok():
+            try:
+                probe = step()
+                if not bool(torch.isfinite(probe).all()) or merger._plan is None:
+                    return False
+                if deferred:
+                    return merger._bands is not None and merger._defer_active and merger._bands_done == len(merger._bands.bands)
+                return bool(merger._plan.done.all())
+            except Exception as exc:  # noqa: BLE001
+                print(f"[bench] {'deferred' if deferred else 'planned'} merger failed ({exc!r})", file=sys.stderr)
+                return False
+
+        if deferred and not probe_ok():
+            print("[bench] falling back to the planned merger without deferred bands", file=sys.stderr)
+            deferred = False
+            merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops)
+        if not deferred and not probe_ok():
+            print("[bench] falling back to the unplanned merger", file=sys.stderr)
             planned = False
             merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
     for _ in range(args.warmup):
@@ -219,11 +235,15 @@ def main():
     step()
     host_ms = (time.perf_counter() - th0) * 1e3
     sync()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         step()
+    ev1.record()
     sync()
     elapsed = time.perf_counter() - t0
+    region_event_ms = ev0.elapsed_time(ev1)
     if use_dist:
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -283,7 +303,13 @@ def main():
     launch_ms = float(np.median(spans)) / max(n_full, 1) if n_full else float("nan")
     bytes_per_tile = VIEWS * CHANNELS * TILE * TILE * 4          # 8 views x C x T x 4 B read per tile
     bytes_per_launch = bytes_per_tile * BATCH
-    if not sharded and planned:
+    n_bands = len(merger._bands.bands) if (not sharded and deferred) else 0
+    if n_bands:
+        # deferred: the 20 band launches of an image ARE the region (they read every model output once and write the merged
+        # map once) and nothing else runs on the stream: one HIP-event pair around the K timed steps / (K x 20 launches)
+        launch_ms = region_event_ms / (args.steps * n_bands)
+        bytes_per_launch = (VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) // n_bands
+    elif not sharded and planned:
         # the planned kernel also writes the region's output (+ C x 5120 x 5120 x 4 B per image): the launch's
         # share of the whole region's algorithmic bytes, 12 532 580 352 B x 8 / 361
         bytes_per_launch += CHANNELS * 5120 * 5120 * 4 * BATCH // n_tiles
@@ -298,7 +324,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("view_accum_d4_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("band_merge_d4_bytes_per_launch" if n_bands else "view_accum_d4_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -320,7 +346,11 @@ def main():
                 "workload": "BASELINE cfg2: 5000x5000x3 image, ImageSlicer 512/256 pyramid (361 tiles, target 5120x5120), "
                             "d4 TTA (8 views) model outputs C=4 fp32 resident in HBM, fused de-augment+mean+integrate_batch in "
                             "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; " +
-                            ("TileMerger(crops=tiler.crops): the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: "
+                            ("TileMerger(crops=tiler.crops, defer=True): the merger keeps references to the (resident, unmodified) "
+                             "batches; the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: not compulsory "
+                             "traffic); each 256-row band of the image is merged by ONE launch when its last tile has arrived (20 "
+                             "launches, no accumulator in HBM), so merge() returns the finished [C,H',W'] map; " if (not sharded and deferred) else
+                             "TileMerger(crops=tiler.crops): the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: "
                              "not compulsory traffic) and every block is divided by it in the launch that brings its last tile, so "
                              "merge() returns the finished [C,H',W'] map; " if (not sharded and planned) else
                              ("ShardedTileMerger: every rank accumulates its tiles into a band, halo rectangles go point-to-point to "
@@ -329,7 +359,8 @@ def main():
                             "model forward excluded",
                 "tiles": n_tiles,
                 "batch_tiles": BATCH,
-                "merger": ("planned (crops= given, no merge pass)" if (not sharded and planned) else
+                "merger": ("planned + deferred bands (crops= given, defer=True)" if (not sharded and deferred) else
+                           "planned (crops= given, no merge pass)" if (not sharded and planned) else
                            ("sharded, unplanned" if sharded else "unplanned (lazy norm_mask + merge pass)")),
                 "parallelism": "single GPU" if world == 1 else (f"{'tile ranges' if partition == 'tiles' else 'tile rows'} sharded over {world} ranks, RCCL p2p halo exchange"),
                 "host_issue_ms_per_step": round(host_ms, 4),
@@ -337,8 +368,10 @@ def main():
                 "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "roofline": {
-                "kernel": "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
-                          "normalisation, 8 tiles/launch)",
+                "kernel": ("band_merge_kernel<8,D4,linear> (fused d4 de-augment + mean + weighted blend of all tiles over a 256-row "
+                           "band + normalisation, 19 or 38 tiles/launch, 20 launches/image)" if n_bands else
+                           "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
+                           "normalisation, 8 tiles/launch)"),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

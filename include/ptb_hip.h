@@ -121,6 +121,18 @@ int ptb_merge_div(const float* image, const float* norm, float* out, int C, int6
 int ptb_merge_div_ex(const float* image, const float* norm, float* out, int C, int64_t HW, int64_t image_cs, int64_t out_cs,
                      const float* extra, int64_t extra_cs, int64_t extra_n, ptb_stream_t stream);
 
+/* Deferred merge of one horizontal band (rows y0:y1 of the accumulator-sized map, lying between two consecutive tile edges) from
+ * ALL the tiles that cover it: == the rows y0:y1 of `merge()` after `integrate_batch(<group>_image_deaugment(batch), crops)` of
+ * those n tiles in the given order (inference/tiles.py:321-346 after inference/tta.py:442-467), without an accumulator in
+ * HBM.  tile_src HOST array of n DEVICE pointers (view 0 of tile t, [C, th, tw] of in_dtype; view v lies tile_view_stride[t]
+ * elements further -- the tiles may belong to different batch tensors), xs / ys HOST tile origins; every tile must cover
+ * all rows of the band.  norm_full [H, W] = the complete normaliser, merged [C, H, W].  Returns PTB_EUNSUPPORTED when the
+ * band does not fit the fast kernel (alignment, more than 48 tiles, more than 4 tiles over one pixel): the caller then
+ * integrates those tiles through the incremental entry points. */
+int ptb_merge_band(float* merged, const float* norm_full, const float* weight, const void* const* tile_src,
+                   const int64_t* tile_view_stride, int in_dtype, int V, const int* views, int reduction, const int64_t* xs,
+                   const int64_t* ys, int n, int C, int th, int tw, int H, int W, int y0, int y1, ptb_stream_t stream);
+
 /* dst[c][r][x] += src[c][r][x] for a packed src [C, rows, cols] and a rectangle of a larger fp32 accumulator (element
  * strides dst_cs per channel, dst_rs per row): folds a halo rectangle received from another rank into the band
  * accumulator (multi-GPU merger; no reference counterpart). */

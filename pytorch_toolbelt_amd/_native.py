@@ -46,6 +46,7 @@ SIGNATURES = {
     "ptb_norm_accumulate": (_c_int, [_vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_debug_plan": (_c_int, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _ip, _c_int]),
     "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),
+    "ptb_merge_band": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_rect_add": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _vp]),
     "ptb_merge_div_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp]),
     "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

@@ -244,6 +244,70 @@ __global__ __launch_bounds__(CH * 16) void norm_accum_kernel(const ViewArgs a, c
 // views share one transposed, XOR-swizzled LDS copy of the chunk (ST[c][r] = S[r][c]) read back with ds_read_b128.
 // NONLIN = backward of a non-linear reduction: the scattered value is u = g * post'(out) / V (a.norm = forward output,
 // a.divisor = V) and every destination is multiplied by pre'(x_k) read at the destination (a.weight = forward input).
+// ------------------------------------------------------------------------------------------------ deferred band merge
+// TileMerger(crops=..., defer=True): the merger keeps references to the model outputs instead of accumulating them, and when
+// the last tile covering a horizontal BAND of the image (the rows between two consecutive tile edges) has arrived, one launch
+// reads every covering tile of the band -- they may live in different batch tensors, hence per-tile source pointers --
+// applies the inverse views, reduces, blends in tile order and writes `sum / norm_full` straight to the merged map.  The
+// accumulator image never exists in HBM: per 8 tiles the incremental path moves 312 MB for 268 MB of model outputs, this one
+// only the outputs and the result.  Same chunk / cover walk and the same gather_reduce as view_accum_kernel (CH = 32), so
+// the fp32 operation order per pixel -- and therefore every bit of the result -- is that of the incremental path.
+constexpr int BAND_CELLS = 40, BAND_TILES = 48;
+struct BandCell {
+    int ox, oy, w, h;
+    int chunk_end;
+    int ntiles;
+    int tile[MAX_COVER];
+};
+struct BandArgs {
+    BandCell cells[BAND_CELLS];
+    int tile_x[BAND_TILES], tile_y[BAND_TILES];
+    const void* tile_src[BAND_TILES];   // view 0, channel 0 of the tile
+    long long tile_vs[BAND_TILES];      // elements between consecutive views of this tile (its batch size * C * H * W)
+};
+
+template <int NV, int CODES, int OPK, int LD>
+__global__ __launch_bounds__(512) void band_merge_kernel(const ViewArgs a, const BandArgs g) {
+    constexpr int CH = 32;
+    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x % a.C;
+    const int chunk = blockIdx.x / a.C;
+    int ci = 0;
+    while (ci < a.ncells - 1 && chunk >= g.cells[ci].chunk_end) ++ci;
+    const BandCell& cell = g.cells[ci];
+    const int first = ci ? g.cells[ci - 1].chunk_end : 0;
+    const int ncx = (cell.w + CW - 1) / CW;
+    const int lc = chunk - first;
+    const int cx0 = (lc % ncx) * CW, cy0 = (lc / ncx) * CH;
+    const int cw = min(CW, cell.w - cx0), ch = min(CH, cell.h - cy0);
+    const int q = tid & 15, r = tid >> 4;
+    const bool act = (r < ch) && (4 * q < cw);
+    const int ax = cell.ox + cx0, ay = cell.oy + cy0;
+    const long long pix = (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
+    float4 nfull = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act) nfull = *reinterpret_cast<const float4*>(a.norm_full + pix);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nt = cell.ntiles;
+    for (int e = 0; e < nt; ++e) {
+        const int gt = cell.tile[e];
+        const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
+        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(g.tile_src[gt]), (long long)c * a.H * a.W,
+                                                                g.tile_vs[gt], a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op,
+                                                                a.divisor, lds, tid, e + 1 < nt);
+        if (act) {
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
+            acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338, no FMA contraction
+            acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, w4.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, w4.z));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(val.w, w4.w));
+        }
+    }
+    if (act)
+        *reinterpret_cast<float4*>(a.merged + (long long)c * a.dst_chan_stride + pix) =
+            make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w));
+}
+
 template <int CH, bool NONLIN>
 __global__ __launch_bounds__(CH * 16) void view_scatter_kernel(const ViewArgs a, int B) {
     __shared__ __attribute__((aligned(16))) float st[CW * CH];
@@ -941,6 +1005,102 @@ extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, floa
     const int rc = launch_group(a, g, cells, fr, fast, ch, (hipStream_t)stream);
     if (rc == PTB_OK) commit_plan(cells, pl);
     return rc;
+}
+
+static void launch_band(const ViewArgs& a, const BandArgs& g, int blocks, hipStream_t s) {
+    const dim3 grid(blocks), block(512);
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+#define PTB_BAND_LD(NV, CODES, LD)                                                                             \
+    do {                                                                                                       \
+        if (nonlinear) hipLaunchKernelGGL((band_merge_kernel<NV, CODES, 1, LD>), grid, block, 0, s, a, g);     \
+        else hipLaunchKernelGGL((band_merge_kernel<NV, CODES, 0, LD>), grid, block, 0, s, a, g);               \
+    } while (0)
+#define PTB_BAND(NV, CODES)                                                                                    \
+    do {                                                                                                       \
+        if (a.in_dtype == PTB_F16) PTB_BAND_LD(NV, CODES, 2);                                                  \
+        else if (a.in_dtype == PTB_BF16) PTB_BAND_LD(NV, CODES, 3);                                            \
+        else PTB_BAND_LD(NV, CODES, 1);                                                                        \
+    } while (0)
+    if (a.nviews == 1 && a.codes == CODES_ID) PTB_BAND(1, CODES_ID);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_BAND(2, CODES_FLIPLR);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_BAND(2, CODES_FLIPUD);
+    else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_BAND(3, CODES_FLIPS);
+    else if (a.nviews == 4 && a.codes == CODES_D2) PTB_BAND(4, CODES_D2);
+    else if (a.nviews == 8 && a.codes == CODES_D4) PTB_BAND(8, CODES_D4);
+    else PTB_BAND(8, -1);
+#undef PTB_BAND
+#undef PTB_BAND_LD
+}
+
+extern "C" int ptb_merge_band(float* merged, const float* norm_full, const float* weight, const void* const* tile_src,
+                              const int64_t* tile_view_stride, int in_dtype, int V, const int* views, int reduction,
+                              const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W, int y0, int y1,
+                              ptb_stream_t stream) {
+    if (!merged || !norm_full || !weight || !tile_src || !tile_view_stride || !xs64 || !ys64) return PTB_EINVAL;
+    if (n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || y0 < 0 || y1 <= y0 || y1 > H) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
+    if (int rc = validate_views(V, views, th, tw)) return rc;
+    if (n > BAND_TILES) return PTB_EUNSUPPORTED;
+    ViewArgs a{};
+    a.weight = weight; a.merged = merged; a.norm_full = norm_full;
+    a.in_dtype = in_dtype;
+    a.H = th; a.W = tw; a.C = C;
+    a.dst_chan_stride = (long long)H * W;
+    a.dst_row_stride = W;
+    a.nviews = V;
+    a.codes = pack_runtime(V, views);
+    a.scale = 1.0f;
+    fill_reduction(a, reduction, V);
+    const int nT = count_transpose(V, a.codes);
+    bool fast = !g_force_scalar && (tw % 4 == 0) && (th % 4 == 0) && (W % 4 == 0) && (y0 % 4 == 0) && (y1 % 4 == 0) &&
+                ((long long)H * W % 4 == 0) && aligned16(merged) && aligned16(norm_full) && aligned16(weight) && nT <= MAX_T;
+    BandArgs g{};
+    for (int t = 0; t < n; ++t) {
+        if (xs64[t] < 0 || ys64[t] < 0 || xs64[t] + tw > W || ys64[t] + th > H) return PTB_EBOUNDS;
+        if (ys64[t] > y0 || ys64[t] + th < y1) return PTB_EINVAL;   // every tile of a band covers all of its rows
+        if (!tile_src[t] || tile_view_stride[t] < (long long)C * th * tw) return PTB_EINVAL;
+        fast = fast && xs64[t] % 4 == 0 && ys64[t] % 4 == 0 && aligned_elems(tile_src[t], in_dtype) && tile_view_stride[t] % 4 == 0;
+        g.tile_x[t] = (int)xs64[t]; g.tile_y[t] = (int)ys64[t];
+        g.tile_src[t] = tile_src[t];
+        g.tile_vs[t] = tile_view_stride[t];
+    }
+    if (!fast) return PTB_EUNSUPPORTED;   // the caller falls back to the incremental path
+    std::vector<int> xe;
+    for (int t = 0; t < n; ++t) { xe.push_back(g.tile_x[t]); xe.push_back(g.tile_x[t] + tw); }
+    std::sort(xe.begin(), xe.end());
+    xe.erase(std::unique(xe.begin(), xe.end()), xe.end());
+    std::vector<BandCell> cells;
+    for (size_t xi = 0; xi + 1 < xe.size(); ++xi) {
+        BandCell c{};
+        c.ox = xe[xi]; c.oy = y0; c.w = xe[xi + 1] - xe[xi]; c.h = y1 - y0;
+        for (int t = 0; t < n; ++t) {
+            if (g.tile_x[t] <= c.ox && c.ox < g.tile_x[t] + tw) {
+                if (c.ntiles == MAX_COVER) return PTB_EUNSUPPORTED;
+                c.tile[c.ntiles++] = t;     // ascending t = the order the tiles were integrated in
+            }
+        }
+        if (!c.ntiles) continue;
+        if (!cells.empty() && cells.back().ox + cells.back().w == c.ox && cells.back().ntiles == c.ntiles &&
+            std::equal(c.tile, c.tile + c.ntiles, cells.back().tile)) {
+            cells.back().w += c.w;   // same cover as the strip to the left: one wider cell
+            continue;
+        }
+        cells.push_back(c);
+    }
+    if (cells.empty() || (int)cells.size() > BAND_CELLS) return PTB_EUNSUPPORTED;
+    std::stable_sort(cells.begin(), cells.end(), [](const BandCell& l, const BandCell& r) { return l.ntiles > r.ntiles; });
+    int run = 0;
+    for (size_t i = 0; i < cells.size(); ++i) {
+        run += ((cells[i].w + CW - 1) / CW) * ((cells[i].h + 31) / 32);
+        cells[i].chunk_end = run;
+        g.cells[i] = cells[i];
+    }
+    a.ncells = (int)cells.size();
+    a.total_chunks = run;
+    const long long blocks = (long long)run * C;
+    if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    launch_band(a, g, (int)blocks, (hipStream_t)stream);
+    return check_launch();
 }
 
 extern "C" int ptb_norm_accumulate(float* norm, const float* weight, const int64_t* xs, const int64_t* ys, int B, int th, int tw,

@@ -314,6 +314,55 @@ class _Plan:
         return False
 
 
+class _Bands:
+    """Deferred planned merging (``TileMerger(..., crops=tiler.crops, defer=True)``).
+
+    A *band* is the rows between two consecutive tile edges; every tile that touches a band covers all of its rows.  The
+    merger only keeps references to the model outputs it is handed, and when the last tile of a band has arrived one launch
+    (``ptb_merge_band``) reads all covering tiles of the band, de-augments, reduces, blends in integration order and writes
+    ``sum / norm`` to the result -- the accumulator image never travels through HBM (the incremental path re-reads and
+    re-writes every pixel once per overlapping tile row).  The fp32 operation order per pixel is the incremental path's,
+    so the result is bit-identical.  Cost: the batches of (at most) the last two tile rows stay alive until their bands
+    are done, and they must not be modified in place in the meantime -- which is why this is opt-in.
+
+    Until the first band is launched any deviation from the plan simply replays the held batches through the incremental
+    path; afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
+
+    MAX_TILES, MAX_COVER = 48, 4
+
+    def __init__(self, bands, ready_at, last_band):
+        self.bands = bands          # [dict(y0, y1, tiles, xs, ys)] top to bottom
+        self.ready_at = ready_at    # plan index of a tile -> bands that are complete once it is in
+        self.last_band = last_band  # plan index of a tile -> the last band that reads it
+
+    @staticmethod
+    def build(plan, th, tw, H, W):
+        xs, ys = plan.xy[0], plan.xy[1]
+        n = len(xs)
+        if tw % 4 or th % 4 or W % 4 or np.any(xs % 4) or np.any(ys % 4):
+            return None
+        edges = np.unique(np.concatenate([ys, ys + th]))
+        bands, ready_at, last_band = [], {}, np.full(n, -1, dtype=np.int64)
+        for y0, y1 in zip(edges[:-1], edges[1:]):
+            tiles = np.nonzero((ys <= y0) & (ys + th >= y1))[0]
+            if len(tiles) == 0:
+                continue
+            if len(tiles) > _Bands.MAX_TILES:
+                return None
+            bx = xs[tiles]
+            cuts = np.unique(np.concatenate([bx, bx + tw]))
+            cover = ((bx[None, :] <= cuts[:-1, None]) & (cuts[:-1, None] < bx[None, :] + tw)).sum(axis=1)
+            if cover.max() > _Bands.MAX_COVER or len(cuts) - 1 > 40:
+                return None
+            b = len(bands)
+            bands.append(dict(y0=int(y0), y1=int(y1), tiles=tiles, xs=np.ascontiguousarray(xs[tiles]), ys=np.ascontiguousarray(ys[tiles])))
+            ready_at.setdefault(int(tiles.max()), []).append(b)
+            last_band[tiles] = b
+        if np.any(last_band < 0):
+            return None
+        return _Bands(bands, ready_at, last_band)
+
+
 class TileMerger:
     """Blend tile predictions into a full-size map that lives in HBM (reference inference/tiles.py:290-350).
 
@@ -323,11 +372,15 @@ class TileMerger:
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
 
-    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None):
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False):
         """``crops`` (extension, optional): the complete crop list the image will receive (``tiler.crops``), in the
         order it will be integrated.  With it the merger runs *planned*: the normaliser is known up front and every
         block of the image is divided by it in the very launch that brings its last tile, so ``merge()`` has nothing
-        left to do.  Results are bit-identical; see ``_Plan`` for what a planned merger restricts."""
+        left to do.  Results are bit-identical; see ``_Plan`` for what a planned merger restricts.
+
+        ``defer=True`` (with ``crops``): *deferred* planned merging -- the merger holds on to the batches and merges a
+        horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
+        ``_Bands`` (the batches must stay unmodified until then)."""
         device = torch.device(device)
         if device.type != "cuda":
             raise RuntimeError(
@@ -359,10 +412,90 @@ class TileMerger:
         self._eager_norm = False  # norm_mask was handed out: keep it up to date inside the accumulate kernels
         self._merged = None       # planned mode: the merge result the accumulate launches fill in
         self._plan = _Plan.build(self, crops) if crops is not None else None
+        self._bands = None
+        if defer and self._plan is not None:
+            self._bands = _Bands.build(self._plan, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height, self.image_width)
+        self._defer_reset()
 
     # ------------------------------------------------------------------ first-touch state
+    # ------------------------------------------------------------------ deferred bands
+    def _defer_reset(self):
+        self._defer_active = self._bands is not None
+        self._held = []          # [batch tensor, coords, views, reduction, last band that reads it], integration order
+        self._bands_done = 0
+        self._defer_cfg = None   # (views, reduction, dtype code) of this image
+        if self._bands is not None:
+            n = self._plan.xy.shape[1]
+            self._tile_src = np.zeros(n, dtype=np.uint64)
+            self._tile_vs = np.zeros(n, dtype=np.int64)
+
+    def _defer_flush(self, what, keep_plan=False):
+        """Leave deferred mode: replay the held batches through the incremental path (only before the first band) --
+        the planned one when ``keep_plan`` (nothing deviated from the plan), else the ordinary one."""
+        if not self._defer_active:
+            return
+        if self._bands_done:
+            raise RuntimeError(f"TileMerger(defer=True): {what} is not available after bands of the image were merged; "
+                               "integrate the planned tiles and call merge(), or construct the merger without defer=True")
+        held, self._held = self._held, []
+        self._defer_active = False
+        self._plan.restart()
+        self._plan.active = keep_plan
+        self._log, self._applied = [], 0
+        for batch, coords, views, reduction, _last in held:
+            self._accumulate(batch, coords, views, reduction)
+
+    def _defer_step(self, batch, coords, xy, views, reduction, dcode):
+        """Take one planned batch into custody and merge the bands it completes.  False: not deferrable (the caller goes on
+        with the incremental path, after the held batches were replayed)."""
+        plan, bands = self._plan, self._bands
+        B = xy.shape[1]
+        cfg = (tuple(views) if views is not None else None, reduction, dcode)
+        ok = (plan.active and not self._eager_norm and plan.pos + B <= plan.xy.shape[1]
+              and xy[0].data == plan.xy[0, plan.pos:plan.pos + B].data and xy[1].data == plan.xy[1, plan.pos:plan.pos + B].data
+              and (self._defer_cfg is None or self._defer_cfg == cfg))
+        if not ok:
+            self._defer_flush("an unplanned tile batch")
+            return False
+        self._defer_cfg = cfg
+        th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
+        per_tile = self.channels * th * tw
+        pos = plan.pos
+        self._tile_src[pos:pos + B] = batch.data_ptr() + np.arange(B, dtype=np.uint64) * np.uint64(per_tile * batch.element_size())
+        self._tile_vs[pos:pos + B] = B * per_tile
+        self._held.append([batch, coords, views, reduction, int(bands.last_band[pos:pos + B].max())])
+        plan.pos += B
+        self._log.append(xy)
+        if self._merged is None:
+            self._merged = torch.empty_like(self._image)
+        varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
+        n_views = len(views) if views is not None else 1
+        lib = N.load()
+        dev = self._image.device
+        for t in range(pos, pos + B):
+            for b in bands.ready_at.get(t, ()):
+                band = bands.bands[b]
+                src = np.ascontiguousarray(self._tile_src[band["tiles"]])
+                vs = np.ascontiguousarray(self._tile_vs[band["tiles"]])
+                with N.on_device(dev):
+                    rc = lib.ptb_merge_band(self._merged.data_ptr(), plan.norm_full.data_ptr(), self.weight.data_ptr(), src.ctypes.data,
+                                            vs.ctypes.data, dcode, n_views, varr, reduction, band["xs"].ctypes.data, band["ys"].ctypes.data,
+                                            len(src), self.channels, th, tw, self.image_height, self.image_width, band["y0"], band["y1"],
+                                            N.stream_ptr(dev))
+                N.bump()
+                if rc == -2 and not self._bands_done:
+                    # (this batch is already in custody: the replay integrates it too)
+                    self._defer_flush("a band the fast kernel does not take", keep_plan=True)
+                    return True
+                N.check(rc, "TileMerger.integrate_batch (deferred band)")
+                self._bands_done += 1
+                while self._held and self._held[0][4] <= b:   # batches no later band reads: let go of them
+                    self._held.pop(0)
+        return True
+
     def _plan_off(self, what):
         """Leave planned mode; impossible once blocks were finalised (their accumulators were never stored)."""
+        self._defer_flush(what)
         if self._plan is not None:
             if self._plan.done.any():
                 raise RuntimeError(f"TileMerger(crops=...): {what} is not available after planned blocks were finalised; "
@@ -410,6 +543,7 @@ class TileMerger:
         self._merged = None
         if self._plan is not None:
             self._plan.restart()
+        self._defer_reset()
 
     def _log_key(self):
         return (self.weight.data_ptr(), self.weight._version, b"".join(a.tobytes() for a in self._log))
@@ -515,6 +649,8 @@ class TileMerger:
         varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
         norm_ptr = self._norm.data_ptr() if self._eager_norm else None
         dcode = N.DTYPE_CODES[batch.dtype]
+        if self._defer_active and B and self._defer_step(batch, coords, xy, views, reduction, dcode):
+            return
 
         def launch(fresh_ptr):
             return lib.ptb_deaug_accumulate_t(
@@ -600,6 +736,12 @@ class TileMerger:
 
     def _finish_planned(self):
         """Planned mode: divide whatever the accumulate launches have not finalised themselves; returns the result."""
+        if self._defer_active:
+            if self._bands_done == len(self._bands.bands):
+                return self._merged          # every band was merged by the launch that completed it
+            self._defer_flush("merge() before all planned tiles were integrated", keep_plan=True)
+            if self._merged is None:
+                return self._merge_into(torch.empty_like(self._image))
         plan, out = self._plan, self._merged
         pending = plan.done == 0
         if pending.any():
@@ -696,5 +838,5 @@ class TileMerger:
 class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
 
-    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None):
-        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops)
+    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False):
+        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer)

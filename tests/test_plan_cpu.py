@@ -129,3 +129,37 @@ def test_first_touch_bitmap():
     assert rc == N.EFRESH
     rc, _ = plan([W], [0], 512, 512, H, W)
     assert rc == -4
+
+
+def test_band_plan_of_the_deferred_merger():
+    """_Bands.build: bands = rows between consecutive tile edges, their covering tiles in integration order, the tile that
+    completes each band, and the last band reading each tile -- for the headline geometry and some irregular ones."""
+    from types import SimpleNamespace
+
+    from oracle import tiles_oracle as TO
+    from pytorch_toolbelt_amd.inference.tiles import _Bands
+
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    crops = geom["crops"]
+    plan = SimpleNamespace(xy=np.ascontiguousarray(crops[:, :2].T))
+    bands = _Bands.build(plan, 512, 512, 5120, 5120)
+    assert len(bands.bands) == 20
+    assert [len(b["tiles"]) for b in bands.bands] == [19] + [38] * 18 + [19]
+    assert [(b["y0"], b["y1"]) for b in bands.bands] == [(256 * k, 256 * k + 256) for k in range(20)]
+    for k, b in enumerate(bands.bands):
+        assert (np.diff(b["tiles"]) > 0).all()                                   # integration order
+        assert k in bands.ready_at[int(b["tiles"].max())]
+    assert sorted(bands.ready_at) == [19 * r + 18 for r in range(19)]            # the last tile of every tile row
+    assert bands.ready_at[360] == [18, 19]                                       # the last row completes two bands
+    assert bands.last_band[0] == 1 and bands.last_band[19] == 2 and bands.last_band[360] == 19
+    # every pixel row belongs to exactly one band
+    cover = np.zeros(5120, dtype=int)
+    for b in bands.bands:
+        cover[b["y0"]:b["y1"]] += 1
+    assert (cover == 1).all()
+    # step < tile / 4: more than 4 tiles over a pixel -> not deferrable
+    dense = TO.slicer_geometry((600, 600), 256, 48)["crops"]
+    assert _Bands.build(SimpleNamespace(xy=np.ascontiguousarray(dense[:, :2].T)), 256, 256, 640, 640) is None
+    # tile origins off the 4-pixel grid -> not deferrable
+    odd = TO.slicer_geometry((300, 300), 130, 65)["crops"]
+    assert _Bands.build(SimpleNamespace(xy=np.ascontiguousarray(odd[:, :2].T)), 130, 130, int(odd[:, 1].max()) + 130, int(odd[:, 0].max()) + 130) is None

@@ -586,3 +586,97 @@ def test_half_precision_model_outputs_are_read_natively(dtype, dev, native):
             got = tta.d4_image_deaugment(xin, reduction=red)
             assert got.dtype == dtype
             assert torch.equal(got, tta.d4_image_deaugment(xin.float(), reduction=red).to(dtype))
+
+
+# ------------------------------------------------------------------ deferred band merging (TileMerger(crops=, defer=True))
+def _deferred_case(dev, shape, tile, step, C, group, reduction, dtype, bs, images=2, seed=0):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+    from pytorch_toolbelt_amd.inference.tta import DEAUGMENT_VIEWS
+
+    slicer = ImageSlicer(shape + (3,), tile, step, weight="pyramid")
+    crops = slicer.crops
+    V = len(DEAUGMENT_VIEWS[group])
+    th = tile if isinstance(tile, int) else tile[0]
+    tw = tile if isinstance(tile, int) else tile[1]
+    deferred = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+    plain = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for image_no in range(images):
+        deferred.reset()
+        plain.reset()
+        for b0 in range(0, len(crops), bs):
+            nb = min(bs, len(crops) - b0)
+            y = (torch.rand((V * nb, C, th, tw), generator=g) * 0.9 + 0.05).to(dev).to(dtype)
+            deferred.integrate_batch_deaugment(y, crops[b0:b0 + nb], group=group, reduction=reduction)
+            plain.integrate_batch_deaugment(y.clone(), crops[b0:b0 + nb], group=group, reduction=reduction)
+            del y
+        got, want = deferred.merge(), plain.merge()
+        assert torch.equal(got, want), f"image {image_no}: max diff {float((got - want).abs().max())}"
+    return deferred
+
+
+@pytest.mark.parametrize("shape,tile,step,C,group,reduction,dtype,bs", [
+    ((1000, 700), 256, 128, 3, "d4", "mean", torch.float32, 8),
+    ((1000, 700), 256, 128, 2, "d4", "gmean", torch.float32, 5),
+    ((640, 900), 128, 64, 4, "d2", "mean", torch.float32, 7),
+    ((600, 520), (128, 192), (64, 128), 1, "fliplr", "sum", torch.float32, 3),    # non-square tiles: no transposing views
+    ((512, 512), 256, 256, 2, "d4", "mean", torch.float32, 4),                    # no overlap at all
+    ((700, 700), 256, 192, 2, "flips", "mean", torch.float32, 6),                 # step > tile / 2: bands of 64 and 192 rows
+    ((900, 600), 256, 128, 3, "d4", "mean", torch.float16, 8),
+    ((900, 600), 256, 128, 3, "d4", "mean", torch.bfloat16, 2),
+])
+def test_deferred_band_merge_is_bit_identical(shape, tile, step, C, group, reduction, dtype, bs, dev):
+    """Every band of the image is merged in ONE launch from all its tiles (no accumulator in HBM); the result must equal the
+    incremental merger's bit for bit, image after image, for every view group, reduction, source dtype and batch size."""
+    from pytorch_toolbelt_amd import _native as N
+
+    before = N.fresh_fallbacks
+    m = _deferred_case(dev, shape, tile, step, C, group, reduction, dtype, bs)
+    assert m._bands is not None and m._bands_done == len(m._bands.bands) and m._defer_active   # the deferred path did run
+    assert not m._held                                                                          # and let go of every batch
+    assert N.fresh_fallbacks == before
+
+
+def test_deferred_merger_fallbacks_and_restrictions(dev):
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer((700, 600, 3), 256, 128, weight="pyramid")
+    crops = slicer.crops
+    n, C = len(crops), 2
+    y = torch.randn((n, C, 256, 256), device=dev)
+    ref = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    ref.integrate_batch(y, crops)
+    want = ref.merge()
+    # 1. reading .image before the first band is merged: the held batches are replayed through the incremental path
+    m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+    m.integrate_batch(y[:2], crops[:2])
+    assert m._defer_active and len(m._held) == 1 and m._bands_done == 0
+    img = m.image
+    assert not m._defer_active and float(img.abs().sum()) > 0
+    m.integrate_batch(y[2:], crops[2:])
+    assert torch.equal(m.merge(), want)
+    # 2. the same merger, next image: deferred again; a batch that is not the planned one before any band -> fallback
+    m.reset()
+    assert m._defer_active
+    m.integrate_batch(y[:1], crops[:1])
+    m.integrate_batch(y[2:3], crops[2:3])          # skips tile 1
+    assert not m._defer_active
+    m.integrate_batch(y[1:2], crops[1:2])
+    m.integrate_batch(y[3:], crops[3:])
+    torch.testing.assert_close(m.merge(), want, rtol=1e-6, atol=1e-6)   # (different order of additions)
+    # 3. after bands were merged the incremental state does not exist: .image and a partial merge() raise
+    m.reset()
+    row = int(np.sum(crops[:, 1] == crops[0, 1]))
+    m.integrate_batch(y[:row], crops[:row])        # the whole first tile row: band 0 is merged
+    assert m._bands_done >= 1
+    with pytest.raises(RuntimeError, match="defer=True"):
+        _ = m.image
+    with pytest.raises(RuntimeError, match="defer=True"):
+        m.merge()
+    m.integrate_batch(y[row:], crops[row:])
+    assert torch.equal(m.merge(), want)
+    assert torch.equal(m.merge_crop(slicer, layout="chw"), want[:, slicer.margin_top:slicer.margin_top + 700, slicer.margin_left:slicer.margin_left + 600])
+    # 4. geometry the band kernel does not take (origins off the 4-pixel grid): defer is silently off, results unchanged
+    odd = ImageSlicer((300, 300, 3), 130, 65, weight="mean")
+    mo = TileMerger(odd.target_shape, 1, odd.weight, device=dev, crops=odd.crops, defer=True)
+    assert mo._bands is None and not mo._defer_active

@@ -41,6 +41,55 @@ __global__ __launch_bounds__(256) void plane_kernel(const float* __restrict__ x,
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// The READ side of the fused d4 tile kernel, nothing else: a 512-thread workgroup owns a 64-column x 32-row chunk of one
+// (tile, channel) and reads it from 8 view planes [8 views][8 tiles][4 ch][512][512]: 4 row-preserving views as 32 rows x
+// 256 B, 4 transposing views as 64 rows x 128 B (the source block of the transposed chunk).  SEG = 0: that pattern;
+// SEG = 1: the same bytes as fully contiguous 8 KB per view and workgroup (what a 1-D stream would read).
+template <int SEG>
+__global__ __launch_bounds__(512) void tile_read_kernel(const float* __restrict__ src, float* sink, int ntiles, int C) {
+    const int tid = threadIdx.x;
+    const int chunks = 8 * 16;                                   // 8 x 16 chunks of 64 x 32 per 512 x 512 plane
+    const int c = blockIdx.x % C;
+    const int chunk = (blockIdx.x / C) % chunks;
+    const int t = blockIdx.x / C / chunks;
+    const int cx = chunk % 8, cy = chunk / 8;
+    const long long plane = 512LL * 512, view_stride = (long long)ntiles * C * plane;
+    const float* p0 = src + ((long long)t * C + c) * plane;
+    float acc = 0.f;
+    v4f v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float* p = p0 + k * view_stride;
+        long long off;
+        if (SEG == 1) off = (long long)chunk * 2048 + tid * 4;
+        else if (k < 4) off = (long long)(cy * 32 + (tid >> 4)) * 512 + cx * 64 + 4 * (tid & 15);
+        else off = (long long)(cx * 64 + (tid >> 3)) * 512 + cy * 32 + 4 * (tid & 7);
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + off));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+    if (acc == 123.456f) sink[0] = acc;
+}
+
+static void run_tiles(const char* name, int seg, const float* src, float* sink) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int ntiles = 8, C = 4, grid = ntiles * C * 128;
+    const int reps = 20, nbuf = 4;                               // rotate over 4 batches (4 x 268 MB) like the bench does
+    const long long batch = 8LL * ntiles * C * 512 * 512;
+    for (int i = 0; i < reps + 3; ++i) {
+        if (i == 3) CK(hipEventRecord(e0));
+        const float* b = src + (i % nbuf) * batch;
+        if (seg) hipLaunchKernelGGL(tile_read_kernel<1>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C);
+        else hipLaunchKernelGGL(tile_read_kernel<0>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C);
+    }
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-60s %7.1f us  %7.1f GB/s\n", name, ms / reps * 1e3, (double)batch * 4 / (ms / reps * 1e-3) / 1e9);
+}
+
 template <typename K>
 static void run(const char* name, K kern, int grid, const float* x, const long long* lab, float* sink, int B, long long HW, int shmem = 0) {
     hipEvent_t e0, e1;
@@ -71,6 +120,16 @@ int main() {
         run("4 x 4 planes, nt", plane_kernel<true, 4, 0>, grid, x, lab, sink, B, HW);
         run("16 planes at once, nt, + 1 exp per element", plane_kernel<true, 1, 1>, grid, x, lab, sink, B, HW);
         run("16 planes at once, nt, + 3 exp per element", plane_kernel<true, 1, 3>, grid, x, lab, sink, B, HW);
+    }
+    {
+        float* tiles;
+        CK(hipMalloc(&tiles, (size_t)4 * 8 * 8 * 4 * 512 * 512 * 4));
+        CK(hipMemset(tiles, 0, (size_t)4 * 8 * 8 * 4 * 512 * 512 * 4));
+        for (int r = 0; r < 2; ++r) {
+            run_tiles("d4 tile read pattern (4 x [32 x 256 B] + 4 x [64 x 128 B] per chunk)", 0, tiles, sink);
+            run_tiles("same bytes, 8 KB contiguous per view and workgroup", 1, tiles, sink);
+        }
+        CK(hipFree(tiles));
     }
     // occupancy: dynamic LDS caps the resident workgroups per CU (4 waves each): 160 KB / lds
     for (int lds : {0, 20 * 1024, 32 * 1024, 40 * 1024, 53 * 1024, 80 * 1024, 160 * 1024}) {

@@ -53,6 +53,11 @@ def main():
     for name, v in sorted(ks.items(), key=lambda kv: -sum(d for d, _ in kv[1])):
         d = [x for x, _ in v]
         lines.append(f"| `{short(name)}` | {len(d)} | {sum(d) / 1e6:.3f} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {100 * sum(d) / total:.1f} |")
+    band = [n for n in ks if "band_merge_kernel" in n]
+    if band:
+        d = [x for x, _ in ks[band[0]]]
+        lines += ["", f"Dominant kernel `{short(band[0])}`: {len(d)} launches (20 per image: 18 bands of 38 tiles, the first and last of 19), "
+                      f"average {sum(d) / len(d) / 1e3:.2f} us over all of them, as in bench.py's roofline block."]
     accum = [n for n in ks if "view_accum_kernel" in n]
     if accum:
         d = sorted(x for x, _ in ks[accum[0]])
@@ -86,12 +91,25 @@ def main():
             traffic["view_accum_d4_bytes_per_launch"] = int(b)
             traffic["view_accum_d4_read_bytes"] = int(f * 2 * 1024)
             traffic["view_accum_d4_write_bytes"] = int(w * 1024)
+        if "band_merge_kernel" in k and "6166440" in k:
+            traffic["band_merge_d4_bytes_per_launch"] = int(b)
+            traffic["band_merge_d4_read_bytes"] = int(f * 2 * 1024)
+            traffic["band_merge_d4_write_bytes"] = int(w * 1024)
         if "merge_div" in k:
             traffic["merge_bytes_per_launch"] = int(b)
             notes.append(f"  (calibration: the merge kernel must read 524 288 000 B and write 419 430 400 B; measured {f * 2 * 1024:.0f} / {w * 1024:.0f})")
     open(os.path.join(ROOT, "profiles", f"{tag}_pmc.md"), "w").write(f"# {tag}: rocprofv3 --pmc <counter> --kernel-trace (one pass per counter group)\n\n" + "\n".join(rows + notes) + "\n")
     traffic["source"] = f"profiles/{tag}_pmc.md"
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        old = json.load(open(tj))      # keep what another run (the incremental merger, --no-defer) measured
+    except Exception:
+        old = {}
+    if "view_accum_d4_bytes_per_launch" in old and "view_accum_d4_bytes_per_launch" not in traffic:
+        for k in ("view_accum_d4_bytes_per_launch", "view_accum_d4_read_bytes", "view_accum_d4_write_bytes"):
+            traffic[k] = old[k]
+        traffic["view_accum_source"] = old.get("view_accum_source", old.get("source", "").replace("_pmc.md", "_pmc_incremental.md"))
+    json.dump(traffic, open(tj, "w"), indent=1)
     print("\n".join(lines[-3:]))
     print("\n".join(notes))
 
