@@ -680,3 +680,27 @@ def test_deferred_merger_fallbacks_and_restrictions(dev):
     odd = ImageSlicer((300, 300, 3), 130, 65, weight="mean")
     mo = TileMerger(odd.target_shape, 1, odd.weight, device=dev, crops=odd.crops, defer=True)
     assert mo._bands is None and not mo._defer_active
+
+
+def test_deferred_band_merge_fuzz(dev):
+    """Random block-aligned geometries, view groups, reductions, channel counts and batch sizes: deferred == incremental, bit
+    for bit (where the geometry is not deferrable the merger must fall back silently and still agree)."""
+    rng = np.random.default_rng(77)
+    ran = 0
+    for case in range(14):
+        th = int(rng.choice([64, 128, 192, 256]))
+        square = bool(rng.integers(0, 2))
+        tw = th if square else int(rng.choice([64, 128, 256]))
+        sy = int(rng.choice([s for s in (32, 64, 96, 128, 192, 256) if s <= th]))
+        sx = int(rng.choice([s for s in (64, 128, 192, 256) if s <= tw]))
+        shape = (int(rng.integers(th, 4 * th)), int(rng.integers(tw, 4 * tw)))
+        group = str(rng.choice(["d4", "d2", "flips", "fliplr", "flipud"] if th == tw else ["d2", "flips", "fliplr", "flipud"]))
+        reduction = str(rng.choice(["mean", "sum", "gmean"]))
+        C = int(rng.integers(1, 5))
+        bs = int(rng.integers(1, 10))
+        try:
+            m = _deferred_case(dev, shape, (th, tw), (sy, sx), C, group, reduction, torch.float32, bs, images=1, seed=case)
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: shape={shape} tile={(th, tw)} step={(sy, sx)} C={C} {group}/{reduction} bs={bs}: {e}") from e
+        ran += int(m._bands is not None and m._bands_done > 0)
+    assert ran >= 8      # most of the cases really took the deferred path
