@@ -16,8 +16,9 @@ dev = torch.device("cuda:0")
 slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
 crops = slicer.crops
 x = torch.randn((64, 4, 512, 512), device=dev)
-planned = len(sys.argv) > 1 and sys.argv[1] == "planned"
-m = TileMerger(slicer.target_shape, 4, slicer.weight, device=dev, crops=crops if planned else None)
+planned = len(sys.argv) > 1 and sys.argv[1] in ("planned", "deferred")
+deferred = len(sys.argv) > 1 and sys.argv[1] == "deferred"
+m = TileMerger(slicer.target_shape, 4, slicer.weight, device=dev, crops=crops if planned else None, defer=deferred)
 batches = [crops[b0:b0 + 8] for b0 in range(0, len(crops), 8)]
 tensors = [x[:8 * len(c)] for c in batches]
 
@@ -42,7 +43,7 @@ for _ in range(20):
     image()
 host = (time.perf_counter() - t0) / 20
 torch.cuda.synchronize()
-print(f"host issue per image: {host * 1e3:.3f} ms = {host / 46 * 1e6:.1f} us per integrate call ({'planned' if planned else 'unplanned'})")
+print(f"host issue per image: {host * 1e3:.3f} ms = {host / 46 * 1e6:.1f} us per integrate call ({'deferred' if deferred else 'planned' if planned else 'unplanned'})")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):
