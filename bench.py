@@ -2,17 +2,20 @@
 """Headline benchmark: megapixels/s of the tiled + d4-TTA merge on 5000x5000 (BASELINE.json configs[1]).
 
 One *step* = one full pass of the hot path over one 5000x5000x3 image: 361 tiles (512/256, pyramid window) whose
-8 d4-view model outputs (C=4, fp32, 12.1 GB) are already resident in HBM -> fused de-augment + mean + weighted
-accumulation in batches of 8 tiles (46 HIP launches) -> merge (image / norm_mask).  The model forward is excluded
-(the config's "dummy UNet" only produces these tensors).  Every step starts from (logically) zero accumulators:
-`reset()` re-arms the first-touch bitmap, so the first write of each block is a store and no memset is needed.  The
-normaliser `norm_mask` depends only on the crop list and the window (SURVEY 8d counts it as precomputable, not
-compulsory, traffic): the merger is constructed with the slicer's crop list (`TileMerger(..., crops=tiler.crops)`),
-precomputes it, and divides every block in the launch that brings its last tile -- `merge()` then returns the finished
-map, so the accumulate kernel does the whole region.  A/B switches: `--unplanned` (no crop list: the accumulate kernels
-skip the normaliser, `merge()` builds it from the logged crops, reuses it while the log repeats, and runs the separate
-division pass), `--memset-accumulators` (kernel-maintained normaliser, memset accumulators: the reference's literal
-data flow).
+8 d4-view model outputs (C=4, fp32, 12.1 GB) are already resident in HBM -> `integrate_batch_deaugment` (fused de-augment +
+mean + weighted blend) in batches of 8 tiles -> `merge()` (image / norm_mask).  The model forward is excluded (the
+config's "dummy UNet" only produces these tensors).  Every step starts from a `reset()` merger and ends with the merged
+[C, 5120, 5120] map in HBM.
+
+Default merger: `TileMerger(..., crops=tiler.crops, defer=True)`.  The crop list is known before the first batch (the
+README loop has it), so the normaliser `norm_mask` -- which depends only on the crop list and the window (not
+compulsory traffic) -- is precomputed, and the merger keeps references to the batches it is handed (they stay resident
+and unmodified here) and merges each 256-row band of the image with ONE launch as soon as its last tile has arrived: 20
+launches per image that read every model output once and write the merged map once; no accumulator in HBM.  A/B switches:
+`--no-defer` (planned, incremental: 46 accumulate launches, every block divided by the normaliser in the launch that
+brings its last tile), `--unplanned` (no crop list: accumulate kernels + lazily built normaliser + separate division
+pass), `--memset-accumulators` (kernel-maintained normaliser, memset accumulators: the reference's literal data flow).
+All four produce bit-identical results (tests/test_tiles_gpu.py).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
