@@ -62,8 +62,10 @@ __global__ __launch_bounds__(512) void tile_read_kernel(const float* __restrict_
         const float* p = p0 + k * view_stride;
         long long off;
         if (SEG == 1) off = (long long)chunk * 2048 + tid * 4;
-        else if (k < 4) off = (long long)(cy * 32 + (tid >> 4)) * 512 + cx * 64 + 4 * (tid & 15);
-        else off = (long long)(cx * 64 + (tid >> 3)) * 512 + cy * 32 + 4 * (tid & 7);
+        else if (SEG == 2 || (SEG == 0 && k < 4)) off = (long long)(cy * 32 + (tid >> 4)) * 512 + cx * 64 + 4 * (tid & 15);          // 32 rows x 256 B
+        else if (SEG == 3 || SEG == 0) off = (long long)(cx * 64 + (tid >> 3)) * 512 + cy * 32 + 4 * (tid & 7);                      // 64 rows x 128 B
+        else if (SEG == 4) off = (long long)((chunk / 4) * 16 + (tid >> 5)) * 512 + (chunk % 4) * 128 + 4 * (tid & 31);             // 16 rows x 512 B
+        else off = (long long)((chunk / 2) * 8 + (tid >> 6)) * 512 + (chunk % 2) * 256 + 4 * (tid & 63);                             // 8 rows x 1 KB
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p + off));
     }
 #pragma unroll
@@ -80,8 +82,14 @@ static void run_tiles(const char* name, int seg, const float* src, float* sink) 
     for (int i = 0; i < reps + 3; ++i) {
         if (i == 3) CK(hipEventRecord(e0));
         const float* b = src + (i % nbuf) * batch;
-        if (seg) hipLaunchKernelGGL(tile_read_kernel<1>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C);
-        else hipLaunchKernelGGL(tile_read_kernel<0>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C);
+        switch (seg) {
+            case 0: hipLaunchKernelGGL(tile_read_kernel<0>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+            case 1: hipLaunchKernelGGL(tile_read_kernel<1>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+            case 2: hipLaunchKernelGGL(tile_read_kernel<2>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+            case 3: hipLaunchKernelGGL(tile_read_kernel<3>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+            case 4: hipLaunchKernelGGL(tile_read_kernel<4>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+            default: hipLaunchKernelGGL(tile_read_kernel<5>, dim3(grid), dim3(512), 0, 0, b, sink, ntiles, C); break;
+        }
     }
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
@@ -128,6 +136,10 @@ int main() {
         for (int r = 0; r < 2; ++r) {
             run_tiles("d4 tile read pattern (4 x [32 x 256 B] + 4 x [64 x 128 B] per chunk)", 0, tiles, sink);
             run_tiles("same bytes, 8 KB contiguous per view and workgroup", 1, tiles, sink);
+            run_tiles("all 8 views as 32 rows x 256 B", 2, tiles, sink);
+            run_tiles("all 8 views as 64 rows x 128 B", 3, tiles, sink);
+            run_tiles("all 8 views as 16 rows x 512 B", 4, tiles, sink);
+            run_tiles("all 8 views as 8 rows x 1 KB", 5, tiles, sink);
         }
         CK(hipFree(tiles));
     }
