@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--tunable", action="append", default=[], help="key=value passed to ptb_set_tunable (A/B experiments)")
     ap.add_argument("--unplanned", action="store_true", help="A/B: TileMerger without crops= (lazily built norm_mask + separate merge pass)")
     ap.add_argument("--no-defer", action="store_true", help="A/B: planned merger without deferred band merging (accumulators in HBM)")
+    ap.add_argument("--ramp-ms", type=float, default=300.0, help="untimed GPU work before the warm-up, so that an idle GPU is out of its "
+                    "low-power state when the W warm-up steps begin (no measurable effect on the boxes of the dev pool)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
@@ -152,10 +154,13 @@ def main():
     crops = slicer.crops[my_tiles]
     batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    outputs = torch.empty((VIEWS * len(crops), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
-    for b0, b1 in batches:  # chunk-major per batch: rows [8*b0, 8*b1) hold view k of tiles b0..b1 at k*nb + j
-        outputs[VIEWS * b0:VIEWS * b1].normal_(generator=gen)
-    batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]
+    if os.environ.get("PTB_BENCH_ONE_BUFFER", "0") == "1":   # A/B: all model outputs as slices of one 12.1 GB allocation
+        outputs = torch.empty((VIEWS * len(crops), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
+        batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]
+    else:   # like a model would leave them: one tensor per batch (chunk-major: view k of tile j at row k * nb + j)
+        batch_tensors = [torch.empty((VIEWS * (b1 - b0), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32) for b0, b1 in batches]
+    for t in batch_tensors:
+        t.normal_(generator=gen)
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
 
     if not sharded:
@@ -231,6 +236,13 @@ def main():
             print("[bench] falling back to the unplanned merger", file=sys.stderr)
             planned = False
             merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
+    # power management: keep a GPU that has been idle (a fresh box, the seconds this process spent importing torch) busy for a
+    # moment before the warm-up (untimed, like the build)
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync()
