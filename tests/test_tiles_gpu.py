@@ -704,3 +704,57 @@ def test_deferred_band_merge_fuzz(dev):
             raise AssertionError(f"case {case}: shape={shape} tile={(th, tw)} step={(sy, sx)} C={C} {group}/{reduction} bs={bs}: {e}") from e
         ran += int(m._bands is not None and m._bands_done > 0)
     assert ran >= 8      # most of the cases really took the deferred path
+
+
+def test_merge_band_c_abi_contract(dev):
+    """ptb_merge_band through ctypes: a band of plain (identity view) tiles equals the oracle's merge rows; tiles that do not
+    cover the band, too many tiles and misaligned origins are refused with the documented codes, nothing is launched."""
+    from pytorch_toolbelt_amd import _native as N
+
+    lib = N.load()
+    C, th, tw, H, W = 2, 64, 64, 128, 256
+    w = TO.pyramid_window(tw, th)[0].astype(np.float32)
+    weight = torch.from_numpy(w).to(dev)
+    xs = np.array([0, 32, 64, 128, 192], dtype=np.int64)
+    ys = np.array([0, 0, 0, 0, 0], dtype=np.int64)
+    tiles = torch.randn((5, C, th, tw), device=dev)
+    merged = torch.full((C, H, W), float("nan"), device=dev)
+    norm_full = torch.zeros((1, H, W), device=dev)
+    for x in xs:
+        norm_full[0, 0:th, x:x + tw] += weight
+    src = np.array([tiles[i].data_ptr() for i in range(5)], dtype=np.uint64)
+    vs = np.full(5, C * th * tw, dtype=np.int64)
+    views = N.int_array([N.IDENT])
+
+    def call(n=5, y0=0, y1=64, xs_=xs, ys_=ys, src_=src):
+        with N.on_device(dev):
+            return lib.ptb_merge_band(merged.data_ptr(), norm_full.data_ptr(), weight.data_ptr(), src_.ctypes.data, vs.ctypes.data, N.F32, 1,
+                                      views, N.RED_SUM, xs_.ctypes.data, ys_.ctypes.data, n, C, th, tw, H, W, y0, y1, N.stream_ptr(dev))
+
+    assert call() == 0
+    st = TO.merger_new((H, W), C, w)
+    TO.merger_integrate(st, tiles.cpu().numpy(), np.stack([xs, ys, np.full(5, tw), np.full(5, th)], axis=1))
+    want = TO.merger_merge(st)
+    got = merged.cpu().numpy()
+    cover = np.zeros(W, dtype=bool)
+    for x in xs:
+        cover[x:x + tw] = True
+    assert np.array_equal(got[:, :64, cover], want[:, :64, cover])
+    assert np.isnan(got[:, 64:]).all() and np.isnan(got[:, :64, ~cover]).all()      # nothing outside the band / the tiles is touched
+    assert call(y0=0, y1=96) == -1                                                  # PTB_EINVAL: the tiles end at row 64
+    assert call(y0=32, y1=64) == 0                                                  # a sub-band is fine
+    bad_y = ys.copy(); bad_y[2] = 32
+    assert call(ys_=bad_y) == -1                                                    # tile 2 does not cover rows 0..32
+    odd = xs.copy(); odd[1] = 34
+    assert call(xs_=odd) == -2                                                      # PTB_EUNSUPPORTED: off the 4-pixel grid
+    many_x = np.zeros(49, dtype=np.int64); many_y = np.zeros(49, dtype=np.int64)
+    many_src = np.full(49, src[0], dtype=np.uint64)
+    global_vs = np.full(49, C * th * tw, dtype=np.int64)
+    with N.on_device(dev):
+        rc = lib.ptb_merge_band(merged.data_ptr(), norm_full.data_ptr(), weight.data_ptr(), many_src.ctypes.data, global_vs.ctypes.data, N.F32, 1,
+                                views, N.RED_SUM, many_x.ctypes.data, many_y.ctypes.data, 49, C, th, tw, H, W, 0, 64, N.stream_ptr(dev))
+    assert rc == -2                                                                 # more than 48 tiles in one band
+    five = np.zeros(5, dtype=np.int64)
+    assert call(xs_=five) == -2                                                     # five tiles over one pixel (MAX_COVER = 4)
+    out_of_map = xs.copy(); out_of_map[4] = 224
+    assert call(xs_=out_of_map) == -4                                               # PTB_EBOUNDS
