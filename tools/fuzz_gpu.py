@@ -6,7 +6,8 @@
 1. TileMerger in its three modes (lazy / kernel-maintained normaliser / planned) over random slicer geometries, bit-exact
    against the oracle (the test function of tests/test_tiles_gpu.py with more seeds);
 2. fused de-augment merges over random groups x reductions x input dtypes x planned-or-not, 2e-5 relative;
-3. the elementwise losses and soft cross entropy over random (odd) shapes and options against the float64 oracle.
+3. the elementwise losses and soft cross entropy over random (odd) shapes and options against the float64 oracle;
+4. deferred band merging vs the incremental merger (bit-exact), 5. Dice / Jaccard / fused region losses vs the fp64 oracle.
 Prints one line per failure and a summary; exit code 1 on any failure."""
 import os
 import sys
@@ -132,10 +133,74 @@ def fuzz_losses(seeds):
     return bad
 
 
+def fuzz_deferred(seeds):
+    """Deferred band merging vs the incremental merger, bit for bit, over random block-aligned geometries."""
+    import test_tiles_gpu as T
+
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        th = int(rng.choice([64, 128, 192, 256]))
+        tw = th if seed % 2 else int(rng.choice([64, 128, 256]))
+        sy = int(rng.choice([v for v in (32, 64, 96, 128, 192, 256) if v <= th]))
+        sx = int(rng.choice([v for v in (64, 128, 192, 256) if v <= tw]))
+        shape = (int(rng.integers(th, 4 * th)), int(rng.integers(tw, 4 * tw)))
+        groups = ["d4", "d2", "flips", "fliplr", "flipud"] if th == tw else ["d2", "flips", "fliplr", "flipud"]
+        group = groups[seed % len(groups)]
+        red = ["mean", "sum", "gmean", "hmean"][seed % 4]
+        dtype = [torch.float32, torch.float32, torch.float16, torch.bfloat16][(seed // 3) % 4]
+        try:
+            T._deferred_case(dev, shape, (th, tw), (sy, sx), int(rng.integers(1, 5)), group, red, dtype, int(rng.integers(1, 10)), images=2, seed=seed)
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("deferred FAIL seed", seed, shape, (th, tw), (sy, sx), group, red, dtype, repr(e)[:300])
+    return bad
+
+
+def fuzz_region_losses(seeds):
+    """Dice / Jaccard / fused focal+Dice+Jaccard (straight-line and generic kernels, epilogue kernel) vs the fp64 oracle."""
+    from oracle import losses_oracle as LO
+
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        C = int(rng.integers(2, 20))
+        B = int(rng.integers(1, 4))
+        H, W = (int(rng.choice([16, 32, 48])), int(rng.choice([16, 32, 64]))) if seed % 3 else (int(rng.integers(5, 40)), int(rng.integers(5, 40)))
+        x = (rng.standard_normal((B, C, H, W)) * rng.choice([1.0, 3.0, 8.0])).astype(np.float32)
+        lab = rng.integers(0, C, (B, H, W))
+        ign = [None, 0, 255][seed % 3]
+        if ign == 255:
+            lab[0, : H // 3] = 255
+        kw = dict(log_loss=bool(seed % 2), smooth=float(rng.choice([0.0, 1.0])))
+        xt, lt = torch.from_numpy(x).to(dev), torch.from_numpy(lab).to(dev)
+        try:
+            got = float(L.DiceLoss("multiclass", ignore_index=ign, **kw)(xt, lt))
+            want = LO.dice_loss(x, lab, "multiclass", ignore_index=ign, **kw)
+            assert abs(got - want) <= 2e-5 * (1 + abs(want)), ("dice", got, want)
+            if ign is None:
+                got = float(L.JaccardLoss("multiclass", **kw)(xt, lt))
+                want = LO.jaccard_loss(x, lab, "multiclass", **kw)
+                assert abs(got - want) <= 2e-5 * (1 + abs(want)), ("jaccard", got, want)
+                xg = xt.clone().requires_grad_(True)
+                fused = L.FocalDiceJaccardLoss("multiclass", **kw)(xg, lt)
+                want = LO.binary_focal_loss(x, lab) + LO.dice_loss(x, lab, "multiclass", **kw) + LO.jaccard_loss(x, lab, "multiclass", **kw)
+                assert abs(float(fused) - want) <= 2e-5 * (1 + abs(want)), ("fused", float(fused), want)
+                fused.backward()
+                x2 = xt.clone().requires_grad_(True)
+                parts = L.BinaryFocalLoss()(x2, lt) + L.DiceLoss("multiclass", **kw)(x2, lt) + L.JaccardLoss("multiclass", **kw)(x2, lt)
+                parts.backward()
+                assert torch.allclose(xg.grad, x2.grad, rtol=2e-4, atol=1e-8), ("fused grad", float((xg.grad - x2.grad).abs().max()))
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("region loss FAIL seed", seed, (B, C, H, W), ign, kw, repr(e)[:300])
+    return bad
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     seeds = range(first, first + count)
-    total = fuzz_merger_modes(seeds) + fuzz_fused(seeds) + fuzz_losses(seeds)
-    print(f"fuzz: {3 * count} cases, {total} failures")
+    total = fuzz_merger_modes(seeds) + fuzz_fused(seeds) + fuzz_losses(seeds) + fuzz_deferred(seeds) + fuzz_region_losses(seeds)
+    print(f"fuzz: {5 * count} cases, {total} failures")
     sys.exit(1 if total else 0)
