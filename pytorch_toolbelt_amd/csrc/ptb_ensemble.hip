@@ -140,10 +140,17 @@ __global__ __launch_bounds__(256) void ensemble_softmax_kernel(const EnsembleArg
             float m[PIX], z[PIX];
 #pragma unroll
             for (int j = 0; j < PIX; ++j) { m[j] = -INFINITY; z[j] = 0.f; }
+            // request every class plane of this model first (only the loads sit behind the `c < C` guards), then reduce:
+            // with the arithmetic inside the guarded block each load was waited for before the next one was issued
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+                for (int j = 0; j < PIX; ++j) x[c][j] = 0.f;
+                if (c < a.C) ld_pix<PIX>(a.in[t] + base + (long long)c * plane, x[c]);
+            }
 #pragma unroll
             for (int c = 0; c < CREG; ++c) {
                 if (c < a.C) {
-                    ld_pix<PIX>(a.in[t] + base + (long long)c * plane, x[c]);
 #pragma unroll
                     for (int j = 0; j < PIX; ++j) {
                         x[c][j] = __fmul_rn(x[c][j], a.temperature);
