@@ -1126,6 +1126,108 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegA
     }
 }
 
+// Straight-line instance of the fused backward for the common case (hard labels, C <= CREG padded with -inf, HW % 256 == 0,
+// default focal configuration; see seg_fwd_lean_kernel): no divergent control flow, only the loads and the stores of the
+// classes beyond C are guarded.
+template <int CREG>
+__global__ __launch_bounds__(256, 3) void seg_fused_bwd_lean_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
+                                                                    const float* __restrict__ gP, float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const float k1 = coef[0], k2 = coef[1];
+    // dL/dP_c is wave-uniform (a scalar operand); dL/dI only matters for the label class of a pixel and is fetched per lane
+    // (gI[label], 4 loads per group).  Keeping both as per-class values in vector registers costs 32 VGPRs and spilled.
+    auto g_p = [&](int c) { return c < C ? gP[c] : 0.f; };
+    const long long per_img = a.HW / 256;
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const int b = (int)(g / per_img);
+        const long long i0 = (g - (long long)b * per_img) * 256 + (long long)lane * 4;
+        const long long base = (long long)b * C * a.HW + i0;
+        int lab[4];
+        {
+            const long long* lp = a.labels + (long long)b * a.HW + i0;
+            const longlong2 l01 = *reinterpret_cast<const longlong2*>(lp), l23 = *reinterpret_cast<const longlong2*>(lp + 2);
+            lab[0] = (int)l01.x; lab[1] = (int)l01.y; lab[2] = (int)l23.x; lab[3] = (int)l23.y;
+        }
+        float gil[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gil[k] = gI[min(max(lab[k], 0), C - 1)];
+        float xv[CREG][4];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[c][k] = -INFINITY;
+            if (c < C) load_px<4>(a.logits + base + (long long)c * a.HW, xv[c], true);
+        }
+        float inv[4], em[4], dot[4], mx[4];
+        bool redo_all[4], redo[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float m = xv[0][k];
+#pragma unroll
+            for (int c = 1; c < CREG; ++c) m = fmaxf(m, xv[c][k]);
+            const float M = m * kLog2e;
+            float d = 0.f, dd = 0.f, ulab = 0.f;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+                const float u = fexp_sub(xv[c][k], M);
+                xv[c][k] = u;
+                d += u;
+                dd = __builtin_fmaf(g_p(c), u, dd);
+                ulab = lab[k] == c ? u : ulab;
+            }
+            dd = __builtin_fmaf(gil[k], ulab, dd);
+            inv[k] = rcp(d);
+            dot[k] = dd * inv[k];
+            em[k] = ex2(-M);
+            mx[k] = m;
+            redo_all[k] = !(fabsf(m) <= 60.f);
+            redo[k] = redo_all[k];
+        }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            float out[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = xv[c][k];
+                const bool t = lab[k] == c;
+                const float r = rcp(u + em[k]);
+                const float ps = u * r, qs = em[k] * r;
+                const float pt = t ? ps : qs, omp = t ? qs : ps;
+                const float ce = -lg2(pt) * kLn2;
+                const float pq = ps * qs;
+                const float df = -2.0f * omp * (t ? pq : -pq);
+                float gx = k1 * (df * ce + omp * omp * (t ? -qs : ps)) + k2 * df;
+                gx = __builtin_fmaf(u * inv[k], (t ? gil[k] : 0.f) + (g_p(c) - dot[k]), gx);
+                out[k] = gx;
+                redo[k] = redo[k] || (t && ps < 1e-36f);
+            }
+            if (c < C) store_px<4>(grad + base + (long long)c * a.HW, out, true);
+        }
+        bool any_redo = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) any_redo = any_redo || redo[k];
+        if (__any(any_redo)) {   // exact rewrite of the elements the fast formulas cannot represent (never on sane logits)
+            const FocalCfg cfg = focal_cfg(a);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!redo[k]) continue;
+                for (int c = 0; c < C; ++c) {
+                    if (!redo_all[k] && c != lab[k]) continue;
+                    const float x = a.logits[base + (long long)c * a.HW + k];
+                    const float t = lab[k] == c ? 1.f : 0.f;
+                    float ce, f, df, p;
+                    focal_parts<true, true>(x, t, cfg, ce, f, df, p);
+                    float gx = k1 * (df * ce + f * (p - t)) + k2 * df;
+                    gx += fexp(x - mx[k]) * inv[k] * (gI[c] * t + gP[c] - dot[k]);
+                    grad[base + (long long)c * a.HW + k] = gx;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ softmax focal
 // softmax_focal_loss_with_logits (functional.py:110-173): per pixel sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c, masked by
 // label != ignore_index.  sums[0] = sum of pixel losses, sums[1] = sum of ALL focal terms (the reference does not
@@ -1625,7 +1727,12 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
                           else hipLaunchKernelGGL((seg_fused_bwd_kernel<4, 16, D, false>), grid, block, 0, s, a, coef, gI, gP, grad); } while (0)
     if (labels && prob == PROB_SOFTMAX) {
         const bool plain = g2 && !class_weights && !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
-        if (plain) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true, true>), grid, block, 0, s, a, coef, gI, gP, grad);
+        if (plain && !g_force_scalar && HW % 256 == 0) {
+            const dim3 lgrid(grid_for_groups(HW / 256 * B, kGridStats));
+            if (C <= 4) hipLaunchKernelGGL((seg_fused_bwd_lean_kernel<4>), lgrid, block, 0, s, a, coef, gI, gP, grad);
+            else if (C <= 8) hipLaunchKernelGGL((seg_fused_bwd_lean_kernel<8>), lgrid, block, 0, s, a, coef, gI, gP, grad);
+            else hipLaunchKernelGGL((seg_fused_bwd_lean_kernel<16>), lgrid, block, 0, s, a, coef, gI, gP, grad);
+        } else if (plain) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true, true>), grid, block, 0, s, a, coef, gI, gP, grad);
         else if (g2) hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, true>), grid, block, 0, s, a, coef, gI, gP, grad);
         else hipLaunchKernelGGL((seg_fused_bwd_shared_kernel<4, 16, false>), grid, block, 0, s, a, coef, gI, gP, grad);
     } else if (labels) PTB_FUSED(false); else PTB_FUSED(true);
