@@ -539,17 +539,25 @@ def test_straight_line_forward_kernels_against_oracle_and_generic_kernels(C, ign
     probs = torch.softmax(logits, 1)
     x64, l64 = logits.numpy(), labels.numpy()
     lib = N.load()
-    results = []
+    results, grads = [], []
     for scalar in (0, 1):
         lib.ptb_set_tunable(1, scalar)
         try:
             d_log = float(L.DiceLoss("multiclass", ignore_index=ignore_index, smooth=0.5)(xl, ll))
             d_prob = float(L.DiceLoss("multiclass", from_logits=False, ignore_index=ignore_index)(probs.to(dev), ll))
-            fused = float(L.FocalDiceJaccardLoss("multiclass")(xl, ll.clamp(max=C - 1))) if ignore_index is None else 0.0
+            fused, grad = 0.0, None
+            if ignore_index is None:
+                xg = xl.clone().requires_grad_(True)
+                loss = L.FocalDiceJaccardLoss("multiclass")(xg, ll)
+                loss.backward()          # seg_fused_bwd_lean_kernel (C padded to 4 / 8 / 16) vs the generic backward kernels
+                fused, grad = float(loss), xg.grad
         finally:
             lib.ptb_set_tunable(1, 0)
         results.append((d_log, d_prob, fused))
+        grads.append(grad)
     assert results[0] == pytest.approx(results[1], rel=2e-6, abs=1e-6)
+    if ignore_index is None:
+        torch.testing.assert_close(grads[0], grads[1], rtol=5e-5, atol=1e-9)
     assert results[0][0] == pytest.approx(LO.dice_loss(x64, l64, "multiclass", ignore_index=ignore_index, smooth=0.5), abs=1e-5)
     assert results[0][1] == pytest.approx(LO.dice_loss(probs.numpy(), l64, "multiclass", from_logits=False, ignore_index=ignore_index), abs=1e-5)
     if ignore_index is None:
