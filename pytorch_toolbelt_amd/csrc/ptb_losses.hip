@@ -1443,6 +1443,178 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
     if (MODE == 0) block_add2(s_loss, s_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * 2, lane, wave);
 }
 
+// Straight-line instances of the softmax focal loss for the common case (C <= CREG padded with -inf, HW % 256 == 0, gamma = 2,
+// no class weights, no reduced threshold; see seg_fwd_lean_kernel).  u = exp(x - m) stays in the registers; the BCE term's
+// sigmoid comes from u and em = exp(-m) like in the wave-uniform fast path of softmax_focal_kernel, and a wave that holds a
+// pixel with |m| > 60 or a logit 80 below its maximum falls back to that kernel's exact formulas for the whole group.
+template <int CREG, int MODE>
+__global__ __launch_bounds__(256, 3) void softmax_focal_lean_kernel(const SmfArgs a, const float* __restrict__ coef,
+                                                                    const float* __restrict__ grad_pix, float* __restrict__ grad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    double s_loss = 0.0, s_term = 0.0;
+    const float k1 = MODE ? coef[0] : 0.f, k2 = MODE ? coef[1] : 0.f;
+    const long long per_img = a.HW / 256;
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const int b = (int)(g / per_img);
+        const long long i0 = (g - (long long)b * per_img) * 256 + (long long)lane * 4;
+        const long long base = (long long)b * C * a.HW + i0;
+        int tgt[4];
+        bool ign[4];
+        {
+            const long long* lp = a.labels + (long long)b * a.HW + i0;
+            const longlong2 l01 = *reinterpret_cast<const longlong2*>(lp), l23 = *reinterpret_cast<const longlong2*>(lp + 2);
+            const long long l64[4] = {l01.x, l01.y, l23.x, l23.y};
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ign[k] = l64[k] == a.ignore_label;
+                bad = bad || (!ign[k] && (l64[k] < 0 || l64[k] >= C));
+                tgt[k] = ign[k] ? 0 : (int)l64[k];          // masked_fill(target, ignore, 0), functional.py:139
+            }
+            if (MODE == 0 && bad) *a.error_flag = 1;
+        }
+        float gp[4] = {1.f, 1.f, 1.f, 1.f};
+        if (MODE && grad_pix) load_px<4>(grad_pix + (long long)b * a.HW + i0, gp, true);
+        float xv[CREG][4];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xv[c][k] = -INFINITY;
+            if (c < C) load_px<4>(a.logits + base + (long long)c * a.HW, xv[c], true);
+        }
+        float mx[4], inv[4], em[4];
+        bool tame = true;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float m = xv[0][k], lo = xv[0][k];
+#pragma unroll
+            for (int c = 1; c < CREG; ++c) { m = fmaxf(m, xv[c][k]); lo = (c < C) ? fminf(lo, xv[c][k]) : lo; }
+            mx[k] = m;
+            tame = tame && (fabsf(m) <= 60.f) && (lo - m >= -80.f);
+        }
+        if (__any(!tame)) {
+            // exact formulas for this group (never on sane logits): rolled loops over the classes, logits re-read from L2 --
+            // small code and few registers, so the fast path keeps its occupancy
+            float lsum = 0.f, tsum = 0.f, pl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {   // (unrolled: tgt / ign / mx / gp are register arrays and need static indices)
+                const float* xp = a.logits + base + k;
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) d += fexp(xp[(long long)c * a.HW] - mx[k]);
+                const float iv = rcp(d);
+                float loss = 0.f, dh = 0.f, dd = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float x = xp[(long long)c * a.HW];
+                    const float t = c == tgt[k] ? 1.f : 0.f;
+                    const float p = fexp(x - mx[k]) * iv;
+                    const float pt = (1.f - t) * p + t * (1.f - p);
+                    const float bce = fmaxf(x, 0.f) - x * t + sigmoid_parts(x).log1pe;
+                    const float df = 2.0f * pt * (1.f - 2.f * t);
+                    loss += pt * pt * bce; tsum += pt * pt;
+                    dh += bce * df * p; dd += df * p;
+                }
+                pl[k] = ign[k] ? 0.f : loss;
+                lsum += pl[k];
+                if (MODE) {
+                    const float g1 = ign[k] ? 0.f : k1 * gp[k];
+                    for (int c = 0; c < C; ++c) {
+                        const float x = xp[(long long)c * a.HW];
+                        const float t = c == tgt[k] ? 1.f : 0.f;
+                        const float p = fexp(x - mx[k]) * iv;
+                        const float pt = (1.f - t) * p + t * (1.f - p);
+                        const Sig sg = sigmoid_parts(x);
+                        const float bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
+                        const float df = 2.0f * pt * (1.f - 2.f * t);
+                        grad[base + (long long)c * a.HW + k] = g1 * (p * (bce * df - dh) + pt * pt * (sg.p - t)) + k2 * (p * (df - dd));
+                    }
+                }
+            }
+            if (MODE == 0) {
+                s_loss += (double)lsum; s_term += (double)tsum;
+                if (a.pixel_out) store_px<4>(a.pixel_out + (long long)b * a.HW + i0, pl, true);
+            }
+            continue;
+        }
+        float loss[4], dh[4], dd[4];
+        float tsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float M = mx[k] * kLog2e;
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+                const float u = fexp_sub(xv[c][k], M);
+                xv[c][k] = u;
+                d += u;
+            }
+            inv[k] = rcp(d);
+            em[k] = ex2(-M);
+            loss[k] = 0.f; dh[k] = 0.f; dd[k] = 0.f;
+        }
+        // pass 1: the pixel loss (forward) or the two softmax-Jacobian dot products (backward)
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = xv[c][k];
+                const bool hit = c == tgt[k];
+                const float p = u * inv[k];
+                const float r = rcp(u + em[k]);
+                const float bce = -lg2((hit ? u : em[k]) * r) * kLn2;
+                const float pt = hit ? 1.f - p : p;
+                if (MODE == 0) {
+                    const float f = pt * pt;
+                    loss[k] = __builtin_fmaf(f, bce, loss[k]);
+                    tsum += f;
+                } else {
+                    const float dfp = (hit ? -2.0f : 2.0f) * pt * p;     // df * p
+                    dh[k] = __builtin_fmaf(bce, dfp, dh[k]);
+                    dd[k] += dfp;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (MODE == 0) {
+            float ls = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { loss[k] = ign[k] ? 0.f : loss[k]; ls += loss[k]; }
+            s_loss += (double)ls;
+            s_term += (double)tsum;
+            if (a.pixel_out) store_px<4>(a.pixel_out + (long long)b * a.HW + i0, loss, true);
+        } else {
+            float g1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                g1[k] = ign[k] ? 0.f : k1 * gp[k];
+                asm volatile("" : "+v"(tgt[k]));
+                opaque(em[k]); opaque(inv[k]);   // pass 2 RECOMPUTES rcp(u + em) and u * inv: kept alive from pass 1 they cost 128 VGPRs (spills)
+            }
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) {
+                float out[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float u = xv[c][k];
+                    const bool hit = c == tgt[k];
+                    const float p = u * inv[k];
+                    const float r = rcp(u + em[k]);
+                    const float ps = u * r, qs = em[k] * r;
+                    const float bce = -lg2(hit ? ps : qs) * kLn2;
+                    const float pt = hit ? 1.f - p : p;
+                    const float df = (hit ? -2.0f : 2.0f) * pt;
+                    const float gl = __builtin_fmaf(p, bce * df - dh[k], pt * pt * (hit ? -qs : ps));
+                    out[k] = __builtin_fmaf(g1[k], gl, k2 * (p * (df - dd[k])));
+                }
+                if (c < C) store_px<4>(grad + base + (long long)c * a.HW, out, true);
+                __builtin_amdgcn_sched_barrier(0);   // one class at a time (interleaving all 64 element chains spills)
+            }
+        }
+    }
+    if (MODE == 0) block_add2(s_loss, s_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * 2, lane, wave);
+}
+
 // ------------------------------------------------------------------------------------------------ scalar epilogue
 // The [C]-sized tail of DiceLoss / JaccardLoss / the fused focal+Dice+Jaccard loss (dice.py:112-131, jaccard.py:95-113) AND
 // its derivative in one launch: as torch ops the tail is ~25 launches forward and ~40 in autograd's backward, more than the
@@ -1680,6 +1852,16 @@ extern "C" int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, con
 
 template <int MODE>
 static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix, float* grad, hipStream_t s) {
+    // forward only: the straight-line backward needs 168 VGPRs + spills for its two passes over 64 elements and measured 332 us
+    // against 275 us for the kernel below
+    if (MODE == 0 && !g_force_scalar && a.HW % 256 == 0 && a.C <= 16 && a.gamma == 2.0f && !a.class_weights && !a.reduced &&
+        vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
+        const dim3 lgrid(grid_for_groups(a.HW / 256 * a.B, kGridStream)), block(256);
+        if (a.C <= 4) hipLaunchKernelGGL((softmax_focal_lean_kernel<4, 0>), lgrid, block, 0, s, a, coef, grad_pix, grad);
+        else if (a.C <= 8) hipLaunchKernelGGL((softmax_focal_lean_kernel<8, 0>), lgrid, block, 0, s, a, coef, grad_pix, grad);
+        else hipLaunchKernelGGL((softmax_focal_lean_kernel<16, 0>), lgrid, block, 0, s, a, coef, grad_pix, grad);
+        return check_launch();
+    }
     if (vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
         const int grid = grid_for_groups((a.HW + 255) / 256 * a.B, kGridStream);
         if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);

@@ -571,3 +571,36 @@ def test_straight_line_forward_kernels_against_oracle_and_generic_kernels(C, ign
         N.load()
         from pytorch_toolbelt_amd.losses import _kernels as K
         K.flush_label_check()
+
+
+@pytest.mark.parametrize("C", [3, 7, 16])
+def test_softmax_focal_straight_line_forward(C, dev):
+    """softmax_focal_lean_kernel (forward, gamma 2, HW % 256 == 0, C padded to 4 / 8 / 16) against the fp64 oracle and the
+    generic kernel, with ignored pixels and a group of extreme logits that takes the in-kernel exact path."""
+    from pytorch_toolbelt_amd import _native as N
+
+    L = _L()
+    g = torch.Generator().manual_seed(300 + C)
+    B, H, W = 2, 16, 64
+    x = torch.randn((B, C, H, W), generator=g) * 3
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab[0, 1, :9] = -100
+    x[1, :, 4] += 70.0                       # |m| > 60: this wave's group is evaluated with the exact formulas
+    x[1, 0, 8, :7] = -140.0
+    xl, ll = x.to(dev), lab.to(dev)
+    lib = N.load()
+    outs = []
+    for scalar in (0, 1):
+        lib.ptb_set_tunable(1, scalar)
+        try:
+            outs.append(L.softmax_focal_loss_with_logits(xl, ll, reduction="none").cpu())
+        finally:
+            lib.ptb_set_tunable(1, 0)
+    torch.testing.assert_close(outs[0], outs[1], rtol=2e-5, atol=2e-6)
+    valid = lab != -100
+    oh = torch.nn.functional.one_hot(lab.masked_fill(~valid, 0), C).permute(0, 3, 1, 2).double()
+    p = torch.softmax(x.double(), 1)
+    pt = (1 - oh) * p + oh * (1 - p)
+    ref = (pt.pow(2) * torch.nn.functional.binary_cross_entropy_with_logits(x.double(), oh, reduction="none")).sum(1) * valid
+    torch.testing.assert_close(outs[0].double(), ref, rtol=2e-5, atol=1e-5)
+    assert float(L.CrossEntropyFocalLoss()(xl, ll)) == pytest.approx(float(LO.softmax_focal_loss_with_logits(x.numpy(), lab.numpy())), abs=1e-5)
