@@ -74,3 +74,36 @@ def test_views_and_merger_beyond_2g_elements(dev):
     assert float(merged[0, S - 1, S - 1]) == 1.0 and float(merged[0, S - 1, S - 80]) == 1.0 and float(merged[0, 0, 0]) == 1.0
     assert torch.isnan(merged[0, S // 2, S // 2])
     assert float(m.image[0, S - 1, S - 40]) == 2.0 and float(m.norm_mask[0, S - 1, S - 40]) == 2.0
+
+
+def test_headline_geometry_all_merger_modes_agree(dev):
+    """BASELINE configs[1] geometry at full size (5000 x 5000, 512 / 256, 361 tiles, d4, batches of 8; C = 2 to bound memory):
+    the deferred band merger, the planned merger and the plain merger give the same bits, and the result has the
+    size-independent properties of a merge (partition of unity: constant model outputs come back as that constant)."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+    crops, C = slicer.crops, 2
+    assert len(crops) == 361 and slicer.target_shape == (5120, 5120)
+    mergers = dict(deferred=TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True),
+                   planned=TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops),
+                   plain=TileMerger(slicer.target_shape, C, slicer.weight, device=dev))
+    g = torch.Generator(device=dev).manual_seed(5)
+    for b0 in range(0, 361, 8):
+        nb = min(8, 361 - b0)
+        y = torch.empty((8 * nb, C, 512, 512), device=dev).normal_(generator=g)
+        for m in mergers.values():
+            m.integrate_batch_deaugment(y, crops[b0:b0 + nb], group="d4", reduction="mean")
+    d = mergers["deferred"]
+    assert d._bands_done == 20 and not d._held
+    out = {k: m.merge() for k, m in mergers.items()}
+    assert torch.isfinite(out["plain"]).all()
+    assert torch.equal(out["deferred"], out["plain"]) and torch.equal(out["planned"], out["plain"])
+    # partition of unity through the deferred path: every tile (all 8 views) constant 0.75 -> the merged map is 0.75
+    d.reset()
+    const = torch.full((64, C, 512, 512), 0.75, device=dev)
+    for b0 in range(0, 361, 8):
+        nb = min(8, 361 - b0)
+        d.integrate_batch_deaugment(const[:8 * nb], crops[b0:b0 + nb], group="d4", reduction="mean")
+    flat = d.merge()
+    assert float((flat - 0.75).abs().max()) <= 1e-6
