@@ -417,7 +417,6 @@ class TileMerger:
             self._bands = _Bands.build(self._plan, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height, self.image_width)
         self._defer_reset()
 
-    # ------------------------------------------------------------------ first-touch state
     # ------------------------------------------------------------------ deferred bands
     def _defer_reset(self):
         self._defer_active = self._bands is not None
@@ -493,6 +492,7 @@ class TileMerger:
                     self._held.pop(0)
         return True
 
+    # ------------------------------------------------------------------ first-touch state
     def _plan_off(self, what):
         """Leave planned mode; impossible once blocks were finalised (their accumulators were never stored)."""
         self._defer_flush(what)
