@@ -54,6 +54,7 @@ class DummyUNet(nn.Module):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiny", action="store_true")
+    ap.add_argument("--defer", action="store_true", help="with --device-edges: TileMerger(crops=, defer=True)")
     ap.add_argument("--device-edges", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -85,13 +86,13 @@ def main():
         stages["merge_d2h"] += time.perf_counter() - t
         return merged
 
-    def run_device():
+    def run_device(defer=False):
         t = time.perf_counter()
         tiler = ImageSlicer(image.shape, tile_size=(512, 512), tile_step=(256, 256), weight="pyramid")
         stages["split"] += time.perf_counter() - t; t = time.perf_counter()
         dimg = torch.from_numpy(image).to(dev, non_blocking=True)
         torch.cuda.synchronize(); stages["h2d"] += time.perf_counter() - t
-        merger = CudaTileMerger(tiler.target_shape, 4, tiler.weight)
+        merger = CudaTileMerger(tiler.target_shape, 4, tiler.weight, crops=tiler.crops if defer else None, defer=defer)
         inv255 = [1.0 / 255.0] * 3
         with torch.no_grad():
             for b0 in range(0, len(tiler.crops), 8):
@@ -108,13 +109,15 @@ def main():
         return labels
 
     if args.device_edges:
-        run_device()
+        ref = run_device()
         for k in stages:
             stages[k] = 0.0
         t0 = time.perf_counter()
-        out = run_device()
+        out = run_device(defer=args.defer)
         total = time.perf_counter() - t0
         assert out.shape == (side, side) and out.max() < 4
+        # (the deferred merger holds references to the model's freshly allocated output tensors: same labels, bit for bit)
+        assert np.array_equal(out, ref), "deferred and incremental mergers disagree"
         print(f"end-to-end (device edges) {side}x{side}: {total * 1e3:.1f} ms -> {side * side / 1e6 / total:.1f} MP/s")
         for k, v in stages.items():
             print(f"  {k:10s} {v * 1e3:9.1f} ms  ({100 * v / total:4.1f} %)")
