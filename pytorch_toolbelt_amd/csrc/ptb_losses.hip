@@ -528,6 +528,71 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
     }
 }
 
+// Region statistics with DENSE targets and a per-element activation (multilabel / binary Dice and Jaccard: sigmoid or given
+// probabilities): no cross-class dependency, so a wave simply streams 1024 consecutive elements of ONE (image, class) plane of
+// logits and targets (2 x 4 x 16 B in flight per lane), keeps the three sums of that class in registers and leaves them with
+// three slotted atomics.  The generic register-resident kernel above needs 198 VGPRs for this case and ran at 3.6 TB/s.
+template <int PROB, bool IGN, bool FOCAL = false>
+__global__ __launch_bounds__(256) void seg_stats_dense_lean_kernel(const SegArgs a) {
+    static_assert(!FOCAL || PROB == PROB_SIGMOID, "the focal term shares the sigmoid of the statistics");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const float term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
+    double f_loss = 0.0, f_term = 0.0;
+    const long long segs_per_plane = a.HW / 1024;
+    const long long segs = segs_per_plane * C * a.B;
+    for (long long sg = (long long)blockIdx.x * 4 + wave; sg < segs; sg += (long long)gridDim.x * 4) {
+        const long long plane = sg / segs_per_plane;           // b * C + c
+        const int c = (int)(plane % C);
+        const long long off = plane * a.HW + (sg - plane * segs_per_plane) * 1024 + (long long)lane * 4;
+        float xv[4][4], tv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_px<4>(a.logits + off + u * 256, xv[u], true);
+            load_px<4>(a.dense + off + u * 256, tv[u], true);
+        }
+        float sI = 0.f, sP = 0.f, sT = 0.f, lsum = 0.f, fsum = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = xv[u][k];
+                float t = tv[u][k];
+                const bool ig = IGN && t == a.ignore_value;
+                float p;
+                if (PROB == PROB_SIGMOID) {
+                    const Sig sgm = sigmoid_parts(x);
+                    p = sgm.p;
+                    if (FOCAL) {   // default focal configuration (gamma 2, nothing else), targets may be soft: functional.py:61-94
+                        const float tt = ig ? 0.f : t;
+                        const float ce = fmaxf(x, 0.f) - x * tt + sgm.log1pe;
+                        const float pt = __builtin_fmaf(p, tt, (1.f - p) * (1.f - tt));
+                        const float omp = fmaxf(1.f - pt, 0.f);
+                        float f = omp * omp;
+                        lsum += ig ? 0.f : f * ce;
+                        fsum += ig ? f * term_mask : f;
+                    }
+                } else {
+                    p = x;
+                }
+                if (ig) { p = 0.f; t = 0.f; }     // p * mask, t * mask (dice.py:85-111)
+                sI = __builtin_fmaf(p, t, sI);
+                sP += p;
+                sT += t;
+            }
+        }
+        sI = wave_sum(sI); sP = wave_sum(sP); sT = wave_sum(sT);
+        if (lane == 0) {
+            double* slot = a.sums + (size_t)((blockIdx.x * 4 + wave) % SUM_SLOTS) * (2 + 3 * C);
+            atomicAdd(&slot[2 + c], (double)sI);
+            atomicAdd(&slot[2 + C + c], (double)sP);
+            atomicAdd(&slot[2 + 2 * C + c], (double)sT);
+        }
+        if (FOCAL) { f_loss += (double)lsum; f_term += (double)fsum; }
+    }
+    if (FOCAL) block_add2(f_loss, f_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C), lane, wave);
+}
+
 // Generic variant: any C, class planes are streamed (softmax: one extra pass for the log-sum-exp), everything run time.
 template <int PIX>
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
@@ -1753,6 +1818,22 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     const bool vec = vec_ok(HW, {logits, dense, elem_out, labels});
     const int gcap = what == SEG_FOCAL ? kGridStream : kGridStats;
     const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B, gcap) : grid_for_groups((HW + 63) / 64 * B, gcap)), block(256);
+    if (!g_force_scalar && dense && !labels && what == (SEG_FOCAL | SEG_STATS) && vec && HW % 1024 == 0 && prob == PROB_SIGMOID && g2 &&
+        !class_weights && !(flags & (SEG_HAS_ALPHA | SEG_REDUCED | SEG_ELEMWISE))) {
+        const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream));
+        if (flags & SEG_HAS_IGNORE) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true, true>), dgrid, block, 0, s, a);
+        else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false, true>), dgrid, block, 0, s, a);
+        return check_launch();
+    }
+    if (!g_force_scalar && dense && !labels && what == SEG_STATS && vec && HW % 1024 == 0 && (prob == PROB_SIGMOID || prob == PROB_IDENTITY)) {
+        const bool ign = flags & SEG_HAS_IGNORE;
+        const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream));
+        if (prob == PROB_SIGMOID) { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true>), dgrid, block, 0, s, a);
+                                    else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false>), dgrid, block, 0, s, a); }
+        else { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, true>), dgrid, block, 0, s, a);
+               else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, false>), dgrid, block, 0, s, a); }
+        return check_launch();
+    }
     // straight-line kernels for the common case (see seg_fwd_lean_kernel)
     if (!g_force_scalar && labels && !dense && vec && HW % 256 == 0 && C <= 16 && (what & SEG_STATS) && !(flags & SEG_ELEMWISE) &&
         (prob == PROB_SOFTMAX || prob == PROB_IDENTITY)) {

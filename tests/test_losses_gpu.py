@@ -604,3 +604,40 @@ def test_softmax_focal_straight_line_forward(C, dev):
     ref = (pt.pow(2) * torch.nn.functional.binary_cross_entropy_with_logits(x.double(), oh, reduction="none")).sum(1) * valid
     torch.testing.assert_close(outs[0].double(), ref, rtol=2e-5, atol=1e-5)
     assert float(L.CrossEntropyFocalLoss()(xl, ll)) == pytest.approx(float(LO.softmax_focal_loss_with_logits(x.numpy(), lab.numpy())), abs=1e-5)
+
+
+@pytest.mark.parametrize("mode,C", [("multilabel", 5), ("multilabel", 16), ("binary", 1)])
+@pytest.mark.parametrize("ignore_index", [None, 255])
+def test_dense_target_statistics_streaming_kernel(mode, C, ignore_index, dev):
+    """seg_stats_dense_lean_kernel (dense targets, sigmoid or given probabilities, HW % 1024 == 0): Dice / Jaccard in multilabel
+    and binary mode against the fp64 oracle and against the generic kernel (ptb_set_tunable(1, 1))."""
+    from pytorch_toolbelt_amd import _native as N
+
+    L = _L()
+    g = torch.Generator().manual_seed(400 + C)
+    B, H, W = 3, 32, 64                                   # HW = 2048
+    x = torch.randn((B, C, H, W), generator=g) * 2
+    t = (torch.rand((B, C, H, W), generator=g) < 0.35).float()
+    if ignore_index is not None:
+        t[0, :, :5] = float(ignore_index)
+    xl, tl = x.to(dev), t.to(dev)
+    probs = torch.sigmoid(x)
+    lib = N.load()
+    res = []
+    for scalar in (0, 1):
+        lib.ptb_set_tunable(1, scalar)
+        try:
+            d = float(L.DiceLoss(mode, ignore_index=ignore_index, smooth=1.0)(xl, tl))
+            dp = float(L.DiceLoss(mode, from_logits=False, ignore_index=ignore_index)(probs.to(dev), tl))
+            j = float(L.JaccardLoss(mode, log_loss=True)(xl, tl)) if ignore_index is None else 0.0
+        finally:
+            lib.ptb_set_tunable(1, 0)
+        res.append((d, dp, j))
+    assert res[0] == pytest.approx(res[1], rel=2e-6, abs=1e-6)
+    assert res[0][0] == pytest.approx(LO.dice_loss(x.numpy(), t.numpy(), mode, ignore_index=ignore_index, smooth=1.0), abs=1e-5)
+    assert res[0][1] == pytest.approx(LO.dice_loss(probs.numpy(), t.numpy(), mode, from_logits=False, ignore_index=ignore_index), abs=1e-5)
+    if ignore_index is None:
+        assert res[0][2] == pytest.approx(LO.jaccard_loss(x.numpy(), t.numpy(), mode, log_loss=True), abs=1e-5)
+        x1 = xl.clone().requires_grad_(True)
+        L.DiceLoss(mode)(x1, tl).backward()               # (backward: the generic statistics kernel; forward: the streaming one)
+        assert torch.isfinite(x1.grad).all() and float(x1.grad.abs().sum()) > 0
