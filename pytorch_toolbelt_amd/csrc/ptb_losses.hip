@@ -1293,6 +1293,58 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_lean_kernel(const SegArg
     }
 }
 
+// Backward of the dense-target statistics (and, FOCAL, of the default-configuration focal sums) as a plain stream: one wave =
+// 1 024 consecutive elements of one (image, class) plane; grad = [k1 dL/dx + k2 dF/dx] + (gI_c t + gP_c) * dp/dx.
+template <int PROB, bool IGN, bool FOCAL>
+__global__ __launch_bounds__(256) void seg_dense_bwd_lean_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
+                                                                 const float* __restrict__ gP, float* __restrict__ grad) {
+    static_assert(!FOCAL || PROB == PROB_SIGMOID, "the focal term shares the sigmoid of the statistics");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const float k1 = FOCAL ? coef[0] : 0.f, k2 = FOCAL ? coef[1] : 0.f;
+    const long long segs_per_plane = a.HW / 1024;
+    const long long segs = segs_per_plane * C * a.B;
+    for (long long sg = (long long)blockIdx.x * 4 + wave; sg < segs; sg += (long long)gridDim.x * 4) {
+        const long long plane = sg / segs_per_plane;
+        const int c = (int)(plane % C);
+        const float gi = gI[c], gp = gP[c];
+        const long long off = plane * a.HW + (sg - plane * segs_per_plane) * 1024 + (long long)lane * 4;
+        float xv[4][4], tv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_px<4>(a.logits + off + u * 256, xv[u], true);
+            load_px<4>(a.dense + off + u * 256, tv[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float out[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float x = xv[u][k], t = tv[u][k];
+                const bool ig = IGN && t == a.ignore_value;
+                float gx;
+                if (PROB == PROB_SIGMOID) {
+                    const Sig sgm = sigmoid_parts(x);
+                    const float p = sgm.p;
+                    const float pq = p * (1.f - p);
+                    gx = (gi * t + gp) * pq;
+                    if (FOCAL) {   // gamma 2, no alpha / threshold / weights: f = (1 - pt)^2, df/dx = -2 (1 - pt) p (1 - p) (2t - 1)
+                        const float ce = fmaxf(x, 0.f) - x * t + sgm.log1pe;
+                        const float pt = __builtin_fmaf(p, t, (1.f - p) * (1.f - t));
+                        const float omp = fmaxf(1.f - pt, 0.f);
+                        const float df = -2.0f * omp * pq * (2.f * t - 1.f);
+                        gx += k1 * (df * ce + omp * omp * (p - t)) + k2 * df;
+                    }
+                } else {
+                    gx = gi * t + gp;
+                }
+                out[k] = ig ? 0.f : gx;
+            }
+            store_px<4>(grad + off + u * 256, out, true);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ softmax focal
 // softmax_focal_loss_with_logits (functional.py:110-173): per pixel sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c, masked by
 // label != ignore_index.  sums[0] = sum of pixel losses, sums[1] = sum of ALL focal terms (the reference does not
@@ -1921,6 +1973,15 @@ extern "C" int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, con
     if (!gI || !gP || !grad) return PTB_EINVAL;
     if ((long long)B * HW == 0) return PTB_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (!g_force_scalar && dense && !labels && HW % 1024 == 0 && (prob == PROB_SIGMOID || prob == PROB_IDENTITY) && vec_ok(HW, {logits, dense, grad})) {
+        const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream)), block(256);
+        const bool ign = flags & SEG_HAS_IGNORE;
+        if (prob == PROB_SIGMOID) { if (ign) hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_SIGMOID, true, false>), dgrid, block, 0, s, a, gI, gI, gP, grad);
+                                    else hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_SIGMOID, false, false>), dgrid, block, 0, s, a, gI, gI, gP, grad); }
+        else { if (ign) hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_IDENTITY, true, false>), dgrid, block, 0, s, a, gI, gI, gP, grad);
+               else hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_IDENTITY, false, false>), dgrid, block, 0, s, a, gI, gI, gP, grad); }
+        return check_launch();
+    }
     if (vec_ok(HW, {logits, dense, grad, labels})) {
         const int grid = grid_for_groups((HW + 255) / 256 * B, kGridStats);
         if (C <= 16 && labels) hipLaunchKernelGGL((seg_stats_bwd_kernel<4, 16, false>), dim3(grid), dim3(256), 0, s, a, gI, gP, grad);
@@ -1982,6 +2043,13 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
     if (int rc = fill_seg(a, logits, labels, dense, class_weights, B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
     if (!coef || !gI || !gP || !grad) return PTB_EINVAL;
     if ((long long)B * HW == 0) return PTB_OK;
+    if (!g_force_scalar && dense && !labels && HW % 1024 == 0 && prob == PROB_SIGMOID && gamma == 2.0f && !class_weights &&
+        !(flags & (SEG_HAS_ALPHA | SEG_REDUCED)) && vec_ok(HW, {logits, dense, grad})) {
+        const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream)), dblock(256);
+        if (flags & SEG_HAS_IGNORE) hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_SIGMOID, true, true>), dgrid, dblock, 0, (hipStream_t)stream, a, coef, gI, gP, grad);
+        else hipLaunchKernelGGL((seg_dense_bwd_lean_kernel<PROB_SIGMOID, false, true>), dgrid, dblock, 0, (hipStream_t)stream, a, coef, gI, gP, grad);
+        return check_launch();
+    }
     if (C > 16 || !vec_ok(HW, {logits, dense, grad, labels}) || (dense && prob == PROB_SOFTMAX)) return PTB_EUNSUPPORTED;
     const dim3 grid(grid_for_groups((HW + 255) / 256 * B, kGridStats)), block(256);
     hipStream_t s = (hipStream_t)stream;

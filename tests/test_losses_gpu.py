@@ -623,17 +623,21 @@ def test_dense_target_statistics_streaming_kernel(mode, C, ignore_index, dev):
     xl, tl = x.to(dev), t.to(dev)
     probs = torch.sigmoid(x)
     lib = N.load()
-    res = []
+    res, grads = [], []
     for scalar in (0, 1):
         lib.ptb_set_tunable(1, scalar)
         try:
             d = float(L.DiceLoss(mode, ignore_index=ignore_index, smooth=1.0)(xl, tl))
             dp = float(L.DiceLoss(mode, from_logits=False, ignore_index=ignore_index)(probs.to(dev), tl))
             j = float(L.JaccardLoss(mode, log_loss=True)(xl, tl)) if ignore_index is None else 0.0
+            xg = xl.clone().requires_grad_(True)          # backward: seg_dense_bwd_lean_kernel vs the generic kernels
+            (L.DiceLoss(mode, ignore_index=ignore_index)(xg, tl) + (L.FocalDiceJaccardLoss(mode, ignore_index=ignore_index)(xg, tl) if mode != "binary" else 0.0)).backward()
+            grads.append(xg.grad)
         finally:
             lib.ptb_set_tunable(1, 0)
         res.append((d, dp, j))
     assert res[0] == pytest.approx(res[1], rel=2e-6, abs=1e-6)
+    torch.testing.assert_close(grads[0], grads[1], rtol=2e-5, atol=1e-9)
     assert res[0][0] == pytest.approx(LO.dice_loss(x.numpy(), t.numpy(), mode, ignore_index=ignore_index, smooth=1.0), abs=1e-5)
     assert res[0][1] == pytest.approx(LO.dice_loss(probs.numpy(), t.numpy(), mode, from_logits=False, ignore_index=ignore_index), abs=1e-5)
     if ignore_index is None:
