@@ -191,6 +191,25 @@ def fuzz_region_losses(seeds):
                 parts = L.BinaryFocalLoss()(x2, lt) + L.DiceLoss("multiclass", **kw)(x2, lt) + L.JaccardLoss("multiclass", **kw)(x2, lt)
                 parts.backward()
                 assert torch.allclose(xg.grad, x2.grad, rtol=2e-4, atol=1e-8), ("fused grad", float((xg.grad - x2.grad).abs().max()))
+            # dense (multilabel) targets: streaming statistics kernels forward and backward vs the oracle and the generic kernels
+            tdense = (rng.random((B, C, H, W)) < 0.3).astype(np.float32)
+            ignd = [None, 255][seed % 2]
+            if ignd is not None:
+                tdense[0, :, : H // 4] = 255.0
+            tt = torch.from_numpy(tdense).to(dev)
+            got = float(L.DiceLoss("multilabel", ignore_index=ignd, **kw)(xt, tt))
+            want = LO.dice_loss(x, tdense, "multilabel", ignore_index=ignd, **kw)
+            assert abs(got - want) <= 2e-5 * (1 + abs(want)), ("dice multilabel", got, want)
+            grads = []
+            for scalar in (0, 1):
+                N.load().ptb_set_tunable(1, scalar)
+                try:
+                    xg = xt.clone().requires_grad_(True)
+                    (L.JaccardLoss("multilabel", **kw)(xg, tt) + L.FocalDiceJaccardLoss("multilabel", ignore_index=ignd)(xg, tt)).backward()
+                    grads.append(xg.grad)
+                finally:
+                    N.load().ptb_set_tunable(1, 0)
+            assert torch.allclose(grads[0], grads[1], rtol=2e-4, atol=1e-8), ("multilabel grad", float((grads[0] - grads[1]).abs().max()))
         except Exception as e:  # noqa: BLE001
             bad += 1
             print("region loss FAIL seed", seed, (B, C, H, W), ign, kw, repr(e)[:300])
