@@ -238,11 +238,17 @@ def main():
             merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
     # power management: keep a GPU that has been idle (a fresh box, the seconds this process spent importing torch) busy for a
     # moment before the warm-up (untimed, like the build)
-    t_ramp = time.perf_counter()
-    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
-        for _ in range(10):
+    if use_dist:
+        # every rank must run the SAME number of steps (each one exchanges halos): a fixed count, not a wall-clock loop
+        for _ in range(30 if args.ramp_ms > 0 else 0):
             step()
         torch.cuda.synchronize()
+    else:
+        t_ramp = time.perf_counter()
+        while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync()
