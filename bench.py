@@ -200,7 +200,7 @@ def main():
     # would after start-up.
     gc.collect()
     gc.freeze()
-    if args.diag and rank == 0:
+    if args.diag and rank == 0 and not use_dist:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
         sync()
         tt = time.perf_counter()
@@ -270,7 +270,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    if args.diag and rank == 0:
+    if args.diag and rank == 0 and not use_dist:   # (extra steps on one rank only would leave the others' halo exchanges unmatched)
         per_step = []
         for _ in range(10):
             sync()
