@@ -622,8 +622,96 @@ def gen_volumes():
         cases.append(dict(name=f"vmerger{k}", fn="vmerger", kwargs=dict(kw, channels=C, batch=bs)))
     save("volumes.npz", A, cases)
 
+# ----------------------------------------------------------------------------------------------- BASELINE configs at full size
+def gen_fullsize():
+    """Digests of the UNMODIFIED reference's outputs on every BASELINE.json config at its stated size.
+
+    The inputs are too big to store (cfg2: 12.1 GB), so they come from oracle/synth.py -- an integer hash that numpy (here)
+    and torch on the GPU (the `-m gpu` tests) evaluate bit-identically -- and only a strided subsample plus float64 sums
+    of every output are kept.  Each entry: `<cfg>_sub` (subsample, steps in `<cfg>_meta`), `<cfg>_sums` (sum, abs-sum)."""
+    sys.path.insert(0, ROOT)
+    from oracle import synth as SY
+
+    A, cases = {}, []
+    torch.set_num_threads(os.cpu_count() or 8)
+
+    # cfg1: 1024x1024x3, ImageSlicer 256/128, pyramid window, C = 3 (reference tests/test_tiles.py path, CPU TileMerger)
+    s = rt.ImageSlicer((1024, 1024, 3), tile_size=256, tile_step=128, weight="pyramid")
+    assert len(s.crops) == 49
+    pred = torch.from_numpy(SY.synth_np((49, 3, 256, 256), 101))
+    m = rt.TileMerger(s.target_shape, 3, s.weight)
+    for b0 in range(0, 49, 8):
+        m.integrate_batch(pred[b0:b0 + 8], s.crops[b0:b0 + 8])
+    merged = t2n(m.merge())
+    A["cfg1_sub"], A["cfg1_sums"] = SY.digest(merged, 13, 17)
+    A["cfg1_meta"] = np.array([13, 17, 101])
+    # the host fp64 path of the same tiles (ImageSlicer.merge, HWC tiles)
+    tiles_hwc = [np.moveaxis(t2n(p), 0, -1) for p in pred]
+    host = s.merge(tiles_hwc, dtype=np.float32)
+    A["cfg1_host_sub"], A["cfg1_host_sums"] = SY.digest(np.moveaxis(host, -1, 0), 13, 17)
+    cases.append(dict(name="cfg1", fn="fullsize", kwargs=dict(image=[1024, 1024, 3], tile=256, step=128, channels=3, seed=101, batch=8)))
+
+    # cfg2: 5000x5000x3, 512/256 pyramid, d4 TTA model outputs C = 4, batches of 8 tiles, seeds 2000 + batch index
+    s = rt.ImageSlicer((5000, 5000, 3), tile_size=(512, 512), tile_step=(256, 256), weight="pyramid")
+    assert len(s.crops) == 361
+    m = rt.TileMerger(s.target_shape, 4, s.weight)
+    for k, b0 in enumerate(range(0, 361, 8)):
+        nb = min(8, 361 - b0)
+        y = torch.from_numpy(SY.synth_np((8 * nb, 4, 512, 512), 2000 + k))
+        m.integrate_batch(rtta.d4_image_deaugment(y, reduction="mean"), s.crops[b0:b0 + nb])
+    merged = t2n(m.merge())
+    A["cfg2_sub"], A["cfg2_sums"] = SY.digest(merged, 97, 101)
+    A["cfg2_meta"] = np.array([97, 101, 2000])
+    A["cfg2_rows"] = merged[:, [0, 255, 256, 2559, 2560, 5119], :].copy()     # whole rows across band / tile edges
+    cases.append(dict(name="cfg2", fn="fullsize", kwargs=dict(image=[5000, 5000, 3], tile=512, step=256, channels=4, seed=2000, batch=8, group="d4")))
+    del merged, m
+
+    # cfg4: [32, 16, 512, 512] logits, int64 labels: BinaryFocalLoss (one-hot target), DiceLoss / JaccardLoss multiclass
+    B, C, H, W = 32, 16, 512, 512
+    x = torch.from_numpy(SY.synth_np((B, C, H, W), 4001)) * 2.0          # uniform on [-4, 4), exact scaling
+    lab = torch.from_numpy(SY.labels_np((B, H, W), 4002, C))
+    onehot = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+    vals = dict(
+        focal=float(rl.BinaryFocalLoss()(x, onehot)),
+        focal_alpha=float(rl.BinaryFocalLoss(alpha=0.25, gamma=2.0)(x, onehot)),
+        dice=float(rl.DiceLoss("multiclass")(x, lab)),
+        jaccard=float(rl.JaccardLoss("multiclass")(x, lab)),
+        ce_focal=float(rl.CrossEntropyFocalLoss()(x, lab)),
+    )
+    del onehot
+    for k_, v in vals.items():
+        A[f"cfg4_{k_}"] = np.array(v, dtype=np.float64)
+    # gradient digest of focal + dice + jaccard (the fused loss of BASELINE configs[3])
+    xg = x.clone().requires_grad_(True)
+    onehot = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+    total = rl.BinaryFocalLoss()(xg, onehot) + rl.DiceLoss("multiclass")(xg, lab) + rl.JaccardLoss("multiclass")(xg, lab)
+    total.backward()
+    A["cfg4_fused"] = np.array(float(total), dtype=np.float64)
+    A["cfg4_grad_sub"], A["cfg4_grad_sums"] = SY.digest(t2n(xg.grad), 37, 41)
+    A["cfg4_meta"] = np.array([37, 41, 4001, 4002])
+    cases.append(dict(name="cfg4", fn="fullsize", kwargs=dict(shape=[B, C, H, W], seeds=[4001, 4002], scale=2.0)))
+    del x, xg, onehot, lab
+
+    # cfg5: multiscale 0.75 / 1.0 / 1.25 of 4096x4096 (pixel offsets -1024, 0, +1024), each scale wrapped in fliplr TTA,
+    # gmean merge; C = 4, probabilities in (0, 1]
+    offs = [-1024, 0, 1024]
+    per_scale = []
+    for i, o in enumerate(offs):
+        y = torch.from_numpy(SY.synth_np((2, 4, 4096 + o, 4096 + o), 5000 + i, "unit"))
+        per_scale.append(rtta.fliplr_image_deaugment(y, reduction="gmean"))
+        del y
+    for ac in (False, True):
+        out = t2n(rtta.ms_image_deaugment(per_scale, offs, reduction="gmean", mode="bilinear", align_corners=ac))
+        A[f"cfg5_ac{int(ac)}_sub"], A[f"cfg5_ac{int(ac)}_sums"] = SY.digest(out, 89, 83)
+    A["cfg5_meta"] = np.array([89, 83, 5000])
+    cases.append(dict(name="cfg5", fn="fullsize", kwargs=dict(size=4096, offsets=offs, channels=4, seed=5000, inner="fliplr:gmean", reduction="gmean")))
+    save("fullsize.npz", A, cases)
+
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
+        gen_fullsize()
+        sys.exit(0)
     gen_tiles()
     gen_tta()
     gen_losses()
@@ -632,3 +720,4 @@ if __name__ == "__main__":
     gen_losses2()
     gen_losses3()
     gen_volumes()
+    gen_fullsize()

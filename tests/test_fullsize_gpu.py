@@ -1,0 +1,156 @@
+"""GPU parity at the FULL size of every BASELINE.json config, through the benchmarked paths.
+
+Two independent checks per config: (1) against digests of the UNMODIFIED reference's outputs (tests/golden/fullsize.npz,
+made in the build container by `python oracle/make_golden.py fullsize`); (2) against the numpy oracle on EVERY pixel of the
+same inputs.  Inputs come from oracle/synth.py, an integer hash numpy and torch-on-the-GPU evaluate bit-identically.
+Tolerance: 1e-5 absolute on blended logits / loss scalars (north_star); slicer indices and the plain merger are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import losses_oracle as LO
+from oracle import synth as SY
+from oracle import tiles_oracle as TO
+from oracle import tta_oracle as AO
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def full():
+    return load_golden("fullsize.npz")
+
+
+def _digest_check(full, key, arr, tol=TOL):
+    sh, sw = (int(v) for v in full[f"{key.split('_')[0]}_meta"][:2])
+    sub, sums = SY.digest(arr, sh, sw)
+    err = float(np.abs(sub - full[f"{key}_sub"]).max())
+    assert err <= tol, f"{key}: max|diff| vs the reference digest = {err}"
+    want = full[f"{key}_sums"]
+    assert abs(sums[1] - want[1]) <= 1e-6 * abs(want[1])
+    return err
+
+
+def test_cfg1_tilemerger_1024_pyramid(dev, full):
+    """BASELINE configs[0]: 1024x1024x3, ImageSlicer 256/128 + pyramid-weight TileMerger (C = 3, batches of 8)."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer((1024, 1024, 3), 256, 128, weight="pyramid")
+    assert len(slicer.crops) == 49 and slicer.target_shape == (1024, 1024)
+    pred = SY.synth_torch((49, 3, 256, 256), 101, device=dev)
+    mergers = dict(plain=TileMerger(slicer.target_shape, 3, slicer.weight, device=dev),
+                   planned=TileMerger(slicer.target_shape, 3, slicer.weight, device=dev, crops=slicer.crops),
+                   deferred=TileMerger(slicer.target_shape, 3, slicer.weight, device=dev, crops=slicer.crops, defer=True))
+    for b0 in range(0, 49, 8):
+        for m in mergers.values():
+            m.integrate_batch(pred[b0:b0 + 8], slicer.crops[b0:b0 + 8])
+    out = {k: m.merge().cpu().numpy() for k, m in mergers.items()}
+    sub, _ = SY.digest(out["plain"], 13, 17)
+    assert np.array_equal(sub, full["cfg1_sub"]), "TileMerger differs from the reference CPU TileMerger (expected bit-exact)"
+    for k in ("planned", "deferred"):
+        assert np.array_equal(out[k], out["plain"]), k
+    # every pixel vs the oracle, and the host fp64 path (ImageSlicer.split -> merge) of the same tiles
+    st = TO.merger_new(slicer.target_shape, 3, slicer.weight)
+    p = pred.cpu().numpy()
+    for b0 in range(0, 49, 8):
+        TO.merger_integrate(st, p[b0:b0 + 8], slicer.crops[b0:b0 + 8])
+    assert np.array_equal(out["plain"], TO.merger_merge(st))
+    host = slicer.merge([np.moveaxis(t, 0, -1) for t in p], dtype=np.float32)
+    assert np.abs(np.moveaxis(host, -1, 0) - out["plain"]).max() <= TOL
+    _digest_check(full, "cfg1_host", np.moveaxis(host, -1, 0), 1e-6)
+
+
+def test_cfg2_5000_d4_merge_all_paths_vs_reference_and_oracle(dev, full):
+    """BASELINE configs[1] exactly as benchmarked: 5000x5000x3, 512/256 pyramid, 361 tiles, d4 model outputs C = 4 in batches
+    of 8; the deferred band merger (bench default), the planned and the plain merger through the fused entry point, and the
+    literal drop-in sequence integrate_batch(d4_image_deaugment(y)) + merge()."""
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+    crops, C = slicer.crops, 4
+    assert len(crops) == 361 and slicer.target_shape == (5120, 5120)
+    fused = dict(deferred=TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True),
+                 planned=TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops),
+                 plain=TileMerger(slicer.target_shape, C, slicer.weight, device=dev))
+    literal = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    st = TO.merger_new(slicer.target_shape, C, slicer.weight)
+    for k, b0 in enumerate(range(0, 361, 8)):
+        nb = min(8, 361 - b0)
+        y = SY.synth_torch((8 * nb, C, 512, 512), 2000 + k, device=dev)
+        for m in fused.values():
+            m.integrate_batch_deaugment(y, crops[b0:b0 + nb], group="d4", reduction="mean")
+        literal.integrate_batch(tta.d4_image_deaugment(y), crops[b0:b0 + nb])
+        TO.merger_integrate(st, AO.image_deaugment(y.cpu().numpy(), "d4", "mean"), crops[b0:b0 + nb])
+    d = fused["deferred"]
+    assert d._bands is not None and d._bands_done == len(d._bands.bands) and not d._held, "the deferred band path did not run"
+    want = TO.merger_merge(st)
+    outs = {k: m.merge().cpu().numpy() for k, m in fused.items()}
+    outs["literal"] = literal.merge().cpu().numpy()
+    for k, got in outs.items():
+        err = float(np.abs(got - want).max())
+        assert np.isfinite(got).all() and err <= TOL, f"{k}: max|diff| vs the oracle over all 4x5120x5120 values = {err}"
+        _digest_check(full, "cfg2", got)
+        assert float(np.abs(got[:, [0, 255, 256, 2559, 2560, 5119], :] - full["cfg2_rows"]).max()) <= TOL, k
+    assert np.array_equal(outs["deferred"], outs["plain"]) and np.array_equal(outs["planned"], outs["plain"])
+    # the cropped original-size map (tiler.crop_to_orignal_size) from the device and from the host agree
+    cropped = slicer.crop_to_orignal_size(np.moveaxis(outs["deferred"], 0, -1))
+    assert cropped.shape == (5000, 5000, 4)
+    assert np.array_equal(fused["deferred"].merge_crop(slicer).cpu().numpy(), cropped)
+
+
+def test_cfg4_losses_32x16x512x512(dev, full):
+    """BASELINE configs[3]: [32,16,512,512] logits + int64 labels: BinaryFocal, Dice, Jaccard, CE-focal and the fused
+    focal+Dice+Jaccard loss vs the reference's values (digests) and the fp64 oracle; gradient of the fused loss vs the
+    reference's autograd."""
+    from pytorch_toolbelt_amd import losses as L
+
+    B, C, H, W = 32, 16, 512, 512
+    x = SY.synth_torch((B, C, H, W), 4001, device=dev) * 2.0
+    lab = SY.labels_torch((B, H, W), 4002, C, device=dev)
+    got = dict(focal=L.BinaryFocalLoss()(x, lab), focal_alpha=L.BinaryFocalLoss(alpha=0.25, gamma=2.0)(x, lab),
+               dice=L.DiceLoss("multiclass")(x, lab), jaccard=L.JaccardLoss("multiclass")(x, lab),
+               ce_focal=L.CrossEntropyFocalLoss()(x, lab))
+    for k, v in got.items():
+        assert float(v) == pytest.approx(float(full[f"cfg4_{k}"]), abs=TOL), k
+    xg = x.clone().requires_grad_(True)
+    fused = L.FocalDiceJaccardLoss("multiclass")(xg, lab)
+    assert float(fused) == pytest.approx(float(full["cfg4_fused"]), abs=TOL)
+    assert float(fused) == pytest.approx(float(got["focal"] + got["dice"] + got["jaccard"]), abs=2e-6)
+    fused.backward()
+    grad = xg.grad.cpu().numpy()
+    sub, sums = SY.digest(grad, 37, 41)
+    np.testing.assert_allclose(sub, full["cfg4_grad_sub"], rtol=2e-4, atol=1e-12)
+    assert sums[1] == pytest.approx(float(full["cfg4_grad_sums"][1]), rel=1e-5)
+    # fp64 oracle on the same tensors (a quarter of the batch at a time for the focal sums)
+    xn, ln = x.cpu().numpy(), lab.cpu().numpy()
+    parts = [float(LO.binary_focal_loss(xn[i:i + 4], ln[i:i + 4], reduction="sum")) for i in range(0, B, 4)]
+    assert float(got["focal"]) == pytest.approx(sum(parts) / xn.size, abs=TOL)
+    assert float(got["dice"]) == pytest.approx(float(LO.dice_loss(xn, ln, "multiclass")), abs=TOL)
+    assert float(got["jaccard"]) == pytest.approx(float(LO.jaccard_loss(xn, ln, "multiclass")), abs=TOL)
+
+
+@pytest.mark.parametrize("align_corners", [False, True])
+def test_cfg5_multiscale_fliplr_gmean_4096(dev, full, align_corners):
+    """BASELINE configs[4]: scales 0.75 / 1.0 / 1.25 of 4096x4096 (offsets -1024, 0, +1024), fliplr TTA inside every scale,
+    gmean merge, C = 4 -- the reference digest on a strided subsample, the oracle on every pixel."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    offs = [-1024, 0, 1024]
+    ys = [SY.synth_torch((2, 4, 4096 + o, 4096 + o), 5000 + i, "unit", device=dev) for i, o in enumerate(offs)]
+    per_scale = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
+    out = tta.ms_image_deaugment(per_scale, offs, reduction="gmean", mode="bilinear", align_corners=align_corners)
+    assert out.shape == (1, 4, 4096, 4096)
+    got = out.cpu().numpy()
+    _digest_check(full, f"cfg5_ac{int(align_corners)}", got)
+    want = AO.ms_image_deaugment([AO.image_deaugment(y.cpu().numpy(), "fliplr", "gmean") for y in ys], offs, "gmean", align_corners)
+    err = float(np.abs(got - want).max())
+    assert err <= TOL, f"max|diff| vs the oracle over all 4x4096x4096 values = {err}"
