@@ -10,8 +10,9 @@ config's "dummy UNet" only produces these tensors).  Every step starts from a `r
 Default merger: `TileMerger(..., crops=tiler.crops, defer=True)`.  The crop list is known before the first batch (the
 README loop has it), so the normaliser `norm_mask` -- which depends only on the crop list and the window (not
 compulsory traffic) -- is precomputed, and the merger keeps references to the batches it is handed (they stay resident
-and unmodified here) and merges each 256-row band of the image with ONE launch as soon as its last tile has arrived: 20
-launches per image that read every model output once and write the merged map once; no accumulator in HBM.  A/B switches:
+and unmodified here) and merges every group of 1024 rows of the image (four 256-row bands between tile edges; `--defer-rows`)
+with ONE launch as soon as its last tile has arrived: 5 launches per image that read every model output once and write the
+merged map once; no accumulator in HBM.  A/B switches:
 `--no-defer` (planned, incremental: 46 accumulate launches, every block divided by the normaliser in the launch that
 brings its last tile), `--unplanned` (no crop list: accumulate kernels + lazily built normaliser + separate division
 pass), `--memset-accumulators` (kernel-maintained normaliser, memset accumulators: the reference's literal data flow).
@@ -62,6 +63,7 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times (each run bracketed by barrier + "
                     "synchronize); `value` is the MEDIAN run, all runs are listed in config.repeat_ms_per_step")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary timings (no-defer / unplanned / literal drop-in sequence)")
+    ap.add_argument("--defer-rows", type=int, default=0, help="rows of the image merged per deferred launch (0: the library default, 1024)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
 
@@ -185,9 +187,10 @@ def main():
         # finished map (+3 % per image; --unplanned: lazily built normaliser + separate merge pass)
         planned = not (args.unplanned or args.memset_accumulators)
         # deferred bands (default): the merger keeps references to the batches (they stay resident and unmodified here) and
-        # merges each 256-row band of the image in ONE launch when its last tile has arrived -- no accumulator in HBM
+        # merges each group of bands (1024 rows) of the image in ONE launch when its last tile has arrived -- no accumulator in HBM
         deferred = planned and not args.no_defer
-        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None, defer=deferred)
+        merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, crops=slicer.crops if planned else None, defer=deferred,
+                            defer_rows=args.defer_rows or None)
     else:
         merger = sharded_merger
 
@@ -330,7 +333,8 @@ def main():
 
         mk = lambda **kw: (lambda: TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, **kw))  # noqa: E731
         variants = {
-            "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True)),
+            "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None)),
+            "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256)),
             "planned_no_defer_ms": variant(mk(crops=slicer.crops)),
             "unplanned_fused_ms": variant(mk()),
             "dropin_literal_ms": variant(mk(), literal=True),
@@ -396,8 +400,8 @@ def main():
     bytes_per_launch = bytes_per_tile * BATCH
     n_bands = len(merger._bands.bands) if (not sharded and deferred) else 0
     if n_bands:
-        # deferred: the 20 band launches of an image ARE the region (they read every model output once and write the merged
-        # map once) and nothing else runs on the stream: one HIP-event pair around the K timed steps / (K x 20 launches)
+        # deferred: the band-group launches of an image ARE the region (they read every model output once and write the merged
+        # map once) and nothing else runs on the stream: one HIP-event pair around the K timed steps / (K x launches per image)
         launch_ms = region_event_ms / (args.steps * n_bands)
         bytes_per_launch = (VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) // n_bands
     elif not sharded and planned:
@@ -439,8 +443,10 @@ def main():
                             "batches of 8 tiles + merge; accumulators reset (first-touch stores, no memset) each step; " +
                             ("TileMerger(crops=tiler.crops, defer=True): the merger keeps references to the (resident, unmodified) "
                              "batches; the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: not compulsory "
-                             "traffic); each 256-row band of the image is merged by ONE launch when its last tile has arrived (20 "
-                             "launches, no accumulator in HBM), so merge() returns the finished [C,H',W'] map; " if (not sharded and deferred) else
+                             f"traffic); each group of bands ({merger._bands.bands[0][1] - merger._bands.bands[0][0]} rows) of the image is merged by ONE "
+                             f"launch when its last tile has arrived ({len(merger._bands.bands)} launches per image, planned once and driven "
+                             "from C: ptb_band_plan_submit; no accumulator in HBM), so merge() returns the finished [C,H',W'] map; "
+                             if (not sharded and deferred) else
                              "TileMerger(crops=tiler.crops): the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: "
                              "not compulsory traffic) and every block is divided by it in the launch that brings its last tile, so "
                              "merge() returns the finished [C,H',W'] map; " if (not sharded and planned) else
@@ -465,8 +471,8 @@ def main():
                 "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
             "roofline": {
-                "kernel": ("band_merge_kernel<8,D4,linear> (fused d4 de-augment + mean + weighted blend of all tiles over a 256-row "
-                           "band + normalisation, 19 or 38 tiles/launch, 20 launches/image)" if n_bands else
+                "kernel": ("band_plan_kernel<8,D4,linear> (fused d4 de-augment + mean + weighted blend of all covering tiles + "
+                           f"normalisation over one group of bands; {n_bands} launches/image)" if n_bands else
                            "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
                            "normalisation, 8 tiles/launch)"),
                 "bound": "hbm",

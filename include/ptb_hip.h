@@ -133,6 +133,43 @@ int ptb_merge_band(float* merged, const float* norm_full, const float* weight, c
                    const int64_t* tile_view_stride, int in_dtype, int V, const int* views, int reduction, const int64_t* xs,
                    const int64_t* ys, int n, int C, int th, int tw, int H, int W, int y0, int y1, ptb_stream_t stream);
 
+/* ---- Deferred merge of a whole image, planned once (TileMerger(crops=tiler.crops, defer=True)).
+ * Replaces the reference's per-batch loop `merger.integrate_batch(<group>_image_deaugment(pred), crops)` + `merger.merge()`
+ * (inference/tta.py:442-467, inference/tiles.py:321-346) when the crop list of the image is known up front.
+ *
+ * ptb_band_plan_create: HOST-side planning from the n tile origins (xs, ys; every tile th x tw, in integration order) of an
+ *   H x W merged map with C channels.  The rows between consecutive tile edges are bands; consecutive bands are grouped into
+ *   launches of about rows_per_launch rows (at most 224 covering tiles each).  Bands lying completely inside rows
+ *   [partial_lo, partial_hi) write the UN-normalised weighted sum instead of sum / norm (multi-GPU merger: rows whose sums are
+ *   completed by a neighbouring rank; pass 0, 0 otherwise).  Returns the size in bytes of the device table the plan needs
+ *   (>= 0; *out receives the plan), PTB_EUNSUPPORTED when the geometry is off the 4-pixel grid / more than 4 tiles cover a pixel.
+ * ptb_band_plan_upload: copies the work-item table into caller-provided device memory (64-byte aligned, the size create
+ *   returned; the library never allocates device memory).  Once per plan.
+ * ptb_band_plan_info: number of launch groups / bands / work items; last_group_of_tile [n] = the last group that reads tile t
+ *   (the caller may release a batch once that group was launched); group_rows [3 * groups] = y0, y1 and the last tile (the
+ *   one whose arrival completes it; -1: no tile covers those rows) of every group.
+ * ptb_band_plan_submit: takes the B tiles pos .. pos+B-1 of the plan -- `batch` = view 0 of the first tile, tile b at
+ *   b * tile_stride elements, view v of a tile view_stride elements further (chunk-major [V*B, C, th, tw] model output:
+ *   tile_stride = C*th*tw, view_stride = B*C*th*tw) -- and launches every group whose last tile is now in: the group's rows of
+ *   merged [C, H, W] = sum_t w * reduce_v(view_v^-1(tile_t)) / norm_full (integration order per pixel, fp32, no contraction:
+ *   bit-identical to the incremental entry points).  The batches must stay alive and unmodified until their last group was
+ *   launched.  Returns the number of launches (>= 0); PTB_EUNSUPPORTED when `pos` is not the next planned tile or the
+ *   configuration (dtype, views, reduction, merged / norm_full / weight pointers) differs from the image's first batch -- nothing
+ *   is launched then and the caller integrates incrementally.
+ * ptb_band_plan_reset: next image.  ptb_band_plan_state: tiles taken / launches issued for the current image. */
+typedef struct ptb_band_plan ptb_band_plan;
+int64_t ptb_band_plan_create(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
+                             int partial_lo, int partial_hi, ptb_band_plan** out);
+int ptb_band_plan_upload(ptb_band_plan* plan, void* dev_table, ptb_stream_t stream);
+int ptb_band_plan_info(const ptb_band_plan* plan, int* n_groups, int* n_bands, int64_t* n_items, int64_t* last_group_of_tile,
+                       int64_t* group_rows);
+int ptb_band_plan_reset(ptb_band_plan* plan);
+int ptb_band_plan_state(const ptb_band_plan* plan, int* pos, int* launched);
+int ptb_band_plan_submit(ptb_band_plan* plan, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride, int in_dtype,
+                         int V, const int* views, int reduction, float* merged, const float* norm_full, const float* weight,
+                         ptb_stream_t stream);
+void ptb_band_plan_destroy(ptb_band_plan* plan);
+
 /* dst[c][r][x] += src[c][r][x] for a packed src [C, rows, cols] and a rectangle of a larger fp32 accumulator (element
  * strides dst_cs per channel, dst_rs per row): folds a halo rectangle received from another rank into the band
  * accumulator (multi-GPU merger; no reference counterpart). */

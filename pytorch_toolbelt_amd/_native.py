@@ -21,6 +21,7 @@ F32, F16, BF16 = range(3)   # PTB_F32 / PTB_F16 / PTB_BF16: element type of the 
 DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 
 EFRESH = -5
+PTB_EUNSUPPORTED = -2
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed", -4: "tile rectangle outside the accumulator"}
 
 _c_int = ctypes.c_int
@@ -47,6 +48,13 @@ SIGNATURES = {
     "ptb_debug_plan": (_c_int, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _ip, _c_int]),
     "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),
     "ptb_merge_band": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_band_plan_create": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vpp]),
+    "ptb_band_plan_upload": (_c_int, [_vp, _vp, _vp]),
+    "ptb_band_plan_info": (_c_int, [_vp, _ip, _ip, _i64p, _i64p, _i64p]),
+    "ptb_band_plan_reset": (_c_int, [_vp]),
+    "ptb_band_plan_state": (_c_int, [_vp, _ip, _ip]),
+    "ptb_band_plan_submit": (_c_int, [_vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _c_int, _c_int, _ip, _c_int, _vp, _vp, _vp, _vp]),
+    "ptb_band_plan_destroy": (None, [_vp]),
     "ptb_rect_add": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _vp]),
     "ptb_merge_div_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp]),
     "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

@@ -1,0 +1,359 @@
+// ptb_bandplan.hip -- deferred planned merging of a whole image, planned once, driven from C (gfx950 / MI355X).
+//
+// TileMerger(crops=tiler.crops, defer=True) (reference data flow: inference/tta.py:442-467 feeding inference/tiles.py:321-346).
+// The crop list of an image is known before its first batch, so everything that depends on geometry only is computed ONCE per
+// merger: the image is cut into *bands* (the rows between two consecutive tile edges; every tile that touches a band covers all
+// its rows), consecutive bands are grouped into *launch groups* of about `rows_per_launch` rows, and every group is expanded into
+// a table of 64 x 32 work items -- origin, extent, the (<= 4) covering tiles in integration order and the item's offset inside
+// each of them.  The table lives in HBM (uploaded once); per image only the tile source pointers change, and those travel in the
+// kernel arguments of the group's launch (<= 224 tiles x 16 B).  `ptb_band_plan_submit` takes one batch of model outputs into the
+// plan and launches every group whose last tile has arrived: one launch reads all covering tiles of its rows once, applies the
+// inverse TTA views, reduces, blends in integration order and writes sum / norm to the merged map.  No accumulator image ever
+// exists in HBM, the per-batch host work is a few table look-ups in C (no Python planning), and the fp32 operation order per
+// pixel is the incremental path's, so the result is bit-identical to it -- and to the reference's sequential loop.
+//
+// Why groups of several bands: a launch of one 256-row band at the headline geometry is 2560 workgroups = 3.3 rounds of the
+// 768 that fit the chip, so ramp-up, the partial last round and the kernel boundary cost ~10 % of its 100 us; a group of 4 bands
+// pays them once per 400 us.  Items are ordered heavy-first (4-tile items before 2- and 1-tile ones) so the tail is short work.
+#include <algorithm>
+#include <vector>
+
+#include "ptb_view_device.h"
+
+namespace ptb {
+
+constexpr int PLAN_TILES = 224;   // tiles of one launch group (kernarg: 224 x 16 B + ViewArgs < 4 KiB)
+constexpr int PLAN_CH = 32;       // item rows (512-thread workgroups, like the incremental kernels' default chunk)
+
+struct BandItem {                 // 64 B = one cache line per workgroup, read with scalar loads only (never copied to registers as a
+    int ax, ay;                   // whole: run-time indexing of a by-value copy would put it in scratch memory); (ax, ay) = origin
+    int cwch;                     // extent: columns | rows << 16  (<= 64 x 32)
+    int ntiles;                   // covering tiles (0: uncovered pixels -> 0 / 0 = NaN like the reference's merge)
+    int partial;                  // 1: write the un-normalised weighted sum (multi-GPU boundary rows) instead of sum / norm
+    int pad[3];
+    unsigned long long cover[MAX_COVER];   // ascending integration order: tile slot | lx << 16 | ly << 32 (item origin in the tile)
+};
+static_assert(sizeof(BandItem) == 64, "BandItem layout");
+
+struct GroupTiles {
+    const void* src[PLAN_TILES];  // view 0, channel 0 of the tile
+    long long vs[PLAN_TILES];     // elements between consecutive views of this tile (its batch size * C * th * tw)
+};
+
+template <int NV, int CODES, int OPK, int LD>
+__global__ __launch_bounds__(512) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
+    constexpr int CH = PLAN_CH;
+    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
+    const int tid = threadIdx.x;
+    const int c = blockIdx.x % a.C;
+    const BandItem* __restrict__ it = items + blockIdx.x / a.C;
+    const int cwch = it->cwch, partial = it->partial;
+    const int cw = cwch & 0xffff, ch = cwch >> 16;
+    const int q = tid & 15, r = tid >> 4;
+    const bool act = (r < ch) && (4 * q < cw);
+    const long long pix = (long long)(it->ay + r) * a.dst_row_stride + it->ax + 4 * q;
+    float4 nfull = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (act && !partial) nfull = *reinterpret_cast<const float4*>(a.norm_full + pix);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nt = it->ntiles;
+    for (int e = 0; e < nt; ++e) {
+        const unsigned long long cv = it->cover[e];
+        const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
+        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
+                                                                a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
+                                                                e + 1 < nt);
+        if (act) {
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
+            acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338: tile * weight rounded, then added (no FMA contraction)
+            acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, w4.y));
+            acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, w4.z));
+            acc.w = __fadd_rn(acc.w, __fmul_rn(val.w, w4.w));
+        }
+    }
+    if (act) {
+        float* o = a.merged + (long long)c * a.dst_chan_stride + pix;
+        if (partial) *reinterpret_cast<float4*>(o) = acc;
+        else *reinterpret_cast<float4*>(o) = make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z),
+                                                         __fdiv_rn(acc.w, nfull.w));   // tiles.py:346
+    }
+}
+
+static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTiles& t, int blocks, hipStream_t s) {
+    const dim3 grid(blocks), block(512);
+    const bool nonlinear = a.op >= PTB_RED_GMEAN;
+#define PTB_PLAN_LD(NV, CODES, LD)                                                                                  \
+    do {                                                                                                            \
+        if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD>), grid, block, 0, s, a, items, t);    \
+        else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD>), grid, block, 0, s, a, items, t);              \
+    } while (0)
+#define PTB_PLAN(NV, CODES)                                                                                         \
+    do {                                                                                                            \
+        if (a.in_dtype == PTB_F16) PTB_PLAN_LD(NV, CODES, 2);                                                       \
+        else if (a.in_dtype == PTB_BF16) PTB_PLAN_LD(NV, CODES, 3);                                                 \
+        else PTB_PLAN_LD(NV, CODES, 1);                                                                             \
+    } while (0)
+    if (a.nviews == 1 && a.codes == CODES_ID) PTB_PLAN(1, CODES_ID);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPLR) PTB_PLAN(2, CODES_FLIPLR);
+    else if (a.nviews == 2 && a.codes == CODES_FLIPUD) PTB_PLAN(2, CODES_FLIPUD);
+    else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_PLAN(3, CODES_FLIPS);
+    else if (a.nviews == 4 && a.codes == CODES_D2) PTB_PLAN(4, CODES_D2);
+    else if (a.nviews == 8 && a.codes == CODES_D4) PTB_PLAN(8, CODES_D4);
+    else PTB_PLAN(8, -1);
+#undef PTB_PLAN
+#undef PTB_PLAN_LD
+}
+
+struct Group {
+    int y0, y1;                 // rows of the merged map this launch writes
+    std::vector<int> tiles;     // plan indices, ascending (slot = position)
+    int last_tile;              // the group is complete once this plan index is in (-1: no tile at all)
+    long long item_off;         // first item in the table
+    int item_cnt;
+};
+
+}  // namespace ptb
+
+struct ptb_band_plan {
+    int n, C, th, tw, H, W;
+    std::vector<int> xs, ys;
+    std::vector<ptb::BandItem> items;
+    std::vector<ptb::Group> groups;
+    std::vector<int> last_group;          // per tile: the last group that reads it
+    std::vector<std::vector<int>> ready;  // per tile: groups complete once it is in
+    const ptb::BandItem* dev_items = nullptr;
+    int n_bands = 0;
+    // per image
+    int pos = 0, launched = 0;
+    std::vector<const void*> src;
+    std::vector<long long> vs;
+    int cfg_set = 0, cfg_dtype = 0, cfg_V = 0, cfg_codes = 0, cfg_red = 0;
+    const void *cfg_merged = nullptr, *cfg_norm = nullptr, *cfg_weight = nullptr;
+};
+
+using namespace ptb;
+
+// x-cells of one band (tiles = plan indices covering it), split into 64 x 32 items appended to `out`
+static int band_items(const ptb_band_plan& p, const std::vector<int>& cover, const std::vector<int>& slot_of, int y0, int y1, int partial,
+                      std::vector<BandItem>& out) {
+    std::vector<int> xe{0, p.W};
+    for (int t : cover) { xe.push_back(p.xs[t]); xe.push_back(p.xs[t] + p.tw); }
+    std::sort(xe.begin(), xe.end());
+    xe.erase(std::unique(xe.begin(), xe.end()), xe.end());
+    struct XCell { int ox, w, n; int tile[MAX_COVER]; };
+    std::vector<XCell> cells;
+    for (size_t xi = 0; xi + 1 < xe.size(); ++xi) {
+        XCell c{};
+        c.ox = xe[xi]; c.w = xe[xi + 1] - xe[xi];
+        for (int t : cover) {   // ascending plan index = the order the tiles are integrated in
+            if (p.xs[t] <= c.ox && c.ox < p.xs[t] + p.tw) {
+                if (c.n == MAX_COVER) return PTB_EUNSUPPORTED;
+                c.tile[c.n++] = t;
+            }
+        }
+        if (!cells.empty() && cells.back().ox + cells.back().w == c.ox && cells.back().n == c.n &&
+            std::equal(c.tile, c.tile + c.n, cells.back().tile)) {
+            cells.back().w += c.w;   // same cover as the strip to the left: one wider cell
+            continue;
+        }
+        cells.push_back(c);
+    }
+    for (const XCell& c : cells) {
+        for (int cy = y0; cy < y1; cy += PLAN_CH) {
+            for (int cx = 0; cx < c.w; cx += CW) {
+                BandItem it{};
+                it.ax = c.ox + cx; it.ay = cy;
+                it.cwch = std::min(CW, c.w - cx) | (std::min(PLAN_CH, y1 - cy) << 16);
+                it.ntiles = c.n;
+                it.partial = partial;
+                for (int e = 0; e < c.n; ++e) {
+                    const int t = c.tile[e];
+                    it.cover[e] = (unsigned long long)slot_of[t] | ((unsigned long long)(it.ax - p.xs[t]) << 16) |
+                                  ((unsigned long long)(it.ay - p.ys[t]) << 32);
+                }
+                out.push_back(it);
+            }
+        }
+    }
+    return PTB_OK;
+}
+
+extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
+                                        int rows_per_launch, int partial_rows_lo, int partial_rows_hi, ptb_band_plan** out) {
+    if (!xs64 || !ys64 || !out || n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
+    *out = nullptr;
+    if (g_force_scalar || tw % 4 || th % 4 || W % 4 || tw > 32767 || th > 32767) return PTB_EUNSUPPORTED;
+    ptb_band_plan* p = new ptb_band_plan();
+    p->n = n; p->C = C; p->th = th; p->tw = tw; p->H = H; p->W = W;
+    p->xs.resize(n); p->ys.resize(n);
+    std::vector<int> edges{0, H};
+    for (int t = 0; t < n; ++t) {
+        if (xs64[t] < 0 || ys64[t] < 0 || xs64[t] + tw > W || ys64[t] + th > H) { delete p; return PTB_EBOUNDS; }
+        if (xs64[t] % 4 || ys64[t] % 4) { delete p; return PTB_EUNSUPPORTED; }
+        p->xs[t] = (int)xs64[t]; p->ys[t] = (int)ys64[t];
+        edges.push_back(p->ys[t]); edges.push_back(p->ys[t] + th);
+    }
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    // bands: consecutive edge intervals with the tiles that cover them
+    struct Band { int y0, y1; std::vector<int> cover; };
+    std::vector<Band> bands;
+    for (size_t i = 0; i + 1 < edges.size(); ++i) {
+        Band b{edges[i], edges[i + 1], {}};
+        for (int t = 0; t < n; ++t)
+            if (p->ys[t] <= b.y0 && p->ys[t] + th >= b.y1) b.cover.push_back(t);
+        if ((int)b.cover.size() > PLAN_TILES) { delete p; return PTB_EUNSUPPORTED; }
+        bands.push_back(std::move(b));
+    }
+    p->n_bands = (int)bands.size();
+    // launch groups: consecutive bands up to ~rows_per_launch rows and PLAN_TILES tiles; a band without tiles (uncovered rows)
+    // rides with its neighbour
+    const int target = std::max(1, rows_per_launch);
+    p->last_group.assign(n, -1);
+    p->ready.assign(n, {});
+    size_t bi = 0;
+    while (bi < bands.size()) {
+        Group g{};
+        g.y0 = bands[bi].y0;
+        std::vector<int> tiles;
+        size_t bj = bi;
+        while (bj < bands.size()) {
+            std::vector<int> merged_tiles = tiles;
+            merged_tiles.insert(merged_tiles.end(), bands[bj].cover.begin(), bands[bj].cover.end());
+            std::sort(merged_tiles.begin(), merged_tiles.end());
+            merged_tiles.erase(std::unique(merged_tiles.begin(), merged_tiles.end()), merged_tiles.end());
+            const bool first = bj == bi;
+            if (!first && ((int)merged_tiles.size() > PLAN_TILES || (bands[bj].y1 - g.y0 > target && !tiles.empty()))) break;
+            tiles.swap(merged_tiles);
+            ++bj;
+        }
+        g.y1 = bands[bj - 1].y1;
+        g.tiles = tiles;
+        g.last_tile = tiles.empty() ? -1 : tiles.back();
+        std::vector<int> slot_of(n, 0);
+        for (size_t s = 0; s < tiles.size(); ++s) slot_of[tiles[s]] = (int)s;
+        g.item_off = (long long)p->items.size();
+        std::vector<BandItem> its;
+        for (size_t b = bi; b < bj; ++b) {
+            const int partial = (bands[b].y0 >= partial_rows_lo && bands[b].y1 <= partial_rows_hi) ? 1 : 0;
+            const int rc = band_items(*p, bands[b].cover, slot_of, bands[b].y0, bands[b].y1, partial, its);
+            if (rc != PTB_OK) { delete p; return rc; }
+        }
+        std::stable_sort(its.begin(), its.end(), [](const BandItem& l, const BandItem& r) { return l.ntiles > r.ntiles; });
+        g.item_cnt = (int)its.size();
+        p->items.insert(p->items.end(), its.begin(), its.end());
+        const int gi = (int)p->groups.size();
+        for (int t : tiles) p->last_group[t] = std::max(p->last_group[t], gi);
+        p->groups.push_back(std::move(g));
+        bi = bj;
+    }
+    // a group without any tile (an image whose first / last rows nobody covers) completes with the first tile of the image
+    for (size_t gi = 0; gi < p->groups.size(); ++gi) {
+        const int lt = p->groups[gi].last_tile < 0 ? 0 : p->groups[gi].last_tile;
+        p->ready[lt].push_back((int)gi);
+    }
+    p->src.assign(n, nullptr);
+    p->vs.assign(n, 0);
+    *out = p;
+    return (int64_t)(p->items.size() * sizeof(BandItem));
+}
+
+extern "C" int ptb_band_plan_upload(ptb_band_plan* p, void* dev_table, ptb_stream_t stream) {
+    if (!p || !dev_table || (reinterpret_cast<uintptr_t>(dev_table) & 63u)) return PTB_EINVAL;
+    const hipError_t e = hipMemcpyAsync(dev_table, p->items.data(), p->items.size() * sizeof(BandItem), hipMemcpyHostToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    p->dev_items = static_cast<const BandItem*>(dev_table);
+    return PTB_OK;
+}
+
+extern "C" int ptb_band_plan_info(const ptb_band_plan* p, int* n_groups, int* n_bands, int64_t* n_items, int64_t* last_group_of_tile,
+                                  int64_t* group_rows /* [3 * n_groups]: y0, y1, last tile */) {
+    if (!p) return PTB_EINVAL;
+    if (n_groups) *n_groups = (int)p->groups.size();
+    if (n_bands) *n_bands = p->n_bands;
+    if (n_items) *n_items = (int64_t)p->items.size();
+    if (last_group_of_tile) for (int t = 0; t < p->n; ++t) last_group_of_tile[t] = p->last_group[t];
+    if (group_rows)
+        for (size_t g = 0; g < p->groups.size(); ++g) {
+            group_rows[3 * g] = p->groups[g].y0; group_rows[3 * g + 1] = p->groups[g].y1; group_rows[3 * g + 2] = p->groups[g].last_tile;
+        }
+    return PTB_OK;
+}
+
+extern "C" int ptb_band_plan_reset(ptb_band_plan* p) {
+    if (!p) return PTB_EINVAL;
+    p->pos = 0; p->launched = 0; p->cfg_set = 0;
+    return PTB_OK;
+}
+
+extern "C" int ptb_band_plan_state(const ptb_band_plan* p, int* pos, int* launched) {
+    if (!p) return PTB_EINVAL;
+    if (pos) *pos = p->pos;
+    if (launched) *launched = p->launched;
+    return PTB_OK;
+}
+
+extern "C" void ptb_band_plan_destroy(ptb_band_plan* p) { delete p; }
+
+extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride,
+                                    int in_dtype, int V, const int* views, int reduction, float* merged, const float* norm_full,
+                                    const float* weight, ptb_stream_t stream) {
+    if (!p || !batch || !merged || !norm_full || !weight || B < 1) return PTB_EINVAL;
+    if (!p->dev_items) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
+    if (V < 1 || V > MAX_VIEWS || !views) return PTB_EINVAL;
+    int nT = 0;
+    for (int k = 0; k < V; ++k) {
+        if (views[k] < 0 || views[k] > 7) return PTB_EINVAL;
+        nT += views[k] & 1;
+    }
+    if (nT && p->th != p->tw) return PTB_EINVAL;
+    // not the next planned tiles, or a different configuration than the image started with: the caller leaves deferred mode
+    if (pos != p->pos || pos + B > p->n) return PTB_EUNSUPPORTED;
+    const int codes = [&] { int v = 0; for (int k = 0; k < V; ++k) v |= (views[k] & 7) << (3 * k); return v; }();
+    if (p->cfg_set) {
+        if (p->cfg_dtype != in_dtype || p->cfg_V != V || p->cfg_codes != codes || p->cfg_red != reduction || p->cfg_merged != merged ||
+            p->cfg_norm != norm_full || p->cfg_weight != weight) return PTB_EUNSUPPORTED;
+    }
+    const long long per_tile = (long long)p->C * p->th * p->tw;
+    const unsigned mask = in_dtype == PTB_F32 ? 15u : 7u;
+    const size_t esz = in_dtype == PTB_F32 ? 4 : 2;
+    if (nT > MAX_T || tile_stride < per_tile || view_stride < per_tile || tile_stride % 4 || view_stride % 4 ||
+        (reinterpret_cast<uintptr_t>(batch) & mask) || !aligned16(merged) || !aligned16(norm_full) || !aligned16(weight))
+        return PTB_EUNSUPPORTED;
+    p->cfg_set = 1; p->cfg_dtype = in_dtype; p->cfg_V = V; p->cfg_codes = codes; p->cfg_red = reduction;
+    p->cfg_merged = merged; p->cfg_norm = norm_full; p->cfg_weight = weight;
+    for (int b = 0; b < B; ++b) {
+        p->src[pos + b] = static_cast<const char*>(batch) + (size_t)b * (size_t)tile_stride * esz;
+        p->vs[pos + b] = view_stride;
+    }
+    p->pos = pos + B;
+    ViewArgs a{};
+    a.weight = weight; a.merged = merged; a.norm_full = norm_full;
+    a.in_dtype = in_dtype;
+    a.H = p->th; a.W = p->tw; a.C = p->C;
+    a.dst_chan_stride = (long long)p->H * p->W;
+    a.dst_row_stride = p->W;
+    a.nviews = V;
+    a.codes = codes;
+    a.scale = 1.0f;
+    a.op = reduction;
+    a.divisor = reduction == PTB_RED_SUM ? 1.0f : (float)V;
+    int launched = 0;
+    for (int t = pos; t < pos + B; ++t) {
+        for (int gi : p->ready[t]) {
+            const Group& g = p->groups[gi];
+            if (!g.item_cnt) { ++p->launched; continue; }
+            GroupTiles gt;
+            for (size_t s = 0; s < g.tiles.size(); ++s) { gt.src[s] = p->src[g.tiles[s]]; gt.vs[s] = p->vs[g.tiles[s]]; }
+            for (size_t s = g.tiles.size(); s < (size_t)PLAN_TILES; ++s) { gt.src[s] = nullptr; gt.vs[s] = 0; }
+            const long long blocks = (long long)g.item_cnt * p->C;
+            if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+            launch_plan(a, p->dev_items + g.item_off, gt, (int)blocks, (hipStream_t)stream);
+            const int rc = check_launch();
+            if (rc != PTB_OK) return rc;
+            ++p->launched;
+            ++launched;
+        }
+    }
+    return launched;
+}

@@ -1,6 +1,8 @@
 // Device-side pieces shared by the view kernels (ptb_views.hip) and the loop-edge kernels (ptb_edges.hip):
 // launch descriptors, TTA reductions, the XOR-swizzled LDS tile and the "one chunk -> all V views" scatter.
 #pragma once
+#include <initializer_list>
+
 #include "ptb_common.h"
 
 namespace ptb {
@@ -216,6 +218,103 @@ __device__ __forceinline__ void scatter_chunk(const ViewArgs& a, int B, int b, i
             *reinterpret_cast<float4*>(a.dst + off) = w;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------ view codes of the TTA groups
+constexpr int pack_codes(std::initializer_list<int> l) {
+    int v = 0, k = 0;
+    for (int c : l) v |= c << (3 * k++);
+    return v;
+}
+constexpr int CODES_ID = 0;
+constexpr int CODES_FLIPLR = pack_codes({0, 4});
+constexpr int CODES_FLIPUD = pack_codes({0, 2});
+constexpr int CODES_FLIPS = pack_codes({0, 4, 2});
+constexpr int CODES_D2 = pack_codes({0, 4, 2, 6});
+constexpr int CODES_D4 = pack_codes({0, 5, 6, 3, 1, 4, 7, 2});  // inverse views of d4_image_deaugment, tta.py:455-466
+
+
+// Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
+// tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
+template <int CH, int NV, int CODES, int OPK, int LD>
+__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt,
+                                                int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
+                                                float divisor, float* lds, int tid, bool more_entries) {
+    constexpr int QPR = CH / 4;  // float4 per source row of a transposed block
+    const int q = tid & 15, r = tid >> 4;
+    const int rr = tid / QPR, qq = tid % QPR;
+    const bool act = (r < ch) && (4 * q < cw);
+    const bool tact = (rr < cw) && (4 * qq < ch);
+    const int nv = CODES >= 0 ? NV : nv_rt;
+    const int codes = CODES >= 0 ? CODES : codes_rt;
+
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (k < nv) {
+            const int code = (codes >> (3 * k)) & 7;
+            const long long p = plane + (long long)k * view_stride;   // element offset of view k
+            if (!(code & 1)) {
+                if (act) {
+                    const int i = ly + r, j = lx + 4 * q;
+                    const int row = (code & 2) ? H - 1 - i : i;
+                    const int col = (code & 4) ? W - 4 - j : j;
+                    const float4 t = ld4<LD>(src, p + (long long)row * W + col);
+                    v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
+                }
+            } else if (tact) {
+                const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
+                const int C0 = (code & 4) ? W - ly - ch : ly;
+                v[k] = ld4<LD>(src, p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+            }
+        }
+    }
+
+    int tb = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        if (k < nv && ((codes >> (3 * k)) & 1)) {
+            const int code = (codes >> (3 * k)) & 7;
+            float* buf = lds + tb * (CW * CH);
+            ++tb;
+            if (tact) {
+                const int jl = (code & 2) ? cw - 1 - rr : rr;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int cc = 4 * qq + m;
+                    const int il = (code & 4) ? ch - 1 - cc : cc;
+                    buf[swz(il, jl)] = comp(v[k], m);
+                }
+            }
+        }
+    }
+    if (tb) {
+        __syncthreads();
+        tb = 0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (k < nv && ((codes >> (3 * k)) & 1)) {
+                const float* buf = lds + tb * (CW * CH);
+                ++tb;
+                v[k] = act ? *reinterpret_cast<const float4*>(buf + swz(r, 4 * q)) : make_float4(1.f, 1.f, 1.f, 1.f);
+            }
+        }
+        if (more_entries) __syncthreads();  // LDS tiles are reused by the next covering tile
+    }
+
+    float4 s = make_float4(red_pre<OPK>(v[0].x, op), red_pre<OPK>(v[0].y, op), red_pre<OPK>(v[0].z, op), red_pre<OPK>(v[0].w, op));
+#pragma unroll
+    for (int k = 1; k < NV; ++k) {
+        if (k < nv) {
+            s.x = __fadd_rn(s.x, red_pre<OPK>(v[k].x, op));
+            s.y = __fadd_rn(s.y, red_pre<OPK>(v[k].y, op));
+            s.z = __fadd_rn(s.z, red_pre<OPK>(v[k].z, op));
+            s.w = __fadd_rn(s.w, red_pre<OPK>(v[k].w, op));
+        }
+    }
+    return make_float4(red_post<OPK>(s.x, op, divisor), red_post<OPK>(s.y, op, divisor), red_post<OPK>(s.z, op, divisor),
+                       red_post<OPK>(s.w, op, divisor));
 }
 
 }  // namespace ptb

@@ -6,6 +6,7 @@ accumulators in HBM and blends with the hand-written HIP kernels of ``libptb_hip
 CPU fallback on that path.
 """
 import math
+import warnings
 from typing import Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -254,6 +255,32 @@ def _coords_xy(crop_coords, n_expected=None):
     return arr
 
 
+_warned = set()
+
+
+def _warn_once(key, message):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+
+
+def _resolve_device(device, what):
+    """The reference's mergers default to device="cpu" (tiles.py:295).  This package keeps the accumulators in MI355X HBM and
+    has no CPU path, so code written against the reference -- `TileMerger(shape, C, weight)` -- gets the current CUDA device
+    instead (said once, loudly); without a GPU the constructor fails in this one place."""
+    device = torch.device(device)
+    if device.type == "cuda":
+        return device
+    if device.type == "cpu" and torch.cuda.is_available():
+        _warn_once(("cpu", what), f"{what}(device='cpu'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU path; "
+                                  f"using device='cuda:{torch.cuda.current_device()}' instead (pass device='cuda' to silence this).")
+        return torch.device("cuda", torch.cuda.current_device())
+    raise RuntimeError(
+        f"{what}(device='{device}'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU "
+        "path; construct it with device='cuda' (or use CudaTileMerger) on a machine with a GPU."
+    )
+
+
 class _Plan:
     """State of a *planned* TileMerger (constructed with the complete ``crops`` of the image).
 
@@ -314,53 +341,68 @@ class _Plan:
         return False
 
 
+def _defer_rows_default():
+    import os
+
+    return int(os.environ.get("PTB_DEFER_ROWS", "1024"))
+
+
 class _Bands:
-    """Deferred planned merging (``TileMerger(..., crops=tiler.crops, defer=True)``).
+    """Deferred planned merging (``TileMerger(..., crops=tiler.crops, defer=True)``), planned once and driven from C
+    (``ptb_band_plan_*``, csrc/ptb_bandplan.hip).
 
-    A *band* is the rows between two consecutive tile edges; every tile that touches a band covers all of its rows.  The
-    merger only keeps references to the model outputs it is handed, and when the last tile of a band has arrived one launch
-    (``ptb_merge_band``) reads all covering tiles of the band, de-augments, reduces, blends in integration order and writes
-    ``sum / norm`` to the result -- the accumulator image never travels through HBM (the incremental path re-reads and
-    re-writes every pixel once per overlapping tile row).  The fp32 operation order per pixel is the incremental path's,
-    so the result is bit-identical.  Cost: the batches of (at most) the last two tile rows stay alive until their bands
-    are done, and they must not be modified in place in the meantime -- which is why this is opt-in.
+    A *band* is the rows between two consecutive tile edges; every tile that touches a band covers all of its rows.  Consecutive
+    bands form a *launch group* of about ``rows`` rows (default 1024; ``defer_rows=`` / ``PTB_DEFER_ROWS``).  The merger only keeps
+    references to the model outputs it is handed, and when the last tile of a group has arrived ONE launch reads all covering
+    tiles of its rows, de-augments, reduces, blends in integration order and writes ``sum / norm`` to the result -- the
+    accumulator image never travels through HBM (the incremental path re-reads and re-writes every pixel once per overlapping
+    tile row).  The fp32 operation order per pixel is the incremental path's, so the result is bit-identical.  Cost: the batches
+    of the last ``rows / step + 1`` tile rows stay alive until their group is done, and they must not be modified in place in the
+    meantime -- which is why this is opt-in.
 
-    Until the first band is launched any deviation from the plan simply replays the held batches through the incremental
-    path; afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
+    Until the first group is launched any deviation from the plan simply replays the held batches through the incremental path;
+    afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
 
-    MAX_TILES, MAX_COVER = 48, 4
+    def __init__(self, handle, table, bands, n_bands, last_group, monotone):
+        self.handle = handle            # ptb_band_plan*
+        self.table = table              # uint8 device tensor holding the work-item table (owned here)
+        self.bands = bands              # [(y0, y1, last tile)] per launch group, top to bottom
+        self.n_bands = n_bands
+        self.last_group = last_group    # plan index of a tile -> the last launch group that reads it
+        self.monotone = monotone        # groups complete in index order (row-major crops): batches can be released early
 
-    def __init__(self, bands, ready_at, last_band):
-        self.bands = bands          # [dict(y0, y1, tiles, xs, ys)] top to bottom
-        self.ready_at = ready_at    # plan index of a tile -> bands that are complete once it is in
-        self.last_band = last_band  # plan index of a tile -> the last band that reads it
+    def __del__(self):
+        try:
+            if self.handle:
+                N.load().ptb_band_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
 
     @staticmethod
-    def build(plan, th, tw, H, W):
-        xs, ys = plan.xy[0], plan.xy[1]
-        n = len(xs)
-        if tw % 4 or th % 4 or W % 4 or np.any(xs % 4) or np.any(ys % 4):
+    def build(plan, channels, th, tw, H, W, device, rows):
+        import ctypes
+
+        lib = N.load()
+        handle = ctypes.c_void_p()
+        n = plan.xy.shape[1]
+        nbytes = lib.ptb_band_plan_create(plan.xy[0].ctypes.data_as(N._i64p), plan.xy[1].ctypes.data_as(N._i64p), n, channels, th, tw, H, W,
+                                          int(rows), 0, 0, ctypes.byref(handle))
+        if nbytes < 0:
             return None
-        edges = np.unique(np.concatenate([ys, ys + th]))
-        bands, ready_at, last_band = [], {}, np.full(n, -1, dtype=np.int64)
-        for y0, y1 in zip(edges[:-1], edges[1:]):
-            tiles = np.nonzero((ys <= y0) & (ys + th >= y1))[0]
-            if len(tiles) == 0:
-                continue
-            if len(tiles) > _Bands.MAX_TILES:
-                return None
-            bx = xs[tiles]
-            cuts = np.unique(np.concatenate([bx, bx + tw]))
-            cover = ((bx[None, :] <= cuts[:-1, None]) & (cuts[:-1, None] < bx[None, :] + tw)).sum(axis=1)
-            if cover.max() > _Bands.MAX_COVER or len(cuts) - 1 > 40:
-                return None
-            b = len(bands)
-            bands.append(dict(y0=int(y0), y1=int(y1), tiles=tiles, xs=np.ascontiguousarray(xs[tiles]), ys=np.ascontiguousarray(ys[tiles])))
-            ready_at.setdefault(int(tiles.max()), []).append(b)
-            last_band[tiles] = b
-        if np.any(last_band < 0):
-            return None
-        return _Bands(bands, ready_at, last_band)
+        table = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        with N.on_device(device):
+            rc = lib.ptb_band_plan_upload(handle, table.data_ptr(), N.stream_ptr(device))
+        N.bump()
+        N.check(rc, "TileMerger(defer=True)")
+        ng, nb, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        lib.ptb_band_plan_info(handle, ctypes.byref(ng), ctypes.byref(nb), ctypes.byref(ni), None, None)
+        last_group = np.zeros(n, dtype=np.int64)
+        rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
+        lib.ptb_band_plan_info(handle, None, None, None, last_group.ctypes.data_as(N._i64p), rows_arr.ctypes.data_as(N._i64p))
+        groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
+        lasts = [g[2] for g in groups]
+        return _Bands(handle, table, groups, nb.value, last_group, all(a <= b for a, b in zip(lasts, lasts[1:])))
 
 
 class TileMerger:
@@ -372,7 +414,7 @@ class TileMerger:
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
 
-    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False):
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None):
         """``crops`` (extension, optional): the complete crop list the image will receive (``tiler.crops``), in the
         order it will be integrated.  With it the merger runs *planned*: the normaliser is known up front and every
         block of the image is divided by it in the very launch that brings its last tile, so ``merge()`` has nothing
@@ -380,13 +422,8 @@ class TileMerger:
 
         ``defer=True`` (with ``crops``): *deferred* planned merging -- the merger holds on to the batches and merges a
         horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
-        ``_Bands`` (the batches must stay unmodified until then)."""
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise RuntimeError(
-                f"TileMerger(device='{device}'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU "
-                "path; construct it with device='cuda' (or use CudaTileMerger)."
-            )
+        ``_Bands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024)."""
+        device = _resolve_device(device, "TileMerger")
         if dtype != torch.float32:
             raise NotImplementedError("TileMerger accumulators are float32 on the native path")
         N.load()
@@ -413,20 +450,29 @@ class TileMerger:
         self._merged = None       # planned mode: the merge result the accumulate launches fill in
         self._plan = _Plan.build(self, crops) if crops is not None else None
         self._bands = None
+        if crops is not None and self._plan is None:
+            _warn_once(("plan", tuple(self.weight.shape), self.image_height, self.image_width),
+                       "TileMerger(crops=...): this geometry is off the 64 x 32 block grid of the planned kernels (tile size / origins); "
+                       "the ordinary accumulate + merge path is used (same results, one more pass).")
         if defer and self._plan is not None:
-            self._bands = _Bands.build(self._plan, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height, self.image_width)
+            self._bands = _Bands.build(self._plan, channels, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height,
+                                       self.image_width, device, defer_rows if defer_rows is not None else _defer_rows_default())
+            if self._bands is None:
+                _warn_once(("defer", tuple(self.weight.shape), self.image_height, self.image_width),
+                           "TileMerger(defer=True): the deferred band kernel does not take this geometry (origins off the 4-pixel grid, "
+                           "more than 48 tiles per band or 4 per pixel); the planned incremental path is used (same results, slower).")
+        elif defer:
+            _warn_once(("defer-noplan",), "TileMerger(defer=True) needs the complete crop list (crops=tiler.crops) on the planned block "
+                                          "grid; the ordinary path is used.")
         self._defer_reset()
 
     # ------------------------------------------------------------------ deferred bands
     def _defer_reset(self):
         self._defer_active = self._bands is not None
-        self._held = []          # [batch tensor, coords, views, reduction, last band that reads it], integration order
-        self._bands_done = 0
-        self._defer_cfg = None   # (views, reduction, dtype code) of this image
+        self._held = []          # [batch tensor, coords, views, reduction, last launch group that reads it], integration order
+        self._bands_done = 0     # launch groups issued for this image
         if self._bands is not None:
-            n = self._plan.xy.shape[1]
-            self._tile_src = np.zeros(n, dtype=np.uint64)
-            self._tile_vs = np.zeros(n, dtype=np.int64)
+            N.load().ptb_band_plan_reset(self._bands.handle)
 
     def _defer_flush(self, what, keep_plan=False):
         """Leave deferred mode: replay the held batches through the incremental path (only before the first band) --
@@ -445,50 +491,44 @@ class TileMerger:
             self._accumulate(batch, coords, views, reduction)
 
     def _defer_step(self, batch, coords, xy, views, reduction, dcode):
-        """Take one planned batch into custody and merge the bands it completes.  False: not deferrable (the caller goes on
-        with the incremental path, after the held batches were replayed)."""
+        """Take one planned batch into custody and merge the launch groups it completes (``ptb_band_plan_submit``: the pointer
+        bookkeeping and the launches happen in C).  False: not deferrable (the caller goes on with the incremental path, after
+        the held batches were replayed)."""
         plan, bands = self._plan, self._bands
         B = xy.shape[1]
-        cfg = (tuple(views) if views is not None else None, reduction, dcode)
-        ok = (plan.active and not self._eager_norm and plan.pos + B <= plan.xy.shape[1]
-              and xy[0].data == plan.xy[0, plan.pos:plan.pos + B].data and xy[1].data == plan.xy[1, plan.pos:plan.pos + B].data
-              and (self._defer_cfg is None or self._defer_cfg == cfg))
-        if not ok:
+        pos = plan.pos
+        ok = (plan.active and not self._eager_norm and pos + B <= plan.xy.shape[1]
+              and xy[0].data == plan.xy[0, pos:pos + B].data and xy[1].data == plan.xy[1, pos:pos + B].data)
+        rc = N.PTB_EUNSUPPORTED
+        if ok:
+            if self._merged is None:
+                self._merged = torch.empty_like(self._image)
+            th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
+            per_tile = self.channels * th * tw
+            varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
+            dev = self._image.device
+            with N.on_device(dev):
+                rc = N.load().ptb_band_plan_submit(bands.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, dcode,
+                                                   len(views) if views is not None else 1, varr, reduction, self._merged.data_ptr(),
+                                                   plan.norm_full.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
+            N.bump()
+        if rc == N.PTB_EUNSUPPORTED:
+            _warn_once(("defer-deviation",), "TileMerger(defer=True): a batch deviates from the planned crop sequence / configuration (or "
+                                             "norm_mask was read); leaving deferred mode for this image, the held batches are replayed incrementally.")
             self._defer_flush("an unplanned tile batch")
             return False
-        self._defer_cfg = cfg
-        th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
-        per_tile = self.channels * th * tw
-        pos = plan.pos
-        self._tile_src[pos:pos + B] = batch.data_ptr() + np.arange(B, dtype=np.uint64) * np.uint64(per_tile * batch.element_size())
-        self._tile_vs[pos:pos + B] = B * per_tile
-        self._held.append([batch, coords, views, reduction, int(bands.last_band[pos:pos + B].max())])
+        if rc < 0:
+            N.check(rc, "TileMerger.integrate_batch (deferred bands)")
+        self._held.append((batch, coords, views, reduction, int(bands.last_group[pos:pos + B].max())))
         plan.pos += B
         self._log.append(xy)
-        if self._merged is None:
-            self._merged = torch.empty_like(self._image)
-        varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
-        n_views = len(views) if views is not None else 1
-        lib = N.load()
-        dev = self._image.device
-        for t in range(pos, pos + B):
-            for b in bands.ready_at.get(t, ()):
-                band = bands.bands[b]
-                src = np.ascontiguousarray(self._tile_src[band["tiles"]])
-                vs = np.ascontiguousarray(self._tile_vs[band["tiles"]])
-                with N.on_device(dev):
-                    rc = lib.ptb_merge_band(self._merged.data_ptr(), plan.norm_full.data_ptr(), self.weight.data_ptr(), src.ctypes.data,
-                                            vs.ctypes.data, dcode, n_views, varr, reduction, band["xs"].ctypes.data, band["ys"].ctypes.data,
-                                            len(src), self.channels, th, tw, self.image_height, self.image_width, band["y0"], band["y1"],
-                                            N.stream_ptr(dev))
-                N.bump()
-                if rc == -2 and not self._bands_done:
-                    # (this batch is already in custody: the replay integrates it too)
-                    self._defer_flush("a band the fast kernel does not take", keep_plan=True)
-                    return True
-                N.check(rc, "TileMerger.integrate_batch (deferred band)")
-                self._bands_done += 1
-                while self._held and self._held[0][4] <= b:   # batches no later band reads: let go of them
+        if rc:
+            self._bands_done += rc
+            if self._bands_done == len(bands.bands):
+                self._held.clear()
+            elif bands.monotone:   # groups 0 .. done-1 are out: batches no later group reads can go
+                done = self._bands_done
+                while self._held and self._held[0][4] < done:
                     self._held.pop(0)
         return True
 
@@ -734,6 +774,16 @@ class TileMerger:
     def device(self) -> torch.device:
         return self._image.device
 
+    @property
+    def mode(self) -> str:
+        """Which path this merger is on right now: "deferred bands" | "planned" | "incremental" (diagnostics; a geometry the
+        faster kernels do not take, or a deviation from the planned crop sequence, degrades it -- with a one-time warning)."""
+        if self._bands is not None and self._defer_active:
+            return "deferred bands"
+        if self._plan is not None and self._plan.active:
+            return "planned"
+        return "incremental"
+
     def _finish_planned(self):
         """Planned mode: divide whatever the accumulate launches have not finalised themselves; returns the result."""
         if self._defer_active:
@@ -838,5 +888,5 @@ class TileMerger:
 class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
 
-    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False):
-        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer)
+    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False, defer_rows=None):
+        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer, defer_rows=defer_rows)

@@ -129,12 +129,9 @@ class VolumeMerger:
     on the GPU.  ``integrate_batch`` adds ``tile * weight`` tile after tile (bit-identical to the reference's loop)."""
 
     def __init__(self, volume_shape, channels: int, weight, device="cpu", dtype=torch.float32):
-        device = torch.device(device)
-        if device.type != "cuda":
-            raise RuntimeError(
-                f"VolumeMerger(device='{device}'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU "
-                "path; construct it with device='cuda'."
-            )
+        from .tiles import _resolve_device
+
+        device = _resolve_device(device, "VolumeMerger")   # the reference's default "cpu" -> current CUDA device, warned once
         if dtype != torch.float32:
             raise NotImplementedError("VolumeMerger accumulators are float32 on the native path")
         N.load()

@@ -16,6 +16,15 @@ def prepare_classes(mode, classes):
     return to_tensor(classes, dtype=torch.long)
 
 
+def _dense_target(y_true, x, bs, C, y_pred):
+    """Dense 0/1 (or soft) target as fp32 [B, C, HW]; the kernels take B, C, HW from the prediction, so a target with another
+    element count (half-resolution mask, wrong channel count) must fail here instead of being read past its end."""
+    dense = K._f32c(y_true.to(device=x.device), "region loss")
+    if dense.numel() != x.numel():
+        raise RuntimeError(f"target shape {tuple(y_true.shape)} does not match prediction shape {tuple(y_pred.shape)}")
+    return dense.reshape(bs, C, -1)
+
+
 def region_statistics(y_pred, y_true, mode, from_logits, ignore_index):
     """(I, P, T) per class over batch and pixels: one HIP pass over the logits; the softmax / sigmoid probabilities, the
     one-hot targets and the ignore mask are formed in registers (reference losses/dice.py:68-111)."""
@@ -35,7 +44,7 @@ def region_statistics(y_pred, y_true, mode, from_logits, ignore_index):
     else:
         C = 1 if mode == BINARY_MODE else x.size(1)
         x = x.reshape(bs, C, -1)
-        dense = K._f32c(y_true.to(device=x.device), "region loss").reshape(bs, C, -1)
+        dense = _dense_target(y_true, x, bs, C, y_pred)
         prob = K.PROB_SIGMOID if from_logits else K.PROB_IDENTITY
         stats = K.RegionStats.apply(x, None, dense, prob, ignore_index is not None, 0, float(ignore_index) if ignore_index is not None else 0.0)
     from ..parallel import sync_region_statistics   # batch sharded over ranks: sum the [C] partials (no-op by default)
@@ -69,8 +78,28 @@ def _inputs(y_pred, y_true, mode, from_logits, ignore_index):
         return x, labels, None, (K.PROB_SOFTMAX if from_logits else K.PROB_IDENTITY), has_ign, int(ignore_index) if has_ign else 0, 0.0
     C = 1 if mode == BINARY_MODE else x.size(1)
     x = x.reshape(bs, C, -1)
-    dense = K._f32c(y_true.to(device=x.device), "region loss").reshape(bs, C, -1)
+    dense = _dense_target(y_true, x, bs, C, y_pred)
     return x, None, dense, (K.PROB_SIGMOID if from_logits else K.PROB_IDENTITY), has_ign, 0, float(ignore_index) if has_ign else 0.0
+
+
+_mask_cache = {}
+
+
+def _class_mask(classes, C, device):
+    """uint8 [C] device mask of the selected classes and their count, built once per (classes, C, device) -- not per forward
+    (a pageable host-to-device copy would block the host on every call).  (None, n) when `classes` holds duplicates: the
+    reference indexes loss[classes], so duplicates would count twice and the caller composes the torch tail instead."""
+    key = (tuple(int(c) for c in classes.reshape(-1).tolist()), int(C), str(device))
+    hit = _mask_cache.get(key)
+    if hit is None:
+        host = torch.zeros(C, dtype=torch.uint8)
+        host[list(key[0])] = 1
+        n_sel = len(key[0])
+        hit = (host.to(device) if int(host.sum()) == n_sel else None, n_sel)
+        if len(_mask_cache) > 64:
+            _mask_cache.clear()
+        _mask_cache[key] = hit
+    return hit
 
 
 def fused_region_loss(y_pred, y_true, mode, from_logits, ignore_index, dice_weight, jaccard_weight, smooth, eps, log_loss, classes,
@@ -87,12 +116,9 @@ def fused_region_loss(y_pred, y_true, mode, from_logits, ignore_index, dice_weig
     C = x.size(1)
     mask, n_sel = None, C
     if classes is not None:
-        mask = torch.zeros(C, dtype=torch.uint8)
-        mask[classes.cpu()] = 1
-        n_sel = int(classes.numel())            # (the reference indexes loss[classes]: duplicates would count twice)
-        if int(mask.sum()) != n_sel:
+        mask, n_sel = _class_mask(classes, C, x.device)
+        if mask is None:
             return None
-        mask = mask.to(x.device)
     flags = K.SEG_HAS_IGNORE if has_ign else 0
     gamma = alpha = 0.0
     scale = 0.0

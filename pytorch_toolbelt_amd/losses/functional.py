@@ -72,6 +72,8 @@ def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, r
         dense = K.as_bchw(K._f32c(dense, "focal loss"))
     else:
         labels = labels.to(device=x.device, dtype=torch.int64).reshape(x.shape[0], -1).contiguous()
+        if labels.shape[1] != x.shape[2]:   # the kernel takes B, C, HW from the logits: a smaller target would be read past its end
+            raise RuntimeError(f"target shape {tuple(labels.shape)} does not match output shape {tuple(shape)}")
     cw = None
     if class_weights is not None:
         cw = class_weights.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()

@@ -81,6 +81,8 @@ def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
     B = x.shape[0]
     x = x.reshape(B, -1)
     y = labels.to(device=x.device, dtype=torch.float32).reshape(B, -1).contiguous()
+    if y.shape[1] != x.shape[1]:
+        raise RuntimeError(f"target shape {tuple(labels.shape)} does not match logits shape {tuple(logits.shape)}")
     seg_loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
                                           float(ignore_index) if ignore_index is not None else 0.0)
     return seg_loss.mean().float() if per_image else seg_loss[0].float()
@@ -97,6 +99,8 @@ def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_i
         raise ValueError("Sigmoid output possible only with 1 class")   # reference lovasz.py:129-131 (always hit for C == 1)
     x = x.reshape(B, C, -1)
     lab = labels.to(device=x.device, dtype=torch.int64).reshape(B, -1).contiguous()
+    if lab.shape[1] != x.shape[2]:
+        raise RuntimeError(f"target shape {tuple(labels.shape)} does not match probabilities shape {tuple(probas.shape)}")
     seg_loss, fg = _LovaszSegments.apply(x, lab, None, _SOFTMAX, bool(per_image), ignore_index is not None,
                                          int(ignore_index) if ignore_index is not None else 0, 0.0)
     groups = B if per_image else 1

@@ -131,35 +131,59 @@ def test_first_touch_bitmap():
     assert rc == -4
 
 
+def _c_band_plan(crops, C, th, tw, H, W, rows):
+    """ptb_band_plan_create + ptb_band_plan_info (host-side planning only: no GPU needed)."""
+    import ctypes
+
+    lib = N.load()
+    xy = np.ascontiguousarray(np.asarray(crops, dtype=np.int64)[:, :2].T)
+    handle = ctypes.c_void_p()
+    nbytes = lib.ptb_band_plan_create(xy[0].ctypes.data_as(N._i64p), xy[1].ctypes.data_as(N._i64p), xy.shape[1], C, th, tw, H, W, rows, 0, 0,
+                                      ctypes.byref(handle))
+    if nbytes < 0:
+        return int(nbytes), None
+    ng, nb, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+    assert lib.ptb_band_plan_info(handle, ctypes.byref(ng), ctypes.byref(nb), ctypes.byref(ni), None, None) == 0
+    last_group = np.zeros(xy.shape[1], dtype=np.int64)
+    rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
+    assert lib.ptb_band_plan_info(handle, None, None, None, last_group.ctypes.data_as(N._i64p), rows_arr.ctypes.data_as(N._i64p)) == 0
+    lib.ptb_band_plan_destroy(handle)
+    assert nbytes == ni.value * 64
+    return int(nbytes), dict(groups=rows_arr.reshape(-1, 3), bands=nb.value, items=ni.value, last_group=last_group)
+
+
 def test_band_plan_of_the_deferred_merger():
-    """_Bands.build: bands = rows between consecutive tile edges, their covering tiles in integration order, the tile that
-    completes each band, and the last band reading each tile -- for the headline geometry and some irregular ones."""
-    from types import SimpleNamespace
-
+    """ptb_band_plan_create: bands = rows between consecutive tile edges, grouped into launches of ~rows_per_launch rows; the
+    tile that completes each group, the last group reading each tile, the work-item count -- for the headline geometry and some
+    irregular ones."""
     from oracle import tiles_oracle as TO
-    from pytorch_toolbelt_amd.inference.tiles import _Bands
 
-    geom = TO.slicer_geometry((5000, 5000), 512, 256)
-    crops = geom["crops"]
-    plan = SimpleNamespace(xy=np.ascontiguousarray(crops[:, :2].T))
-    bands = _Bands.build(plan, 512, 512, 5120, 5120)
-    assert len(bands.bands) == 20
-    assert [len(b["tiles"]) for b in bands.bands] == [19] + [38] * 18 + [19]
-    assert [(b["y0"], b["y1"]) for b in bands.bands] == [(256 * k, 256 * k + 256) for k in range(20)]
-    for k, b in enumerate(bands.bands):
-        assert (np.diff(b["tiles"]) > 0).all()                                   # integration order
-        assert k in bands.ready_at[int(b["tiles"].max())]
-    assert sorted(bands.ready_at) == [19 * r + 18 for r in range(19)]            # the last tile of every tile row
-    assert bands.ready_at[360] == [18, 19]                                       # the last row completes two bands
-    assert bands.last_band[0] == 1 and bands.last_band[19] == 2 and bands.last_band[360] == 19
-    # every pixel row belongs to exactly one band
-    cover = np.zeros(5120, dtype=int)
-    for b in bands.bands:
-        cover[b["y0"]:b["y1"]] += 1
-    assert (cover == 1).all()
+    crops = TO.slicer_geometry((5000, 5000), 512, 256)["crops"]
+    # one band per launch: the 20 bands of the headline geometry
+    _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 256)
+    assert p["bands"] == 20 and len(p["groups"]) == 20
+    assert [(int(g[0]), int(g[1])) for g in p["groups"]] == [(256 * k, 256 * k + 256) for k in range(20)]
+    assert [int(g[2]) for g in p["groups"]] == [19 * min(k, 18) + 18 for k in range(20)]   # the last tile of tile row k (19 and 18: row 18)
+    assert p["items"] == 20 * (5120 // 64) * (256 // 32)
+    assert p["last_group"][0] == 1 and p["last_group"][19] == 2 and p["last_group"][360] == 19
+    # 1024 rows per launch (the default): 5 launches of 4 bands, every pixel row in exactly one group
+    _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1024)
+    assert [(int(g[0]), int(g[1])) for g in p["groups"]] == [(1024 * k, 1024 * k + 1024) for k in range(5)]
+    assert [int(g[2]) for g in p["groups"]] == [19 * 3 + 18, 19 * 7 + 18, 19 * 11 + 18, 19 * 15 + 18, 360]   # tile row r covers rows 256 r .. 256 r + 512
+    assert p["last_group"][0] == 0 and p["last_group"][19 * 3] == 1 and p["last_group"][360] == 4
+    assert p["items"] == (5120 // 64) * (5120 // 32)
+    # a launch never takes more than 224 tiles: one launch for the whole image is cut into several
+    _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1 << 20)
+    assert len(p["groups"]) == 2 and int(p["groups"][0][0]) == 0 and int(p["groups"][-1][1]) == 5120
+    # uncovered rows / columns are planned too (they merge to NaN like the reference's 0 / 0)
+    _, p = _c_band_plan(np.array([[64, 64, 128, 128], [256, 64, 128, 128]]), 1, 128, 128, 320, 512, 64)
+    assert int(p["groups"][0][0]) == 0 and int(p["groups"][-1][1]) == 320
+    assert p["items"] == (512 // 64) * (320 // 32)
     # step < tile / 4: more than 4 tiles over a pixel -> not deferrable
     dense = TO.slicer_geometry((600, 600), 256, 48)["crops"]
-    assert _Bands.build(SimpleNamespace(xy=np.ascontiguousarray(dense[:, :2].T)), 256, 256, 640, 640) is None
+    assert _c_band_plan(dense, 1, 256, 256, 640, 640, 256)[0] == -2
     # tile origins off the 4-pixel grid -> not deferrable
     odd = TO.slicer_geometry((300, 300), 130, 65)["crops"]
-    assert _Bands.build(SimpleNamespace(xy=np.ascontiguousarray(odd[:, :2].T)), 130, 130, int(odd[:, 1].max()) + 130, int(odd[:, 0].max()) + 130) is None
+    assert _c_band_plan(odd, 1, 130, 130, int(odd[:, 1].max()) + 130, int(odd[:, 0].max()) + 130, 256)[0] == -2
+    # a tile outside the map
+    assert _c_band_plan(np.array([[0, 0, 64, 64], [480, 0, 64, 64]]), 1, 64, 64, 64, 512, 64)[0] == -4

@@ -648,7 +648,7 @@ def test_deferred_merger_fallbacks_and_restrictions(dev):
     ref.integrate_batch(y, crops)
     want = ref.merge()
     # 1. reading .image before the first band is merged: the held batches are replayed through the incremental path
-    m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+    m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True, defer_rows=128)
     m.integrate_batch(y[:2], crops[:2])
     assert m._defer_active and len(m._held) == 1 and m._bands_done == 0
     img = m.image
@@ -758,3 +758,80 @@ def test_merge_band_c_abi_contract(dev):
     assert call(xs_=five) == -2                                                     # five tiles over one pixel (MAX_COVER = 4)
     out_of_map = xs.copy(); out_of_map[4] = 224
     assert call(xs_=out_of_map) == -4                                               # PTB_EBOUNDS
+
+
+def test_reference_default_device_and_loud_fallbacks(dev):
+    """Code written against the reference -- TileMerger(shape, C, weight) with its default device="cpu" -- runs on the current
+    GPU (warned once); a defer / crops request the fast kernels cannot honour is announced instead of silently degraded, and
+    `merger.mode` tells which path is live."""
+    import warnings
+
+    from pytorch_toolbelt_amd.inference import tiles as T
+
+    T._warned.clear()
+    s = T.ImageSlicer((400, 360, 3), 128, 64, weight="pyramid")
+    with pytest.warns(RuntimeWarning, match="no CPU path"):
+        m = T.TileMerger(s.target_shape, 2, s.weight)
+    assert m.device.type == "cuda" and m.mode == "incremental"
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # said once only
+        T.TileMerger(s.target_shape, 2, s.weight)
+        d = T.TileMerger(s.target_shape, 2, s.weight, device=dev, crops=s.crops, defer=True)
+    assert d.mode == "deferred bands"
+    # off the 4-pixel grid: neither planned nor deferred -> one warning each, ordinary path, same numbers
+    s2 = T.ImageSlicer((100, 100, 3), 51, 26, weight="pyramid")
+    with pytest.warns(RuntimeWarning, match="block grid"):
+        p2 = T.TileMerger(s2.target_shape, 1, s2.weight, device=dev, crops=s2.crops, defer=True)
+    assert p2.mode == "incremental"
+    tiles = torch.rand((len(s2.crops), 1, 51, 51), device=dev)
+    p2.integrate_batch(tiles, s2.crops)
+    plain = T.TileMerger(s2.target_shape, 1, s2.weight, device=dev)
+    plain.integrate_batch(tiles, s2.crops)
+    assert torch.equal(p2.merge(), plain.merge())
+    # a deviation from the planned sequence leaves deferred mode with a warning (results stay those of the plain merger)
+    T._warned.clear()
+    y = torch.rand((len(s.crops), 2, 128, 128), device=dev)
+    order = np.arange(len(s.crops))[::-1].copy()
+    with pytest.warns(RuntimeWarning, match="deviates from the planned"):
+        d.integrate_batch(y[order], s.crops[order])
+    assert d.mode == "incremental"
+    ref = T.TileMerger(s.target_shape, 2, s.weight, device=dev)
+    ref.integrate_batch(y[order], s.crops[order])
+    assert torch.equal(d.merge(), ref.merge())
+
+
+@pytest.mark.parametrize("rows", [64, 128, 320, 1 << 20])
+def test_deferred_launch_grouping_is_bit_identical(rows, dev):
+    """The rows merged per launch (defer_rows) only change how many launches an image takes, never a bit of the result; pixels no
+    tile covers come out as NaN (0 / 0) exactly like the reference's merge()."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer((700, 520, 3), 128, 64, weight="pyramid")
+    crops, C = slicer.crops, 3
+    y = torch.randn((8 * len(crops), C, 128, 128), device=dev)
+    ref = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True, defer_rows=rows)
+    n = len(crops)
+    for b0 in range(0, n, 5):
+        b1 = min(n, b0 + 5)
+        batch = torch.cat([y[k * n + b0:k * n + b1] for k in range(8)])
+        ref.integrate_batch_deaugment(batch, crops[b0:b1], group="d4", reduction="mean")
+        m.integrate_batch_deaugment(batch, crops[b0:b1], group="d4", reduction="mean")
+    assert m.mode == "deferred bands" and m._bands_done == len(m._bands.bands) and not m._held
+    assert torch.equal(m.merge(), ref.merge())
+    # a crop list with holes: rows 0..63 and a column strip are never covered
+    H, W = 320, 512
+    holes = np.array([[64, 64, 128, 128], [256, 64, 128, 128], [64, 192, 128, 128]])
+    w = slicer.weight
+    t = torch.randn((3, 2, 128, 128), device=dev)
+    a = TileMerger((H, W), 2, w, device=dev)
+    a.integrate_batch(t, holes)
+    want = a.merge()
+    for gridded in (np.array([[64, 64, 128, 128], [256, 64, 128, 128], [64, 192, 128, 128]]),):
+        b = TileMerger((H, W), 2, w, device=dev, crops=gridded, defer=True, defer_rows=rows)
+        if b._bands is None:     # x = 64 is on the 64-column block grid, y = 64 on the 32-row grid: planned
+            pytest.fail("geometry should be deferrable")
+        b.integrate_batch(t, gridded)
+        got = b.merge()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)) and bool(torch.isnan(got).any())
+        assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
