@@ -133,6 +133,11 @@ int ptb_merge_band(float* merged, const float* norm_full, const float* weight, c
                    const int64_t* tile_view_stride, int in_dtype, int V, const int* views, int reduction, const int64_t* xs,
                    const int64_t* ys, int n, int C, int th, int tw, int H, int W, int y0, int y1, ptb_stream_t stream);
 
+/* Diagnostic (no reference counterpart): streams `bytes` of device memory through a read-only kernel (16 B per lane, eight
+ * non-temporal loads in flight, 8192 workgroups) so that a benchmark can time what this GPU's memory system gives a pure
+ * read stream and quote its kernels against that as well as against the 8 TB/s spec.  `sink` = 4 writable device bytes. */
+int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t stream);
+
 /* ---- Deferred merge of a whole image, planned once (TileMerger(crops=tiler.crops, defer=True)).
  * Replaces the reference's per-batch loop `merger.integrate_batch(<group>_image_deaugment(pred), crops)` + `merger.merge()`
  * (inference/tta.py:442-467, inference/tiles.py:321-346) when the crop list of the image is known up front.
@@ -299,6 +304,19 @@ int ptb_focal_bwd(const float* logits, const int64_t* labels, const float* dense
                   float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
                   ptb_stream_t stream);
 
+/* focal_loss_with_logits(..., activation="softmax", softmax_dim=d) (losses/functional.py:61-107 with :63-64
+ * `p = torch.softmax(output, dim=softmax_dim)`): the tensor is passed as the [B, C, HW] view whose C is the softmax dimension.
+ * Same flags / sums[0..1] / elem_out / coef / grad_elem contract as ptb_seg_loss_fwd (PTB_SEG_FOCAL) and ptb_focal_bwd, except
+ * that `sums` is [PTB_SUM_SLOTS, 2].  class_weights follow dim 1 of the ORIGINAL tensor (functional.py:83-88): cw_mode 0 =
+ * none, 1 = indexed by the softmax channel c (cw_n == C), 2 = by (b / cw_div) % cw_n, 3 = by (position / cw_div) % cw_n. */
+int ptb_focal_softmax_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights, int cw_mode,
+                          int cw_n, int64_t cw_div, double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags,
+                          float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value, ptb_stream_t stream);
+int ptb_focal_softmax_bwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights, int cw_mode,
+                          int cw_n, int64_t cw_div, const float* coef, const float* grad_elem, float* grad, int B, int C, int64_t HW,
+                          int flags, float gamma, float alpha, float threshold, int64_t ignore_label, float ignore_value,
+                          ptb_stream_t stream);
+
 /* Gradient of any function of the region statistics w.r.t. logits, given DEVICE arrays gI[C] = dLoss/dI_c and
  * gP[C] = dLoss/dP_c (T does not depend on the logits). */
 int ptb_seg_stats_bwd(const float* logits, const int64_t* labels, const float* dense, const float* gI, const float* gP,
@@ -338,9 +356,11 @@ int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const floa
  * per-channel weight / pos_weight [C] or NULL with element channel = (i / HW) % C), 1 balanced BCE (losses/
  * balanced_bce.py:27-40), 2 QualityFocalLoss (losses/quality_focal_loss.py:33-35; p0 = beta), 3 wing_loss (losses/
  * functional.py:260-269; p0 = width, p1 = curvature, p2 = width - width*log(1 + width/curvature)), 4 log_cosh_loss
- * (losses/functional.py:338-341).  flags: 1 = elements whose target == ignore_value contribute 0; 2 = label smoothing.
+ * (losses/functional.py:338-341), 5 soft F1 counts of one class (losses/soft_f1.py:22-24, 63-78: p = clamp(sigmoid(x), p0,
+ * 1 - p0), or p = x when flags & 2).  flags: 1 = elements whose target == ignore_value contribute 0; 2 = label smoothing.
  * x, t: DEVICE fp32 [n].  sums: DEVICE double [PTB_SUM_SLOTS][4], zeroed by the caller, slot-wise partial sums of
- *   kind 0,3,4: {loss};  kind 1: {sum t*logsigmoid(x), sum (1-t)*logsigmoid(-x), #(t == 1), #(t == 0)};  kind 2: {loss, focal}.
+ *   kind 0,3,4: {loss};  kind 1: {sum t*logsigmoid(x), sum (1-t)*logsigmoid(-x), #(t == 1), #(t == 0)};  kind 2: {loss, focal};
+ *   kind 5: {sum p t, sum p, sum t, #kept} (TP = s0, FP = s1 - s0, FN = s2 - s0); its apply gives d(coef[0] s0 + coef[1] s1)/dx.
  * elem_out (optional, not for kind 1): per-element loss. */
 int ptb_pointwise_loss_fwd(int kind, const float* x, const float* t, const float* chan_w, const float* chan_pw, double* sums,
                            float* elem_out, int64_t n, int C, int64_t HW, int flags, float p0, float p1, float p2,

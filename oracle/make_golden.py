@@ -580,6 +580,68 @@ def gen_losses3():
     save("losses3.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- focal, activation="softmax"
+def gen_losses4():
+    """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
+    the unmodified reference over the option matrix, several softmax dimensions included."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(31)
+    B, C, H, W = 3, 5, 12, 10
+    x = torch.randn((B, C, H, W), generator=g) * 2.5
+    x[1] += 1.0
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab_ign = lab.clone()
+    lab_ign[torch.rand((B, H, W), generator=g) < 0.15] = 255
+    onehot = torch.nn.functional.one_hot(lab, C).permute(0, 3, 1, 2).float()
+    soft = (torch.rand((B, C, H, W), generator=g) * 0.8 + 0.1)
+    onehot_ign = onehot.clone()
+    onehot_ign[torch.rand((B, C, H, W), generator=g) < 0.1] = 255
+    cw = torch.tensor([0.5, 1.0, 2.0, 1.5, 0.25])
+    x3 = torch.randn((7, 9, 11), generator=g) * 2.0          # odd sizes: scalar kernels; 3-D input
+    t3 = (torch.rand((7, 9, 11), generator=g) < 0.3).float()
+    cw3 = torch.rand(9, generator=g) + 0.5
+    for k, v in dict(x=x, lab=lab, lab_ign=lab_ign, onehot=onehot, soft=soft, onehot_ign=onehot_ign, cw=cw, x3=x3, t3=t3, cw3=cw3).items():
+        A[k] = t2n(v)
+
+    def add(name, fn, kwargs, inputs, make, wkey=None):
+        xin = torch.from_numpy(A[inputs[0]]).clone().requires_grad_(True)
+        val = make(xin, torch.from_numpy(A[inputs[1]]))
+        A[name] = t2n(val)
+        (val * (torch.arange(val.numel(), dtype=torch.float32).reshape(val.shape) % 7 + 1.0) if val.dim() else val).sum().backward()
+        A[name + "_grad"] = t2n(xin.grad)
+        cases.append(dict(name=name, fn=fn, kwargs=kwargs, inputs=inputs, output=name, weights=wkey))
+
+    opts = [
+        dict(softmax_dim=1), dict(softmax_dim=1, alpha=None), dict(softmax_dim=1, gamma=1.5, alpha=0.6), dict(softmax_dim=1, reduction="sum"),
+        dict(softmax_dim=1, reduction="none"), dict(softmax_dim=1, reduction="batchwise_mean"), dict(softmax_dim=1, normalized=True),
+        dict(softmax_dim=1, reduced_threshold=0.5), dict(softmax_dim=1, reduced_threshold=0.3, normalized=True, gamma=3.0),
+        dict(softmax_dim=1, gamma=0.0, alpha=None), dict(softmax_dim=1, gamma=1.0),
+        dict(softmax_dim=-1), dict(softmax_dim=0, alpha=None), dict(softmax_dim=2, reduction="none"), dict(softmax_dim=-3, gamma=2.5),
+    ]
+    for i, kw in enumerate(opts):
+        add(f"fsm_{i}", "focal_softmax_fn", kw, ["x", "onehot"], lambda a, b, kw=kw: rlf.focal_loss_with_logits(a, b, activation="softmax", **kw))
+    add("fsm_soft", "focal_softmax_fn", dict(softmax_dim=1, alpha=0.3), ["x", "soft"], lambda a, b: rlf.focal_loss_with_logits(a, b, activation="softmax", softmax_dim=1, alpha=0.3))
+    add("fsm_ign", "focal_softmax_fn", dict(softmax_dim=1, ignore_index=255, normalized=True), ["x", "onehot_ign"],
+        lambda a, b: rlf.focal_loss_with_logits(a, b, activation="softmax", softmax_dim=1, ignore_index=255, normalized=True))
+    add("fsm_ign_none", "focal_softmax_fn", dict(softmax_dim=1, ignore_index=255, reduction="none"), ["x", "onehot_ign"],
+        lambda a, b: rlf.focal_loss_with_logits(a, b, activation="softmax", softmax_dim=1, ignore_index=255, reduction="none"))
+    for i, d in enumerate([1, 0, 2, 3]):   # class weights always follow dim 1 of the tensor, whatever the softmax dimension
+        add(f"fsm_cw_{i}", "focal_softmax_fn", dict(softmax_dim=d, class_weights=True), ["x", "onehot"],
+            lambda a, b, d=d: rlf.focal_loss_with_logits(a, b, activation="softmax", softmax_dim=d, class_weights=cw), wkey="cw")
+    for i, d in enumerate([0, 1, 2]):
+        add(f"fsm_3d_{i}", "focal_softmax_fn", dict(softmax_dim=d, class_weights=True, reduction="sum"), ["x3", "t3"],
+            lambda a, b, d=d: rlf.focal_loss_with_logits(a, b, activation="softmax", softmax_dim=d, class_weights=cw3, reduction="sum"), wkey="cw3")
+    # the module with a label map (one-hot along dim 1, ignore handling) and a dense map
+    for i, (kw, t) in enumerate([(dict(), "lab"), (dict(alpha=0.25), "lab"), (dict(ignore_index=255), "lab_ign"),
+                                 (dict(ignore_index=255, normalized=True, alpha=0.4), "lab_ign"), (dict(reduction="sum", gamma=1.0), "lab"),
+                                 (dict(), "onehot")]):
+        add(f"fsm_mod_{i}", "focal_softmax_module", dict(kw, softmax_dim=1), ["x", t],
+            lambda a, b, kw=kw: rl.BinaryFocalLoss(activation="softmax", softmax_dim=1, **kw)(a, b))
+    add("fsm_mod_cw", "focal_softmax_module", dict(softmax_dim=1, class_weights=True), ["x", "lab"],
+        lambda a, b: rl.BinaryFocalLoss(activation="softmax", softmax_dim=1, class_weights=cw)(a, b), wkey="cw")
+    save("losses4.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- 3-D tiles (8f-4)
 def gen_volumes():
     from pytorch_toolbelt.inference import tiles_3d as rt3
@@ -712,6 +774,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "fullsize":
         gen_fullsize()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] in globals():    # one fixture: python oracle/make_golden.py gen_losses4
+        globals()[sys.argv[1]]()
+        sys.exit(0)
     gen_tiles()
     gen_tta()
     gen_losses()
@@ -719,5 +784,6 @@ if __name__ == "__main__":
     gen_ensembling()
     gen_losses2()
     gen_losses3()
+    gen_losses4()
     gen_volumes()
     gen_fullsize()

@@ -91,7 +91,34 @@ extern "C" int ptb_merge_div_masked(const float* image, const float* norm, float
     return check_launch();
 }
 
-extern "C" int ptb_version(void) { return 100; }
+// Diagnostic: what THIS GPU's memory system gives a pure read-only stream (16 B per lane, 8 independent non-temporal loads in
+// flight per lane, 8192 workgroups -- the best configuration of tools/bw_probe.hip).  bench.py runs it over the very buffers
+// the merge reads and reports the result next to the roofline fraction, because boxes of one pool differ by ~10 %.
+__global__ __launch_bounds__(256) void read_probe_kernel(const float* __restrict__ in, float* __restrict__ sink, long long n4) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f* p = reinterpret_cast<const v4f*>(in);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    float acc = 0.f;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        v4f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&p[i + u * stride]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    for (; i < n4; i += stride) { const v4f v = __builtin_nontemporal_load(&p[i]); acc += v.x + v.y + v.z + v.w; }
+    if (acc == 123.456f) sink[0] = acc;   // never true for real data: keeps the loads alive
+}
+
+extern "C" int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t stream) {
+    if (!buf || !sink || bytes < 16 || !aligned16(buf)) return PTB_EINVAL;
+    hipLaunchKernelGGL(read_probe_kernel, dim3(8192), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(buf), sink,
+                       (long long)(bytes / 16));
+    return check_launch();
+}
+
+extern "C" int ptb_version(void) { return 101; }
 
 extern "C" const char* ptb_last_hip_error(void) { return g_last_error.c_str(); }
 

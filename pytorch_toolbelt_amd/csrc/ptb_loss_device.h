@@ -1,0 +1,235 @@
+// Device- and host-side pieces shared by the loss translation units (ptb_losses.hip, ptb_focal_softmax.hip): launch arguments,
+// 16-byte streaming loads, wave / workgroup reductions into the slotted fp64 sums, the branch-free focal configuration and
+// the wave-group walk over [B, C, HW] logits.  Not part of the C ABI.
+#pragma once
+#include <initializer_list>
+
+#include "ptb_common.h"
+
+// the losses are tolerance-checked (1e-5), not bit-exact: let the compiler fuse multiply-adds in the loss translation units
+#pragma clang fp contract(fast)
+
+namespace ptb {
+
+enum {
+    SEG_FOCAL = 1,             // accumulate sigmoid-focal sums
+    SEG_STATS = 2,             // accumulate per-class region statistics
+    SEG_HAS_IGNORE = 4,
+    SEG_HAS_ALPHA = 8,
+    SEG_REDUCED = 16,          // reduced focal loss (threshold)
+    SEG_MASK_FOCAL_TERM = 32,  // normalised focal: ignored elements contribute 0 to sums[1]
+    SEG_ELEMWISE = 64,         // also write the per-element focal loss
+};
+enum { PROB_SOFTMAX = 0, PROB_SIGMOID = 1, PROB_IDENTITY = 2 };
+
+struct SegArgs {
+    const float* logits;
+    const long long* labels;     // [B, HW] or null
+    const float* dense;          // [B, C, HW] or null
+    const float* class_weights;  // [C] or null
+    double* sums;                // [2 + 3*C]: focal loss, focal term, I[C], P[C], T[C]
+    float* elem_out;             // [B, C, HW] when SEG_ELEMWISE
+    int* error_flag;             // set to 1 on a label outside [0, C) that is not ignore_index
+    int B, C;
+    long long HW;
+    int flags, prob;
+    float gamma, alpha, threshold, ignore_value;
+    long long ignore_label;
+};
+
+// ------------------------------------------------------------------------------------------------ small helpers
+template <int PIX>
+__device__ __forceinline__ void load_px(const float* __restrict__ p, float (&x)[PIX], bool ok) {
+    if (!ok) return;
+    if constexpr (PIX == 4) {
+        // streamed once: non-temporal (leaves L2 / Infinity Cache to the labels and class weights); +2..3 % measured
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+        x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else if constexpr (PIX == 2) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        const v2f v = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(p));
+        x[0] = v.x; x[1] = v.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) x[k] = p[k];
+    }
+}
+template <int PIX>
+__device__ __forceinline__ void store_px(float* __restrict__ p, const float (&x)[PIX], bool ok) {
+    if (!ok) return;
+    if constexpr (PIX == 4) {
+        *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) p[k] = x[k];
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }     // v_rcp_f32, 1 ulp
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }    // v_exp_f32 (2^x), no range fix-ups
+__device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }     // v_log_f32 (log2 x)
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fexp(float x) { return ex2(x * kLog2e); }
+// exp(x - m) as 2^(x * log2e - M) with M = m * log2e rounded ONCE per pixel: one fma + v_exp per element.  Every class of a
+// pixel is scaled by the same 2^(m * log2e - M) (1 +- 2e-6), which cancels in the softmax ratio and in u / (u + 2^-M).
+__device__ __forceinline__ float fexp_sub(float x, float M) { return ex2(__builtin_fmaf(x, kLog2e, -M)); }
+
+// x^g for x >= 0 without branches: 2^(g log2 x); x = 0 gives 0 for g > 0 (g == 0 is patched by the caller)
+__device__ __forceinline__ float pow_pos(float base, float g) { return ex2(g * lg2(base)); }
+
+// sigmoid(x) and log(1 + exp(-|x|)) from one exp (absolute error ~1e-7, far inside the 1e-5 loss tolerance)
+struct Sig { float p, log1pe; };
+__device__ __forceinline__ Sig sigmoid_parts(float x) {
+    const float e = fexp(-fabsf(x));
+    const float s1 = 1.0f + e;
+    const float inv = rcp(s1);
+    Sig s;
+    s.p = x >= 0.f ? inv : e * inv;
+    s.log1pe = lg2(s1) * kLn2;
+    return s;
+}
+
+// Wave-uniform focal configuration, built once per kernel so the per-element math has no branches.
+struct FocalCfg {
+    float gamma, gm1;      // gamma, gamma - 1
+    float a1, a0;          // alpha weight = a1 * t + a0 (a1 = 0, a0 = 1 when alpha is None)
+    float thr, sc;         // reduced focal: f = 1 where pt < thr, base scaled by sc = 1 / (1 - thr); (-inf, 1) otherwise
+    float f_when_g0;       // 1 if gamma == 0 (x^0 = 1 even at x = 0) else NaN marker unused
+    float term_mask;       // multiplier of the focal term of ignored elements (0 when normalised, else 1)
+    bool g0, g1;
+};
+__device__ __forceinline__ FocalCfg focal_cfg(const SegArgs& a) {
+    FocalCfg c;
+    c.gamma = a.gamma; c.gm1 = a.gamma - 1.0f;
+    const bool ha = a.flags & SEG_HAS_ALPHA;
+    c.a1 = ha ? 2.0f * a.alpha - 1.0f : 0.0f;
+    c.a0 = ha ? 1.0f - a.alpha : 1.0f;
+    const bool red = a.flags & SEG_REDUCED;
+    c.thr = red ? a.threshold : -INFINITY;
+    c.sc = red ? 1.0f / (1.0f - a.threshold) : 1.0f;
+    c.f_when_g0 = 1.0f;
+    c.term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
+    c.g0 = a.gamma == 0.0f; c.g1 = a.gamma == 1.0f;
+    return c;
+}
+
+// BCE, focal term f, d f / d x and sigmoid of one element (functional.py:61-94).  G2 = gamma is exactly 2.
+template <bool G2, bool GRAD>
+__device__ __forceinline__ void focal_parts(float x, float t, const FocalCfg& c, float& ce, float& f, float& df, float& p) {
+    const Sig s = sigmoid_parts(x);
+    p = s.p;
+    ce = fmaxf(x, 0.f) - x * t + s.log1pe;                 // BCE with logits
+    const float pt = p * t + (1.f - p) * (1.f - t);
+    const float base = fmaxf(1.f - pt, 0.f) * c.sc;
+    const bool below = pt < c.thr;
+    if (G2) f = base * base;
+    else { f = pow_pos(base, c.gamma); f = c.g0 ? 1.0f : f; }
+    f = below ? 1.0f : f;
+    df = 0.f;
+    if (GRAD) {
+        const float dpt = p * (1.f - p) * (2.f * t - 1.f);
+        float pw;                                           // base^(gamma-1)
+        if (G2) pw = base;
+        else { pw = pow_pos(base, c.gm1); pw = c.g1 ? 1.0f : pw; }
+        df = -c.gamma * pw * c.sc * dpt;
+        df = (below || (!G2 && c.g0)) ? 0.f : df;
+    }
+}
+
+// Same-address device atomics serialise (~12 ns each): 8192 waves adding into ONE double costs more than the whole
+// streaming pass.  So each workgroup reduces its 4 waves in LDS first and adds into one of PTB_SUM_SLOTS copies of the
+// sums (slot = blockIdx % PTB_SUM_SLOTS); the caller adds the slots up (a [64, n] -> [n] sum).
+constexpr int SUM_SLOTS = 64;
+
+__device__ __forceinline__ void block_add2(double v0, double v1, double* dst /* slot base */, int lane, int wave) {
+    __shared__ double red[2][4];
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&dst[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        atomicAdd(&dst[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// One wave-group: image b, first pixel i0 of this lane, validity; labels of the lane's PIX pixels.
+template <int PIX>
+struct Group {
+    int b;
+    long long i0;
+    bool ok;                // PIX == 4: all-or-nothing (HW % 4 == 0); PIX == 1: the single pixel
+    long long lab[PIX];
+    bool ign[PIX];
+};
+
+template <int PIX>
+__device__ __forceinline__ Group<PIX> make_group(long long g, long long per_img, int lane, long long HW, const long long* __restrict__ labels,
+                                                 bool has_ignore, long long ignore_label, int C, int* error_flag) {
+    Group<PIX> G;
+    G.b = (int)(g / per_img);
+    G.i0 = (g - (long long)G.b * per_img) * 64 * PIX + (long long)lane * PIX;
+    G.ok = G.i0 < HW;
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) { G.lab[k] = -1; G.ign[k] = false; }
+    if (labels && G.ok) {
+        const long long* lp = labels + (long long)G.b * HW + G.i0;
+        if constexpr (PIX == 4) {
+            const longlong2 a = *reinterpret_cast<const longlong2*>(lp);
+            const longlong2 b2 = *reinterpret_cast<const longlong2*>(lp + 2);
+            G.lab[0] = a.x; G.lab[1] = a.y; G.lab[2] = b2.x; G.lab[3] = b2.y;
+        } else {
+            G.lab[0] = lp[0];
+        }
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            G.ign[k] = has_ignore && G.lab[k] == ignore_label;
+            if (error_flag && !G.ign[k] && (G.lab[k] < 0 || G.lab[k] >= C)) *error_flag = 1;
+        }
+    }
+    return G;
+}
+
+
+// ------------------------------------------------------------------------------------------------ host side
+// Measured on MI355X (tools/ab_losses.py): the streaming kernels (focal fwd/bwd, softmax focal) gain ~10 % from an
+// oversubscribed grid (32 workgroups per CU, one pixel group per wave), the statistics kernels lose from it (more
+// per-workgroup LDS reductions + atomics), so they keep 8 per CU.
+constexpr int kGridStream = 256 * 32, kGridStats = 256 * 8;
+static inline int grid_for_groups(long long groups, int dflt) {
+    const long long want = (groups + 3) / 4;
+    const long long cap = g_loss_grid_cap > 0 ? g_loss_grid_cap : dflt;
+    return (int)(want < 1 ? 1 : (want < cap ? want : cap));
+}
+
+static inline int fill_seg(SegArgs& a, const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                    int B, int C, int64_t HW, int flags, int prob, float gamma, float alpha, float threshold,
+                    int64_t ignore_label, float ignore_value) {
+    if (!logits || (!labels && !dense) || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
+    if (prob < PROB_SOFTMAX || prob > PROB_IDENTITY) return PTB_EINVAL;
+    a.logits = logits; a.labels = (const long long*)labels; a.dense = dense; a.class_weights = class_weights;
+    a.B = B; a.C = C; a.HW = HW; a.flags = flags; a.prob = prob;
+    a.gamma = gamma; a.alpha = alpha; a.threshold = threshold; a.ignore_label = ignore_label; a.ignore_value = ignore_value;
+    return PTB_OK;
+}
+
+static inline bool vec_ok(int64_t HW, std::initializer_list<const void*> ptrs) {
+    if (HW % 4 != 0 || g_force_scalar) return false;
+    for (const void* p : ptrs) if (p && !aligned16(p)) return false;
+    return true;
+}
+
+
+}  // namespace ptb

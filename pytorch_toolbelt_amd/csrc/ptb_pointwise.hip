@@ -5,6 +5,7 @@
 //   QualityFocalLoss                           losses/quality_focal_loss.py:5-46
 //   wing_loss                                  losses/functional.py:250-277
 //   log_cosh_loss                              losses/functional.py:326-342
+//   BinarySoftF1Loss / soft_micro_f1 (one class)     losses/soft_f1.py:8-78 (soft TP / FP / FN counts in one pass)
 //   SoftCrossEntropyLoss / label_smoothed_nll_loss   losses/soft_ce.py:9-33, losses/functional.py:280-323
 //
 // The reference evaluates each as a chain of 6-15 full-tensor torch ops; here the forward is one read of logits +
@@ -60,7 +61,7 @@ __device__ __forceinline__ void block_add(const float* part, double* slot) {
 
 }  // namespace
 
-enum { PW_SOFT_BCE = 0, PW_BALANCED_BCE = 1, PW_QFL = 2, PW_WING = 3, PW_LOGCOSH = 4, PW_KINDS = 5 };
+enum { PW_SOFT_BCE = 0, PW_BALANCED_BCE = 1, PW_QFL = 2, PW_WING = 3, PW_LOGCOSH = 4, PW_SOFT_F1 = 5, PW_KINDS = 6 };
 enum { PWF_IGNORE = 1, PWF_SMOOTH = 2 };
 
 struct PwArgs {
@@ -106,6 +107,17 @@ __device__ __forceinline__ void pw_forward(float x, float t, float w, float pw, 
         loss = f * bce;
         s[0] += loss;
         s[1] += f;
+    } else if (KIND == PW_SOFT_F1) {  // soft_f1.py:22-24, 63-78: p = clamp(sigmoid(x), eps, 1 - eps) (flag PWF_SMOOTH: x IS the
+        // probability); soft counts sum p t, sum p, sum t -- TP = s0, FP = s1 - s0, FN = s2 - s0 -- and the number of kept elements
+        const bool ig = (a.flags & PWF_IGNORE) && t == a.ignore_value;
+        float p = (a.flags & PWF_SMOOTH) ? x : fminf(fmaxf(sigmoid_parts(x).p, a.p0), 1.f - a.p0);
+        p = ig ? 0.f : p;
+        const float tt = ig ? 0.f : t;
+        s[0] += p * tt;
+        s[1] += p;
+        s[2] += tt;
+        s[3] += ig ? 0.f : 1.f;
+        loss = 0.f;
     } else if (KIND == PW_WING) {  // functional.py:260-269
         const float d = fabsf(t - x);
         loss = d < a.p0 ? a.p0 * logf(1.f + d / a.p1) : d - a.p2;
@@ -149,6 +161,12 @@ __device__ __forceinline__ float pw_backward(float x, float t, float w, float pw
         float df = a.p0 * pwm1 * sgn * g.p * (1.f - g.p);
         df = a.p0 == 0.f ? 0.f : df;
         return k0 * gi * (df * bce + f * diff) + k1 * df;
+    } else if (KIND == PW_SOFT_F1) {   // d(k0 * sum p t + k1 * sum p) / dx; the clamp has zero slope outside (eps, 1 - eps)
+        const bool ig = (a.flags & PWF_IGNORE) && t == a.ignore_value;
+        if (a.flags & PWF_SMOOTH) return ig ? 0.f : gi * (k0 * t + k1);
+        const float p = sigmoid_parts(x).p;
+        const bool inside = p > a.p0 && p < 1.f - a.p0;
+        return (ig || !inside) ? 0.f : gi * (k0 * t + k1) * p * (1.f - p);
     } else if (KIND == PW_WING) {
         const float diff = t - x, d = fabsf(diff);
         const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
@@ -162,7 +180,7 @@ __device__ __forceinline__ float pw_backward(float x, float t, float w, float pw
 }
 
 template <int KIND>
-constexpr int pw_nsums() { return KIND == PW_BALANCED_BCE ? 4 : (KIND == PW_QFL ? 2 : 1); }
+constexpr int pw_nsums() { return (KIND == PW_BALANCED_BCE || KIND == PW_SOFT_F1) ? 4 : (KIND == PW_QFL ? 2 : 1); }
 
 template <int KIND, bool VEC>
 __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwArgs a) {
@@ -525,6 +543,7 @@ using namespace ptb;
         case PW_BALANCED_BCE: if (VECFLAG) KERNEL(PW_BALANCED_BCE, true, __VA_ARGS__); else KERNEL(PW_BALANCED_BCE, false, __VA_ARGS__); break; \
         case PW_QFL: if (VECFLAG) KERNEL(PW_QFL, true, __VA_ARGS__); else KERNEL(PW_QFL, false, __VA_ARGS__); break;                           \
         case PW_WING: if (VECFLAG) KERNEL(PW_WING, true, __VA_ARGS__); else KERNEL(PW_WING, false, __VA_ARGS__); break;                       \
+        case PW_SOFT_F1: if (VECFLAG) KERNEL(PW_SOFT_F1, true, __VA_ARGS__); else KERNEL(PW_SOFT_F1, false, __VA_ARGS__); break;              \
         default: if (VECFLAG) KERNEL(PW_LOGCOSH, true, __VA_ARGS__); else KERNEL(PW_LOGCOSH, false, __VA_ARGS__); break;                      \
     }
 

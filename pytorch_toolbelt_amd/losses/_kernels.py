@@ -123,6 +123,54 @@ class SigmoidFocalSums(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None, None
 
 
+class SoftmaxActFocalSums(torch.autograd.Function):
+    """``focal_loss_with_logits(activation="softmax")``: sums[0] = sum_i L_i, sums[1] = sum_i F_i, optionally the unreduced map.
+
+    x: [B, C, HW] fp32 view whose C is the softmax dimension; labels int64 [B, HW] or dense fp32 [B, C, HW];
+    cw = (class_weights | None, mode, n, div) -- see ptb_focal_softmax_fwd."""
+
+    @staticmethod
+    def forward(ctx, x, labels, dense, cw, flags, gamma, alpha, threshold, ignore_label, ignore_value):
+        B, C, HW = x.shape
+        weights, cw_mode, cw_n, cw_div = cw
+        sums = torch.zeros((SUM_SLOTS, 2), dtype=torch.float64, device=x.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        elem = torch.empty_like(x) if flags & SEG_ELEMWISE else None
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_focal_softmax_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(weights), cw_mode, cw_n, cw_div, sums.data_ptr(),
+                                           _ptr(elem), flag.data_ptr(), B, C, HW, flags | SEG_FOCAL, gamma, alpha, threshold, ignore_label,
+                                           ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_focal_softmax_fwd")
+        if labels is not None:
+            check_labels(flag)
+        ctx.save_for_backward(x, labels, dense, weights)
+        ctx.cfg = (flags, gamma, alpha, threshold, ignore_label, ignore_value, cw_mode, cw_n, cw_div)
+        ctx.has_elem = elem is not None
+        return sums.sum(dim=0), (elem if elem is not None else x.new_empty(0))
+
+    @staticmethod
+    def backward(ctx, g_sums, g_elem):
+        x, labels, dense, weights = ctx.saved_tensors
+        flags, gamma, alpha, threshold, ignore_label, ignore_value, cw_mode, cw_n, cw_div = ctx.cfg
+        B, C, HW = x.shape
+        coef = g_sums.to(torch.float32).contiguous() if g_sums is not None else torch.zeros(2, device=x.device)
+        grad_elem = None
+        if ctx.has_elem and g_elem is not None:
+            grad_elem = (g_elem.to(torch.float32) + coef[0]).contiguous()   # (g_sums[0] + g_elem) * dL: multiplier 1
+            coef = torch.stack([torch.ones((), device=x.device), coef[1]])
+        grad = torch.empty_like(x)
+        lib = N.load()
+        with N.on_device(x.device):
+            rc = lib.ptb_focal_softmax_bwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(weights), cw_mode, cw_n, cw_div, coef.data_ptr(),
+                                           _ptr(grad_elem), grad.data_ptr(), B, C, HW, flags, gamma, alpha, threshold, ignore_label,
+                                           ignore_value, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_focal_softmax_bwd")
+        return grad, None, None, None, None, None, None, None, None, None
+
+
 class RegionStats(torch.autograd.Function):
     """stats [3, C] float64: I_c = sum p t, P_c = sum p, T_c = sum t over batch and pixels (masked), p = activation(x)."""
 

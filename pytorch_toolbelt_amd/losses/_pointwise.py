@@ -10,7 +10,7 @@ import torch
 from .. import _native as N
 from ._kernels import SUM_SLOTS, _ptr, check_labels
 
-SOFT_BCE, BALANCED_BCE, QFL, WING, LOGCOSH = range(5)
+SOFT_BCE, BALANCED_BCE, QFL, WING, LOGCOSH, SOFT_F1 = range(6)
 F_IGNORE, F_SMOOTH = 1, 2
 
 

@@ -5,7 +5,7 @@ import torch
 from torch import Tensor, nn
 
 from ..utils.support import pytorch_toolbelt_deprecated
-from .functional import _sigmoid_focal, softmax_focal_loss_with_logits
+from .functional import _sigmoid_focal, _softmax_act_focal, softmax_focal_loss_with_logits
 
 __all__ = ["CrossEntropyFocalLoss", "BinaryFocalLoss", "FocalLoss"]
 
@@ -47,9 +47,10 @@ class BinaryFocalLoss(nn.Module):
         )
 
     def forward(self, inputs: Tensor, targets: Tensor) -> Tensor:
-        if self.activation != "sigmoid":
-            raise NotImplementedError("BinaryFocalLoss: only activation='sigmoid' has a native kernel")
         labels, dense = (targets, None) if targets.dim() + 1 == inputs.dim() else (None, targets)
+        if self.activation != "sigmoid":   # "softmax" (functional.py:61-64)
+            return _softmax_act_focal(inputs, labels, dense, self.softmax_dim, self.gamma, self.alpha, self.reduction, self.normalized,
+                                      self.reduced_threshold, 1e-6, self.ignore_index, self.class_weights)
         return _sigmoid_focal(inputs, labels, dense, self.gamma, self.alpha, self.reduction, self.normalized,
                               self.reduced_threshold, 1e-6, self.ignore_index, self.class_weights)
 

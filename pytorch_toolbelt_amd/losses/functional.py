@@ -46,9 +46,85 @@ def focal_loss_with_logits(
     reduction: "mean" (over all elements, ignored ones included) | "sum" | "batchwise_mean" (a sum over dim 0, as in
     the reference) | anything else -> unreduced tensor.
     """
-    if activation != "sigmoid":
-        raise NotImplementedError("focal_loss_with_logits: only activation='sigmoid' has a native kernel")
+    if activation != "sigmoid":   # anything else means softmax in the reference (functional.py:61-64)
+        return _softmax_act_focal(output, None, target, softmax_dim, gamma, alpha, reduction, normalized, reduced_threshold, eps,
+                                  ignore_index, class_weights)
     return _sigmoid_focal(output, None, target, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights)
+
+
+def _focal_flags(alpha, reduced_threshold, ignore_index, normalized, reduction):
+    flags = 0
+    if alpha is not None:
+        flags |= K.SEG_HAS_ALPHA
+    if reduced_threshold is not None:
+        flags |= K.SEG_REDUCED
+    if ignore_index is not None:
+        flags |= K.SEG_HAS_IGNORE
+        if normalized:
+            flags |= K.SEG_MASK_FOCAL_TERM
+    want_map = reduction not in ("mean", "sum")
+    if want_map:
+        flags |= K.SEG_ELEMWISE
+    return flags, want_map
+
+
+def _softmax_act_focal(output, labels, dense, softmax_dim, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index,
+                       class_weights):
+    """``activation="softmax"``: the focal term's probability is ``softmax(output, dim=softmax_dim)`` while the BCE term keeps the
+    logits (functional.py:61-78).  The contiguous tensor is handed to the kernel as the [B, C, HW] view whose C is the softmax
+    dimension; class_weights keep following dim 1 of the original tensor."""
+    if softmax_dim is None:
+        raise RuntimeError("focal_loss_with_logits(activation='softmax'): softmax_dim must be given (torch.softmax(dim=None) fails too)")
+    shape = tuple(output.shape)
+    nd = len(shape)
+    if not -nd <= softmax_dim < nd:
+        raise IndexError(f"Dimension out of range (expected to be in range of [{-nd}, {nd - 1}], but got {softmax_dim})")
+    d = softmax_dim % nd
+    x = K._f32c(output, "focal loss")
+    B, C, HW = math.prod(shape[:d]), shape[d], math.prod(shape[d + 1:])
+    x = x.reshape(B, C, HW)
+    flags, want_map = _focal_flags(alpha, reduced_threshold, ignore_index, normalized, reduction)
+    if dense is not None:
+        if tuple(dense.shape) != shape:
+            raise RuntimeError(f"target shape {tuple(dense.shape)} does not match output shape {shape}")
+        dense = K._f32c(dense, "focal loss").reshape(B, C, HW)
+    else:
+        if d != 1:   # index labels one-hot along dim 1 (focal.py:88-105); only that layout has the on-the-fly one-hot
+            raise NotImplementedError("BinaryFocalLoss with label maps and activation='softmax' needs softmax_dim=1")
+        labels = labels.to(device=x.device, dtype=torch.int64).reshape(B, -1).contiguous()
+        if labels.shape[1] != HW:
+            raise RuntimeError(f"target shape {tuple(labels.shape)} does not match output shape {shape}")
+    cw = (None, 0, 0, 1)
+    if class_weights is not None:
+        if nd < 2:
+            raise RuntimeError("class_weights need a tensor with a class dimension (dim 1)")
+        w = class_weights.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        if w.numel() != shape[1]:
+            raise RuntimeError("class_weights must have one entry per channel")
+        if d == 1:
+            cw = (w, 1, shape[1], 1)
+        elif d > 1:
+            cw = (w, 2, shape[1], max(1, math.prod(shape[2:d])))
+        else:
+            cw = (w, 3, shape[1], max(1, math.prod(shape[2:])))
+    sums, elem = K.SoftmaxActFocalSums.apply(
+        x, labels, dense, cw, flags, float(gamma), float(alpha if alpha is not None else 0.0),
+        float(reduced_threshold if reduced_threshold is not None else 0.0),
+        int(ignore_index) if (ignore_index is not None and labels is not None) else 0,
+        float(ignore_index) if ignore_index is not None else 0.0,
+    )
+    norm = sums[1].clamp_min(eps) if normalized else None
+    if want_map:
+        loss = elem.view(shape)
+        if normalized:
+            loss = loss / norm.float()
+        if reduction == "batchwise_mean":
+            loss = loss.sum(dim=0)
+        return loss
+    total = sums[0] / norm if normalized else sums[0]
+    if reduction == "mean":
+        total = total / x.numel()
+    return total.float()
 
 
 def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights):

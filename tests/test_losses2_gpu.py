@@ -214,3 +214,72 @@ def test_binary_bitempered_native_vs_algebra_at_scale(dev):
         diff = (ga - xr.grad).abs()
         scale = float(xr.grad.abs().max())
         assert float(diff.mean()) <= 1e-6 * scale and float((diff > 1e-4 * scale).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize("case", G3.by_fn("binary_soft_f1", "soft_f1"), ids=lambda c: c["name"])
+def test_soft_f1_native_matches_reference(case, dev, native):
+    """BinarySoftF1Loss / SoftF1Loss on GPU tensors run the fused HIP passes (soft TP / FP / FN counts): values and input
+    gradients vs the unmodified reference."""
+    from pytorch_toolbelt_amd import losses as L
+
+    x = torch.from_numpy(G3[case["inputs"][0]]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(G3[case["inputs"][1]]).to(dev)
+    before = native.calls
+    cls = L.BinarySoftF1Loss if case["fn"] == "binary_soft_f1" else L.SoftF1Loss
+    val = cls(**case["kwargs"])(x, t)
+    assert native.calls == before + 1
+    np.testing.assert_allclose(val.detach().cpu().numpy(), G3[case["name"]], rtol=1e-5, atol=1e-5)
+    val.sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), G3[case["name"] + "_grad"], rtol=1e-4, atol=1e-6)
+
+
+def test_soft_f1_at_scale_and_edges(dev):
+    """[16, 1, 512, 512] maps and [65536, 12] class scores against the formulas evaluated by torch in float64; everything
+    ignored -> 0 without a host synchronisation; soft_micro_f1 on probabilities."""
+    from pytorch_toolbelt_amd import losses as L
+    from pytorch_toolbelt_amd.losses.soft_f1 import soft_micro_f1
+
+    torch.manual_seed(3)
+    x = (torch.randn((16, 1, 512, 512), device=dev) * 3).requires_grad_(True)
+    t = (torch.rand((16, 1, 512, 512), device=dev) < 0.3).float()
+    t_ign = t.clone()
+    t_ign[torch.rand_like(t) < 0.2] = 255
+
+    def ref_binary(xv, tv, ignore):
+        xv, tv = xv.double().reshape(-1), tv.double().reshape(-1)
+        if ignore is not None:
+            keep = tv != ignore
+            xv, tv = xv[keep], tv[keep]
+        p = xv.sigmoid().clamp(1e-6, 1 - 1e-6)
+        tp, fp, fn = (p * tv).sum(), (p * (1 - tv)).sum(), ((1 - p) * tv).sum()
+        return 1 - 2 * tp / (2 * tp + fn + fp + 1e-6)
+
+    for tt, ign in ((t, None), (t_ign, 255)):
+        x.grad = None
+        got = L.BinarySoftF1Loss(ignore_index=ign)(x, tt)
+        got.backward()
+        xr = x.detach().clone().requires_grad_(True)
+        want = ref_binary(xr, tt, ign)
+        want.backward()
+        assert float(got) == pytest.approx(float(want), abs=1e-6)
+        torch.testing.assert_close(x.grad, xr.grad.float(), rtol=1e-4, atol=1e-12)
+    assert float(L.BinarySoftF1Loss(ignore_index=255)(x.detach(), torch.full_like(t, 255.0))) == 0.0
+    # multi-class
+    logits = (torch.randn((65536, 12), device=dev) * 2).requires_grad_(True)
+    lab = torch.randint(0, 12, (65536,), device=dev)
+    got = L.SoftF1Loss()(logits, lab)
+    got.backward()
+    lr = logits.detach().clone().requires_grad_(True)
+    p = lr.double().softmax(1).clamp(1e-6, 1 - 1e-6)
+    oh = torch.nn.functional.one_hot(lab, 12).double()
+    tp, fp, fn = (p * oh).sum(0), (p * (1 - oh)).sum(0), ((1 - p) * oh).sum(0)
+    want = (1 - 2 * tp / (2 * tp + fn + fp + 1e-6)).mean()
+    want.backward()
+    assert float(got) == pytest.approx(float(want), abs=1e-6)
+    torch.testing.assert_close(logits.grad, lr.grad.float(), rtol=1e-4, atol=1e-10)
+    probs = torch.rand((4096, 7), device=dev)
+    tg = (torch.rand((4096, 7), device=dev) < 0.4).float()
+    pd_, td = probs.double(), tg.double()
+    tp, fp, fn = (pd_ * td).sum(0), (pd_ * (1 - td)).sum(0), ((1 - pd_) * td).sum(0)
+    assert float(soft_micro_f1(probs, tg)) == pytest.approx(float((1 - 2 * tp / (2 * tp + fn + fp + 1e-6)).mean()), abs=1e-6)
+    assert float(soft_micro_f1(probs[:, :1], tg[:, :1])) == pytest.approx(float(1 - 2 * tp[0] / (2 * tp[0] + fn[0] + fp[0] + 1e-6)), abs=1e-6)

@@ -39,10 +39,6 @@ def _kw(case, dev):
 @pytest.mark.parametrize("case", GL.by_fn("focal_loss_with_logits"), ids=lambda c: c["name"])
 def test_golden_focal_functional(case, dev):
     kw = _kw(case, dev)
-    if kw.get("activation") == "softmax":
-        with pytest.raises(NotImplementedError):
-            _L().focal_loss_with_logits(_t(GL[case["inputs"][0]], dev), _t(GL[case["inputs"][1]], dev), **kw)
-        return
     from pytorch_toolbelt_amd import _native as N
 
     before = N.calls
@@ -645,3 +641,53 @@ def test_dense_target_statistics_streaming_kernel(mode, C, ignore_index, dev):
         x1 = xl.clone().requires_grad_(True)
         L.DiceLoss(mode)(x1, tl).backward()               # (backward: the generic statistics kernel; forward: the streaming one)
         assert torch.isfinite(x1.grad).all() and float(x1.grad.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------ focal, activation="softmax" (functional.py:61-66)
+GL4 = load_golden("losses4.npz")
+
+
+@pytest.mark.parametrize("case", GL4.cases, ids=lambda c: c["name"])
+def test_golden_focal_softmax_activation(case, dev):
+    """Values AND gradients of focal_loss_with_logits / BinaryFocalLoss with activation="softmax" against the unmodified
+    reference (autograd goldens): every option, softmax over any dimension, class weights along dim 1."""
+    from pytorch_toolbelt_amd import _native as N
+
+    L = _L()
+    kw = dict(case["kwargs"])
+    if kw.pop("class_weights", None):
+        kw["class_weights"] = _t(GL4[case["weights"]], dev)
+    x = _t(GL4[case["inputs"][0]], dev).requires_grad_(True)
+    t = _t(GL4[case["inputs"][1]], dev)
+    before = N.calls
+    if case["fn"] == "focal_softmax_module":
+        out = L.BinaryFocalLoss(activation="softmax", **kw).to(dev)(x, t)
+    else:
+        out = L.focal_loss_with_logits(x, t, activation="softmax", **kw)
+    assert N.calls > before
+    want = GL4[case["output"]]
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    w = (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % 7 + 1.0) if out.dim() else None
+    (out * w if w is not None else out).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), GL4[case["output"] + "_grad"], rtol=2e-4, atol=2e-6)
+
+
+def test_focal_softmax_activation_errors_and_big(dev):
+    L = _L()
+    x = torch.randn((2, 4, 8, 8), device=dev)
+    t = (torch.rand((2, 4, 8, 8), device=dev) < 0.3).float()
+    with pytest.raises(RuntimeError):
+        L.focal_loss_with_logits(x, t, activation="softmax")                 # softmax_dim missing (torch.softmax(dim=None) fails)
+    with pytest.raises(IndexError):
+        L.focal_loss_with_logits(x, t, activation="softmax", softmax_dim=4)
+    with pytest.raises(RuntimeError, match="does not match"):
+        L.focal_loss_with_logits(x, t[:, :2], activation="softmax", softmax_dim=1)
+    # cfg4-sized tensor: finite, below the sigmoid focal loss for confident correct predictions, and equal to a torch restatement
+    xb = torch.randn((4, 16, 256, 256), device=dev) * 2
+    lab = torch.randint(0, 16, (4, 256, 256), device=dev)
+    got = L.BinaryFocalLoss(activation="softmax", softmax_dim=1)(xb, lab)
+    oh = torch.nn.functional.one_hot(lab, 16).permute(0, 3, 1, 2).float()
+    p = torch.softmax(xb, 1)
+    pt = p * oh + (1 - p) * (1 - oh)
+    ref = ((1 - pt) ** 2 * torch.nn.functional.binary_cross_entropy_with_logits(xb, oh, reduction="none")).mean()
+    assert float(got) == pytest.approx(float(ref), abs=1e-5)

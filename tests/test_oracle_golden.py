@@ -356,3 +356,18 @@ def test_pointwise_loss_oracle(case):
     want = GL2[case["name"]]
     assert np.shape(got) == want.shape
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5)
+
+
+# ------------------------------------------------------------------ focal, activation="softmax" (functional.py:61-66)
+GL4 = load_golden("losses4.npz")
+
+
+@pytest.mark.parametrize("case", GL4.cases, ids=lambda c: c["name"])
+def test_focal_softmax_activation_oracle(case):
+    kw = dict(case["kwargs"])
+    if kw.pop("class_weights", None):
+        kw["class_weights"] = GL4[case["weights"]]
+    x, t = GL4[case["inputs"][0]], GL4[case["inputs"][1]]
+    fn = LO.binary_focal_loss if case["fn"] == "focal_softmax_module" else LO.focal_loss_with_logits
+    out = fn(x, t, activation="softmax", **kw)
+    np.testing.assert_allclose(out, GL4[case["output"]], rtol=1e-5, atol=1e-6)
