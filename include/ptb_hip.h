@@ -396,11 +396,12 @@ int ptb_bitempered_binary_bwd(const float* x, const float* t, const float* coef,
  * whole batch; S = groups*C segments of P = (per_image ? HW : B*HW) elements, n = S*P < 2^31.
  * seg_loss[s] (double, zeroed by the caller) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
  * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward).
- * Workspaces are caller-provided device buffers: keys_a/keys_b u64[n] (segment rank << 32 | ordered error bits),
- * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (rocPRIM radix sort). */
+ * Workspaces are caller-provided device buffers: keys_a/keys_b u32[n] (complemented order-preserving error bits),
+ * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (digit histograms of the
+ * hand-written segmented radix sort: four stable 8-bit passes per segment). */
 int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments);
 int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
-                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint64_t* keys_a, uint64_t* keys_b,
+                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                    unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                    double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream);
 /* grad[pred layout] = coef[s] * grad_at_pixel * d(error)/d(pred); coef = DEVICE float[S]. */

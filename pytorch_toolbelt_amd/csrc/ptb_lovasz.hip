@@ -4,19 +4,20 @@
 // Per class (and per image with per_image=True) the reference sorts the errors, gathers the ground truth, runs two
 // cumsums, a division, a first difference and a dot product -- a Python loop over classes with a host sync each
 // (`fg.sum() == 0`).  Here every (group, class) pair is one *segment* of a single pipeline:
-//   1. error kernel:   key = error (ignored pixels get -inf so they sort last and contribute 0), value = index<<1 | fg
-//   2. ONE rocPRIM radix sort, descending, over 64-bit composite keys (segment rank << 32 | order-preserving bits of
-//      the error): all classes / images are sorted by a single multi-pass HBM-bound radix sort (rocPRIM's *segmented*
-//      sort is built for many small segments and measured 24 ms for 16 segments of 1 M; the composite-key sort is
-//      ~40x faster).  The ROCm primitive is used as-is for the sort, everything around it is hand-written
+//   1. error kernel:   key = ~(order-preserving bits of the error) (ignored pixels get -inf so they sort last and contribute
+//      0), value = index<<1 | fg
+//   2. a hand-written segmented LSD radix sort for gfx950 (below): every segment is sorted by its 32-bit keys in four 8-bit
+//      passes; a pass = per-tile digit histograms (wave-private LDS counters fed by ballot-matched lane groups, no
+//      atomics), one row scan per (segment, digit), and a stable scatter that ranks the 4096 keys of a tile with the same
+//      ballot match, stages them by digit in LDS and writes every digit run coalesced.  No inter-workgroup communication,
+//      so it is deterministic and needs no forward-progress assumptions.  (Round 1 used rocPRIM's radix sort over 64-bit
+//      composite keys here: 0.72 ms of the 1.29 ms for 16 segments of 1 M.)
 //   3. fused scan kernel: chunked prefix count of fg over the sorted order -> Jaccard gradient grad_k = J_k - J_{k-1}
 //      -> sum_k relu(e_k) * grad_k per segment (fp64 atomics), and grad_k scattered back to pixel order for backward
 //   4. backward kernel: d(loss)/d(pred) = coef[segment] * grad_at_pixel * d(error)/d(pred)
 // No host synchronisation anywhere: class presence (G > 0) is returned as a device array and the mean over present
 // classes is [segments]-sized scalar algebra on the caller's side.
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "ptb_common.h"
 
@@ -74,7 +75,7 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
     return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-__global__ __launch_bounds__(256) void lovasz_error_kernel(const LovArgs a, unsigned long long* __restrict__ keys, unsigned* __restrict__ vals) {
+__global__ __launch_bounds__(256) void lovasz_error_kernel(const LovArgs a, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const long long n = a.P * a.S;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
@@ -84,9 +85,157 @@ __global__ __launch_bounds__(256) void lovasz_error_kernel(const LovArgs a, unsi
         unsigned fg;
         bool valid;
         error_of(a, s, i, e, fg, valid);
-        // descending sort: segment 0 must come first, so it gets the largest segment rank
-        keys[t] = ((unsigned long long)(unsigned)(a.S - 1 - s) << 32) | ordered_bits(valid ? e : -INFINITY);
+        keys[t] = ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
         vals[t] = ((unsigned)i << 1) | (valid ? fg : 0u);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ segmented radix sort
+// S segments of P (key, value) pairs each, contiguous; ascending by the 32-bit key, stable, four passes of 8 bits.
+// Tile = 4096 elements per 256-thread workgroup; wave w of a tile owns elements w*1024 .. w*1024+1023 and its item j covers the
+// 64 consecutive elements w*1024 + j*64 + lane (every load instruction of a wave reads 256 contiguous bytes).
+constexpr int RS_ITEMS = 16, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 64 * RS_ITEMS;
+
+// lanes of this wave whose digit equals mine (8 ballots), as a 64-bit mask
+__device__ __forceinline__ unsigned long long match_digit(unsigned d) {
+    unsigned long long m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+
+// inclusive scan of one value per thread over the 256 threads of the workgroup (wave shuffles + 4 wave totals in LDS)
+__device__ __forceinline__ unsigned block_inclusive_scan(unsigned v, unsigned* wave_tot /* [4] LDS */, unsigned& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();                       // (wave_tot may still be read from a previous call)
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned off = 0;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    return incl + off;
+}
+
+// pass step 1: digit histogram of every tile -> hist[(seg * 256 + digit) * T + tile]
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[4][256];
+    const int seg = blockIdx.x / T, tile = blockIdx.x % T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) h[w][threadIdx.x] = 0;
+    __syncthreads();
+    const long long t0 = (long long)tile * RS_TILE;
+    const unsigned* kp = keys + (long long)seg * P + t0;
+    const long long left = P - t0;
+    unsigned k[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
+        k[j] = idx < left ? kp[idx] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
+        const bool valid = idx < left;
+        const unsigned d = (k[j] >> shift) & 255u;
+        const unsigned long long m = match_digit(d) & __ballot(valid);
+        // one lane per distinct digit adds the whole group to the wave's private counter: no atomics, no conflicts
+        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) h[wave][d] += (unsigned)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    hist[((long long)seg * 256 + threadIdx.x) * T + tile] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+}
+
+// pass step 2: one workgroup per (segment, digit) row of T tile counts: exclusive prefix in place, row total -> rowsum
+__global__ __launch_bounds__(256) void rs_rowscan_kernel(unsigned* __restrict__ hist, int T, unsigned* __restrict__ rowsum) {
+    __shared__ unsigned wave_tot[4];
+    unsigned* row = hist + (long long)blockIdx.x * T;
+    unsigned carry = 0;
+    for (int t0 = 0; t0 < T; t0 += 256) {
+        const int t = t0 + threadIdx.x;
+        const unsigned v = t < T ? row[t] : 0u;
+        unsigned total;
+        const unsigned incl = block_inclusive_scan(v, wave_tot, total);
+        if (t < T) row[t] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) rowsum[blockIdx.x] = carry;
+}
+
+// pass step 3: stable scatter of one tile
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
+                                                         unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
+                                                         int shift, const unsigned* __restrict__ hist, const unsigned* __restrict__ rowsum) {
+    __shared__ unsigned wave_hist[4][256];   // per wave: running digit counts, then the wave's start inside the tile's digit run
+    __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
+    __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
+    __shared__ unsigned wave_tot[4];
+    __shared__ unsigned skey[RS_TILE], sval[RS_TILE];
+    const int seg = blockIdx.x / T, tile = blockIdx.x % T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long t0 = (long long)tile * RS_TILE;
+    const long long base = (long long)seg * P;
+    const long long left = P - t0;
+    const int count = left < RS_TILE ? (int)left : RS_TILE;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wave_hist[w][threadIdx.x] = 0;
+    unsigned k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
+        // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
+        // (they are the last in tile order and the sort is stable) and are never written
+        k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
+        v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const unsigned d = (k[j] >> shift) & 255u;
+        const unsigned long long m = match_digit(d);
+        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned old = wave_hist[wave][d];                    // every lane of the group reads the counter ...
+        __builtin_amdgcn_wave_barrier();
+        if (below == 0) wave_hist[wave][d] = old + (unsigned)__popcll(m);   // ... before its first lane advances it
+        __builtin_amdgcn_wave_barrier();
+        rank[j] = old + below;                                      // rank among the wave's elements with this digit, in order
+    }
+    __syncthreads();
+    // per digit (thread = digit): waves' starts inside the run, the tile's count, the run's start inside the tile and in the output
+    const unsigned c0 = wave_hist[0][threadIdx.x], c1 = wave_hist[1][threadIdx.x], c2 = wave_hist[2][threadIdx.x], c3 = wave_hist[3][threadIdx.x];
+    wave_hist[0][threadIdx.x] = 0; wave_hist[1][threadIdx.x] = c0; wave_hist[2][threadIdx.x] = c0 + c1; wave_hist[3][threadIdx.x] = c0 + c1 + c2;
+    const unsigned tot = c0 + c1 + c2 + c3;
+    unsigned total;
+    const unsigned excl = block_inclusive_scan(tot, wave_tot, total) - tot;
+    const unsigned rs = rowsum[seg * 256 + threadIdx.x];
+    const unsigned dstart = block_inclusive_scan(rs, wave_tot, total) - rs;   // elements of the segment with a smaller digit
+    tile_off[threadIdx.x] = excl;
+    digit_base[threadIdx.x] = dstart + hist[((long long)seg * 256 + threadIdx.x) * T + tile] - excl;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS_ITEMS; ++j) {
+        const unsigned d = (k[j] >> shift) & 255u;
+        const unsigned slot = tile_off[d] + wave_hist[wave][d] + rank[j];
+        skey[slot] = k[j];
+        sval[slot] = v[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += 256) {
+        const unsigned kk = skey[i];
+        const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
+        keys_out[pos] = kk;
+        vals_out[pos] = sval[i];
     }
 }
 
@@ -142,7 +291,7 @@ __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // 
 }
 
 // phase c: per element of the sorted order: cum fg -> grad_k = J_k - J_{k-1}; accumulate relu(e_k) * grad_k; scatter grad_k
-__global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned long long* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
+__global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
                                                          const unsigned* __restrict__ fg_total, double* __restrict__ seg_loss,
                                                          float* __restrict__ grad_at_pixel) {
@@ -158,7 +307,7 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned long lon
     for (int u = 0; u < 8; ++u) {
         const long long i = first + u;
         v[u] = i < P ? vals[base + i] : 0u;
-        e[u] = i < P ? from_ordered_bits((unsigned)keys[base + i]) : -INFINITY;
+        e[u] = i < P ? from_ordered_bits(~keys[base + i]) : -INFINITY;
         local += v[u] & 1u;
     }
     // exclusive prefix of `local` across the 256 threads
@@ -246,27 +395,19 @@ static int blocks_for(long long n) {
 
 using namespace ptb;
 
-static int key_bits(int segments) {
-    int b = 0;
-    while ((1 << b) < segments) ++b;
-    return 32 + b;
-}
-
-// bytes of rocPRIM temporary storage for sorting `segments` segments of `per_segment` elements
+// bytes of sort workspace for `segments` segments of `per_segment` elements: the per-tile digit histograms
+// u32[segments][256][tiles] followed by the row totals u32[segments][256]
 extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
-    size_t bytes = 0;
-    const size_t n = (size_t)(per_segment * segments);
-    hipError_t e = rocprim::radix_sort_pairs_desc(nullptr, bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                                  (unsigned*)nullptr, (unsigned*)nullptr, n, 0, key_bits(segments), (hipStream_t)0);
-    if (e != hipSuccess) return -1;
-    return (int64_t)bytes;
+    if (per_segment < 0 || segments < 0) return -1;
+    const int64_t tiles = (per_segment + RS_TILE - 1) / RS_TILE;
+    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256) * (int64_t)sizeof(unsigned);
 }
 
-// Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u64[n]; vals_a, vals_b u32[n];
+// Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
 // chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (zeroed by the caller);
 // grad_at_pixel float[n] (kept for backward); temp = ptb_lovasz_temp_bytes bytes.
 extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
-                              int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint64_t* keys_a, uint64_t* keys_b,
+                              int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                               unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                               double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
     LovArgs a{};
@@ -275,19 +416,32 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     const long long n = a.P * a.S;
     if (n == 0) return PTB_OK;
     if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;  // offsets / packed indices are 32-bit
+    if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lovasz_error_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, (unsigned long long*)keys_a, vals_a);
+    hipLaunchKernelGGL(lovasz_error_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, keys_a, vals_a);
     if (int rc = check_launch()) return rc;
-    size_t tb = (size_t)temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs_desc(temp, tb, (unsigned long long*)keys_a, (unsigned long long*)keys_b, vals_a, vals_b,
-                                                  (size_t)n, 0, key_bits(a.S), s);
-    if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
+    const int T = (int)((a.P + RS_TILE - 1) / RS_TILE);
+    const long long tiles = (long long)T * a.S;
+    if (tiles > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    unsigned* hist = static_cast<unsigned*>(temp);
+    unsigned* rowsum = hist + (long long)a.S * 256 * T;
+    unsigned *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
+    for (int shift = 0; shift < 32; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
+        hipLaunchKernelGGL(rs_rowscan_kernel, dim3(a.S * 256), dim3(256), 0, s, hist, T, rowsum);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, rowsum);
+        if (int rc = check_launch()) return rc;
+        unsigned* tk = kin; kin = kout; kout = tk;
+        unsigned* tv = vin; vin = vout; vout = tv;
+    }
+    // (an even number of passes: the sorted pairs are back in keys_a / vals_a)
     const int cps = (int)((a.P + CHUNK - 1) / CHUNK);
     const long long total_chunks = (long long)cps * a.S;
     if (total_chunks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
-    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vals_b, a.P, cps, chunk);
+    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin == keys_a ? vals_a : vals_b, a.P, cps, chunk);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, (const unsigned long long*)keys_b, vals_b, a.P, cps, chunk, fg_total, seg_loss,
+    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, seg_loss,
                        grad_at_pixel);
     return check_launch();
 }

@@ -2,7 +2,7 @@
 
 Algorithm of Berman et al. 2018 as used by the reference (losses/lovasz.py): sort the per-pixel errors of one class in
 decreasing order, weight them by the discrete gradient of the Jaccard index along that order, sum.  Here all classes
-(and all images when ``per_image``) are segments of ONE segmented radix sort followed by one fused scan/dot kernel,
+(and all images when ``per_image``) are segments of ONE hand-written segmented radix sort followed by one fused scan/dot kernel,
 with no host synchronisation (the reference syncs once per class to test ``fg.sum() == 0``).
 """
 from typing import Optional, Union
@@ -38,7 +38,7 @@ class _LovaszSegments(torch.autograd.Function):
         gpix = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
         if n > 0:
             lib = N.load()
-            keys = torch.empty((2, n), dtype=torch.int64, device=dev)
+            keys = torch.empty((2, n), dtype=torch.int32, device=dev)
             vals = torch.empty((2, n), dtype=torch.int32, device=dev)
             chunk = torch.empty(S * ((P + _CHUNK - 1) // _CHUNK), dtype=torch.int32, device=dev)
             with N.on_device(dev):

@@ -691,3 +691,56 @@ def test_focal_softmax_activation_errors_and_big(dev):
     pt = p * oh + (1 - p) * (1 - oh)
     ref = ((1 - pt) ** 2 * torch.nn.functional.binary_cross_entropy_with_logits(xb, oh, reduction="none")).mean()
     assert float(got) == pytest.approx(float(ref), abs=1e-5)
+
+
+@pytest.mark.parametrize("B,C,H,W,per_image", [(2, 3, 37, 53, False), (3, 2, 64, 64, True), (1, 16, 512, 512, False), (4, 4, 256, 300, True),
+                                                 (2, 1, 1, 5, False)])
+def test_lovasz_radix_sort_is_a_stable_descending_sort(B, C, H, W, per_image, dev):
+    """The hand-written segmented radix sort behind the Lovasz losses (csrc/ptb_lovasz.hip), checked on its own through the C
+    ABI workspaces: after ptb_lovasz_fwd, keys_a / vals_a hold every segment's (key, index << 1 | fg) pairs in EXACTLY the order
+    a stable descending torch.sort of the errors gives -- segment sizes off the 4096-element tile grid, ties, ignored pixels."""
+    from pytorch_toolbelt_amd import _native as N
+
+    lib = N.load()
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + C)
+    HW = H * W
+    probs = torch.softmax(torch.randn((B, C, HW), device=dev, generator=g) * 2, 1).contiguous()
+    probs[:, :, ::7] = probs[:, :, ::7].round()          # many exact ties (errors 0 and 1)
+    labels = torch.randint(0, C, (B, HW), device=dev, generator=g)
+    labels[:, ::11] = 255
+    groups = B if per_image else 1
+    P = HW if per_image else B * HW
+    S = groups * C
+    n = P * S
+    keys = torch.zeros((2, n), dtype=torch.int32, device=dev)
+    vals = torch.zeros((2, n), dtype=torch.int32, device=dev)
+    chunk = torch.empty(S * ((P + 2047) // 2048), dtype=torch.int32, device=dev)
+    fg_total = torch.zeros(S, dtype=torch.int32, device=dev)
+    seg_loss = torch.zeros(S, dtype=torch.float64, device=dev)
+    gpix = torch.empty(n, dtype=torch.float32, device=dev)
+    tb = lib.ptb_lovasz_temp_bytes(P, S)
+    temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
+    rc = lib.ptb_lovasz_fwd(probs.data_ptr(), labels.data_ptr(), None, B, C, HW, 0, 1 if per_image else 0, 1, 255, 0.0, keys[0].data_ptr(),
+                            keys[1].data_ptr(), vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
+                            seg_loss.data_ptr(), gpix.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    # expectation: per segment (group j, class c) the errors |fg - p| (ignored -> -inf) in stable descending order
+    if per_image:
+        p_seg = probs.reshape(S, P)                                    # segment = b * C + c
+        lab_seg = labels.repeat_interleave(C, dim=0)
+        cls = torch.arange(C, device=dev).repeat(B).view(S, 1)
+    else:
+        p_seg = probs.permute(1, 0, 2).reshape(C, P)
+        lab_seg = labels.reshape(1, P).expand(C, P)
+        cls = torch.arange(C, device=dev).view(C, 1)
+    valid = lab_seg != 255
+    fg = ((lab_seg == cls) & valid)
+    err = torch.where(valid, (fg.float() - p_seg).abs(), torch.full_like(p_seg, float("-inf")))
+    order = torch.sort(err, dim=1, descending=True, stable=True).indices
+    want_vals = (order << 1) | torch.gather(fg.long(), 1, order)
+    got_vals = vals[0].view(S, P).long() & 0xFFFFFFFF
+    assert torch.equal(got_vals, want_vals)
+    got_err = torch.gather(err, 1, got_vals >> 1)
+    assert bool((got_err[:, 1:] <= got_err[:, :-1]).all())
+    assert torch.equal(fg_total.long(), fg.sum(1))
