@@ -7,9 +7,9 @@
 //   1. error kernel:   key = ~(order-preserving bits of the error) (ignored pixels get -inf so they sort last and contribute
 //      0), value = index<<1 | fg
 //   2. a hand-written segmented LSD radix sort for gfx950 (below): every segment is sorted by its 32-bit keys in four 8-bit
-//      passes; a pass = per-tile digit histograms (wave-private LDS counters fed by ballot-matched lane groups, no
-//      atomics), one row scan per (segment, digit), and a stable scatter that ranks the 4096 keys of a tile with the same
-//      ballot match, stages them by digit in LDS and writes every digit run coalesced.  No inter-workgroup communication,
+//      passes; a pass = per-tile digit histograms (wave-private LDS counters), a scan over the tiles of every segment, and a
+//      stable scatter that ranks the 4096 keys of a tile with ballot-matched lane groups (no atomics where order matters), stages them by digit in LDS and writes every digit run coalesced (tile-major histograms, scanned in spans
+//      of 32 tiles, so every histogram access is a coalesced 1 KiB row).  No inter-workgroup communication,
 //      so it is deterministic and needs no forward-progress assumptions.  (Round 1 used rocPRIM's radix sort over 64-bit
 //      composite keys here: 0.72 ms of the 1.29 ms for 16 segments of 1 M.)
 //   3. fused scan kernel: chunked prefix count of fg over the sorted order -> Jaccard gradient grad_k = J_k - J_{k-1}
@@ -96,16 +96,22 @@ __global__ __launch_bounds__(256) void lovasz_error_kernel(const LovArgs a, unsi
 // 64 consecutive elements w*1024 + j*64 + lane (every load instruction of a wave reads 256 contiguous bytes).
 constexpr int RS_ITEMS = 16, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 64 * RS_ITEMS;
 
-// lanes of this wave whose digit equals mine (8 ballots), as a 64-bit mask
-__device__ __forceinline__ unsigned long long match_digit(unsigned d) {
-    unsigned long long m = ~0ull;
+// Lanes of this wave whose digit equals mine: per bit one ballot (a scalar pair) folded into the lane's mask halves with
+// XNOR against the sign-extended bit -- 6 vector instructions per bit (a per-lane select between the ballot and its complement
+// costs twice that: two scalar operands in one VOP3 are not encodable).  Returns the group size; `below` = members in lower lanes.
+__device__ __forceinline__ unsigned match_digit(unsigned d, int lane, unsigned& below) {
+    unsigned m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        const int sb = ((int)(d << (31 - b))) >> 31;              // 0 or ~0
+        const unsigned long long bal = __ballot(sb != 0);
+        m_lo &= ~((unsigned)bal ^ (unsigned)sb);
+        m_hi &= ~((unsigned)(bal >> 32) ^ (unsigned)sb);
     }
-    return m;
+    const unsigned lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const unsigned lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    below = __popc(m_lo & lt_lo) + __popc(m_hi & lt_hi);
+    return __popc(m_lo) + __popc(m_hi);
 }
 
 // inclusive scan of one value per thread over the 256 threads of the workgroup (wave shuffles + 4 wave totals in LDS)
@@ -126,13 +132,18 @@ __device__ __forceinline__ unsigned block_inclusive_scan(unsigned v, unsigned* w
     return incl + off;
 }
 
-// pass step 1: digit histogram of every tile -> hist[(seg * 256 + digit) * T + tile]
+// pass step 1: digit histogram of every tile -> hist[(seg * T + tile) * 256 + digit]  (one coalesced 1 KiB row per tile)
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist) {
-    __shared__ unsigned h[4][256];
+    // counts only, no order: LDS atomics (ds_add_u32 without return).  Four copies per wave (lane & 3) keep the same-address
+    // serialisation short when the digit is nearly constant (the exponent byte of probabilities); a wave whose 64 keys share
+    // one digit adds 64 from a single lane.
+    __shared__ unsigned h[4][4][256];
     const int seg = blockIdx.x / T, tile = blockIdx.x % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) h[w][threadIdx.x] = 0;
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h[w][c][threadIdx.x] = 0;
     __syncthreads();
     const long long t0 = (long long)tile * RS_TILE;
     const unsigned* kp = keys + (long long)seg * P + t0;
@@ -148,35 +159,47 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
         const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
         const bool valid = idx < left;
         const unsigned d = (k[j] >> shift) & 255u;
-        const unsigned long long m = match_digit(d) & __ballot(valid);
-        // one lane per distinct digit adds the whole group to the wave's private counter: no atomics, no conflicts
-        if (valid && (m & ((1ull << lane) - 1ull)) == 0ull) h[wave][d] += (unsigned)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
+        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+        const bool full = wave * RS_WAVE_SPAN + j * 64 + 63 < left;      // (wave-uniform)
+        if (full && __all(d == d0)) {
+            if (lane == 0) atomicAdd(&h[wave][0][d0], 64u);
+        } else if (valid) {
+            atomicAdd(&h[wave][lane & 3][d], 1u);
+        }
     }
     __syncthreads();
-    hist[((long long)seg * 256 + threadIdx.x) * T + tile] = h[0][threadIdx.x] + h[1][threadIdx.x] + h[2][threadIdx.x] + h[3][threadIdx.x];
+    unsigned tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tot += h[w][c][threadIdx.x];
+    hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
 }
 
-// pass step 2: one workgroup per (segment, digit) row of T tile counts: exclusive prefix in place, row total -> rowsum
-__global__ __launch_bounds__(256) void rs_rowscan_kernel(unsigned* __restrict__ hist, int T, unsigned* __restrict__ rowsum) {
-    __shared__ unsigned wave_tot[4];
-    unsigned* row = hist + (long long)blockIdx.x * T;
-    unsigned carry = 0;
-    for (int t0 = 0; t0 < T; t0 += 256) {
-        const int t = t0 + threadIdx.x;
-        const unsigned v = t < T ? row[t] : 0u;
-        unsigned total;
-        const unsigned incl = block_inclusive_scan(v, wave_tot, total);
-        if (t < T) row[t] = carry + incl - v;
-        carry += total;
+// pass step 2: one workgroup per (segment, span of RS_SPAN tiles); thread = digit: running count over the span's tiles in place
+// (every access is a coalesced 1 KiB row, the loads of a span are independent of each other), span total -> span_tot
+constexpr int RS_SPAN = 32;
+__global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot) {
+    const int seg = blockIdx.x / spans, span = blockIdx.x % spans;
+    const int t0 = span * RS_SPAN, t1 = min(T, t0 + RS_SPAN);
+    unsigned* row = hist + ((long long)seg * T + t0) * 256 + threadIdx.x;
+    unsigned v[RS_SPAN];
+#pragma unroll
+    for (int t = 0; t < RS_SPAN; ++t) v[t] = t0 + t < t1 ? row[(long long)t * 256] : 0u;
+    unsigned run = 0;
+#pragma unroll
+    for (int t = 0; t < RS_SPAN; ++t) {
+        if (t0 + t < t1) row[(long long)t * 256] = run;
+        run += v[t];
     }
-    if (threadIdx.x == 0) rowsum[blockIdx.x] = carry;
+    span_tot[((long long)seg * spans + span) * 256 + threadIdx.x] = run;
 }
 
 // pass step 3: stable scatter of one tile
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                          unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
-                                                         int shift, const unsigned* __restrict__ hist, const unsigned* __restrict__ rowsum) {
+                                                         int shift, const unsigned* __restrict__ hist, int spans,
+                                                         const unsigned* __restrict__ span_tot) {
     __shared__ unsigned wave_hist[4][256];   // per wave: running digit counts, then the wave's start inside the tile's digit run
     __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
@@ -203,11 +226,11 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
-        const unsigned long long m = match_digit(d);
-        const unsigned below = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        unsigned below;
+        const unsigned group = match_digit(d, lane, below);
         const unsigned old = wave_hist[wave][d];                    // every lane of the group reads the counter ...
         __builtin_amdgcn_wave_barrier();
-        if (below == 0) wave_hist[wave][d] = old + (unsigned)__popcll(m);   // ... before its first lane advances it
+        if (below == 0) wave_hist[wave][d] = old + group;           // ... before its first lane advances it
         __builtin_amdgcn_wave_barrier();
         rank[j] = old + below;                                      // rank among the wave's elements with this digit, in order
     }
@@ -218,10 +241,17 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
     const unsigned tot = c0 + c1 + c2 + c3;
     unsigned total;
     const unsigned excl = block_inclusive_scan(tot, wave_tot, total) - tot;
-    const unsigned rs = rowsum[seg * 256 + threadIdx.x];
+    // this digit's elements in earlier spans of the segment, and in the whole segment
+    unsigned before = 0, rs = 0;
+    const int my_span = tile / RS_SPAN;
+    for (int sp = 0; sp < spans; ++sp) {
+        const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
+        before += sp < my_span ? c : 0u;
+        rs += c;
+    }
     const unsigned dstart = block_inclusive_scan(rs, wave_tot, total) - rs;   // elements of the segment with a smaller digit
     tile_off[threadIdx.x] = excl;
-    digit_base[threadIdx.x] = dstart + hist[((long long)seg * 256 + threadIdx.x) * T + tile] - excl;
+    digit_base[threadIdx.x] = dstart + before + hist[((long long)seg * T + tile) * 256 + threadIdx.x] - excl;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
@@ -290,7 +320,11 @@ __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // 
     return 1.0f - inter / uni;
 }
 
-// phase c: per element of the sorted order: cum fg -> grad_k = J_k - J_{k-1}; accumulate relu(e_k) * grad_k; scatter grad_k
+// phase c: per element of the sorted order: cum fg -> grad_k = J_k - J_{k-1}; accumulate relu(e_k) * grad_k; scatter grad_k back
+// to pixel order.  The scatter is 16.7 M four-byte writes to random addresses at [4,16,512,512] and dominates this kernel
+// (~200 us).  Measured alternatives, both dropped: keeping a segment's scatter on one XCD (b % 8 placement) so that its lines
+// fill up in one L2: +6 %; returning through 16384-pixel bins (append (pixel, grad) runs to <= 1024 sequential streams, then
+// order each bin in LDS and write it coalesced): 205 + 36 us against 198 us for the direct scatter.
 __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
                                                          const unsigned* __restrict__ fg_total, double* __restrict__ seg_loss,
@@ -303,12 +337,22 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
     unsigned v[8];
     float e[8];
     unsigned local = 0;
+    if (first + 8 <= P && ((base + first) & 3) == 0) {
+        // 2 x 16-byte loads per array: with eight 4-byte loads a wave instruction touches 16 cache lines and uses an eighth of each
+        const uint4 va = *reinterpret_cast<const uint4*>(vals + base + first), vb = *reinterpret_cast<const uint4*>(vals + base + first + 4);
+        const uint4 ka = *reinterpret_cast<const uint4*>(keys + base + first), kb = *reinterpret_cast<const uint4*>(keys + base + first + 4);
+        v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
+        const unsigned kk[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const long long i = first + u;
-        v[u] = i < P ? vals[base + i] : 0u;
-        e[u] = i < P ? from_ordered_bits(~keys[base + i]) : -INFINITY;
-        local += v[u] & 1u;
+        for (int u = 0; u < 8; ++u) { e[u] = from_ordered_bits(~kk[u]); local += v[u] & 1u; }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long i = first + u;
+            v[u] = i < P ? vals[base + i] : 0u;
+            e[u] = i < P ? from_ordered_bits(~keys[base + i]) : -INFINITY;
+            local += v[u] & 1u;
+        }
     }
     // exclusive prefix of `local` across the 256 threads
     __shared__ unsigned wsum[4];
@@ -396,11 +440,12 @@ static int blocks_for(long long n) {
 using namespace ptb;
 
 // bytes of sort workspace for `segments` segments of `per_segment` elements: the per-tile digit histograms
-// u32[segments][256][tiles] followed by the row totals u32[segments][256]
+// u32[segments][tiles][256] followed by the span totals u32[segments][ceil(tiles / 32)][256]
 extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
     if (per_segment < 0 || segments < 0) return -1;
     const int64_t tiles = (per_segment + RS_TILE - 1) / RS_TILE;
-    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256) * (int64_t)sizeof(unsigned);
+    const int64_t spans = (tiles + RS_SPAN - 1) / RS_SPAN;
+    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256 * spans) * (int64_t)sizeof(unsigned);
 }
 
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
@@ -425,12 +470,13 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     const long long tiles = (long long)T * a.S;
     if (tiles > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     unsigned* hist = static_cast<unsigned*>(temp);
-    unsigned* rowsum = hist + (long long)a.S * 256 * T;
+    unsigned* span_tot = hist + (long long)a.S * 256 * T;
+    const int spans = (T + RS_SPAN - 1) / RS_SPAN;
     unsigned *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     for (int shift = 0; shift < 32; shift += 8) {
         hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
-        hipLaunchKernelGGL(rs_rowscan_kernel, dim3(a.S * 256), dim3(256), 0, s, hist, T, rowsum);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, rowsum);
+        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
