@@ -267,6 +267,34 @@ int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* hs_full, co
                               const int* src_rows, int n, float* out, int64_t planes, int hout_full, int wout, int out_row0,
                               int out_rows, int align_corners, int reduction, ptb_stream_t stream);
 
+/* Adjoints of the resize entry points ("TTA respects gradient flow", inference/tta.py:3-4; the reference gets them from autograd
+ * through F.interpolate).  grad_in / grad_inputs[s] must be ZEROED by the caller: the 4 taps of several output pixels land on
+ * the same source pixel and are added with fp32 atomics (summation order, hence the last bit, not deterministic -- as in
+ * ATen's upsample_bilinear2d_backward).  ptb_ms_deaug_reduce_bwd: gradient of ptb_ms_deaug_reduce w.r.t. every scale's map;
+ * fwd_out = the forward result (needed by the non-linear reductions, may be NULL for sum / mean). */
+int ptb_resize_bilinear_bwd(const float* grad_out, float* grad_in, int64_t planes, int hin, int win, int hout, int wout,
+                            int align_corners, ptb_stream_t stream);
+int ptb_ms_deaug_reduce_bwd(const float* const* inputs, const int* hs, const int* ws, int n, const float* fwd_out, const float* grad_out,
+                            float* const* grad_inputs, int64_t planes, int hout, int wout, int align_corners, int reduction,
+                            ptb_stream_t stream);
+
+/* F.interpolate(x, size, mode="nearest") for [planes, hin, win] -> [planes, hout, wout] (multiscale TTA with mode="nearest",
+ * inference/tta.py:599-621, 645-689): out[p, y, x] = in[p, min(floor(y * hin / hout), hin - 1), min(floor(x * win / wout), win - 1)].
+ * backward != 0: `in` is grad_out [planes, hout, wout] and `out` the ZEROED grad_in [planes, hin, win] (atomic adds). */
+int ptb_resize_nearest(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
+                       ptb_stream_t stream);
+
+/* Multiscale + flip TTA in one pass (BASELINE configs[4]; extension): inputs[s] = the model output for the flip-augmented batch
+ * of scale s, [V * B, C, hs[s], ws[s]] chunk-major (view v of plane p at (v * planes + p) * hs * ws; planes = B * C),
+ *   out = reduction_s( bilinear_s( inner_reduction_v( view_v^-1( inputs[s][v] ) ) ) )
+ * == ms_image_deaugment([<group>_image_deaugment(y_s, inner_reduction) for s], ...) (inference/tta.py:287-316, 344-365, 503-524 then
+ * :645-689) without the flip-reduced maps ever reaching HBM.  views[V] = the group's INVERSE view codes (row-preserving only:
+ * PTB_VIEW_IDENT / FLIPLR / FLIPUD / ROT180).  Returns PTB_EUNSUPPORTED for transposing views, widths not divisible by 4, or a
+ * scale ratio above ~1.3 (source window of a 64 x 64 tile larger than 88 x 96): the caller then composes the two entry points. */
+int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, int V, const int* views,
+                             int inner_reduction, float* out, int64_t planes, int hout, int wout, int align_corners, int reduction,
+                             ptb_stream_t stream);
+
 /* ================================= segmentation losses (pytorch_toolbelt.losses) =================================
  * logits [B, C, HW] fp32; targets are either labels int64 [B, HW] (one-hot is formed on the fly, never materialised)
  * or dense fp32 [B, C, HW]; exactly one of `labels` / `dense` is non-NULL.  Scalars are accumulated in fp64.

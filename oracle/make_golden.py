@@ -580,6 +580,54 @@ def gen_losses3():
     save("losses3.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- multiscale: nearest + gradients
+def gen_tta2():
+    """ms_image_augment / ms_image_deaugment of the unmodified reference with mode="nearest", and autograd gradients through the
+    bilinear and nearest paths (inference/tta.py:599-621, 645-689; "TTA respects gradient flow", tta.py:3-4)."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(41)
+    x = torch.rand((2, 3, 24, 36), generator=g) * 0.9 + 0.05
+    A["x"] = t2n(x)
+    offsets = [-8, 0, 12, (4, -4)]
+    for mode, ac in (("bilinear", False), ("bilinear", True), ("nearest", None)):
+        xin = x.clone().requires_grad_(True)
+        outs = rtta.ms_image_augment(xin, offsets, mode=mode, align_corners=ac)
+        tot = sum((o * (torch.arange(o.numel(), dtype=torch.float32).reshape(o.shape) % 5 + 1.0)).sum() for o in outs)
+        tot.backward()
+        key = f"aug_{mode}_{ac}"
+        for i, o in enumerate(outs):
+            A[f"{key}_{i}"] = t2n(o)
+        A[f"{key}_grad"] = t2n(xin.grad)
+        cases.append(dict(name=key, fn="ms_image_augment_grad", kwargs=dict(size_offsets=[list(o) if isinstance(o, tuple) else o for o in offsets], mode=mode, align_corners=ac)))
+    # de-augment: maps of the augmented sizes back to 24 x 36
+    fmaps = [torch.rand((2, 3, 24 + (o[0] if isinstance(o, tuple) else o), 36 + (o[1] if isinstance(o, tuple) else o)), generator=g) * 0.9 + 0.05 for o in offsets]
+    for i, f in enumerate(fmaps):
+        A[f"fm_{i}"] = t2n(f)
+    for mode, ac in (("bilinear", False), ("bilinear", True), ("nearest", None)):
+        for red in ("mean", "sum", "gmean", "hmean", "harmonic1p", "logodd", "log1p"):
+            ins = [f.clone().requires_grad_(True) for f in fmaps]
+            out = rtta.ms_image_deaugment(ins, offsets, reduction=red, mode=mode, align_corners=ac)
+            (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 7 + 1.0)).sum().backward()
+            key = f"deaug_{mode}_{ac}_{red}"
+            A[key] = t2n(out)
+            for i, t in enumerate(ins):
+                A[f"{key}_grad_{i}"] = t2n(t.grad)
+            cases.append(dict(name=key, fn="ms_image_deaugment_grad", kwargs=dict(size_offsets=[list(o) if isinstance(o, tuple) else o for o in offsets], mode=mode, align_corners=ac, reduction=red)))
+    # flips inside every scale (what ms_flips_image_deaugment fuses): fliplr / d2 / flips groups, inner and outer reductions
+    for group, V in (("fliplr", 2), ("flipud", 2), ("flips", 3), ("d2", 4)):
+        ys = [torch.rand((V * 2, 3, f.shape[2], f.shape[3]), generator=g) * 0.9 + 0.05 for f in fmaps]
+        for i, y in enumerate(ys):
+            A[f"fz_{group}_y{i}"] = t2n(y)
+        deaug = getattr(rtta, f"{group}_image_deaugment")
+        for inner, outer, ac in (("mean", "mean", True), ("gmean", "gmean", False), ("mean", "gmean", True), ("hmean", "sum", False)):
+            out = rtta.ms_image_deaugment([deaug(y, reduction=inner) for y in ys], offsets, reduction=outer, mode="bilinear", align_corners=ac)
+            key = f"fz_{group}_{inner}_{outer}_{int(ac)}"
+            A[key] = t2n(out)
+            cases.append(dict(name=key, fn="ms_flips_image_deaugment", kwargs=dict(group=group, inner_reduction=inner, reduction=outer, align_corners=ac,
+                                                                                     size_offsets=[list(o) if isinstance(o, tuple) else o for o in offsets])))
+    save("tta2.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -785,5 +833,6 @@ if __name__ == "__main__":
     gen_losses2()
     gen_losses3()
     gen_losses4()
+    gen_tta2()
     gen_volumes()
     gen_fullsize()

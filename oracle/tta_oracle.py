@@ -212,20 +212,37 @@ def bilinear_resize(x, size, align_corners):
     return top * (one - lr)[:, None] + bot * lr[:, None]
 
 
-def ms_image_augment(x, size_offsets, align_corners=False):
-    """tta.py:599-621 (bilinear): offsets are pixel deltas; 0 -> the input itself."""
+def nearest_resize(x, size):
+    """F.interpolate(x, size=size, mode='nearest') on [B,C,H,W] numpy: src = min(floor(dst * in / out), in - 1), the scale and the
+    product evaluated in float32 (aten UpSample.h nearest_neighbor_compute_source_index)."""
+    def idx(n_in, n_out):
+        scale = np.float32(n_in / n_out)
+        return np.minimum(np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64), n_in - 1)
+    return x[:, :, idx(x.shape[2], size[0])][:, :, :, idx(x.shape[3], size[1])]
+
+
+def _resize(x, size, mode, align_corners):
+    if mode == "nearest":
+        if align_corners is not None:
+            raise ValueError("align_corners option can only be set with the interpolating modes")
+        return nearest_resize(x, size)
+    return bilinear_resize(x, size, bool(align_corners))
+
+
+def ms_image_augment(x, size_offsets, align_corners=False, mode="bilinear"):
+    """tta.py:599-621: offsets are pixel deltas; 0 -> the input itself."""
     out = []
     for off in size_offsets:
         ro, co = _offsets(off)
         if ro == 0 and co == 0:
             out.append(x)
         else:
-            out.append(bilinear_resize(x, (x.shape[2] + ro, x.shape[3] + co), align_corners))
+            out.append(_resize(x, (x.shape[2] + ro, x.shape[3] + co), mode, align_corners))
     return out
 
 
-def ms_image_deaugment(images, size_offsets, reduction="mean", align_corners=True, stride=1):
-    """tta.py:645-689 (bilinear): resize each map back to rows - off//stride (Python floor division, quirk Q3)."""
+def ms_image_deaugment(images, size_offsets, reduction="mean", align_corners=True, stride=1, mode="bilinear"):
+    """tta.py:645-689: resize each map back to rows - off//stride (Python floor division, quirk Q3)."""
     if len(images) != len(size_offsets):
         raise ValueError("Number of images must be equal to number of size offsets")
     back = []
@@ -235,5 +252,5 @@ def ms_image_deaugment(images, size_offsets, reduction="mean", align_corners=Tru
             back.append(fm)
         else:
             size = (fm.shape[2] - ro // stride, fm.shape[3] - co // stride)       # tta.py:682
-            back.append(bilinear_resize(fm, size, align_corners))
+            back.append(_resize(fm, size, mode, align_corners))
     return deaugment_averaging(np.stack(back), reduction)

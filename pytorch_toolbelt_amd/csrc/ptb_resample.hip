@@ -2,7 +2,9 @@
 // torch.nn.functional.interpolate(mode="bilinear")).  4-tap gather, HBM/L2-bound; index and weight arithmetic
 // follows ATen's area_pixel_compute_source_index / compute_source_index_and_lambda in fp32 so results match the
 // reference's torch kernels to rounding.
-#include "ptb_common.h"
+#include <algorithm>
+
+#include "ptb_view_device.h"
 
 namespace ptb {
 
@@ -265,6 +267,268 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
     else for (int m = 0; m < 4; ++m) if (ox + m < a.wout) o[m] = res[m];
 }
 
+// ---------------------------------------------------------------------------------------------- fused flips + multiscale
+// BASELINE configs[4]: every scale's model output is itself a flip-augmented batch [V*B, C, h_s, w_s] (tta.py:257-284,
+// 319-341, 470-484), de-augmented per scale (tta.py:287-316, 344-365, 503-524) and then merged over the scales
+// (tta.py:645-689).  As separate calls that is one pass per scale that writes the flip-reduced map and one more that reads it
+// back; here ONE launch reads every view of every scale once and writes the merged map once:
+//     out = outer_s( bilinear_s( inner_v( flip_v^-1( y_s[v] ) ) ) )
+// A workgroup owns a 64 x 64 output tile (the 64 x 16 tiles of ms_reduce_tiled_kernel refetch 1.21x the source bytes: halo rows /
+// columns and 16-byte alignment of every window; at 64 x 64 it is 1.08x).  Per resized scale the tile's source window
+// (<= 88 x 96) is brought in with 16-byte loads, 4 window rows x V views in flight per lane, mirrored views read at mirrored
+// addresses (a reversed row is still one contiguous segment); the inner reduction over the views happens ON THE WAY INTO LDS, so
+// the window holds flip-reduced values exactly like the reference's intermediate tensor and the 4-tap gathers never see the
+// views.  Scales that already have the output size are reduced straight from registers.  Only row-preserving views (flips
+// of rows / columns) -- the groups the reference combines with multiscale TTA.
+constexpr int FZ_T = 64, FZ_LR = 88, FZ_LC = 96, FZ_LP = 112, FZ_VMAX = 4;
+
+struct FzArgs {
+    const float* in[MS_MAX];           // view 0 of scale s: [planes, h, w]; view v lies v * planes * h * w elements further
+    int h[MS_MAX], w[MS_MAX];
+    float sh[MS_MAX], sw[MS_MAX];
+    int n, nviews, codes;              // codes: 3 bits per view (bit 1 = flip rows, bit 2 = flip columns; bit 0 must be 0)
+    int planes, hout, wout, align_corners, op_outer, op_inner;
+    float inner_div;
+};
+
+// 4 consecutive de-augmented values of view `code` of a [h, w] plane at (row, col) (col % 4 == 0, w % 4 == 0)
+__device__ __forceinline__ float4 fz_load(const float* __restrict__ plane, int h, int w, int row, int col, int code) {
+    const int r = (code & 2) ? h - 1 - row : row;
+    const int c = (code & 4) ? w - 4 - col : col;
+    const float4 t = ld16<true>(plane + (long long)r * w + c);
+    return (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
+}
+
+template <int NV, int INNER>
+__device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op, float div) {
+    float4 s;
+    if (INNER == 0) {
+        s = x[0];
+#pragma unroll
+        for (int k = 1; k < NV; ++k)
+            if (k < nv) { s.x = __fadd_rn(s.x, x[k].x); s.y = __fadd_rn(s.y, x[k].y); s.z = __fadd_rn(s.z, x[k].z); s.w = __fadd_rn(s.w, x[k].w); }
+        return make_float4(red_post<0>(s.x, op, div), red_post<0>(s.y, op, div), red_post<0>(s.z, op, div), red_post<0>(s.w, op, div));
+    }
+    if (INNER == 2) {   // gmean, branch-free (the run-time switch over all reductions costs more than the loads it sits between)
+        s = make_float4(fast_log(x[0].x), fast_log(x[0].y), fast_log(x[0].z), fast_log(x[0].w));
+#pragma unroll
+        for (int k = 1; k < NV; ++k)
+            if (k < nv) { s.x += fast_log(x[k].x); s.y += fast_log(x[k].y); s.z += fast_log(x[k].z); s.w += fast_log(x[k].w); }
+        const float inv = fast_rcp(div);
+        return make_float4(fast_exp(s.x * inv), fast_exp(s.y * inv), fast_exp(s.z * inv), fast_exp(s.w * inv));
+    }
+    s = make_float4(red_pre<1>(x[0].x, op), red_pre<1>(x[0].y, op), red_pre<1>(x[0].z, op), red_pre<1>(x[0].w, op));
+#pragma unroll
+    for (int k = 1; k < NV; ++k)
+        if (k < nv) {
+            s.x += red_pre<1>(x[k].x, op); s.y += red_pre<1>(x[k].y, op); s.z += red_pre<1>(x[k].z, op); s.w += red_pre<1>(x[k].w, op);
+        }
+    return make_float4(red_post<1>(s.x, op, div), red_post<1>(s.y, op, div), red_post<1>(s.z, op, div), red_post<1>(s.w, op, div));
+}
+
+template <int NV, int INNER, int OUTER, int ALIGN>
+__global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
+    constexpr int FZ_U = NV <= 2 ? 3 : 2;   // window slots a lane has in flight at once (x NV views)
+    __shared__ __attribute__((aligned(16))) float lds[FZ_LR * FZ_LP];
+    __shared__ __attribute__((aligned(16))) Taps ctap[FZ_T];
+    const int tiles_x = (a.wout + FZ_T - 1) / FZ_T, tiles_y = (a.hout + FZ_T - 1) / FZ_T;
+    int bid = blockIdx.x;
+    const int txi = bid % tiles_x;
+    bid /= tiles_x;
+    const int tyi = bid % tiles_y;
+    const long long p = bid / tiles_y;
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ox0 = txi * FZ_T, oy0 = tyi * FZ_T, ox = ox0 + 4 * lx;
+    const bool col_ok = ox < a.wout;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[j][m] = 0.f;
+    for (int s = 0; s < a.n; ++s) {
+        const int hin = a.h[s], win = a.w[s];
+        const long long plane_sz = (long long)hin * win, vstride = (long long)a.planes * plane_sz;
+        const float* src = a.in[s] + p * plane_sz;
+        float v[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) v[j][m] = 1.f;
+        if (hin == a.hout && win == a.wout) {
+            // same size: the reference skips F.interpolate (offset 0) -- reduce the views straight from registers
+            float4 xs[4][NV];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = oy0 + ly + 16 * j;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    xs[j][k] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (k < a.nviews && col_ok && oy < a.hout) xs[j][k] = fz_load(src + k * vstride, hin, win, oy, ox, (a.codes >> (3 * k)) & 7);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 r = fz_inner<NV, INNER>(xs[j], a.nviews, a.op_inner, a.inner_div);
+                v[j][0] = r.x; v[j][1] = r.y; v[j][2] = r.z; v[j][3] = r.w;
+            }
+        } else {
+            const int oy_last = min(oy0 + FZ_T, a.hout) - 1, ox_last = min(ox0 + FZ_T, a.wout) - 1;
+            const int r_lo = taps<ALIGN>(oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps<ALIGN>(oy_last, a.sh[s], hin, a.align_corners).i1;
+            const int c_lo = taps<ALIGN>(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps<ALIGN>(ox_last, a.sw[s], win, a.align_corners).i1;
+            const int nr = min(r_hi - r_lo + 1, FZ_LR), nc = min(c_hi - c_lo + 1, FZ_LC);   // (the host only launches shapes that fit)
+            // every lane takes 16-byte slots tid, tid + 256, ... of the window (row-major, q_per_row slots per row: all lanes busy,
+            // whatever the window width); FZ_U slots x V views are requested together
+            const int q_per_row = min((nc + 3) / 4, (win - c_lo + 3) / 4);
+            const int total = nr * q_per_row;
+            const unsigned recip = (65536u + q_per_row - 1) / q_per_row;      // slot / q_per_row == (slot * recip) >> 16 for slot < 2112
+            for (int s0 = tid; s0 < total; s0 += 256 * FZ_U) {
+                float4 x[FZ_U][NV];
+                int row[FZ_U], qq[FZ_U];
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u) {
+                    const int slot = s0 + 256 * u;
+                    row[u] = (int)(((unsigned)slot * recip) >> 16);
+                    qq[u] = slot - row[u] * q_per_row;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        x[u][k] = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (k < a.nviews && slot < total) x[u][k] = fz_load(src + k * vstride, hin, win, r_lo + row[u], c_lo + 4 * qq[u], (a.codes >> (3 * k)) & 7);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < FZ_U; ++u)
+                    if (s0 + 256 * u < total) *reinterpret_cast<float4*>(&lds[row[u] * FZ_LP + 4 * qq[u]]) = fz_inner<NV, INNER>(x[u], a.nviews, a.op_inner, a.inner_div);
+            }
+            if (tid < FZ_T) ctap[tid] = taps<ALIGN>(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
+            __syncthreads();
+            Taps tx[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) tx[m] = ctap[4 * lx + m];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = min(oy0 + ly + 16 * j, a.hout - 1);   // rows past the bottom edge: computed from the last row, never stored
+                const Taps ty = taps<ALIGN>(oy, a.sh[s], hin, a.align_corners);
+                const float* l0 = lds + min(ty.i0 - r_lo, FZ_LR - 1) * FZ_LP - c_lo;
+                const float* l1 = lds + min(ty.i1 - r_lo, FZ_LR - 1) * FZ_LP - c_lo;
+                float t[4][4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { t[m][0] = l0[tx[m].i0]; t[m][1] = l0[tx[m].i1]; t[m][2] = l1[tx[m].i0]; t[m][3] = l1[tx[m].i1]; }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    v[j][m] = ty.l0 * (tx[m].l0 * t[m][0] + tx[m].l1 * t[m][1]) + ty.l1 * (tx[m].l0 * t[m][2] + tx[m].l1 * t[m][3]);
+            }
+            __syncthreads();  // the next scale reuses the LDS window
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float t = OUTER == 0 ? v[j][m] : (OUTER == 2 ? ms_log(v[j][m]) : ms_pre(v[j][m], a.op_outer));
+                acc[j][m] = s ? acc[j][m] + t : t;
+            }
+    }
+    if (!col_ok) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int oy = oy0 + ly + 16 * j;
+        if (oy < a.hout) {
+            float r[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) r[m] = OUTER == 2 ? ms_exp(acc[j][m] / (float)a.n) : ms_post(acc[j][m], a.op_outer, (float)a.n);
+            *reinterpret_cast<float4*>(out + (p * a.hout + oy) * (long long)a.wout + ox) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- nearest + backward passes
+// TTA "respects gradient flow" (tta.py:3-4): the adjoints of the resize kernels.  A bilinear output pixel reads 4 taps, so its
+// gradient is added to 4 source pixels; several output pixels share a source pixel, hence fp32 atomics (global_atomic_add_f32,
+// like ATen's upsample_bilinear2d_backward -- the summation order, and with it the last bit, is not deterministic).
+__global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, int planes, int hin,
+                                                                  int win, int hout, int wout, float sh, float sw, int align_corners) {
+    const long long total = (long long)planes * hout * wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % wout);
+        const long long rest = idx / wout;
+        const int oy = (int)(rest % hout);
+        const long long p = rest / hout;
+        const Taps ty = taps(oy, sh, hin, align_corners), tx = taps(ox, sw, win, align_corners);
+        const float g = gout[idx];
+        float* r0 = gin + (p * hin + ty.i0) * (long long)win;
+        float* r1 = gin + (p * hin + ty.i1) * (long long)win;
+        atomicAdd(r0 + tx.i0, g * ty.l0 * tx.l0);
+        atomicAdd(r0 + tx.i1, g * ty.l0 * tx.l1);
+        atomicAdd(r1 + tx.i0, g * ty.l1 * tx.l0);
+        atomicAdd(r1 + tx.i1, g * ty.l1 * tx.l1);
+    }
+}
+
+// F.interpolate(mode="nearest"): src = min(floor(dst * in / out), in - 1) (ATen nearest_neighbor_compute_source_index)
+__device__ __forceinline__ int nearest_src(int dst, float scale, int n_in) { return min((int)floorf((float)dst * scale), n_in - 1); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int hin, int win,
+                                                             int hout, int wout, float sh, float sw) {
+    // forward: out[p, oy, ox] = in[p, sy, sx];  BWD: `in` = grad_out [planes, hout, wout], `out` = grad_in [planes, hin, win] (zeroed)
+    const long long total = (long long)planes * hout * wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % wout);
+        const long long rest = idx / wout;
+        const int oy = (int)(rest % hout);
+        const long long p = rest / hout;
+        const long long src = (p * hin + nearest_src(oy, sh, hin)) * (long long)win + nearest_src(ox, sw, win);
+        if (BWD) atomicAdd(out + src, in[idx]);
+        else out[idx] = in[src];
+    }
+}
+
+// backward of ms_deaug_reduce: out = post(sum_s pre(v_s) / n), v_s = bilinear_s(x_s) (or x_s itself at the output size):
+//   d out / d x_s[tap] = g * post'(out) / n * pre'(v_s) * tap weight      (linear reductions: g / n, or g for "sum")
+struct MsGrads { float* g[MS_MAX]; };   // (kernel argument: the unrolled scale loop indexes it with compile-time constants)
+
+__global__ __launch_bounds__(256) void ms_reduce_bwd_kernel(const MsArgs a, const float* __restrict__ fwd_out, const float* __restrict__ gout,
+                                                            const MsGrads gin_) {
+    float* const* gin = gin_.g;
+    const long long total = (long long)a.planes * a.hout * a.wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const bool nonlin = a.op >= PTB_RED_GMEAN;
+    const float inv_n = a.op == PTB_RED_SUM ? 1.0f : 1.0f / (float)a.n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % a.wout);
+        const long long rest = idx / a.wout;
+        const int oy = (int)(rest % a.hout);
+        const long long p = rest / a.hout;
+        float g = gout[idx] * inv_n;
+        if (nonlin) g *= red_dpost(fwd_out[idx], a.op);
+#pragma unroll
+        for (int s = 0; s < MS_MAX; ++s) {
+            if (s >= a.n) break;
+            const int hin = a.h[s], win = a.w[s];
+            const float* src = a.in[s] + p * (long long)hin * win;
+            float* dst = gin[s] + p * (long long)hin * win;
+            if (hin == a.hout && win == a.wout) {
+                const long long o = (long long)oy * win + ox;
+                dst[o] = nonlin ? g * red_dpre(src[o], a.op) : g;      // every source pixel is hit exactly once
+            } else {
+                const Taps ty = taps(oy, a.sh[s], hin, a.align_corners), tx = taps(ox, a.sw[s], win, a.align_corners);
+                const long long o00 = (long long)ty.i0 * win + tx.i0, o01 = (long long)ty.i0 * win + tx.i1;
+                const long long o10 = (long long)ty.i1 * win + tx.i0, o11 = (long long)ty.i1 * win + tx.i1;
+                float c = g;
+                if (nonlin) {
+                    const float v = ty.l0 * (tx.l0 * src[o00] + tx.l1 * src[o01]) + ty.l1 * (tx.l0 * src[o10] + tx.l1 * src[o11]);
+                    c *= red_dpre(v, a.op);
+                }
+                atomicAdd(dst + o00, c * ty.l0 * tx.l0);
+                atomicAdd(dst + o01, c * ty.l0 * tx.l1);
+                atomicAdd(dst + o10, c * ty.l1 * tx.l0);
+                atomicAdd(dst + o11, c * ty.l1 * tx.l1);
+            }
+        }
+    }
+}
+
 }  // namespace ptb
 
 using namespace ptb;
@@ -346,4 +610,119 @@ extern "C" int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* 
     if (!src_row0 || !src_rows) return PTB_EINVAL;
     return ms_reduce_impl(inputs, hs_full, ws, src_row0, src_rows, n, out, planes, hout_full, wout, out_row0, out_rows, align_corners,
                           reduction, stream);
+}
+
+template <int NV, int INNER>
+static void launch_fz(const FzArgs& a, float* out, unsigned blocks, hipStream_t st) {
+    const dim3 grid(blocks), block(256);
+#define PTB_FZ(OUTER) do { if (a.align_corners) hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 1>), grid, block, 0, st, a, out); \
+                           else hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 0>), grid, block, 0, st, a, out); } while (0)
+    if (a.op_outer == PTB_RED_GMEAN) PTB_FZ(2);
+    else if (a.op_outer >= PTB_RED_GMEAN) PTB_FZ(1);
+    else PTB_FZ(0);
+#undef PTB_FZ
+}
+
+extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, int V, const int* views,
+                                        int inner_reduction, float* out, int64_t planes, int hout, int wout, int align_corners,
+                                        int reduction, ptb_stream_t stream) {
+    if (!inputs || !hs || !ws || !out || !views || n < 1 || n > MS_MAX || V < 1 || V > FZ_VMAX || planes < 0 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || inner_reduction < PTB_RED_SUM || inner_reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    FzArgs a{};
+    for (int k = 0; k < V; ++k) {
+        if (views[k] < 0 || views[k] > 7) return PTB_EINVAL;
+        if (views[k] & 1) return PTB_EUNSUPPORTED;           // transposing views: not combined with multiscale here
+        a.codes |= (views[k] & 7) << (3 * k);
+    }
+    if (g_force_scalar || wout % 4 || !aligned16(out)) return PTB_EUNSUPPORTED;
+    for (int s = 0; s < n; ++s) {
+        if (!inputs[s] || hs[s] < 1 || ws[s] < 1) return PTB_EINVAL;
+        if (ws[s] % 4 || !aligned16(inputs[s])) return PTB_EUNSUPPORTED;
+        a.in[s] = inputs[s]; a.h[s] = hs[s]; a.w[s] = ws[s];
+        if (align_corners) {
+            a.sh[s] = hout > 1 ? (float)(hs[s] - 1) / (float)(hout - 1) : 0.f;
+            a.sw[s] = wout > 1 ? (float)(ws[s] - 1) / (float)(wout - 1) : 0.f;
+        } else {
+            a.sh[s] = (float)hs[s] / (float)hout;
+            a.sw[s] = (float)ws[s] / (float)wout;
+        }
+        if (hs[s] == hout && ws[s] == wout) continue;
+        // the source window of a 64 x 64 tile must fit the LDS window (conservative bounds: + 2 taps, + 3 alignment, + 1 rounding)
+        // (a window never exceeds the map itself, so small maps fit whatever the ratio)
+        const int need_r = std::min((int)ceilf(FZ_T * a.sh[s]) + 3, hs[s]), need_c = std::min((int)ceilf(FZ_T * a.sw[s]) + 6, ws[s] + 3);
+        if (need_r > FZ_LR || need_c > FZ_LC) return PTB_EUNSUPPORTED;
+    }
+    a.n = n; a.nviews = V; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners;
+    a.op_outer = reduction; a.op_inner = inner_reduction;
+    a.inner_div = inner_reduction == PTB_RED_SUM ? 1.0f : (float)V;
+    const long long tiles = planes * ((hout + FZ_T - 1) / FZ_T) * ((wout + FZ_T - 1) / FZ_T);
+    if (tiles > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int inner = inner_reduction == PTB_RED_GMEAN ? 2 : (inner_reduction > PTB_RED_GMEAN ? 1 : 0);
+    if (V == 1) launch_fz<1, 0>(a, out, (unsigned)tiles, st);
+    else if (V == 2) { if (inner == 2) launch_fz<2, 2>(a, out, (unsigned)tiles, st); else if (inner) launch_fz<2, 1>(a, out, (unsigned)tiles, st); else launch_fz<2, 0>(a, out, (unsigned)tiles, st); }
+    else { if (inner == 2) launch_fz<4, 2>(a, out, (unsigned)tiles, st); else if (inner) launch_fz<4, 1>(a, out, (unsigned)tiles, st); else launch_fz<4, 0>(a, out, (unsigned)tiles, st); }
+    return check_launch();
+}
+
+static int grid_1d(long long total) {
+    const long long want = (total + 255) / 256;
+    return (int)(want < 1 ? 1 : (want < 256 * 32 ? want : 256 * 32));
+}
+
+static void resize_scales(int hin, int win, int hout, int wout, int align_corners, float& sh, float& sw) {
+    if (align_corners) {
+        sh = hout > 1 ? (float)(hin - 1) / (float)(hout - 1) : 0.f;
+        sw = wout > 1 ? (float)(win - 1) / (float)(wout - 1) : 0.f;
+    } else {
+        sh = (float)hin / (float)hout;
+        sw = (float)win / (float)wout;
+    }
+}
+
+extern "C" int ptb_resize_bilinear_bwd(const float* grad_out, float* grad_in, int64_t planes, int hin, int win, int hout, int wout,
+                                       int align_corners, ptb_stream_t stream) {
+    if (!grad_out || !grad_in || planes < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    float sh, sw;
+    resize_scales(hin, win, hout, wout, align_corners, sh, sw);
+    hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(grid_1d(planes * hout * wout)), dim3(256), 0, (hipStream_t)stream, grad_out, grad_in,
+                       (int)planes, hin, win, hout, wout, sh, sw, align_corners);
+    return check_launch();
+}
+
+extern "C" int ptb_resize_nearest(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
+                                  ptb_stream_t stream) {
+    if (!in || !out || planes < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+    const dim3 grid(grid_1d(planes * hout * wout)), block(256);
+    if (backward) hipLaunchKernelGGL(resize_nearest_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    else hipLaunchKernelGGL(resize_nearest_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    return check_launch();
+}
+
+extern "C" int ptb_ms_deaug_reduce_bwd(const float* const* inputs, const int* hs, const int* ws, int n, const float* fwd_out,
+                                       const float* grad_out, float* const* grad_inputs, int64_t planes, int hout, int wout,
+                                       int align_corners, int reduction, ptb_stream_t stream) {
+    if (!inputs || !hs || !ws || !grad_out || !grad_inputs || n < 1 || n > MS_MAX || planes < 0 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P) return PTB_EINVAL;
+    if (reduction >= PTB_RED_GMEAN && !fwd_out) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    MsArgs a{};
+    MsGrads g{};
+    for (int s = 0; s < n; ++s) {
+        if (!inputs[s] || !grad_inputs[s] || hs[s] < 1 || ws[s] < 1) return PTB_EINVAL;
+        a.in[s] = inputs[s]; a.h[s] = hs[s]; a.w[s] = ws[s]; a.hfull[s] = hs[s];
+        resize_scales(hs[s], ws[s], hout, wout, align_corners, a.sh[s], a.sw[s]);
+        g.g[s] = grad_inputs[s];
+    }
+    a.n = n; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners; a.op = reduction; a.hout_full = hout;
+    hipLaunchKernelGGL(ms_reduce_bwd_kernel, dim3(grid_1d(planes * hout * wout)), dim3(256), 0, (hipStream_t)stream, a, fwd_out, grad_out, g);
+    return check_launch();
 }

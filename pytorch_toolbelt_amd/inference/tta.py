@@ -50,6 +50,7 @@ __all__ = [
     "ms_image_augment",
     "ms_labels_augment",
     "ms_image_deaugment",
+    "ms_flips_image_deaugment",
     "tencrop_image2label",
 ]
 
@@ -336,7 +337,7 @@ def ms_image_deaugment(images: List[Tensor], size_offsets: List[Union[int, Tuple
         for fmap, offset in zip(images, size_offsets):
             dr, dc = _offset_pair(offset)
             sizes.add((fmap.size(2) - dr // stride, fmap.size(3) - dc // stride) if (dr != 0 or dc != 0) else (fmap.size(2), fmap.size(3)))
-        if len(sizes) == 1 and not any(t.requires_grad for t in images):
+        if len(sizes) == 1:
             from . import _resample
 
             return _resample.ms_reduce(list(images), sizes.pop(), align_corners, code)
@@ -349,6 +350,37 @@ def ms_image_deaugment(images: List[Tensor], size_offsets: List[Union[int, Tuple
             size = fmap.size(2) - dr // stride, fmap.size(3) - dc // stride
             restored.append(_resize(fmap, size, mode, align_corners))
     return _deaugment_averaging(torch.stack(restored), reduction=reduction)
+
+
+def ms_flips_image_deaugment(images: List[Tensor], size_offsets: List[Union[int, Tuple[int, int]]], group: str = "fliplr",
+                             inner_reduction: MaybeStrOrCallable = "mean", reduction: MaybeStrOrCallable = "mean", mode: str = "bilinear",
+                             align_corners: bool = True, stride: int = 1) -> Tensor:
+    """Extension (BASELINE configs[4]): multiscale TTA whose every scale is itself flip-augmented, merged in ONE pass.
+
+    ``images[s]`` is the model output for the ``<group>_image_augment``-ed input of scale ``s`` (``[V*B, C, h_s, w_s]``,
+    chunk-major).  Equals ``ms_image_deaugment([<group>_image_deaugment(y, inner_reduction) for y in images], size_offsets,
+    reduction, mode, align_corners, stride)`` -- which is also what runs whenever the fused kernel does not take the
+    configuration (transposing groups, callables, non-bilinear modes, autograd, widths not divisible by 4)."""
+    if group not in DEAUGMENT_VIEWS:
+        raise KeyError(group)
+    if len(images) != len(size_offsets):
+        raise ValueError("Number of images must be equal to number of size offsets")
+    views = DEAUGMENT_VIEWS[group]
+    inner, outer = _reduction_code(inner_reduction), _reduction_code(reduction)
+    if (inner is not None and outer is not None and mode == "bilinear" and 1 <= len(images) <= 8
+            and not (torch.is_grad_enabled() and any(t.requires_grad for t in images))):
+        sizes = set()
+        for fmap, offset in zip(images, size_offsets):
+            dr, dc = _offset_pair(offset)
+            sizes.add((fmap.size(2) - dr // stride, fmap.size(3) - dc // stride) if (dr != 0 or dc != 0) else (fmap.size(2), fmap.size(3)))
+        if len(sizes) == 1:
+            from . import _resample
+
+            out = _resample.ms_flip_reduce(list(images), views, sizes.pop(), align_corners, inner, outer)
+            if out is not None:
+                return out
+    per_scale = [_image_deaugment(y, group, inner_reduction) for y in images]
+    return ms_image_deaugment(per_scale, size_offsets, reduction=reduction, mode=mode, align_corners=align_corners, stride=stride)
 
 
 def _resize(x: Tensor, size, mode, align_corners):

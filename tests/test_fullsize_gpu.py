@@ -154,3 +154,13 @@ def test_cfg5_multiscale_fliplr_gmean_4096(dev, full, align_corners):
     want = AO.ms_image_deaugment([AO.image_deaugment(y.cpu().numpy(), "fliplr", "gmean") for y in ys], offs, "gmean", align_corners)
     err = float(np.abs(got - want).max())
     assert err <= TOL, f"max|diff| vs the oracle over all 4x4096x4096 values = {err}"
+    # the one-pass kernel (every view of every scale read once, the flip-reduced maps never reach HBM): same reference, same oracle
+    from pytorch_toolbelt_amd import _native as N
+
+    before = N.calls
+    fused = tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction="gmean", reduction="gmean", align_corners=align_corners)
+    assert N.calls == before + 1, "the fused flips + multiscale kernel did not run"
+    fz = fused.cpu().numpy()
+    _digest_check(full, f"cfg5_ac{int(align_corners)}", fz)
+    err = float(np.abs(fz - want).max())
+    assert err <= TOL, f"fused pass: max|diff| vs the oracle over all 4x4096x4096 values = {err}"

@@ -371,3 +371,28 @@ def test_focal_softmax_activation_oracle(case):
     fn = LO.binary_focal_loss if case["fn"] == "focal_softmax_module" else LO.focal_loss_with_logits
     out = fn(x, t, activation="softmax", **kw)
     np.testing.assert_allclose(out, GL4[case["output"]], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ multiscale: nearest mode, flips inside every scale
+GT2 = load_golden("tta2.npz")
+
+
+def _offs(kw):
+    return [tuple(o) if isinstance(o, list) else o for o in kw["size_offsets"]]
+
+
+@pytest.mark.parametrize("case", GT2.cases, ids=lambda c: c["name"])
+def test_multiscale_modes_and_flip_composition_oracle(case):
+    kw = case["kwargs"]
+    offs = _offs(kw)
+    if case["fn"] == "ms_image_augment_grad":
+        outs = AO.ms_image_augment(GT2["x"], offs, kw["align_corners"], mode=kw["mode"])
+        for i, o in enumerate(outs):
+            np.testing.assert_allclose(o, GT2[f"{case['name']}_{i}"], rtol=1e-5, atol=1e-6)
+    elif case["fn"] == "ms_image_deaugment_grad":
+        out = AO.ms_image_deaugment([GT2[f"fm_{i}"] for i in range(len(offs))], offs, kw["reduction"], kw["align_corners"], mode=kw["mode"])
+        np.testing.assert_allclose(out, GT2[case["name"]], rtol=1e-5, atol=1e-6)
+    else:
+        ys = [GT2[f"fz_{kw['group']}_y{i}"] for i in range(len(offs))]
+        out = AO.ms_image_deaugment([AO.image_deaugment(y, kw["group"], kw["inner_reduction"]) for y in ys], offs, kw["reduction"], kw["align_corners"])
+        np.testing.assert_allclose(out, GT2[case["name"]], rtol=1e-5, atol=1e-6)

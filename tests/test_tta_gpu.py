@@ -331,3 +331,83 @@ def test_multiscale_row_strips_equal_the_full_result(world, align_corners, reduc
             assert 0 <= s0 < s1 <= h and s1 - s0 < h or world == 1 or h <= 40
         pieces.append(ms_image_deaugment_strip(strips, heights, entry["src"], entry["out"], (H, W), reduction, align_corners))
     assert torch.equal(torch.cat(pieces, dim=2), full)
+
+
+# ------------------------------------------------------------------ multiscale: nearest mode, gradients, flips fused per scale
+GT2 = load_golden("tta2.npz")
+
+
+def _offs2(kw):
+    return [tuple(o) if isinstance(o, list) else o for o in kw["size_offsets"]]
+
+
+@pytest.mark.parametrize("case", GT2.by_fn("ms_image_augment_grad"), ids=lambda c: c["name"])
+def test_ms_image_augment_values_and_gradients(case, dev):
+    """ms_image_augment (bilinear both align_corners, nearest) against the unmodified reference: every scale's values and
+    the autograd gradient w.r.t. the input (adjoint resize kernels: 'TTA respects gradient flow', tta.py:3-4)."""
+    tta = _tta()
+    kw = case["kwargs"]
+    x = torch.from_numpy(GT2["x"]).to(dev).requires_grad_(True)
+    outs = tta.ms_image_augment(x, _offs2(kw), mode=kw["mode"], align_corners=kw["align_corners"])
+    tot = 0
+    for i, o in enumerate(outs):
+        np.testing.assert_allclose(o.detach().cpu().numpy(), GT2[f"{case['name']}_{i}"], rtol=1e-5, atol=1e-6)
+        tot = tot + (o * (torch.arange(o.numel(), dtype=torch.float32, device=dev).reshape(o.shape) % 5 + 1.0)).sum()
+    tot.backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), GT2[case["name"] + "_grad"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", GT2.by_fn("ms_image_deaugment_grad"), ids=lambda c: c["name"])
+def test_ms_image_deaugment_values_and_gradients(case, dev):
+    tta = _tta()
+    kw = case["kwargs"]
+    offs = _offs2(kw)
+    ins = [torch.from_numpy(GT2[f"fm_{i}"]).to(dev).requires_grad_(True) for i in range(len(offs))]
+    out = tta.ms_image_deaugment(ins, offs, reduction=kw["reduction"], mode=kw["mode"], align_corners=kw["align_corners"])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), GT2[case["name"]], rtol=1e-5, atol=1e-5)
+    (out * (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % 7 + 1.0)).sum().backward()
+    for i, t in enumerate(ins):
+        np.testing.assert_allclose(t.grad.cpu().numpy(), GT2[f"{case['name']}_grad_{i}"], rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("case", GT2.by_fn("ms_flips_image_deaugment"), ids=lambda c: c["name"])
+def test_ms_flips_image_deaugment_matches_reference_composition(case, dev):
+    """The one-pass flips + multiscale merge (extension) equals the reference's composition ms_image_deaugment([<group>_image_
+    deaugment(y) ...]) -- here on odd sizes (36 columns: the fused kernel takes them; (4, -4) offsets: mixed ratios)."""
+    from pytorch_toolbelt_amd import _native as N
+
+    tta = _tta()
+    kw = case["kwargs"]
+    offs = _offs2(kw)
+    ys = [torch.from_numpy(GT2[f"fz_{kw['group']}_y{i}"]).to(dev) for i in range(len(offs))]
+    before = N.calls
+    out = tta.ms_flips_image_deaugment(ys, offs, group=kw["group"], inner_reduction=kw["inner_reduction"], reduction=kw["reduction"],
+                                       align_corners=kw["align_corners"])
+    assert N.calls == before + 1, "the fused one-pass kernel did not take this configuration"
+    np.testing.assert_allclose(out.cpu().numpy(), GT2[case["name"]], rtol=1e-5, atol=1e-5)
+
+
+def test_ms_flips_fused_equals_composition_at_scale(dev):
+    """1024 x 1024, scales 0.75 / 1.0 / 1.25, fliplr and d2: fused == composed (same kernels' arithmetic up to fp32 rounding),
+    fallbacks (d4: transposing views; callable reduction; autograd) still give the composed result."""
+    tta = _tta()
+    torch.manual_seed(5)
+    N_ = 1024
+    offs = [-N_ // 4, 0, N_ // 4]
+    for group, V in (("fliplr", 2), ("d2", 4)):
+        ys = [torch.rand((V, 4, N_ + o, N_ + o), device=dev) * 0.9 + 0.05 for o in offs]
+        for inner, outer, ac in (("gmean", "gmean", False), ("mean", "mean", True)):
+            fused = tta.ms_flips_image_deaugment(ys, offs, group=group, inner_reduction=inner, reduction=outer, align_corners=ac)
+            comp = tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac)
+            assert float((fused - comp).abs().max()) <= 2e-6
+    ys = [torch.rand((8, 2, 64 + o, 64 + o), device=dev) * 0.9 + 0.05 for o in (-16, 0, 16)]
+    comp = tta.ms_image_deaugment([tta.d4_image_deaugment(y) for y in ys], [-16, 0, 16])
+    assert torch.allclose(tta.ms_flips_image_deaugment(ys, [-16, 0, 16], group="d4"), comp)
+    yg = [y[:4].clone().requires_grad_(True) for y in ys]
+    out = tta.ms_flips_image_deaugment(yg, [-16, 0, 16], group="d2", inner_reduction="gmean", reduction="mean")
+    out.sum().backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in yg)
+    with pytest.raises(ValueError, match="align_corners"):
+        tta.ms_image_augment(ys[1], [8], mode="nearest", align_corners=False)       # F.interpolate's own rule
+    with pytest.raises(NotImplementedError):
+        tta.ms_image_augment(ys[1], [8], mode="bicubic")

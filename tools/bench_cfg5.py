@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4] on one GPU: multiscale TTA (0.75 / 1.0 / 1.25) + fliplr on 4096 x 4096, gmean merge, C = 4.
+Times the composed reference sequence (3 x fliplr_image_deaugment + ms_image_deaugment: 4 launches, the flip-reduced maps go
+through HBM) and the one-pass ms_flips_image_deaugment; algorithmic bytes = every model output read once + the
+merged map written once = 1 946 157 056 B."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_toolbelt_amd.inference import tta  # noqa: E402
+
+dev = torch.device("cuda:0")
+N_, C, V = 4096, 4, 2
+offs = [-N_ // 4, 0, N_ // 4]
+ys = [torch.rand((V, C, N_ + o, N_ + o), device=dev) * 0.9 + 0.05 for o in offs]
+alg = sum(y.numel() for y in ys) * 4 + C * N_ * N_ * 4
+
+
+def timeit(fn, n=20):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for inner, outer in (("gmean", "gmean"), ("mean", "mean")):
+    comp = timeit(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=False))
+    fused = timeit(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=inner, reduction=outer, align_corners=False))
+    print(f"cfg5 {inner}/{outer}: composed {comp:7.1f} us = {alg / comp / 1e6:5.2f} TB/s ({alg / comp / 8e6 * 100:4.1f} % of 8 TB/s) | "
+          f"fused one pass {fused:7.1f} us = {alg / fused / 1e6:5.2f} TB/s ({alg / fused / 8e6 * 100:4.1f} %)")
+maps = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
+plain = timeit(lambda: tta.ms_image_deaugment(maps, offs, reduction="gmean", align_corners=False))
+alg1 = sum(m.numel() for m in maps) * 4 + C * N_ * N_ * 4
+print(f"ms_image_deaugment alone (3 maps -> 1): {plain:7.1f} us = {alg1 / plain / 1e6:5.2f} TB/s of {alg1 / 1e6:.0f} MB")
