@@ -485,15 +485,18 @@ def main():
                              "TileMerger(crops=tiler.crops): the data-independent norm_mask is precomputed from the crop list (SURVEY 8d: "
                              "not compulsory traffic) and every block is divided by it in the launch that brings its last tile, so "
                              "merge() returns the finished [C,H',W'] map; " if (not sharded and planned) else
-                             ("ShardedTileMerger: every rank accumulates its tiles into a band, halo rectangles go point-to-point to "
-                              "the rank owning those rows, each rank divides its rows by the locally computed norm_mask; " if sharded
+                             ("ShardedTileMerger: every rank merges its tiles band by band straight from the model outputs (C band plan, no "
+                              "accumulator; rows shared with a neighbour hold partial sums), the partial-sum rectangles go point-to-point to "
+                              "the rank owning those rows, each rank adds what it received and divides those rows by the locally computed "
+                              "norm_mask; " if sharded
                               else "norm_mask built lazily from the crop log, merge() = one division pass; ")) +
                             "model forward excluded",
                 "tiles": n_tiles,
                 "batch_tiles": BATCH,
                 "merger": ("planned + deferred bands (crops= given, defer=True)" if (not sharded and deferred) else
                            "planned (crops= given, no merge pass)" if (not sharded and planned) else
-                           ("sharded, unplanned" if sharded else "unplanned (lazy norm_mask + merge pass)")),
+                           (("sharded, deferred bands" if getattr(merger, "_deferred", None) is not None else "sharded, incremental") if sharded
+                            else "unplanned (lazy norm_mask + merge pass)")),
                 "parallelism": "single GPU" if world == 1 else (f"{'tile ranges' if partition == 'tiles' else 'tile rows'} sharded over {world} ranks, RCCL p2p halo exchange"),
                 "fallback": fallback,
                 "host_issue_ms_per_step": round(host_ms, 4),

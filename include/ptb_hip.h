@@ -145,8 +145,10 @@ int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t str
  * ptb_band_plan_create: HOST-side planning from the n tile origins (xs, ys; every tile th x tw, in integration order) of an
  *   H x W merged map with C channels.  The rows between consecutive tile edges are bands; consecutive bands are grouped into
  *   launches of about rows_per_launch rows (at most 224 covering tiles each).  Bands lying completely inside rows
- *   [partial_lo, partial_hi) write the UN-normalised weighted sum instead of sum / norm (multi-GPU merger: rows whose sums are
- *   completed by a neighbouring rank; pass 0, 0 otherwise).  Returns the size in bytes of the device table the plan needs
+ *   [final_lo, final_hi) are normalised (sum / norm); all others write the UN-normalised weighted sum (multi-GPU merger: rows
+ *   whose sums are completed by, or belong to, a neighbouring rank; a single-GPU merger passes 0, H).  cuts [ncuts] (may be
+ *   NULL / 0): additional row positions (multiples of 4) that are band edges and launch-group boundaries, so that a caller can
+ *   have rows it must hand over early finished by their own launch.  Returns the size in bytes of the device table the plan needs
  *   (>= 0; *out receives the plan), PTB_EUNSUPPORTED when the geometry is off the 4-pixel grid / more than 4 tiles cover a pixel.
  * ptb_band_plan_upload: copies the work-item table into caller-provided device memory (64-byte aligned, the size create
  *   returned; the library never allocates device memory).  Once per plan.
@@ -164,7 +166,7 @@ int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t str
  * ptb_band_plan_reset: next image.  ptb_band_plan_state: tiles taken / launches issued for the current image. */
 typedef struct ptb_band_plan ptb_band_plan;
 int64_t ptb_band_plan_create(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
-                             int partial_lo, int partial_hi, ptb_band_plan** out);
+                             int final_lo, int final_hi, const int64_t* cuts, int ncuts, ptb_band_plan** out);
 int ptb_band_plan_upload(ptb_band_plan* plan, void* dev_table, ptb_stream_t stream);
 int ptb_band_plan_info(const ptb_band_plan* plan, int* n_groups, int* n_bands, int64_t* n_items, int64_t* last_group_of_tile,
                        int64_t* group_rows);

@@ -49,7 +49,7 @@ SIGNATURES = {
     "ptb_debug_plan": (_c_int, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _ip, _c_int]),
     "ptb_merge_div": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _vp]),
     "ptb_merge_band": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
-    "ptb_band_plan_create": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vpp]),
+    "ptb_band_plan_create": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _i64p, _c_int, _vpp]),
     "ptb_band_plan_upload": (_c_int, [_vp, _vp, _vp]),
     "ptb_band_plan_info": (_c_int, [_vp, _ip, _ip, _i64p, _i64p, _i64p]),
     "ptb_band_plan_reset": (_c_int, [_vp]),

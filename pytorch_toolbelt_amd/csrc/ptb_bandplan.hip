@@ -178,8 +178,9 @@ static int band_items(const ptb_band_plan& p, const std::vector<int>& cover, con
 }
 
 extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
-                                        int rows_per_launch, int partial_rows_lo, int partial_rows_hi, ptb_band_plan** out) {
-    if (!xs64 || !ys64 || !out || n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1) return PTB_EINVAL;
+                                        int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
+                                        ptb_band_plan** out) {
+    if (!xs64 || !ys64 || !out || n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || ncuts < 0 || (ncuts && !cuts)) return PTB_EINVAL;
     *out = nullptr;
     if (g_force_scalar || tw % 4 || th % 4 || W % 4 || tw > 32767 || th > 32767) return PTB_EUNSUPPORTED;
     ptb_band_plan* p = new ptb_band_plan();
@@ -191,6 +192,12 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
         if (xs64[t] % 4 || ys64[t] % 4) { delete p; return PTB_EUNSUPPORTED; }
         p->xs[t] = (int)xs64[t]; p->ys[t] = (int)ys64[t];
         edges.push_back(p->ys[t]); edges.push_back(p->ys[t] + th);
+    }
+    // caller-given row cuts (multi-GPU: ownership boundaries, rows other ranks also cover): band edges AND launch-group breaks
+    std::vector<int> breaks;
+    for (int k = 0; k < ncuts; ++k) {
+        if (cuts[k] % 4) { delete p; return PTB_EUNSUPPORTED; }
+        if (cuts[k] > 0 && cuts[k] < H) { edges.push_back((int)cuts[k]); breaks.push_back((int)cuts[k]); }
     }
     std::sort(edges.begin(), edges.end());
     edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
@@ -222,7 +229,8 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
             std::sort(merged_tiles.begin(), merged_tiles.end());
             merged_tiles.erase(std::unique(merged_tiles.begin(), merged_tiles.end()), merged_tiles.end());
             const bool first = bj == bi;
-            if (!first && ((int)merged_tiles.size() > PLAN_TILES || (bands[bj].y1 - g.y0 > target && !tiles.empty()))) break;
+            if (!first && ((int)merged_tiles.size() > PLAN_TILES || (bands[bj].y1 - g.y0 > target && !tiles.empty()) ||
+                           std::find(breaks.begin(), breaks.end(), bands[bj].y0) != breaks.end())) break;
             tiles.swap(merged_tiles);
             ++bj;
         }
@@ -234,7 +242,7 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
         g.item_off = (long long)p->items.size();
         std::vector<BandItem> its;
         for (size_t b = bi; b < bj; ++b) {
-            const int partial = (bands[b].y0 >= partial_rows_lo && bands[b].y1 <= partial_rows_hi) ? 1 : 0;
+            const int partial = (bands[b].y0 >= final_lo && bands[b].y1 <= final_hi) ? 0 : 1;
             const int rc = band_items(*p, bands[b].cover, slot_of, bands[b].y0, bands[b].y1, partial, its);
             if (rc != PTB_OK) { delete p; return rc; }
         }

@@ -387,7 +387,7 @@ class _Bands:
         handle = ctypes.c_void_p()
         n = plan.xy.shape[1]
         nbytes = lib.ptb_band_plan_create(plan.xy[0].ctypes.data_as(N._i64p), plan.xy[1].ctypes.data_as(N._i64p), n, channels, th, tw, H, W,
-                                          int(rows), 0, 0, ctypes.byref(handle))
+                                          int(rows), 0, H, None, 0, ctypes.byref(handle))
         if nbytes < 0:
             return None
         table = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
+__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
            "ms_image_deaugment_strip"]
 
 
@@ -145,6 +145,157 @@ class _HipOps:
         N.check(rc, "ptb_rect_add")
 
 
+def deferred_geometry(plan, rank: int, crops: np.ndarray, image_height: int):
+    """Rows of rank ``rank``'s band it can finish on its own, and where its band plan has to cut.
+
+    Returns ``(final, cuts)`` in ABSOLUTE rows: ``final = (f0, f1)`` = the longest run of rows of the rank's band that no other
+    rank's tile touches, clipped to the rows the rank owns (there the kernels write ``sum / norm`` straight away; everywhere else
+    they leave un-normalised partial sums that are exchanged and / or completed in ``merge()``); ``cuts`` = row positions
+    that must be band edges and launch boundaries: the ends of ``final``, of the owned rows and of every send / receive
+    rectangle (so that the rows a neighbour waits for are finished by their own, early launch)."""
+    me = plan[rank]
+    if me["band"] is None:
+        return (0, 0), []
+    crops = np.asarray(crops)
+    th = int(crops[0, 3])
+    a, b = me["band"]
+    o0, o1 = me["owned"]
+    others = np.zeros(image_height + 1, dtype=bool)
+    for r, p in enumerate(plan):
+        if r == rank or p["band"] is None:
+            continue
+        for y in np.unique(crops[p["tiles"], 1]):
+            others[int(y):int(y) + th] = True
+    free = ~others[a:b]
+    best, start = (0, 0), None
+    for i, f in enumerate(np.append(free, False)):      # longest run of rows nobody else touches
+        if f and start is None:
+            start = i
+        elif not f and start is not None:
+            if i - start > best[1] - best[0]:
+                best = (start, i)
+            start = None
+    f0, f1 = max(a + best[0], o0), min(a + best[1], o1)
+    final = (f0, f1) if f1 > f0 else (0, 0)
+    cuts = {o0, o1, final[0], final[1]}
+    for _peer, r0, r1, _c0, _c1 in list(me["sends"]) + list(me["recvs"]):
+        cuts.update((r0, r1))
+    return final, sorted(int(c) for c in cuts)
+
+
+class _DeferredBand:
+    """One rank's band merged without an accumulator: the C band plan of ``TileMerger(defer=True)`` over the rank's own tiles
+    (csrc/ptb_bandplan.hip), in the rank's issue order and local row coordinates.  ``out`` [C, rows, W] receives ``sum / norm``
+    on the rows the rank finishes alone and un-normalised partial sums on the rows it shares with (or hands to) a neighbour --
+    what is exchanged are those partial sums instead of accumulator rectangles, and no accumulator read-modify-write happens
+    at all.  The model outputs handed in are held (by reference) until the image is merged."""
+
+    def __init__(self, handle, table, groups, out, norm, weight, xy_abs, top, channels, th, tw):
+        self.handle, self.table, self.groups = handle, table, groups      # groups: [(y0, y1, last tile)] local rows
+        self.out, self.norm, self.weight = out, norm, weight
+        self.xy_abs, self.top = xy_abs, top
+        self.channels, self.th, self.tw = channels, th, tw
+        self.pos = 0
+        self.held = []
+        self.cfg = None
+
+    def __del__(self):
+        try:
+            from . import _native as N
+
+            if self.handle:
+                N.load().ptb_band_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001
+            pass
+
+    @staticmethod
+    def build(merger, crops, weight, rows):
+        import ctypes
+
+        from . import _native as N
+
+        me = merger.plan[merger.rank]
+        top, bottom, W = merger.top, merger.bottom, merger.image_width
+        th, tw = int(crops[0, 3]), int(crops[0, 2])
+        final, cuts = deferred_geometry(merger.plan, merger.rank, crops, merger.image_height)
+        mine = np.ascontiguousarray(crops[me["tiles"], :2].T.astype(np.int64))        # [2, n] absolute, issue order
+        local = mine.copy()
+        local[1] -= top
+        cut_arr = np.ascontiguousarray(np.array([c - top for c in cuts if top < c < bottom], dtype=np.int64))
+        lib = N.load()
+        handle = ctypes.c_void_p()
+        nbytes = lib.ptb_band_plan_create(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], merger.channels,
+                                          th, tw, bottom - top, W, int(rows), final[0] - top if final[1] > final[0] else 0,
+                                          final[1] - top if final[1] > final[0] else 0,
+                                          cut_arr.ctypes.data_as(N._i64p) if len(cut_arr) else None, len(cut_arr), ctypes.byref(handle))
+        if nbytes < 0:
+            return None
+        dev = merger.device
+        table = torch.empty(max(int(nbytes), 64), dtype=torch.uint8, device=dev)
+        with N.on_device(dev):
+            rc = lib.ptb_band_plan_upload(handle, table.data_ptr(), N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "ShardedTileMerger (deferred band plan)")
+        ng = ctypes.c_int()
+        lib.ptb_band_plan_info(handle, ctypes.byref(ng), None, None, None, None)
+        rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
+        lib.ptb_band_plan_info(handle, None, None, None, None, rows_arr.ctypes.data_as(N._i64p))
+        groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
+        out = torch.empty((merger.channels, bottom - top, W), device=dev, dtype=torch.float32)
+        norm = torch.zeros((1, bottom - top, W), device=dev, dtype=torch.float32)
+        o0, o1 = merger.owned_rows
+        if merger.norm_owned is not None:
+            norm[:, o0 - top:o1 - top] = merger.norm_owned
+        w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).to(dev).reshape(1, th, tw).contiguous()
+        band = _DeferredBand(handle, table, groups, out, norm, w, mine, top, merger.channels, th, tw)
+        band.final = final
+        return band
+
+    def reset(self):
+        from . import _native as N
+
+        N.load().ptb_band_plan_reset(self.handle)
+        self.pos, self.held, self.cfg = 0, [], None
+
+    def submit(self, batch, coords_abs, views, reduction):
+        """Take the next planned tiles; returns the number of launches.  The tiles must arrive in ``merger.tiles`` order."""
+        from . import _native as N
+
+        B = len(coords_abs)
+        xy = np.ascontiguousarray(np.asarray(coords_abs, dtype=np.int64)[:, :2].T)
+        if self.pos + B > self.xy_abs.shape[1] or not np.array_equal(xy, self.xy_abs[:, self.pos:self.pos + B]):
+            raise RuntimeError("ShardedTileMerger: tiles must be integrated in the order of `merger.tiles` (the deferred band plan "
+                               "was built for that order); construct the merger with defer=False for free-form accumulation")
+        if batch.dtype not in N.DTYPE_CODES:
+            batch = batch.float()
+        batch = batch.detach().contiguous()
+        n_views = len(views) if views is not None else 1
+        if batch.shape[0] != B * n_views or tuple(batch.shape[1:]) != (self.channels, self.th, self.tw):
+            raise RuntimeError(f"tile batch of shape {tuple(batch.shape)} does not match {B} tiles x {n_views} views of "
+                               f"[{self.channels}, {self.th}, {self.tw}]")
+        varr = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
+        per_tile = self.channels * self.th * self.tw
+        dev = self.out.device
+        with N.on_device(dev):
+            rc = N.load().ptb_band_plan_submit(self.handle, self.pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype], n_views,
+                                               varr, reduction, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
+        N.bump()
+        if rc < 0:
+            N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
+        self.held.append(batch)
+        self.pos += B
+        return rc
+
+    def rows_launched(self, r0, r1):
+        """Every launch group that writes absolute rows r0:r1 has been issued (its last tile is in)."""
+        l0, l1 = r0 - self.top, r1 - self.top
+        return all(last < self.pos for y0, y1, last in self.groups if y0 < l1 and y1 > l0)
+
+    def complete(self):
+        return self.pos == self.xy_abs.shape[1]
+
+
 class ShardedTileMerger:
     """Drop-in shaped like ``TileMerger`` for one rank of a sharded merge of ONE image.
 
@@ -155,7 +306,8 @@ class ShardedTileMerger:
     reference's ``split_across_nodes`` rule; default) or ``"rows"`` (whole tile rows).
     """
 
-    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles"):
+    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=True,
+                 defer_rows=None):
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -203,6 +355,18 @@ class ShardedTileMerger:
             self._boundary[(int(x), int(y))] = self._boundary.get((int(x), int(y)), 0) + 1
         self._send_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _d, r0, r1, c0, c1 in self.sends]
         self._recv_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _s, r0, r1, c0, c1 in self.recvs]
+        # Deferred band merging (default on the HIP path): the rank's tiles are merged band by band straight from the model outputs
+        # -- no accumulator read-modify-write, partial sums instead of accumulator rectangles on the rows shared with neighbours.
+        # Needs the tiles in `self.tiles` order and a geometry on the 4-pixel grid; otherwise the incremental path below is used.
+        self._deferred = None
+        if defer and self.ops is _HipOps and o1 > o0:
+            from .inference.tiles import _defer_rows_default, _warn_once
+
+            self._deferred = _DeferredBand.build(self, crops, weight, defer_rows if defer_rows is not None else _defer_rows_default())
+            if self._deferred is None:
+                _warn_once(("sharded-defer",), "ShardedTileMerger(defer=True): the band plan does not take this geometry (tile origins / "
+                                               "ownership cuts off the 4-pixel grid, more than 4 tiles over a pixel); using the "
+                                               "incremental accumulate + exchange path.")
         self.reset()
 
     # ------------------------------------------------------------------ per-image cycle
@@ -211,6 +375,10 @@ class ShardedTileMerger:
         self._wait_pending()
         self._exchanged = False
         if self.local is None:
+            return
+        if self._deferred is not None:
+            self._deferred.reset()
+            self._remaining = {}
             return
         if hasattr(self.local, "reset"):
             self.local.reset()          # first-touch accumulators: no memset
@@ -238,14 +406,37 @@ class ShardedTileMerger:
         if not rem and not self._exchanged:
             self._start_exchange()
 
+    def _submit_deferred(self, batch, crop_coords, views, code):
+        from . import _native as N
+
+        N.require_device(batch, "ShardedTileMerger")
+        coords = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4)
+        self._deferred.submit(batch, coords, views, code)
+        if not self._exchanged and all(self._deferred.rows_launched(r0, r1) for _d, r0, r1, _c0, _c1 in self.sends):
+            self._start_exchange()      # every row a neighbour waits for has been written by its launch: hand them over now
+
     def integrate_batch(self, batch, crop_coords):
         if len(batch) != len(crop_coords):
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        if self._deferred is not None:
+            from . import _native as N
+
+            return self._submit_deferred(batch, crop_coords, None, N.RED_SUM)
         c, origins = self._shift(crop_coords)
         self.local.integrate_batch(batch, c)
         self._after_integrate(origins)
 
     def integrate_batch_deaugment(self, batch, crop_coords, group="d4", reduction="mean"):
+        if self._deferred is not None:
+            from .inference.tta import DEAUGMENT_VIEWS, _reduction_code
+
+            views = DEAUGMENT_VIEWS[group]
+            if len(batch) != len(crop_coords) * len(views):
+                raise ValueError("Number of images in batch does not correspond to number of coordinates x views")
+            code = _reduction_code(reduction)
+            if code is None:
+                raise ValueError(f"reduction={reduction!r} cannot be fused into the tile merge")
+            return self._submit_deferred(batch, crop_coords, list(views), code)
         c, origins = self._shift(crop_coords)
         self.local.integrate_batch_deaugment(batch, c, group=group, reduction=reduction)
         self._after_integrate(origins)
@@ -253,6 +444,8 @@ class ShardedTileMerger:
     def _rect(self, r0, r1, c0, c1):
         """View of the band accumulator on an absolute pixel rectangle, valid to READ now: blocks of the rectangle no
         kernel has written yet are zero-filled first (only those -- the interior keeps its first-touch state)."""
+        if self._deferred is not None:      # partial sums written by the band launches (the caller checked rows_launched)
+            return self._deferred.out[:, r0 - self.top:r1 - self.top, c0:c1]
         loc = self.local
         if hasattr(loc, "_zero_fresh"):
             loc._zero_fresh(r0 - self.top, r1 - self.top, c0, c1)
@@ -298,6 +491,8 @@ class ShardedTileMerger:
         o0, o1 = self.owned_rows
         if o1 <= o0:
             return None
+        if self._deferred is not None:
+            return self._merge_deferred(o0, o1)
         # the band accumulator, readable on the rows this rank owns and on every received rectangle (blocks there that no
         # kernel has written are zero-filled; rows owned by other ranks keep their first-touch state: nobody reads them)
         for _src, r0, r1, c0, c1 in [(None, o0, o1, 0, self.image_width)] + list(self.recvs):
@@ -311,6 +506,23 @@ class ShardedTileMerger:
                 self.ops.add_rect(image, self.top, (r0, r1, c0, c1), buf)
         out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
         return self.ops.merge_rows(image[:, o0 - self.top:o1 - self.top], self.norm_owned[0], out, extra, extra_rows)
+
+    def _merge_deferred(self, o0, o1):
+        """Owned rows from the band plan's output: the rows finished alone already hold ``sum / norm``; the others hold this
+        rank's partial sums, get the neighbours' partial sums added and are divided in place (<= 2 row ranges)."""
+        d = self._deferred
+        if not d.complete():
+            raise RuntimeError("ShardedTileMerger.merge(): not all of this rank's tiles were integrated")
+        for buf, (_src, r0, r1, c0, c1) in zip(self._recv_buf, self.recvs):
+            self.ops.add_rect(d.out, self.top, (r0, r1, c0, c1), buf)
+        f0, f1 = d.final
+        ranges = [(o0, o1)] if f1 <= f0 else [(o0, f0), (f1, o1)]
+        for r0, r1 in ranges:
+            if r1 > r0:
+                rows = d.out[:, r0 - self.top:r1 - self.top]
+                self.ops.merge_rows(rows, d.norm[0, r0 - self.top:r1 - self.top], rows)
+        d.held = []
+        return d.out[:, o0 - self.top:o1 - self.top]
 
     def gather(self, band):
         """All-gather the bands into the full ``[C, H, W]`` map on every rank (optional; 52 MB per rank at cfg2)."""

@@ -131,15 +131,17 @@ def test_first_touch_bitmap():
     assert rc == -4
 
 
-def _c_band_plan(crops, C, th, tw, H, W, rows):
+def _c_band_plan(crops, C, th, tw, H, W, rows, final=None, cuts=()):
     """ptb_band_plan_create + ptb_band_plan_info (host-side planning only: no GPU needed)."""
     import ctypes
 
     lib = N.load()
     xy = np.ascontiguousarray(np.asarray(crops, dtype=np.int64)[:, :2].T)
     handle = ctypes.c_void_p()
-    nbytes = lib.ptb_band_plan_create(xy[0].ctypes.data_as(N._i64p), xy[1].ctypes.data_as(N._i64p), xy.shape[1], C, th, tw, H, W, rows, 0, 0,
-                                      ctypes.byref(handle))
+    cut_arr = np.asarray(cuts, dtype=np.int64)
+    nbytes = lib.ptb_band_plan_create(xy[0].ctypes.data_as(N._i64p), xy[1].ctypes.data_as(N._i64p), xy.shape[1], C, th, tw, H, W, rows,
+                                      final[0] if final else 0, final[1] if final else H, cut_arr.ctypes.data_as(N._i64p) if len(cut_arr) else None,
+                                      len(cut_arr), ctypes.byref(handle))
     if nbytes < 0:
         return int(nbytes), None
     ng, nb, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
@@ -187,3 +189,7 @@ def test_band_plan_of_the_deferred_merger():
     assert _c_band_plan(odd, 1, 130, 130, int(odd[:, 1].max()) + 130, int(odd[:, 0].max()) + 130, 256)[0] == -2
     # a tile outside the map
     assert _c_band_plan(np.array([[0, 0, 64, 64], [480, 0, 64, 64]]), 1, 64, 64, 64, 512, 64)[0] == -4
+    # caller-given cuts are band edges and launch boundaries (multi-GPU ownership rows)
+    _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1024, final=(128, 896), cuts=[128, 896])
+    assert [(int(g[0]), int(g[1])) for g in p["groups"]][:4] == [(0, 128), (128, 896), (896, 1792), (1792, 2816)]   # groups restart at a cut
+    assert p["bands"] == 22

@@ -303,3 +303,35 @@ def test_headline_geometry_eight_ranks_in_process():
     ranks = _simulate((5000, 5000), 512, 256, 8, "tiles", C=1, seed=3)
     assert [len(m.tiles) for m in ranks] == [45, 45, 45, 45, 45, 45, 45, 46]
     assert max(m.bottom - m.top for m in ranks) <= 1280       # band accumulators: at most 4 tile rows + ownership slack
+
+
+@pytest.mark.parametrize("world,partition", [(2, "tiles"), (4, "tiles"), (8, "tiles"), (8, "rows"), (3, "rows")])
+def test_deferred_geometry_of_every_rank(world, partition):
+    """What the deferred band plan of a rank is built from (headline geometry): the rows a rank finishes alone are touched by
+    none of the other ranks' tiles and lie inside the rows it owns; the cuts contain the ends of the owned rows, of the final rows
+    and of every exchanged rectangle, all on the 4-pixel grid; together the ranks' owned rows tile the image."""
+    from pytorch_toolbelt_amd.parallel import deferred_geometry
+
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    crops = geom["crops"]
+    plan = band_plan(crops, world, 5120, partition)
+    covered = np.zeros(5120, dtype=int)
+    final_rows = 0
+    for r in range(world):
+        (f0, f1), cuts = deferred_geometry(plan, r, crops, 5120)
+        o0, o1 = plan[r]["owned"]
+        covered[o0:o1] += 1
+        assert all(c % 4 == 0 for c in cuts) and {o0, o1} <= set(cuts)
+        for _peer, r0, r1, _c0, _c1 in plan[r]["sends"] + plan[r]["recvs"]:
+            assert {r0, r1} <= set(cuts)
+        if f1 > f0:
+            assert o0 <= f0 < f1 <= o1 and {f0, f1} <= set(cuts)
+            for q in range(world):
+                if q != r:
+                    ys = crops[plan[q]["tiles"], 1]
+                    assert not ((ys < f1) & (ys + 512 > f0)).any(), "a row finished alone is touched by another rank's tile"
+            for _src, r0, r1, _c0, _c1 in plan[r]["recvs"]:
+                assert r1 <= f0 or r0 >= f1
+            final_rows += f1 - f0
+    assert (covered == 1).all()
+    assert final_rows >= (5120 - world * 1024)     # at most ~2 tile heights per rank are shared with neighbours

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--partition", default="tiles")
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--no-defer", action="store_true", help="incremental accumulate + exchange path (round-1 behaviour) instead of the band plan")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
@@ -65,7 +66,7 @@ def main():
     gc.disable()   # a generation-2 pass (30-45 ms) inside one rank's loop would masquerade as a slow rank
     worst = 0.0
     for r in range(args.world):
-        m = ShardedTileMerger(slicer.target_shape, C, slicer.weight, slicer.crops, device=dev, dist=FakeDist(r, args.world), partition=args.partition)
+        m = ShardedTileMerger(slicer.target_shape, C, slicer.weight, slicer.crops, device=dev, dist=FakeDist(r, args.world), partition=args.partition, defer=not args.no_defer)
         for buf in m._recv_buf:
             buf.zero_()
         crops = slicer.crops[m.tiles]
@@ -99,7 +100,7 @@ def main():
             devms = min(devms, e0.elapsed_time(e1) / args.steps)
         worst = max(worst, devms)
         halo = sum((r1 - r0) * (c1 - c0) * C * 4 for _d, r0, r1, c0, c1 in m.sends) / 1e6
-        print(f"rank {r}/{args.world} [{args.partition}]: {len(crops)} tiles, {len(batches)} launches, boundary tiles {len(m.plan[r]['boundary'])}, "
+        print(f"rank {r}/{args.world} [{args.partition}, {'deferred bands' if m._deferred is not None else 'incremental'}]: {len(crops)} tiles, {len(batches)} launches, boundary tiles {len(m.plan[r]['boundary'])}, "
               f"owned rows {m.owned_rows}, halo out {halo:.1f} MB: {devms:.3f} ms per image (host issue {host:.3f} ms; "
               f"median step {sorted(per)[len(per) // 2]:.3f}, worst step {max(per):.3f})")
         del m, outs
