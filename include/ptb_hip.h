@@ -138,6 +138,12 @@ int ptb_merge_band(float* merged, const float* norm_full, const float* weight, c
  * read stream and quote its kernels against that as well as against the 8 TB/s spec.  `sink` = 4 writable device bytes. */
 int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t stream);
 
+/* out[i] = sum_s slot_sums[s][i] for the [nslots][n] slotted fp64 sums the loss entry points produce (they zero the slots and
+ * the label flag themselves, on the launch stream: callers hand in uninitialised workspaces).  When error_flag (may be NULL) was
+ * raised by the forward kernel -- a label outside [0, C) that is not ignore_index, where the reference's F.one_hot raises -- every
+ * sum becomes NaN, so the condition can never produce a finite loss, even before the asynchronous host check reports it. */
+int ptb_sums_finalize(const double* slot_sums, int nslots, int n, double* out, const int* error_flag, ptb_stream_t stream);
+
 /* ---- Deferred merge of a whole image, planned once (TileMerger(crops=tiler.crops, defer=True)).
  * Replaces the reference's per-batch loop `merger.integrate_batch(<group>_image_deaugment(pred), crops)` + `merger.merge()`
  * (inference/tta.py:442-467, inference/tiles.py:321-346) when the crop list of the image is known up front.
@@ -320,7 +326,7 @@ int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const in
 /* One pass over logits+targets for focal_loss_with_logits (losses/functional.py:19-107, sigmoid activation),
  * BinaryFocalLoss (losses/focal.py:77-105) and the sums of soft_dice_score / soft_jaccard_score with dims=(0,2)
  * (losses/functional.py:188-247; DiceLoss losses/dice.py:59-131, JaccardLoss losses/jaccard.py:48-103).
- * sums: double[PTB_SUM_SLOTS][2 + 3*C], must be zeroed by the caller; error_flag: int, set to 1 when a label is outside [0, C)
+ * sums: double[PTB_SUM_SLOTS][2 + 3*C] (zeroed by this call, like error_flag; reduce with ptb_sums_finalize); error_flag: int, set to 1 when a label is outside [0, C)
  * and not ignore_label (the reference's F.one_hot raises).  class_weights [C] fp32 or NULL. */
 int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
                      double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags, int prob,
@@ -367,13 +373,14 @@ int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, const float* d
  *   loss_c = [T_c > 0] * (log_loss ? -log(max(score_c, eps)) : 1 - score_c); the mean runs over the n_selected classes with
  *   class_mask[c] != 0 (class_mask NULL: all C).  fp32 arithmetic on the fp64 sums rounded to fp32, like the reference.
  * coef DEVICE float[2 + 2C] receives d loss / d (focal loss sum, focal term sum, I[C], P[C]) -- the arrays
- * ptb_focal_bwd / ptb_seg_stats_bwd / ptb_seg_fused_bwd take (after scaling by the upstream gradient). */
+ * ptb_focal_bwd / ptb_seg_stats_bwd / ptb_seg_fused_bwd take (after scaling by the upstream gradient).  error_flag (may be NULL): the
+ * forward kernel's label flag; when raised the loss is NaN. */
 int ptb_region_epilogue(const double* sums, int slots, int C, float focal_scale, float dice_weight, float jaccard_weight,
                         float smooth, float eps, int log_loss, const uint8_t* class_mask, int n_selected, float* loss,
-                        float* coef, ptb_stream_t stream);
+                        float* coef, const int* error_flag, ptb_stream_t stream);
 
 /* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
- * sums double[PTB_SUM_SLOTS][2] (zeroed by the caller): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
+ * sums double[PTB_SUM_SLOTS][2] (zeroed by this call): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
 int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,
                           float* pixel_out, int* error_flag, int B, int C, int64_t HW, int reduced, float gamma,
                           float threshold, int64_t ignore_label, ptb_stream_t stream);
@@ -388,7 +395,7 @@ int ptb_softmax_focal_bwd(const float* logits, const int64_t* labels, const floa
  * functional.py:260-269; p0 = width, p1 = curvature, p2 = width - width*log(1 + width/curvature)), 4 log_cosh_loss
  * (losses/functional.py:338-341), 5 soft F1 counts of one class (losses/soft_f1.py:22-24, 63-78: p = clamp(sigmoid(x), p0,
  * 1 - p0), or p = x when flags & 2).  flags: 1 = elements whose target == ignore_value contribute 0; 2 = label smoothing.
- * x, t: DEVICE fp32 [n].  sums: DEVICE double [PTB_SUM_SLOTS][4], zeroed by the caller, slot-wise partial sums of
+ * x, t: DEVICE fp32 [n].  sums: DEVICE double [PTB_SUM_SLOTS][4], zeroed by this call, slot-wise partial sums of
  *   kind 0,3,4: {loss};  kind 1: {sum t*logsigmoid(x), sum (1-t)*logsigmoid(-x), #(t == 1), #(t == 0)};  kind 2: {loss, focal};
  *   kind 5: {sum p t, sum p, sum t, #kept} (TP = s0, FP = s1 - s0, FN = s2 - s0); its apply gives d(coef[0] s0 + coef[1] s1)/dx.
  * elem_out (optional, not for kind 1): per-element loss. */
@@ -424,7 +431,7 @@ int ptb_bitempered_binary_bwd(const float* x, const float* t, const float* coef,
  * mode 0 (softmax): pred = probabilities [B, C, HW], labels int64 [B, HW]; mode 1 (hinge): pred = logits [B, HW],
  * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the
  * whole batch; S = groups*C segments of P = (per_image ? HW : B*HW) elements, n = S*P < 2^31.
- * seg_loss[s] (double, zeroed by the caller) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
+ * seg_loss[s] (double, zeroed by this call) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
  * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward).
  * Workspaces are caller-provided device buffers: keys_a/keys_b u32[n] (complemented order-preserving error bits),
  * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (digit histograms of the

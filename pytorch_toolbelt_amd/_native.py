@@ -39,6 +39,7 @@ SIGNATURES = {
     "ptb_last_hip_error": (ctypes.c_char_p, []),
     "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
     "ptb_read_probe": (_c_int, [_vp, _c_i64, _vp, _vp]),
+    "ptb_sums_finalize": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),
     "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_deaug_reduce_t": (_c_int, [_vp, _c_int, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_deaug_accumulate_t": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
@@ -73,7 +74,7 @@ SIGNATURES = {
     "ptb_focal_softmax_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_focal_softmax_bwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_seg_stats_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_i64, _c_f, _vp]),
-    "ptb_region_epilogue": (_c_int, [_vp, _c_int, _c_int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _vp, _c_int, _vp, _vp, _vp]),
+    "ptb_region_epilogue": (_c_int, [_vp, _c_int, _c_int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp]),
     "ptb_seg_fused_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_softmax_focal_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_i64, _vp]),
     "ptb_softmax_focal_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_i64, _vp]),

@@ -118,7 +118,25 @@ extern "C" int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_s
     return check_launch();
 }
 
-extern "C" int ptb_version(void) { return 101; }
+// out[i] = sum over the slots of slot_sums[s][i] (the loss kernels spread their fp64 atomics over PTB_SUM_SLOTS copies of the
+// sums); a raised label-error flag turns every sum into NaN, so a label outside [0, C) can never train silently.
+__global__ __launch_bounds__(256) void sums_finalize_kernel(const double* __restrict__ slots, int nslots, int n, double* __restrict__ out,
+                                                            const int* __restrict__ flag) {
+    const bool bad = flag && *flag;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        double t = 0.0;
+        for (int s = 0; s < nslots; ++s) t += slots[(long long)s * n + i];
+        out[i] = bad ? (double)__builtin_nanf("") : t;
+    }
+}
+
+extern "C" int ptb_sums_finalize(const double* slot_sums, int nslots, int n, double* out, const int* error_flag, ptb_stream_t stream) {
+    if (!slot_sums || !out || nslots < 1 || n < 1) return PTB_EINVAL;
+    hipLaunchKernelGGL(sums_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, slot_sums, nslots, n, out, error_flag);
+    return check_launch();
+}
+
+extern "C" int ptb_version(void) { return 102; }
 
 extern "C" const char* ptb_last_hip_error(void) { return g_last_error.c_str(); }
 

@@ -157,8 +157,9 @@ extern "C" int ptb_focal_softmax_fwd(const float* logits, const int64_t* labels,
     if (int rc = fsm_fill(fa, logits, labels, dense, class_weights, cw_mode, cw_n, cw_div, B, C, HW, flags, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
     if (!sums || !error_flag || ((flags & SEG_ELEMWISE) && !elem_out)) return PTB_EINVAL;
     fa.s.sums = sums; fa.s.elem_out = elem_out; fa.s.error_flag = error_flag;
-    if ((long long)B * HW == 0) return PTB_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (int rc = zero_sums(sums, 2, error_flag, s)) return rc;
+    if ((long long)B * HW == 0) return PTB_OK;
     const bool vec = vec_ok(HW, {logits, dense, elem_out, labels});
     const dim3 grid(vec ? grid_for_groups((HW + 255) / 256 * B, kGridStream) : grid_for_groups((HW + 63) / 64 * B, kGridStream)), block(256);
     const bool g2 = gamma == 2.0f;

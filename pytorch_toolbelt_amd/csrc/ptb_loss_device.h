@@ -204,6 +204,15 @@ __device__ __forceinline__ Group<PIX> make_group(long long g, long long per_img,
 
 
 // ------------------------------------------------------------------------------------------------ host side
+// The slotted sums (SUM_SLOTS rows of `row` doubles) and the label flag start every forward from zero: zeroed here, on the launch
+// stream, so that callers hand in plain uninitialised workspaces (no framework fill kernels on the loss path).
+static inline int zero_sums(double* sums, int row, int* error_flag, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)SUM_SLOTS * row * sizeof(double), s);
+    if (e == hipSuccess && error_flag) e = hipMemsetAsync(error_flag, 0, sizeof(int), s);
+    if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    return PTB_OK;
+}
+
 // Measured on MI355X (tools/ab_losses.py): the streaming kernels (focal fwd/bwd, softmax focal) gain ~10 % from an
 // oversubscribed grid (32 workgroups per CU, one pixel group per wave), the statistics kernels lose from it (more
 // per-workgroup LDS reductions + atomics), so they keep 8 per CU.

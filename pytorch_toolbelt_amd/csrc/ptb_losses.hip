@@ -1555,6 +1555,7 @@ struct EpiArgs {
     int n_selected;
     float* loss;          // [1]
     float* coef;          // [2 + 2C]: d loss / d (focal loss sum, focal term sum, I[C], P[C])
+    const int* error_flag;  // set by the forward kernel on a label outside [0, C): the loss becomes NaN (or null)
 };
 
 __device__ __forceinline__ void score_loss(float score, bool active, int log_loss, float eps, float& loss, float& dscore) {
@@ -1622,7 +1623,7 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
         const float focal = a.focal_scale != 0.f ? a.focal_scale * (float)f : 0.f;
         const float dice = a.dice_w != 0.f ? a.dice_w * ((float)red[0][0] * inv_n) : 0.f;
         const float jacc = a.jacc_w != 0.f ? a.jacc_w * ((float)red[1][0] * inv_n) : 0.f;
-        a.loss[0] = focal + dice + jacc;
+        a.loss[0] = (a.error_flag && *a.error_flag) ? __builtin_nanf("") : focal + dice + jacc;
         a.coef[0] = a.focal_scale;
         a.coef[1] = 0.f;
     }
@@ -1643,9 +1644,10 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     if (!sums || !error_flag || ((flags & SEG_ELEMWISE) && !elem_out)) return PTB_EINVAL;
     if (C > 1024) return PTB_EUNSUPPORTED;
     a.sums = sums; a.elem_out = elem_out; a.error_flag = error_flag;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = zero_sums(sums, 2 + 3 * C, error_flag, s)) return rc;   // the slot sums and the label flag start from zero
     if ((long long)B * HW == 0) return PTB_OK;
     const size_t shmem = (size_t)4 * 3 * C * sizeof(float);
-    hipStream_t s = (hipStream_t)stream;
     const int what = flags & (SEG_FOCAL | SEG_STATS);
     if (!what) return PTB_EINVAL;
     const bool g2 = gamma == 2.0f;
@@ -1801,6 +1803,7 @@ extern "C" int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels,
                                      float* pixel_out, int* error_flag, int B, int C, int64_t HW, int reduced, float gamma,
                                      float threshold, int64_t ignore_label, ptb_stream_t stream) {
     if (!logits || !labels || !sums || !error_flag || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
+    if (int rc = zero_sums(sums, 2, error_flag, (hipStream_t)stream)) return rc;
     if ((long long)B * HW == 0) return PTB_OK;
     SmfArgs a{logits, (const long long*)labels, class_weights, sums, pixel_out, error_flag, B, C, HW, reduced, gamma, threshold, ignore_label};
     return launch_smf<0>(a, nullptr, nullptr, nullptr, (hipStream_t)stream);
@@ -1855,9 +1858,9 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
 
 extern "C" int ptb_region_epilogue(const double* sums, int slots, int C, float focal_scale, float dice_weight, float jaccard_weight,
                                    float smooth, float eps, int log_loss, const uint8_t* class_mask, int n_selected, float* loss,
-                                   float* coef, ptb_stream_t stream) {
+                                   float* coef, const int* error_flag, ptb_stream_t stream) {
     if (!sums || !loss || !coef || slots < 1 || C < 1 || n_selected < 1 || n_selected > C) return PTB_EINVAL;
-    EpiArgs a{sums, slots, C, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected, loss, coef};
+    EpiArgs a{sums, slots, C, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected, loss, coef, error_flag};
     hipLaunchKernelGGL(region_epilogue_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch();
 }

@@ -449,7 +449,7 @@ extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
 }
 
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
-// chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (zeroed by the caller);
+// chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (zeroed here);
 // grad_at_pixel float[n] (kept for backward); temp = ptb_lovasz_temp_bytes bytes.
 extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                               int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
@@ -463,6 +463,10 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;  // offsets / packed indices are 32-bit
     if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
+    {   // the per-segment dot products are accumulated with atomics: start from zero (on the launch stream)
+        const hipError_t e = hipMemsetAsync(seg_loss, 0, (size_t)a.S * sizeof(double), s);
+        if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    }
     hipLaunchKernelGGL(lovasz_error_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, keys_a, vals_a);
     if (int rc = check_launch()) return rc;
     // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a

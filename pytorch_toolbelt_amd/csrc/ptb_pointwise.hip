@@ -533,6 +533,13 @@ static int fill_pw(PwArgs& a, int kind, const float* x, const float* t, const fl
     return PTB_OK;
 }
 
+static int pw_zero(double* sums, int* error_flag, hipStream_t s) {   // slot sums (and the label flag) start from zero
+    hipError_t e = hipMemsetAsync(sums, 0, (size_t)PW_SLOTS * 4 * sizeof(double), s);
+    if (e == hipSuccess && error_flag) e = hipMemsetAsync(error_flag, 0, sizeof(int), s);
+    if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    return PTB_OK;
+}
+
 }  // namespace ptb
 
 using namespace ptb;
@@ -553,9 +560,10 @@ extern "C" int ptb_pointwise_loss_fwd(int kind, const float* x, const float* t, 
     PwArgs a{};
     if (int rc = fill_pw(a, kind, x, t, chan_w, chan_pw, n, C, HW, flags, p0, p1, p2, ignore_value)) return rc;
     if (!sums) return PTB_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (int rc = pw_zero(sums, nullptr, s)) return rc;
     if (n == 0) return PTB_OK;
     a.sums = sums; a.out = elem_out;
-    hipStream_t s = (hipStream_t)stream;
     const bool vec = pw_vec(a, nullptr);
     const dim3 grid(pw_grid(vec ? n / 4 : n)), block(256);
 #define PTB_PW_FWD(K, V, dummy) hipLaunchKernelGGL((pw_fwd_kernel<K, V>), grid, block, 0, s, a)
@@ -618,6 +626,7 @@ static int launch_sce(const SceArgs& a, int mode, const float* coef, const float
 extern "C" int ptb_soft_ce_fwd(const float* logits, const int64_t* labels, double* sums, float* pixel_out, int* error_flag, int B, int C,
                                int64_t HW, float eps, int has_ignore, int64_t ignore_label, ptb_stream_t stream) {
     if (!logits || !labels || !sums || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
+    if (int rc = pw_zero(sums, error_flag, (hipStream_t)stream)) return rc;
     if ((long long)B * HW == 0) return PTB_OK;
     SceArgs a{logits, reinterpret_cast<const long long*>(labels), sums, pixel_out, error_flag, B, C, (long long)HW, eps, has_ignore,
               (long long)ignore_label};
@@ -636,6 +645,7 @@ extern "C" int ptb_soft_ce_bwd(const float* logits, const int64_t* labels, const
 extern "C" int ptb_bitempered_binary_fwd(const float* x, const float* t, double* sums, float* elem_out, int64_t n, float t1, float t2,
                                          float smoothing, int iters, int has_ignore, float ignore_value, ptb_stream_t stream) {
     if (!x || !t || !sums || n < 0 || iters < 0 || t1 == 2.0f) return PTB_EINVAL;
+    if (int rc = pw_zero(sums, nullptr, (hipStream_t)stream)) return rc;
     if (n == 0) return PTB_OK;
     BtArgs a{x, t, sums, elem_out, (long long)n, t1, t2, smoothing, ignore_value, iters, has_ignore};
     hipLaunchKernelGGL(bitempered_binary_kernel<false>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, a, nullptr, nullptr);

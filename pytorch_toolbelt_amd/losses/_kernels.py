@@ -5,6 +5,7 @@ clamp, 1 - score, log, mean over classes) is ordinary differentiable torch code 
 kernels only need d(loss)/d(sum) -- delivered as device arrays, without a host synchronisation.
 """
 import os
+import threading
 
 import torch
 
@@ -15,7 +16,9 @@ PROB_SOFTMAX, PROB_SIGMOID, PROB_IDENTITY = 0, 1, 2
 SUM_SLOTS = 64  # PTB_SUM_SLOTS: the kernels spread their fp64 atomics over this many copies of the sums
 
 # Labels outside [0, C): the reference's F.one_hot raises on CPU and trips a device-side assert on GPU (no host sync).
-# The kernels record the condition in a device flag.  By default the flag is checked WITHOUT synchronising: it is copied
+# The kernels record the condition in a device flag, and the flag POISONS the result: ptb_sums_finalize / ptb_region_epilogue
+# turn the sums / the loss into NaN when it is set, so a bad label can never train silently.  The exception itself is raised
+# WITHOUT synchronising: the flag is copied
 # to pinned host memory asynchronously and examined at the next loss call (or by ``flush_label_check()``), so a bad
 # label surfaces one call late -- the same asynchronous error model as a device assert, minus the dead context.
 # PTB_SYNC_LABEL_CHECK=1 (or ``SYNC_LABEL_CHECK = True``) checks immediately at the price of one host sync per call;
@@ -24,6 +27,7 @@ _CHECK_LABELS = os.environ.get("PTB_SKIP_LABEL_CHECK", "0") != "1"
 SYNC_LABEL_CHECK = os.environ.get("PTB_SYNC_LABEL_CHECK", "0") == "1"
 _LABEL_MSG = "Class values must be smaller than num_classes."
 _pending = []  # (pinned host int32 tensor, event)
+_pending_lock = threading.Lock()
 
 
 def _f32c(t, what):
@@ -40,14 +44,18 @@ def _ptr(t):
 def _poll(block: bool):
     global _pending
     keep, bad = [], False
-    for host, ev in _pending:
+    with _pending_lock:
+        todo, _pending = _pending, []
+    for host, ev in todo:
         if block:
             ev.synchronize()
         if block or ev.query():
             bad = bad or int(host[0]) != 0
         else:
             keep.append((host, ev))
-    _pending = keep
+    if keep:
+        with _pending_lock:
+            _pending = keep + _pending
     if bad:
         raise RuntimeError(_LABEL_MSG + " (reported asynchronously by an earlier loss call)")
 
@@ -69,7 +77,26 @@ def check_labels(flag):
     host.copy_(flag, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(flag.device))
-    _pending.append((host, ev))
+    with _pending_lock:
+        _pending.append((host, ev))
+
+
+def new_sums(row, device, with_flag=True):
+    """Uninitialised slot-sum workspace [SUM_SLOTS, row] (+ the int32 label flag): the forward entry points zero them on the launch
+    stream themselves, so no framework fill kernel runs on the loss path."""
+    sums = torch.empty((SUM_SLOTS, row), dtype=torch.float64, device=device)
+    return sums, (torch.empty(1, dtype=torch.int32, device=device) if with_flag else None)
+
+
+def finalize(sums, flag=None):
+    """[row] float64 = the slots added up by ``ptb_sums_finalize``; NaN when the kernel raised the label flag (a label outside
+    [0, C) that is not ignore_index can therefore never yield a finite loss, whatever the asynchronous host check does)."""
+    out = torch.empty(sums.shape[1], dtype=torch.float64, device=sums.device)
+    lib = N.load()
+    with N.on_device(sums.device):
+        rc = lib.ptb_sums_finalize(sums.data_ptr(), sums.shape[0], sums.shape[1], out.data_ptr(), _ptr(flag), N.stream_ptr(sums.device))
+    N.check(rc, "ptb_sums_finalize")
+    return out
 
 
 class SigmoidFocalSums(torch.autograd.Function):
@@ -80,8 +107,7 @@ class SigmoidFocalSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, dense, class_weights, flags, gamma, alpha, threshold, ignore_label, ignore_value):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2 + 3 * C, x.device)
         elem = torch.empty_like(x) if flags & SEG_ELEMWISE else None
         lib = N.load()
         with N.on_device(x.device):
@@ -99,7 +125,7 @@ class SigmoidFocalSums(torch.autograd.Function):
             ctx.has_elem = False
         else:
             ctx.has_elem = True
-        return sums.sum(dim=0)[:2], elem
+        return finalize(sums, flag if labels is not None else None)[:2], elem
 
     @staticmethod
     def backward(ctx, g_sums, g_elem):
@@ -133,8 +159,7 @@ class SoftmaxActFocalSums(torch.autograd.Function):
     def forward(ctx, x, labels, dense, cw, flags, gamma, alpha, threshold, ignore_label, ignore_value):
         B, C, HW = x.shape
         weights, cw_mode, cw_n, cw_div = cw
-        sums = torch.zeros((SUM_SLOTS, 2), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2, x.device)
         elem = torch.empty_like(x) if flags & SEG_ELEMWISE else None
         lib = N.load()
         with N.on_device(x.device):
@@ -148,7 +173,7 @@ class SoftmaxActFocalSums(torch.autograd.Function):
         ctx.save_for_backward(x, labels, dense, weights)
         ctx.cfg = (flags, gamma, alpha, threshold, ignore_label, ignore_value, cw_mode, cw_n, cw_div)
         ctx.has_elem = elem is not None
-        return sums.sum(dim=0), (elem if elem is not None else x.new_empty(0))
+        return finalize(sums, flag if labels is not None else None), (elem if elem is not None else x.new_empty(0))
 
     @staticmethod
     def backward(ctx, g_sums, g_elem):
@@ -177,8 +202,7 @@ class RegionStats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, dense, prob, has_ignore, ignore_label, ignore_value):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2 + 3 * C, x.device)
         flags = SEG_STATS | (SEG_HAS_IGNORE if has_ignore else 0)
         lib = N.load()
         with N.on_device(x.device):
@@ -190,7 +214,7 @@ class RegionStats(torch.autograd.Function):
             check_labels(flag)
         ctx.save_for_backward(x, labels, dense)
         ctx.cfg = (flags, prob, ignore_label, ignore_value)
-        return sums.sum(dim=0)[2:].view(3, C)
+        return finalize(sums, flag if labels is not None else None)[2:].view(3, C)
 
     @staticmethod
     def backward(ctx, g):
@@ -214,8 +238,7 @@ class SoftmaxFocalSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, class_weights, reduced, gamma, threshold, ignore_label, want_map):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 2), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2, x.device)
         pix = torch.empty((B, HW), dtype=torch.float32, device=x.device) if want_map else None
         lib = N.load()
         with N.on_device(x.device):
@@ -227,7 +250,7 @@ class SoftmaxFocalSums(torch.autograd.Function):
         ctx.save_for_backward(x, labels, class_weights)
         ctx.cfg = (reduced, gamma, threshold, ignore_label)
         ctx.has_map = want_map
-        return sums.sum(dim=0), (pix if want_map else x.new_empty(0))
+        return finalize(sums, flag), (pix if want_map else x.new_empty(0))
 
     @staticmethod
     def backward(ctx, g_sums, g_pix):
@@ -263,8 +286,7 @@ class FusedSegSums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, dense, class_weights, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2 + 3 * C, x.device)
         lib = N.load()
         with N.on_device(x.device):
             rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), sums.data_ptr(), None,
@@ -276,7 +298,7 @@ class FusedSegSums(torch.autograd.Function):
             check_labels(flag)
         ctx.save_for_backward(x, labels, dense, class_weights)
         ctx.cfg = (flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)
-        total = sums.sum(dim=0)
+        total = finalize(sums, flag if labels is not None else None)
         return total[:2], total[2:].view(3, C)
 
     @staticmethod
@@ -319,8 +341,7 @@ class RegionLoss(torch.autograd.Function):
     def forward(ctx, x, labels, dense, class_weights, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value,
                 with_focal, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 2 + 3 * C), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(2 + 3 * C, x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         coef = torch.empty(2 + 2 * C, dtype=torch.float32, device=x.device)
         what = SEG_STATS | (SEG_FOCAL if with_focal else 0)
@@ -332,7 +353,7 @@ class RegionLoss(torch.autograd.Function):
             N.check(rc, "ptb_seg_loss_fwd")
             rc = lib.ptb_region_epilogue(sums.data_ptr(), SUM_SLOTS, C, focal_scale if with_focal else 0.0, dice_weight, jaccard_weight,
                                          smooth, eps, 1 if log_loss else 0, _ptr(class_mask), n_selected, loss.data_ptr(),
-                                         coef.data_ptr(), N.stream_ptr(x.device))
+                                         coef.data_ptr(), flag.data_ptr() if labels is not None else None, N.stream_ptr(x.device))
             N.check(rc, "ptb_region_epilogue")
         N.bump()
         if labels is not None:

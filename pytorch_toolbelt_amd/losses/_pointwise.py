@@ -8,7 +8,7 @@ needs d(loss)/d(sum), handed to the kernels as device arrays -- nothing synchron
 import torch
 
 from .. import _native as N
-from ._kernels import SUM_SLOTS, _ptr, check_labels
+from ._kernels import SUM_SLOTS, _ptr, check_labels, finalize, new_sums
 
 SOFT_BCE, BALANCED_BCE, QFL, WING, LOGCOSH, SOFT_F1 = range(6)
 F_IGNORE, F_SMOOTH = 1, 2
@@ -24,7 +24,7 @@ class PointwiseSums(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, chan_w, chan_pw, kind, flags, p0, p1, p2, ignore_value, C, HW, want_elem):
-        sums = torch.zeros((SUM_SLOTS, 4), dtype=torch.float64, device=x.device)
+        sums, _ = new_sums(4, x.device, with_flag=False)
         elem = torch.empty_like(x) if want_elem else None
         lib = N.load()
         with N.on_device(x.device):
@@ -35,7 +35,7 @@ class PointwiseSums(torch.autograd.Function):
         ctx.save_for_backward(x, t, chan_w, chan_pw)
         ctx.cfg = (kind, flags, p0, p1, p2, ignore_value, C, HW)
         ctx.has_elem = want_elem
-        return sums.sum(dim=0), (elem if want_elem else x.new_empty(0))
+        return finalize(sums), (elem if want_elem else x.new_empty(0))
 
     @staticmethod
     def backward(ctx, g_sums, g_elem):
@@ -102,8 +102,7 @@ class SoftCESums(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, eps, has_ignore, ignore_label, want_map):
         B, C, HW = x.shape
-        sums = torch.zeros((SUM_SLOTS, 4), dtype=torch.float64, device=x.device)
-        flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+        sums, flag = new_sums(4, x.device)
         pix = torch.empty((B, HW), dtype=torch.float32, device=x.device) if want_map else None
         lib = N.load()
         with N.on_device(x.device):
@@ -115,7 +114,7 @@ class SoftCESums(torch.autograd.Function):
         ctx.save_for_backward(x, labels)
         ctx.cfg = (eps, has_ignore, ignore_label)
         ctx.has_map = want_map
-        s = sums.sum(dim=0)
+        s = finalize(sums, flag)
         return (1.0 - eps) * s[0] + (eps / C) * s[1], (pix if want_map else x.new_empty(0))
 
     @staticmethod
@@ -144,7 +143,7 @@ class BiTemperedBinarySums(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, t, t1, t2, smoothing, iters, has_ignore, ignore_value, want_elem):
-        sums = torch.zeros((SUM_SLOTS, 4), dtype=torch.float64, device=x.device)
+        sums, _ = new_sums(4, x.device, with_flag=False)
         elem = torch.empty_like(x) if want_elem else None
         lib = N.load()
         with N.on_device(x.device):
@@ -155,7 +154,7 @@ class BiTemperedBinarySums(torch.autograd.Function):
         ctx.save_for_backward(x, t)
         ctx.cfg = (t1, t2, smoothing, iters, has_ignore, ignore_value)
         ctx.has_elem = want_elem
-        return sums.sum(dim=0)[0], (elem if want_elem else x.new_empty(0))
+        return finalize(sums)[0], (elem if want_elem else x.new_empty(0))
 
     @staticmethod
     def backward(ctx, g_sum, g_elem):

@@ -33,8 +33,9 @@ class _LovaszSegments(torch.autograd.Function):
         S = groups * C
         n = P * S
         dev = pred.device
-        seg_loss = torch.zeros(S, dtype=torch.float64, device=dev)
-        fg_total = torch.zeros(S, dtype=torch.int32, device=dev)
+        alloc = torch.empty if n > 0 else torch.zeros     # (the forward entry point zeroes / fills both itself)
+        seg_loss = alloc(S, dtype=torch.float64, device=dev)
+        fg_total = alloc(S, dtype=torch.int32, device=dev)
         gpix = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
         if n > 0:
             lib = N.load()

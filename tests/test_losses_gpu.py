@@ -184,10 +184,23 @@ def test_label_errors_and_modes(dev, monkeypatch):
     good = torch.zeros((2, 8, 8), dtype=torch.long, device=dev)
     # default: asynchronous report (no host sync per call) -- the error surfaces at flush / a later call
     K.flush_label_check()
-    L.DiceLoss("multiclass")(x, bad)
+    poisoned = L.DiceLoss("multiclass")(x, bad)
     with pytest.raises(RuntimeError, match="asynchronously"):
         K.flush_label_check()
-    L.DiceLoss("multiclass")(x, good)
+    # ... and until then the loss is NaN, never a finite wrong number (the label flag poisons the sums on the device)
+    assert torch.isnan(poisoned)
+    for crit in (L.JaccardLoss("multiclass"), L.BinaryFocalLoss(), L.CrossEntropyFocalLoss(), L.FocalDiceJaccardLoss("multiclass"),
+                 L.SoftCrossEntropyLoss(smooth_factor=0.1), L.BinaryFocalLoss(activation="softmax", softmax_dim=1)):
+        assert torch.isnan(crit(x, bad)), type(crit).__name__
+        with pytest.raises(RuntimeError):
+            K.flush_label_check()
+    mixed = good.clone()
+    mixed[0, 0, 0] = 255            # the classic void label without ignore_index
+    assert torch.isnan(L.DiceLoss("multiclass")(x, mixed))
+    with pytest.raises(RuntimeError):
+        K.flush_label_check()
+    assert torch.isfinite(L.DiceLoss("multiclass", ignore_index=255)(x, mixed))
+    assert torch.isfinite(L.DiceLoss("multiclass")(x, good))
     K.flush_label_check()
     # synchronous mode: immediate error like the reference's F.one_hot on CPU
     monkeypatch.setattr(K, "SYNC_LABEL_CHECK", True)
