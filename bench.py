@@ -419,6 +419,12 @@ def main():
         # map once) and nothing else runs on the stream: one HIP-event pair around the K timed steps / (K x launches per image)
         launch_ms = region_event_ms / (args.steps * n_bands)
         bytes_per_launch = (VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) // n_bands
+    elif sharded:
+        # one rank's share of the image: its tiles read once + its owned rows written once, over the whole step (kernels, the
+        # partial-sum exchange and the completion of the shared rows) -- the per-rank effective rate, not a single kernel's
+        owned = merger.owned_rows or (0, 0)
+        bytes_per_launch = bytes_per_tile * len(crops) + CHANNELS * (owned[1] - owned[0]) * 5120 * 4
+        launch_ms = elapsed / args.steps * 1e3
     elif not sharded and planned:
         # the planned kernel also writes the region's output (+ C x 5120 x 5120 x 4 B per image): the launch's
         # share of the whole region's algorithmic bytes, 12 532 580 352 B x 8 / 361
@@ -454,7 +460,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("band_merge_d4_bytes_per_launch" if n_bands else "view_accum_d4_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("band_plan_d4_bytes_per_launch" if n_bands else "view_accum_d4_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -511,8 +517,10 @@ def main():
             "roofline": {
                 "kernel": ("band_plan_kernel<8,D4,linear> (fused d4 de-augment + mean + weighted blend of all covering tiles + "
                            f"normalisation over one group of bands; {n_bands} launches/image)" if n_bands else
-                           "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
-                           "normalisation, 8 tiles/launch)"),
+                           ("rank 0's whole step (band_plan_kernel launches over its tiles + partial-sum exchange + completion of the rows "
+                            "shared with neighbours): its tiles read once and its owned rows written once / step time" if sharded else
+                            "view_accum_kernel<CH,8,D4,linear> (fused d4 de-augment + mean + weighted accumulate + last-touch "
+                            "normalisation, 8 tiles/launch)")),
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,

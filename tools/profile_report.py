@@ -45,38 +45,43 @@ def short(name):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    # on the GPU box only gpurun_out/ travels back: PTB_PROFILE_OUT=gpurun_out/profiles writes the reports there (the raw
+    # databases can then be deleted on the box; they exceed the 64 MiB that is copied back)
+    outdir = os.environ.get("PTB_PROFILE_OUT") or os.path.join(ROOT, "profiles")
+    os.makedirs(outdir, exist_ok=True)
     ks = kernels(os.path.join(PROF, "trace", "run_results.db"))
     total = sum(d for v in ks.values() for d, _ in v)
-    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline", "",
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline", "",
              "| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for name, v in sorted(ks.items(), key=lambda kv: -sum(d for d, _ in kv[1])):
         d = [x for x, _ in v]
         lines.append(f"| `{short(name)}` | {len(d)} | {sum(d) / 1e6:.3f} | {sum(d) / len(d) / 1e3:.2f} | {min(d) / 1e3:.2f} | {max(d) / 1e3:.2f} | {100 * sum(d) / total:.1f} |")
-    band = [n for n in ks if "band_merge_kernel" in n]
+    band = [n for n in ks if "band_plan_kernel" in n and "6166440" in n]
     if band:
-        d = [x for x, _ in ks[band[0]]]
-        lines += ["", f"Dominant kernel `{short(band[0])}`: {len(d)} launches (20 per image: 18 bands of 38 tiles, the first and last of 19), "
-                      f"average {sum(d) / len(d) / 1e3:.2f} us over all of them, as in bench.py's roofline block."]
+        d = sorted(x for x, _ in ks[band[0]])
+        med = d[len(d) // 2]
+        full = [x for x in d if x > 0.5 * med]     # (the variants block also runs 256-row launches: they are listed, not averaged here)
+        lines += ["", f"Dominant kernel `{short(band[0])}`: {len(d)} launches, of which {len(full)} are the 1024-row launch groups of the headline "
+                      f"configuration (5 per image): average {sum(full) / len(full) / 1e3:.2f} us, as in bench.py's roofline block."]
     accum = [n for n in ks if "view_accum_kernel" in n]
     if accum:
         d = sorted(x for x, _ in ks[accum[0]])
         full = [x for x in d if x > 0.5 * d[len(d) // 2]]
         lines += ["", f"Dominant kernel `{short(accum[0])}`: {len(full)} full 8-tile launches, average {sum(full) / len(full) / 1e3:.2f} us "
                       f"(the {len(d) - len(full)} one-tile tail launches of each image are excluded, as in bench.py's roofline block)."]
-    open(os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+    open(os.path.join(outdir, f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
 
     rows = ["| kernel | counter | dispatches | avg per dispatch |", "|---|---|---|---|"]
     agg = {}
-    for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
+    for sub in ("FETCH_SIZE", "WRITE_SIZE", "FETCH_SIZE_cal", "WRITE_SIZE_cal", "TCC_HIT_sum", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT"):
         db = os.path.join(PROF, sub, "run_results.db")
         if not os.path.exists(db):
             continue
         for k, d in counters(db).items():
             for c, v in sorted(d.items()):
-                if c in ("FETCH_SIZE", "WRITE_SIZE") and "view_accum" in k:
+                if c in ("FETCH_SIZE", "WRITE_SIZE") and ("view_accum" in k or "band_plan" in k):
                     med = sorted(v)[len(v) // 2]
-                    v = [x for x in v if x > 0.5 * med]  # full launches only
+                    v = [x for x in v if x > 0.5 * med]  # full launches only (8-tile batches / 1024-row launch groups)
                 agg[(k, c)] = sum(v) / len(v)
                 rows.append(f"| `{short(k)}` | {c} | {len(v)} | {sum(v) / len(v):.1f} |")
     notes = ["", "HBM bytes per launch (FETCH_SIZE x 2 x 1024 + WRITE_SIZE x 1024; gfx950 correction from guides/MI355X_MICROARCH.md):", ""]
@@ -91,16 +96,16 @@ def main():
             traffic["view_accum_d4_bytes_per_launch"] = int(b)
             traffic["view_accum_d4_read_bytes"] = int(f * 2 * 1024)
             traffic["view_accum_d4_write_bytes"] = int(w * 1024)
-        if "band_merge_kernel" in k and "6166440" in k:
-            traffic["band_merge_d4_bytes_per_launch"] = int(b)
-            traffic["band_merge_d4_read_bytes"] = int(f * 2 * 1024)
-            traffic["band_merge_d4_write_bytes"] = int(w * 1024)
+        if "band_plan_kernel" in k and "6166440" in k:
+            traffic["band_plan_d4_bytes_per_launch"] = int(b)
+            traffic["band_plan_d4_read_bytes"] = int(f * 2 * 1024)
+            traffic["band_plan_d4_write_bytes"] = int(w * 1024)
         if "merge_div" in k:
             traffic["merge_bytes_per_launch"] = int(b)
             notes.append(f"  (calibration: the merge kernel must read 524 288 000 B and write 419 430 400 B; measured {f * 2 * 1024:.0f} / {w * 1024:.0f})")
-    open(os.path.join(ROOT, "profiles", f"{tag}_pmc.md"), "w").write(f"# {tag}: rocprofv3 --pmc <counter> --kernel-trace (one pass per counter group)\n\n" + "\n".join(rows + notes) + "\n")
+    open(os.path.join(outdir, f"{tag}_pmc.md"), "w").write(f"# {tag}: rocprofv3 --pmc <counter> --kernel-trace (one pass per counter group)\n\n" + "\n".join(rows + notes) + "\n")
     traffic["source"] = f"profiles/{tag}_pmc.md"
-    tj = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = os.path.join(outdir, "traffic.json")
     try:
         old = json.load(open(tj))      # keep what another run (the incremental merger, --no-defer) measured
     except Exception:
