@@ -163,6 +163,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_loss_grid_cap = value;
         return PTB_OK;
     }
+    if (key == 5) {
+        g_fused_pix2 = value ? 1 : 0;
+        return PTB_OK;
+    }
     return PTB_EINVAL;
 }
 

@@ -60,6 +60,8 @@ __device__ __forceinline__ void store_px(float* __restrict__ p, const float (&x)
     if (!ok) return;
     if constexpr (PIX == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    } else if constexpr (PIX == 2) {
+        *reinterpret_cast<float2*>(p) = make_float2(x[0], x[1]);
     } else {
 #pragma unroll
         for (int k = 0; k < PIX; ++k) p[k] = x[k];
@@ -190,6 +192,9 @@ __device__ __forceinline__ Group<PIX> make_group(long long g, long long per_img,
             const longlong2 a = *reinterpret_cast<const longlong2*>(lp);
             const longlong2 b2 = *reinterpret_cast<const longlong2*>(lp + 2);
             G.lab[0] = a.x; G.lab[1] = a.y; G.lab[2] = b2.x; G.lab[3] = b2.y;
+        } else if constexpr (PIX == 2) {
+            const longlong2 a = *reinterpret_cast<const longlong2*>(lp);
+            G.lab[0] = a.x; G.lab[1] = a.y;
         } else {
             G.lab[0] = lp[0];
         }

@@ -1631,6 +1631,8 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
 
 // ------------------------------------------------------------------------------------------------ host side
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
+int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
+                          // instead of 4 pixels: 163 VGPRs, 3 waves): 0.164-0.171 vs 0.173-0.186 ms per FocalDiceJaccardLoss forward at cfg4
 }  // namespace ptb
 
 using namespace ptb;
@@ -1678,7 +1680,8 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
                                  !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
         const dim3 lgrid(grid_for_groups(HW / 256 * B, kGridStats));
 #define PTB_LEAN(CR) do { \
-            if (plain_focal) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false>), lgrid, block, shmem, s, a); \
+            if (plain_focal) { if (g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2>), dim3(grid_for_groups(HW / 128 * B, kGridStats)), block, shmem, s, a); \
+                               else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false>), lgrid, block, shmem, s, a); } \
             else if (prob == PROB_SOFTMAX) { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, true>), lgrid, block, shmem, s, a); \
                                              else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, false>), lgrid, block, shmem, s, a); } \
             else { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_IDENTITY, false, true>), lgrid, block, shmem, s, a); \
@@ -1790,6 +1793,7 @@ static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix
     }
     if (vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
         const int grid = grid_for_groups((a.HW + 255) / 256 * a.B, kGridStream);
+        // (2 pixels per lane for the backward: 151 -> fewer VGPRs but the same 442 us forward + backward at cfg4: not used)
         if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else if (a.C <= 16) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else hipLaunchKernelGGL((softmax_focal_kernel<4, 0, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
