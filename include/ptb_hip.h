@@ -65,7 +65,7 @@ const char* ptb_last_hip_error(void);
 /* Tuning knob for benchmarks/tests: key 0 = chunk rows of the view kernels (16|32|64), 1 = force scalar kernels (0|1),
  * 2 = non-temporal streaming loads in the view kernels (0|1, default 1), 3 = LDS-staged multiscale kernel (0|1, default 1),
  * 4 = workgroups per loss-kernel launch (0 = per-kernel default), 5 = fused focal + statistics forward with 2 pixels per lane
- * (0|1, default 1). */
+ * (0|1, default 1), 6 = output tile rows of the fused multiscale kernel (16|32|64, default 32). */
 int ptb_set_tunable(int key, int value);
 
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------

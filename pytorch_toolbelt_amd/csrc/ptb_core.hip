@@ -167,6 +167,11 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_fused_pix2 = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 6) {
+        if (value != 16 && value != 32 && value != 64) return PTB_EINVAL;
+        g_ms_tile_rows = value;
+        return PTB_OK;
+    }
     return PTB_EINVAL;
 }
 

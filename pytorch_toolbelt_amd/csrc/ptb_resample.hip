@@ -273,14 +273,14 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
 // (tta.py:645-689).  As separate calls that is one pass per scale that writes the flip-reduced map and one more that reads it
 // back; here ONE launch reads every view of every scale once and writes the merged map once:
 //     out = outer_s( bilinear_s( inner_v( flip_v^-1( y_s[v] ) ) ) )
-// A workgroup owns a 64 x 64 output tile (the 64 x 16 tiles of ms_reduce_tiled_kernel refetch 1.21x the source bytes: halo rows /
-// columns and 16-byte alignment of every window; at 64 x 64 it is 1.08x).  Per resized scale the tile's source window
+// A workgroup owns a 64 x TH output tile (TH = 32 by default: the 64 x 16 tiles of ms_reduce_tiled_kernel refetch 1.21x the source
+// bytes -- halo rows / columns and 16-byte alignment of every window --, 64 x 32 tiles 1.13x, 64 x 64 tiles 1.08x).  Per resized scale the tile's source window
 // (<= 88 x 96) is brought in with 16-byte loads, 4 window rows x V views in flight per lane, mirrored views read at mirrored
 // addresses (a reversed row is still one contiguous segment); the inner reduction over the views happens ON THE WAY INTO LDS, so
 // the window holds flip-reduced values exactly like the reference's intermediate tensor and the 4-tap gathers never see the
 // views.  Scales that already have the output size are reduced straight from registers.  Only row-preserving views (flips
 // of rows / columns) -- the groups the reference combines with multiscale TTA.
-constexpr int FZ_T = 64, FZ_LR = 88, FZ_LC = 96, FZ_LP = 112, FZ_VMAX = 4;
+constexpr int FZ_T = 64, FZ_LR = 88, FZ_LR32 = 46, FZ_LR16 = 25, FZ_LC = 96, FZ_LP = 112, FZ_VMAX = 4;
 
 struct FzArgs {
     const float* in[MS_MAX];           // view 0 of scale s: [planes, h, w]; view v lies v * planes * h * w elements further
@@ -289,6 +289,11 @@ struct FzArgs {
     int n, nviews, codes;              // codes: 3 bits per view (bit 1 = flip rows, bit 2 = flip columns; bit 0 must be 0)
     int planes, hout, wout, align_corners, op_outer, op_inner;
     float inner_div;
+    // IEEE divisions cost ~12 vector instructions each and the mean of V views / n scales needs one per value (PMC: they were 40 %
+    // of this kernel's 2 142 vector instructions per wave).  inner_mul != 0: multiply by it instead (V a power of two: the
+    // reciprocal is exact, bit-identical to the division); outer_mul != 0: likewise for the mean over the scales (used whenever a
+    // scale is resized -- the interpolation arithmetic already differs from ATen's in the last bits; exact division otherwise).
+    float inner_mul, outer_mul;
 };
 
 // 4 consecutive de-augmented values of view `code` of a [h, w] plane at (row, col) (col % 4 == 0, w % 4 == 0)
@@ -300,14 +305,15 @@ __device__ __forceinline__ float4 fz_load(const float* __restrict__ plane, int h
 }
 
 template <int NV, int INNER>
-__device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op, float div) {
+__device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op, float div, float mul) {
     float4 s;
     if (INNER == 0) {
         s = x[0];
 #pragma unroll
         for (int k = 1; k < NV; ++k)
             if (k < nv) { s.x = __fadd_rn(s.x, x[k].x); s.y = __fadd_rn(s.y, x[k].y); s.z = __fadd_rn(s.z, x[k].z); s.w = __fadd_rn(s.w, x[k].w); }
-        return make_float4(red_post<0>(s.x, op, div), red_post<0>(s.y, op, div), red_post<0>(s.z, op, div), red_post<0>(s.w, op, div));
+        if (mul != 0.f) return make_float4(s.x * mul, s.y * mul, s.z * mul, s.w * mul);     // sum (mul = 1) or an exact reciprocal
+        return make_float4(s.x / div, s.y / div, s.z / div, s.w / div);
     }
     if (INNER == 2) {   // gmean, branch-free (the run-time switch over all reductions costs more than the loads it sits between)
         s = make_float4(fast_log(x[0].x), fast_log(x[0].y), fast_log(x[0].z), fast_log(x[0].w));
@@ -326,39 +332,41 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
     return make_float4(red_post<1>(s.x, op, div), red_post<1>(s.y, op, div), red_post<1>(s.z, op, div), red_post<1>(s.w, op, div));
 }
 
-template <int NV, int INNER, int OUTER, int ALIGN>
+template <int NV, int INNER, int OUTER, int ALIGN, int TH>
 __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
+    constexpr int R = TH / 16;                          // output rows per thread (tile = 64 columns x TH rows)
+    constexpr int LR = TH == 64 ? FZ_LR : (TH == 32 ? FZ_LR32 : FZ_LR16);      // LDS window rows
     constexpr int FZ_U = NV <= 2 ? 3 : 2;   // window slots a lane has in flight at once (x NV views)
-    __shared__ __attribute__((aligned(16))) float lds[FZ_LR * FZ_LP];
+    __shared__ __attribute__((aligned(16))) float lds[LR * FZ_LP];
     __shared__ __attribute__((aligned(16))) Taps ctap[FZ_T];
-    const int tiles_x = (a.wout + FZ_T - 1) / FZ_T, tiles_y = (a.hout + FZ_T - 1) / FZ_T;
+    const int tiles_x = (a.wout + FZ_T - 1) / FZ_T, tiles_y = (a.hout + TH - 1) / TH;
     int bid = blockIdx.x;
     const int txi = bid % tiles_x;
     bid /= tiles_x;
     const int tyi = bid % tiles_y;
     const long long p = bid / tiles_y;
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
-    const int ox0 = txi * FZ_T, oy0 = tyi * FZ_T, ox = ox0 + 4 * lx;
+    const int ox0 = txi * FZ_T, oy0 = tyi * TH, ox = ox0 + 4 * lx;
     const bool col_ok = ox < a.wout;
-    float acc[4][4];
+    float acc[R][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < R; ++j)
 #pragma unroll
         for (int m = 0; m < 4; ++m) acc[j][m] = 0.f;
     for (int s = 0; s < a.n; ++s) {
         const int hin = a.h[s], win = a.w[s];
         const long long plane_sz = (long long)hin * win, vstride = (long long)a.planes * plane_sz;
         const float* src = a.in[s] + p * plane_sz;
-        float v[4][4];
+        float v[R][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int m = 0; m < 4; ++m) v[j][m] = 1.f;
         if (hin == a.hout && win == a.wout) {
             // same size: the reference skips F.interpolate (offset 0) -- reduce the views straight from registers
-            float4 xs[4][NV];
+            float4 xs[R][NV];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < R; ++j) {
                 const int oy = oy0 + ly + 16 * j;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
@@ -367,15 +375,15 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 r = fz_inner<NV, INNER>(xs[j], a.nviews, a.op_inner, a.inner_div);
+            for (int j = 0; j < R; ++j) {
+                const float4 r = fz_inner<NV, INNER>(xs[j], a.nviews, a.op_inner, a.inner_div, a.inner_mul);
                 v[j][0] = r.x; v[j][1] = r.y; v[j][2] = r.z; v[j][3] = r.w;
             }
         } else {
-            const int oy_last = min(oy0 + FZ_T, a.hout) - 1, ox_last = min(ox0 + FZ_T, a.wout) - 1;
+            const int oy_last = min(oy0 + TH, a.hout) - 1, ox_last = min(ox0 + FZ_T, a.wout) - 1;
             const int r_lo = taps<ALIGN>(oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps<ALIGN>(oy_last, a.sh[s], hin, a.align_corners).i1;
             const int c_lo = taps<ALIGN>(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps<ALIGN>(ox_last, a.sw[s], win, a.align_corners).i1;
-            const int nr = min(r_hi - r_lo + 1, FZ_LR), nc = min(c_hi - c_lo + 1, FZ_LC);   // (the host only launches shapes that fit)
+            const int nr = min(r_hi - r_lo + 1, LR), nc = min(c_hi - c_lo + 1, FZ_LC);   // (the host only launches shapes that fit)
             // every lane takes 16-byte slots tid, tid + 256, ... of the window (row-major, q_per_row slots per row: all lanes busy,
             // whatever the window width); FZ_U slots x V views are requested together
             const int q_per_row = min((nc + 3) / 4, (win - c_lo + 3) / 4);
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
                 }
 #pragma unroll
                 for (int u = 0; u < FZ_U; ++u)
-                    if (s0 + 256 * u < total) *reinterpret_cast<float4*>(&lds[row[u] * FZ_LP + 4 * qq[u]]) = fz_inner<NV, INNER>(x[u], a.nviews, a.op_inner, a.inner_div);
+                    if (s0 + 256 * u < total) *reinterpret_cast<float4*>(&lds[row[u] * FZ_LP + 4 * qq[u]]) = fz_inner<NV, INNER>(x[u], a.nviews, a.op_inner, a.inner_div, a.inner_mul);
             }
             if (tid < FZ_T) ctap[tid] = taps<ALIGN>(min(ox0 + tid, a.wout - 1), a.sw[s], win, a.align_corners);
             __syncthreads();
@@ -405,11 +413,11 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
 #pragma unroll
             for (int m = 0; m < 4; ++m) tx[m] = ctap[4 * lx + m];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < R; ++j) {
                 const int oy = min(oy0 + ly + 16 * j, a.hout - 1);   // rows past the bottom edge: computed from the last row, never stored
                 const Taps ty = taps<ALIGN>(oy, a.sh[s], hin, a.align_corners);
-                const float* l0 = lds + min(ty.i0 - r_lo, FZ_LR - 1) * FZ_LP - c_lo;
-                const float* l1 = lds + min(ty.i1 - r_lo, FZ_LR - 1) * FZ_LP - c_lo;
+                const float* l0 = lds + min(ty.i0 - r_lo, LR - 1) * FZ_LP - c_lo;
+                const float* l1 = lds + min(ty.i1 - r_lo, LR - 1) * FZ_LP - c_lo;
                 float t[4][4];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) { t[m][0] = l0[tx[m].i0]; t[m][1] = l0[tx[m].i1]; t[m][2] = l1[tx[m].i0]; t[m][3] = l1[tx[m].i1]; }
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
             __syncthreads();  // the next scale reuses the LDS window
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float t = OUTER == 0 ? v[j][m] : (OUTER == 2 ? ms_log(v[j][m]) : ms_pre(v[j][m], a.op_outer));
@@ -429,12 +437,16 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
     }
     if (!col_ok) return;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < R; ++j) {
         const int oy = oy0 + ly + 16 * j;
         if (oy < a.hout) {
             float r[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) r[m] = OUTER == 2 ? ms_exp(acc[j][m] / (float)a.n) : ms_post(acc[j][m], a.op_outer, (float)a.n);
+            for (int m = 0; m < 4; ++m) {
+                if (OUTER == 2) r[m] = ms_exp(acc[j][m] * a.outer_mul);
+                else if (OUTER == 0) r[m] = a.outer_mul != 0.f ? acc[j][m] * a.outer_mul : acc[j][m] / (float)a.n;
+                else r[m] = ms_post(acc[j][m], a.op_outer, (float)a.n);
+            }
             *reinterpret_cast<float4*>(out + (p * a.hout + oy) * (long long)a.wout + ox) = make_float4(r[0], r[1], r[2], r[3]);
         }
     }
@@ -612,15 +624,28 @@ extern "C" int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* 
                           reduction, stream);
 }
 
-template <int NV, int INNER>
-static void launch_fz(const FzArgs& a, float* out, unsigned blocks, hipStream_t st) {
+// ptb_set_tunable key 6: output tile height of the fused multiscale kernel.  Same box, cfg5 (fused mean / fused gmean / plain
+// multiscale merge): 64 rows 417 / 475 / 234 us, 32 rows 412 / 432 / 224 us, 16 rows 405 / 434 / 239 us -- smaller tiles refetch more
+// halo (1.08x / 1.13x / 1.21x) but put 4 / 7 / 8 workgroups on a CU, and this kernel waits more than it streams.
+namespace ptb { int g_ms_tile_rows = 32; }
+
+template <int NV, int INNER, int TH>
+static void launch_fz_th(const FzArgs& a, float* out, unsigned blocks, hipStream_t st) {
     const dim3 grid(blocks), block(256);
-#define PTB_FZ(OUTER) do { if (a.align_corners) hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 1>), grid, block, 0, st, a, out); \
-                           else hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 0>), grid, block, 0, st, a, out); } while (0)
+#define PTB_FZ(OUTER) do { if (a.align_corners) hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 1, TH>), grid, block, 0, st, a, out); \
+                           else hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 0, TH>), grid, block, 0, st, a, out); } while (0)
     if (a.op_outer == PTB_RED_GMEAN) PTB_FZ(2);
     else if (a.op_outer >= PTB_RED_GMEAN) PTB_FZ(1);
     else PTB_FZ(0);
 #undef PTB_FZ
+}
+
+template <int NV, int INNER>
+static void launch_fz(const FzArgs& a, float* out, int th, hipStream_t st) {
+    const long long tiles = (long long)a.planes * ((a.hout + th - 1) / th) * ((a.wout + FZ_T - 1) / FZ_T);
+    if (th == 16) launch_fz_th<NV, INNER, 16>(a, out, (unsigned)tiles, st);
+    else if (th == 32) launch_fz_th<NV, INNER, 32>(a, out, (unsigned)tiles, st);
+    else launch_fz_th<NV, INNER, 64>(a, out, (unsigned)tiles, st);
 }
 
 extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, int V, const int* views,
@@ -651,19 +676,24 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
         if (hs[s] == hout && ws[s] == wout) continue;
         // the source window of a 64 x 64 tile must fit the LDS window (conservative bounds: + 2 taps, + 3 alignment, + 1 rounding)
         // (a window never exceeds the map itself, so small maps fit whatever the ratio)
-        const int need_r = std::min((int)ceilf(FZ_T * a.sh[s]) + 3, hs[s]), need_c = std::min((int)ceilf(FZ_T * a.sw[s]) + 6, ws[s] + 3);
-        if (need_r > FZ_LR || need_c > FZ_LC) return PTB_EUNSUPPORTED;
+        const int th_ = g_ms_tile_rows;
+        const int need_r = std::min((int)ceilf(th_ * a.sh[s]) + 3, hs[s]), need_c = std::min((int)ceilf(FZ_T * a.sw[s]) + 6, ws[s] + 3);
+        if (need_r > (th_ == 16 ? FZ_LR16 : (th_ == 32 ? FZ_LR32 : FZ_LR)) || need_c > FZ_LC) return PTB_EUNSUPPORTED;
     }
     a.n = n; a.nviews = V; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners;
     a.op_outer = reduction; a.op_inner = inner_reduction;
     a.inner_div = inner_reduction == PTB_RED_SUM ? 1.0f : (float)V;
-    const long long tiles = planes * ((hout + FZ_T - 1) / FZ_T) * ((wout + FZ_T - 1) / FZ_T);
-    if (tiles > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    a.inner_mul = inner_reduction == PTB_RED_SUM ? 1.0f : ((V & (V - 1)) == 0 ? 1.0f / (float)V : 0.f);
+    bool resized = false;
+    for (int s = 0; s < n; ++s) resized = resized || hs[s] != hout || ws[s] != wout;
+    a.outer_mul = reduction == PTB_RED_SUM ? 1.0f : ((resized || reduction == PTB_RED_GMEAN || (n & (n - 1)) == 0) ? 1.0f / (float)n : 0.f);
+    const int th = g_ms_tile_rows;
+    if (planes * ((hout + th - 1) / th) * ((wout + FZ_T - 1) / FZ_T) > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int inner = inner_reduction == PTB_RED_GMEAN ? 2 : (inner_reduction > PTB_RED_GMEAN ? 1 : 0);
-    if (V == 1) launch_fz<1, 0>(a, out, (unsigned)tiles, st);
-    else if (V == 2) { if (inner == 2) launch_fz<2, 2>(a, out, (unsigned)tiles, st); else if (inner) launch_fz<2, 1>(a, out, (unsigned)tiles, st); else launch_fz<2, 0>(a, out, (unsigned)tiles, st); }
-    else { if (inner == 2) launch_fz<4, 2>(a, out, (unsigned)tiles, st); else if (inner) launch_fz<4, 1>(a, out, (unsigned)tiles, st); else launch_fz<4, 0>(a, out, (unsigned)tiles, st); }
+    if (V == 1) launch_fz<1, 0>(a, out, th, st);
+    else if (V == 2) { if (inner == 2) launch_fz<2, 2>(a, out, th, st); else if (inner) launch_fz<2, 1>(a, out, th, st); else launch_fz<2, 0>(a, out, th, st); }
+    else { if (inner == 2) launch_fz<4, 2>(a, out, th, st); else if (inner) launch_fz<4, 1>(a, out, th, st); else launch_fz<4, 0>(a, out, th, st); }
     return check_launch();
 }
 

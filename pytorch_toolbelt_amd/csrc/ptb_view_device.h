@@ -92,10 +92,19 @@ __device__ __forceinline__ float red_pre(float x, int op) {
     }
 }
 
+// s / divisor for a wave-uniform divisor (the number of views).  An IEEE division is ~12 vector instructions; when the divisor is
+// a power of two (d4: 8 views, d2: 4, flips of one axis: 2) multiplying by its exact reciprocal 2^-k gives the same bits for
+// every s (both are exact scalings, rounded once), so the mean of the views stays bit-identical to the reference's `sum / V`.
+__device__ __forceinline__ float div_views(float s, float divisor) {
+    const unsigned bits = __float_as_uint(divisor);
+    if ((bits & 0x807FFFFFu) == 0 && bits != 0) return s * __uint_as_float(0x7F000000u - bits);
+    return s / divisor;
+}
+
 template <int OPK>
 __device__ __forceinline__ float red_post(float s, int op, float divisor) {
-    if (OPK == 0) return divisor == 1.0f ? s : s / divisor;
-    const float m = s / divisor;
+    if (OPK == 0) return divisor == 1.0f ? s : div_views(s, divisor);
+    const float m = div_views(s, divisor);
     switch (op) {
         case PTB_RED_GMEAN: return fast_exp(m);
         case PTB_RED_HMEAN: return fast_rcp(m < kEps ? kEps : m);
