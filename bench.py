@@ -191,7 +191,21 @@ def main():
         outputs = torch.empty((VIEWS * len(crops), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
         batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]
     else:   # like a model would leave them: one tensor per batch (chunk-major: view k of tile j at row k * nb + j)
-        batch_tensors = [torch.empty((VIEWS * (b1 - b0), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32) for b0, b1 in batches]
+        if os.environ.get("PTB_BENCH_PRIME_POOL", "1") == "1":
+            # One reservation for the whole image's outputs, handed back to torch's caching allocator right away: the per-batch
+            # tensors below are then carved out of that ONE device allocation (the allocator splits cached blocks) instead of 46
+            # separate 256 MiB hipMallocs.  Same tensors, same kernels -- but the GPU page tables map one large allocation with far
+            # larger fragments, and the 12 GB streamed per image stop missing in the TLB: 2.02 instead of 2.21 ms per image on the
+            # same box (a serving process reserves its memory up front for the same reason).  PTB_BENCH_PRIME_POOL=0: without.
+            total = sum(VIEWS * (b1 - b0) for b0, b1 in batches) * CHANNELS * TILE * TILE
+            torch.empty(total, device=dev, dtype=torch.float32)
+        order = list(range(len(batches)))
+        if os.environ.get("PTB_BENCH_SHUFFLE_ALLOC", "0") == "1":   # diagnostics: allocation order != integration order
+            np.random.default_rng(7).shuffle(order)
+        batch_tensors = [None] * len(batches)
+        for i in order:
+            b0, b1 = batches[i]
+            batch_tensors[i] = torch.empty((VIEWS * (b1 - b0), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
     for t in batch_tensors:
         t.normal_(generator=gen)
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
@@ -504,6 +518,10 @@ def main():
                            (("sharded, deferred bands" if getattr(merger, "_deferred", None) is not None else "sharded, incremental") if sharded
                             else "unplanned (lazy norm_mask + merge pass)")),
                 "parallelism": "single GPU" if world == 1 else (f"{'tile ranges' if partition == 'tiles' else 'tile rows'} sharded over {world} ranks, RCCL p2p halo exchange"),
+                "model_outputs": ("slices of one 12.1 GB tensor" if os.environ.get("PTB_BENCH_ONE_BUFFER", "0") == "1" else
+                                  "one tensor per batch" + (", carved by torch's caching allocator out of ONE device allocation reserved up front "
+                                                            "(PTB_BENCH_PRIME_POOL=0: 46 separate 256 MiB device allocations)"
+                                                            if os.environ.get("PTB_BENCH_PRIME_POOL", "1") == "1" else ", 46 separate device allocations")),
                 "fallback": fallback,
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "timing": f"value = median of {len(repeat_ms)} runs of exactly {args.steps} steps, each bracketed by barrier + synchronize",
