@@ -326,7 +326,9 @@ class _Plan:
                                          xy[1].ctypes.data_as(N._i64p), xy.shape[1], th, tw, H, W, None, 0, N.stream_ptr(dev))
         N.bump()
         N.check(rc, "TileMerger(crops=...)")
-        return _Plan(xy, remaining.astype(np.uint8), norm_full)
+        plan = _Plan(xy, remaining.astype(np.uint8), norm_full)
+        plan.crops4 = np.ascontiguousarray(crops, dtype=np.int64)     # the planned (x, y, w, h) rows, for the deferred fast path
+        return plan
 
     def restart(self):
         self.remaining = self.remaining0.copy()
@@ -450,6 +452,8 @@ class TileMerger:
         self._merged = None       # planned mode: the merge result the accumulate launches fill in
         self._plan = _Plan.build(self, crops) if crops is not None else None
         self._bands = None
+        self._fast_cache = {}
+        self.fast_submits = 0     # deferred batches that took the cached host path (diagnostic)
         if crops is not None and self._plan is None:
             _warn_once(("plan", tuple(self.weight.shape), self.image_height, self.image_width),
                        "TileMerger(crops=...): this geometry is off the 64 x 32 block grid of the planned kernels (tile size / origins); "
@@ -752,7 +756,56 @@ class TileMerger:
         """Accumulate ``[B, C, h, w]`` predictions at ``crop_coords[b] = (x, y, w, h)``."""
         if len(batch) != len(crop_coords):
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        if self._defer_active and self._defer_fast(batch, crop_coords, None, None, N.RED_SUM):
+            return
         self._accumulate(self._prep(batch), _coords_xy(crop_coords), None, N.RED_SUM)
+
+    def _defer_fast(self, batch, crop_coords, key, views, code):
+        """Deferred mode, the common call: a contiguous model output on this device for exactly the next planned crops (a numpy
+        slice of ``tiler.crops``).  Everything constant per merger / per (group, reduction) is cached, the rest is one C call
+        (``ptb_band_plan_submit``): ~10 us of host time instead of ~20.  False: the general path decides (and reports)."""
+        plan = self._plan
+        if not (self._defer_active and plan.active and not self._eager_norm and type(crop_coords) is np.ndarray and crop_coords.ndim == 2 and crop_coords.dtype == np.int64
+                and batch.is_cuda and batch.is_contiguous() and not batch.requires_grad):
+            return False
+        dcode = N.DTYPE_CODES.get(batch.dtype)
+        B, pos = crop_coords.shape[0], plan.pos
+        if dcode is None or B == 0 or batch.device != self._image.device or not np.array_equal(crop_coords, plan.crops4[pos:pos + B]):
+            return False
+        cache = self._fast_cache
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = (N.int_array(list(views)) if views is not None else N.int_array([N.IDENT]), len(views) if views is not None else 1)
+        varr, n_views = ent
+        th, tw = self.weight.shape[1], self.weight.shape[2]
+        if batch.shape != (B * n_views, self.channels, th, tw):
+            return False
+        if self._merged is None:
+            self._merged = torch.empty_like(self._image)
+        per_tile = self.channels * th * tw
+        dev = self._image.device
+        bands = self._bands
+        with N.on_device(dev):
+            rc = N.load().ptb_band_plan_submit(bands.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, dcode, n_views, varr, code,
+                                               self._merged.data_ptr(), plan.norm_full.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
+        N.bump()
+        if rc < 0:
+            if rc == N.PTB_EUNSUPPORTED:
+                return False       # (nothing was launched: the general path warns and replays)
+            N.check(rc, "TileMerger.integrate_batch (deferred bands)")
+        self._held.append((batch, crop_coords, views, code, int(bands.last_group[pos:pos + B].max())))
+        plan.pos = pos + B
+        self.fast_submits += 1
+        self._log.append(np.ascontiguousarray(crop_coords[:, :2].T))
+        if rc:
+            done = self._bands_done = self._bands_done + rc
+            if done == len(bands.bands):
+                self._held.clear()
+            elif bands.monotone:
+                held = self._held
+                while held and held[0][4] < done:
+                    held.pop(0)
+        return True
 
     def integrate_batch_deaugment(self, batch: torch.Tensor, crop_coords, group: str = "d4", reduction="mean"):
         """Fused ``integrate_batch(tta.<group>_image_deaugment(batch, reduction), crop_coords)``.
@@ -763,6 +816,10 @@ class TileMerger:
         from .tta import DEAUGMENT_VIEWS, _reduction_code
 
         views = DEAUGMENT_VIEWS[group]
+        if self._defer_active and type(reduction) is str:
+            code = _reduction_code(reduction)
+            if code is not None and self._defer_fast(batch, crop_coords, (group, code), views, code):
+                return
         if len(batch) != len(crop_coords) * len(views):
             raise ValueError("Number of images in batch does not correspond to number of coordinates x views")
         code = _reduction_code(reduction)

@@ -635,6 +635,7 @@ def test_deferred_band_merge_is_bit_identical(shape, tile, step, C, group, reduc
     assert m._bands is not None and m._bands_done == len(m._bands.bands) and m._defer_active   # the deferred path did run
     assert not m._held                                                                          # and let go of every batch
     assert N.fresh_fallbacks == before
+    assert m.fast_submits > 0, "the cached host path of the deferred merger was not taken"
 
 
 def test_deferred_merger_fallbacks_and_restrictions(dev):
