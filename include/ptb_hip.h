@@ -65,7 +65,8 @@ const char* ptb_last_hip_error(void);
 /* Tuning knob for benchmarks/tests: key 0 = chunk rows of the view kernels (16|32|64), 1 = force scalar kernels (0|1),
  * 2 = non-temporal streaming loads in the view kernels (0|1, default 1), 3 = LDS-staged multiscale kernel (0|1, default 1),
  * 4 = workgroups per loss-kernel launch (0 = per-kernel default), 5 = fused focal + statistics forward with 2 pixels per lane
- * (0|1, default 1), 6 = output tile rows of the fused multiscale kernel (16|32|64, default 32). */
+ * (0|1, default 1), 6 = output tile rows of the fused multiscale kernel (16|32|64, default 32),
+ * 7 = softmax focal backward that keeps the per-class terms in registers: pixels per lane (0 = off | 2 | 4, default 4). */
 int ptb_set_tunable(int key, int value);
 
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------
@@ -315,6 +316,7 @@ int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const in
 #define PTB_SEG_REDUCED 16         /* reduced focal loss with `threshold` */
 #define PTB_SEG_MASK_FOCAL_TERM 32 /* normalized focal: ignored elements add 0 to sums[1] (functional.py:90-98) */
 #define PTB_SEG_ELEMWISE 64        /* also write the unreduced focal loss to elem_out [B, C, HW] */
+#define PTB_SEG_NO_TERM 128       /* the caller will not read sums[1] (no normalized=True): kernels may leave it unset */
 /* prob (activation used for the region statistics): */
 #define PTB_PROB_SOFTMAX 0         /* log_softmax(dim=1).exp()  (dice.py:68-72 multiclass) */
 #define PTB_PROB_SIGMOID 1         /* logsigmoid.exp()          (dice.py:73-75 binary / multilabel) */

@@ -19,6 +19,7 @@ enum {
     SEG_REDUCED = 16,          // reduced focal loss (threshold)
     SEG_MASK_FOCAL_TERM = 32,  // normalised focal: ignored elements contribute 0 to sums[1]
     SEG_ELEMWISE = 64,         // also write the per-element focal loss
+    SEG_NO_TERM = 128,         // the caller will not read sums[1] (focal loss without normalized=True): kernels may skip it
 };
 enum { PROB_SOFTMAX = 0, PROB_SIGMOID = 1, PROB_IDENTITY = 2 };
 

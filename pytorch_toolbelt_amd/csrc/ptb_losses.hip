@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
 // their loads are guarded), and no control flow diverges: about 8 (statistics) / 20 (+ focal) vector instructions per
 // element (2 pixels per lane, 98 VGPRs, measured the same as 4: 105 vs 106 us).  T_c is a label count: taken per WAVE from the compare mask the class loop needs anyway (s_bcnt1 on the scalar
 // unit).  FOCAL shares the exp with the softmax as described at `share` above, with the same exact redo of extreme elements.
-template <int CREG, int PROB, bool FOCAL, bool IGN, int PIX = 4>
+template <int CREG, int PROB, bool FOCAL, bool IGN, int PIX = 4, bool TERM = true, bool FULL = false>   // FULL: C == CREG
 __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const SegArgs a) {
     static_assert(!FOCAL || PROB == PROB_SOFTMAX, "the shared exp needs the softmax numerators");
     extern __shared__ float lds[];  // [4 waves][3][C]
@@ -252,15 +252,22 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
             for (int k = 0; k < PIX; ++k) xv[c][k] = pad;
             if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], true);
         }
-        float inv[PIX], em[PIX], mx[PIX];
-        bool redo_all[PIX], redo[PIX];
+        float inv[PIX], em[PIX];
+        // FOCAL: the class loop below is exact only while every sigmoid and its complement stay normal fp32 numbers when formed
+        // as u / (u + em), em / (u + em): all logits of the lane's pixels in [-80, 60] (then u = exp(x - m) >= e^-140 / e^-80 ... is
+        // covered by x - m >= -80 as well).  A wave holding anything else redoes its focal sums from the re-read logits with the
+        // generic formula (never on sane logits); the region statistics need no such care.
+        bool tame = true;
 #pragma unroll
         for (int k = 0; k < PIX; ++k) {
-            inv[k] = 1.0f; em[k] = 1.0f; mx[k] = 0.f; redo_all[k] = false; redo[k] = false;
+            inv[k] = 1.0f; em[k] = 1.0f;
             if (PROB == PROB_SOFTMAX) {
-                float m = xv[0][k];
+                float m = xv[0][k], lo = xv[0][k];
 #pragma unroll
-                for (int c = 1; c < CREG; ++c) m = fmaxf(m, xv[c][k]);
+                for (int c = 1; c < CREG; ++c) {
+                    m = fmaxf(m, xv[c][k]);
+                    if (FOCAL) lo = fminf(lo, (FULL || c < C) ? xv[c][k] : lo);   // (the padding is -inf)
+                }
                 const float M = m * kLog2e;
                 float d = 0.f;
 #pragma unroll
@@ -272,13 +279,11 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
                 inv[k] = rcp(d);
                 if (FOCAL) {
                     em[k] = ex2(-M);
-                    mx[k] = m;
-                    redo_all[k] = !(fabsf(m) <= 60.f);
-                    redo[k] = redo_all[k];
+                    tame = tame && (m <= 60.f) && (lo >= -80.f) && (lo - m >= -80.f);
                 }
             }
         }
-        float lsum = 0.f, fsum = 0.f;
+        float lsum = 0.f, fsum = 0.f;    // lsum: sum of f * log2(p_t), scaled by -ln 2 once per group
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
 #pragma unroll
@@ -290,11 +295,8 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
                     const float ps = u * r, qs = em[k] * r;                  // sigmoid(x), 1 - sigmoid(x)
                     const float pt = hit ? ps : qs, omp = hit ? qs : ps;
                     const float f = omp * omp;
-                    const float l = f * (-lg2(pt) * kLn2);
-                    const bool skip = redo_all[k] || (hit && ps < 1e-36f);
-                    redo[k] = redo[k] || skip;
-                    lsum += skip ? 0.f : l;
-                    fsum += skip ? 0.f : f;
+                    lsum = __builtin_fmaf(f, lg2(pt), lsum);
+                    if (TERM) fsum += f;
                 }
                 const float pm = (IGN && !valid[k]) ? 0.f : u;
                 aP[c] = __builtin_fmaf(pm, inv[k], aP[c]);
@@ -303,19 +305,14 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
             }
         }
         if (FOCAL) {
-            bool any_redo = false;
-#pragma unroll
-            for (int k = 0; k < PIX; ++k) any_redo = any_redo || redo[k];
-            if (__any(any_redo)) {   // exact redo from re-read logits (never on sane logits)
+            lsum *= -kLn2;
+            if (__any(!tame)) {   // the whole wave: exact sums from the re-read logits
                 const FocalCfg cfg = focal_cfg(a);
+                lsum = 0.f; fsum = 0.f;
 #pragma unroll
-                for (int k = 0; k < PIX; ++k) {
-                    if (!redo[k]) continue;
-                    for (int c = 0; c < C; ++c) {
-                        if (!redo_all[k] && c != lab[k]) continue;
+                for (int k = 0; k < PIX; ++k)
+                    for (int c = 0; c < C; ++c)
                         lsum += focal_one<true>(a.logits[base + (long long)c * a.HW + k], lab[k] == c ? 1.f : 0.f, false, 1.0f, cfg, fsum);
-                    }
-                }
             }
             f_loss += (double)lsum;
             f_term += (double)fsum;
@@ -1214,8 +1211,8 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
             }
             // Fast path (wave-uniform): keep u = exp(x - m) in the registers instead of x -- the softmax probability is
             // u / d, and with em = exp(-m) the sigmoid the BCE term needs is u / (u + em), 1 - sigmoid = em / (u + em), BCE =
-            // -log of one of the two: one exp per element instead of one per element and pass plus a sigmoid.  Needs em and
-            // every u + em inside the fp32 range: |m| <= 60 and x - m >= -80 for all classes, else the wave takes the exact path.
+            // -log of one of the two: one exp per element instead of one per element and pass plus a sigmoid.  Needs u, em and
+            // both quotients to be normal fp32 numbers: every logit in [-80, 60] and x - m >= -80, else the wave takes the exact path.
             bool tame = true;
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
@@ -1223,7 +1220,7 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
 #pragma unroll
                 for (int c = 0; c < CREG; ++c) if (c < C) { m = fmaxf(m, xr[c][k]); lo = fminf(lo, xr[c][k]); }
                 mx[k] = m;
-                tame = tame && (fabsf(m) <= 60.f) && (lo - m >= -80.f);
+                tame = tame && (m <= 60.f) && (lo >= -80.f) && (lo - m >= -80.f);   // every sigmoid and its complement a normal fp32 number
             }
             fast = !__any(!tame);
 #pragma unroll
@@ -1369,6 +1366,106 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
     if (MODE == 0) block_add2(s_loss, s_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * 2, lane, wave);
 }
 
+// Backward for C <= CREG with ONE evaluation of the transcendental terms: with A_c = p_c w_c bce_c df_c, D_c = p_c df_c and
+// F_c = w_c f_c (sigmoid(x_c) - t_c) the gradient above is  grad_c = T_c - p_c S,  T_c = g1 (A_c + F_c) + k2 D_c,
+// S = g1 sum_c A_c + k2 sum_c D_c.  Pass 1 leaves T_c in registers next to u_c = exp(x_c - m) (2 x CREG x PIX values), pass 2 is one
+// fma and the store: exp + rcp + log per element instead of exp + 2 (rcp + log).  The exact (non-"tame") waves keep x_c and pay
+// one more exp in pass 2.
+template <int PIX, int CREG, bool G2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? (G2 ? 4 : 3) : 2))) void softmax_focal_bwd_kernel(const SmfArgs a, const float* __restrict__ coef,
+                                                                const float* __restrict__ grad_pix, float* __restrict__ grad) {
+    const float thr = a.reduced ? a.threshold : -INFINITY, sc = a.reduced ? 1.0f / a.threshold : 1.0f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int C = a.C;
+    const float k1 = coef[0], k2 = coef[1];
+    const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
+    const long long groups = per_img * a.B;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+        const Group<PIX> G = make_group<PIX>(g, per_img, lane, a.HW, a.labels, true, a.ignore_label, C, nullptr);
+        if (!G.ok) continue;
+        const long long base = (long long)G.b * C * a.HW + G.i0;
+        float mx[PIX], inv[PIX], em[PIX], S[PIX], g1[PIX];
+        int tg[PIX];
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) { g1[k] = 1.f; tg[k] = G.ign[k] ? 0 : (int)G.lab[k]; }   // masked_fill(target, ignore, 0), functional.py:139
+        if (grad_pix) load_px<PIX>(grad_pix + (long long)G.b * a.HW + G.i0, g1, true);
+        float xr[CREG][PIX], T[CREG][PIX];
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) xr[c][k] = 0.f;
+            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xr[c], true);
+        }
+        bool tame = true;
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            float m = -INFINITY, lo = INFINITY;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) if (c < C) { m = fmaxf(m, xr[c][k]); lo = fminf(lo, xr[c][k]); }
+            mx[k] = m;
+            tame = tame && (m <= 60.f) && (lo >= -80.f) && (lo - m >= -80.f);   // every sigmoid and its complement a normal fp32 number
+            g1[k] = G.ign[k] ? 0.f : k1 * g1[k];
+            S[k] = 0.f;
+        }
+        const bool fast = !__any(!tame);
+#pragma unroll
+        for (int k = 0; k < PIX; ++k) {
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) if (c < C) {
+                const float u = fexp(xr[c][k] - mx[k]);
+                d += u;
+                if (fast) xr[c][k] = u;
+            }
+            inv[k] = rcp(d);
+            em[k] = fexp(-mx[k]);
+        }
+        auto pass1 = [&](int c, auto fast_tag) {
+            constexpr bool FAST = decltype(fast_tag)::value;
+            const float w = a.class_weights ? a.class_weights[c] : 1.f;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                const float x = xr[c][k];                         // FAST: u = exp(logit - m)
+                const bool is_t = c == tg[k];
+                const float t = is_t ? 1.f : 0.f;
+                float p, bce, smt;
+                if constexpr (FAST) {
+                    p = x * inv[k];
+                    const float r = rcp(x + em[k]);
+                    const float ps = x * r, qs = em[k] * r;
+                    bce = -lg2(is_t ? ps : qs) * kLn2;
+                    smt = is_t ? -qs : ps;
+                } else {
+                    p = fexp(x - mx[k]) * inv[k];
+                    const Sig sg = sigmoid_parts(x);
+                    bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
+                    smt = sg.p - t;
+                }
+                const float pt = is_t ? 1.f - p : p;
+                const float df = smf_dterm<G2>(pt, t, a, sc, thr);
+                const float f = smf_term<G2>(pt, a, sc, thr);
+                const float D = p * df;
+                const float A = D * (w * bce);
+                const float v = g1[k] * A + k2 * D;
+                S[k] += v;
+                T[c][k] = v + g1[k] * (w * f * smt);
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) if (c < C) { if (fast) pass1(c, std::true_type{}); else pass1(c, std::false_type{}); }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) if (c < C) {
+            float out[PIX];
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {
+                const float p = (fast ? xr[c][k] : fexp(xr[c][k] - mx[k])) * inv[k];
+                out[k] = T[c][k] - p * S[k];
+            }
+            store_px<PIX>(grad + base + (long long)c * a.HW, out, true);
+        }
+    }
+}
+
 // Straight-line instances of the softmax focal loss for the common case (C <= CREG padded with -inf, HW % 256 == 0, gamma = 2,
 // no class weights, no reduced threshold; see seg_fwd_lean_kernel).  u = exp(x - m) stays in the registers; the BCE term's
 // sigmoid comes from u and em = exp(-m) like in the wave-uniform fast path of softmax_focal_kernel, and a wave that holds a
@@ -1418,7 +1515,7 @@ __global__ __launch_bounds__(256, 3) void softmax_focal_lean_kernel(const SmfArg
 #pragma unroll
             for (int c = 1; c < CREG; ++c) { m = fmaxf(m, xv[c][k]); lo = (c < C) ? fminf(lo, xv[c][k]) : lo; }
             mx[k] = m;
-            tame = tame && (fabsf(m) <= 60.f) && (lo - m >= -80.f);
+            tame = tame && (m <= 60.f) && (lo >= -80.f) && (lo - m >= -80.f);   // every sigmoid and its complement a normal fp32 number
         }
         if (__any(!tame)) {
             // exact formulas for this group (never on sane logits): rolled loops over the classes, logits re-read from L2 --
@@ -1631,6 +1728,7 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
 
 // ------------------------------------------------------------------------------------------------ host side
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
+int g_smf_bwd_stash = 4;  // ptb_set_tunable key 7: 4 pixels per lane (251 VGPRs, 2 waves per SIMD) measured 0.372 ms fwd+bwd at cfg4, 2 pixels 0.54, the two-pass kernel 0.41-0.48
 int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
                           // instead of 4 pixels: 163 VGPRs, 3 waves): 0.164-0.171 vs 0.173-0.186 ms per FocalDiceJaccardLoss forward at cfg4
 }  // namespace ptb
@@ -1679,9 +1777,13 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
         const bool plain_focal = what == (SEG_FOCAL | SEG_STATS) && prob == PROB_SOFTMAX && g2 && !class_weights &&
                                  !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
         const dim3 lgrid(grid_for_groups(HW / 256 * B, kGridStats));
+        const bool no_term = flags & SEG_NO_TERM;
 #define PTB_LEAN(CR) do { \
-            if (plain_focal) { if (g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2>), dim3(grid_for_groups(HW / 128 * B, kGridStats)), block, shmem, s, a); \
-                               else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false>), lgrid, block, shmem, s, a); } \
+            if (plain_focal) { const dim3 g2(grid_for_groups(HW / 128 * B, kGridStats)); \
+                               if (!g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 4, true, false>), lgrid, block, shmem, s, a); \
+                               else if (no_term && C == CR) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true>), g2, block, shmem, s, a); \
+                               else if (no_term) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, false>), g2, block, shmem, s, a); \
+                               else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, true, false>), g2, block, shmem, s, a); } \
             else if (prob == PROB_SOFTMAX) { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, true>), lgrid, block, shmem, s, a); \
                                              else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, false>), lgrid, block, shmem, s, a); } \
             else { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_IDENTITY, false, true>), lgrid, block, shmem, s, a); \
@@ -1794,6 +1896,15 @@ static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix
     if (vec_ok(a.HW, {a.logits, a.pixel_out, grad_pix, grad, a.labels})) {
         const int grid = grid_for_groups((a.HW + 255) / 256 * a.B, kGridStream);
         // (2 pixels per lane for the backward: 151 -> fewer VGPRs but the same 442 us forward + backward at cfg4: not used)
+        if (MODE == 1 && a.C <= 16 && !g_force_scalar && g_smf_bwd_stash) {   // one transcendental pass, T_c kept in registers
+            const int pix = g_smf_bwd_stash;
+            const int g2 = grid_for_groups((a.HW + 64 * pix - 1) / (64 * pix) * a.B, kGridStream);
+            if (pix == 2 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_bwd_kernel<2, 16, true>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
+            else if (pix == 2) hipLaunchKernelGGL((softmax_focal_bwd_kernel<2, 16, false>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
+            else if (a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_bwd_kernel<4, 16, true>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
+            else hipLaunchKernelGGL((softmax_focal_bwd_kernel<4, 16, false>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
+            return check_launch();
+        }
         if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else if (a.C <= 16) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);
         else hipLaunchKernelGGL((softmax_focal_kernel<4, 0, MODE, false>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);

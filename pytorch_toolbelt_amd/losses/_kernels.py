@@ -11,7 +11,7 @@ import torch
 
 from .. import _native as N
 
-SEG_FOCAL, SEG_STATS, SEG_HAS_IGNORE, SEG_HAS_ALPHA, SEG_REDUCED, SEG_MASK_FOCAL_TERM, SEG_ELEMWISE = 1, 2, 4, 8, 16, 32, 64
+SEG_FOCAL, SEG_STATS, SEG_HAS_IGNORE, SEG_HAS_ALPHA, SEG_REDUCED, SEG_MASK_FOCAL_TERM, SEG_ELEMWISE, SEG_NO_TERM = 1, 2, 4, 8, 16, 32, 64, 128
 PROB_SOFTMAX, PROB_SIGMOID, PROB_IDENTITY = 0, 1, 2
 SUM_SLOTS = 64  # PTB_SUM_SLOTS: the kernels spread their fp64 atomics over this many copies of the sums
 

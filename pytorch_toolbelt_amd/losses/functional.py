@@ -62,6 +62,8 @@ def _focal_flags(alpha, reduced_threshold, ignore_index, normalized, reduction):
         flags |= K.SEG_HAS_IGNORE
         if normalized:
             flags |= K.SEG_MASK_FOCAL_TERM
+    if not normalized:
+        flags |= K.SEG_NO_TERM      # sums[1] is only read for normalized=True
     want_map = reduction not in ("mean", "sum")
     if want_map:
         flags |= K.SEG_ELEMWISE
@@ -139,6 +141,8 @@ def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, r
         flags |= K.SEG_HAS_IGNORE
         if normalized:
             flags |= K.SEG_MASK_FOCAL_TERM
+    if not normalized:
+        flags |= K.SEG_NO_TERM      # sums[1] is only read for normalized=True
     want_map = reduction not in ("mean", "sum")
     if want_map:
         flags |= K.SEG_ELEMWISE

@@ -36,7 +36,7 @@ class FocalDiceJaccardLoss(nn.Module):
             return loss
         bs = y_pred.size(0)
         x = K._f32c(y_pred, "fused loss")
-        flags = (K.SEG_HAS_ALPHA if self.alpha is not None else 0) | (K.SEG_HAS_IGNORE if self.ignore_index is not None else 0)
+        flags = (K.SEG_HAS_ALPHA if self.alpha is not None else 0) | (K.SEG_HAS_IGNORE if self.ignore_index is not None else 0) | K.SEG_NO_TERM
         ign = self.ignore_index
         if self.mode == R.MULTICLASS_MODE:
             x = x.reshape(bs, x.size(1), -1)

@@ -194,6 +194,8 @@ class _DeferredBand:
         self.handle, self.table, self.groups = handle, table, groups      # groups: [(y0, y1, last tile)] local rows
         self.out, self.norm, self.weight = out, norm, weight
         self.xy_abs, self.top = xy_abs, top
+        self.xy_abs_rows = np.ascontiguousarray(xy_abs.T)      # [N, 2] (x, y), the layout callers' crop rows compare against
+        self._varr = {}
         self.channels, self.th, self.tw = channels, th, tw
         self.pos = 0
         self.held = []
@@ -263,18 +265,21 @@ class _DeferredBand:
         from . import _native as N
 
         B = len(coords_abs)
-        xy = np.ascontiguousarray(np.asarray(coords_abs, dtype=np.int64)[:, :2].T)
-        if self.pos + B > self.xy_abs.shape[1] or not np.array_equal(xy, self.xy_abs[:, self.pos:self.pos + B]):
+        if self.pos + B > self.xy_abs.shape[1] or not np.array_equal(coords_abs[:, :2], self.xy_abs_rows[self.pos:self.pos + B]):
             raise RuntimeError("ShardedTileMerger: tiles must be integrated in the order of `merger.tiles` (the deferred band plan "
                                "was built for that order); construct the merger with defer=False for free-form accumulation")
         if batch.dtype not in N.DTYPE_CODES:
             batch = batch.float()
-        batch = batch.detach().contiguous()
+        if batch.requires_grad or not batch.is_contiguous():
+            batch = batch.detach().contiguous()
         n_views = len(views) if views is not None else 1
         if batch.shape[0] != B * n_views or tuple(batch.shape[1:]) != (self.channels, self.th, self.tw):
             raise RuntimeError(f"tile batch of shape {tuple(batch.shape)} does not match {B} tiles x {n_views} views of "
                                f"[{self.channels}, {self.th}, {self.tw}]")
-        varr = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
+        key = tuple(views) if views is not None else None
+        varr = self._varr.get(key)
+        if varr is None:
+            varr = self._varr[key] = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
         per_tile = self.channels * self.th * self.tw
         dev = self.out.device
         with N.on_device(dev):
@@ -411,8 +416,8 @@ class ShardedTileMerger:
 
         N.require_device(batch, "ShardedTileMerger")
         coords = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4)
-        self._deferred.submit(batch, coords, views, code)
-        if not self._exchanged and all(self._deferred.rows_launched(r0, r1) for _d, r0, r1, _c0, _c1 in self.sends):
+        launched = self._deferred.submit(batch, coords, views, code)
+        if launched and not self._exchanged and all(self._deferred.rows_launched(r0, r1) for _d, r0, r1, _c0, _c1 in self.sends):
             self._start_exchange()      # every row a neighbour waits for has been written by its launch: hand them over now
 
     def integrate_batch(self, batch, crop_coords):

@@ -298,7 +298,18 @@ def test_region_loss_gradient(kind, mode, log_loss, smooth, dev):
     torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-4, atol=1e-8)
 
 
-def test_softmax_focal_and_lovasz_gradients(dev):
+@pytest.fixture(params=[0, 2, 4], ids=lambda v: f"bwd_stash{v}")
+def smf_bwd_variant(request):
+    """ptb_set_tunable key 7: the softmax focal backward as two transcendental passes (0) or with the per-class terms kept in
+    registers at 2 / 4 pixels per lane (the default, 4)."""
+    from pytorch_toolbelt_amd import _native as N
+
+    assert N.load().ptb_set_tunable(7, request.param) == 0
+    yield request.param
+    assert N.load().ptb_set_tunable(7, 4) == 0
+
+
+def test_softmax_focal_and_lovasz_gradients(dev, smf_bwd_variant):
     L = _L()
     g = torch.Generator().manual_seed(7)
     x = (torch.randn((2, 6, 8, 9), generator=g) * 2).to(dev)
@@ -441,7 +452,7 @@ def test_fused_forward_shared_exp_and_extreme_logits(kw, dev):
     torch.testing.assert_close(x1.grad, x2.grad, rtol=2e-5, atol=1e-10)
 
 
-def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev):
+def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev, smf_bwd_variant):
     """softmax_focal_kernel keeps u = exp(x - m) in registers and derives the BCE term's sigmoid from it (wave-uniform fast
     path); waves holding a pixel with |max| > 60 or a logit 80 below the maximum take the exact path.  Both against an fp64
     torch restatement of functional.py:110-173, values and gradients, on a map that mixes tame and extreme pixels."""
@@ -454,6 +465,9 @@ def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev):
     x[0, :, 1] -= 70.0
     x[0, 5, 2] = -120.0
     lab[0, 2, :8] = 5
+    x[1, :, 8] -= 50.0                           # max about -45, the label's logit 70 below it: sigmoid(x_t) = e^-115 is not an fp32
+    x[1, 3, 8] -= 70.0                           # number, the focal term's -log(sigmoid) = 115 is
+    lab[1, 8, :] = 3
     lab[1, 3, :5] = -100
     for kw in (dict(), dict(gamma=1.5), dict(reduced_threshold=0.5)):
         x1 = x.to(dev).requires_grad_(True)
