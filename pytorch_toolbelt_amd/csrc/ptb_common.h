@@ -19,6 +19,12 @@ inline int check_launch() {
     return PTB_OK;
 }
 
+// Index of the wave inside its workgroup as a SCALAR: every lane of a wave computes the same threadIdx.x >> 6, but only through
+// readfirstlane does the compiler know it, and everything derived from it (grid-stride group index, image / plane offsets, base
+// addresses) then runs on the scalar unit and the loads take an SGPR base -- on the loss kernels that was 7 of 25 vector
+// instructions per element.
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // tunables (ptb_set_tunable)
@@ -27,6 +33,7 @@ extern int g_force_scalar;  // 0 | 1
 extern int g_loss_grid_cap;  // workgroups per loss-kernel launch
 extern int g_ms_tiled;       // 0 | 1: LDS-staged multiscale kernel
 extern int g_fused_pix2;     // 0 | 1: A/B of the fused loss forward with 2 pixels per lane
+extern int g_loss_prefetch;   // 0 | 1: the fused loss forward fetches the next pixel group while it computes the current one
 extern int g_smf_bwd_stash;  // 0 | 2 | 4: softmax focal backward with the per-class terms kept in registers, pixels per lane
 extern int g_ms_tile_rows;   // 64 | 32: output tile height of the fused multiscale kernel
 extern int g_nt_loads;      // 0 | 1: non-temporal streaming loads in the linear view kernels

@@ -172,6 +172,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_ms_tile_rows = value;
         return PTB_OK;
     }
+    if (key == 8) {
+        g_loss_prefetch = value ? 1 : 0;
+        return PTB_OK;
+    }
     if (key == 7) {
         if (value != 0 && value != 2 && value != 4) return PTB_EINVAL;
         g_smf_bwd_stash = value;

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void focal_softmax_kernel(const FsmArgs fa, co
                                                             float* __restrict__ grad) {
     const SegArgs& a = fa.s;
     const FocalCfg cfg = focal_cfg(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const bool elem = a.flags & SEG_ELEMWISE;

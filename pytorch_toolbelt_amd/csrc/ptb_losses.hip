@@ -73,7 +73,7 @@ template <int PIX, int CREG, int WHAT, bool DENSE, bool G2, bool SHARE = false, 
 __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(const SegArgs a) {
     const FocalCfg cfg = focal_cfg(a);
     extern __shared__ float lds[];  // [4 waves][3][C]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     float* wl = lds + wave * 3 * C;
     constexpr bool stats = WHAT & SEG_STATS, focal = WHAT & SEG_FOCAL;
@@ -207,11 +207,11 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
 // their loads are guarded), and no control flow diverges: about 8 (statistics) / 20 (+ focal) vector instructions per
 // element (2 pixels per lane, 98 VGPRs, measured the same as 4: 105 vs 106 us).  T_c is a label count: taken per WAVE from the compare mask the class loop needs anyway (s_bcnt1 on the scalar
 // unit).  FOCAL shares the exp with the softmax as described at `share` above, with the same exact redo of extreme elements.
-template <int CREG, int PROB, bool FOCAL, bool IGN, int PIX = 4, bool TERM = true, bool FULL = false>   // FULL: C == CREG
+template <int CREG, int PROB, bool FOCAL, bool IGN, int PIX = 4, bool TERM = true, bool FULL = false, bool PF = false>   // FULL: C == CREG
 __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const SegArgs a) {
     static_assert(!FOCAL || PROB == PROB_SOFTMAX, "the shared exp needs the softmax numerators");
     extern __shared__ float lds[];  // [4 waves][3][C]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     float* wl = lds + wave * 3 * C;
     float aI[CREG], aP[CREG];
@@ -221,20 +221,30 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
     double f_loss = 0.0, f_term = 0.0;
     const long long per_img = a.HW / (64 * PIX);
     const long long groups = per_img * a.B;
-    for (long long g = (long long)blockIdx.x * 4 + wave; g < groups; g += (long long)gridDim.x * 4) {
+    const long long stride = (long long)gridDim.x * 4;
+    // one pixel group = 64 * PIX pixels of one image: its CREG class planes and labels are fetched as one batch of loads
+    auto fetch = [&](long long g, float (&xv)[CREG][PIX], long long (&l64)[PIX], long long& base) {
         const int b = (int)(g / per_img);
         const long long i0 = (g - (long long)b * per_img) * (64 * PIX) + (long long)lane * PIX;
-        const long long base = (long long)b * C * a.HW + i0;
+        base = (long long)b * C * a.HW + i0;
+        const long long* lp = a.labels + (long long)b * a.HW + i0;
+#pragma unroll
+        for (int k = 0; k < PIX; k += 2) {
+            const longlong2 l2 = *reinterpret_cast<const longlong2*>(lp + k);
+            l64[k] = l2.x; l64[k + 1] = l2.y;
+        }
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            const float pad = PROB == PROB_SOFTMAX ? -INFINITY : 0.f;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) xv[c][k] = pad;
+            if (FULL || c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], true);
+        }
+    };
+    auto process = [&](float (&xv)[CREG][PIX], const long long (&l64)[PIX], const long long base) {
         int lab[PIX];
         bool valid[PIX];
         {
-            const long long* lp = a.labels + (long long)b * a.HW + i0;
-            long long l64[PIX];
-#pragma unroll
-            for (int k = 0; k < PIX; k += 2) {
-                const longlong2 l2 = *reinterpret_cast<const longlong2*>(lp + k);
-                l64[k] = l2.x; l64[k + 1] = l2.y;
-            }
             bool bad = false;
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
@@ -243,14 +253,6 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
                 lab[k] = valid[k] ? (int)l64[k] : -1;
             }
             if (bad) *a.error_flag = 1;
-        }
-        float xv[CREG][PIX];
-#pragma unroll
-        for (int c = 0; c < CREG; ++c) {
-            const float pad = PROB == PROB_SOFTMAX ? -INFINITY : 0.f;
-#pragma unroll
-            for (int k = 0; k < PIX; ++k) xv[c][k] = pad;
-            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xv[c], true);
         }
         float inv[PIX], em[PIX];
         // FOCAL: the class loop below is exact only while every sigmoid and its complement stay normal fp32 numbers when formed
@@ -317,6 +319,28 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
             f_loss += (double)lsum;
             f_term += (double)fsum;
         }
+    };
+    const long long g0 = (long long)blockIdx.x * 4 + wave;
+    if constexpr (PF) {
+        // two register buffers: the loads of the NEXT group are in flight while this one is computed (the compute phase of a
+        // group is ~1 us of VALU time during which the wave would otherwise have nothing outstanding)
+        float xa[CREG][PIX], xb[CREG][PIX];
+        long long la[PIX], lb[PIX], ba = 0, bb = 0;
+        if (g0 < groups) fetch(g0, xa, la, ba);
+        for (long long g = g0; g < groups; g += 2 * stride) {
+            const bool hb = g + stride < groups;
+            if (hb) fetch(g + stride, xb, lb, bb);
+            process(xa, la, ba);
+            if (g + 2 * stride < groups) fetch(g + 2 * stride, xa, la, ba);
+            if (hb) process(xb, lb, bb);
+        }
+    } else {
+        for (long long g = g0; g < groups; g += stride) {
+            float xv[CREG][PIX];
+            long long l64[PIX], base;
+            fetch(g, xv, l64, base);
+            process(xv, l64, base);
+        }
     }
     double* slot = a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C);
     if (FOCAL) block_add2(f_loss, f_term, slot, lane, wave);
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
 template <int PROB, bool IGN, bool FOCAL = false>
 __global__ __launch_bounds__(256) void seg_stats_dense_lean_kernel(const SegArgs a) {
     static_assert(!FOCAL || PROB == PROB_SIGMOID, "the focal term shares the sigmoid of the statistics");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const float term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
     double f_loss = 0.0, f_term = 0.0;
@@ -404,7 +428,7 @@ template <int PIX>
 __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
     const FocalCfg cfg = focal_cfg(a);
     extern __shared__ float lds[];  // [4 waves][3][C]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     float* wl = lds + wave * 3 * C;
     const bool stats = a.flags & SEG_STATS, focal = a.flags & SEG_FOCAL;
@@ -485,7 +509,7 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
 template <int PIX, bool DENSE, bool G2>
 __global__ __launch_bounds__(256) void focal_fwd_kernel(const SegArgs a) {
     const FocalCfg cfg = focal_cfg(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const bool elem = a.flags & SEG_ELEMWISE;
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const SegArgs a) {
 // -inf, whose element is exactly 0.  IGN: ignored pixels add no loss, and their focal terms only count when not normalised.
 template <int CCH, bool IGN>
 __global__ __launch_bounds__(256) void focal_fwd_lean_kernel(const SegArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const float term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
     double f_loss = 0.0, f_term = 0.0;
@@ -611,7 +635,7 @@ template <int PIX, bool DENSE, bool GELEM, bool G2>
 __global__ __launch_bounds__(256) void focal_bwd_kernel(const SegArgs a, const float* __restrict__ coef,
                                                         const float* __restrict__ grad_elem, float* __restrict__ grad) {
     const FocalCfg cfg = focal_cfg(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const float k1 = coef[0], k2 = coef[1];
@@ -676,7 +700,7 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const SegArgs a, const f
 template <int PIX, int CREG, bool DENSE>
 __global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, const float* __restrict__ gI,
                                                             const float* __restrict__ gP, float* __restrict__ grad) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
@@ -810,7 +834,7 @@ template <int PIX, int CREG, bool DENSE, bool G2>
 __global__ __launch_bounds__(256) void seg_fused_bwd_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
                                                             const float* __restrict__ gP, float* __restrict__ grad) {
     const FocalCfg cfg = focal_cfg(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const float k1 = coef[0], k2 = coef[1];
@@ -892,7 +916,7 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegA
                                                                       const float* __restrict__ gI, const float* __restrict__ gP,
                                                                       float* __restrict__ grad) {
     const FocalCfg cfg = focal_cfg(a);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const bool ignf = a.flags & SEG_HAS_IGNORE;
     const float k1 = coef[0], k2 = coef[1];
@@ -1003,7 +1027,7 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegA
 template <int CREG>
 __global__ __launch_bounds__(256, 3) void seg_fused_bwd_lean_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
                                                                     const float* __restrict__ gP, float* __restrict__ grad) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const float k1 = coef[0], k2 = coef[1];
     // dL/dP_c is wave-uniform (a scalar operand); dL/dI only matters for the label class of a pixel and is fetched per lane
@@ -1105,7 +1129,7 @@ template <int PROB, bool IGN, bool FOCAL>
 __global__ __launch_bounds__(256) void seg_dense_bwd_lean_kernel(const SegArgs a, const float* __restrict__ coef, const float* __restrict__ gI,
                                                                  const float* __restrict__ gP, float* __restrict__ grad) {
     static_assert(!FOCAL || PROB == PROB_SIGMOID, "the focal term shares the sigmoid of the statistics");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const float k1 = FOCAL ? coef[0] : 0.f, k2 = FOCAL ? coef[1] : 0.f;
     const long long segs_per_plane = a.HW / 1024;
@@ -1185,7 +1209,7 @@ template <int PIX, int CREG, int MODE, bool G2>
 __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, const float* __restrict__ coef,
                                                             const float* __restrict__ grad_pix, float* __restrict__ grad) {
     const float thr = a.reduced ? a.threshold : -INFINITY, sc = a.reduced ? 1.0f / a.threshold : 1.0f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     double s_loss = 0.0, s_term = 0.0;
     const float k1 = MODE ? coef[0] : 0.f, k2 = MODE ? coef[1] : 0.f;
@@ -1371,12 +1395,12 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
 // S = g1 sum_c A_c + k2 sum_c D_c.  Pass 1 leaves T_c in registers next to u_c = exp(x_c - m) (2 x CREG x PIX values), pass 2 is one
 // fma and the store: exp + rcp + log per element instead of exp + 2 (rcp + log).  The exact (non-"tame") waves keep x_c and pay
 // one more exp in pass 2.
-template <int PIX, int CREG, bool G2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? (G2 ? 4 : 3) : 2))) void softmax_focal_bwd_kernel(const SmfArgs a, const float* __restrict__ coef,
-                                                                const float* __restrict__ grad_pix, float* __restrict__ grad) {
+template <int PIX, int CREG, bool G2, bool FULL>   // FULL: C == CREG (no padded classes)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? 4 : 2))) void softmax_focal_bwd_kernel(
+    const SmfArgs a, const float* __restrict__ coef, const float* __restrict__ grad_pix, float* __restrict__ grad) {
     const float thr = a.reduced ? a.threshold : -INFINITY, sc = a.reduced ? 1.0f / a.threshold : 1.0f;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int C = a.C;
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int C = FULL ? CREG : a.C;
     const float k1 = coef[0], k2 = coef[1];
     const long long per_img = (a.HW + 64 * PIX - 1) / (64 * PIX);
     const long long groups = per_img * a.B;
@@ -1393,54 +1417,78 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? 
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
 #pragma unroll
-            for (int k = 0; k < PIX; ++k) xr[c][k] = 0.f;
-            if (c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xr[c], true);
+            for (int k = 0; k < PIX; ++k) xr[c][k] = -INFINITY;     // padded classes: u = 0 exactly, every term below is 0
+            if (FULL || c < C) load_px<PIX>(a.logits + base + (long long)c * a.HW, xr[c], true);
         }
         bool tame = true;
 #pragma unroll
         for (int k = 0; k < PIX; ++k) {
-            float m = -INFINITY, lo = INFINITY;
+            float m = xr[0][k], lo = xr[0][k];
 #pragma unroll
-            for (int c = 0; c < CREG; ++c) if (c < C) { m = fmaxf(m, xr[c][k]); lo = fminf(lo, xr[c][k]); }
+            for (int c = 1; c < CREG; ++c) { m = fmaxf(m, xr[c][k]); lo = fminf(lo, (FULL || c < C) ? xr[c][k] : lo); }
             mx[k] = m;
             tame = tame && (m <= 60.f) && (lo >= -80.f) && (lo - m >= -80.f);   // every sigmoid and its complement a normal fp32 number
             g1[k] = G.ign[k] ? 0.f : k1 * g1[k];
             S[k] = 0.f;
         }
-        const bool fast = !__any(!tame);
+        if (__any(!tame)) {
+            // exact formulas for this group (never on sane logits): rolled loops over the classes, logits re-read from L2 -- small
+            // code and few registers, so the straight-line path below keeps its registers for the 2 x CREG x PIX stashed values
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) {   // (unrolled: tg / g1 / mx are register arrays and need static indices)
+                const float* xp = a.logits + base + k;
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) d += fexp(xp[(long long)c * a.HW] - mx[k]);
+                const float iv = rcp(d);
+                float dh = 0.f, dd = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float x = xp[(long long)c * a.HW], w = a.class_weights ? a.class_weights[c] : 1.f;
+                    const float t = c == tg[k] ? 1.f : 0.f;
+                    const float p = fexp(x - mx[k]) * iv;
+                    const float pt = (1.f - t) * p + t * (1.f - p);
+                    const float bce = fmaxf(x, 0.f) - x * t + sigmoid_parts(x).log1pe;
+                    const float df = smf_dterm<G2>(pt, t, a, sc, thr);
+                    dh += w * bce * df * p; dd += df * p;
+                }
+                for (int c = 0; c < C; ++c) {
+                    const float x = xp[(long long)c * a.HW], w = a.class_weights ? a.class_weights[c] : 1.f;
+                    const float t = c == tg[k] ? 1.f : 0.f;
+                    const float p = fexp(x - mx[k]) * iv;
+                    const float pt = (1.f - t) * p + t * (1.f - p);
+                    const Sig sg = sigmoid_parts(x);
+                    const float bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
+                    const float df = smf_dterm<G2>(pt, t, a, sc, thr), f = smf_term<G2>(pt, a, sc, thr);
+                    grad[base + (long long)c * a.HW + k] = g1[k] * (p * (w * bce * df - dh) + w * f * (sg.p - t)) + k2 * (p * (df - dd));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < PIX; ++k) {
+            const float M = mx[k] * kLog2e;
             float d = 0.f;
 #pragma unroll
-            for (int c = 0; c < CREG; ++c) if (c < C) {
-                const float u = fexp(xr[c][k] - mx[k]);
+            for (int c = 0; c < CREG; ++c) {
+                const float u = fexp_sub(xr[c][k], M);
                 d += u;
-                if (fast) xr[c][k] = u;
+                xr[c][k] = u;
             }
             inv[k] = rcp(d);
-            em[k] = fexp(-mx[k]);
+            em[k] = ex2(-M);
         }
-        auto pass1 = [&](int c, auto fast_tag) {
-            constexpr bool FAST = decltype(fast_tag)::value;
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) if (FULL || c < C) {
             const float w = a.class_weights ? a.class_weights[c] : 1.f;
 #pragma unroll
             for (int k = 0; k < PIX; ++k) {
-                const float x = xr[c][k];                         // FAST: u = exp(logit - m)
+                const float u = xr[c][k];                         // exp(logit - m)
                 const bool is_t = c == tg[k];
                 const float t = is_t ? 1.f : 0.f;
-                float p, bce, smt;
-                if constexpr (FAST) {
-                    p = x * inv[k];
-                    const float r = rcp(x + em[k]);
-                    const float ps = x * r, qs = em[k] * r;
-                    bce = -lg2(is_t ? ps : qs) * kLn2;
-                    smt = is_t ? -qs : ps;
-                } else {
-                    p = fexp(x - mx[k]) * inv[k];
-                    const Sig sg = sigmoid_parts(x);
-                    bce = fmaxf(x, 0.f) - x * t + sg.log1pe;
-                    smt = sg.p - t;
-                }
+                const float p = u * inv[k];
+                const float r = rcp(u + em[k]);
+                const float ps = u * r, qs = em[k] * r;           // sigmoid(x), 1 - sigmoid(x)
+                const float bce = -lg2(is_t ? ps : qs) * kLn2;
+                const float smt = is_t ? -qs : ps;
                 const float pt = is_t ? 1.f - p : p;
                 const float df = smf_dterm<G2>(pt, t, a, sc, thr);
                 const float f = smf_term<G2>(pt, a, sc, thr);
@@ -1450,17 +1498,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? 
                 S[k] += v;
                 T[c][k] = v + g1[k] * (w * f * smt);
             }
-        };
+        }
 #pragma unroll
-        for (int c = 0; c < CREG; ++c) if (c < C) { if (fast) pass1(c, std::true_type{}); else pass1(c, std::false_type{}); }
+        for (int k = 0; k < PIX; ++k) S[k] *= inv[k];
 #pragma unroll
-        for (int c = 0; c < CREG; ++c) if (c < C) {
+        for (int c = 0; c < CREG; ++c) if (FULL || c < C) {
             float out[PIX];
 #pragma unroll
-            for (int k = 0; k < PIX; ++k) {
-                const float p = (fast ? xr[c][k] : fexp(xr[c][k] - mx[k])) * inv[k];
-                out[k] = T[c][k] - p * S[k];
-            }
+            for (int k = 0; k < PIX; ++k) out[k] = T[c][k] - xr[c][k] * S[k];
             store_px<PIX>(grad + base + (long long)c * a.HW, out, true);
         }
     }
@@ -1473,7 +1518,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? 
 template <int CREG, int MODE>
 __global__ __launch_bounds__(256, 3) void softmax_focal_lean_kernel(const SmfArgs a, const float* __restrict__ coef,
                                                                     const float* __restrict__ grad_pix, float* __restrict__ grad) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     double s_loss = 0.0, s_term = 0.0;
     const float k1 = MODE ? coef[0] : 0.f, k2 = MODE ? coef[1] : 0.f;
@@ -1728,6 +1773,7 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
 
 // ------------------------------------------------------------------------------------------------ host side
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
+int g_loss_prefetch = 0;   // ptb_set_tunable key 8: register double buffering in the fused loss forward (measured: no gain, 0.146 vs 0.141-0.145 ms)
 int g_smf_bwd_stash = 4;  // ptb_set_tunable key 7: 4 pixels per lane (251 VGPRs, 2 waves per SIMD) measured 0.372 ms fwd+bwd at cfg4, 2 pixels 0.54, the two-pass kernel 0.41-0.48
 int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
                           // instead of 4 pixels: 163 VGPRs, 3 waves): 0.164-0.171 vs 0.173-0.186 ms per FocalDiceJaccardLoss forward at cfg4
@@ -1781,6 +1827,7 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
 #define PTB_LEAN(CR) do { \
             if (plain_focal) { const dim3 g2(grid_for_groups(HW / 128 * B, kGridStats)); \
                                if (!g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 4, true, false>), lgrid, block, shmem, s, a); \
+                               else if (no_term && C == CR && g_loss_prefetch) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true, true>), g2, block, shmem, s, a); \
                                else if (no_term && C == CR) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true>), g2, block, shmem, s, a); \
                                else if (no_term) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, false>), g2, block, shmem, s, a); \
                                else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, true, false>), g2, block, shmem, s, a); } \
@@ -1899,10 +1946,12 @@ static int launch_smf(const SmfArgs& a, const float* coef, const float* grad_pix
         if (MODE == 1 && a.C <= 16 && !g_force_scalar && g_smf_bwd_stash) {   // one transcendental pass, T_c kept in registers
             const int pix = g_smf_bwd_stash;
             const int g2 = grid_for_groups((a.HW + 64 * pix - 1) / (64 * pix) * a.B, kGridStream);
-            if (pix == 2 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_bwd_kernel<2, 16, true>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
-            else if (pix == 2) hipLaunchKernelGGL((softmax_focal_bwd_kernel<2, 16, false>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
-            else if (a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_bwd_kernel<4, 16, true>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
-            else hipLaunchKernelGGL((softmax_focal_bwd_kernel<4, 16, false>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad);
+#define PTB_SMF_BWD(P, G, F) hipLaunchKernelGGL((softmax_focal_bwd_kernel<P, 16, G, F>), dim3(g2), dim3(256), 0, s, a, coef, grad_pix, grad)
+            const bool gm2 = a.gamma == 2.0f;
+            // (FULL = true, all 16 loads unconditional, lets the scheduler hoist everything: 256 VGPRs + scratch against 184 -- not used)
+            if (pix == 2) { if (gm2) PTB_SMF_BWD(2, true, false); else PTB_SMF_BWD(2, false, false); }
+            else { if (gm2) PTB_SMF_BWD(4, true, false); else PTB_SMF_BWD(4, false, false); }
+#undef PTB_SMF_BWD
             return check_launch();
         }
         if (a.C <= 16 && a.gamma == 2.0f) hipLaunchKernelGGL((softmax_focal_kernel<4, 16, MODE, true>), dim3(grid), dim3(256), 0, s, a, coef, grad_pix, grad);

@@ -49,7 +49,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int NS>
 __device__ __forceinline__ void block_add(const float* part, double* slot) {
     __shared__ double red[NS][4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = wave_id();
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const double v = wave_sum((double)part[k]);

@@ -123,7 +123,7 @@ def fused_region_loss(y_pred, y_true, mode, from_logits, ignore_index, dice_weig
     gamma = alpha = 0.0
     scale = 0.0
     if focal is not None:
-        flags |= K.SEG_HAS_ALPHA if focal["alpha"] is not None else 0
+        flags |= (K.SEG_HAS_ALPHA if focal["alpha"] is not None else 0) | K.SEG_NO_TERM    # (no normalized focal here: sums[1] is never read)
         gamma, alpha = float(focal["gamma"]), float(focal["alpha"] or 0.0)
         scale = float(focal["weight"]) / x.numel()
     return K.RegionLoss.apply(x, labels, dense, None, flags, prob, gamma, alpha, 0.0, ign_label, ign_value, focal is not None, scale,

@@ -486,7 +486,12 @@ def test_softmax_focal_fast_and_exact_paths_agree_with_fp64(dev, smf_bwd_variant
         (out * w.float().to(dev)).sum().backward()
         (ref * w).sum().backward()
         assert torch.isfinite(x1.grad).all()
-        torch.testing.assert_close(x1.grad.cpu().double(), x2.grad, rtol=2e-4, atol=2e-6)
+        # pixels with |logit| > 60: the gradient is the difference of terms ~ bce * df = 2 x 80 that cancel to ~0.1, so fp32 leaves
+        # ~1e-5 absolute whatever the order of operations (the reference's own fp32 autograd is 2.2e-5 off fp64 on this map)
+        extreme = (x.abs().amax(1, keepdim=True) > 60).expand_as(x)
+        got, want = x1.grad.cpu().double(), x2.grad
+        torch.testing.assert_close(got[~extreme], want[~extreme], rtol=2e-4, atol=2e-6)
+        torch.testing.assert_close(got[extreme], want[extreme], rtol=2e-4, atol=1e-4)
 
 
 class _TwoRankEcho:
