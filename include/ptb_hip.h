@@ -245,6 +245,16 @@ int ptb_deaug_accumulate_t(float* image, float* norm, const float* weight, const
                            int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw, int H, int W,
                            uint8_t* fresh, int fresh_rows, ptb_stream_t stream);
 
+/* ---- reductions over a stack of ANY length, explicit eps (inference/functional.py:247-331; tta.py:63-95) ----------
+ * out[i] = post(mean_t pre(src[t, i])) for src [T, n] contiguous fp32: geometric_mean, harmonic_mean(eps), harmonic1p_mean,
+ * logodd_mean(eps), log1p_mean, mean, sum along dim 0.  The fused view kernels above take at most 8 planes and the default
+ * eps = 1e-6; this entry is `_deaugment_averaging` for tencrop TTA (T = 10), ensembles of more than 8 predictions, and the
+ * reductions called with their eps argument.  eps is the Python double: the kernel clamps at (float)eps / (float)(1 - eps).
+ * The backward takes the forward output: grad[t, i] = grad_out[i] * post'(out[i]) * pre'(src[t, i]) / T. */
+int ptb_stack_reduce(const float* src, int T, int64_t n, int reduction, double eps, float* out, ptb_stream_t stream);
+int ptb_stack_reduce_bwd(const float* src, const float* out, const float* grad_out, int T, int64_t n, int reduction, double eps,
+                         float* grad, ptb_stream_t stream);
+
 /* ---- per-view transform without reduction ----------------------------------------------------------------------
  * out[k*B + b] = scale * view_k(in[src]) with src = b (in_is_batch = 1: *_image_augment, inference/tta.py:257-284,
  * 319-341,385-422,470-484; in [B,C,H,W]) or src = k*B + b (in_is_batch = 0: de-augment with reduction=None).

@@ -628,6 +628,38 @@ def gen_tta2():
     save("tta2.npz", A, cases)
 
 
+def gen_tta3():
+    """`_deaugment_averaging` over stacks longer than the 8 planes of the TTA groups (tencrop: 10; larger ensembles) and the
+    reductions called with their eps argument (inference/tta.py:63-95, inference/functional.py:264-318) -- values and autograd
+    gradients of the unmodified reference."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(43)
+    for T in (10, 12, 17):
+        x = torch.rand((T, 2, 3, 9, 11), generator=g) * 0.98 + 0.01
+        x[0, 0, 0, 0, :3] = torch.tensor([0.0, 1.0, 1e-9])            # the clamps of hmean / logodd
+        A[f"stack_{T}"] = t2n(x)
+        for red in ("mean", "sum", "gmean", "hmean", "harmonic1p", "logodd", "log1p"):
+            xin = x.clone().requires_grad_(True)
+            out = rtta._deaugment_averaging(xin, red)
+            (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 5 + 1.0)).sum().backward()
+            key = f"avg_{T}_{red}"
+            A[key], A[key + "_grad"] = t2n(out), t2n(xin.grad)
+            cases.append(dict(name=key, fn="deaugment_averaging", kwargs=dict(reduction=red), inputs=[f"stack_{T}"], output=key))
+    x = torch.rand((5, 4, 33), generator=g)
+    x[0, 0, :4] = torch.tensor([0.0, 1.0, 5e-4, 0.9995])
+    A["eps_x"] = t2n(x)
+    for fn in ("harmonic_mean", "logodd_mean"):
+        for eps in (1e-3, 0.05):
+            for dim in (0, 1):
+                xin = x.clone().requires_grad_(True)
+                out = getattr(rfn, fn)(xin, dim=dim, eps=eps)
+                (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 3 + 1.0)).sum().backward()
+                key = f"{fn}_{eps}_{dim}"
+                A[key], A[key + "_grad"] = t2n(out), t2n(xin.grad)
+                cases.append(dict(name=key, fn=fn, kwargs=dict(dim=dim, eps=eps), inputs=["eps_x"], output=key))
+    save("tta3.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -834,5 +866,6 @@ if __name__ == "__main__":
     gen_losses3()
     gen_losses4()
     gen_tta2()
+    gen_tta3()
     gen_volumes()
     gen_fullsize()

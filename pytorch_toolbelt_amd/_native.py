@@ -26,6 +26,7 @@ _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch
 
 _c_int = ctypes.c_int
 _c_f = ctypes.c_float
+_c_d = ctypes.c_double
 _c_i64 = ctypes.c_int64
 _vp = ctypes.c_void_p
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -67,6 +68,8 @@ SIGNATURES = {
     "ptb_ms_deaug_reduce_strip": (_c_int, [_vp, _ip, _ip, _ip, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_resize_bilinear_bwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_deaug_reduce_bwd": (_c_int, [_vp, _ip, _ip, _c_int, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_stack_reduce": (_c_int, [_vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
+    "ptb_stack_reduce_bwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
     "ptb_resize_nearest": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_flip_deaug_reduce": (_c_int, [_vp, _ip, _ip, _c_int, _c_int, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_seg_loss_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),

@@ -199,21 +199,52 @@ class _StackReduce(torch.autograd.Function):
         return grad.view(ctx.T, *g.shape), None
 
 
-def stack_reduce(x, code):
-    """Reduce dim 0 of ``x [T, ...]`` (float32, GPU) with the HIP reduction ``code``; T <= 8."""
+class _StackReduceAny(torch.autograd.Function):
+    """reduce dim 0 of a [T, ...] tensor of any length, explicit eps: ``ptb_stack_reduce`` (one pass over the T planes)."""
+
+    @staticmethod
+    def forward(ctx, x, code, eps):
+        T, rest = x.shape[0], x.shape[1:]
+        flat = x.contiguous().view(T, -1)
+        out = torch.empty(flat.shape[1], dtype=torch.float32, device=x.device)
+        with N.on_device(x.device):
+            rc = N.load().ptb_stack_reduce(flat.data_ptr(), T, flat.shape[1], code, float(eps), out.data_ptr(), N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_stack_reduce")
+        ctx.cfg, ctx.rest = (code, float(eps), T), rest
+        ctx.save_for_backward(flat, out)
+        return out.view(rest)
+
+    @staticmethod
+    def backward(ctx, g):
+        code, eps, T = ctx.cfg
+        flat, out = ctx.saved_tensors
+        g = g.contiguous().view(-1).float()
+        grad = torch.empty_like(flat)
+        with N.on_device(flat.device):
+            rc = N.load().ptb_stack_reduce_bwd(flat.data_ptr(), out.data_ptr(), g.data_ptr(), T, flat.shape[1], code, eps, grad.data_ptr(),
+                                               N.stream_ptr(flat.device))
+        N.bump()
+        N.check(rc, "ptb_stack_reduce_bwd")
+        return grad.view((T,) + tuple(ctx.rest)), None, None
+
+
+DEFAULT_EPS = 1e-6
+
+
+def stack_reduce(x, code, eps=DEFAULT_EPS):
+    """Reduce dim 0 of ``x [T, ...]`` (float32, GPU) with the HIP reduction ``code``.  Up to 8 planes with the default eps go through
+    the unrolled view kernels (the TTA groups); longer stacks and a caller-chosen eps through ``ptb_stack_reduce``."""
     N.require_device(x, "TTA reduction")
     if x.dtype in _LOW_PRECISION:
-        return stack_reduce(x.float(), code).to(x.dtype)
+        return stack_reduce(x.float(), code, eps).to(x.dtype)
     if x.dtype != torch.float32:
         raise NotImplementedError(f"TTA reduction: the native path is float32 (half / bfloat16 are converted), got {x.dtype}")
     T = x.shape[0]
     if T < 1:
         raise RuntimeError("cannot reduce an empty stack")
-    if T > 8:
-        # chain groups of <= 8: only valid for the linear reductions (sum; mean = sum / T)
-        if code not in (N.RED_SUM, N.RED_MEAN):
-            raise NotImplementedError("non-linear reductions over more than 8 stacked predictions")
-        parts = [_StackReduce.apply(x[i:i + 8], N.RED_SUM) for i in range(0, T, 8)]
-        total = stack_reduce(torch.stack(parts), N.RED_SUM)
-        return total / T if code == N.RED_MEAN else total
+    if T > 8 or (eps != DEFAULT_EPS and code in (N.RED_HMEAN, N.RED_LOGODD)):
+        if x.numel() == 0:
+            return x.new_empty(x.shape[1:])
+        return _StackReduceAny.apply(x, code, eps)
     return _StackReduce.apply(x, code)

@@ -201,10 +201,10 @@ def unpad_xyxy_bboxes(bboxes_tensor: Tensor, pad, dim=-1):
 
 
 # ------------------------------------------------------------------------------------------- reductions
-def _reduce_dim(x: Tensor, dim: int, code: int) -> Tensor:
+def _reduce_dim(x: Tensor, dim: int, code: int, eps: float = V.DEFAULT_EPS) -> Tensor:
     if dim != 0:
         x = x.movedim(dim, 0)
-    return V.stack_reduce(x.contiguous(), code)
+    return V.stack_reduce(x.contiguous(), code, eps)
 
 
 def geometric_mean(x: Tensor, dim: int) -> Tensor:
@@ -214,9 +214,7 @@ def geometric_mean(x: Tensor, dim: int) -> Tensor:
 
 def harmonic_mean(x: Tensor, dim: int, eps: float = 1e-6) -> Tensor:
     """1 / mean(1 / max(x, eps)) along ``dim`` (the result's denominator is clamped at eps too)."""
-    if eps != 1e-6:
-        raise NotImplementedError("harmonic_mean: the native kernel uses the reference default eps=1e-6")
-    return _reduce_dim(x, dim, N.RED_HMEAN)
+    return _reduce_dim(x, dim, N.RED_HMEAN, eps)
 
 
 def harmonic1p_mean(x: Tensor, dim: int) -> Tensor:
@@ -226,9 +224,7 @@ def harmonic1p_mean(x: Tensor, dim: int) -> Tensor:
 
 def logodd_mean(x: Tensor, dim: int, eps: float = 1e-6) -> Tensor:
     """sigmoid(mean(logit(clamp(x, eps, 1 - eps)))) along ``dim``."""
-    if eps != 1e-6:
-        raise NotImplementedError("logodd_mean: the native kernel uses the reference default eps=1e-6")
-    return _reduce_dim(x, dim, N.RED_LOGODD)
+    return _reduce_dim(x, dim, N.RED_LOGODD, eps)
 
 
 def log1p_mean(x: Tensor, dim: int) -> Tensor:

@@ -396,3 +396,18 @@ def test_multiscale_modes_and_flip_composition_oracle(case):
         ys = [GT2[f"fz_{kw['group']}_y{i}"] for i in range(len(offs))]
         out = AO.ms_image_deaugment([AO.image_deaugment(y, kw["group"], kw["inner_reduction"]) for y in ys], offs, kw["reduction"], kw["align_corners"])
         np.testing.assert_allclose(out, GT2[case["name"]], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ stacks longer than 8, reductions with their eps argument
+GT3 = load_golden("tta3.npz")
+
+
+@pytest.mark.parametrize("case", GT3.cases, ids=lambda c: c["name"])
+def test_long_stacks_and_eps_oracle(case):
+    kw = case["kwargs"]
+    x = GT3[case["inputs"][0]]
+    if case["fn"] == "deaugment_averaging":
+        out = AO.deaugment_averaging(x, kw["reduction"])
+    else:
+        out = getattr(AO, case["fn"])(x, axis=kw["dim"], eps=kw["eps"])
+    np.testing.assert_allclose(out, GT3[case["output"]], rtol=1e-5, atol=1e-6)

@@ -411,3 +411,30 @@ def test_ms_flips_fused_equals_composition_at_scale(dev):
         tta.ms_image_augment(ys[1], [8], mode="nearest", align_corners=False)       # F.interpolate's own rule
     with pytest.raises(NotImplementedError):
         tta.ms_image_augment(ys[1], [8], mode="bicubic")
+
+
+# ------------------------------------------------------------------ stacks longer than 8, reductions with their eps argument
+GT3 = load_golden("tta3.npz")
+
+
+@pytest.mark.parametrize("case", GT3.cases, ids=lambda c: c["name"])
+def test_long_stacks_and_explicit_eps_values_and_gradients(case, dev):
+    """`_deaugment_averaging` over 10 / 12 / 17 stacked predictions (tencrop, large ensembles) with every reduction, and
+    harmonic_mean / logodd_mean with a caller-chosen eps along dim 0 and 1: values and autograd gradients of the unmodified
+    reference (ptb_stack_reduce / ptb_stack_reduce_bwd, csrc/ptb_stack.hip)."""
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    kw = case["kwargs"]
+    x = torch.from_numpy(GT3[case["inputs"][0]]).to(dev).requires_grad_(True)
+    before = N.calls
+    if case["fn"] == "deaugment_averaging":
+        out = _tta()._deaugment_averaging(x, kw["reduction"])
+        period = 5
+    else:
+        out = getattr(F, case["fn"])(x, dim=kw["dim"], eps=kw["eps"])
+        period = 3
+    assert N.calls > before, "no native launch"
+    np.testing.assert_allclose(out.detach().cpu().numpy(), GT3[case["output"]], rtol=1e-5, atol=1e-6)
+    (out * (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % period + 1.0)).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), GT3[case["output"] + "_grad"], rtol=2e-4, atol=1e-5)
