@@ -305,6 +305,13 @@ int ptb_ms_deaug_reduce_bwd(const float* const* inputs, const int* hs, const int
 int ptb_resize_nearest(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
                        ptb_stream_t stream);
 
+/* F.interpolate(x, size, mode="bicubic", align_corners) for [planes, hin, win] -> [planes, hout, wout] (multiscale TTA with
+ * mode="bicubic"): 4 x 4 taps around floor(src) (src without the clamp at 0 of the linear modes), indices clamped into the image,
+ * cubic convolution weights with A = -0.75, rows first (aten UpSampleBicubic2d).  backward != 0: `in` is grad_out
+ * [planes, hout, wout], `out` the ZEROED grad_in [planes, hin, win] (atomic adds, like aten's backward). */
+int ptb_resize_bicubic(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int align_corners, int backward,
+                       ptb_stream_t stream);
+
 /* Multiscale + flip TTA in one pass (BASELINE configs[4]; extension): inputs[s] = the model output for the flip-augmented batch
  * of scale s, [V * B, C, hs[s], ws[s]] chunk-major (view v of plane p at (v * planes + p) * hs * ws; planes = B * C),
  *   out = reduction_s( bilinear_s( inner_reduction_v( view_v^-1( inputs[s][v] ) ) ) )

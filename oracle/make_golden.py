@@ -660,6 +660,41 @@ def gen_tta3():
     save("tta3.npz", A, cases)
 
 
+def gen_tta4():
+    """ms_image_augment / ms_image_deaugment with mode="bicubic" (F.interpolate's 4 x 4-tap cubic convolution, A = -0.75): values
+    and autograd gradients of the unmodified reference (inference/tta.py:599-621, 645-689)."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(47)
+    x = torch.rand((2, 3, 24, 36), generator=g) * 0.9 + 0.05
+    A["x"] = t2n(x)
+    offsets = [-8, 0, 12, (4, -4)]
+    offs_json = [list(o) if isinstance(o, tuple) else o for o in offsets]
+    for ac in (False, True):
+        xin = x.clone().requires_grad_(True)
+        outs = rtta.ms_image_augment(xin, offsets, mode="bicubic", align_corners=ac)
+        tot = sum((o * (torch.arange(o.numel(), dtype=torch.float32).reshape(o.shape) % 5 + 1.0)).sum() for o in outs)
+        tot.backward()
+        key = f"aug_bicubic_{ac}"
+        for i, o in enumerate(outs):
+            A[f"{key}_{i}"] = t2n(o)
+        A[f"{key}_grad"] = t2n(xin.grad)
+        cases.append(dict(name=key, fn="ms_image_augment_grad", kwargs=dict(size_offsets=offs_json, mode="bicubic", align_corners=ac)))
+    fmaps = [torch.rand((2, 3, 24 + (o[0] if isinstance(o, tuple) else o), 36 + (o[1] if isinstance(o, tuple) else o)), generator=g) * 0.4 + 0.3 for o in offsets]   # (cubic overshoot must stay inside (0, 1) for gmean / logodd)
+    for i, f in enumerate(fmaps):
+        A[f"fm_{i}"] = t2n(f)
+    for ac in (False, True):
+        for red in ("mean", "sum", "gmean", "logodd"):
+            ins = [f.clone().requires_grad_(True) for f in fmaps]
+            out = rtta.ms_image_deaugment(ins, offsets, reduction=red, mode="bicubic", align_corners=ac)
+            (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 7 + 1.0)).sum().backward()
+            key = f"deaug_bicubic_{ac}_{red}"
+            A[key] = t2n(out)
+            for i, t in enumerate(ins):
+                A[f"{key}_grad_{i}"] = t2n(t.grad)
+            cases.append(dict(name=key, fn="ms_image_deaugment_grad", kwargs=dict(size_offsets=offs_json, mode="bicubic", align_corners=ac, reduction=red)))
+    save("tta4.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -867,5 +902,6 @@ if __name__ == "__main__":
     gen_losses4()
     gen_tta2()
     gen_tta3()
+    gen_tta4()
     gen_volumes()
     gen_fullsize()

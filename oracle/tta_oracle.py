@@ -221,11 +221,57 @@ def nearest_resize(x, size):
     return x[:, :, idx(x.shape[2], size[0])][:, :, :, idx(x.shape[3], size[1])]
 
 
+def _cubic_taps(n_in, n_out, align_corners, dtype):
+    """Taps of torch's bicubic upsample (aten UpSampleBicubic2d / UpSample.h): source index WITHOUT the clamp at 0 of the linear
+    modes, 4 neighbours floor(src) - 1 .. + 2 clamped into the image (upsample_get_value_bounded), cubic convolution weights with
+    A = -0.75 (get_cubic_upsample_coefficients).  Returns idx [4, n_out], weights [4, n_out] in ``dtype``."""
+    dst = np.arange(n_out, dtype=dtype)
+    if align_corners:
+        scale = dtype((n_in - 1) / (n_out - 1)) if n_out > 1 else dtype(0)
+        src = dst * scale
+    else:
+        scale = dtype(n_in / n_out)
+        src = scale * (dst + dtype(0.5)) - dtype(0.5)
+    fl = np.floor(src)
+    t = (src - fl).astype(dtype)
+    base = fl.astype(np.int64)
+    A, one = dtype(-0.75), dtype(1)
+
+    def conv1(x):   # |x| <= 1
+        return ((A + dtype(2)) * x - (A + dtype(3))) * x * x + one
+
+    def conv2(x):   # 1 < |x| < 2
+        return ((A * x - dtype(5) * A) * x + dtype(8) * A) * x - dtype(4) * A
+
+    w = np.stack([conv2(t + one), conv1(t), conv1(one - t), conv2(dtype(2) - t)]).astype(dtype)
+    idx = np.stack([np.clip(base - 1 + k, 0, n_in - 1) for k in range(4)])
+    return idx, w
+
+
+def bicubic_resize(x, size, align_corners):
+    """F.interpolate(x, size=size, mode='bicubic', align_corners=...) on [B,C,H,W] numpy: 4 x 4 taps, rows interpolated along x
+    first, then the 4 row results along y (cubic_interp1d of cubic_interp1d, aten UpSampleBicubic2d.cpp)."""
+    ri, rw = _cubic_taps(x.shape[2], size[0], bool(align_corners), x.dtype.type)
+    ci, cw = _cubic_taps(x.shape[3], size[1], bool(align_corners), x.dtype.type)
+    out = None
+    for i in range(4):
+        rows = x[:, :, ri[i]]                                  # [B, C, ho, W]
+        acc = None
+        for j in range(4):
+            term = rows[:, :, :, ci[j]] * cw[j]
+            acc = term if acc is None else acc + term
+        acc = acc * rw[i][:, None]
+        out = acc if out is None else out + acc
+    return out
+
+
 def _resize(x, size, mode, align_corners):
     if mode == "nearest":
         if align_corners is not None:
             raise ValueError("align_corners option can only be set with the interpolating modes")
         return nearest_resize(x, size)
+    if mode == "bicubic":
+        return bicubic_resize(x, size, bool(align_corners))
     return bilinear_resize(x, size, bool(align_corners))
 
 

@@ -496,6 +496,60 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bicubic (F.interpolate mode="bicubic")
+// aten UpSampleBicubic2d: source coordinate WITHOUT the clamp at 0 of the linear modes, the 4 x 4 neighbours floor(src) - 1 .. + 2
+// clamped into the image, cubic convolution weights with A = -0.75; rows are interpolated along x first, then the 4 results along y.
+struct Cubic { int i[4]; float w[4]; };
+__device__ __forceinline__ Cubic cubic_taps(int dst, float scale, int n_in, int align_corners) {
+    const float src = align_corners ? scale * (float)dst : __fsub_rn(__fmul_rn(scale, (float)dst + 0.5f), 0.5f);
+    const float fl = floorf(src);
+    const float t = src - fl;
+    const int base = (int)fl;
+    constexpr float A = -0.75f;
+    auto conv1 = [](float x) { return __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(A + 2.0f, x), A + 3.0f), x), x), 1.0f); };
+    auto conv2 = [](float x) { return __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x), 5.0f * A), x), 8.0f * A), x), 4.0f * A); };
+    Cubic c;
+    c.w[0] = conv2(t + 1.0f); c.w[1] = conv1(t); c.w[2] = conv1(1.0f - t); c.w[3] = conv2(2.0f - t);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) c.i[k] = min(max(base - 1 + k, 0), n_in - 1);
+    return c;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void resize_bicubic_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int hin, int win,
+                                                             int hout, int wout, float sh, float sw, int align_corners) {
+    // forward: out[p, oy, ox] = sum_ij wy[i] wx[j] in[p, iy[i], ix[j]];  BWD: `in` = grad_out, `out` = grad_in (zeroed), atomic adds
+    const long long total = (long long)planes * hout * wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % wout);
+        const long long rest = idx / wout;
+        const int oy = (int)(rest % hout);
+        const long long p = rest / hout;
+        const Cubic cy = cubic_taps(oy, sh, hin, align_corners), cx = cubic_taps(ox, sw, win, align_corners);
+        if (BWD) {
+            float* dst = out + p * (long long)hin * win;
+            const float g = in[idx];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(dst + (long long)cy.i[i] * win + cx.i[j], g * cy.w[i] * cx.w[j]);
+        } else {
+            const float* src = in + p * (long long)hin * win;
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* row = src + (long long)cy.i[i] * win;
+                float r = __fmul_rn(row[cx.i[0]], cx.w[0]);
+#pragma unroll
+                for (int j = 1; j < 4; ++j) r = __fadd_rn(r, __fmul_rn(row[cx.i[j]], cx.w[j]));
+                acc = i == 0 ? __fmul_rn(r, cy.w[0]) : __fadd_rn(acc, __fmul_rn(r, cy.w[i]));
+            }
+            out[idx] = acc;
+        }
+    }
+}
+
 // backward of ms_deaug_reduce: out = post(sum_s pre(v_s) / n), v_s = bilinear_s(x_s) (or x_s itself at the output size):
 //   d out / d x_s[tap] = g * post'(out) / n * pre'(v_s) * tap weight      (linear reductions: g / n, or g for "sum")
 struct MsGrads { float* g[MS_MAX]; };   // (kernel argument: the unrolled scale loop indexes it with compile-time constants)
@@ -733,6 +787,19 @@ extern "C" int ptb_resize_nearest(const float* in, float* out, int64_t planes, i
     const dim3 grid(grid_1d(planes * hout * wout)), block(256);
     if (backward) hipLaunchKernelGGL(resize_nearest_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
     else hipLaunchKernelGGL(resize_nearest_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    return check_launch();
+}
+
+extern "C" int ptb_resize_bicubic(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int align_corners,
+                                  int backward, ptb_stream_t stream) {
+    if (!in || !out || planes < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    float sh, sw;
+    resize_scales(hin, win, hout, wout, align_corners, sh, sw);
+    const dim3 grid(grid_1d(planes * hout * wout)), block(256);
+    if (backward) hipLaunchKernelGGL(resize_bicubic_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw, align_corners);
+    else hipLaunchKernelGGL(resize_bicubic_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw, align_corners);
     return check_launch();
 }
 

@@ -1,4 +1,4 @@
-"""Resizing on the GPU for multiscale TTA: HIP kernels ptb_resize_bilinear / ptb_resize_nearest (+ their adjoints),
+"""Resizing on the GPU for multiscale TTA: HIP kernels ptb_resize_bilinear / ptb_resize_bicubic / ptb_resize_nearest (+ their adjoints),
 ptb_ms_deaug_reduce (+ adjoint) and the fused flips + multiscale pass ptb_ms_flip_deaug_reduce.
 
 The reference calls ``torch.nn.functional.interpolate`` (inference/tta.py:599-621, 645-689) and gets gradients from autograd;
@@ -10,12 +10,12 @@ import torch
 
 from .. import _native as N
 
-_MODES = ("bilinear", "nearest")
+_MODES = ("bilinear", "nearest", "bicubic")
 
 
 def _check_mode(mode, align_corners):
     if mode not in _MODES:
-        raise NotImplementedError(f"multiscale TTA: mode={mode!r} has no native kernel (available: 'bilinear', 'nearest')")
+        raise NotImplementedError(f"multiscale TTA: mode={mode!r} has no native kernel (available: 'bilinear', 'bicubic', 'nearest')")
     if mode == "nearest" and align_corners is not None:
         # F.interpolate's own rule (the reference forwards both arguments, tta.py:613-615 / 683-685)
         raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | trilinear")
@@ -38,6 +38,8 @@ class _Resize(torch.autograd.Function):
         with N.on_device(x.device):
             if mode == "bilinear":
                 rc = lib.ptb_resize_bilinear(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 1 if align_corners else 0, N.stream_ptr(x.device))
+            elif mode == "bicubic":
+                rc = lib.ptb_resize_bicubic(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 1 if align_corners else 0, 0, N.stream_ptr(x.device))
             else:
                 rc = lib.ptb_resize_nearest(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 0, N.stream_ptr(x.device))
         N.bump()
@@ -54,6 +56,8 @@ class _Resize(torch.autograd.Function):
         with N.on_device(g.device):
             if mode == "bilinear":
                 rc = lib.ptb_resize_bilinear_bwd(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1 if ac else 0, N.stream_ptr(g.device))
+            elif mode == "bicubic":
+                rc = lib.ptb_resize_bicubic(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1 if ac else 0, 1, N.stream_ptr(g.device))
             else:
                 rc = lib.ptb_resize_nearest(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1, N.stream_ptr(g.device))
         N.bump()
@@ -63,7 +67,7 @@ class _Resize(torch.autograd.Function):
 
 def resize(x: torch.Tensor, size, mode: str, align_corners) -> torch.Tensor:
     """``F.interpolate(x, size=size, mode=mode, align_corners=align_corners)`` for a [B, C, H, W] GPU tensor
-    (mode "bilinear" | "nearest"), differentiable."""
+    (mode "bilinear" | "bicubic" | "nearest"), differentiable."""
     _check_mode(mode, align_corners)
     y = _Resize.apply(_f32(x), (int(size[0]), int(size[1])), mode, align_corners)
     return y if x.dtype == torch.float32 else y.to(x.dtype)

@@ -411,3 +411,18 @@ def test_long_stacks_and_eps_oracle(case):
     else:
         out = getattr(AO, case["fn"])(x, axis=kw["dim"], eps=kw["eps"])
     np.testing.assert_allclose(out, GT3[case["output"]], rtol=1e-5, atol=1e-6)
+
+
+GT4 = load_golden("tta4.npz")
+
+
+@pytest.mark.parametrize("case", GT4.cases, ids=lambda c: c["name"])
+def test_multiscale_bicubic_oracle(case):
+    kw = case["kwargs"]
+    offs = _offs(kw)
+    if case["fn"] == "ms_image_augment_grad":
+        for i, o in enumerate(AO.ms_image_augment(GT4["x"], offs, kw["align_corners"], mode="bicubic")):
+            np.testing.assert_allclose(o, GT4[f"{case['name']}_{i}"], rtol=1e-5, atol=2e-6)
+    else:
+        out = AO.ms_image_deaugment([GT4[f"fm_{i}"] for i in range(len(offs))], offs, kw["reduction"], kw["align_corners"], mode="bicubic")
+        np.testing.assert_allclose(out, GT4[case["name"]], rtol=1e-5, atol=2e-6)

@@ -410,7 +410,7 @@ def test_ms_flips_fused_equals_composition_at_scale(dev):
     with pytest.raises(ValueError, match="align_corners"):
         tta.ms_image_augment(ys[1], [8], mode="nearest", align_corners=False)       # F.interpolate's own rule
     with pytest.raises(NotImplementedError):
-        tta.ms_image_augment(ys[1], [8], mode="bicubic")
+        tta.ms_image_augment(ys[1], [8], mode="area")
 
 
 # ------------------------------------------------------------------ stacks longer than 8, reductions with their eps argument
@@ -438,3 +438,32 @@ def test_long_stacks_and_explicit_eps_values_and_gradients(case, dev):
     np.testing.assert_allclose(out.detach().cpu().numpy(), GT3[case["output"]], rtol=1e-5, atol=1e-6)
     (out * (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % period + 1.0)).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), GT3[case["output"] + "_grad"], rtol=2e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ multiscale with mode="bicubic"
+GT4 = load_golden("tta4.npz")
+
+
+@pytest.mark.parametrize("case", GT4.cases, ids=lambda c: c["name"])
+def test_multiscale_bicubic_values_and_gradients(case, dev):
+    """ms_image_augment / ms_image_deaugment with mode="bicubic" (ptb_resize_bicubic and its adjoint) against the unmodified
+    reference: values of every scale / of the merged map, and the autograd gradients."""
+    tta = _tta()
+    kw = case["kwargs"]
+    offs = _offs2(kw)
+    if case["fn"] == "ms_image_augment_grad":
+        x = torch.from_numpy(GT4["x"]).to(dev).requires_grad_(True)
+        outs = tta.ms_image_augment(x, offs, mode="bicubic", align_corners=kw["align_corners"])
+        tot = 0
+        for i, o in enumerate(outs):
+            np.testing.assert_allclose(o.detach().cpu().numpy(), GT4[f"{case['name']}_{i}"], rtol=1e-5, atol=2e-6)
+            tot = tot + (o * (torch.arange(o.numel(), dtype=torch.float32, device=dev).reshape(o.shape) % 5 + 1.0)).sum()
+        tot.backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), GT4[case["name"] + "_grad"], rtol=1e-4, atol=2e-5)
+    else:
+        ins = [torch.from_numpy(GT4[f"fm_{i}"]).to(dev).requires_grad_(True) for i in range(len(offs))]
+        out = tta.ms_image_deaugment(ins, offs, reduction=kw["reduction"], mode="bicubic", align_corners=kw["align_corners"])
+        np.testing.assert_allclose(out.detach().cpu().numpy(), GT4[case["name"]], rtol=1e-5, atol=1e-5)
+        (out * (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % 7 + 1.0)).sum().backward()
+        for i, t in enumerate(ins):
+            np.testing.assert_allclose(t.grad.cpu().numpy(), GT4[f"{case['name']}_grad_{i}"], rtol=2e-4, atol=2e-5)
