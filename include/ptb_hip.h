@@ -448,6 +448,14 @@ int ptb_bitempered_binary_bwd(const float* x, const float* t, const float* coef,
                               float t1, float t2, float smoothing, int iters, int has_ignore, float ignore_value,
                               ptb_stream_t stream);
 
+/* bi_tempered_logistic_loss (losses/bitempered_loss.py:135-180) for activations [R, K] (classes last) with DENSE targets [R, K]
+ * (one-hot or soft; label smoothing applied inside): out[r] = the unreduced loss of row r.  One wave per row; the tempered softmax's
+ * normalisation runs `iters` iterations (the reference's num_iters = 5): fixed point for t2 > 1, bisection for t2 < 1, log-sum-exp
+ * for t2 = 1.  backward != 0: grad_loss [R] in, out = d loss / d activations [R, K] (closed form via the escort distribution,
+ * :94-104).  t1 = 2 is rejected (the loss formula divides by 2 - t1). */
+int ptb_bitempered_rows(const float* activations, const float* onehot, const float* grad_loss, float* out, int64_t R, int K, float t1,
+                        float t2, float smoothing, int iters, int backward, ptb_stream_t stream);
+
 /* ---- Lovasz hinge / Lovasz-softmax (losses/lovasz.py:23-184) ---------------------------------------------------
  * mode 0 (softmax): pred = probabilities [B, C, HW], labels int64 [B, HW]; mode 1 (hinge): pred = logits [B, HW],
  * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the

@@ -69,6 +69,7 @@ SIGNATURES = {
     "ptb_resize_bilinear_bwd": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_deaug_reduce_bwd": (_c_int, [_vp, _ip, _ip, _c_int, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_resize_bicubic": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_bitempered_rows": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_int, _c_int, _vp]),
     "ptb_stack_reduce": (_c_int, [_vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
     "ptb_stack_reduce_bwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
     "ptb_resize_nearest": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

@@ -508,6 +508,112 @@ __global__ __launch_bounds__(256) void bitempered_binary_kernel(const BtArgs a, 
     if (!BWD) block_add<1>(s, a.sums + (size_t)(blockIdx.x % PW_SLOTS) * 4);
 }
 
+// ------------------------------------------------------------------------------------------------ bi-tempered, rows of K classes
+// bi_tempered_logistic_loss (losses/bitempered_loss.py:135-180) for activations [R, K] with dense (one-hot or soft) targets: one
+// WAVE per row -- the row maximum, every iteration of the normalisation (fixed point for t2 > 1, :25-45; bisection for t2 < 1,
+// :48-75; log-sum-exp for t2 = 1) and the loss terms are wave reductions over the K classes (lanes stride the row; rows of a
+// classification head are a few KB and stay in L1/L2 between the passes).  Backward: closed form through the escort distribution
+// (:94-104), like the binary kernel above.
+struct BtRowArgs {
+    const float* act;
+    const float* onehot;
+    const float* grad_loss;   // backward: [R]
+    float* out;               // forward: loss [R]; backward: grad [R, K]
+    long long R;
+    int K;
+    float t1, t2, smoothing;
+    int iters;
+};
+
+__device__ __forceinline__ float bt_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float bt_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// u^e for u >= 0 with the limits torch.pow gives at u = 0 (0 for e > 0, 1 for e = 0, inf for e < 0)
+__device__ __forceinline__ float bt_pow0(float u, float e) { return u > 0.0f ? bt_pow(u, e) : (e > 0.0f ? 0.0f : (e == 0.0f ? 1.0f : INFINITY)); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void bitempered_rows_kernel(const BtRowArgs a) {
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int K = a.K;
+    const float t1 = a.t1, t2 = a.t2;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < a.R; row += (long long)gridDim.x * 4) {
+        const float* x = a.act + row * K;
+        const float* y = a.onehot + row * K;
+        float mu = -INFINITY;
+        for (int k = lane; k < K; k += 64) mu = fmaxf(mu, x[k]);
+        mu = bt_wave_max(mu);
+        float norm;   // normalisation of the SHIFTED activations: p_k = exp_t(x_k - mu - norm)
+        if (t2 == 1.0f) {
+            float z = 0.f;
+            for (int k = lane; k < K; k += 64) z += fexp(x[k] - mu);
+            norm = flog(bt_wave_sum(z));
+        } else if (t2 > 1.0f) {
+            float sc = 1.0f, z = 0.f;
+            for (int it = 0; it <= a.iters; ++it) {
+                z = 0.f;
+                for (int k = lane; k < K; k += 64) z += bt_exp_t((x[k] - mu) * sc, t2);
+                z = bt_wave_sum(z);
+                if (it < a.iters) sc = bt_pow(z, 1.0f - t2);
+            }
+            norm = -bt_log_t(1.0f / z, t2);
+        } else {
+            const float edge = -1.0f / (1.0f - t2);
+            float dim = 0.f;
+            for (int k = lane; k < K; k += 64) dim += (x[k] - mu > edge) ? 1.0f : 0.0f;
+            dim = bt_wave_sum(dim);
+            float lo = 0.0f, hi = -bt_log_t(1.0f / dim, t2);
+            for (int it = 0; it < a.iters; ++it) {
+                const float mid = (hi + lo) * 0.5f;
+                float mass = 0.f;
+                for (int k = lane; k < K; k += 64) mass += bt_exp_t(x[k] - mu - mid, t2);
+                mass = bt_wave_sum(mass);
+                if (mass < 1.0f) hi = mid; else lo = mid;
+            }
+            norm = (hi + lo) * 0.5f;
+        }
+        const float sm_scale = a.smoothing > 0.0f ? 1.0f - a.smoothing * (float)K / (float)(K - 1) : 1.0f;
+        const float sm_add = a.smoothing > 0.0f ? a.smoothing / (float)(K - 1) : 0.0f;
+        const float e = 2.0f - t1;
+        if (!BWD) {
+            float l = 0.f;
+            for (int k = lane; k < K; k += 64) {
+                const float yk = sm_scale * y[k] + sm_add;
+                const float p = t2 == 1.0f ? fexp(x[k] - mu - norm) : bt_exp_t(x[k] - mu - norm, t2);
+                l += yk * bt_log_t(yk + 1e-10f, t1) - yk * bt_log_t(p, t1) - bt_pow0(yk, e) / e + bt_pow0(p, e) / e;   // :159-165
+            }
+            l = bt_wave_sum(l);
+            if (lane == 0) a.out[row] = l;
+        } else {
+            // dL/dp_k = -y_k p_k^(-t1) + p_k^(1 - t1);  dp_k/dx_j = p_k^t2 (delta_kj - escort_j), escort = p^t2 / sum p^t2
+            float dot = 0.f, S = 0.f;
+            for (int k = lane; k < K; k += 64) {
+                const float yk = sm_scale * y[k] + sm_add;
+                const float p = t2 == 1.0f ? fexp(x[k] - mu - norm) : bt_exp_t(x[k] - mu - norm, t2);
+                const float q = bt_pow0(p, t2);
+                const float gk = -yk * bt_pow0(p, -t1) + bt_pow0(p, 1.0f - t1);
+                dot += p > 0.0f ? gk * q : 0.0f;     // (a class outside the finite support passes no gradient, see the binary kernel)
+                S += q;
+            }
+            dot = bt_wave_sum(dot); S = bt_wave_sum(S);
+            const float gl = a.grad_loss[row], r = dot / S;
+            for (int k = lane; k < K; k += 64) {
+                const float yk = sm_scale * y[k] + sm_add;
+                const float p = t2 == 1.0f ? fexp(x[k] - mu - norm) : bt_exp_t(x[k] - mu - norm, t2);
+                const float q = bt_pow0(p, t2);
+                const float gk = -yk * bt_pow0(p, -t1) + bt_pow0(p, 1.0f - t1);
+                a.out[row * K + k] = gl * ((p > 0.0f ? gk * q : 0.0f) - r * q);
+            }
+        }
+    }
+}
+
 static unsigned pw_grid(long long groups) {
     long long want = (groups + 255) / 256;
     const long long cap = g_loss_grid_cap > 0 ? g_loss_grid_cap : 8192;
@@ -659,5 +765,18 @@ extern "C" int ptb_bitempered_binary_bwd(const float* x, const float* t, const f
     if (n == 0) return PTB_OK;
     BtArgs a{x, t, nullptr, grad, (long long)n, t1, t2, smoothing, ignore_value, iters, has_ignore};
     hipLaunchKernelGGL(bitempered_binary_kernel<true>, dim3(pw_grid(n)), dim3(256), 0, (hipStream_t)stream, a, coef, grad_elem);
+    return check_launch();
+}
+
+extern "C" int ptb_bitempered_rows(const float* activations, const float* onehot, const float* grad_loss, float* out, int64_t R, int K, float t1,
+                                   float t2, float smoothing, int iters, int backward, ptb_stream_t stream) {
+    if (!activations || !onehot || !out || R < 0 || K < 1 || iters < 0 || t1 == 2.0f || (backward && !grad_loss)) return PTB_EINVAL;
+    if (smoothing > 0.0f && K < 2) return PTB_EINVAL;
+    if (R == 0) return PTB_OK;
+    BtRowArgs a{activations, onehot, grad_loss, out, (long long)R, K, t1, t2, smoothing, iters};
+    const long long blocks = (R + 3) / 4;
+    const dim3 grid((unsigned)(blocks < 256 * 8 ? blocks : 256 * 8)), block(256);
+    if (backward) hipLaunchKernelGGL(bitempered_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(bitempered_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
     return check_launch();
 }

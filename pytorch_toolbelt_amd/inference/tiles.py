@@ -426,8 +426,14 @@ class TileMerger:
         horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
         ``_Bands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024)."""
         device = _resolve_device(device, "TileMerger")
-        if dtype != torch.float32:
-            raise NotImplementedError("TileMerger accumulators are float32 on the native path")
+        # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
+        # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
+        # of that dtype are read as they are, and merge() / image / norm_mask hand out tensors of that dtype.  For float16 / bfloat16
+        # that is a strictly more accurate sum than the reference's, for float64 a less accurate one (about 1e-7 relative).
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
+            raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
+        self.dtype = dtype
+        dtype = torch.float32
         N.load()
         self.image_height = image_shape[0]
         self.image_width = image_shape[1]
@@ -551,13 +557,13 @@ class TileMerger:
         """``[C, H', W']`` accumulator (zeros where nothing was integrated yet)."""
         self._plan_off("reading .image")
         self._materialize()
-        return self._image
+        return self._image if self.dtype == torch.float32 else self._image.to(self.dtype)   # (a copy: write through integrate_* only)
 
     @image.setter
     def image(self, value: torch.Tensor):
         self._plan_off("assigning .image")
         self._materialize()
-        self._image = value
+        self._image = value.to(device=self._image.device, dtype=torch.float32).contiguous()
 
     @property
     def norm_mask(self) -> torch.Tensor:
@@ -568,7 +574,7 @@ class TileMerger:
         self._norm_ready()
         self._materialize()
         self._eager_norm, self._norm_pure, self._norm_key = True, False, None
-        return self._norm
+        return self._norm if self.dtype == torch.float32 else self._norm.to(self.dtype)
 
     @norm_mask.setter
     def norm_mask(self, value: torch.Tensor):
@@ -880,6 +886,10 @@ class TileMerger:
 
     def merge(self) -> torch.Tensor:
         """``image / norm_mask`` as a new tensor (no eps clamp: never-covered pixels are NaN, like the reference)."""
+        out = self._merge_f32()
+        return out if self.dtype == torch.float32 else out.to(self.dtype)
+
+    def _merge_f32(self) -> torch.Tensor:
         if self._merged is not None:
             # planned: the accumulate launches have been writing the result block by block.  The buffer belongs to this
             # image (reset() lets go of it); a second merge() of the same image returns the same, updated tensor.
@@ -887,10 +897,11 @@ class TileMerger:
         return self._merge_into(torch.empty_like(self._image))
 
     def merge_(self) -> torch.Tensor:
-        """In-place ``image /= norm_mask``; returns ``image``."""
+        """In-place ``image /= norm_mask``; returns ``image`` (a converted copy of it when ``dtype`` is not float32)."""
         self._plan_off("merge_()")
         self._materialize()
-        return self._merge_into(self._image)
+        out = self._merge_into(self._image)
+        return out if self.dtype == torch.float32 else out.to(self.dtype)
 
     _CROP_KINDS = {"float32": (0, torch.float32), "uint8": (1, torch.uint8), "argmax_u8": (2, torch.uint8), "argmax_i64": (3, torch.int64)}
 

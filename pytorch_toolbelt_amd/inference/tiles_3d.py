@@ -132,8 +132,10 @@ class VolumeMerger:
         from .tiles import _resolve_device
 
         device = _resolve_device(device, "VolumeMerger")   # the reference's default "cpu" -> current CUDA device, warned once
-        if dtype != torch.float32:
-            raise NotImplementedError("VolumeMerger accumulators are float32 on the native path")
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
+            raise TypeError(f"VolumeMerger: dtype must be a floating point type, got {dtype}")
+        self.dtype = dtype          # honoured by merge(); the accumulators themselves are float32 (see TileMerger)
+        dtype = torch.float32
         N.load()
         self.channels = channels
         shape = tuple(int(s) for s in volume_shape)
@@ -181,4 +183,4 @@ class VolumeMerger:
                                    self.norm_mask.numel(), N.stream_ptr(dev))
         N.bump()
         N.check(rc, "VolumeMerger.merge")
-        return out
+        return out if self.dtype == torch.float32 else out.to(self.dtype)

@@ -174,3 +174,35 @@ class BiTemperedBinarySums(torch.autograd.Function):
         N.bump()
         N.check(rc, "ptb_bitempered_binary_bwd")
         return (grad,) + (None,) * 8
+
+
+class BiTemperedRows(torch.autograd.Function):
+    """Unreduced bi-tempered loss of fp32 activations [R, K] against dense targets [R, K] (``ptb_bitempered_rows``, one wave per row)."""
+
+    @staticmethod
+    def forward(ctx, act, onehot, t1, t2, smoothing, iters):
+        R, Kc = act.shape
+        loss = torch.empty(R, dtype=torch.float32, device=act.device)
+        lib = N.load()
+        with N.on_device(act.device):
+            rc = lib.ptb_bitempered_rows(act.data_ptr(), onehot.data_ptr(), None, loss.data_ptr(), R, Kc, t1, t2, smoothing, iters, 0,
+                                         N.stream_ptr(act.device))
+        N.bump()
+        N.check(rc, "ptb_bitempered_rows")
+        ctx.save_for_backward(act, onehot)
+        ctx.cfg = (t1, t2, smoothing, iters)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        act, onehot = ctx.saved_tensors
+        t1, t2, smoothing, iters = ctx.cfg
+        g = g.to(torch.float32).contiguous()
+        grad = torch.empty_like(act)
+        lib = N.load()
+        with N.on_device(act.device):
+            rc = lib.ptb_bitempered_rows(act.data_ptr(), onehot.data_ptr(), g.data_ptr(), grad.data_ptr(), act.shape[0], act.shape[1], t1, t2,
+                                         smoothing, iters, 1, N.stream_ptr(act.device))
+        N.bump()
+        N.check(rc, "ptb_bitempered_rows (backward)")
+        return grad, None, None, None, None, None

@@ -1,8 +1,9 @@
 """Bi-tempered logistic loss (Amid et al., https://arxiv.org/abs/1906.03361; reference losses/bitempered_loss.py).
 
-The general form is classification-shaped (rows of ``num_classes`` activations with an iterative per-row normalisation)
-and written as torch tensor algebra (runs on the MI355X through ATen); the binary form on GPU segmentation maps has a fused
-HIP kernel (``BinaryBiTemperedLogisticLoss._native``).  The tempered
+The general form is classification-shaped (rows of ``num_classes`` activations with an iterative per-row normalisation): on the
+GPU one fused HIP pass per direction with a wave per row (``ptb_bitempered_rows``); the torch tensor algebra below is what the
+kernels restate (used for CPU tensors, soft labels that require a gradient and the degenerate t1 = 2).  The binary form on GPU
+segmentation maps has its own per-pixel kernel (``BinaryBiTemperedLogisticLoss._native``).  The tempered
 logarithm / exponential are ``log_t(u) = (u^(1-t) - 1) / (1 - t)`` and ``exp_t(u) = [1 + (1-t) u]_+^(1/(1-t))``.
 """
 from typing import Optional
@@ -86,6 +87,23 @@ def bi_tempered_logistic_loss(activations, labels, t1, t2, label_smoothing=0.0, 
         onehot.scatter_(1, labels[..., None], 1)
     else:
         onehot = labels
+    if (activations.is_cuda and activations.dim() >= 1 and activations.is_floating_point() and not onehot.requires_grad and t1 != 2.0
+            and onehot.shape == activations.shape and activations.numel() > 0 and (label_smoothing <= 0 or activations.shape[-1] > 1)):
+        # GPU: one fused HIP pass per direction, a wave per row of classes (csrc/ptb_pointwise.hip: bitempered_rows_kernel)
+        from . import _pointwise as P
+
+        kc = activations.shape[-1]
+        act = P.as_f32(activations, "bi_tempered_logistic_loss").reshape(-1, kc)
+        hot = P.as_f32(onehot.detach(), "bi_tempered_logistic_loss").reshape(-1, kc)
+        loss = P.BiTemperedRows.apply(act, hot, float(t1), float(t2), float(max(label_smoothing, 0.0)), int(num_iters)).reshape(activations.shape[:-1])
+        loss = loss.to(activations.dtype)
+        if reduction == "none":
+            return loss
+        if reduction == "sum":
+            return loss.sum()
+        if reduction == "mean":
+            return loss.mean()
+        return None
     if label_smoothing > 0:
         k = onehot.shape[-1]
         onehot = (1 - label_smoothing * k / (k - 1)) * onehot + label_smoothing / (k - 1)

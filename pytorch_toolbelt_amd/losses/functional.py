@@ -238,7 +238,14 @@ def _region_sums(output: torch.Tensor, target: torch.Tensor, dims):
         red = sorted({d % nd for d in (dims if isinstance(dims, (list, tuple)) else [dims])})
         keep = [d for d in range(nd) if d not in red]
         if len(keep) > 1:
-            raise NotImplementedError("soft scores: the native kernel keeps at most one dimension")
+            # several kept dimensions (e.g. dims=(2, 3): one score per sample and class): they become ONE class axis of length
+            # prod(kept), the reduced ones one pixel axis -- a view when the kept dimensions lead (the usual case), else one copy
+            shape = [int(output.shape[d]) for d in keep]
+            perm = keep + red
+            o3 = output.permute(perm).reshape(1, math.prod(shape), -1)
+            t3 = target.permute(perm).reshape(o3.shape)
+            stats = K.RegionStats.apply(K._f32c(o3, "soft score"), None, K._f32c(t3, "soft score"), K.PROB_IDENTITY, False, 0, 0.0)
+            return stats[0].float().reshape(shape), (stats[1] + stats[2]).float().reshape(shape)
         if not keep:
             kept = None
             o3 = output.reshape(1, 1, -1)

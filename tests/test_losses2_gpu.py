@@ -283,3 +283,42 @@ def test_soft_f1_at_scale_and_edges(dev):
     tp, fp, fn = (pd_ * td).sum(0), (pd_ * (1 - td)).sum(0), ((1 - pd_) * td).sum(0)
     assert float(soft_micro_f1(probs, tg)) == pytest.approx(float((1 - 2 * tp / (2 * tp + fn + fp + 1e-6)).mean()), abs=1e-6)
     assert float(soft_micro_f1(probs[:, :1], tg[:, :1])) == pytest.approx(float(1 - 2 * tp[0] / (2 * tp[0] + fn[0] + fp[0] + 1e-6)), abs=1e-6)
+
+
+@pytest.mark.parametrize("case", G3.by_fn("bitempered"), ids=lambda c: c["name"])
+def test_bitempered_rows_native_matches_reference(case, dev, native):
+    """BiTemperedLogisticLoss on GPU activations [R, K] runs the wave-per-row HIP kernel (ptb_bitempered_rows): values and input
+    gradients against the unmodified reference (t2 > 1 fixed point, t2 < 1 bisection, t2 = 1, label smoothing, reductions)."""
+    from pytorch_toolbelt_amd import losses as L
+
+    x = torch.from_numpy(G3[case["inputs"][0]]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(G3[case["inputs"][1]]).to(dev)
+    before = native.calls
+    val = L.BiTemperedLogisticLoss(**case["kwargs"])(x, t)
+    assert native.calls == before + 1
+    want = G3[case["name"]]
+    assert tuple(val.shape) == want.shape
+    np.testing.assert_allclose(val.detach().cpu().numpy(), want, rtol=2e-5, atol=1e-5)
+    val.sum().backward()
+    assert native.calls == before + 2
+    np.testing.assert_allclose(x.grad.cpu().numpy(), G3[case["name"] + "_grad"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("t1,t2,sm,K", [(0.8, 1.2, 0.0, 1000), (0.7, 0.6, 0.05, 257), (1.0, 1.0, 0.1, 64), (0.5, 3.0, 0.0, 3), (0.9, 1.5, 0.2, 130)])
+def test_bitempered_rows_native_vs_algebra(t1, t2, sm, K, dev):
+    """Wider rows than the goldens (K up to 1000: several strides of the wave over a row), soft targets, fp64 torch algebra of the same
+    formulas as the yardstick (this package's CPU form, pinned against the reference in tests/test_aux_losses_cpu.py)."""
+    from pytorch_toolbelt_amd.losses.bitempered_loss import bi_tempered_logistic_loss
+
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn((37, K), generator=g) * 2.5
+    soft = torch.softmax(torch.randn((37, K), generator=g) * 3, -1)
+    xa = x.to(dev).requires_grad_(True)
+    a = bi_tempered_logistic_loss(xa, soft.to(dev), t1, t2, label_smoothing=sm, reduction="none")
+    xb = x.double().requires_grad_(True)
+    b = bi_tempered_logistic_loss(xb, soft.double(), t1, t2, label_smoothing=sm, reduction="none")
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().numpy(), rtol=2e-4, atol=2e-5)
+    w = torch.rand(37, generator=g)
+    (a * w.to(dev)).sum().backward()
+    (b * w.double()).sum().backward()
+    np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.numpy(), rtol=2e-3, atol=2e-5)

@@ -776,3 +776,26 @@ def test_lovasz_radix_sort_is_a_stable_descending_sort(B, C, H, W, per_image, de
     got_err = torch.gather(err, 1, got_vals >> 1)
     assert bool((got_err[:, 1:] <= got_err[:, :-1]).all())
     assert torch.equal(fg_total.long(), fg.sum(1))
+
+
+@pytest.mark.parametrize("dims", [(2, 3), (1,), (0, 2), (3,), (0, 1, 2, 3), (1, 3)])
+def test_soft_scores_any_dims(dims, dev):
+    """soft_dice_score / soft_jaccard_score over any subset of dimensions (losses/functional.py:188-247): several kept dimensions are
+    folded into the class axis of the statistics kernel; values against the fp64 oracle, gradients against the formula in torch."""
+    L = _L()
+    g = torch.Generator().manual_seed(5)
+    o = torch.rand((3, 4, 6, 10), generator=g)
+    t = (torch.rand((3, 4, 6, 10), generator=g) < 0.4).float()
+    for fn, ofn in ((L.soft_dice_score, LO.soft_dice_score), (L.soft_jaccard_score, LO.soft_jaccard_score)):
+        x = o.to(dev).requires_grad_(True)
+        got = fn(x, t.to(dev), smooth=0.5, eps=1e-7, dims=dims)
+        want = ofn(o.numpy(), t.numpy(), smooth=0.5, eps=1e-7, dims=dims)
+        assert tuple(got.shape) == tuple(np.shape(want))
+        np.testing.assert_allclose(got.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+        x2 = o.clone().requires_grad_(True)
+        inter, card = (x2 * t).sum(dims), (x2 + t).sum(dims)
+        ref = (2 * inter + 0.5) / (card + 0.5).clamp_min(1e-7) if fn is L.soft_dice_score else (inter + 0.5) / (card - inter + 0.5).clamp_min(1e-7)
+        w = torch.rand(ref.shape, generator=g)
+        (got * w.to(dev)).sum().backward()
+        (ref * w).sum().backward()
+        torch.testing.assert_close(x.grad.cpu(), x2.grad, rtol=1e-4, atol=1e-6)

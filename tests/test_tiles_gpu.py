@@ -836,3 +836,28 @@ def test_deferred_launch_grouping_is_bit_identical(rows, dev):
         got = b.merge()
         assert torch.equal(torch.isnan(got), torch.isnan(want)) and bool(torch.isnan(got).any())
         assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
+def test_tile_merger_dtype_argument(dtype, dev):
+    """TileMerger(..., dtype=...) (reference tiles.py:295: accumulators of any floating dtype): tile batches of that dtype are
+    taken as they are, merge() / image / norm_mask come back in it; the sums themselves are float32."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+    from pytorch_toolbelt_amd.inference.tiles_3d import VolumeMerger
+
+    slicer = ImageSlicer((200, 180, 3), 64, 32, weight="pyramid")
+    crops = slicer.crops
+    g = torch.Generator().manual_seed(3)
+    pred = torch.rand((len(crops), 2, 64, 64), generator=g)
+    m = TileMerger(slicer.target_shape, 2, slicer.weight, device=dev, dtype=dtype)
+    ref = TileMerger(slicer.target_shape, 2, slicer.weight, device=dev)
+    m.integrate_batch(pred.to(dev).to(dtype), crops)
+    ref.integrate_batch(pred.to(dtype).float().to(dev), crops)
+    out = m.merge()
+    assert out.dtype == dtype and m.image.dtype == dtype and m.norm_mask.dtype == dtype
+    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3, torch.float64: 1e-6}[dtype]
+    torch.testing.assert_close(out.float(), ref.merge(), rtol=tol, atol=tol)
+    with pytest.raises(TypeError):
+        TileMerger(slicer.target_shape, 2, slicer.weight, device=dev, dtype=torch.int32)
+    vm = VolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=dtype)
+    assert vm.merge().dtype == dtype
