@@ -172,6 +172,11 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_ms_tile_rows = value;
         return PTB_OK;
     }
+    if (key == 9) {
+        if (value < 0 || value > 64) return PTB_EINVAL;
+        g_ms_strip = value;
+        return PTB_OK;
+    }
     if (key == 8) {
         g_loss_prefetch = value ? 1 : 0;
         return PTB_OK;

@@ -294,6 +294,8 @@ struct FzArgs {
     // reciprocal is exact, bit-identical to the division); outer_mul != 0: likewise for the mean over the scales (used whenever a
     // scale is resized -- the interpolation arithmetic already differs from ATen's in the last bits; exact division otherwise).
     float inner_mul, outer_mul;
+    int strip;                         // > 0: XCD-aware tile order, strips of this many tile columns (see the kernel); 0: row-major
+    long long total_tiles;
 };
 
 // 4 consecutive de-augmented values of view `code` of a [h, w] plane at (row, col) (col % 4 == 0, w % 4 == 0)
@@ -340,11 +342,31 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
     __shared__ __attribute__((aligned(16))) float lds[LR * FZ_LP];
     __shared__ __attribute__((aligned(16))) Taps ctap[FZ_T];
     const int tiles_x = (a.wout + FZ_T - 1) / FZ_T, tiles_y = (a.hout + TH - 1) / TH;
-    int bid = blockIdx.x;
-    const int txi = bid % tiles_x;
-    bid /= tiles_x;
-    const int tyi = bid % tiles_y;
-    const long long p = bid / tiles_y;
+    int txi, tyi;
+    long long p;
+    if (a.strip > 0) {
+        // XCD-aware order: the dispatcher deals workgroups round-robin over the 8 XCDs, each with its own L2.  Workgroup b therefore
+        // becomes tile  (b % 8) * ceil(N / 8) + b / 8  of a walk that goes down strips of `strip` tile columns: neighbouring tiles --
+        // which share halo rows / columns and the 16-byte alignment overlap of their source windows -- run on the same XCD within a
+        // few hundred workgroups of each other, so the second reader of those bytes finds them in that L2 instead of in HBM.
+        const long long per_xcd = (a.total_tiles + 7) / 8;
+        const long long L = (long long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (L >= a.total_tiles) return;
+        const int tpp = tiles_x * tiles_y;
+        p = L / tpp;
+        const int r = (int)(L - p * tpp);
+        const int per_strip = a.strip * tiles_y;
+        const int st = r / per_strip, r2 = r - st * per_strip;
+        const int width = min(a.strip, tiles_x - st * a.strip);
+        tyi = r2 / width;
+        txi = st * a.strip + (r2 - tyi * width);
+    } else {
+        int bid = blockIdx.x;
+        txi = bid % tiles_x;
+        bid /= tiles_x;
+        tyi = bid % tiles_y;
+        p = bid / tiles_y;
+    }
     const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
     const int ox0 = txi * FZ_T, oy0 = tyi * TH, ox = ox0 + 4 * lx;
     const bool col_ok = ox < a.wout;
@@ -681,7 +703,11 @@ extern "C" int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* 
 // ptb_set_tunable key 6: output tile height of the fused multiscale kernel.  Same box, cfg5 (fused mean / fused gmean / plain
 // multiscale merge): 64 rows 417 / 475 / 234 us, 32 rows 412 / 432 / 224 us, 16 rows 405 / 434 / 239 us -- smaller tiles refetch more
 // halo (1.08x / 1.13x / 1.21x) but put 4 / 7 / 8 workgroups on a CU, and this kernel waits more than it streams.
-namespace ptb { int g_ms_tile_rows = 32; }
+// ptb_set_tunable key 9: XCD-aware tile order, strip width in tile columns (0 = plain row-major over all XCDs).  Same box, cfg5 fused
+// gmean / fused mean / plain merge: row-major 434 / 412 / 224 us; strips of 2: 467 / 446 / 240, 4: 456 / 431 / 232, 8: 468 / 446 / 239,
+// 16: 428 / 399 / 217, 64 (= whole tile rows: every XCD walks its own contiguous eighth of the tiles row-major): 414 / 391 / 211.
+// Keeping neighbours on one L2 pays; narrow strips cost more in DRAM page locality than the vertical halo reuse returns.
+namespace ptb { int g_ms_tile_rows = 32; int g_ms_strip = 64; }
 
 template <int NV, int INNER, int TH>
 static void launch_fz_th(const FzArgs& a, float* out, unsigned blocks, hipStream_t st) {
@@ -697,9 +723,13 @@ static void launch_fz_th(const FzArgs& a, float* out, unsigned blocks, hipStream
 template <int NV, int INNER>
 static void launch_fz(const FzArgs& a, float* out, int th, hipStream_t st) {
     const long long tiles = (long long)a.planes * ((a.hout + th - 1) / th) * ((a.wout + FZ_T - 1) / FZ_T);
-    if (th == 16) launch_fz_th<NV, INNER, 16>(a, out, (unsigned)tiles, st);
-    else if (th == 32) launch_fz_th<NV, INNER, 32>(a, out, (unsigned)tiles, st);
-    else launch_fz_th<NV, INNER, 64>(a, out, (unsigned)tiles, st);
+    FzArgs b = a;
+    b.strip = g_ms_strip;
+    b.total_tiles = tiles;
+    const long long blocks = b.strip > 0 ? 8 * ((tiles + 7) / 8) : tiles;
+    if (th == 16) launch_fz_th<NV, INNER, 16>(b, out, (unsigned)blocks, st);
+    else if (th == 32) launch_fz_th<NV, INNER, 32>(b, out, (unsigned)blocks, st);
+    else launch_fz_th<NV, INNER, 64>(b, out, (unsigned)blocks, st);
 }
 
 extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, int V, const int* views,

@@ -36,6 +36,9 @@ from pytorch_toolbelt_amd import _native as N  # noqa: E402
 if os.environ.get("PTB_MS_TILE_ROWS"):
     assert N.load().ptb_set_tunable(6, int(os.environ["PTB_MS_TILE_ROWS"])) == 0
     print("fused multiscale kernel: output tiles of 64 x", os.environ["PTB_MS_TILE_ROWS"])
+if os.environ.get("PTB_MS_STRIP"):
+    assert N.load().ptb_set_tunable(9, int(os.environ["PTB_MS_STRIP"])) == 0
+    print("fused multiscale kernel: XCD-aware tile order, strip width", os.environ["PTB_MS_STRIP"], "(0 = row-major)")
 for inner, outer in (("gmean", "gmean"), ("mean", "mean")):
     comp = timeit(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=False))
     fused = timeit(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=inner, reduction=outer, align_corners=False))
