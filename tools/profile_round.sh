@@ -17,4 +17,10 @@ rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg5 -o run -- python $R/tools/ben
 cd $R
 { for w in 8 4 2; do python tools/shard_sim.py --world $w 2>/dev/null | grep -v amdgpu; echo; done; echo "--- incremental accumulate + exchange path (round 1) for comparison"; python tools/shard_sim.py --world 8 --no-defer 2>/dev/null | grep -v amdgpu; } > $O/${TAG}_shard_sim.txt
 python tools/bench_losses.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_losses_microbench.txt
+tools/build/valu_probe > $O/${TAG}_valu_probe.txt 2>&1
+# PMC (own passes, kernel trace only): vector-ALU occupancy of the two loss kernels section 3.4 of DESIGN.md discusses
+for w in "fused" "cefocal bwd"; do t=$(echo $w | tr " " "_"); bash tools/pmc_cmd.sh $t "VALUBusy" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "MemUnitBusy" -- python $R/tools/prof_one_loss.py $w; done
+{ echo "# $TAG: rocprofv3 --pmc <group> --kernel-trace -- python tools/prof_one_loss.py {fused | cefocal bwd}  (cfg4 shape; one counter group per run)"; echo;
+  for f in $(find $R/gpurun_out/pmc -name "*.db" | sort); do python tools/pmc_summary.py $f ptb:: ; done; } > $O/${TAG}_losses_pmc.md 2>&1
+rm -rf $R/gpurun_out/pmc
 ls -la $O
