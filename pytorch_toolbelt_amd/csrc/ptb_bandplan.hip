@@ -45,8 +45,20 @@ __global__ __launch_bounds__(512) void band_plan_kernel(const ViewArgs a, const 
     constexpr int CH = PLAN_CH;
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
-    const int c = blockIdx.x % a.C;
-    const BandItem* __restrict__ it = items + blockIdx.x / a.C;
+    unsigned bid = blockIdx.x;
+    if (a.ncells == 1) {   // XCD-aware order (A/B, ptb_set_tunable key 10): every XCD walks a contiguous eighth of the (item, channel) list
+        const unsigned per_xcd = ((unsigned)a.total_chunks + 7u) / 8u;
+        bid = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        if (bid >= (unsigned)a.total_chunks) return;
+    }
+    int c = bid % a.C;
+    unsigned item = bid / a.C;
+    if (a.ncells == 2) {   // channel-major: consecutive workgroups = neighbouring chunks of ONE channel plane
+        const unsigned n_items = (unsigned)a.total_chunks / (unsigned)a.C;
+        c = bid / n_items;
+        item = bid - c * n_items;
+    }
+    const BandItem* __restrict__ it = items + item;
     const int cwch = it->cwch, partial = it->partial;
     const int cw = cwch & 0xffff, ch = cwch >> 16;
     const int q = tid & 15, r = tid >> 4;
@@ -356,7 +368,8 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
             for (size_t s = g.tiles.size(); s < (size_t)PLAN_TILES; ++s) { gt.src[s] = nullptr; gt.vs[s] = 0; }
             const long long blocks = (long long)g.item_cnt * p->C;
             if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
-            launch_plan(a, p->dev_items + g.item_off, gt, (int)blocks, (hipStream_t)stream);
+            a.ncells = g_band_xcd; a.total_chunks = (int)blocks;
+            launch_plan(a, p->dev_items + g.item_off, gt, g_band_xcd == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, (hipStream_t)stream);
             const int rc = check_launch();
             if (rc != PTB_OK) return rc;
             ++p->launched;

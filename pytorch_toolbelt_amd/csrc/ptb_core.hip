@@ -9,6 +9,7 @@ static thread_local std::string g_last_error;
 int g_chunk_rows = 32;  // 32x64 chunks (512-thread workgroups) measured best on MI355X (profiles/)
 int g_force_scalar = 0;
 int g_nt_loads = 1;
+int g_band_xcd = 0;   // ptb_set_tunable key 10
 int g_ms_tiled = 1;
 
 void set_hip_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
@@ -170,6 +171,11 @@ extern "C" int ptb_set_tunable(int key, int value) {
     if (key == 6) {
         if (value != 16 && value != 32 && value != 64) return PTB_EINVAL;
         g_ms_tile_rows = value;
+        return PTB_OK;
+    }
+    if (key == 10) {
+        if (value < 0 || value > 2) return PTB_EINVAL;
+        g_band_xcd = value;
         return PTB_OK;
     }
     if (key == 9) {
