@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 IMAGE = (5000, 5000, 3)
-TILE, STEP, CHANNELS, VIEWS, BATCH = 512, 256, 4, 8, 8
+TILE, STEP, CHANNELS, VIEWS, BATCH = 512, 256, 4, 8, int(os.environ.get("PTB_BENCH_BATCH", "8"))   # (BASELINE: batches of 8; the env override is a diagnostic)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -187,6 +187,8 @@ def main():
     crops = slicer.crops[my_tiles]
     batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    pad_mb = int(os.environ.get("PTB_BENCH_PAD_MB", "0"))   # diagnostics: shift where the model outputs land in device memory
+    _pad = torch.empty(pad_mb << 20, device=dev, dtype=torch.uint8) if pad_mb else None
     if os.environ.get("PTB_BENCH_ONE_BUFFER", "0") == "1":   # A/B: all model outputs as slices of one 12.1 GB allocation
         outputs = torch.empty((VIEWS * len(crops), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
         batch_tensors = [outputs[VIEWS * b0:VIEWS * b1] for b0, b1 in batches]

@@ -68,7 +68,9 @@ const char* ptb_last_hip_error(void);
  * (0|1, default 1), 6 = output tile rows of the fused multiscale kernel (16|32|64, default 32),
  * 7 = softmax focal backward that keeps the per-class terms in registers: pixels per lane (0 = off | 2 | 4, default 4),
  * 8 = the fused loss forward prefetches the next pixel group into a second register buffer (0|1, default 0: measured no gain),
- * 9 = XCD-aware tile order of the fused multiscale kernel: strip width in tile columns (0 = row-major order over all XCDs, default 64). */
+ * 9 = XCD-aware tile order of the fused multiscale kernel: strip width in tile columns (0 = row-major order over all XCDs, default 64),
+ * 10 = workgroup order of the band plan kernel (A/B): 0 = channels of a work item adjacent (default, fastest), 1 = every XCD a contiguous
+ * eighth of the list, 2 = channel-major. */
 int ptb_set_tunable(int key, int value);
 
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------
