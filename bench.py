@@ -305,8 +305,11 @@ def main():
     # takes the first allocation as it comes.
     placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
     if args.placement_tries > 1:      # (N > 1: every rank searches its own GPU; all ranks run the same number of steps)
+        search_steps = 30
+
         def run_ms(tensors, k):
-            nonlocal batch_tensors
+            nonlocal batch_tensors, search_steps
+            search_steps += k + 1
             batch_tensors = tensors                      # (step() reads the variable)
             q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             step()
@@ -338,7 +341,7 @@ def main():
         batch_tensors, _keep = cands[chosen]
         cands = None
         torch.cuda.empty_cache()                         # the others go back to the driver
-        placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen,
+        placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen, "steps_run_by_the_search": search_steps,
                      "note": "untimed set-up: candidate pools for the model outputs are allocated side by side, a few steps are run on each, the "
                              "fastest is kept and the rest freed -- which device memory backs the pool decides 10-15 % of the loop's speed"}
     # power management: keep a GPU that has been idle (a fresh box, the seconds this process spent importing torch) busy for a
