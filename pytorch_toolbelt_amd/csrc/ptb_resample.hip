@@ -318,12 +318,13 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
         return make_float4(s.x / div, s.y / div, s.z / div, s.w / div);
     }
     if (INNER == 2) {   // gmean, branch-free (the run-time switch over all reductions costs more than the loads it sits between)
-        s = make_float4(fast_log(x[0].x), fast_log(x[0].y), fast_log(x[0].z), fast_log(x[0].w));
+        // in the log2 domain: exp2(mean(log2 x)) == exp(mean(log x)) without the two constant multiplies per value
+        s = make_float4(__builtin_amdgcn_logf(x[0].x), __builtin_amdgcn_logf(x[0].y), __builtin_amdgcn_logf(x[0].z), __builtin_amdgcn_logf(x[0].w));
 #pragma unroll
         for (int k = 1; k < NV; ++k)
-            if (k < nv) { s.x += fast_log(x[k].x); s.y += fast_log(x[k].y); s.z += fast_log(x[k].z); s.w += fast_log(x[k].w); }
+            if (k < nv) { s.x += __builtin_amdgcn_logf(x[k].x); s.y += __builtin_amdgcn_logf(x[k].y); s.z += __builtin_amdgcn_logf(x[k].z); s.w += __builtin_amdgcn_logf(x[k].w); }
         const float inv = fast_rcp(div);
-        return make_float4(fast_exp(s.x * inv), fast_exp(s.y * inv), fast_exp(s.z * inv), fast_exp(s.w * inv));
+        return make_float4(__builtin_amdgcn_exp2f(s.x * inv), __builtin_amdgcn_exp2f(s.y * inv), __builtin_amdgcn_exp2f(s.z * inv), __builtin_amdgcn_exp2f(s.w * inv));
     }
     s = make_float4(red_pre<1>(x[0].x, op), red_pre<1>(x[0].y, op), red_pre<1>(x[0].z, op), red_pre<1>(x[0].w, op));
 #pragma unroll
@@ -334,8 +335,11 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
     return make_float4(red_post<1>(s.x, op, div), red_post<1>(s.y, op, div), red_post<1>(s.z, op, div), red_post<1>(s.w, op, div));
 }
 
+// (the gmean instances of the default tile height are pinned at 6 waves per SIMD: 80 VGPRs is an occupancy cliff, and a two-register
+// drift of the allocator -- 82 VGPRs, 5 waves -- cost them 7 %; the other instances keep whatever the allocator chooses)
 template <int NV, int INNER, int OUTER, int ALIGN, int TH>
-__global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NV <= 2 && INNER == 2 && OUTER == 2 && TH == 32) ? 6 : 1)))
+void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
     constexpr int R = TH / 16;                          // output rows per thread (tile = 64 columns x TH rows)
     constexpr int LR = TH == 64 ? FZ_LR : (TH == 32 ? FZ_LR32 : FZ_LR16);      // LDS window rows
     constexpr int FZ_U = NV <= 2 ? 3 : 2;   // window slots a lane has in flight at once (x NV views)
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
         for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const float t = OUTER == 0 ? v[j][m] : (OUTER == 2 ? ms_log(v[j][m]) : ms_pre(v[j][m], a.op_outer));
+                const float t = OUTER == 0 ? v[j][m] : (OUTER == 2 ? __builtin_amdgcn_logf(v[j][m]) : ms_pre(v[j][m], a.op_outer));   // (gmean: log2 domain)
                 acc[j][m] = s ? acc[j][m] + t : t;
             }
     }
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(256) void ms_flip_reduce_kernel(const FzArgs a, flo
             float r[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                if (OUTER == 2) r[m] = ms_exp(acc[j][m] * a.outer_mul);
+                if (OUTER == 2) r[m] = __builtin_amdgcn_exp2f(acc[j][m] * a.outer_mul);
                 else if (OUTER == 0) r[m] = a.outer_mul != 0.f ? acc[j][m] * a.outer_mul : acc[j][m] / (float)a.n;
                 else r[m] = ms_post(acc[j][m], a.op_outer, (float)a.n);
             }
