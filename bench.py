@@ -336,11 +336,17 @@ def main():
                 if enough or len(cands) >= args.placement_tries or torch.cuda.mem_get_info(dev)[0] < need + (24 << 30):
                     break
             # the level is a property of ~36 GB regions of device memory: skip ahead so that the next candidate lands in another one
-            if True:
+            try:
                 skip = min((36 << 30) - need, torch.cuda.mem_get_info(dev)[0] - need - (40 << 30))
                 if skip > (1 << 30):
                     skip_ahead.append(torch.empty(skip, device=dev, dtype=torch.uint8))
-            cands.append(alloc_outputs(0))
+                cands.append(alloc_outputs(0))
+            except RuntimeError as exc:      # (out of memory on a shared box: keep what there is)
+                print(f"[bench] placement search stopped: {exc!r}"[:300], file=sys.stderr)
+                if use_dist:                 # keep the step counts of the ranks equal: re-measure the last candidate instead
+                    cands.append(cands[-1])
+                else:
+                    break
         skip_ahead = None
         chosen = min(range(len(cands)), key=lambda i: per_cand[i])
         batch_tensors, _keep = cands[chosen]
