@@ -300,8 +300,8 @@ def main():
     # half a process gets is the driver's physical placement (not page tables: UTCL1 misses are identical; not the kernel; not
     # warm-up).  That is the whole 2.0-2.3 ms box-to-box / run-to-run spread of the headline.  A long-lived
     # serving process picks its buffer pool once, so the benchmark does what such a process can do at start-up: allocate a few
-    # candidate pools side by side (288 GB of HBM; candidates are added until one is clearly fast), run a few untimed steps on each, keep the fastest and
-    # give the others back to the driver.  Every candidate's time is in the JSON line (config.placement); --placement-tries 1
+    # candidate pools one ~36 GB region apart (pytorch_toolbelt_amd/placement.py), run a few untimed steps on each, keep the fastest
+    # and give the others back to the driver.  Every candidate's time is in the JSON line (config.placement); --placement-tries 1
     # takes the first allocation as it comes.
     placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
     if args.placement_tries > 1:      # (N > 1: every rank searches its own GPU; all ranks run the same number of steps)
@@ -322,36 +322,14 @@ def main():
 
         for _ in range(30):      # (leave the idle power state before anything is compared)
             step()
-        # candidates are added one at a time (all kept meanwhile), each ~36 GB further into device memory, until one is in the fastest
-        # class seen on these boxes (11 % quicker than the slowest so far) or --placement-tries pools exist or device memory gets short
-        cands, per_cand, skip_ahead = [(batch_tensors, _keep)], [], []
+        from pytorch_toolbelt_amd.placement import choose_placement
+
         need = sum(t.numel() * t.element_size() for t in batch_tensors)
-        while True:
-            per_cand.append(round(min(run_ms(cands[-1][0], 4), run_ms(cands[-1][0], 4)), 4))
-            if use_dist:     # every rank must run the same number of steps (halo exchanges): a fixed number of candidates
-                if len(cands) >= min(args.placement_tries, 6):
-                    break
-            else:
-                enough = len(cands) >= 3 and min(per_cand) <= 0.89 * max(per_cand)      # (the fastest class seen: 1.94-2.00 against 2.25-2.30)
-                if enough or len(cands) >= args.placement_tries or torch.cuda.mem_get_info(dev)[0] < need + (24 << 30):
-                    break
-            # the level is a property of ~36 GB regions of device memory: skip ahead so that the next candidate lands in another one
-            try:
-                skip = min((36 << 30) - need, torch.cuda.mem_get_info(dev)[0] - need - (40 << 30))
-                if skip > (1 << 30):
-                    skip_ahead.append(torch.empty(skip, device=dev, dtype=torch.uint8))
-                cands.append(alloc_outputs(0))
-            except RuntimeError as exc:      # (out of memory on a shared box: keep what there is)
-                print(f"[bench] placement search stopped: {exc!r}"[:300], file=sys.stderr)
-                if use_dist:                 # keep the step counts of the ranks equal: re-measure the last candidate instead
-                    cands.append(cands[-1])
-                else:
-                    break
-        skip_ahead = None
-        chosen = min(range(len(cands)), key=lambda i: per_cand[i])
-        batch_tensors, _keep = cands[chosen]
-        cands = None
-        torch.cuda.empty_cache()                         # the others go back to the driver
+        (batch_tensors, _keep), rep = choose_placement(
+            lambda: alloc_outputs(0), lambda pool: min(run_ms(pool[0], 4), run_ms(pool[0], 4)), need, dev, first=(batch_tensors, _keep),
+            max_tries=args.placement_tries, fixed_count=min(args.placement_tries, 6) if use_dist else None)
+        per_cand, chosen = rep["by_candidate"], rep["chosen"]
+        torch.cuda.empty_cache()      # (the first pool was still referenced from here while the search ran)
         placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen, "steps_run_by_the_search": search_steps,
                      "note": "untimed set-up: candidate pools for the model outputs are allocated side by side, a few steps are run on each, the "
                              "fastest is kept and the rest freed -- which device memory backs the pool decides 10-15 % of the loop's speed"}

@@ -99,14 +99,12 @@ def main():
                 torch.cuda.synchronize()
                 return q0.elapsed_time(q1) / 10
 
-            cands, times, pads = [outs], [quick(outs)], []
-            while len(cands) < args.placement_tries and torch.cuda.mem_get_info(dev)[0] > (80 << 30):
-                pads.append(torch.empty((36 << 30) - outs.numel() * 4, device=dev, dtype=torch.uint8))
-                cands.append(torch.randn_like(outs))
-                times.append(quick(cands[-1]))
-            outs = state["outs"] = cands[int(np.argmin(times))]
+            from pytorch_toolbelt_amd.placement import choose_placement
+
+            outs, rep = choose_placement(lambda: torch.randn_like(outs), quick, outs.numel() * 4, dev, first=outs, fixed_count=args.placement_tries)
+            state["outs"] = outs
+            times = rep["by_candidate"]
             placed = " placement candidates " + "/".join(f"{t:.3f}" for t in times) + ";"
-            del cands, pads
             torch.cuda.empty_cache()
         else:
             placed = ""
