@@ -21,7 +21,8 @@ REGION_BYTES = 36 << 30       # the granularity at which the speed level was see
 
 def choose_placement(allocate: Callable[[], Any], measure: Callable[[Any], float], nbytes: int, device, *, first: Any = None, max_tries: int = 8,
                      stop_ratio: float = 0.89, fixed_count: Optional[int] = None, region_bytes: int = REGION_BYTES,
-                     reserve_bytes: int = 40 << 30) -> Tuple[Any, Dict[str, Any]]:
+                     reserve_bytes: int = 40 << 30, free_bytes: Optional[Callable[[], int]] = None,
+                     make_spacer: Optional[Callable[[int], Any]] = None) -> Tuple[Any, Dict[str, Any]]:
     """Return ``(pool, report)``: the fastest of several candidate pools.
 
     ``allocate()`` creates one candidate (any object that keeps its device tensors alive; ``nbytes`` = its size), ``measure(pool)``
@@ -31,8 +32,14 @@ def choose_placement(allocate: Callable[[], Any], measure: Callable[[Any], float
     max`` over at least 3 candidates), after ``max_tries`` candidates, or when free memory gets short; with ``fixed_count`` exactly
     that many candidates are measured whatever they show (ranks of a distributed job must run the same number of steps).  Everything
     but the winner is released to the driver (``torch.cuda.empty_cache()``).  ``first``: an already allocated pool to start from.
-    ``report``: ``{"by_candidate": [...], "chosen": index}``."""
+    ``report``: ``{"by_candidate": [...], "chosen": index}``.  ``free_bytes`` / ``make_spacer`` replace the device queries (free memory,
+    the allocation that holds the gap) -- the CPU tests drive the search logic through them."""
     device = torch.device(device)
+    on_gpu = device.type == "cuda"
+    if free_bytes is None:
+        free_bytes = lambda: torch.cuda.mem_get_info(device)[0]      # noqa: E731
+    if make_spacer is None:
+        make_spacer = lambda n: torch.empty(n, device=device, dtype=torch.uint8)      # noqa: E731
     cands, times, spacers = [first if first is not None else allocate()], [], []
     while True:
         times.append(float(measure(cands[-1])))
@@ -41,12 +48,12 @@ def choose_placement(allocate: Callable[[], Any], measure: Callable[[Any], float
                 break
         else:
             found = len(cands) >= 3 and min(times) <= stop_ratio * max(times)
-            if found or len(cands) >= max_tries or torch.cuda.mem_get_info(device)[0] < nbytes + (24 << 30):
+            if found or len(cands) >= max_tries or free_bytes() < nbytes + (24 << 30):
                 break
         try:
-            gap = min(region_bytes - nbytes, torch.cuda.mem_get_info(device)[0] - nbytes - reserve_bytes)
+            gap = min(region_bytes - nbytes, free_bytes() - nbytes - reserve_bytes)
             if gap > (1 << 30):
-                spacers.append(torch.empty(gap, device=device, dtype=torch.uint8))
+                spacers.append(make_spacer(gap))
             cands.append(allocate())
         except RuntimeError:          # out of memory on a shared device: decide among what exists
             if fixed_count is None:
@@ -55,5 +62,6 @@ def choose_placement(allocate: Callable[[], Any], measure: Callable[[Any], float
     chosen = min(range(len(times)), key=lambda i: times[i])
     pool = cands[chosen]
     del cands, spacers
-    torch.cuda.empty_cache()
+    if on_gpu:
+        torch.cuda.empty_cache()
     return pool, {"by_candidate": [round(t, 4) for t in times], "chosen": chosen}
