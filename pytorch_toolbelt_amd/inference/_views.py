@@ -35,19 +35,22 @@ REDUCTION_CODES = {
 
 
 _LOW_PRECISION = (torch.float16, torch.bfloat16)
+_EXACT_IN_F32 = (torch.uint8, torch.int8, torch.int16, torch.bool)
 
 
-def _check_image(x, what):
+def _check_image(x, what, ints=False):
     """Validate and return (float32 tensor, dtype to cast the result back to or None).  Half / bfloat16 inputs are
     evaluated in float32 by the kernels and the result is cast back (at least as accurate as the reference's
     half-precision op chain)."""
     N.require_device(x, what)
     if x.dim() != 4:
         raise NotImplementedError(f"{what}: expected a [B, C, H, W] tensor, got shape {tuple(x.shape)}")
-    if x.dtype in _LOW_PRECISION:
-        return x.float(), x.dtype
+    if x.dtype in _LOW_PRECISION or (ints and x.dtype in _EXACT_IN_F32):
+        return x.float(), x.dtype        # (uint8 / int8 / int16 / bool images: every value is exact in float32, so are the views of them)
+    if x.dtype == torch.float64:
+        return x.float(), x.dtype        # evaluated in float32 like everything else here (documented deviation)
     if x.dtype != torch.float32:
-        raise NotImplementedError(f"{what}: the native path is float32 (half / bfloat16 are converted), got {x.dtype}")
+        raise NotImplementedError(f"{what}: the native path is float32 (half / bfloat16 / float64 and 8 / 16-bit integers are converted), got {x.dtype}")
     return x, None
 
 
@@ -142,7 +145,7 @@ class _DeaugReduce(torch.autograd.Function):
 
 
 def view_transform(x, views, in_is_batch=True, scale=1.0):
-    x, back = _check_image(x, "view transform")
+    x, back = _check_image(x, "view transform", ints=True)     # (pure data movement: integer images are fine)
     out = _ViewTransform.apply(x, list(views), in_is_batch, scale)
     return out.to(back) if back is not None else out
 

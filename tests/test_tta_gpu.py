@@ -269,6 +269,11 @@ def test_half_precision_inputs(dev):
         assert lab.dtype == dt
     with pytest.raises(NotImplementedError):
         tta.d4_image_augment(torch.zeros((1, 1, 8, 8), device=dev, dtype=torch.int32))
+    # 8 / 16-bit integer and float64 images go through float32 exactly (the reference's view ops take any dtype)
+    for dt in (torch.uint8, torch.int16, torch.float64):
+        xi = (torch.rand((2, 3, 16, 16), device=dev) * 200).to(dt)
+        got = tta.d4_image_augment(xi)
+        assert got.dtype == dt and torch.equal(got.float(), tta.d4_image_augment(xi.float()))
 
 
 @pytest.mark.parametrize("reduction", ["gmean", "hmean", "harmonic1p", "logodd", "log1p"])
