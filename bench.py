@@ -304,7 +304,9 @@ def main():
     # and give the others back to the driver.  Every candidate's time is in the JSON line (config.placement); --placement-tries 1
     # takes the first allocation as it comes.
     placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
-    if args.placement_tries > 1:      # (N > 1: every rank searches its own GPU; all ranks run the same number of steps)
+    # N > 1: the per-rank pools are small (1.5 GB at N = 8) and the search moved them by +-4 % in tools/shard_sim.py, inside its own
+    # noise, so it is off unless PTB_BENCH_DIST_PLACEMENT=1 (then every rank tries a fixed number of candidates on its own GPU)
+    if args.placement_tries > 1 and (not use_dist or os.environ.get("PTB_BENCH_DIST_PLACEMENT", "0") == "1"):
         search_steps = 30
 
         def run_ms(tensors, k):
