@@ -179,6 +179,12 @@ __device__ __forceinline__ float pw_backward(float x, float t, float w, float pw
     }
 }
 
+typedef float pw_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pw_ld16(const float* p) {     // 16-byte non-temporal load (streamed once)
+    const pw_v4f v = __builtin_nontemporal_load(reinterpret_cast<const pw_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <int KIND>
 constexpr int pw_nsums() { return (KIND == PW_BALANCED_BCE || KIND == PW_SOFT_F1) ? 4 : (KIND == PW_QFL ? 2 : 1); }
 
@@ -189,27 +195,43 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwArgs a) {
     const long long groups = (a.n + PIX - 1) / PIX;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const bool per_chan = a.chan_w || a.chan_pw;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += stride) {
-        const long long i = g * PIX;
-        float x[PIX], t[PIX], l[PIX];
-        if (VEC) {
-            const float4 xv = *reinterpret_cast<const float4*>(a.x + i), tv = *reinterpret_cast<const float4*>(a.t + i);
-            x[0] = xv.x; t[0] = tv.x;
-            if (PIX == 4) { x[1] = xv.y; x[2] = xv.z; x[3] = xv.w; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w; }
-        } else {
-            x[0] = a.x[i]; t[0] = a.t[i];
-        }
-        float w = 1.f, pw = 1.f;
-        if (per_chan) {  // HW % 4 == 0 on the vector path: the 4 elements share a channel
-            const int c = (int)((i / a.HW) % a.C);
-            w = a.chan_w ? a.chan_w[c] : 1.f;
-            pw = a.chan_pw ? a.chan_pw[c] : 1.f;
+    // two groups per trip on the vector path: 4 x 16 B of logits and targets in flight per lane before the first transcendental
+    constexpr int U = VEC ? 2 : 1;
+    for (long long g0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; g0 < groups; g0 += U * stride) {
+        float x[U][PIX], t[U][PIX];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long g = g0 + u * stride;
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) { x[u][k] = 0.f; t[u][k] = 0.f; }
+            if (g >= groups) continue;
+            const long long i = g * PIX;
+            if (VEC) {
+                const float4 xv = pw_ld16(a.x + i), tv = pw_ld16(a.t + i);
+                x[u][0] = xv.x; t[u][0] = tv.x;
+                if (PIX == 4) { x[u][1] = xv.y; x[u][2] = xv.z; x[u][3] = xv.w; t[u][1] = tv.y; t[u][2] = tv.z; t[u][3] = tv.w; }
+            } else {
+                x[u][0] = a.x[i]; t[u][0] = a.t[i];
+            }
         }
 #pragma unroll
-        for (int k = 0; k < PIX; ++k) pw_forward<KIND>(x[k], t[k], w, pw, a, s, l[k]);
-        if (a.out) {
-            if (VEC) *reinterpret_cast<float4*>(a.out + i) = make_float4(l[0], l[PIX > 1 ? 1 : 0], l[PIX > 2 ? 2 : 0], l[PIX > 3 ? 3 : 0]);
-            else a.out[i] = l[0];
+        for (int u = 0; u < U; ++u) {
+            const long long g = g0 + u * stride;
+            if (g >= groups) continue;
+            const long long i = g * PIX;
+            float l[PIX];
+            float w = 1.f, pw = 1.f;
+            if (per_chan) {  // HW % 4 == 0 on the vector path: the 4 elements share a channel
+                const int c = (int)((i / a.HW) % a.C);
+                w = a.chan_w ? a.chan_w[c] : 1.f;
+                pw = a.chan_pw ? a.chan_pw[c] : 1.f;
+            }
+#pragma unroll
+            for (int k = 0; k < PIX; ++k) pw_forward<KIND>(x[u][k], t[u][k], w, pw, a, s, l[k]);
+            if (a.out) {
+                if (VEC) *reinterpret_cast<float4*>(a.out + i) = make_float4(l[0], l[PIX > 1 ? 1 : 0], l[PIX > 2 ? 2 : 0], l[PIX > 3 ? 3 : 0]);
+                else a.out[i] = l[0];
+            }
         }
     }
     block_add<pw_nsums<KIND>()>(s, a.sums + (size_t)(blockIdx.x % PW_SLOTS) * 4);
