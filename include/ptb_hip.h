@@ -464,7 +464,8 @@ int ptb_bitempered_rows(const float* activations, const float* onehot, const flo
  * flabels = float 0/1 labels [B, HW], C = 1.  A segment is one (group, class): group = image when per_image else the
  * whole batch; S = groups*C segments of P = (per_image ? HW : B*HW) elements, n = S*P < 2^31.
  * seg_loss[s] (double, zeroed by this call) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
- * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward).
+ * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward;
+ * may be NULL when no backward will follow: the scatter of the gradients to pixel order is then skipped).
  * Workspaces are caller-provided device buffers: keys_a/keys_b u32[n] (complemented order-preserving error bits),
  * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (digit histograms of the
  * hand-written segmented radix sort: four stable 8-bit passes per segment). */

@@ -321,13 +321,13 @@ __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // 
 }
 
 // phase c: per element of the sorted order: cum fg -> grad_k = J_k - J_{k-1}; accumulate relu(e_k) * grad_k; scatter grad_k back
-// to pixel order.  The scatter is 16.7 M four-byte writes to random addresses at [4,16,512,512] and dominates this kernel
-// (~200 us).  Measured alternatives, both dropped: keeping a segment's scatter on one XCD (b % 8 placement) so that its lines
+// to pixel order.  The scatter is 16.7 M four-byte writes to random addresses at [4,16,512,512].  Measured alternatives to the
+// direct scatter, both dropped: keeping a segment's scatter on one XCD (b % 8 placement) so that its lines
 // fill up in one L2: +6 %; returning through 16384-pixel bins (append (pixel, grad) runs to <= 1024 sequential streams, then
 // order each bin in LDS and write it coalesced): 205 + 36 us against 198 us for the direct scatter.
 __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
-                                                         const unsigned* __restrict__ fg_total, double* __restrict__ seg_loss,
+                                                         const unsigned* __restrict__ fg_total, double* __restrict__ partial,
                                                          float* __restrict__ grad_at_pixel) {
     const int s = blockIdx.x / chunks_per_seg, k = blockIdx.x % chunks_per_seg;
     const long long base = (long long)s * P, i0 = (long long)k * CHUNK;
@@ -381,12 +381,31 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
             const float jprev = i == 0 ? 0.0f : jaccard_at(G, kf - 1.0f, before);
             const float g = jk - jprev;                       // lovasz.py:32-33
             acc += (double)(fmaxf(e[u], 0.0f) * g);           // dot(relu(errors_sorted), grad), lovasz.py:71 / :139
-            grad_at_pixel[base + (v[u] >> 1)] = g;
+            if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
         }
     }
+    // One partial sum per workgroup, added up per segment by lovasz_segsum_kernel.  (Consecutive workgroups belong to the same
+    // segment, so an fp64 atomic per wave meant ~2 000 atomics in a row on ONE address per segment: they serialise, and they -- not
+    // the gradient scatter -- were 150 of this kernel's 200 us.)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0 && acc != 0.0) atomicAdd(&seg_loss[s], acc);
+    __shared__ double wacc[4];
+    if (lane == 0) wacc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = wacc[0] + wacc[1] + wacc[2] + wacc[3];
+}
+
+// seg_loss[s] = sum of the segment's per-chunk partial sums (fixed order: the result does not depend on scheduling)
+__global__ __launch_bounds__(256) void lovasz_segsum_kernel(const double* __restrict__ partial, int chunks_per_seg, double* __restrict__ seg_loss) {
+    const int s = blockIdx.x;
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < chunks_per_seg; k += 256) acc += partial[(long long)s * chunks_per_seg + k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double wacc[4];
+    if ((threadIdx.x & 63) == 0) wacc[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) seg_loss[s] = wacc[0] + wacc[1] + wacc[2] + wacc[3];
 }
 
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const LovArgs a, const float* __restrict__ coef,
@@ -449,24 +468,20 @@ extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
 }
 
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
-// chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (zeroed here);
-// grad_at_pixel float[n] (kept for backward); temp = ptb_lovasz_temp_bytes bytes.
+// chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (written here);
+// grad_at_pixel float[n] (kept for backward; NULL when no gradient will be asked for); temp = ptb_lovasz_temp_bytes bytes.
 extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                               int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                               unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                               double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
     LovArgs a{};
     if (int rc = fill(a, pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)) return rc;
-    if (!keys_a || !keys_b || !vals_a || !vals_b || !chunk || !fg_total || !seg_loss || !grad_at_pixel) return PTB_EINVAL;
+    if (!keys_a || !keys_b || !vals_a || !vals_b || !chunk || !fg_total || !seg_loss) return PTB_EINVAL;
     const long long n = a.P * a.S;
     if (n == 0) return PTB_OK;
     if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;  // offsets / packed indices are 32-bit
     if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    {   // the per-segment dot products are accumulated with atomics: start from zero (on the launch stream)
-        const hipError_t e = hipMemsetAsync(seg_loss, 0, (size_t)a.S * sizeof(double), s);
-        if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
-    }
     hipLaunchKernelGGL(lovasz_error_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, keys_a, vals_a);
     if (int rc = check_launch()) return rc;
     // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
@@ -491,8 +506,10 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     if (total_chunks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin == keys_a ? vals_a : vals_b, a.P, cps, chunk);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, seg_loss,
+    double* partial = static_cast<double*>(temp);      // (the sort is done with its histograms: 1 KB per 4096-element tile, 16 B needed)
+    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial,
                        grad_at_pixel);
+    hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
     return check_launch();
 }
 

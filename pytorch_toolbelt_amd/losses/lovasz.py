@@ -23,7 +23,7 @@ class _LovaszSegments(torch.autograd.Function):
     """Per-segment Lovasz dot products [S] (float64) and per-segment foreground counts [S] (int32)."""
 
     @staticmethod
-    def forward(ctx, pred, labels, flabels, mode, per_image, has_ignore, ignore_label, ignore_value):
+    def forward(ctx, pred, labels, flabels, mode, per_image, has_ignore, ignore_label, ignore_value, want_grad=True):
         if mode == _SOFTMAX:
             B, C, HW = pred.shape
         else:
@@ -36,7 +36,9 @@ class _LovaszSegments(torch.autograd.Function):
         alloc = torch.empty if n > 0 else torch.zeros     # (the forward entry point zeroes / fills both itself)
         seg_loss = alloc(S, dtype=torch.float64, device=dev)
         fg_total = alloc(S, dtype=torch.int32, device=dev)
-        gpix = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        # want_grad False (the caller saw no_grad / a detached input): forward only, the per-pixel gradient is never written
+        want_grad = bool(want_grad and ctx.needs_input_grad[0])
+        gpix = torch.empty(max(n, 1) if want_grad else 0, dtype=torch.float32, device=dev)
         if n > 0:
             lib = N.load()
             keys = torch.empty((2, n), dtype=torch.int32, device=dev)
@@ -50,7 +52,7 @@ class _LovaszSegments(torch.autograd.Function):
                 rc = lib.ptb_lovasz_fwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
                                         1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
                                         vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
-                                        seg_loss.data_ptr(), gpix.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
+                                        seg_loss.data_ptr(), gpix.data_ptr() if want_grad else None, temp.data_ptr(), int(tb), N.stream_ptr(dev))
             N.bump()
             N.check(rc, "ptb_lovasz_fwd")
         ctx.save_for_backward(pred, labels, flabels, gpix)
@@ -72,7 +74,7 @@ class _LovaszSegments(torch.autograd.Function):
                                         N.stream_ptr(pred.device))
             N.bump()
             N.check(rc, "ptb_lovasz_bwd")
-        return grad, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None
 
 
 def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
@@ -85,7 +87,7 @@ def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
     if y.shape[1] != x.shape[1]:
         raise RuntimeError(f"target shape {tuple(labels.shape)} does not match logits shape {tuple(logits.shape)}")
     seg_loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
-                                          float(ignore_index) if ignore_index is not None else 0.0)
+                                          float(ignore_index) if ignore_index is not None else 0.0, torch.is_grad_enabled() and x.requires_grad)
     return seg_loss.mean().float() if per_image else seg_loss[0].float()
 
 
@@ -103,7 +105,7 @@ def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_i
     if lab.shape[1] != x.shape[2]:
         raise RuntimeError(f"target shape {tuple(labels.shape)} does not match probabilities shape {tuple(probas.shape)}")
     seg_loss, fg = _LovaszSegments.apply(x, lab, None, _SOFTMAX, bool(per_image), ignore_index is not None,
-                                         int(ignore_index) if ignore_index is not None else 0, 0.0)
+                                         int(ignore_index) if ignore_index is not None else 0, 0.0, torch.is_grad_enabled() and x.requires_grad)
     groups = B if per_image else 1
     seg_loss = seg_loss.view(groups, C)
     if classes == "present":

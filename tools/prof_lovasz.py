@@ -24,3 +24,13 @@ for _ in range(20):
 e1.record()
 torch.cuda.synchronize()
 print(f"LovaszLoss forward [4,16,512,512]: {e0.elapsed_time(e1) / 20:.3f} ms")
+with torch.no_grad():
+    for _ in range(3):
+        L.LovaszLoss()(probs, lab)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        L.LovaszLoss()(probs, lab)
+    e1.record()
+    torch.cuda.synchronize()
+print(f"LovaszLoss forward [4,16,512,512] under no_grad (no per-pixel gradient scatter): {e0.elapsed_time(e1) / 20:.3f} ms")
