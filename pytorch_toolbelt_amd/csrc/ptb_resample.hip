@@ -335,10 +335,10 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
     return make_float4(red_post<1>(s.x, op, div), red_post<1>(s.y, op, div), red_post<1>(s.z, op, div), red_post<1>(s.w, op, div));
 }
 
-// (the gmean instances of the default tile height are pinned at 6 waves per SIMD: 80 VGPRs is an occupancy cliff, and a two-register
+// (the mean / mean and gmean / gmean instances of the default tile height are pinned at 6 waves per SIMD: 80 VGPRs is an occupancy cliff, and a two-register
 // drift of the allocator -- 82 VGPRs, 5 waves -- cost them 7 %; the other instances keep whatever the allocator chooses)
 template <int NV, int INNER, int OUTER, int ALIGN, int TH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NV <= 2 && INNER == 2 && OUTER == 2 && TH == 32) ? 6 : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NV <= 2 && TH == 32 && ((INNER == 2 && OUTER == 2) || (INNER == 0 && OUTER == 0))) ? 6 : 1)))
 void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
     constexpr int R = TH / 16;                          // output rows per thread (tile = 64 columns x TH rows)
     constexpr int LR = TH == 64 ? FZ_LR : (TH == 32 ? FZ_LR32 : FZ_LR16);      // LDS window rows

@@ -1,0 +1,74 @@
+"""Register budgets of the hot kernels, from the compiler's own report (hipcc cross-compiles for gfx950 without a GPU).
+
+The kernels of the benchmarked paths sit right at occupancy cliffs: the fused multiscale kernel at 80 VGPRs (6 waves per SIMD; a
+two-register drift once cost its gmean instance 7 %), the band-plan kernel must not touch scratch memory (run-time indexing of a
+by-value struct once put 52 B per lane there: 2.58 instead of 2.19 ms per image), the straight-line loss kernels must not spill.
+This test recompiles the three translation units with -Rpass-analysis=kernel-resource-usage and checks those budgets."""
+import re
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+import pytest
+
+import __graft_entry__ as entry
+
+CSRC = Path(entry.CSRC)
+
+
+def _report(src):
+    cmd = [entry.HIPCC] + [f for f in entry.FLAGS if f != "-shared"] + ["-c", str(CSRC / src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+(VGPRs|VGPRs Spill|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).split(" [")[0]] = int(m.group(2))
+    return kernels
+
+
+@pytest.fixture(scope="module")
+def reports():
+    with ThreadPoolExecutor(3) as pool:
+        r = list(pool.map(_report, ["ptb_resample.hip", "ptb_bandplan.hip", "ptb_losses.hip"]))
+    return dict(resample=r[0], bandplan=r[1], losses=r[2])
+
+
+def _find(kernels, *needles):
+    hits = {k: v for k, v in kernels.items() if all(n in k for n in needles)}
+    assert hits, f"no kernel matching {needles}"
+    return hits
+
+
+def test_fused_multiscale_kernel_stays_on_its_occupancy_step(reports):
+    # ms_flip_reduce_kernel<NV = 2, INNER, OUTER, ALIGN, TH = 32>: the cfg5 instances (mean / mean = <2,0,0,*,32>, gmean / gmean = <2,2,2,*,32>)
+    for k, r in _find(reports["resample"], "ms_flip_reduce_kernelILi2ELi0ELi0E", "ELi32EE").items():
+        assert r["VGPRs"] <= 80 and r["ScratchSize"] == 0 and r["Occupancy"] >= 6, (k, r)
+    for k, r in _find(reports["resample"], "ms_flip_reduce_kernelILi2ELi2ELi2E", "ELi32EE").items():
+        assert r["VGPRs"] <= 80 and r["ScratchSize"] <= 16 and r["Occupancy"] >= 6, (k, r)     # (align_corners = 1 spills 2 registers to stay there)
+    for k, r in _find(reports["resample"], "ms_flip_reduce_kernel").items():
+        assert r["LDS Size"] <= 41 * 1024, (k, r)      # 64 x 64 tiles: 40 KB, 4 workgroups per CU
+
+
+def test_band_plan_kernel_has_no_scratch(reports):
+    hits = _find(reports["bandplan"], "band_plan_kernel")
+    for k, r in hits.items():
+        assert r["ScratchSize"] == 0 and r.get("VGPRs Spill", 0) == 0, (k, r)
+    d4_mean = _find(hits, "ILi8ELi6166440ELi0ELi1E")          # the headline instance: 8 views, D4 codes, linear reduction, fp32 source
+    for k, r in d4_mean.items():
+        assert r["VGPRs"] <= 64 and r["Occupancy"] >= 8, (k, r)     # 512-thread workgroups: 8 waves per SIMD = 4 workgroups per CU
+
+
+def test_straight_line_loss_kernels_do_not_spill(reports):
+    fused = _find(reports["losses"], "seg_fwd_lean_kernelILi16ELi0ELb1ELb0ELi2ELb0ELb1ELb0E")    # cfg4 fused forward, C = 16
+    for k, r in fused.items():
+        assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0, (k, r)
+    for k, r in _find(reports["losses"], "softmax_focal_bwd_kernelILi4ELi16ELb1E").items():
+        assert r["ScratchSize"] == 0 and r.get("VGPRs Spill", 0) == 0, (k, r)
+    for k, r in _find(reports["losses"], "seg_fused_bwd_lean_kernelILi16E").items():
+        assert r["ScratchSize"] == 0, (k, r)
