@@ -697,8 +697,9 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const SegArgs a, const f
 
 // ------------------------------------------------------------------------------------------------ region-stat backward
 // With G_c = (gI[c]*t_c + gP[c]) * mask:  softmax: p_k (G_k - sum_c G_c p_c);  sigmoid: G p (1-p);  identity: G.
+// (the C <= 16 label instance is pinned at 5 waves per SIMD: the allocator took 101 VGPRs, 5 over the step; 95 without a spill)
 template <int PIX, int CREG, bool DENSE>
-__global__ __launch_bounds__(256) void seg_stats_bwd_kernel(const SegArgs a, const float* __restrict__ gI,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PIX == 4 && CREG == 16 && !DENSE) ? 5 : 1))) void seg_stats_bwd_kernel(const SegArgs a, const float* __restrict__ gI,
                                                             const float* __restrict__ gP, float* __restrict__ grad) {
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;

@@ -72,3 +72,5 @@ def test_straight_line_loss_kernels_do_not_spill(reports):
         assert r["ScratchSize"] == 0 and r.get("VGPRs Spill", 0) == 0, (k, r)
     for k, r in _find(reports["losses"], "seg_fused_bwd_lean_kernelILi16E").items():
         assert r["ScratchSize"] == 0, (k, r)
+    for k, r in _find(reports["losses"], "seg_stats_bwd_kernelILi4ELi16ELb0E").items():      # Dice / Jaccard backward at cfg4
+        assert r["VGPRs"] <= 96 and r["ScratchSize"] == 0 and r["Occupancy"] >= 5, (k, r)
