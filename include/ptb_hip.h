@@ -70,7 +70,8 @@ const char* ptb_last_hip_error(void);
  * 8 = the fused loss forward prefetches the next pixel group into a second register buffer (0|1, default 0: measured no gain),
  * 9 = XCD-aware tile order of the fused multiscale kernel: strip width in tile columns (0 = row-major order over all XCDs, default 64),
  * 10 = workgroup order of the band plan kernel (A/B): 0 = channels of a work item adjacent (default, fastest), 1 = every XCD a contiguous
- * eighth of the list, 2 = channel-major. */
+ * eighth of the list, 2 = channel-major,
+ * 11 = rows per work item of band plans created afterwards (32 | 64, default 64). */
 int ptb_set_tunable(int key, int value);
 
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------

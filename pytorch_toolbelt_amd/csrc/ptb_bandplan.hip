@@ -23,11 +23,11 @@
 namespace ptb {
 
 constexpr int PLAN_TILES = 224;   // tiles of one launch group (kernarg: 224 x 16 B + ViewArgs < 4 KiB)
-constexpr int PLAN_CH = 32;       // item rows (512-thread workgroups, like the incremental kernels' default chunk)
+constexpr int PLAN_CH = 32;       // item rows of the 512-thread instance; plans are created with 32 or 64 rows per item (ptb_set_tunable key 11)
 
 struct BandItem {                 // 64 B = one cache line per workgroup, read with scalar loads only (never copied to registers as a
     int ax, ay;                   // whole: run-time indexing of a by-value copy would put it in scratch memory); (ax, ay) = origin
-    int cwch;                     // extent: columns | rows << 16  (<= 64 x 32)
+    int cwch;                     // extent: columns | rows << 16  (<= 64 x 64)
     int ntiles;                   // covering tiles (0: uncovered pixels -> 0 / 0 = NaN like the reference's merge)
     int partial;                  // 1: write the un-normalised weighted sum (multi-GPU boundary rows) instead of sum / norm
     int pad[3];
@@ -40,9 +40,8 @@ struct GroupTiles {
     long long vs[PLAN_TILES];     // elements between consecutive views of this tile (its batch size * C * th * tw)
 };
 
-template <int NV, int CODES, int OPK, int LD>
-__global__ __launch_bounds__(512) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
-    constexpr int CH = PLAN_CH;
+template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH>
+__global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
     unsigned bid = blockIdx.x;
@@ -90,12 +89,15 @@ __global__ __launch_bounds__(512) void band_plan_kernel(const ViewArgs a, const 
     }
 }
 
-static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTiles& t, int blocks, hipStream_t s) {
-    const dim3 grid(blocks), block(512);
+static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTiles& t, int blocks, int ch, hipStream_t s) {
+    const dim3 grid(blocks), block(16 * ch);
     const bool nonlinear = a.op >= PTB_RED_GMEAN;
 #define PTB_PLAN_LD(NV, CODES, LD)                                                                                  \
     do {                                                                                                            \
-        if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD>), grid, block, 0, s, a, items, t);    \
+        if (ch == 64) {                                                                                             \
+            if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, 64>), grid, block, 0, s, a, items, t); \
+            else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, 64>), grid, block, 0, s, a, items, t);       \
+        } else if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD>), grid, block, 0, s, a, items, t);    \
         else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD>), grid, block, 0, s, a, items, t);              \
     } while (0)
 #define PTB_PLAN(NV, CODES)                                                                                         \
@@ -127,6 +129,7 @@ struct Group {
 
 struct ptb_band_plan {
     int n, C, th, tw, H, W;
+    int ch = ptb::PLAN_CH;                // rows per work item (ptb_set_tunable key 11 at creation: 32 | 64)
     std::vector<int> xs, ys;
     std::vector<ptb::BandItem> items;
     std::vector<ptb::Group> groups;
@@ -170,11 +173,11 @@ static int band_items(const ptb_band_plan& p, const std::vector<int>& cover, con
         cells.push_back(c);
     }
     for (const XCell& c : cells) {
-        for (int cy = y0; cy < y1; cy += PLAN_CH) {
+        for (int cy = y0; cy < y1; cy += p.ch) {
             for (int cx = 0; cx < c.w; cx += CW) {
                 BandItem it{};
                 it.ax = c.ox + cx; it.ay = cy;
-                it.cwch = std::min(CW, c.w - cx) | (std::min(PLAN_CH, y1 - cy) << 16);
+                it.cwch = std::min(CW, c.w - cx) | (std::min(p.ch, y1 - cy) << 16);
                 it.ntiles = c.n;
                 it.partial = partial;
                 for (int e = 0; e < c.n; ++e) {
@@ -197,6 +200,7 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
     if (g_force_scalar || tw % 4 || th % 4 || W % 4 || tw > 32767 || th > 32767) return PTB_EUNSUPPORTED;
     ptb_band_plan* p = new ptb_band_plan();
     p->n = n; p->C = C; p->th = th; p->tw = tw; p->H = H; p->W = W;
+    p->ch = g_band_rows;
     p->xs.resize(n); p->ys.resize(n);
     std::vector<int> edges{0, H};
     for (int t = 0; t < n; ++t) {
@@ -369,7 +373,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
             const long long blocks = (long long)g.item_cnt * p->C;
             if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
             a.ncells = g_band_xcd; a.total_chunks = (int)blocks;
-            launch_plan(a, p->dev_items + g.item_off, gt, g_band_xcd == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, (hipStream_t)stream);
+            launch_plan(a, p->dev_items + g.item_off, gt, g_band_xcd == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, p->ch, (hipStream_t)stream);
             const int rc = check_launch();
             if (rc != PTB_OK) return rc;
             ++p->launched;

@@ -154,11 +154,21 @@ def _c_band_plan(crops, C, th, tw, H, W, rows, final=None, cuts=()):
     return int(nbytes), dict(groups=rows_arr.reshape(-1, 3), bands=nb.value, items=ni.value, last_group=last_group)
 
 
-def test_band_plan_of_the_deferred_merger():
+@pytest.mark.parametrize("item_rows", [64, 32])
+def test_band_plan_of_the_deferred_merger(item_rows):
     """ptb_band_plan_create: bands = rows between consecutive tile edges, grouped into launches of ~rows_per_launch rows; the
-    tile that completes each group, the last group reading each tile, the work-item count -- for the headline geometry and some
-    irregular ones."""
+    tile that completes each group, the last group reading each tile, the work-item count (64 columns x `item_rows` rows each:
+    ptb_set_tunable key 11, default 64) -- for the headline geometry and some irregular ones."""
     from oracle import tiles_oracle as TO
+
+    assert N.load().ptb_set_tunable(11, item_rows) == 0
+    try:
+        _band_plan_checks(TO, item_rows)
+    finally:
+        assert N.load().ptb_set_tunable(11, 64) == 0
+
+
+def _band_plan_checks(TO, item_rows):
 
     crops = TO.slicer_geometry((5000, 5000), 512, 256)["crops"]
     # one band per launch: the 20 bands of the headline geometry
@@ -166,21 +176,21 @@ def test_band_plan_of_the_deferred_merger():
     assert p["bands"] == 20 and len(p["groups"]) == 20
     assert [(int(g[0]), int(g[1])) for g in p["groups"]] == [(256 * k, 256 * k + 256) for k in range(20)]
     assert [int(g[2]) for g in p["groups"]] == [19 * min(k, 18) + 18 for k in range(20)]   # the last tile of tile row k (19 and 18: row 18)
-    assert p["items"] == 20 * (5120 // 64) * (256 // 32)
+    assert p["items"] == 20 * (5120 // 64) * (256 // item_rows)
     assert p["last_group"][0] == 1 and p["last_group"][19] == 2 and p["last_group"][360] == 19
     # 1024 rows per launch (the default): 5 launches of 4 bands, every pixel row in exactly one group
     _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1024)
     assert [(int(g[0]), int(g[1])) for g in p["groups"]] == [(1024 * k, 1024 * k + 1024) for k in range(5)]
     assert [int(g[2]) for g in p["groups"]] == [19 * 3 + 18, 19 * 7 + 18, 19 * 11 + 18, 19 * 15 + 18, 360]   # tile row r covers rows 256 r .. 256 r + 512
     assert p["last_group"][0] == 0 and p["last_group"][19 * 3] == 1 and p["last_group"][360] == 4
-    assert p["items"] == (5120 // 64) * (5120 // 32)
+    assert p["items"] == (5120 // 64) * (5120 // item_rows)
     # a launch never takes more than 224 tiles: one launch for the whole image is cut into several
     _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1 << 20)
     assert len(p["groups"]) == 2 and int(p["groups"][0][0]) == 0 and int(p["groups"][-1][1]) == 5120
     # uncovered rows / columns are planned too (they merge to NaN like the reference's 0 / 0)
     _, p = _c_band_plan(np.array([[64, 64, 128, 128], [256, 64, 128, 128]]), 1, 128, 128, 320, 512, 64)
     assert int(p["groups"][0][0]) == 0 and int(p["groups"][-1][1]) == 320
-    assert p["items"] == (512 // 64) * (320 // 32)
+    assert p["items"] == (512 // 64) * (320 // item_rows)      # bands of 64, 128, 128 rows
     # step < tile / 4: more than 4 tiles over a pixel -> not deferrable
     dense = TO.slicer_geometry((600, 600), 256, 48)["crops"]
     assert _c_band_plan(dense, 1, 256, 256, 640, 640, 256)[0] == -2

@@ -861,3 +861,34 @@ def test_tile_merger_dtype_argument(dtype, dev):
         TileMerger(slicer.target_shape, 2, slicer.weight, device=dev, dtype=torch.int32)
     vm = VolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=dtype)
     assert vm.merge().dtype == dtype
+
+
+@pytest.mark.parametrize("group,reduction,dtype", [("d4", "mean", torch.float32), ("d4", "gmean", torch.float32), ("fliplr", "sum", torch.float32),
+                                                   ("d4", "mean", torch.float16)])
+def test_band_plan_item_rows_32_and_64_are_bit_identical(group, reduction, dtype, dev):
+    """Band plans are made of 64 x 64 work items by default (1024-thread workgroups) or 64 x 32 (ptb_set_tunable key 11): the same
+    sums in the same order, so the merged maps must agree bit for bit -- with each other and with the incremental merger."""
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+    from pytorch_toolbelt_amd.inference.tta import DEAUGMENT_VIEWS
+
+    slicer = ImageSlicer((900, 700, 3), 256, 128, weight="pyramid")
+    crops, C, V = slicer.crops, 3, len(DEAUGMENT_VIEWS[group])
+    mergers = {}
+    try:
+        for rows in (32, 64):
+            assert N.load().ptb_set_tunable(11, rows) == 0
+            mergers[rows] = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+    finally:
+        assert N.load().ptb_set_tunable(11, 64) == 0
+    mergers["plain"] = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    g = torch.Generator().manual_seed(5)
+    for b0 in range(0, len(crops), 7):
+        nb = min(7, len(crops) - b0)
+        y = (torch.rand((V * nb, C, 256, 256), generator=g) * 0.9 + 0.05).to(dev).to(dtype)
+        for m in mergers.values():
+            m.integrate_batch_deaugment(y, crops[b0:b0 + nb], group=group, reduction=reduction)
+    outs = {k: m.merge() for k, m in mergers.items()}
+    for rows in (32, 64):
+        assert mergers[rows]._bands is not None and mergers[rows]._bands_done == len(mergers[rows]._bands.bands)
+        assert torch.equal(outs[rows], outs["plain"]), rows
