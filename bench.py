@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--ramp-max-ms", type=float, default=4000.0)
     ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are run this many times (each run bracketed by barrier + "
                     "synchronize); `value` is the MEDIAN run, all runs are listed in config.repeat_ms_per_step")
+    ap.add_argument("--no-secondary", action="store_true", help="skip config.secondary (cfg4 losses, cfg5 multiscale, Lovasz on this GPU)")
     ap.add_argument("--no-variants", action="store_true", help="skip the secondary timings (no-defer / unplanned / literal drop-in sequence)")
     ap.add_argument("--defer-rows", type=int, default=0, help="rows of the image merged per deferred launch (0: the library default, 1024)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
@@ -134,6 +135,121 @@ def cpu_baseline(slicer, max_seconds=25.0):
     }
 
 
+def _gpu_ms(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
+    """The other BASELINE configs on this GPU, driver-visible (bounded: < 3 s of GPU work, ~10 s of CPU baselines):
+    configs[3] fused BinaryFocal + Dice + Jaccard on [32,16,512,512] (forward, forward + backward), configs[4] multiscale
+    (0.75 / 1.0 / 1.25) + fliplr on 4096 x 4096 with gmean (one-pass kernel and the composed reference call sequence), and the
+    Lovasz-softmax loss on [4,16,512,512].  Per entry: ms per call (HIP events around back-to-back calls, module call = every launch
+    it makes), the algorithmic bytes of SURVEY 8d (inputs read once + outputs written once), their fraction of the 8 TB/s peak, and
+    the reference's op chain timed on the host CPU (oracle/torch_chain.py, a bounded sample, scaled)."""
+    from pytorch_toolbelt_amd import losses as L
+    from pytorch_toolbelt_amd.inference import tta
+
+    out = {}
+
+    def entry(ms, nbytes, **extra):
+        d = {"ms": round(ms, 4), "bytes": int(nbytes), "frac": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        d.update(extra)
+        return d
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    # ---- configs[3]
+    B, C, H, W = 32, 16, 512, 512
+    x = torch.randn((B, C, H, W), device=dev, generator=g)
+    labels = torch.randint(0, C, (B, H, W), device=dev, generator=g)
+    fwd_bytes = x.numel() * 4 + labels.numel() * 8                      # 603 979 776
+    bwd_bytes = fwd_bytes + x.numel() * 4                               # + one more read of logits and labels, the gradient written
+    crit = L.FocalDiceJaccardLoss("multiclass")
+    with torch.no_grad():
+        t_f = _gpu_ms(lambda: crit(x, labels), 30)
+    xg = x.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        xg.grad = None
+        crit(xg, labels).backward()
+
+    t_fb = _gpu_ms(fwd_bwd, 20)
+    out["cfg4_fwd"] = entry(t_f, fwd_bytes, what="FocalDiceJaccardLoss('multiclass') forward, [32,16,512,512] fp32 logits + int64 labels, per module call")
+    out["cfg4_fwd_bwd"] = entry(t_fb, fwd_bytes + bwd_bytes, what="same, forward + backward (gradient wrt the logits)")
+    seps = {"BinaryFocalLoss": L.BinaryFocalLoss(), "DiceLoss": L.DiceLoss("multiclass"), "JaccardLoss": L.JaccardLoss("multiclass")}
+    with torch.no_grad():
+        out["cfg4_fwd"]["separate_modules_ms"] = {k: round(_gpu_ms(lambda c=c: c(x, labels), 10), 4) for k, c in seps.items()}
+    del xg
+    # ---- Lovasz
+    probs = torch.softmax(x[:4], 1).contiguous()
+    lab4 = labels[:4].contiguous()
+    lov = L.LovaszLoss()
+    lov_in = probs.numel() * 4 + lab4.numel() * 8
+    with torch.no_grad():
+        t_lf = _gpu_ms(lambda: lov(probs, lab4), 10)
+    pg = probs.clone().requires_grad_(True)
+
+    def lov_fb():
+        pg.grad = None
+        lov(pg, lab4).backward()
+
+    t_lfb = _gpu_ms(lov_fb, 10)
+    out["lovasz_fwd"] = entry(t_lf, lov_in, what="LovaszLoss() forward on [4,16,512,512] probabilities (16 segments of 1 M sorted; sort-bound, the "
+                                                 "fraction counts the inputs once)")
+    out["lovasz_fwd_bwd"] = entry(t_lfb, lov_in + probs.numel() * 4, what="same, forward + backward")
+    del pg, probs
+    # ---- configs[4]
+    n, c5 = 4096, 4
+    offs = [-n // 4, 0, n // 4]
+    ys = [torch.rand((2, c5, n + o, n + o), device=dev, generator=g) * 0.9 + 0.05 for o in offs]
+    alg5 = sum(y.numel() for y in ys) * 4 + c5 * n * n * 4               # 1 946 157 056
+    for name, red in (("cfg5_gmean", "gmean"), ("cfg5_mean", "mean")):
+        t_one = _gpu_ms(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=red, reduction=red, align_corners=False), 20)
+        t_lit = _gpu_ms(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=red) for y in ys], offs, reduction=red,
+                                                       align_corners=False), 10)
+        out[name] = entry(t_one, alg5, what=f"multiscale 0.75/1.0/1.25 + fliplr on 4096x4096, C=4, {red}: tta.ms_flips_image_deaugment (one pass)",
+                          reference_call_sequence_ms=round(t_lit, 4))
+    if with_cpu:
+        from oracle import torch_chain as TC
+
+        cores, _logical, model = TC.host_description()
+        prev = torch.get_num_threads()
+        try:
+            torch.set_num_threads(min(cores, 32))
+            used = torch.get_num_threads()
+            xs, ls = x[:2].cpu(), labels[:2].cpu()
+            TC.binary_focal_multiclass_dice_jaccard(xs[:1], ls[:1])
+            t0 = time.perf_counter()
+            TC.binary_focal_multiclass_dice_jaccard(xs, ls)
+            t_c4 = (time.perf_counter() - t0) * (B / 2)
+            out["cfg4_fwd"]["cpu_baseline"] = {"ms": round(t_c4 * 1e3, 1), "cores": used, "kind": "port",
+                                               "sample": f"2 of {B} images through the reference's op chain (one-hot focal + Dice + Jaccard), x{B // 2}; {model}"}
+            p1, l1 = torch.softmax(xs[:1], 1), ls[:1]
+            t0 = time.perf_counter()
+            TC.lovasz_softmax(p1, l1)
+            t_lv = (time.perf_counter() - t0) * 4
+            out["lovasz_fwd"]["cpu_baseline"] = {"ms": round(t_lv * 1e3, 1), "cores": used, "kind": "port",
+                                                 "sample": "1 of 4 images (16 classes: sort + cumsum + dot per class), x4"}
+            if time.perf_counter() - t0 < cpu_budget_s:
+                ys_cpu = [y[:, :1].cpu() for y in ys]
+                t0 = time.perf_counter()
+                TC.ms_fliplr_deaugment(ys_cpu, offs, "gmean", align_corners=False)
+                t_c5 = (time.perf_counter() - t0) * c5
+                out["cfg5_gmean"]["cpu_baseline"] = {"ms": round(t_c5 * 1e3, 1), "cores": used, "kind": "port",
+                                                     "sample": f"1 of {c5} channels (flip + stack + gmean per scale, F.interpolate, stack + gmean), x{c5}"}
+        finally:
+            torch.set_num_threads(prev)
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -188,7 +304,8 @@ def main():
     if not sharded:
         my_tiles = np.arange(n_tiles)
     else:
-        sharded_merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev, partition=partition)
+        sharded_merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev, partition=partition,
+                                           defer=os.environ.get("PTB_BENCH_SHARDED_DEFER", "1") == "1")
         my_tiles = sharded_merger.tiles
     crops = slicer.crops[my_tiles]
     batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]
@@ -304,6 +421,25 @@ def main():
     # and give the others back to the driver.  Every candidate's time is in the JSON line (config.placement); --placement-tries 1
     # takes the first allocation as it comes.
     placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
+    first_alloc = None
+    if args.placement_tries > 1 and not use_dist:
+        # what a process that takes its first allocation as it comes would report (the ADVICE of round 2: the search result is
+        # best-of-N placements): a short ramp, then the same K steps timed the same way, on the pool allocated first
+        for _ in range(60):
+            step()
+        torch.cuda.synchronize()
+        fa = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            fa.append((time.perf_counter() - t0) / args.steps * 1e3)
+        fa_ms = sorted(fa)[1]
+        first_alloc = {"ms_per_step": round(fa_ms, 4), "value_MP_s": round(IMAGE[0] * IMAGE[1] / 1e3 / fa_ms, 1),
+                       "region_hbm_frac": round((VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) / (fa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "note": "the same K steps on the model-output pool as first allocated, before the placement search (median of 3 runs)"}
     # N > 1: the per-rank pools are small (1.5 GB at N = 8) and the search moved them by +-4 % in tools/shard_sim.py, inside its own
     # noise, so it is off unless PTB_BENCH_DIST_PLACEMENT=1 (then every rank tries a fixed number of candidates on its own GPU)
     if args.placement_tries > 1 and (not use_dist or os.environ.get("PTB_BENCH_DIST_PLACEMENT", "0") == "1"):
@@ -393,35 +529,58 @@ def main():
     if not sharded and not args.no_variants:
         from pytorch_toolbelt_amd.inference import tta as _tta
 
-        def variant(make, literal=False):
+        from pytorch_toolbelt_amd.inference import tiles as _tiles
+
+        def variant(make, literal=False, fresh=False, eager=False):
             m = make()
+            prev = (_tta.set_lazy_deaugment(not eager), _tiles.set_auto_plan(not eager))
+            _tiles._auto.clear()
 
             def vstep():
-                m.reset()
+                nonlocal m
+                if fresh:
+                    m = make()    # the README loop: a new merger for every image
+                else:
+                    m.reset()
                 for t, c in zip(batch_tensors, batch_crops):
-                    if literal:   # the reference's two calls, unfused: the reduced tile travels through HBM
+                    if literal:   # the reference's two calls
                         m.integrate_batch(_tta.d4_image_deaugment(t), c)
                     else:
                         m.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
                 return m.merge()
 
-            for _ in range(3):
-                vstep()
-            vr = sorted(timed_run(vstep, args.steps)[0] for _ in range(3))
+            try:
+                for _ in range(3):
+                    vstep()
+                vr = sorted(timed_run(vstep, args.steps)[0] for _ in range(3))
+                mode = m.mode
+            finally:
+                _tta.set_lazy_deaugment(prev[0])
+                _tiles.set_auto_plan(prev[1])
             del m
-            return round(vr[1] / args.steps * 1e3, 4)
+            return round(vr[1] / args.steps * 1e3, 4), mode
 
         mk = lambda **kw: (lambda: TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, **kw))  # noqa: E731
+        lit, lit_mode = variant(mk(), literal=True)
+        lit_new, lit_new_mode = variant(mk(), literal=True, fresh=True)
         variants = {
-            "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None)),
-            "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256)),
-            "planned_no_defer_ms": variant(mk(crops=slicer.crops)),
-            "unplanned_fused_ms": variant(mk()),
-            "dropin_literal_ms": variant(mk(), literal=True),
+            "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None))[0],
+            "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256))[0],
+            "planned_no_defer_ms": variant(mk(crops=slicer.crops))[0],
+            "unplanned_fused_ms": variant(mk(auto_plan=False))[0],
+            "dropin_literal_ms": lit,
+            "dropin_literal_merger_mode": lit_mode,
+            "dropin_literal_new_merger_per_image_ms": lit_new,
+            "dropin_literal_new_merger_per_image_mode": lit_new_mode,
+            "dropin_literal_eager_ms": variant(mk(), literal=True, eager=True)[0],
             "note": "ms per 5000x5000 image, median of 3 runs of K steps; deferred_bands = TileMerger(crops=, defer=True) + "
                     "integrate_batch_deaugment (the headline); planned_no_defer = TileMerger(crops=) + integrate_batch_deaugment; "
-                    "unplanned_fused = TileMerger() + integrate_batch_deaugment + merge(); dropin_literal = the reference's literal "
-                    "calls TileMerger() + integrate_batch(tta.d4_image_deaugment(y), crops) + merge(), no API extension",
+                    "unplanned_fused = TileMerger(auto_plan=False) + integrate_batch_deaugment + merge(); dropin_literal = the reference's "
+                    "literal calls, no API extension: TileMerger(shape, C, weight) + integrate_batch(tta.d4_image_deaugment(y), crops) + "
+                    "merge() -- the de-augmentation comes back as a lazy handle the merger fuses into its launch, and the merger plans "
+                    "itself from the crop sequence of the previous image (reset() per image; _new_merger_per_image: a new TileMerger "
+                    "per image as in the README); dropin_literal_eager = the same calls with both switched off (round 2's behaviour: "
+                    "the reduced tile travels through HBM, separate merge pass)",
         }
 
     if args.diag and rank == 0 and not use_dist:   # (extra steps on one rank only would leave the others' halo exchanges unmatched)
@@ -502,30 +661,42 @@ def main():
         sink = torch.zeros(4, device=dev)
         lib = N.load()
 
-        def probe_pass():
-            for t in batch_tensors:
-                lib.ptb_read_probe(t.data_ptr(), t.numel() * t.element_size(), sink.data_ptr(), N.stream_ptr(dev))
+        import ctypes
 
-        probe_pass()
-        torch.cuda.synchronize()
-        pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        pe0.record()
-        for _ in range(3):
-            probe_pass()
-        pe1.record()
-        torch.cuda.synchronize()
-        box_ceiling = 3 * sum(t.numel() * t.element_size() for t in batch_tensors) / (pe0.elapsed_time(pe1) * 1e-3) / 1e9
+        nb = len(batch_tensors)
+        ptrs = (ctypes.c_void_p * nb)(*[t.data_ptr() for t in batch_tensors])
+        sizes = (ctypes.c_int64 * nb)(*[t.numel() * t.element_size() for t in batch_tensors])
+
+        def probe_pass(wgs):   # ONE launch over all batches (a persistent grid; ramp-up and tail paid once, like a band launch)
+            got = lib.ptb_read_probe_multi(ptrs, sizes, nb, sink.data_ptr(), wgs, N.stream_ptr(dev))
+            assert got > 0, got
+            return got
+
+        best = 0.0
+        for wgs in (2048, 4096, 8192):
+            probe_pass(wgs)
+            torch.cuda.synchronize()
+            pe0, pe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            pe0.record()
+            read = sum(probe_pass(wgs) for _ in range(3))
+            pe1.record()
+            torch.cuda.synchronize()
+            best = max(best, read / (pe0.elapsed_time(pe1) * 1e-3) / 1e9)
+        box_ceiling = best
 
     mp = IMAGE[0] * IMAGE[1] / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     value = mp * args.steps / elapsed  # one image per step for the whole job (strong scaling for N > 1)
     region_bytes = VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4  # 12 532 580 352 B
 
-    traffic = None
+    traffic, traffic_when = None, ""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("band_plan_d4_bytes_per_launch" if n_bands else "view_accum_d4_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("band_plan_d4_bytes_per_launch" if n_bands else "view_accum_d4_bytes_per_launch")
+            if tj.get("measured"):
+                traffic_when = f"; PMC run of {tj['measured']}"
         except Exception:
             traffic = None
 
@@ -574,6 +745,7 @@ def main():
                                                             "(PTB_BENCH_PRIME_POOL=0: 46 separate 256 MiB device allocations)"
                                                             if os.environ.get("PTB_BENCH_PRIME_POOL", "1") == "1" else ", 46 separate device allocations")),
                 "placement": placement,
+                "first_allocation": first_alloc,
                 "fallback": fallback,
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "timing": f"value = median of {len(repeat_ms)} runs of exactly {args.steps} steps, each bracketed by barrier + synchronize",
@@ -597,17 +769,26 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                "traffic_source": "rocprofv3 PMC passes of this command (profiles/traffic.json: FETCH_SIZE x2 + WRITE_SIZE per launch), not re-measured in this run",
+                "traffic_source": "rocprofv3 PMC passes of this command (profiles/traffic.json: FETCH_SIZE x2 + WRITE_SIZE per launch), not re-measured in "
+                                  "this run" + traffic_when,
                 "box_read_ceiling": None if box_ceiling is None else round(box_ceiling, 1),
                 "frac_of_box_read_ceiling": None if box_ceiling is None else round(achieved / box_ceiling, 4),
-                "box_read_ceiling_note": "GB/s of a pure read-only stream (ptb_read_probe: 16 B/lane, 8 nt loads in flight, 8192 workgroups) "
-                                         "over the same 12.1 GB of model outputs on THIS box, measured in this run",
+                "box_read_ceiling_note": "GB/s of a pure read-only stream (ptb_read_probe_multi: 16 B/lane, 8 nt loads in flight, ONE launch of a "
+                                         "persistent grid over all batches, best of 2048 / 4096 / 8192 workgroups) over the same 12.1 GB of model "
+                                         "outputs on THIS box, measured in this run",
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "avg_launch_ms": round(launch_ms, 5),
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(slicer)
+        if world == 1 and not use_dist and not args.no_secondary:
+            del batch_tensors, _keep
+            torch.cuda.empty_cache()
+            try:
+                line["config"]["secondary"] = secondary_workloads(dev, with_cpu=not args.no_cpu_baseline)
+            except Exception as exc:  # noqa: BLE001  (the headline line must survive a failing side measurement)
+                line["config"]["secondary"] = {"error": repr(exc)}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

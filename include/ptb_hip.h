@@ -145,6 +145,12 @@ int ptb_merge_band(float* merged, const float* norm_full, const float* weight, c
  * read stream and quote its kernels against that as well as against the 8 TB/s spec.  `sink` = 4 writable device bytes. */
 int ptb_read_probe(const void* buf, int64_t bytes, float* sink, ptb_stream_t stream);
 
+/* The same read-only stream over `n` (<= 64) buffers in ONE launch (pointer table in the kernel arguments, a persistent grid of
+ * `workgroups` (0: 8192) workgroups walking 32 KiB chunks of the concatenation), so that a pass over the per-batch model outputs
+ * of an image pays ramp-up and tail once, like the band kernel it is compared with.  Returns the bytes the launch reads (whole
+ * 32 KiB chunks of every buffer) or a negative error code. */
+int64_t ptb_read_probe_multi(const void* const* bufs, const int64_t* bytes, int n, float* sink, int workgroups, ptb_stream_t stream);
+
 /* out[i] = sum_s slot_sums[s][i] for the [nslots][n] slotted fp64 sums the loss entry points produce (they zero the slots and
  * the label flag themselves, on the launch stream: callers hand in uninitialised workspaces).  When error_flag (may be NULL) was
  * raised by the forward kernel -- a label outside [0, C) that is not ignore_index, where the reference's F.one_hot raises -- every

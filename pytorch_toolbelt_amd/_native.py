@@ -40,6 +40,7 @@ SIGNATURES = {
     "ptb_last_hip_error": (ctypes.c_char_p, []),
     "ptb_set_tunable": (_c_int, [_c_int, _c_int]),
     "ptb_read_probe": (_c_int, [_vp, _c_i64, _vp, _vp]),
+    "ptb_read_probe_multi": (_c_i64, [_vpp, _i64p, _c_int, _vp, _c_int, _vp]),
     "ptb_sums_finalize": (_c_int, [_vp, _c_int, _c_int, _vp, _vp, _vp]),
     "ptb_tile_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_deaug_reduce_t": (_c_int, [_vp, _c_int, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

@@ -1,0 +1,198 @@
+"""Lazy de-augmentation results: what lets the reference's literal loop take the fused kernels.
+
+The reference's hot loop is two calls (README.md:215-226; inference/tta.py:442-467 feeding inference/tiles.py:321-339)::
+
+    merger.integrate_batch(tta.d4_image_deaugment(model(tta.d4_image_augment(tiles))), crops)
+
+Evaluated call by call, the reduced tile travels through HBM between them (one write + one read of ``[B, C, h, w]`` and a
+second launch per batch).  ``*_image_deaugment`` therefore returns a ``LazyDeaugment``: a ``torch.Tensor`` subclass that has
+the result's shape / dtype / device and remembers ``(source, views, reduction)`` instead of computing anything.
+``TileMerger.integrate_batch`` recognises it and launches the fused de-augment + blend kernel on the source
+(``ptb_deaug_accumulate`` / the planned kernel / the band plan); ANY other use -- an operator, a method, ``print``, indexing,
+``.cpu()``, ``data_ptr()``, a custom kernel -- goes through ``__torch_function__`` / ``__torch_dispatch__``, which first run
+the ordinary de-augment kernel (``ptb_deaug_reduce``) once and then hand the real tensor on.  The value is cached, so in-place
+operations on the handle behave like in-place operations on the eager result.
+
+What a caller could observe, and how it is bounded:
+
+* the source is kept alive until the handle dies or is evaluated -- at most ``PTB_LAZY_DEAUG_BYTES`` (default 4 GiB) of
+  sources are kept across all pending handles, older ones are evaluated when a new one would exceed it;
+* a source modified in place before the handle is evaluated would change the result: the source's version counter is
+  checked at evaluation and a ``RuntimeError`` says so (tensors created under ``torch.inference_mode()`` have no counter;
+  there the check is skipped);
+* evaluation happens on the stream that is current *then*; when that is not the stream of the call the source is
+  ``record_stream``-ed.
+
+Only inference-shaped calls are lazy (float32 CUDA source, string reduction, no autograd, no tracing / compiling);
+everything else is evaluated on the spot exactly as before.  ``tta.set_lazy_deaugment(False)`` / ``PTB_LAZY_DEAUG=0``
+switch it off.
+"""
+import os
+import weakref
+from collections import OrderedDict
+
+import torch
+from torch.utils._pytree import tree_map
+
+_ENABLED = os.environ.get("PTB_LAZY_DEAUG", "1") != "0"
+_BUDGET = int(os.environ.get("PTB_LAZY_DEAUG_BYTES", str(4 << 30)))
+_pending = OrderedDict()      # id(handle) -> (weakref, bytes of its source), creation order
+_pending_bytes = 0
+evaluations = 0               # handles that had to be evaluated by themselves (diagnostics / tests)
+fused = 0                     # handles a merger consumed through the fused path (diagnostics / tests)
+
+
+def set_enabled(flag: bool) -> bool:
+    """Switch lazy de-augmentation on / off; returns the previous setting."""
+    global _ENABLED
+    prev, _ENABLED = _ENABLED, bool(flag)
+    return prev
+
+
+def enabled() -> bool:
+    return _ENABLED
+
+
+def _source_version(t):
+    try:
+        return t._version
+    except RuntimeError:      # inference tensors do not track a version counter
+        return None
+
+
+def _forget(key):
+    global _pending_bytes
+    ent = _pending.pop(key, None)
+    if ent is not None:
+        _pending_bytes -= ent[1]
+
+
+def _admit(handle, nbytes):
+    """Register a new pending handle; evaluate the oldest ones while the sources kept alive exceed the budget."""
+    global _pending_bytes
+    while _pending and _pending_bytes + nbytes > _BUDGET:
+        key, (ref, _n) = next(iter(_pending.items()))
+        old = ref()
+        if old is None:
+            _forget(key)
+        else:
+            try:
+                old._evaluate()   # (forgets itself)
+            except RuntimeError:  # its source was modified: that is for ITS user to hear about, not for this unrelated call
+                _forget(key)
+    key = id(handle)
+    _pending[key] = (weakref.ref(handle, lambda _r, k=key: _forget(k)), nbytes)
+    _pending_bytes += nbytes
+
+
+# attribute getters / methods that only look at metadata the wrapper itself carries: answered without evaluating
+_META_NAMES = ("shape", "dtype", "device", "ndim", "is_cuda", "is_cpu", "layout", "requires_grad", "grad_fn", "is_leaf", "is_sparse",
+               "is_quantized", "is_meta", "names", "grad", "is_nested", "is_mkldnn", "is_xpu", "is_mps", "output_nr")
+_META_FUNCS = set()
+for _n in _META_NAMES:
+    _p = getattr(torch.Tensor, _n, None)
+    if _p is not None and hasattr(_p, "__get__"):
+        _META_FUNCS.add(_p.__get__)
+for _n in ("size", "dim", "ndimension", "numel", "nelement", "__len__", "element_size", "is_floating_point", "is_complex", "get_device",
+           "is_contiguous", "stride", "storage_offset", "is_inference", "is_signed", "is_shared", "is_pinned", "is_same_size", "has_names"):
+    _f = getattr(torch.Tensor, _n, None)
+    if _f is not None:
+        _META_FUNCS.add(_f)
+del _n, _p, _f
+
+
+class LazyDeaugment(torch.Tensor):
+    """Result of ``<group>_image_deaugment(source, reduction)`` that has not been computed yet (see the module docstring)."""
+
+    @staticmethod
+    def __new__(cls, source, group, views, code, compute):
+        n_views = len(views)
+        shape = (source.shape[0] // n_views,) + tuple(source.shape[1:])
+        return torch.Tensor._make_wrapper_subclass(cls, shape, dtype=source.dtype, device=source.device, requires_grad=False)
+
+    def __init__(self, source, group, views, code, compute):
+        self._src = source                 # [V*B, C, H, W] contiguous float32 model output (chunk-major)
+        self._group = group                # "d4" | "d2" | "flips" | "fliplr" | "flipud"
+        self._views = views                # inverse view codes, chunk order
+        self._code = code                  # HIP reduction code
+        self._compute = compute            # (source, views, code) -> tensor: the eager kernel
+        self._value = None
+        self._src_version = _source_version(source)
+        self._stream = torch.cuda.current_stream(source.device) if source.is_cuda else None
+        _admit(self, source.numel() * source.element_size())
+
+    # ---------------------------------------------------------------- evaluation
+    def _check_source(self):
+        if self._src_version is not None and _source_version(self._src) != self._src_version:
+            raise RuntimeError("the model output passed to *_image_deaugment was modified in place before the (lazily evaluated) result was "
+                               "used; evaluate the result first, or switch lazy de-augmentation off (tta.set_lazy_deaugment(False))")
+
+    def _note_stream(self):
+        src = self._src
+        if self._stream is not None:
+            cur = torch.cuda.current_stream(src.device)
+            if cur != self._stream:
+                src.record_stream(cur)
+
+    def _evaluate(self):
+        """The real tensor (computed once)."""
+        value = self._value
+        if value is None:
+            global evaluations
+            self._check_source()
+            self._note_stream()
+            with torch._C.DisableTorchFunctionSubclass():
+                value = self._compute(self._src, self._views, self._code)
+            self._value = value
+            self._src = None
+            _forget(id(self))
+            evaluations += 1
+        return value
+
+    def _take_source(self):
+        """For a merger: ``(source, group, views, code)`` when the fused path may still be taken, else None.  The handle stays
+        valid (a later use evaluates it from the same source)."""
+        if self._value is not None:
+            return None
+        self._check_source()
+        self._note_stream()
+        return self._src, self._group, self._views, self._code
+
+    # ---------------------------------------------------------------- protocol
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in _META_FUNCS:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        args, kwargs = tree_map(_unwrap, args), tree_map(_unwrap, kwargs)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):   # safety net: code that reaches ATen without __torch_function__
+        kwargs = kwargs or {}
+        return func(*tree_map(_unwrap, args), **tree_map(_unwrap, kwargs))
+
+    def __repr__(self):   # noqa: D105
+        return repr(self._evaluate())
+
+
+def _unwrap(x):
+    return x._evaluate() if type(x) is LazyDeaugment else x
+
+
+def maybe_lazy(source, group, views, code, compute):
+    """A ``LazyDeaugment`` for this call when it is inference-shaped, else None (the caller evaluates eagerly)."""
+    if not _ENABLED or type(source) is not torch.Tensor or not source.is_cuda or source.dtype != torch.float32 or source.dim() != 4:
+        return None
+    if source.requires_grad and torch.is_grad_enabled():
+        return None
+    n_views = len(views)
+    if source.shape[0] % n_views != 0 or source.numel() == 0 or not source.is_contiguous():
+        return None
+    if any(v & 1 for v in views) and source.shape[2] != source.shape[3]:
+        return None
+    if torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling():
+        return None
+    return LazyDeaugment(source, group, views, code, compute)

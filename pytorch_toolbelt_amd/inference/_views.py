@@ -32,6 +32,9 @@ REDUCTION_CODES = {
     "logodd": N.RED_LOGODD,
     "log1p": N.RED_LOG1P,
 }
+REDUCTION_NAMES = {}
+for _name, _code in REDUCTION_CODES.items():
+    REDUCTION_NAMES.setdefault(_code, _name)
 
 
 _LOW_PRECISION = (torch.float16, torch.bfloat16)

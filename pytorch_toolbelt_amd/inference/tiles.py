@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import _native as N
+from . import _lazy
 
 __all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "compute_pyramid_patch_weight_loss"]
 
@@ -281,6 +282,66 @@ def _resolve_device(device, what):
     )
 
 
+# ------------------------------------------------------------------------------------------------ self-planning mergers
+# The reference's loop builds `TileMerger(tiler.target_shape, C, tiler.weight)` -- no crop list -- for every image and feeds it the
+# same crops in the same order (README.md:201-226).  A merger without `crops=` therefore records the crop sequence it saw
+# (at `merge()`), and the NEXT merger of the same geometry and window (or the same one after `reset()`) plans itself from it:
+# normaliser precomputed, every block divided in the launch that brings its last tile, no separate merge pass.  Any deviation
+# from the remembered sequence drops back to the ordinary path for the rest of that image (bit-identical results either way).
+_AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "1") != "0"
+_AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser in HBM once planned)
+_auto = __import__("collections").OrderedDict()   # key -> _AutoEntry
+_weight_sigs = {}        # id(weight array) -> (weakref, signature)
+
+
+def set_auto_plan(flag: bool) -> bool:
+    """Switch self-planning of ``TileMerger`` without ``crops=`` on / off (default on; ``PTB_AUTO_PLAN=0``); returns the previous setting."""
+    global _AUTO_PLAN
+    prev, _AUTO_PLAN = _AUTO_PLAN, bool(flag)
+    return prev
+
+
+def _weight_signature(weight: np.ndarray):
+    """Content signature of a blending window, O(1) when the same array object comes back (``tiler.weight`` every image)."""
+    import hashlib
+    import weakref
+
+    probe = weight.reshape(-1)[::4099][:64].tobytes()
+    ent = _weight_sigs.get(id(weight))
+    if ent is not None and ent[0]() is weight and ent[2] == probe:
+        return ent[1]
+    sig = (weight.shape, weight.dtype.str, hashlib.blake2b(np.ascontiguousarray(weight).tobytes(), digest_size=12).digest())
+    try:
+        if len(_weight_sigs) > 64:
+            _weight_sigs.clear()
+        _weight_sigs[id(weight)] = (weakref.ref(weight), sig, probe)
+    except TypeError:
+        pass
+    return sig
+
+
+class _AutoEntry:
+    __slots__ = ("log", "seen", "need", "parts", "disabled")
+
+    def __init__(self):
+        self.log = None        # bytes of the [n, 4] int64 crop sequence of the last merged image
+        self.seen = 0          # consecutive merged images that ended with exactly this sequence
+        self.need = 1          # repeats required before planning (grows when a planned image deviated)
+        self.parts = None      # (xy, remaining0, norm_full, crops4) shared by the mergers planned from `log`
+        self.disabled = False  # this geometry cannot be planned / its user reads accumulators or merges partially
+
+
+def _auto_entry(key, create=False):
+    ent = _auto.get(key)
+    if ent is None and create:
+        while len(_auto) >= _AUTO_MAX:
+            _auto.popitem(last=False)
+        ent = _auto[key] = _AutoEntry()
+    elif ent is not None:
+        _auto.move_to_end(key)
+    return ent
+
+
 class _Plan:
     """State of a *planned* TileMerger (constructed with the complete ``crops`` of the image).
 
@@ -341,6 +402,40 @@ class _Plan:
             if self.done[y // _FRESH_ROWS:(y + th + _FRESH_ROWS - 1) // _FRESH_ROWS, x // 64:(x + tw + 63) // 64].any():
                 return True
         return False
+
+
+def _tensor_version(t):
+    try:
+        return t._version
+    except RuntimeError:      # inference tensors carry no version counter: in-place edits of them cannot be seen
+        return None
+
+
+def _held_entry(batch):
+    """(first byte, one past the last byte, version counter) of a batch a deferred merger is about to keep a reference to."""
+    p0 = batch.data_ptr()
+    return p0, p0 + batch.numel() * batch.element_size(), _tensor_version(batch)
+
+
+def _check_held(held, batch, span, launches, what):
+    """The contract of deferred merging, enforced: a held batch is read by a LATER launch, so (1) a new batch must not live in
+    the memory of one that is still held -- a model writing into a static output buffer (HIP graphs, ``out=``, preallocated
+    outputs) has then already overwritten data the merger has not read, which no fallback can bring back -- and (2) a held batch
+    must not have been modified in place since it was handed in (checked when its launch is due).  ``held`` rows end with
+    (p0, p1, version); ``span`` = ``_held_entry(batch)``."""
+    p0, p1, _v = span
+    for h in held:
+        if h[-3] < p1 and p0 < h[-2] and h[0] is not batch:
+            raise RuntimeError(f"{what}: this batch occupies memory of an earlier batch that is still held for a later launch (bytes "
+                               f"{max(p0, h[-3]):#x}..{min(p1, h[-2]):#x}) -- the model writes its outputs into a reused buffer, so the earlier "
+                               "predictions are already gone.  Deferred merging needs every batch to stay alive and unmodified until its rows "
+                               "are merged: hand over fresh tensors (or clones), or construct the merger without defer=True.")
+    if launches:
+        for i, h in enumerate(held):
+            if h[-1] is not None and _tensor_version(h[0]) != h[-1]:
+                raise RuntimeError(f"{what}: held batch {i} of the rows about to be merged was modified in place after it was handed to the "
+                                   "merger (its version counter moved).  Deferred merging reads the batches later: keep them unmodified, "
+                                   "or construct the merger without defer=True.")
 
 
 def _defer_rows_default():
@@ -416,7 +511,8 @@ class TileMerger:
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
 
-    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None):
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None,
+                 auto_plan=None):
         """``crops`` (extension, optional): the complete crop list the image will receive (``tiler.crops``), in the
         order it will be integrated.  With it the merger runs *planned*: the normaliser is known up front and every
         block of the image is divided by it in the very launch that brings its last tile, so ``merge()`` has nothing
@@ -424,7 +520,13 @@ class TileMerger:
 
         ``defer=True`` (with ``crops``): *deferred* planned merging -- the merger holds on to the batches and merges a
         horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
-        ``_Bands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024)."""
+        ``_Bands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024).
+
+        Without ``crops`` the merger plans itself (``auto_plan``, default on: ``set_auto_plan`` / ``PTB_AUTO_PLAN``): the crop
+        sequence an image ended with at ``merge()`` is remembered per geometry + window, and the next merger of that geometry
+        (or this one after ``reset()``) runs planned from it -- the reference's per-image ``TileMerger(shape, C, weight)``
+        gets the planned kernels from the second image on.  A deviating batch, a read of ``image`` / ``norm_mask`` or
+        ``merge_()`` drop back to the ordinary path (see ``_unfinalise`` for the one case that is not bit-exact)."""
         device = _resolve_device(device, "TileMerger")
         # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
         # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
@@ -457,6 +559,14 @@ class TileMerger:
         self._eager_norm = False  # norm_mask was handed out: keep it up to date inside the accumulate kernels
         self._merged = None       # planned mode: the merge result the accumulate launches fill in
         self._plan = _Plan.build(self, crops) if crops is not None else None
+        self._auto_key = None     # self-planning: key of this geometry + window in the module cache
+        self._auto_planned = False
+        self._auto_noted = None   # log length at the last merge() of this image
+        self._weight_version0, self._weight_ptr0 = self.weight._version, self.weight.data_ptr()
+        if crops is None and (auto_plan if auto_plan is not None else _AUTO_PLAN) and isinstance(weight, np.ndarray):
+            self._auto_key = (device.index if device.index is not None else torch.cuda.current_device(), int(self.image_height),
+                              int(self.image_width)) + _weight_signature(weight)
+            self._auto_attach()
         self._bands = None
         self._fast_cache = {}
         self.fast_submits = 0     # deferred batches that took the cached host path (diagnostic)
@@ -469,8 +579,9 @@ class TileMerger:
                                        self.image_width, device, defer_rows if defer_rows is not None else _defer_rows_default())
             if self._bands is None:
                 _warn_once(("defer", tuple(self.weight.shape), self.image_height, self.image_width),
-                           "TileMerger(defer=True): the deferred band kernel does not take this geometry (origins off the 4-pixel grid, "
-                           "more than 48 tiles per band or 4 per pixel); the planned incremental path is used (same results, slower).")
+                           "TileMerger(defer=True): the deferred band kernel does not take this geometry (tile origins, tile size or image width "
+                           "off the 4-pixel grid, more than 224 tiles per launch group or more than 4 tiles over a pixel); the planned incremental "
+                           "path is used (same results, slower).")
         elif defer:
             _warn_once(("defer-noplan",), "TileMerger(defer=True) needs the complete crop list (crops=tiler.crops) on the planned block "
                                           "grid; the ordinary path is used.")
@@ -479,7 +590,7 @@ class TileMerger:
     # ------------------------------------------------------------------ deferred bands
     def _defer_reset(self):
         self._defer_active = self._bands is not None
-        self._held = []          # [batch tensor, coords, views, reduction, last launch group that reads it], integration order
+        self._held = []          # [batch tensor, coords, views, reduction, last launch group that reads it, p0, p1, version], integration order
         self._bands_done = 0     # launch groups issued for this image
         if self._bands is not None:
             N.load().ptb_band_plan_reset(self._bands.handle)
@@ -497,8 +608,20 @@ class TileMerger:
         self._plan.restart()
         self._plan.active = keep_plan
         self._log, self._applied = [], 0
-        for batch, coords, views, reduction, _last in held:
+        for batch, coords, views, reduction, *_rest in held:
             self._accumulate(batch, coords, views, reduction)
+
+    def _launch_due(self, end):
+        """Will a submit that brings the planned tiles up to index ``end`` (exclusive) launch a group?  (Only then are the held
+        batches' version counters compared; groups of a row-major crop list complete in index order.)"""
+        bands = self._bands
+        if not bands.monotone:
+            return True
+        return self._bands_done < len(bands.bands) and end > bands.bands[self._bands_done][2]
+
+    def _window_edited(self):
+        w = self.weight
+        return w._version != self._weight_version0 or w.data_ptr() != self._weight_ptr0
 
     def _defer_step(self, batch, coords, xy, views, reduction, dcode):
         """Take one planned batch into custody and merge the launch groups it completes (``ptb_band_plan_submit``: the pointer
@@ -511,6 +634,8 @@ class TileMerger:
               and xy[0].data == plan.xy[0, pos:pos + B].data and xy[1].data == plan.xy[1, pos:pos + B].data)
         rc = N.PTB_EUNSUPPORTED
         if ok:
+            span = _held_entry(batch)
+            _check_held(self._held, batch, span, self._launch_due(pos + B), "TileMerger(defer=True)")
             if self._merged is None:
                 self._merged = torch.empty_like(self._image)
             th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
@@ -529,7 +654,7 @@ class TileMerger:
             return False
         if rc < 0:
             N.check(rc, "TileMerger.integrate_batch (deferred bands)")
-        self._held.append((batch, coords, views, reduction, int(bands.last_group[pos:pos + B].max())))
+        self._held.append((batch, coords, views, reduction, int(bands.last_group[pos:pos + B].max())) + span)
         plan.pos += B
         self._log.append(xy)
         if rc:
@@ -548,9 +673,89 @@ class TileMerger:
         self._defer_flush(what)
         if self._plan is not None:
             if self._plan.done.any():
-                raise RuntimeError(f"TileMerger(crops=...): {what} is not available after planned blocks were finalised; "
-                                   "call merge(), or construct the merger without crops=")
+                if not self._auto_planned:
+                    raise RuntimeError(f"TileMerger(crops=...): {what} is not available after planned blocks were finalised; "
+                                       "call merge(), or construct the merger without crops=")
+                self._unfinalise(what)
             self._plan.active = False
+        self._auto_opt_out()
+
+    # ------------------------------------------------------------------ self-planning (no crops= given)
+    def _auto_attach(self):
+        """(Re)plan this merger from the crop sequence its geometry ended the last image(s) with, when there is a stable one."""
+        ent = _auto_entry(self._auto_key)
+        usable = (ent is not None and not ent.disabled and ent.log is not None and ent.seen >= ent.need and not self._window_edited())
+        if not usable:
+            if self._auto_planned:
+                self._plan, self._auto_planned = None, False
+            return
+        if self._auto_planned and ent.parts is not None and ent.parts[0] is self._plan.xy:
+            self._plan.restart()
+            return
+        if ent.parts is None:
+            plan = _Plan.build(self, np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4))
+            if plan is None:          # off the block grid: this geometry never plans
+                ent.disabled = True
+                self._plan, self._auto_planned = None, False
+                return
+            ent.parts = (plan.xy, plan.remaining0, plan.norm_full, plan.crops4)
+        xy, remaining0, norm_full, crops4 = ent.parts
+        plan = _Plan(xy, remaining0, norm_full)
+        plan.crops4 = crops4
+        self._plan, self._auto_planned = plan, True
+
+    def _auto_opt_out(self):
+        """The caller touched the accumulators themselves: this geometry stays on the ordinary (exact, unplanned) path from now on."""
+        if self._auto_key is not None:
+            _auto_entry(self._auto_key, create=True).disabled = True
+
+    def _auto_note(self):
+        """At merge(): remember the crop sequence this image was made of (what the next image of this geometry is planned from)."""
+        if self._auto_key is None:
+            return
+        n = len(self._log)
+        if self._auto_noted == n:
+            return
+        ent = _auto_entry(self._auto_key, create=True)
+        if self._auto_noted is not None or self._eager_norm or self._window_edited():
+            ent.disabled = True       # tiles after a merge() / a caller-visible norm_mask / an edited window: not the README loop
+            return
+        self._auto_noted = n
+        if n == 0:
+            return
+        plan = self._plan
+        if self._auto_planned and plan.active and plan.pos == plan.xy.shape[1] and ent.parts is not None and ent.parts[0] is plan.xy:
+            ent.seen += 1             # the planned sequence, start to end
+            return
+        xy = np.concatenate(self._log, axis=1)
+        crops4 = np.empty((xy.shape[1], 4), dtype=np.int64)
+        crops4[:, 0], crops4[:, 1] = xy[0], xy[1]
+        crops4[:, 2], crops4[:, 3] = int(self.weight.shape[2]), int(self.weight.shape[1])
+        log = crops4.tobytes()
+        if self._auto_planned:        # a planned image that went another way: ask for more evidence before planning again
+            ent.need = min(ent.need + 1, 4)
+        if ent.log == log:
+            ent.seen += 1
+        else:
+            ent.log, ent.seen, ent.parts = log, 1, None
+
+    def _unfinalise(self, what):
+        """Self-planned merger only: somebody needs the accumulators of blocks the planned kernels have already turned into
+        results (their sums were never stored).  They are rebuilt as ``result * normaliser`` -- the one place where a value
+        can differ from the reference's in the last bit (fl(fl(s / n) * n) vs s) -- the merger goes back to the ordinary path
+        and its geometry stops planning itself, so it happens once."""
+        plan = self._plan
+        _warn_once(("unfinalise", self._auto_key), f"TileMerger: {what} after the self-planned kernels had finalised part of the image; the "
+                                                   "accumulators of those blocks are rebuilt as merged * norm_mask (last-bit differences possible, "
+                                                   "this once); mergers of this geometry use the ordinary accumulate + merge path from now on "
+                                                   "(TileMerger(..., auto_plan=False) avoids this).")
+        dev = self._image.device
+        done = torch.from_numpy(plan.done.astype(np.bool_)).to(dev)
+        mask = done.repeat_interleave(_FRESH_ROWS, 0).repeat_interleave(64, 1)[:self.image_height, :self.image_width]
+        torch.where(mask, self._merged * plan.norm_full, self._image, out=self._image)
+        plan.done[:] = 0
+        plan.active = False
+        self._auto_opt_out()
 
     @property
     def image(self) -> torch.Tensor:
@@ -571,6 +776,7 @@ class TileMerger:
         kernels keep this tensor up to date, exactly like the reference's attribute)."""
         if self._plan is not None:
             self._plan.active = False   # (finalised blocks keep their results; the rest accumulates with this norm)
+        self._auto_opt_out()
         self._norm_ready()
         self._materialize()
         self._eager_norm, self._norm_pure, self._norm_key = True, False, None
@@ -580,6 +786,7 @@ class TileMerger:
     def norm_mask(self, value: torch.Tensor):
         if self._plan is not None:
             self._plan.active = False
+        self._auto_opt_out()
         self._norm_ready()
         self._materialize()
         self._eager_norm, self._norm_pure, self._norm_key = True, False, None
@@ -591,7 +798,10 @@ class TileMerger:
         self._log, self._applied = [], 0
         self._norm_zero, self._norm_pure, self._eager_norm = True, False, False
         self._merged = None
-        if self._plan is not None:
+        self._auto_noted = None
+        if self._auto_key is not None:
+            self._auto_attach()       # plan from what the last image(s) looked like / restart / drop a plan that no longer holds
+        elif self._plan is not None:
             self._plan.restart()
         self._defer_reset()
 
@@ -681,6 +891,8 @@ class TileMerger:
 
     def _accumulate(self, batch, coords, views, reduction):
         self._check_state()
+        if self._plan is not None and self._plan.active and self._window_edited():
+            self._plan_off("integrating with an edited blending window")   # (the planned normaliser was built from the original one)
         th, tw = int(self.weight.shape[1]), int(self.weight.shape[2])
         n_views = len(views) if views is not None else 1
         B = len(coords)
@@ -737,6 +949,8 @@ class TileMerger:
                     N.check(rc, "TileMerger.integrate_batch")
                 # nothing was launched: this batch (and the rest of the image) takes the ordinary path
             plan.active = False
+            if plan.done.any() and plan.touches_done(xy, th, tw) and self._auto_planned:
+                self._unfinalise("a tile over pixels that were already merged")
             if plan.done.any() and plan.touches_done(xy, th, tw):
                 raise RuntimeError("TileMerger(crops=...): a tile touches pixels that were already finalised -- every planned "
                                    "tile may be integrated once; construct the merger without crops= for free-form accumulation")
@@ -762,6 +976,16 @@ class TileMerger:
         """Accumulate ``[B, C, h, w]`` predictions at ``crop_coords[b] = (x, y, w, h)``."""
         if len(batch) != len(crop_coords):
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        if type(batch) is _lazy.LazyDeaugment:
+            # the reference's literal `integrate_batch(tta.d4_image_deaugment(y), crops)`: the de-augmentation has not run yet, so
+            # it is fused into this launch (bit-identical: same reduction, then the same multiply and add per pixel)
+            taken = batch._take_source()
+            if taken is not None:
+                source, _group, views, code = taken
+                _lazy.fused += 1
+                if self._defer_active and self._defer_fast(source, crop_coords, (_group, code), views, code):
+                    return
+                return self._accumulate(self._prep(source), _coords_xy(crop_coords), list(views), code)
         if self._defer_active and self._defer_fast(batch, crop_coords, None, None, N.RED_SUM):
             return
         self._accumulate(self._prep(batch), _coords_xy(crop_coords), None, N.RED_SUM)
@@ -771,7 +995,7 @@ class TileMerger:
         slice of ``tiler.crops``).  Everything constant per merger / per (group, reduction) is cached, the rest is one C call
         (``ptb_band_plan_submit``): ~10 us of host time instead of ~20.  False: the general path decides (and reports)."""
         plan = self._plan
-        if not (self._defer_active and plan.active and not self._eager_norm and type(crop_coords) is np.ndarray and crop_coords.ndim == 2 and crop_coords.dtype == np.int64
+        if not (self._defer_active and plan.active and not self._eager_norm and not self._window_edited() and type(crop_coords) is np.ndarray and crop_coords.ndim == 2 and crop_coords.dtype == np.int64
                 and batch.is_cuda and batch.is_contiguous() and not batch.requires_grad):
             return False
         dcode = N.DTYPE_CODES.get(batch.dtype)
@@ -786,11 +1010,13 @@ class TileMerger:
         th, tw = self.weight.shape[1], self.weight.shape[2]
         if batch.shape != (B * n_views, self.channels, th, tw):
             return False
+        bands = self._bands
+        span = _held_entry(batch)
+        _check_held(self._held, batch, span, self._launch_due(pos + B), "TileMerger(defer=True)")
         if self._merged is None:
             self._merged = torch.empty_like(self._image)
         per_tile = self.channels * th * tw
         dev = self._image.device
-        bands = self._bands
         with N.on_device(dev):
             rc = N.load().ptb_band_plan_submit(bands.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, dcode, n_views, varr, code,
                                                self._merged.data_ptr(), plan.norm_full.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
@@ -799,7 +1025,7 @@ class TileMerger:
             if rc == N.PTB_EUNSUPPORTED:
                 return False       # (nothing was launched: the general path warns and replays)
             N.check(rc, "TileMerger.integrate_batch (deferred bands)")
-        self._held.append((batch, crop_coords, views, code, int(bands.last_group[pos:pos + B].max())))
+        self._held.append((batch, crop_coords, views, code, int(bands.last_group[pos:pos + B].max())) + span)
         plan.pos = pos + B
         self.fast_submits += 1
         self._log.append(np.ascontiguousarray(crop_coords[:, :2].T))
@@ -890,6 +1116,7 @@ class TileMerger:
         return out if self.dtype == torch.float32 else out.to(self.dtype)
 
     def _merge_f32(self) -> torch.Tensor:
+        self._auto_note()
         if self._merged is not None:
             # planned: the accumulate launches have been writing the result block by block.  The buffer belongs to this
             # image (reset() lets go of it); a second merge() of the same image returns the same, updated tensor.
@@ -930,6 +1157,7 @@ class TileMerger:
         kind, out_dtype = self._CROP_KINDS[key]
         if top < 0 or left < 0 or oh < 0 or ow < 0 or top + oh > self.image_height or left + ow > self.image_width:
             raise ValueError("crop window is outside the accumulator")
+        self._auto_note()
         planned = self._merged is not None
         if planned:
             src, norm_ptr = self._finish_planned(), None     # already normalised
@@ -956,5 +1184,6 @@ class TileMerger:
 class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
 
-    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False, defer_rows=None):
-        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer, defer_rows=defer_rows)
+    def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False, defer_rows=None, auto_plan=None):
+        super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer, defer_rows=defer_rows,
+                         auto_plan=auto_plan)

@@ -15,6 +15,7 @@ from torch import Tensor, nn
 
 from .. import _native as N
 from ..utils.support import pytorch_toolbelt_deprecated
+from . import _lazy
 from . import _views as V
 from . import functional as F
 
@@ -76,6 +77,12 @@ def _reduction_code(reduction):
     return None
 
 
+def set_lazy_deaugment(flag: bool) -> bool:
+    """Extension: switch the lazy results of ``*_image_deaugment`` on / off (default on; ``PTB_LAZY_DEAUG=0``).  Returns the
+    previous setting.  See ``inference/_lazy.py`` for what "lazy" means and why nothing but the speed changes."""
+    return _lazy.set_enabled(flag)
+
+
 def split_into_chunks(input: Tensor, batch_size: int) -> Tuple[Tensor, ...]:
     """Split dim 0 into ``batch_size`` equal chunks (the argument is the NUMBER of chunks, as in the reference)."""
     if not torch.jit.is_scripting() and not torch.jit.is_tracing():
@@ -110,7 +117,10 @@ def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable) -
         raise RuntimeError(f"Input batch size ({image.size(0)}) must be divisible by {len(views)}.")
     code = _reduction_code(reduction)
     if code is not None:
-        return V.deaug_reduce(image, views, code)
+        # inference-shaped calls come back as a handle that `TileMerger.integrate_batch` fuses into its own launch and that
+        # turns into the real tensor on any other use (inference/_lazy.py); everything else is evaluated here and now
+        lazy = _lazy.maybe_lazy(image, group, views, code, V.deaug_reduce)
+        return lazy if lazy is not None else V.deaug_reduce(image, views, code)
     if not (callable(reduction) or reduction in {None, "None", "none"}):
         raise KeyError(f"Unsupported reduction mode {reduction}")
     stack = V.view_transform(image, views, in_is_batch=False)

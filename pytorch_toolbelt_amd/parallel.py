@@ -111,7 +111,7 @@ class _HipOps:
     def new_local(shape, channels, weight, device):
         from .inference.tiles import TileMerger
 
-        return TileMerger(shape, channels, weight, device=device)
+        return TileMerger(shape, channels, weight, device=device, auto_plan=False)   # (a band accumulator: fed rank-local crops)
 
     @staticmethod
     def merge_rows(image, norm, out, extra=None, extra_rows=0):
@@ -190,9 +190,11 @@ class _DeferredBand:
     what is exchanged are those partial sums instead of accumulator rectangles, and no accumulator read-modify-write happens
     at all.  The model outputs handed in are held (by reference) until the image is merged."""
 
-    def __init__(self, handle, table, groups, out, norm, weight, xy_abs, top, channels, th, tw):
+    def __init__(self, handle, table, groups, out_shape, norm, weight, xy_abs, top, channels, th, tw):
         self.handle, self.table, self.groups = handle, table, groups      # groups: [(y0, y1, last tile)] local rows
-        self.out, self.norm, self.weight = out, norm, weight
+        self.out_shape, self.norm, self.weight = out_shape, norm, weight
+        self.out = None              # [C, rows, W] of THIS image: allocated with its first batch, handed to the caller by merge()
+        self.launched = 0
         self.xy_abs, self.top = xy_abs, top
         self.xy_abs_rows = np.ascontiguousarray(xy_abs.T)      # [N, 2] (x, y), the layout callers' crop rows compare against
         self._varr = {}
@@ -244,13 +246,12 @@ class _DeferredBand:
         rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
         lib.ptb_band_plan_info(handle, None, None, None, None, rows_arr.ctypes.data_as(N._i64p))
         groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
-        out = torch.empty((merger.channels, bottom - top, W), device=dev, dtype=torch.float32)
         norm = torch.zeros((1, bottom - top, W), device=dev, dtype=torch.float32)
         o0, o1 = merger.owned_rows
         if merger.norm_owned is not None:
             norm[:, o0 - top:o1 - top] = merger.norm_owned
         w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).to(dev).reshape(1, th, tw).contiguous()
-        band = _DeferredBand(handle, table, groups, out, norm, w, mine, top, merger.channels, th, tw)
+        band = _DeferredBand(handle, table, groups, (merger.channels, bottom - top, W), norm, w, mine, top, merger.channels, th, tw)
         band.final = final
         return band
 
@@ -258,7 +259,8 @@ class _DeferredBand:
         from . import _native as N
 
         N.load().ptb_band_plan_reset(self.handle)
-        self.pos, self.held, self.cfg = 0, [], None
+        self.pos, self.held, self.cfg, self.launched = 0, [], None, 0
+        self.out = None              # (the previous image's buffer now belongs to whoever merge() gave it to)
 
     def submit(self, batch, coords_abs, views, reduction):
         """Take the next planned tiles; returns the number of launches.  The tiles must arrive in ``merger.tiles`` order."""
@@ -281,15 +283,23 @@ class _DeferredBand:
         if varr is None:
             varr = self._varr[key] = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
         per_tile = self.channels * self.th * self.tw
-        dev = self.out.device
+        dev = self.norm.device
+        from .inference.tiles import _check_held, _held_entry
+
+        span = _held_entry(batch)
+        due = self.launched < len(self.groups) and self.pos + B > self.groups[self.launched][2]
+        _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
+        if self.out is None:
+            self.out = torch.empty(self.out_shape, device=dev, dtype=torch.float32)
         with N.on_device(dev):
             rc = N.load().ptb_band_plan_submit(self.handle, self.pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype], n_views,
                                                varr, reduction, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
         N.bump()
         if rc < 0:
             N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
-        self.held.append(batch)
+        self.held.append((batch,) + span)
         self.pos += B
+        self.launched += rc
         return rc
 
     def rows_launched(self, r0, r1):
@@ -311,8 +321,12 @@ class ShardedTileMerger:
     reference's ``split_across_nodes`` rule; default) or ``"rows"`` (whole tile rows).
     """
 
-    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=True,
+    def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=False,
                  defer_rows=None):
+        """``defer=True`` (opt-in, like ``TileMerger``): the rank's tiles are merged band by band straight from the model outputs
+        (no accumulator).  The contract that comes with it: the batches are kept by reference and read by a LATER launch, so they
+        must stay alive and unmodified until ``merge()`` (a reused output buffer or an in-place edit raises), and the tiles must
+        be fed in ``self.tiles`` order."""
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
@@ -331,6 +345,7 @@ class ShardedTileMerger:
         self.owned_rows = me["owned"]
         self.sends, self.recvs = me["sends"], me["recvs"]
         self.local = None
+        self._result = None
         self._pending = []
         if self.band is None:
             return
@@ -360,7 +375,7 @@ class ShardedTileMerger:
             self._boundary[(int(x), int(y))] = self._boundary.get((int(x), int(y)), 0) + 1
         self._send_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _d, r0, r1, c0, c1 in self.sends]
         self._recv_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _s, r0, r1, c0, c1 in self.recvs]
-        # Deferred band merging (default on the HIP path): the rank's tiles are merged band by band straight from the model outputs
+        # Deferred band merging (opt-in): the rank's tiles are merged band by band straight from the model outputs
         # -- no accumulator read-modify-write, partial sums instead of accumulator rectangles on the rows shared with neighbours.
         # Needs the tiles in `self.tiles` order and a geometry on the 4-pixel grid; otherwise the incremental path below is used.
         self._deferred = None
@@ -379,6 +394,7 @@ class ShardedTileMerger:
         """Start a new image: zero the band accumulator and re-arm the exchange."""
         self._wait_pending()
         self._exchanged = False
+        self._result = None
         if self.local is None:
             return
         if self._deferred is not None:
@@ -423,6 +439,15 @@ class ShardedTileMerger:
     def integrate_batch(self, batch, crop_coords):
         if len(batch) != len(crop_coords):
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        from .inference import _lazy
+
+        if type(batch) is _lazy.LazyDeaugment:      # integrate_batch(tta.<group>_image_deaugment(y), crops): fused, like TileMerger
+            taken = batch._take_source()
+            if taken is not None:
+                _lazy.fused += 1
+                from .inference._views import REDUCTION_NAMES
+
+                return self.integrate_batch_deaugment(taken[0], crop_coords, group=taken[1], reduction=REDUCTION_NAMES[taken[3]])
         if self._deferred is not None:
             from . import _native as N
 
@@ -490,14 +515,18 @@ class ShardedTileMerger:
         """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank that owns no rows)."""
         if self.local is None:
             return None
+        if self._result is not None:       # a second merge() of the same image: the same tensor (nothing is added or divided twice)
+            return self._result
         if not self._exchanged:
             self._start_exchange()
         self._wait_pending()
         o0, o1 = self.owned_rows
         if o1 <= o0:
             return None
-        if self._deferred is not None:
-            return self._merge_deferred(o0, o1)
+        self._result = self._merge_deferred(o0, o1) if self._deferred is not None else self._merge_incremental(o0, o1)
+        return self._result
+
+    def _merge_incremental(self, o0, o1):
         # the band accumulator, readable on the rows this rank owns and on every received rectangle (blocks there that no
         # kernel has written are zero-filled; rows owned by other ranks keep their first-touch state: nobody reads them)
         for _src, r0, r1, c0, c1 in [(None, o0, o1, 0, self.image_width)] + list(self.recvs):

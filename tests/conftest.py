@@ -11,6 +11,10 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The suites choose their merger path explicitly (plain / planned / deferred) and read accumulators bit for bit, so mergers do not
+# plan themselves behind the tests' backs; tests/test_dropin_gpu.py switches self-planning on for the tests that are about it.
+os.environ.setdefault("PTB_AUTO_PLAN", "0")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")

@@ -1,0 +1,368 @@
+"""GPU: the reference's LITERAL loop takes the fused / planned kernels (README.md:201-226; inference/tta.py:442-467 feeding
+inference/tiles.py:321-346), and the deferred merger enforces its contract.
+
+* ``tta.*_image_deaugment`` returns a lazy handle (inference/_lazy.py) that ``TileMerger.integrate_batch`` fuses into its launch
+  and that behaves like the evaluated tensor everywhere else;
+* ``TileMerger(shape, C, weight)`` without ``crops=`` plans itself from the second image of a geometry on;
+* ``TileMerger(defer=True)`` refuses a batch that lives in a held batch's memory and notices in-place edits of held batches.
+
+Everything is compared bit for bit with the eager, unplanned path of the same library (itself pinned to the reference's goldens in
+tests/test_tiles_gpu.py) and against the numpy oracle within 1e-5 (BASELINE.json north_star)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tiles_oracle as TO
+from oracle import tta_oracle as AO
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture()
+def lazy():
+    from pytorch_toolbelt_amd.inference import _lazy
+
+    prev = _lazy.set_enabled(True)
+    yield _lazy
+    _lazy.set_enabled(prev)
+
+
+@pytest.fixture()
+def autoplan():
+    from pytorch_toolbelt_amd.inference import tiles
+
+    prev = tiles.set_auto_plan(True)
+    tiles._auto.clear()
+    tiles._warned.clear()
+    yield tiles
+    tiles._auto.clear()
+    tiles.set_auto_plan(prev)
+
+
+GROUPS = {"fliplr": 2, "flipud": 2, "flips": 3, "d2": 4, "d4": 8}
+
+
+def _eager(fn, x, **kw):
+    from pytorch_toolbelt_amd.inference import _lazy
+
+    prev = _lazy.set_enabled(False)
+    try:
+        out = fn(x, **kw)
+    finally:
+        _lazy.set_enabled(prev)
+    assert type(out) is torch.Tensor
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ lazy handles
+@pytest.mark.parametrize("group", sorted(GROUPS))
+@pytest.mark.parametrize("reduction", ["mean", "sum", "gmean", "logodd"])
+def test_lazy_deaugment_equals_eager(group, reduction, dev, lazy):
+    from pytorch_toolbelt_amd.inference import tta
+
+    fn = getattr(tta, f"{group}_image_deaugment")
+    V = GROUPS[group]
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.rand((V * 3, 2, 64, 64), device=dev, generator=g) * 0.9 + 0.05
+    want = _eager(fn, x, reduction=reduction)
+    ev0 = lazy.evaluations
+    y = fn(x, reduction=reduction)
+    assert type(y) is lazy.LazyDeaugment and isinstance(y, torch.Tensor)
+    assert y.shape == want.shape and y.dtype == want.dtype and y.device == want.device and len(y) == 3 and y.dim() == 4
+    assert lazy.evaluations == ev0, "metadata must not evaluate the handle"
+    assert torch.equal(y, want) and lazy.evaluations == ev0 + 1
+    assert torch.equal(y + 1, want + 1) and torch.equal(y[1], want[1]) and torch.equal(torch.cat([y, y]), torch.cat([want, want]))
+    assert np.array_equal(y.cpu().numpy(), want.cpu().numpy()) and lazy.evaluations == ev0 + 1
+    # against the oracle, like the eager tests
+    assert np.abs(y.cpu().numpy() - AO.image_deaugment(x.cpu().numpy(), group, reduction)).max() <= 1e-5
+
+
+def test_lazy_handle_in_place_and_consumers(dev, lazy):
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.inference.ensembling import Ensembler  # noqa: F401  (a consumer module of this package imports fine)
+
+    x = torch.rand((8 * 2, 3, 32, 32), device=dev)
+    want = _eager(tta.d4_image_deaugment, x)
+    y = tta.d4_image_deaugment(x)
+    y.mul_(2.0)                               # in place on the handle == in place on the evaluated tensor
+    assert torch.equal(y, want * 2)
+    z = tta.d4_image_deaugment(x)
+    assert torch.equal(torch.nn.functional.interpolate(z, scale_factor=2, mode="nearest"), torch.nn.functional.interpolate(want, scale_factor=2, mode="nearest"))
+    assert torch.equal(tta.fliplr_image_augment(z), tta.fliplr_image_augment(want))     # our own kernels take it (data_ptr through the handle)
+    assert z.data_ptr() == z._evaluate().data_ptr() and "tensor(" in repr(z)
+    assert float(tta.d4_image_deaugment(x).sum()) == pytest.approx(float(want.sum()), rel=1e-6)
+    # autograd-shaped and non-fp32 calls are evaluated on the spot
+    xg = x.clone().requires_grad_(True)
+    yg = tta.d4_image_deaugment(xg)
+    assert type(yg) is torch.Tensor and yg.requires_grad
+    yg.sum().backward()
+    assert xg.grad is not None
+    assert type(tta.d4_image_deaugment(x.half())) is torch.Tensor
+    assert type(tta.d4_image_deaugment(x, reduction=None)) is torch.Tensor
+    with torch.no_grad():
+        assert type(tta.d4_image_deaugment(xg)) is lazy.LazyDeaugment
+
+
+def test_lazy_source_edit_is_reported_and_budget_bounds_memory(dev, lazy):
+    from pytorch_toolbelt_amd.inference import tta
+
+    x = torch.rand((2 * 2, 1, 16, 16), device=dev)
+    y = tta.fliplr_image_deaugment(x)
+    x.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        y + 0
+    with torch.inference_mode():              # no version counters there: the handle still works
+        xi = torch.rand((2 * 2, 1, 16, 16), device=dev)
+        yi = tta.fliplr_image_deaugment(xi)
+        assert type(yi) is lazy.LazyDeaugment and torch.equal(yi, _eager(tta.fliplr_image_deaugment, xi))
+    old = lazy._BUDGET
+    try:
+        src = torch.rand((2 * 4, 2, 32, 32), device=dev)
+        lazy._BUDGET = lazy._pending_bytes + 3 * src.numel() * 4
+        hs = [tta.fliplr_image_deaugment(src) for _ in range(6)]
+        assert [h._value is not None for h in hs] == [True, True, True, False, False, False]
+        want = _eager(tta.fliplr_image_deaugment, src)
+        assert all(torch.equal(h, want) for h in hs)
+    finally:
+        lazy._BUDGET = old
+
+
+def _run_image(merger, outputs, crops, batch, literal=True, group="d4", reduction="mean"):
+    from pytorch_toolbelt_amd.inference import tta
+
+    V = GROUPS[group]
+    n = len(crops)
+    fn = getattr(tta, f"{group}_image_deaugment")
+    for b0 in range(0, n, batch):
+        b1 = min(n, b0 + batch)
+        y = torch.cat([outputs[k * n + b0:k * n + b1] for k in range(V)])       # chunk-major model output of the batch
+        if literal:
+            merger.integrate_batch(fn(y, reduction=reduction), crops[b0:b1])
+        else:
+            merger.integrate_batch_deaugment(y, crops[b0:b1], group=group, reduction=reduction)
+    return merger.merge()
+
+
+def _oracle_image(geom, C, w, outputs, batch, group="d4", reduction="mean", keep=None):
+    V = GROUPS[group]
+    crops = geom["crops"]
+    n = len(crops)
+    st = TO.merger_new(geom["target_shape"], C, w)
+    onp = outputs.cpu().numpy()
+    for b0 in range(0, n, batch):
+        b1 = min(n, b0 + batch)
+        y = np.concatenate([onp[k * n + b0:k * n + b1] for k in range(V)])
+        TO.merger_integrate(st, AO.image_deaugment(y, group, reduction), crops[b0:b1])
+    return TO.merger_merge(st)
+
+
+@pytest.mark.parametrize("group,reduction,shape,tile,step,C,batch", [
+    ("d4", "mean", (500, 420), 128, 64, 4, 8),
+    ("d4", "gmean", (300, 300), 64, 32, 2, 5),
+    ("d2", "mean", (200, 330), (64, 128), (32, 64), 3, 4),
+    ("fliplr", "sum", (130, 170), (52, 36), (20, 12), 2, 9),     # off the vector grid: scalar kernels
+])
+def test_literal_loop_is_fused_and_bit_identical(group, reduction, shape, tile, step, C, batch, dev, lazy):
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    tile2 = (tile, tile) if isinstance(tile, int) else tile
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile2)[0]
+    n, V = len(geom["crops"]), GROUPS[group]
+    g = torch.Generator(device=dev).manual_seed(11)
+    outputs = torch.rand((V * n, C, *tile2), device=dev, generator=g) * 0.9 + 0.05
+    prev = lazy.set_enabled(False)
+    want = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, geom["crops"], batch, group=group, reduction=reduction)
+    lazy.set_enabled(prev)
+    f0, e0 = lazy.fused, lazy.evaluations
+    got = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, geom["crops"], batch, group=group, reduction=reduction)
+    assert lazy.fused - f0 == (n + batch - 1) // batch and lazy.evaluations == e0, "the literal calls did not take the fused launch"
+    assert torch.equal(got, want)
+    assert np.nanmax(np.abs(got.cpu().numpy() - _oracle_image(geom, C, w, outputs, batch, group, reduction))) <= 1e-5
+    # the same through a planned and a deferred merger
+    for kw in ({"crops": geom["crops"]}, {"crops": geom["crops"], "defer": True}):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = TileMerger(geom["target_shape"], C, w, device=dev, **kw)
+        assert torch.equal(_run_image(m, outputs, geom["crops"], batch, group=group, reduction=reduction), want)
+
+
+# ------------------------------------------------------------------------------------------------ self-planning mergers
+def test_new_merger_per_image_plans_itself_from_the_second_image(dev, lazy, autoplan):
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((500, 420), 128, 64)
+    crops, C, batch = geom["crops"], 3, 8
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    modes = []
+    for image in range(4):
+        g = torch.Generator(device=dev).manual_seed(100 + image)
+        outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=g)
+        exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch, literal=False)
+        m = TileMerger(geom["target_shape"], C, w, device=dev)          # the reference's constructor call, once per image
+        modes.append(m.mode)
+        got = _run_image(m, outputs, crops, batch)
+        assert torch.equal(got, exact), f"image {image} ({modes[-1]})"
+        if m._plan is not None:
+            assert m._plan.done.all() and m._plan.pos == n
+    assert modes == ["incremental", "planned", "planned", "planned"]
+    assert np.nanmax(np.abs(got.cpu().numpy() - _oracle_image(geom, C, w, outputs, batch))) <= 1e-5
+
+
+def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((384, 384), 128, 64)
+    crops, C, batch = geom["crops"], 2, 4
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    g = torch.Generator(device=dev).manual_seed(5)
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=g)
+    exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch, literal=False)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "incremental" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    m.reset()
+    assert m.mode == "planned" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    # an image that skips tiles (content-dependent loops do): correct, and planning asks for more evidence afterwards
+    keep = np.array([i for i in range(n) if i not in (3, 7, 8)])
+    sub = torch.cat([outputs[k * n + keep] for k in range(8)])
+    sub_geom = {"crops": crops[keep], "target_shape": geom["target_shape"]}
+    exact_sub = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), sub, crops[keep], batch, literal=False)
+    m.reset()
+    assert m.mode == "planned"
+    got = _run_image(m, sub, crops[keep], batch)
+    assert m.mode == "incremental"                       # it left the plan at the first deviating batch
+    assert torch.equal(got, exact_sub)
+    assert np.nanmax(np.abs(got.cpu().numpy() - _oracle_image(sub_geom, C, w, sub, batch))) <= 1e-5
+    m.reset()
+    assert m.mode == "incremental"                       # one odd image seen: not yet planned from it
+    assert torch.equal(_run_image(m, outputs, crops, batch), exact)
+    m.reset()
+    assert m.mode == "incremental" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    m.reset()
+    assert m.mode == "planned" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+
+
+def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan):
+    """Reading ``image`` after the planned kernels finalised blocks: rebuilt (within an ulp), warned about once, and the
+    geometry stays on the exact path afterwards."""
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((256, 256), 128, 64)
+    crops, C, batch = geom["crops"], 2, 3
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    ref = TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False)
+    exact = _run_image(ref, outputs, crops, batch, literal=False)
+    exact_image, exact_norm = ref.image.clone(), ref.norm_mask.clone()
+    _run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch)        # image 1: remembered
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "planned"
+    got = _run_image(m, outputs, crops, batch)
+    assert torch.equal(got, exact)
+    with pytest.warns(RuntimeWarning, match="rebuilt"):
+        img = m.image
+    assert torch.allclose(img, exact_image, rtol=2.4e-7, atol=0) and torch.equal(m.norm_mask, exact_norm)
+    assert torch.allclose(m.merge(), exact, rtol=4e-7, atol=0)
+    m2 = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m2.mode == "incremental"                      # this geometry's user reads accumulators: exact path from now on
+    assert torch.equal(_run_image(m2, outputs, crops, batch), exact) and torch.equal(m2.image, exact_image)
+
+
+def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan):
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((256, 256), 128, 64)
+    crops, C = geom["crops"], 1
+    w = TO.mean_window(128, 128)
+    n = len(crops)
+    outputs = torch.randn((n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    first = TileMerger(geom["target_shape"], C, w, device=dev)
+    first.integrate_batch(outputs, crops)
+    first.merge()
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "planned"
+    m.integrate_batch(outputs, crops)
+    with pytest.warns(RuntimeWarning, match="rebuilt"):
+        m.integrate_batch(outputs[:1], crops[4:5])       # one more tile over pixels that were already merged
+    st = TO.merger_new(geom["target_shape"], C, w)
+    TO.merger_integrate(st, outputs.cpu().numpy(), crops)
+    TO.merger_integrate(st, outputs[:1].cpu().numpy(), crops[4:5])
+    assert np.abs(m.merge().cpu().numpy() - TO.merger_merge(st)).max() <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ deferred merger: the contract
+def _deferred(geom, C, w, dev):
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    m = TileMerger(geom["target_shape"], C, w, device=dev, crops=geom["crops"], defer=True, defer_rows=128)
+    assert m.mode == "deferred bands"
+    return m
+
+
+def test_deferred_merger_refuses_a_reused_output_buffer(dev):
+    """A model that writes every batch into one static buffer (HIP graphs, out=): by the time the second batch arrives the first
+    one -- still held, not yet read -- is gone, so no fallback could be correct: the merger raises instead of returning stale data."""
+    geom = TO.slicer_geometry((384, 384), 128, 64)
+    crops, C = geom["crops"], 2
+    w = TO.pyramid_window(128, 128)[0]
+    outputs = torch.randn((len(crops), C, 128, 128), device=dev)
+    m = _deferred(geom, C, w, dev)
+    static = torch.empty((4, C, 128, 128), device=dev)
+    static.copy_(outputs[0:4])
+    m.integrate_batch(static, crops[0:4])
+    static.copy_(outputs[4:8])
+    with pytest.raises(RuntimeError, match="occupies memory of an earlier batch"):
+        m.integrate_batch(static, crops[4:8])
+    # overlapping views of one big buffer are the same hazard
+    m = _deferred(geom, C, w, dev)
+    pool = torch.randn((6, C, 128, 128), device=dev)
+    m.integrate_batch(pool[0:4], crops[0:4])
+    with pytest.raises(RuntimeError, match="occupies memory"):
+        m.integrate_batch(pool[2:6], crops[4:8])
+    # ... while the planned merger without defer reads every batch when it is handed in: same loop, correct result
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    safe = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops)
+    for b0 in range(0, len(crops), 4):
+        static[:len(crops[b0:b0 + 4])].copy_(outputs[b0:b0 + 4])
+        safe.integrate_batch(static[:len(crops[b0:b0 + 4])], crops[b0:b0 + 4])
+    st = TO.merger_new(geom["target_shape"], C, w)
+    TO.merger_integrate(st, outputs.cpu().numpy(), crops)
+    assert np.array_equal(safe.merge().cpu().numpy(), TO.merger_merge(st))
+
+
+def test_deferred_merger_notices_in_place_edits_of_held_batches(dev):
+    geom = TO.slicer_geometry((384, 384), 128, 64)
+    crops, C = geom["crops"], 2
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    outputs = [torch.randn((len(crops[b0:b0 + 4]), C, 128, 128), device=dev) for b0 in range(0, n, 4)]
+    m = _deferred(geom, C, w, dev)
+    m.integrate_batch(outputs[0], crops[0:4])
+    outputs[0].mul_(2.0)                                  # the merger has not read it yet
+    with pytest.raises(RuntimeError, match="held batch 0 .* modified in place"):
+        for i in range(1, len(outputs)):
+            m.integrate_batch(outputs[i], crops[4 * i:4 * i + 4])
+    # untouched batches: fine, and bit-identical to the incremental merger
+    outputs = [torch.randn((len(crops[b0:b0 + 4]), C, 128, 128), device=dev) for b0 in range(0, n, 4)]
+    m = _deferred(geom, C, w, dev)
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    plain = TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False)
+    for i, o in enumerate(outputs):
+        m.integrate_batch(o, crops[4 * i:4 * i + 4])
+        plain.integrate_batch(o, crops[4 * i:4 * i + 4])
+    assert m.mode == "deferred bands" and torch.equal(m.merge(), plain.merge())
+    with torch.inference_mode():                          # no version counters: accepted, nothing to compare
+        m = _deferred(geom, C, w, dev)
+        outs = [o.clone() for o in outputs]
+        for i, o in enumerate(outs):
+            m.integrate_batch(o, crops[4 * i:4 * i + 4])
+        assert torch.equal(m.merge(), plain.merge())

@@ -68,11 +68,37 @@ def test_cfg1_tilemerger_1024_pyramid(dev, full):
     _digest_check(full, "cfg1_host", np.moveaxis(host, -1, 0), 1e-6)
 
 
+_CFG2 = {}
+
+
+def _cfg2_oracle(dev):
+    """The numpy oracle's merged map of BASELINE configs[1] / [2] (same image, same inputs): computed once per test session."""
+    if "want" not in _CFG2:
+        from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+
+        slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+        st = TO.merger_new(slicer.target_shape, 4, slicer.weight)
+        for k, b0 in enumerate(range(0, 361, 8)):
+            nb = min(8, 361 - b0)
+            y = SY.synth_torch((8 * nb, 4, 512, 512), 2000 + k, device=dev)
+            TO.merger_integrate(st, AO.image_deaugment(y.cpu().numpy(), "d4", "mean"), slicer.crops[b0:b0 + nb])
+        _CFG2["want"] = TO.merger_merge(st)
+    return _CFG2["want"]
+
+
+def _check_cfg2_result(full, key, got, want):
+    err = float(np.abs(got - want).max())
+    assert np.isfinite(got).all() and err <= TOL, f"{key}: max|diff| vs the oracle over all 4x5120x5120 values = {err}"
+    _digest_check(full, "cfg2", got)
+    assert float(np.abs(got[:, [0, 255, 256, 2559, 2560, 5119], :] - full["cfg2_rows"]).max()) <= TOL, key
+
+
 def test_cfg2_5000_d4_merge_all_paths_vs_reference_and_oracle(dev, full):
     """BASELINE configs[1] exactly as benchmarked: 5000x5000x3, 512/256 pyramid, 361 tiles, d4 model outputs C = 4 in batches
     of 8; the deferred band merger (bench default), the planned and the plain merger through the fused entry point, and the
-    literal drop-in sequence integrate_batch(d4_image_deaugment(y)) + merge()."""
-    from pytorch_toolbelt_amd.inference import tta
+    literal drop-in sequence integrate_batch(d4_image_deaugment(y)) + merge() -- evaluated call by call (lazy results off: the
+    reduced tile travels through HBM) and as the library runs it by default (the lazy result fused into the merger's launch)."""
+    from pytorch_toolbelt_amd.inference import _lazy, tta
     from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
 
     slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
@@ -82,29 +108,94 @@ def test_cfg2_5000_d4_merge_all_paths_vs_reference_and_oracle(dev, full):
                  planned=TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops),
                  plain=TileMerger(slicer.target_shape, C, slicer.weight, device=dev))
     literal = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
-    st = TO.merger_new(slicer.target_shape, C, slicer.weight)
+    literal_lazy = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    fused0, eval0 = _lazy.fused, _lazy.evaluations
     for k, b0 in enumerate(range(0, 361, 8)):
         nb = min(8, 361 - b0)
         y = SY.synth_torch((8 * nb, C, 512, 512), 2000 + k, device=dev)
         for m in fused.values():
             m.integrate_batch_deaugment(y, crops[b0:b0 + nb], group="d4", reduction="mean")
+        prev = _lazy.set_enabled(False)
         literal.integrate_batch(tta.d4_image_deaugment(y), crops[b0:b0 + nb])
-        TO.merger_integrate(st, AO.image_deaugment(y.cpu().numpy(), "d4", "mean"), crops[b0:b0 + nb])
+        _lazy.set_enabled(True)
+        literal_lazy.integrate_batch(tta.d4_image_deaugment(y), crops[b0:b0 + nb])
+        _lazy.set_enabled(prev)
+    assert _lazy.fused - fused0 == 46 and _lazy.evaluations == eval0, "the literal calls were not fused into the merger's launches"
     d = fused["deferred"]
     assert d._bands is not None and d._bands_done == len(d._bands.bands) and not d._held, "the deferred band path did not run"
-    want = TO.merger_merge(st)
+    want = _cfg2_oracle(dev)
     outs = {k: m.merge().cpu().numpy() for k, m in fused.items()}
     outs["literal"] = literal.merge().cpu().numpy()
+    outs["literal_lazy"] = literal_lazy.merge().cpu().numpy()
     for k, got in outs.items():
-        err = float(np.abs(got - want).max())
-        assert np.isfinite(got).all() and err <= TOL, f"{k}: max|diff| vs the oracle over all 4x5120x5120 values = {err}"
-        _digest_check(full, "cfg2", got)
-        assert float(np.abs(got[:, [0, 255, 256, 2559, 2560, 5119], :] - full["cfg2_rows"]).max()) <= TOL, k
-    assert np.array_equal(outs["deferred"], outs["plain"]) and np.array_equal(outs["planned"], outs["plain"])
+        _check_cfg2_result(full, k, got, want)
+    for k in ("deferred", "planned", "literal", "literal_lazy"):
+        assert np.array_equal(outs[k], outs["plain"]), k
     # the cropped original-size map (tiler.crop_to_orignal_size) from the device and from the host agree
     cropped = slicer.crop_to_orignal_size(np.moveaxis(outs["deferred"], 0, -1))
     assert cropped.shape == (5000, 5000, 4)
     assert np.array_equal(fused["deferred"].merge_crop(slicer).cpu().numpy(), cropped)
+
+
+class _OneRank:
+    """torch.distributed stand-in that plays rank `rank` of `world` (the exchange is done by hand below)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
+def test_cfg3_5000_eight_ranks_vs_oracle(dev, full, defer):
+    """BASELINE configs[2] at full size through the HIP sharded path: the 361 tiles of the 5000x5000 image over 8 ranks
+    (`ShardedTileMerger(partition="tiles")`: the reference's split_across_nodes rule, utils/distributed.py:240-309 -- 45 / 46
+    consecutive tiles each), C = 4, d4, batches of 8, the cfg2 inputs.  The 8 ranks are played in turn on the one GPU, each with
+    its own band plan (deferred) or band accumulator (incremental); the halo rectangles every rank would receive over xGMI are
+    handed over by hand; the assembled map must equal the single-device result (inference/tiles.py:321-346): the oracle on every
+    pixel and the unmodified reference's cfg2 digests (same inputs, same answer)."""
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger, tile_range_partition
+
+    slicer = ImageSlicer((5000, 5000, 3), 512, 256, weight="pyramid")
+    crops, C, world = slicer.crops, 4, 8
+    # the cfg2 inputs, resident (12.1 GB): tile t is column t % 8 of batch t // 8, its view v at row v * nb + t % 8
+    batches = [SY.synth_torch((8 * min(8, 361 - b0), C, 512, 512), 2000 + k, device=dev) for k, b0 in enumerate(range(0, 361, 8))]
+
+    def model_output(tiles):
+        rows = []
+        for v in range(8):
+            for t in tiles:
+                yk = batches[t // 8]
+                rows.append(yk[v * (yk.shape[0] // 8) + t % 8])
+        return torch.stack(rows)
+
+    parts = tile_range_partition(crops, world)
+    assert sorted(len(p) for p in parts) == [45] * 7 + [46] and np.array_equal(np.concatenate(parts), np.arange(361))
+    ranks = []
+    for r in range(world):
+        m = ShardedTileMerger(slicer.target_shape, C, slicer.weight, crops, device=dev, dist=_OneRank(r, world), partition="tiles", defer=defer)
+        assert (m._deferred is not None) == defer
+        assert sorted(m.tiles.tolist()) == parts[r].tolist()
+        m._start_exchange = lambda: None     # no process group here: the rectangles are moved below
+        m.reset()
+        mine = [int(t) for t in m.tiles]
+        for b0 in range(0, len(mine), 8):
+            idx = mine[b0:b0 + 8]
+            m.integrate_batch_deaugment(model_output(idx), crops[idx], group="d4", reduction="mean")
+        ranks.append(m)
+    got = torch.full((C, 5120, 5120), float("nan"), device=dev)
+    for m in ranks:
+        for buf, (src, r0, r1, c0, c1) in zip(m._recv_buf, m.recvs):   # what rank `src` sends: its partial sums on that rectangle
+            buf.copy_(ranks[src]._rect(r0, r1, c0, c1))
+        m._exchanged = True
+        o0, o1 = m.owned_rows
+        got[:, o0:o1] = m.merge()
+    _check_cfg2_result(full, f"cfg3 ({'deferred' if defer else 'incremental'})", got.cpu().numpy(), _cfg2_oracle(dev))
 
 
 def test_cfg4_losses_32x16x512x512(dev, full):

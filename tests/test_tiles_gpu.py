@@ -266,9 +266,10 @@ class _SoloDist:
         return self.world
 
 
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
 @pytest.mark.parametrize("partition", ["tiles", "rows"])
 @pytest.mark.parametrize("world", [1, 2, 3, 5])
-def test_sharded_merger_bands_on_gpu(world, partition, dev):
+def test_sharded_merger_bands_on_gpu(world, partition, defer, dev):
     """Every rank of a `world`-way sharding is played in turn on one GPU; halo rectangles are handed over by hand.
     The assembled result must equal the single-device TileMerger (same HIP kernels, different accumulation order)."""
     from pytorch_toolbelt_amd.parallel import ShardedTileMerger
@@ -286,7 +287,7 @@ def test_sharded_merger_bands_on_gpu(world, partition, dev):
 
     ranks = []
     for r in range(world):
-        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_SoloDist(r, world), partition=partition)
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_SoloDist(r, world), partition=partition, defer=defer)
         m._start_exchange = lambda: None  # no process group here: rectangles are moved below
         mine = m.tiles
         m.reset()
