@@ -320,6 +320,25 @@ def _weight_signature(weight: np.ndarray):
     return sig
 
 
+_device_windows = __import__("collections").OrderedDict()   # (device index, window signature) -> float32 [1, h, w] device tensor
+
+
+def _device_window(weight: np.ndarray, device):
+    """The blending window as a float32 ``[1, h, w]`` device tensor.  A merger per image (the README loop) would otherwise upload
+    the same window from pageable host memory every time -- a synchronous copy that also waits for the GPU to drain; uploaded
+    windows are kept per device (a handful of MB) and every merger gets its own device-side copy of the cached one."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),) + _weight_signature(weight)
+    cached = _device_windows.get(key)
+    if cached is None:
+        cached = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=torch.float32).contiguous()
+        while len(_device_windows) >= 16:
+            _device_windows.popitem(last=False)
+        _device_windows[key] = cached
+    else:
+        _device_windows.move_to_end(key)
+    return cached.clone()
+
+
 class _AutoEntry:
     __slots__ = ("log", "seen", "need", "parts", "disabled")
 
@@ -425,7 +444,7 @@ def _check_held(held, batch, span, launches, what):
     (p0, p1, version); ``span`` = ``_held_entry(batch)``."""
     p0, p1, _v = span
     for h in held:
-        if h[-3] < p1 and p0 < h[-2] and h[0] is not batch:
+        if h[-3] < p1 and p0 < h[-2]:
             raise RuntimeError(f"{what}: this batch occupies memory of an earlier batch that is still held for a later launch (bytes "
                                f"{max(p0, h[-3]):#x}..{min(p1, h[-2]):#x}) -- the model writes its outputs into a reused buffer, so the earlier "
                                "predictions are already gone.  Deferred merging needs every batch to stay alive and unmodified until its rows "
@@ -540,7 +559,10 @@ class TileMerger:
         self.image_height = image_shape[0]
         self.image_width = image_shape[1]
         self.channels = channels
-        self.weight = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=dtype).contiguous()
+        if isinstance(weight, np.ndarray):
+            self.weight = _device_window(weight, device)
+        else:
+            self.weight = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=dtype).contiguous()
         # First-touch accumulators: allocated uninitialised; `_fresh` (host, one byte per 64x32 block) records which
         # blocks were never written.  The kernels STORE into fresh blocks instead of read-modify-write, so no memset and
         # no read of zeros is ever paid; reading `image` / `norm_mask` zero-fills whatever is still fresh first.
@@ -562,7 +584,7 @@ class TileMerger:
         self._auto_key = None     # self-planning: key of this geometry + window in the module cache
         self._auto_planned = False
         self._auto_noted = None   # log length at the last merge() of this image
-        self._weight_version0, self._weight_ptr0 = self.weight._version, self.weight.data_ptr()
+        self._weight_version0, self._weight_ptr0 = _tensor_version(self.weight), self.weight.data_ptr()
         if crops is None and (auto_plan if auto_plan is not None else _AUTO_PLAN) and isinstance(weight, np.ndarray):
             self._auto_key = (device.index if device.index is not None else torch.cuda.current_device(), int(self.image_height),
                               int(self.image_width)) + _weight_signature(weight)
@@ -621,7 +643,7 @@ class TileMerger:
 
     def _window_edited(self):
         w = self.weight
-        return w._version != self._weight_version0 or w.data_ptr() != self._weight_ptr0
+        return _tensor_version(w) != self._weight_version0 or w.data_ptr() != self._weight_ptr0
 
     def _defer_step(self, batch, coords, xy, views, reduction, dcode):
         """Take one planned batch into custody and merge the launch groups it completes (``ptb_band_plan_submit``: the pointer
@@ -806,7 +828,7 @@ class TileMerger:
         self._defer_reset()
 
     def _log_key(self):
-        return (self.weight.data_ptr(), self.weight._version, b"".join(a.tobytes() for a in self._log))
+        return (self.weight.data_ptr(), _tensor_version(self.weight), b"".join(a.tobytes() for a in self._log))
 
     def _norm_ready(self):
         """Bring ``_norm`` up to date with the crop log (a no-op in eager mode, where the kernels maintain it)."""

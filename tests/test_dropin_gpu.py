@@ -320,7 +320,7 @@ def test_deferred_merger_refuses_a_reused_output_buffer(dev):
     static.copy_(outputs[4:8])
     with pytest.raises(RuntimeError, match="occupies memory of an earlier batch"):
         m.integrate_batch(static, crops[4:8])
-    # overlapping views of one big buffer are the same hazard
+    # overlapping views of one big buffer are refused too (the merger cannot know who writes to the shared bytes)
     m = _deferred(geom, C, w, dev)
     pool = torch.randn((6, C, 128, 128), device=dev)
     m.integrate_batch(pool[0:4], crops[0:4])
