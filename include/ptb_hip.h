@@ -410,6 +410,21 @@ int ptb_region_epilogue(const double* sums, int slots, int C, float focal_scale,
                         float smooth, float eps, int log_loss, const uint8_t* class_mask, int n_selected, float* loss,
                         float* coef, const int* error_flag, ptb_stream_t stream);
 
+/* The two above in ONE launch (no reference counterpart: losses/dice.py:66-131 and losses/jaccard.py:62-113 are ~40 torch ops): the
+ * streaming statistics kernel of ptb_seg_loss_fwd, whose last-arriving workgroup adds up the slot sums, evaluates the scalar tail
+ * of ptb_region_epilogue and its derivative, and leaves the workspace zeroed for the next call -- no memset, finalize or epilogue
+ * launches.  `workspace`: ptb_region_workspace_bytes(C) bytes of 8-byte aligned DEVICE memory that were ZERO before the first call
+ * and are used by one stream at a time; every call leaves them zero.  flags must contain SEG_STATS (2), optionally SEG_FOCAL (1)
+ * and the option bits of ptb_seg_loss_fwd (not ELEMWISE).  loss DEVICE float[1], coef DEVICE float[2 + 2C] as for
+ * ptb_region_epilogue; error_out (may be NULL): int[1], device OR pinned-host memory, receives the call's label flag (a label
+ * outside [0, C) that is not ignore_index also turns the loss into NaN).  Returns PTB_EUNSUPPORTED for an empty input. */
+int64_t ptb_region_workspace_bytes(int C);
+int ptb_region_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights, void* workspace,
+                        int B, int C, int64_t HW, int flags, int prob, float gamma, float alpha, float threshold, int64_t ignore_label,
+                        float ignore_value, float focal_scale, float dice_weight, float jaccard_weight, float smooth, float eps,
+                        int log_loss, const unsigned char* class_mask, int n_selected, float* loss, float* coef, int* error_out,
+                        ptb_stream_t stream);
+
 /* softmax_focal_loss_with_logits / CrossEntropyFocalLoss (losses/functional.py:110-173, losses/focal.py:108-161).
  * sums double[PTB_SUM_SLOTS][2] (zeroed by this call): sum of per-pixel losses, sum of all focal terms; pixel_out [B, HW] optional. */
 int ptb_softmax_focal_fwd(const float* logits, const int64_t* labels, const float* class_weights, double* sums,

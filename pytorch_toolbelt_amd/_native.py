@@ -80,6 +80,9 @@ SIGNATURES = {
     "ptb_focal_softmax_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_focal_softmax_bwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_seg_stats_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_i64, _c_f, _vp]),
+    "ptb_region_workspace_bytes": (_c_i64, [_c_int]),
+    "ptb_region_loss_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                     _c_f, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp]),
     "ptb_region_epilogue": (_c_int, [_vp, _c_int, _c_int, _c_f, _c_f, _c_f, _c_f, _c_f, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp]),
     "ptb_seg_fused_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),
     "ptb_softmax_focal_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_i64, _vp]),

@@ -216,6 +216,16 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_fused_pix2 = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 12) {
+        if (value < 0 || value > 2) return PTB_EINVAL;
+        g_focal_pk = value;
+        return PTB_OK;
+    }
+    if (key == 13) {
+        if (value < 1) return PTB_EINVAL;
+        g_focal_pk_grid = value;
+        return PTB_OK;
+    }
     if (key == 6) {
         if (value != 16 && value != 32 && value != 64) return PTB_EINVAL;
         g_ms_tile_rows = value;

@@ -36,6 +36,16 @@ struct SegArgs {
     int flags, prob;
     float gamma, alpha, threshold, ignore_value;
     long long ignore_label;
+    // In-launch tail (ptb_region_loss_fwd): the workgroup that arrives LAST adds up the slots, evaluates the [C]-sized scalar
+    // epilogue and its derivative, and leaves slots / counter / flag zeroed for the next call -- no memset, finalize or epilogue
+    // launches around the streaming kernel.  tail_counter == null: the plain kernel (slots are added up by a later launch).
+    unsigned int* tail_counter;  // [SUM_SLOTS + 1] arrival tickets; `sums`, these and `error_flag` live in a persistent all-zero workspace
+    int* tail_error_out;         // [1] the call's label-error flag as the host reads it (written by the last workgroup), or null
+    const unsigned char* tail_class_mask;
+    float* tail_loss;            // [1]
+    float* tail_coef;            // [2 + 2C]
+    float tail_focal_scale, tail_dice_w, tail_jacc_w, tail_smooth, tail_eps;
+    int tail_log_loss, tail_n_selected;
 };
 
 // ------------------------------------------------------------------------------------------------ small helpers
@@ -156,6 +166,13 @@ __device__ __forceinline__ void focal_parts(float x, float t, const FocalCfg& c,
 // sums (slot = blockIdx % PTB_SUM_SLOTS); the caller adds the slots up (a [64, n] -> [n] sum).
 constexpr int SUM_SLOTS = 64;
 
+// fp64 add into a slot, in the RETURNING form: the value comes back from where the add was performed, so once a wave has waited
+// for it (s_waitcnt vmcnt(0) in region_tail) the add is visible to an atomic read from any other workgroup / XCD.
+__device__ __forceinline__ void slot_add(double* p, double v) {
+    const double old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(old));
+}
+
 __device__ __forceinline__ void block_add2(double v0, double v1, double* dst /* slot base */, int lane, int wave) {
     __shared__ double red[2][4];
     v0 = wave_sum(v0);
@@ -163,9 +180,134 @@ __device__ __forceinline__ void block_add2(double v0, double v1, double* dst /* 
     if (lane == 0) { red[0][wave] = v0; red[1][wave] = v1; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&dst[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        atomicAdd(&dst[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        slot_add(&dst[0], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        slot_add(&dst[1], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ in-launch scalar epilogue
+__device__ __forceinline__ void tail_score_loss(float score, bool active, int log_loss, float eps, float& loss, float& dscore) {
+    if (log_loss) {
+        const float cl = fmaxf(score, eps);
+        loss = -logf(cl);
+        dscore = score >= eps ? -1.0f / cl : 0.f;
+    } else {
+        loss = 1.0f - score;
+        dscore = -1.0f;
+    }
+    if (!active) { loss = 0.f; dscore = 0.f; }
+}
+
+// Called by every thread of every workgroup at the very end of a forward statistics kernel, after the workgroup's slot atomics.
+// Everything that crosses workgroups here is an ATOMIC on device memory (the slot sums are fp64 atomic adds, the label flag an
+// atomic or, the ticket an atomic add), i.e. performed at the memory side where all eight XCDs see it -- so the hand-off needs no
+// cache write-back: each wave waits for its own atomics to be acknowledged (vmcnt), the workgroup synchronises, one lane draws a
+// ticket.  The last arriver reads every slot value with an atomic EXCHANGE against zero: coherent wherever the adds came from,
+// and the workspace is clean again for the next launch without a memset.  `scratch` = the kernel's dynamic LDS (>= 24 C + 80 bytes).
+__device__ __forceinline__ void region_tail(const SegArgs& a, float* scratch) {
+    const int C = a.C, row = 2 + 3 * C;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    scratch = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(scratch) + 7) & ~(uintptr_t)7);   // (doubles live here below)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* flagw = reinterpret_cast<int*>(scratch);
+    if (threadIdx.x == 0) {
+        // Two-level arrival count: 2048 workgroups finishing together on ONE counter would serialise (~12 ns per same-address
+        // atomic = 25 us); they draw tickets from SUM_SLOTS group counters instead, and only each group's last arriver -- by then
+        // every add of its group has been performed -- goes on to the top-level counter.
+        const unsigned group = blockIdx.x % SUM_SLOTS;
+        const unsigned group_size = (gridDim.x - group + SUM_SLOTS - 1) / SUM_SLOTS;
+        const unsigned n_groups = gridDim.x < (unsigned)SUM_SLOTS ? gridDim.x : (unsigned)SUM_SLOTS;
+        int last_one = 0;
+        if (__hip_atomic_fetch_add(a.tail_counter + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == group_size - 1) {
+            __hip_atomic_store(a.tail_counter + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_one = __hip_atomic_fetch_add(a.tail_counter + SUM_SLOTS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1;
+        }
+        flagw[0] = last_one;
+    }
+    __syncthreads();
+    const bool last = flagw[0] != 0;
+    __syncthreads();
+    if (!last) return;
+    double* tot = reinterpret_cast<double*>(scratch);          // [row] totals, then [8] reduction scratch
+    unsigned long long* slots = reinterpret_cast<unsigned long long*>(a.sums);
+    // The label flag and the top-level counter first (one lane), so that their round trip overlaps the slot exchanges below.
+    int bad = 0;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.tail_counter + SUM_SLOTS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = a.error_flag ? __hip_atomic_exchange(a.error_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    // wave w takes the values v = w, w + 4, ...; lane = slot.  Sixteen exchanges in flight per lane (one round trip up to C = 20),
+    // then sixteen wave reductions.
+    for (int v0 = wave; v0 < row; v0 += 64) {
+        double x[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int v = v0 + 4 * u;
+            x[u] = 0.0;
+            if (v < row) x[u] = __longlong_as_double((long long)__hip_atomic_exchange(&slots[(size_t)lane * row + v], 0ull, __ATOMIC_RELAXED,
+                                                                                      __HIP_MEMORY_SCOPE_AGENT));
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int v = v0 + 4 * u;
+            if (v0 + 4 * u - wave >= row) break;      // (wave-uniform: no value of this wave is left)
+            const double t = wave_sum(x[u]);
+            if (lane == 0 && v < row) tot[v] = t;
+        }
+    }
+    if (threadIdx.x == 0 && a.tail_error_out) a.tail_error_out[0] = bad;     // (thread 0 keeps `bad` for the loss below)
+    __syncthreads();
+    double dsum = 0.0, jsum = 0.0;
+    const float inv_n = 1.0f / (float)a.tail_n_selected;
+    for (int c = threadIdx.x; c < C; c += 256) {          // fp32 arithmetic in the reference's order (dice.py:112-131, jaccard.py:95-113)
+        const float I = (float)tot[2 + c], P = (float)tot[2 + C + c], T = (float)tot[2 + 2 * C + c];
+        const bool sel = !a.tail_class_mask || a.tail_class_mask[c];
+        const bool active = T > 0.f;
+        float gI = 0.f, gP = 0.f;
+        if (a.tail_dice_w != 0.f) {
+            const float num = 2.0f * I + a.tail_smooth, card = P + T + a.tail_smooth, den = fmaxf(card, a.tail_eps);
+            float l, ds;
+            tail_score_loss(num / den, active, a.tail_log_loss, a.tail_eps, l, ds);
+            if (sel) {
+                dsum += (double)l;
+                gI += a.tail_dice_w * ds * (2.0f / den);
+                gP += a.tail_dice_w * ds * (card >= a.tail_eps ? -num / (den * den) : 0.f);
+            }
+        }
+        if (a.tail_jacc_w != 0.f) {
+            const float num = I + a.tail_smooth, uni = P + T - I + a.tail_smooth, den = fmaxf(uni, a.tail_eps);
+            float l, ds;
+            tail_score_loss(num / den, active, a.tail_log_loss, a.tail_eps, l, ds);
+            if (sel) {
+                jsum += (double)l;
+                const float dden = uni >= a.tail_eps ? num / (den * den) : 0.f;
+                gI += a.tail_jacc_w * ds * (1.0f / den + dden);
+                gP += a.tail_jacc_w * ds * (-dden);
+            }
+        }
+        a.tail_coef[2 + c] = gI * inv_n;
+        a.tail_coef[2 + C + c] = gP * inv_n;
+    }
+    dsum = wave_sum(dsum);
+    jsum = wave_sum(jsum);
+    double* red = tot + row;
+    if (lane == 0) { red[wave] = dsum; red[4 + wave] = jsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double d = red[0] + red[1] + red[2] + red[3], j = red[4] + red[5] + red[6] + red[7];
+        const float focal = a.tail_focal_scale != 0.f ? a.tail_focal_scale * (float)tot[0] : 0.f;
+        const float dice = a.tail_dice_w != 0.f ? a.tail_dice_w * ((float)d * inv_n) : 0.f;
+        const float jacc = a.tail_jacc_w != 0.f ? a.tail_jacc_w * ((float)j * inv_n) : 0.f;
+        a.tail_loss[0] = bad ? __builtin_nanf("") : focal + dice + jacc;     // a label outside [0, C) poisons the loss
+        a.tail_coef[0] = a.tail_focal_scale;
+        a.tail_coef[1] = 0.f;
+    }
+}
+
+// Label outside [0, C): raised with an atomic (the in-launch tail reads it from another workgroup, possibly another XCD).
+__device__ __forceinline__ void raise_label_error(int* flag) {
+    __hip_atomic_fetch_or(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // One wave-group: image b, first pixel i0 of this lane, validity; labels of the lane's PIX pixels.
@@ -202,7 +344,7 @@ __device__ __forceinline__ Group<PIX> make_group(long long g, long long per_img,
 #pragma unroll
         for (int k = 0; k < PIX; ++k) {
             G.ign[k] = has_ignore && G.lab[k] == ignore_label;
-            if (error_flag && !G.ign[k] && (G.lab[k] < 0 || G.lab[k] >= C)) *error_flag = 1;
+            if (error_flag && !G.ign[k] && (G.lab[k] < 0 || G.lab[k] >= C)) raise_label_error(error_flag);
         }
     }
     return G;

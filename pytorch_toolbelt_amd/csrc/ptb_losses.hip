@@ -194,9 +194,10 @@ __global__ __launch_bounds__(256, SHARE ? 3 : 1) void seg_loss_fwd_reg_kernel(co
         __syncthreads();
         for (int k = threadIdx.x; k < 3 * C; k += 256) {
             const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
-            if (v != 0.0) atomicAdd(&slot[2 + k], v);
+            if (v != 0.0) slot_add(&slot[2 + k], v);
         }
     }
+    if (a.tail_counter) region_tail(a, lds);
 }
 
 // Straight-line variant for the common case -- hard labels, C <= CREG, HW % 256 == 0 (every lane of every wave holds 4 valid
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
                 bad = bad || (valid[k] && (l64[k] < 0 || l64[k] >= C));
                 lab[k] = valid[k] ? (int)l64[k] : -1;
             }
-            if (bad) *a.error_flag = 1;
+            if (bad) raise_label_error(a.error_flag);
         }
         float inv[PIX], em[PIX];
         // FOCAL: the class loop below is exact only while every sigmoid and its complement stay normal fp32 numbers when formed
@@ -354,8 +355,175 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
     __syncthreads();
     for (int k = threadIdx.x; k < 3 * C; k += 256) {
         const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
-        if (v != 0.0) atomicAdd(&slot[2 + k], v);
+        if (v != 0.0) slot_add(&slot[2 + k], v);
     }
+    if (a.tail_counter) region_tail(a, lds);
+}
+
+
+// The cfg4 instance of the fused forward (hard labels, softmax statistics + default focal, 2 pixels per lane) with the vector
+// instruction count cut by a quarter (rocprofv3 on seg_fwd_lean_kernel<.., FOCAL>: VALU 71 % busy, the kernel is co-bound by issue):
+//  * everything per element is written on PAIRS (the lane's two pixels) so that the plain arithmetic issues as packed fp32
+//    (v_pk_add / v_pk_mul / v_pk_fma_f32: two elements per full-rate slot); only v_exp / v_rcp / v_log stay per element;
+//  * no per-element select on "is this the label's class": every element is summed with the t = 0 formula
+//    sigma(x)^2 log2(1 - sigma(x)), where log2(1 - sigma) = log2(em / (u + em)) = -M - log2(u + em) needs no multiply -- so a pixel's
+//    classes give -M F - FL with F = sum f, FL = sum f log2(u + em) -- and the label's class is corrected once per PIXEL
+//    (its u picked from the registers by a 4-level select tree on the label's bits: 15 selects per pixel instead of 3 per element);
+//  * I_c and T_c get one LDS add per pixel each into the lane's own column of a per-wave [class][lane] table (ds_add_f32, no
+//    bank conflicts, no cross-lane traffic) instead of a select + fma and a compare + ballot per element.
+// Results agree with seg_fwd_lean_kernel to rounding (same exp / rcp / log instructions, another association of the sums).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f rcp2(v2f x) { return v2f{rcp(x.x), rcp(x.y)}; }
+__device__ __forceinline__ v2f lg22(v2f x) { return v2f{lg2(x.x), lg2(x.y)}; }
+__device__ __forceinline__ v2f ex22(v2f x) { return v2f{ex2(x.x), ex2(x.y)}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <int CREG, bool TERM, bool FULL, bool PF = false>   // PF: the next pixel group's loads are in flight while this one is computed
+__global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const SegArgs a) {
+    extern __shared__ float lds[];  // [4 waves][2][CREG][64] per-lane columns of I and T; afterwards [4][3][C] wave sums + the tail's scratch
+    const int lane = threadIdx.x & 63, wave = wave_id();
+    const int C = a.C;
+    float* colI = lds + wave * (2 * CREG * 64) + lane;
+    float* colT = colI + CREG * 64;
+#pragma unroll
+    for (int c = 0; c < CREG; ++c) { colI[c * 64] = 0.f; colT[c * 64] = 0.f; }
+    v2f aP[CREG];
+#pragma unroll
+    for (int c = 0; c < CREG; ++c) aP[c] = v2f{0.f, 0.f};
+    double f_loss = 0.0, f_term = 0.0;
+    const long long per_img = a.HW / 128;
+    const long long groups = per_img * a.B;
+    const long long stride = (long long)gridDim.x * 4;
+    auto fetch = [&](long long g, v2f (&xv)[CREG], longlong2& l2, long long& base) {
+        const int b = (int)(g / per_img);
+        const long long i0 = (g - (long long)b * per_img) * 128 + (long long)lane * 2;
+        base = (long long)b * C * a.HW + i0;
+        l2 = *reinterpret_cast<const longlong2*>(a.labels + (long long)b * a.HW + i0);
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            xv[c] = v2f{-INFINITY, -INFINITY};
+            if (FULL || c < C) xv[c] = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(a.logits + base + (long long)c * a.HW));
+        }
+    };
+    auto process = [&](v2f (&xv)[CREG], const longlong2 l2, const long long base) {
+        if (l2.x < 0 || l2.x >= C || l2.y < 0 || l2.y >= C) raise_label_error(a.error_flag);
+        const int lab[2] = {(int)l2.x & (CREG - 1), (int)l2.y & (CREG - 1)};     // (masked: a bad label must not leave the LDS table)
+        v2f m = xv[0], lo = xv[0];
+#pragma unroll
+        for (int c = 1; c < CREG; ++c) {
+            m = v2f{fmaxf(m.x, xv[c].x), fmaxf(m.y, xv[c].y)};
+            if (FULL || c < C) lo = v2f{fminf(lo.x, xv[c].x), fminf(lo.y, xv[c].y)};
+        }
+        const v2f M = m * kLog2e;
+        v2f d = v2f{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            xv[c] = ex22(fma2(xv[c], v2f{kLog2e, kLog2e}, -M));         // u = exp(x - m)
+            d += xv[c];
+        }
+        const v2f inv = rcp2(d), em = ex22(-M);
+        const bool tame = m.x <= 60.f && m.y <= 60.f && lo.x >= -80.f && lo.y >= -80.f && lo.x - m.x >= -80.f && lo.y - m.y >= -80.f;
+        v2f FL = v2f{0.f, 0.f}, F = v2f{0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CREG; ++c) {
+            const v2f u = xv[c];
+            const v2f sm = u + em;
+            const v2f r = rcp2(sm), L = lg22(sm);
+            const v2f ps = u * r;                                       // sigmoid(x)
+            const v2f f = ps * ps;
+            FL = fma2(f, L, FL);
+            F += f;
+            aP[c] = fma2(u, inv, aP[c]);
+        }
+        // the label's class of each pixel: replace its t = 0 term by the t = 1 one, and feed I_c / T_c
+        float lsum = 0.f, fsum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float sel[CREG];
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) sel[c] = k ? xv[c].y : xv[c].x;
+#pragma unroll
+            for (int w = CREG / 2, bit = 1; w >= 1; w >>= 1, bit <<= 1) {
+                const bool up = lab[k] & bit;
+#pragma unroll
+                for (int j = 0; j < w; ++j) sel[j] = up ? sel[2 * j + 1] : sel[2 * j];
+            }
+            const float uh = sel[0], emk = k ? em.y : em.x, Mk = k ? M.y : M.x, invk = k ? inv.y : inv.x;
+            const float sh = uh + emk, rh = rcp(sh), Lh = lg2(sh), lu = lg2(uh);
+            const float psh = uh * rh, qsh = emk * rh;
+            const float f0 = psh * psh, f1 = qsh * qsh;
+            const float Fk = k ? F.y : F.x, FLk = k ? FL.y : FL.x;
+            // sum_c f_c log2(q_c) = -M F - FL;  label's class: f0 (-M - Lh) out, f1 (lu - Lh) in
+            lsum += __builtin_fmaf(f1, lu - Lh, __builtin_fmaf(f0, Mk + Lh, -__builtin_fmaf(Mk, Fk, FLk)));
+            if (TERM) fsum += Fk + (f1 - f0);
+            atomicAdd(colI + lab[k] * 64, uh * invk);      // ds_add_f32 into this lane's own column
+            atomicAdd(colT + lab[k] * 64, 1.0f);
+        }
+        lsum *= -kLn2;
+        if (__any(!tame)) {   // the whole wave: exact focal sums from the re-read logits (never on sane logits)
+            const FocalCfg cfg = focal_cfg(a);
+            lsum = 0.f; fsum = 0.f;
+            const long long labs[2] = {l2.x, l2.y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                for (int c = 0; c < C; ++c)
+                    lsum += focal_one<true>(a.logits[base + (long long)c * a.HW + k], labs[k] == c ? 1.f : 0.f, false, 1.0f, cfg, fsum);
+        }
+        f_loss += (double)lsum;
+        f_term += (double)fsum;
+    };
+    const long long g0 = (long long)blockIdx.x * 4 + wave;
+    if constexpr (PF) {
+        v2f xa[CREG], xb[CREG];
+        longlong2 la{}, lb{};
+        long long ba = 0, bb = 0;
+        if (g0 < groups) fetch(g0, xa, la, ba);
+        for (long long g = g0; g < groups; g += 2 * stride) {
+            const bool hb = g + stride < groups;
+            if (hb) fetch(g + stride, xb, lb, bb);
+            process(xa, la, ba);
+            if (g + 2 * stride < groups) fetch(g + 2 * stride, xa, la, ba);
+            if (hb) process(xb, lb, bb);
+        }
+    } else {
+        for (long long g = g0; g < groups; g += stride) {
+            v2f xv[CREG];
+            longlong2 l2;
+            long long base;
+            fetch(g, xv, l2, base);
+            process(xv, l2, base);
+        }
+    }
+    double* slot = a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C);
+    block_add2(f_loss, f_term, slot, lane, wave);
+    // Row sums of the wave's [2 CREG][64] table without 6-step shuffles per value: lane L adds up half (L / 32... for 2 CREG = 32
+    // rows; in general 64 / ROWS parts) of row L % ROWS, walking the columns rotated by its row number so that the lanes of one
+    // read hit distinct banks; the parts are then combined across lanes.  P (registers) goes through the same table afterwards.
+    constexpr int ROWS = 2 * CREG, PARTS = 64 / ROWS, SPAN = 64 / PARTS;      // CREG 16: 32 rows x 2 halves of 32 columns
+    const float* tab = lds + wave * (ROWS * 64);
+    auto row_part_sum = [&](int rows) {                                        // sum of my part of row (lane % rows)
+        const int r = lane % rows, part = lane / rows, span = 64 / (64 / rows);
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < span; ++j) acc += tab[r * 64 + part * span + ((j + r) & (span - 1))];
+        for (int o = rows; o < 64; o <<= 1) acc += __shfl_xor(acc, o);        // combine the parts (lanes r, r + rows, ...)
+        return acc;
+    };
+    static_assert(PARTS >= 1 && SPAN * PARTS == 64, "table rows");
+    const float itsum = row_part_sum(ROWS);            // lanes 0 .. CREG-1: I_c, lanes CREG .. 2 CREG-1: T_c (of this wave)
+#pragma unroll
+    for (int c = 0; c < CREG; ++c) colI[c * 64] = aP[c].x + aP[c].y;          // (own column again: rows 0 .. CREG-1 now hold P)
+    const float psum = row_part_sum(CREG);             // lanes 0 .. CREG-1: P_c
+    __syncthreads();                 // every wave has read its table: it becomes the [4][3][C] wave sums
+    float* wl = lds + wave * 3 * C;
+    if (lane < CREG && lane < C) { wl[lane] = itsum; wl[C + lane] = psum; }
+    if (lane >= CREG && lane < 2 * CREG && lane - CREG < C) wl[2 * C + lane - CREG] = itsum;
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * C; k += 256) {
+        const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
+        if (v != 0.0) slot_add(&slot[2 + k], v);
+    }
+    if (a.tail_counter) region_tail(a, lds);
 }
 
 // Region statistics with DENSE targets and a per-element activation (multilabel / binary Dice and Jaccard: sigmoid or given
@@ -365,6 +533,7 @@ __global__ __launch_bounds__(256, FOCAL ? 3 : 1) void seg_fwd_lean_kernel(const 
 template <int PROB, bool IGN, bool FOCAL = false>
 __global__ __launch_bounds__(256) void seg_stats_dense_lean_kernel(const SegArgs a) {
     static_assert(!FOCAL || PROB == PROB_SIGMOID, "the focal term shares the sigmoid of the statistics");
+    extern __shared__ float lds[];  // only the in-launch tail uses it here
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
     const float term_mask = (a.flags & SEG_MASK_FOCAL_TERM) ? 0.0f : 1.0f;
@@ -414,13 +583,14 @@ __global__ __launch_bounds__(256) void seg_stats_dense_lean_kernel(const SegArgs
         sI = wave_sum(sI); sP = wave_sum(sP); sT = wave_sum(sT);
         if (lane == 0) {
             double* slot = a.sums + (size_t)((blockIdx.x * 4 + wave) % SUM_SLOTS) * (2 + 3 * C);
-            atomicAdd(&slot[2 + c], (double)sI);
-            atomicAdd(&slot[2 + C + c], (double)sP);
-            atomicAdd(&slot[2 + 2 * C + c], (double)sT);
+            slot_add(&slot[2 + c], (double)sI);
+            slot_add(&slot[2 + C + c], (double)sP);
+            slot_add(&slot[2 + 2 * C + c], (double)sT);
         }
         if (FOCAL) { f_loss += (double)lsum; f_term += (double)fsum; }
     }
     if (FOCAL) block_add2(f_loss, f_term, a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C), lane, wave);
+    if (a.tail_counter) region_tail(a, lds);
 }
 
 // Generic variant: any C, class planes are streamed (softmax: one extra pass for the log-sum-exp), everything run time.
@@ -499,9 +669,10 @@ __global__ __launch_bounds__(256) void seg_loss_fwd_kernel(const SegArgs a) {
         __syncthreads();
         for (int k = threadIdx.x; k < 3 * C; k += 256) {
             const double v = (double)lds[k] + (double)lds[3 * C + k] + (double)lds[6 * C + k] + (double)lds[9 * C + k];
-            if (v != 0.0) atomicAdd(&slot[2 + k], v);
+            if (v != 0.0) slot_add(&slot[2 + k], v);
         }
     }
+    if (a.tail_counter) region_tail(a, lds);
 }
 
 // ------------------------------------------------------------------------------------------------ focal-only forward
@@ -592,7 +763,7 @@ __global__ __launch_bounds__(256) void focal_fwd_lean_kernel(const SegArgs a) {
                 bad = bad || (valid[k] && (l64[k] < 0 || l64[k] >= C));
                 lab[k] = valid[k] ? (int)l64[k] : -1;
             }
-            if (bad) *a.error_flag = 1;
+            if (bad) raise_label_error(a.error_flag);
         }
         float lrelu = 0.f, llog = 0.f, fsum = 0.f;   // loss = sum f * relu(y) + ln2 * sum f * log2(1 + e)
         for (int c0 = 0; c0 < C; c0 += CCH) {
@@ -1542,7 +1713,7 @@ __global__ __launch_bounds__(256, 3) void softmax_focal_lean_kernel(const SmfArg
                 bad = bad || (!ign[k] && (l64[k] < 0 || l64[k] >= C));
                 tgt[k] = ign[k] ? 0 : (int)l64[k];          // masked_fill(target, ignore, 0), functional.py:139
             }
-            if (MODE == 0 && bad) *a.error_flag = 1;
+            if (MODE == 0 && bad) raise_label_error(a.error_flag);
         }
         float gp[4] = {1.f, 1.f, 1.f, 1.f};
         if (MODE && grad_pix) load_px<4>(grad_pix + (long long)b * a.HW + i0, gp, true);
@@ -1776,11 +1947,15 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
 int g_loss_prefetch = 0;   // ptb_set_tunable key 8: register double buffering in the fused loss forward (measured: no gain, 0.146 vs 0.141-0.145 ms)
 int g_smf_bwd_stash = 4;  // ptb_set_tunable key 7: 4 pixels per lane (251 VGPRs, 2 waves per SIMD) measured 0.372 ms fwd+bwd at cfg4, 2 pixels 0.54, the two-pass kernel 0.41-0.48
+int g_focal_pk_grid = 512;   // ptb_set_tunable key 13: workgroups of seg_focal_pk_kernel (2 per CU measured best: per-workgroup prologue / epilogue / slot atomics)
+int g_focal_pk = 1;       // ptb_set_tunable key 12 (2 = with register prefetch of the next pixel group): packed-fp32 / per-pixel-correction instance of the fused forward (seg_focal_pk_kernel); 0 = seg_fwd_lean_kernel
 int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
                           // instead of 4 pixels: 163 VGPRs, 3 waves): 0.164-0.171 vs 0.173-0.186 ms per FocalDiceJaccardLoss forward at cfg4
 }  // namespace ptb
 
 using namespace ptb;
+
+static int seg_loss_fwd_launch(SegArgs& a, hipStream_t s);
 
 extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
                                 double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags, int prob,
@@ -1794,7 +1969,51 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     hipStream_t s = (hipStream_t)stream;
     if (int rc = zero_sums(sums, 2 + 3 * C, error_flag, s)) return rc;   // the slot sums and the label flag start from zero
     if ((long long)B * HW == 0) return PTB_OK;
-    const size_t shmem = (size_t)4 * 3 * C * sizeof(float);
+    return seg_loss_fwd_launch(a, s);
+}
+
+extern "C" int64_t ptb_region_workspace_bytes(int C) {
+    if (C < 1 || C > 1024) return PTB_EINVAL;
+    return (int64_t)SUM_SLOTS * (2 + 3 * C) * (int64_t)sizeof(double) + (SUM_SLOTS + 2) * (int64_t)sizeof(int);   // slot sums, tickets, label flag
+}
+
+// The whole Dice / Jaccard / focal + Dice + Jaccard forward in ONE launch: the streaming statistics kernel, whose last-arriving
+// workgroup adds up the slots, evaluates the scalar epilogue and its derivative (what ptb_region_epilogue computes) and leaves the
+// workspace zeroed.  `workspace`: ptb_region_workspace_bytes(C) bytes of device memory that were zero before the FIRST call and
+// are used by one stream at a time; every call leaves them zero again.
+extern "C" int ptb_region_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
+                                   void* workspace, int B, int C, int64_t HW, int flags, int prob, float gamma, float alpha,
+                                   float threshold, int64_t ignore_label, float ignore_value, float focal_scale, float dice_weight,
+                                   float jaccard_weight, float smooth, float eps, int log_loss, const unsigned char* class_mask,
+                                   int n_selected, float* loss, float* coef, int* error_out, ptb_stream_t stream) {
+    SegArgs a{};
+    if (int rc = fill_seg(a, logits, labels, dense, class_weights, B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
+    if (!workspace || !loss || !coef || n_selected < 1 || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return PTB_EINVAL;
+    if (!(flags & SEG_STATS) || (flags & SEG_ELEMWISE)) return PTB_EINVAL;
+    if (C > 1024) return PTB_EUNSUPPORTED;
+    if ((long long)B * HW == 0) return PTB_EUNSUPPORTED;      // (nothing would launch: the caller composes the empty case)
+    a.sums = static_cast<double*>(workspace);
+    int* words = reinterpret_cast<int*>(a.sums + (size_t)SUM_SLOTS * (2 + 3 * C));
+    a.tail_counter = reinterpret_cast<unsigned int*>(words);
+    a.error_flag = words + SUM_SLOTS + 1;
+    a.tail_error_out = error_out;
+    a.tail_class_mask = class_mask;
+    a.tail_loss = loss; a.tail_coef = coef;
+    a.tail_focal_scale = (flags & SEG_FOCAL) ? focal_scale : 0.f;
+    a.tail_dice_w = dice_weight; a.tail_jacc_w = jaccard_weight; a.tail_smooth = smooth; a.tail_eps = eps;
+    a.tail_log_loss = log_loss; a.tail_n_selected = n_selected;
+    return seg_loss_fwd_launch(a, (hipStream_t)stream);
+}
+
+static int seg_loss_fwd_launch(SegArgs& a, hipStream_t s) {
+    const float *logits = a.logits, *dense = a.dense, *class_weights = a.class_weights;
+    const long long* labels = a.labels;
+    float* elem_out = a.elem_out;
+    const int B = a.B, C = a.C, flags = a.flags, prob = a.prob;
+    const int64_t HW = a.HW;
+    const float gamma = a.gamma;
+    // [4 waves][3][C] floats of per-wave sums; the in-launch tail reuses it for (2 + 3 C) doubles + 8 more (+ alignment slack)
+    const size_t shmem = (size_t)4 * 3 * C * sizeof(float) + (a.tail_counter ? 128 : 0);
     const int what = flags & (SEG_FOCAL | SEG_STATS);
     if (!what) return PTB_EINVAL;
     const bool g2 = gamma == 2.0f;
@@ -1804,17 +2023,17 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
     if (!g_force_scalar && dense && !labels && what == (SEG_FOCAL | SEG_STATS) && vec && HW % 1024 == 0 && prob == PROB_SIGMOID && g2 &&
         !class_weights && !(flags & (SEG_HAS_ALPHA | SEG_REDUCED | SEG_ELEMWISE))) {
         const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream));
-        if (flags & SEG_HAS_IGNORE) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true, true>), dgrid, block, 0, s, a);
-        else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false, true>), dgrid, block, 0, s, a);
+        if (flags & SEG_HAS_IGNORE) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true, true>), dgrid, block, shmem, s, a);
+        else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false, true>), dgrid, block, shmem, s, a);
         return check_launch();
     }
     if (!g_force_scalar && dense && !labels && what == SEG_STATS && vec && HW % 1024 == 0 && (prob == PROB_SIGMOID || prob == PROB_IDENTITY)) {
         const bool ign = flags & SEG_HAS_IGNORE;
         const dim3 dgrid(grid_for_groups(HW / 1024 * C * B, kGridStream));
-        if (prob == PROB_SIGMOID) { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true>), dgrid, block, 0, s, a);
-                                    else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false>), dgrid, block, 0, s, a); }
-        else { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, true>), dgrid, block, 0, s, a);
-               else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, false>), dgrid, block, 0, s, a); }
+        if (prob == PROB_SIGMOID) { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, true>), dgrid, block, shmem, s, a);
+                                    else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_SIGMOID, false>), dgrid, block, shmem, s, a); }
+        else { if (ign) hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, true>), dgrid, block, shmem, s, a);
+               else hipLaunchKernelGGL((seg_stats_dense_lean_kernel<PROB_IDENTITY, false>), dgrid, block, shmem, s, a); }
         return check_launch();
     }
     // straight-line kernels for the common case (see seg_fwd_lean_kernel)
@@ -1827,7 +2046,13 @@ extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, cons
         const bool no_term = flags & SEG_NO_TERM;
 #define PTB_LEAN(CR) do { \
             if (plain_focal) { const dim3 g2(grid_for_groups(HW / 128 * B, kGridStats)); \
-                               if (!g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 4, true, false>), lgrid, block, shmem, s, a); \
+                               const size_t pk_lds = std::max(shmem, (size_t)4 * 2 * CR * 64 * sizeof(float)); \
+                               const dim3 gpk(grid_for_groups(HW / 128 * B, g_focal_pk_grid)); \
+                               if (g_fused_pix2 && g_focal_pk == 2 && no_term && C == CR) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, true, true>), gpk, block, pk_lds, s, a); \
+                               else if (g_fused_pix2 && g_focal_pk && no_term && C == CR) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, true>), gpk, block, pk_lds, s, a); \
+                               else if (g_fused_pix2 && g_focal_pk && no_term) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, false>), gpk, block, pk_lds, s, a); \
+                               else if (g_fused_pix2 && g_focal_pk) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, true, false>), gpk, block, pk_lds, s, a); \
+                               else if (!g_fused_pix2) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 4, true, false>), lgrid, block, shmem, s, a); \
                                else if (no_term && C == CR && g_loss_prefetch) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true, true>), g2, block, shmem, s, a); \
                                else if (no_term && C == CR) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true>), g2, block, shmem, s, a); \
                                else if (no_term) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, false>), g2, block, shmem, s, a); \

@@ -27,6 +27,7 @@ _CHECK_LABELS = os.environ.get("PTB_SKIP_LABEL_CHECK", "0") != "1"
 SYNC_LABEL_CHECK = os.environ.get("PTB_SYNC_LABEL_CHECK", "0") == "1"
 _LABEL_MSG = "Class values must be smaller than num_classes."
 _pending = []  # (pinned host int32 tensor, event)
+ONE_LAUNCH_REGION_LOSS = os.environ.get("PTB_ONE_LAUNCH_REGION_LOSS", "1") != "0"   # (A/B switch: 0 = kernel + finalize-free epilogue launch)
 _pending_lock = threading.Lock()
 
 
@@ -79,6 +80,50 @@ def check_labels(flag):
     ev.record(torch.cuda.current_stream(flag.device))
     with _pending_lock:
         _pending.append((host, ev))
+
+
+_flag_ring = None        # pinned int32 [256]: label flags the kernels of the one-launch region loss write straight into host memory
+_flag_next = 0
+_workspaces = {}         # (device index, stream) -> zeroed uint8 workspace of ptb_region_loss_fwd
+
+
+def host_flag_slot():
+    """One int32 of pinned host memory (a ring of 256) for a kernel to write its label flag into -- no device-to-host copy on the
+    stream; the slot is valid once the event recorded after the launch has completed."""
+    global _flag_ring, _flag_next
+    if _flag_ring is None:
+        _flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+    _flag_next = (_flag_next + 1) % 256
+    return _flag_ring[_flag_next:_flag_next + 1]
+
+
+def watch_host_flag(slot, device):
+    """Register a pinned flag slot the launch just issued on the current stream will write (see ``check_labels``)."""
+    if not _CHECK_LABELS:
+        return
+    if SYNC_LABEL_CHECK:
+        torch.cuda.current_stream(device).synchronize()
+        if int(slot[0]) != 0:
+            raise RuntimeError(_LABEL_MSG)
+        return
+    _poll(block=False)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    with _pending_lock:
+        _pending.append((slot, ev))
+
+
+def region_workspace(device, C):
+    """The persistent workspace of ``ptb_region_loss_fwd`` for the current stream of ``device``: zero when created, left zero by
+    every launch (the last workgroup exchanges the slot sums, its counter and the label flag against zero)."""
+    need = int(N.load().ptb_region_workspace_bytes(C))
+    if need < 0:
+        return None
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _workspaces[key] = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
+    return ws
 
 
 def new_sums(row, device, with_flag=True):
@@ -341,11 +386,29 @@ class RegionLoss(torch.autograd.Function):
     def forward(ctx, x, labels, dense, class_weights, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value,
                 with_focal, focal_scale, dice_weight, jaccard_weight, smooth, eps, log_loss, class_mask, n_selected):
         B, C, HW = x.shape
-        sums, flag = new_sums(2 + 3 * C, x.device)
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         coef = torch.empty(2 + 2 * C, dtype=torch.float32, device=x.device)
         what = SEG_STATS | (SEG_FOCAL if with_focal else 0)
         lib = N.load()
+        ctx.save_for_backward(x, labels, dense, class_weights, coef)
+        ctx.cfg = (flags, prob, gamma, alpha, threshold, ignore_label, ignore_value, with_focal)
+        ws = region_workspace(x.device, C) if ONE_LAUNCH_REGION_LOSS else None
+        if ws is not None:
+            # one launch: the streaming kernel's last workgroup adds up the slots, evaluates the tail and its derivative and leaves
+            # the workspace zeroed (no memset / finalize / epilogue launches, no device-to-host copy of the label flag)
+            slot = host_flag_slot() if (labels is not None and _CHECK_LABELS) else None
+            with N.on_device(x.device):
+                rc = lib.ptb_region_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), ws.data_ptr(), B, C, HW, flags | what,
+                                             prob, gamma, alpha, threshold, ignore_label, ignore_value, focal_scale if with_focal else 0.0,
+                                             dice_weight, jaccard_weight, smooth, eps, 1 if log_loss else 0, _ptr(class_mask), n_selected,
+                                             loss.data_ptr(), coef.data_ptr(), _ptr(slot), N.stream_ptr(x.device))
+            if rc != N.PTB_EUNSUPPORTED:
+                N.check(rc, "ptb_region_loss_fwd")
+                N.bump()
+                if slot is not None:
+                    watch_host_flag(slot, x.device)
+                return loss
+        sums, flag = new_sums(2 + 3 * C, x.device)
         with N.on_device(x.device):
             rc = lib.ptb_seg_loss_fwd(x.data_ptr(), _ptr(labels), _ptr(dense), _ptr(class_weights), sums.data_ptr(), None,
                                       flag.data_ptr(), B, C, HW, flags | what, prob, gamma, alpha, threshold, ignore_label, ignore_value,
@@ -358,8 +421,6 @@ class RegionLoss(torch.autograd.Function):
         N.bump()
         if labels is not None:
             check_labels(flag)
-        ctx.save_for_backward(x, labels, dense, class_weights, coef)
-        ctx.cfg = (flags, prob, gamma, alpha, threshold, ignore_label, ignore_value, with_focal)
         return loss
 
     @staticmethod

@@ -91,9 +91,10 @@ class SoftF1Loss(nn.Module):
         self.eps = eps
 
     def forward(self, preds: Tensor, targets: Tensor) -> Tensor:
-        if preds.is_cuda and preds.dim() == 2 and targets.dim() == 1 and self.ignore_index is None and preds.numel():
+        if preds.is_cuda and preds.dim() == 2 and targets.dim() == 1 and self.ignore_index is None and preds.numel() and self.eps <= 1e-6:
             # softmax + one-hot + the three per-class sums in one pass over the class-major view [1, C, N]; the clamp to
-            # [eps, 1 - eps] (1e-6 by default) moves a probability by at most eps -- far inside the 1e-5 parity tolerance
+            # [eps, 1 - eps] (1e-6 by default) moves a probability by at most eps -- far inside the 1e-5 parity tolerance; a caller's
+            # larger eps takes the op chain below, which clamps for real
             x = K._f32c(preds, "SoftF1Loss").t().contiguous().unsqueeze(0)
             labels = targets.to(device=preds.device, dtype=torch.int64).reshape(1, -1).contiguous()
             if labels.shape[1] != x.shape[2]:

@@ -65,9 +65,11 @@ def test_band_plan_kernel_has_no_scratch(reports):
 
 
 def test_straight_line_loss_kernels_do_not_spill(reports):
-    fused = _find(reports["losses"], "seg_fwd_lean_kernelILi16ELi0ELb1ELb0ELi2ELb0ELb1ELb0E")    # cfg4 fused forward, C = 16
+    fused = _find(reports["losses"], "seg_fwd_lean_kernelILi16ELi0ELb1ELb0ELi2ELb0ELb1ELb0E")    # cfg4 fused forward, C = 16 (ptb_set_tunable(12, 0))
     for k, r in fused.items():
-        assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0, (k, r)
+        assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0, (k, r)      # (the in-launch tail is inlined: a call would cost a stack and 20 VGPRs)
+    for k, r in _find(reports["losses"], "seg_focal_pk_kernelILi16ELb0ELb1ELb0E").items():          # the packed-fp32 instance that runs by default
+        assert r["VGPRs"] <= 128 and r["ScratchSize"] == 0 and r["Occupancy"] >= 4, (k, r)
     for k, r in _find(reports["losses"], "softmax_focal_bwd_kernelILi4ELi16ELb1E").items():
         assert r["ScratchSize"] == 0 and r.get("VGPRs Spill", 0) == 0, (k, r)
     for k, r in _find(reports["losses"], "seg_fused_bwd_lean_kernelILi16E").items():

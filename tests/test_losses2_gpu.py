@@ -277,6 +277,13 @@ def test_soft_f1_at_scale_and_edges(dev):
     want.backward()
     assert float(got) == pytest.approx(float(want), abs=1e-6)
     torch.testing.assert_close(logits.grad, lr.grad.float(), rtol=1e-4, atol=1e-10)
+    # a caller's eps is honoured on GPU tensors too (the fused pass only stands in for the default clamp)
+    with torch.no_grad():
+        got_eps = L.SoftF1Loss(eps=0.05)(logits, lab)
+    p5 = lr.detach().double().softmax(1).clamp(0.05, 0.95)
+    tp, fp, fn = (p5 * oh).sum(0), (p5 * (1 - oh)).sum(0), ((1 - p5) * oh).sum(0)
+    assert float(got_eps) == pytest.approx(float((1 - 2 * tp / (2 * tp + fn + fp + 1e-6)).mean()), abs=1e-5)
+    assert abs(float(got_eps) - float(got)) > 1e-3
     probs = torch.rand((4096, 7), device=dev)
     tg = (torch.rand((4096, 7), device=dev) < 0.4).float()
     pd_, td = probs.double(), tg.double()
@@ -322,3 +329,62 @@ def test_bitempered_rows_native_vs_algebra(t1, t2, sm, K, dev):
     (a * w.to(dev)).sum().backward()
     (b * w.double()).sum().backward()
     np.testing.assert_allclose(xa.grad.cpu().numpy(), xb.grad.numpy(), rtol=2e-3, atol=2e-5)
+
+
+def test_one_launch_region_loss_matches_the_two_launch_path(dev):
+    """ptb_region_loss_fwd (the streaming kernel's last workgroup evaluates the scalar tail and re-zeroes the workspace) against
+    kernel + ptb_region_epilogue: same loss and gradient for Dice / Jaccard / the fused loss in every kernel family (straight-line,
+    generic register-resident, dense-target, streamed classes), call after call on one workspace; a bad label poisons the loss
+    and is reported asynchronously; two streams keep separate workspaces."""
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd import losses as L
+    from pytorch_toolbelt_amd.losses import _kernels as K
+
+    g = torch.Generator(device=dev).manual_seed(4)
+    cases = []
+    for (B, C, H, W) in [(4, 16, 64, 64), (2, 5, 48, 40), (3, 3, 17, 23), (2, 40, 32, 32)]:
+        x = torch.randn((B, C, H, W), device=dev, generator=g) * 2
+        lab = torch.randint(0, C, (B, H, W), device=dev, generator=g)
+        dense = (torch.rand((B, C, H, W), device=dev, generator=g) < 0.3).float()
+        cases += [(L.DiceLoss("multiclass"), x, lab), (L.JaccardLoss("multiclass", log_loss=True, smooth=1.0), x, lab),
+                  (L.FocalDiceJaccardLoss("multiclass"), x, lab), (L.DiceLoss("multiclass", ignore_index=1, classes=[0, 2]), x, lab),
+                  (L.DiceLoss("multilabel"), x, dense), (L.FocalDiceJaccardLoss("multilabel"), x, dense)]
+    assert K.ONE_LAUNCH_REGION_LOSS
+    for rep in range(2):          # twice: the second round runs on the workspaces the first one left behind
+        for crit, x, t in cases:
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            before = N.calls
+            la = crit(xa, t)
+            assert N.calls == before + 1, "the one-launch path did not run"
+            la.backward()
+            K.ONE_LAUNCH_REGION_LOSS = False
+            try:
+                lb = crit(xb, t)
+                lb.backward()
+            finally:
+                K.ONE_LAUNCH_REGION_LOSS = True
+            assert float(la) == pytest.approx(float(lb), rel=2e-6, abs=1e-7), (type(crit).__name__, tuple(x.shape))
+            torch.testing.assert_close(xa.grad, xb.grad, rtol=2e-5, atol=1e-9)
+    for ws in K._workspaces.values():
+        assert int(ws.count_nonzero()) == 0, "a launch left its workspace dirty"
+    # a label outside [0, C): NaN loss now, RuntimeError at the next check
+    K.flush_label_check()
+    x = torch.randn((2, 4, 32, 32), device=dev)
+    lab = torch.randint(0, 4, (2, 32, 32), device=dev)
+    lab[1, 3, 3] = 7
+    loss = L.DiceLoss("multiclass")(x, lab)
+    assert torch.isnan(loss)
+    with pytest.raises(RuntimeError, match="Class values must be smaller than num_classes"):
+        K.flush_label_check()
+    for ws in K._workspaces.values():
+        assert int(ws.count_nonzero()) == 0
+    lab[1, 3, 3] = 1
+    good = L.DiceLoss("multiclass")(x, lab)
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    n_ws = len(K._workspaces)
+    with torch.cuda.stream(side):
+        other = L.DiceLoss("multiclass")(x, lab)
+    side.synchronize()
+    assert len(K._workspaces) == n_ws + 1 and float(other) == float(good) and torch.isfinite(good)
+    K.flush_label_check()
