@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg5"], help="cfg2 (default): the headline tiled + d4 merge (BASELINE "
+                    "configs[1], sharded over the ranks = configs[2]); cfg5: multiscale 0.75/1.0/1.25 + fliplr TTA, gmean, on 4096x4096 "
+                    "(BASELINE configs[4]), output row strips over the ranks")
     ap.add_argument("--chunk-rows", type=int, default=0, help="override the view-kernel chunk rows (16|32|64)")
     ap.add_argument("--memset-accumulators", action="store_true", help="A/B: zero the accumulators with a memset each step instead of first-touch stores")
     ap.add_argument("--placement-tries", type=int, default=8, help="candidate placements of the model-output pool tried in the untimed set-up (1 = take the first)")
@@ -250,8 +253,130 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     return out
 
 
+def main_cfg5(args):
+    """BASELINE configs[4]: multiscale (0.75 / 1.0 / 1.25) + fliplr TTA on 4096 x 4096, gmean inside every scale and across the
+    scales, C = 4.  One step = one image: every rank merges its strip of output rows from the rows (with the bilinear taps' halo)
+    of the three model outputs it holds -- no collective, the strips of the result stay sharded (parallel.ms_strip_plan, SURVEY 8e:
+    the reference's MultiscaleTTA, inference/tta.py:759-801, on one device).  N = 1: the one-pass kernel (ptb_ms_flip_deaug_reduce)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if os.environ.get("PTB_BENCH_SAME_GPU", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    use_dist = world > 1
+    if use_dist:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = os.environ.get("PTB_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    import __graft_entry__ as entry
+
+    if rank == 0:
+        entry.build()
+    if use_dist:
+        dist.barrier()
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.parallel import ms_image_deaugment_strip, ms_strip_plan
+
+    n, C, V = 4096, 4, 2
+    offs = [-n // 4, 0, n // 4]
+    heights = [n + o for o in offs]
+    g = torch.Generator(device=dev).manual_seed(1234)
+    plan = ms_strip_plan(heights, n, world, align_corners=False)[rank]
+    r0, r1 = plan["out"]
+    if world == 1:
+        ys = [torch.rand((V, C, h, h), device=dev, generator=g) * 0.9 + 0.05 for h in heights]
+
+        def step():
+            return tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction="gmean", reduction="gmean", align_corners=False)
+    else:
+        # this rank's rows of every scale's (fliplr-augmented) model output: the strip the model would have produced here
+        ys = [torch.rand((V, C, s1 - s0, h), device=dev, generator=g) * 0.9 + 0.05 for (s0, s1), h in zip(plan["src"], heights)]
+
+        def step():
+            maps = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
+            return ms_image_deaugment_strip(maps, heights, plan["src"], plan["out"], (n, n), reduction="gmean", align_corners=False)
+
+    def sync():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gc.collect()
+    gc.freeze()
+    for _ in range(max(args.warmup, 20)):
+        step()
+    runs = []
+    for _ in range(max(1, args.repeats)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        wall = time.perf_counter() - t0
+        if use_dist:
+            tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        runs.append(wall)
+    elapsed = sorted(runs)[len(runs) // 2]
+    ms_per_step = elapsed / args.steps * 1e3
+    my_bytes = sum(y.numel() for y in ys) * 4 + C * (r1 - r0) * n * 4
+    line = None
+    if rank == 0:
+        line = {
+            "metric": "megapixels/sec multiscale(0.75/1.0/1.25)+fliplr TTA gmean merge on 4096x4096", "value": round(n * n / 1e6 * args.steps / elapsed, 1),
+            "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg5: 4096x4096, scales 0.75/1.0/1.25 (offsets -1024, 0, +1024), fliplr TTA inside every scale (2 views), "
+                                   "gmean / gmean, C=4 model outputs resident in HBM; " +
+                                   ("one pass (tta.ms_flips_image_deaugment)" if world == 1 else
+                                    f"output rows split over {world} ranks (parallel.ms_strip_plan: np.linspace rows, each rank holds the source rows "
+                                    "its taps touch), per rank 3 x fliplr_image_deaugment on its strips + ms_image_deaugment_strip; no collective"),
+                       "parallelism": "single GPU" if world == 1 else f"row strips over {world} ranks", "rank0_out_rows": [r0, r1],
+                       "repeat_ms_per_step": [round(w / args.steps * 1e3, 4) for w in runs]},
+            "roofline": {"kernel": "ms_flip_reduce_kernel (one pass)" if world == 1 else "rank 0's step: fliplr de-augment launches + ms_reduce strip kernel",
+                         "bound": "hbm", "achieved": round(my_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(my_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": my_bytes, "avg_launch_ms": round(ms_per_step, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import torch_chain as TC
+
+            cores, _logical, model = TC.host_description()
+            prev = torch.get_num_threads()
+            torch.set_num_threads(min(cores, 32))
+            ys_cpu = [y[:, :1].cpu() for y in ys]
+            t0 = time.perf_counter()
+            TC.ms_fliplr_deaugment(ys_cpu, offs, "gmean", align_corners=False)
+            per_image = (time.perf_counter() - t0) * C
+            torch.set_num_threads(prev)
+            line["cpu_baseline"] = {"value": round(n * n / 1e6 / per_image, 3), "unit": "MP/s", "cores": min(cores, 32), "kind": "port",
+                                    "sample": f"1 of {C} channels through the reference's op chain (x{C}); {model}"}
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "cfg5":
+        return main_cfg5(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -196,6 +196,30 @@ int ptb_band_plan_submit(ptb_band_plan* plan, int pos, int B, const void* batch,
                          ptb_stream_t stream);
 void ptb_band_plan_destroy(ptb_band_plan* plan);
 
+/* Multi-GPU (no reference counterpart; the single-device result of inference/tiles.py:321-346 is the specification).
+ * ptb_band_plan_create2 = ptb_band_plan_create + `early`: n_early row ranges [lo, hi) of the plan's rows (ends among the cuts) that a
+ * neighbouring rank waits for.  With them launch groups are formed by class: all early bands in one launch (issued as soon as the
+ * tiles feeding them are in, however far apart the rows lie), the others in groups of ~rows_per_launch rows that do not break at the cuts.
+ * ptb_band_plan_rows_launched: 1 when every group writing rows r0 .. r1-1 has been issued for the current image, else 0.
+ * ptb_halo_pack: strided rectangle -> contiguous send buffer, dst[c][r][x] = src[c * chan_stride + r * row_stride + x].
+ * ptb_band_plan_submit_rank: ptb_band_plan_submit, then packs every outgoing rectangle (rects: n_sends x {r0, r1, c0, c1}, the plan's
+ * rows) whose rows are complete into send_bufs[k] (`packed` [n_sends] in/out, zero at the start of an image) and, when the last one
+ * has just been packed, records ready_event (a hipEvent_t, may be NULL) on the stream.  Returns the band launches issued (>= 0).
+ * ptb_band_plan_finish_rank: the end of a rank's image -- adds the n_recvs received rectangles of partial sums ({r0, r1, c0, c1} in
+ * the plan's rows, packed [C][rows][cols] buffers) to `merged` and divides the n_ranges row ranges {r0, r1} that held partial sums by
+ * `norm` [H][W] in place (launches only). */
+int64_t ptb_band_plan_create2(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
+                              int final_lo, int final_hi, const int64_t* cuts, int ncuts, const int64_t* early, int n_early,
+                              ptb_band_plan** out);
+int ptb_band_plan_rows_launched(const ptb_band_plan* plan, int r0, int r1);
+int ptb_halo_pack(const float* src, int64_t chan_stride, int64_t row_stride, int C, int rows, int cols, float* dst, ptb_stream_t stream);
+int ptb_band_plan_finish_rank(const ptb_band_plan* plan, float* merged, const float* norm, int n_recvs, const int64_t* rects,
+                              const float* const* recv_bufs, int n_ranges, const int64_t* ranges, ptb_stream_t stream);
+int ptb_band_plan_submit_rank(ptb_band_plan* plan, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride, int in_dtype,
+                              int V, const int* views, int reduction, float* merged, const float* norm_full, const float* weight,
+                              int n_sends, const int64_t* rects, float* const* send_bufs, int* packed, void* ready_event,
+                              int* all_packed, ptb_stream_t stream);
+
 /* dst[c][r][x] += src[c][r][x] for a packed src [C, rows, cols] and a rectangle of a larger fp32 accumulator (element
  * strides dst_cs per channel, dst_rs per row): folds a halo rectangle received from another rank into the band
  * accumulator (multi-GPU merger; no reference counterpart). */

@@ -59,6 +59,12 @@ SIGNATURES = {
     "ptb_band_plan_state": (_c_int, [_vp, _ip, _ip]),
     "ptb_band_plan_submit": (_c_int, [_vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _c_int, _c_int, _ip, _c_int, _vp, _vp, _vp, _vp]),
     "ptb_band_plan_destroy": (None, [_vp]),
+    "ptb_band_plan_create2": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _i64p, _c_int, _i64p, _c_int, _vpp]),
+    "ptb_band_plan_rows_launched": (_c_int, [_vp, _c_int, _c_int]),
+    "ptb_halo_pack": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _vp, _vp]),
+    "ptb_band_plan_finish_rank": (_c_int, [_vp, _vp, _vp, _c_int, _i64p, _vpp, _c_int, _i64p, _vp]),
+    "ptb_band_plan_submit_rank": (_c_int, [_vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _c_int, _c_int, _ip, _c_int, _vp, _vp, _vp, _c_int, _i64p, _vpp, _ip, _vp,
+                                           _ip, _vp]),
     "ptb_rect_add": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_i64, _c_i64, _vp]),
     "ptb_merge_div_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp]),
     "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

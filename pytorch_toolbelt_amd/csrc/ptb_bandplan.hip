@@ -135,6 +135,8 @@ struct ptb_band_plan {
     std::vector<ptb::Group> groups;
     std::vector<int> last_group;          // per tile: the last group that reads it
     std::vector<std::vector<int>> ready;  // per tile: groups complete once it is in
+    std::vector<int> band_y0, band_y1, band_group;   // every band's rows and the launch group that writes them
+    std::vector<char> group_launched;     // per image
     const ptb::BandItem* dev_items = nullptr;
     int n_bands = 0;
     // per image
@@ -195,7 +197,18 @@ static int band_items(const ptb_band_plan& p, const std::vector<int>& cover, con
 extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
                                         int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
                                         ptb_band_plan** out) {
+    return ptb_band_plan_create2(xs64, ys64, n, C, th, tw, H, W, rows_per_launch, final_lo, final_hi, cuts, ncuts, nullptr, 0, out);
+}
+
+// `early` = n_early row ranges [lo, hi) (their ends must be among the cuts): the rows a neighbouring rank waits for.  With them the
+// launch groups are formed by CLASS instead of by position: all early bands together (one launch as soon as the tiles feeding them
+// are in -- the caller issues those first -- however far apart the rows lie), and the remaining bands in groups of ~rows_per_launch
+// rows that do not break at the cuts.  A rank of an 8-way sharded 5000 x 5000 image gets 2 launches instead of 6.
+extern "C" int64_t ptb_band_plan_create2(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
+                                         int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
+                                         const int64_t* early, int n_early, ptb_band_plan** out) {
     if (!xs64 || !ys64 || !out || n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || ncuts < 0 || (ncuts && !cuts)) return PTB_EINVAL;
+    if (n_early < 0 || (n_early && !early)) return PTB_EINVAL;
     *out = nullptr;
     if (g_force_scalar || tw % 4 || th % 4 || W % 4 || tw > 32767 || th > 32767) return PTB_EUNSUPPORTED;
     ptb_band_plan* p = new ptb_band_plan();
@@ -233,42 +246,89 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
     const int target = std::max(1, rows_per_launch);
     p->last_group.assign(n, -1);
     p->ready.assign(n, {});
-    size_t bi = 0;
-    while (bi < bands.size()) {
+    p->band_y0.resize(bands.size()); p->band_y1.resize(bands.size()); p->band_group.assign(bands.size(), -1);
+    for (size_t b = 0; b < bands.size(); ++b) { p->band_y0[b] = bands[b].y0; p->band_y1[b] = bands[b].y1; }
+    // emit one launch group from a list of band indices (any rows, ascending)
+    auto emit_group = [&](const std::vector<size_t>& members, const std::vector<int>& tiles) -> int {
         Group g{};
-        g.y0 = bands[bi].y0;
-        std::vector<int> tiles;
-        size_t bj = bi;
-        while (bj < bands.size()) {
-            std::vector<int> merged_tiles = tiles;
-            merged_tiles.insert(merged_tiles.end(), bands[bj].cover.begin(), bands[bj].cover.end());
-            std::sort(merged_tiles.begin(), merged_tiles.end());
-            merged_tiles.erase(std::unique(merged_tiles.begin(), merged_tiles.end()), merged_tiles.end());
-            const bool first = bj == bi;
-            if (!first && ((int)merged_tiles.size() > PLAN_TILES || (bands[bj].y1 - g.y0 > target && !tiles.empty()) ||
-                           std::find(breaks.begin(), breaks.end(), bands[bj].y0) != breaks.end())) break;
-            tiles.swap(merged_tiles);
-            ++bj;
-        }
-        g.y1 = bands[bj - 1].y1;
+        g.y0 = bands[members.front()].y0;
+        g.y1 = bands[members.back()].y1;      // (the hull when the members are not adjacent: ptb_band_plan_rows_launched has the exact rows)
         g.tiles = tiles;
         g.last_tile = tiles.empty() ? -1 : tiles.back();
         std::vector<int> slot_of(n, 0);
         for (size_t s = 0; s < tiles.size(); ++s) slot_of[tiles[s]] = (int)s;
         g.item_off = (long long)p->items.size();
         std::vector<BandItem> its;
-        for (size_t b = bi; b < bj; ++b) {
+        const int gi = (int)p->groups.size();
+        for (size_t b : members) {
             const int partial = (bands[b].y0 >= final_lo && bands[b].y1 <= final_hi) ? 0 : 1;
             const int rc = band_items(*p, bands[b].cover, slot_of, bands[b].y0, bands[b].y1, partial, its);
-            if (rc != PTB_OK) { delete p; return rc; }
+            if (rc != PTB_OK) return rc;
+            p->band_group[b] = gi;
         }
         std::stable_sort(its.begin(), its.end(), [](const BandItem& l, const BandItem& r) { return l.ntiles > r.ntiles; });
         g.item_cnt = (int)its.size();
         p->items.insert(p->items.end(), its.begin(), its.end());
-        const int gi = (int)p->groups.size();
         for (int t : tiles) p->last_group[t] = std::max(p->last_group[t], gi);
         p->groups.push_back(std::move(g));
-        bi = bj;
+        return PTB_OK;
+    };
+    auto with_band = [&](const std::vector<int>& tiles, size_t b) {
+        std::vector<int> merged_tiles = tiles;
+        merged_tiles.insert(merged_tiles.end(), bands[b].cover.begin(), bands[b].cover.end());
+        std::sort(merged_tiles.begin(), merged_tiles.end());
+        merged_tiles.erase(std::unique(merged_tiles.begin(), merged_tiles.end()), merged_tiles.end());
+        return merged_tiles;
+    };
+    if (n_early > 0) {
+        for (int k = 0; k < n_early; ++k)
+            if (early[2 * k] % 4 || early[2 * k + 1] % 4) { delete p; return PTB_EUNSUPPORTED; }
+        auto is_early = [&](const Band& b) {
+            for (int k = 0; k < n_early; ++k) if (b.y0 >= early[2 * k] && b.y1 <= early[2 * k + 1]) return true;
+            return false;
+        };
+        for (int cls = 0; cls < 2; ++cls) {             // early bands first: their group indices come first too
+            std::vector<size_t> members;
+            std::vector<int> tiles;
+            int rows = 0;
+            for (size_t b = 0; b < bands.size(); ++b) {
+                if ((is_early(bands[b]) ? 0 : 1) != cls) continue;
+                std::vector<int> merged_tiles = with_band(tiles, b);
+                const int h = bands[b].y1 - bands[b].y0;
+                if (!members.empty() && ((int)merged_tiles.size() > PLAN_TILES || (cls == 1 && rows + h > target && !tiles.empty()))) {
+                    const int rc = emit_group(members, tiles);
+                    if (rc != PTB_OK) { delete p; return rc; }
+                    members.clear(); rows = 0;
+                    merged_tiles = with_band({}, b);
+                }
+                tiles.swap(merged_tiles);
+                members.push_back(b);
+                rows += h;
+            }
+            if (!members.empty()) {
+                const int rc = emit_group(members, tiles);
+                if (rc != PTB_OK) { delete p; return rc; }
+            }
+        }
+    } else {
+        size_t bi = 0;
+        while (bi < bands.size()) {
+            std::vector<int> tiles;
+            std::vector<size_t> members;
+            size_t bj = bi;
+            while (bj < bands.size()) {
+                std::vector<int> merged_tiles = with_band(tiles, bj);
+                const bool first = bj == bi;
+                if (!first && ((int)merged_tiles.size() > PLAN_TILES || (bands[bj].y1 - bands[bi].y0 > target && !tiles.empty()) ||
+                               std::find(breaks.begin(), breaks.end(), bands[bj].y0) != breaks.end())) break;
+                tiles.swap(merged_tiles);
+                members.push_back(bj);
+                ++bj;
+            }
+            const int rc = emit_group(members, tiles);
+            if (rc != PTB_OK) { delete p; return rc; }
+            bi = bj;
+        }
     }
     // a group without any tile (an image whose first / last rows nobody covers) completes with the first tile of the image
     for (size_t gi = 0; gi < p->groups.size(); ++gi) {
@@ -277,6 +337,7 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
     }
     p->src.assign(n, nullptr);
     p->vs.assign(n, 0);
+    p->group_launched.assign(p->groups.size(), 0);
     *out = p;
     return (int64_t)(p->items.size() * sizeof(BandItem));
 }
@@ -306,6 +367,7 @@ extern "C" int ptb_band_plan_info(const ptb_band_plan* p, int* n_groups, int* n_
 extern "C" int ptb_band_plan_reset(ptb_band_plan* p) {
     if (!p) return PTB_EINVAL;
     p->pos = 0; p->launched = 0; p->cfg_set = 0;
+    std::fill(p->group_launched.begin(), p->group_launched.end(), 0);
     return PTB_OK;
 }
 
@@ -366,6 +428,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     for (int t = pos; t < pos + B; ++t) {
         for (int gi : p->ready[t]) {
             const Group& g = p->groups[gi];
+            p->group_launched[gi] = 1;
             if (!g.item_cnt) { ++p->launched; continue; }
             GroupTiles gt;
             for (size_t s = 0; s < g.tiles.size(); ++s) { gt.src[s] = p->src[g.tiles[s]]; gt.vs[s] = p->vs[g.tiles[s]]; }
@@ -381,4 +444,101 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
         }
     }
     return launched;
+}
+
+// 1 when every launch group that writes rows r0 .. r1-1 of the merged map has been issued for the current image (a band the rows
+// cut through counts as a whole), 0 otherwise.
+extern "C" int ptb_band_plan_rows_launched(const ptb_band_plan* p, int r0, int r1) {
+    if (!p || r1 < r0) return PTB_EINVAL;
+    for (size_t b = 0; b < p->band_y0.size(); ++b)
+        if (p->band_y0[b] < r1 && p->band_y1[b] > r0 && !p->group_launched[p->band_group[b]]) return 0;
+    return 1;
+}
+
+// Strided rectangle -> contiguous buffer: dst[c][r][x] = src[c * chan_stride + r * row_stride + x] (the send side of the halo
+// exchange; ptb_rect_add is the receive side).  16-byte accesses when the rectangle allows.
+template <int V>
+__global__ __launch_bounds__(256) void halo_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int rows, int cols,
+                                                        long long cs, long long rs) {
+    const long long per_row = cols / V;
+    const long long total = (long long)C * rows * per_row;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long x = i % per_row, cr = i / per_row;
+        const long long r = cr % rows, c = cr / rows;
+        const float* s = src + c * cs + r * rs + x * V;
+        float* d = dst + i * V;
+        if (V == 4) *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
+        else d[0] = s[0];
+    }
+}
+
+extern "C" int ptb_halo_pack(const float* src, int64_t chan_stride, int64_t row_stride, int C, int rows, int cols, float* dst,
+                             ptb_stream_t stream) {
+    if (!src || !dst || C < 1 || rows < 0 || cols < 0 || row_stride < cols || chan_stride < (int64_t)rows * row_stride) return PTB_EINVAL;
+    if (rows == 0 || cols == 0) return PTB_OK;
+    const bool vec = !g_force_scalar && cols % 4 == 0 && chan_stride % 4 == 0 && row_stride % 4 == 0 && aligned16(src) && aligned16(dst);
+    const long long total = (long long)C * rows * (vec ? cols / 4 : cols);
+    const int grid = (int)std::min<long long>((total + 255) / 256, 256 * 16);
+    if (vec) hipLaunchKernelGGL(halo_pack_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, rows, cols, (long long)chan_stride, (long long)row_stride);
+    else hipLaunchKernelGGL(halo_pack_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, dst, C, rows, cols, (long long)chan_stride, (long long)row_stride);
+    return check_launch();
+}
+
+// One rank's step of a sharded merge as ONE host call: ptb_band_plan_submit, then every outgoing halo rectangle whose rows have all
+// been written by their launches is packed into its send buffer (rects: n_sends x {r0, r1, c0, c1} in the plan's local rows;
+// `packed` [n_sends] in/out, 0 at the start of an image), and -- when the last of them has just been packed -- `ready_event`
+// (a hipEvent_t, may be NULL) is recorded on the stream: the communication stream waits for it and posts the sends.
+// Returns the number of band launches (>= 0) or a negative code; *all_packed (may be NULL) = every rectangle is in its buffer.
+extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride,
+                                         int in_dtype, int V, const int* views, int reduction, float* merged, const float* norm_full,
+                                         const float* weight, int n_sends, const int64_t* rects, float* const* send_bufs, int* packed,
+                                         void* ready_event, int* all_packed, ptb_stream_t stream) {
+    if (n_sends < 0 || (n_sends && (!rects || !send_bufs || !packed))) return PTB_EINVAL;
+    const int rc = ptb_band_plan_submit(p, pos, B, batch, tile_stride, view_stride, in_dtype, V, views, reduction, merged, norm_full, weight, stream);
+    if (rc < 0) return rc;
+    int done = 0, fresh = 0;
+    for (int k = 0; k < n_sends; ++k) {
+        if (!packed[k] && rc > 0) {
+            const int r0 = (int)rects[4 * k], r1 = (int)rects[4 * k + 1], c0 = (int)rects[4 * k + 2], c1 = (int)rects[4 * k + 3];
+            if (r0 < 0 || r1 > p->H || c0 < 0 || c1 > p->W || r1 < r0 || c1 < c0 || !send_bufs[k]) return PTB_EINVAL;
+            if (ptb_band_plan_rows_launched(p, r0, r1) == 1) {
+                const int prc = ptb_halo_pack(merged + (long long)r0 * p->W + c0, (int64_t)p->H * p->W, p->W, p->C, r1 - r0, c1 - c0, send_bufs[k], stream);
+                if (prc != PTB_OK) return prc;
+                packed[k] = 1;
+                ++fresh;
+            }
+        }
+        done += packed[k] ? 1 : 0;
+    }
+    const bool all = done == n_sends;
+    if (all && fresh && ready_event) {
+        const hipError_t e = hipEventRecord((hipEvent_t)ready_event, (hipStream_t)stream);
+        if (e != hipSuccess) { set_hip_error(e); return PTB_ELAUNCH; }
+    }
+    if (all_packed) *all_packed = all ? 1 : 0;
+    return rc;
+}
+
+// The end of a rank's image as ONE host call: the partial sums received from the neighbours (n_recvs rectangles {r0, r1, c0, c1} in
+// the plan's rows, packed [C][r1 - r0][c1 - c0] buffers) are added to `merged`, then the row ranges that held partial sums
+// (n_ranges x {r0, r1}) are divided by `norm` in place (tiles.py:346).  Launches only: ptb_rect_add + ptb_merge_div_ex per item.
+extern "C" int ptb_band_plan_finish_rank(const ptb_band_plan* p, float* merged, const float* norm, int n_recvs, const int64_t* rects,
+                                         const float* const* recv_bufs, int n_ranges, const int64_t* ranges, ptb_stream_t stream) {
+    if (!p || !merged || !norm || n_recvs < 0 || n_ranges < 0 || (n_recvs && (!rects || !recv_bufs)) || (n_ranges && !ranges)) return PTB_EINVAL;
+    const int64_t plane = (int64_t)p->H * p->W;
+    for (int k = 0; k < n_recvs; ++k) {
+        const int64_t r0 = rects[4 * k], r1 = rects[4 * k + 1], c0 = rects[4 * k + 2], c1 = rects[4 * k + 3];
+        if (r0 < 0 || r1 > p->H || c0 < 0 || c1 > p->W || r1 < r0 || c1 < c0 || !recv_bufs[k]) return PTB_EINVAL;
+        const int rc = ptb_rect_add(merged + r0 * p->W + c0, recv_bufs[k], p->C, (int)(r1 - r0), (int)(c1 - c0), plane, p->W, stream);
+        if (rc != PTB_OK) return rc;
+    }
+    for (int k = 0; k < n_ranges; ++k) {
+        const int64_t r0 = ranges[2 * k], r1 = ranges[2 * k + 1];
+        if (r0 < 0 || r1 > p->H || r1 < r0) return PTB_EINVAL;
+        if (r1 == r0) continue;
+        float* rows = merged + r0 * p->W;
+        const int rc = ptb_merge_div_ex(rows, norm + r0 * p->W, rows, p->C, (r1 - r0) * p->W, plane, plane, nullptr, 0, 0, stream);
+        if (rc != PTB_OK) return rc;
+    }
+    return PTB_OK;
 }

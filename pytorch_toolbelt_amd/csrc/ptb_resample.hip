@@ -785,6 +785,7 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
     return check_launch();
 }
 
+
 static int grid_1d(long long total) {
     const long long want = (total + 255) / 256;
     return (int)(want < 1 ? 1 : (want < 256 * 32 ? want : 256 * 32));

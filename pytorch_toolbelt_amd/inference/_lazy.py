@@ -101,6 +101,9 @@ for _n in ("size", "dim", "ndimension", "numel", "nelement", "__len__", "element
 del _n, _p, _f
 
 
+_CONTAINERS = (list, tuple, dict)
+
+
 class LazyDeaugment(torch.Tensor):
     """Result of ``<group>_image_deaugment(source, reduction)`` that has not been computed yet (see the module docstring)."""
 
@@ -165,7 +168,10 @@ class LazyDeaugment(torch.Tensor):
         if func in _META_FUNCS:
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
-        args, kwargs = tree_map(_unwrap, args), tree_map(_unwrap, kwargs)
+        # (flat argument lists -- almost every call -- are unwrapped by hand: tree_map costs ~10 us per call)
+        args = tuple(a._evaluate() if type(a) is LazyDeaugment else (tree_map(_unwrap, a) if isinstance(a, _CONTAINERS) else a) for a in args)
+        if kwargs:
+            kwargs = {k: (v._evaluate() if type(v) is LazyDeaugment else (tree_map(_unwrap, v) if isinstance(v, _CONTAINERS) else v)) for k, v in kwargs.items()}
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)
 

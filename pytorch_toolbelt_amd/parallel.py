@@ -227,12 +227,17 @@ class _DeferredBand:
         local = mine.copy()
         local[1] -= top
         cut_arr = np.ascontiguousarray(np.array([c - top for c in cuts if top < c < bottom], dtype=np.int64))
+        # the rows neighbours wait for (the outgoing rectangles) form ONE early launch group, everything else is merged in groups of
+        # `rows` rows that ignore the cuts: 2 launches per rank at N = 8 instead of 6 (ptb_band_plan_create2)
+        spans = sorted({(int(r0) - top, int(r1) - top) for _d, r0, r1, _c0, _c1 in me["sends"]})
+        early = np.ascontiguousarray(np.array(spans, dtype=np.int64).reshape(-1)) if (spans and merger.two_phase) else np.zeros(0, dtype=np.int64)
         lib = N.load()
         handle = ctypes.c_void_p()
-        nbytes = lib.ptb_band_plan_create(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], merger.channels,
-                                          th, tw, bottom - top, W, int(rows), final[0] - top if final[1] > final[0] else 0,
-                                          final[1] - top if final[1] > final[0] else 0,
-                                          cut_arr.ctypes.data_as(N._i64p) if len(cut_arr) else None, len(cut_arr), ctypes.byref(handle))
+        nbytes = lib.ptb_band_plan_create2(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], merger.channels,
+                                           th, tw, bottom - top, W, int(rows), final[0] - top if final[1] > final[0] else 0,
+                                           final[1] - top if final[1] > final[0] else 0,
+                                           cut_arr.ctypes.data_as(N._i64p) if len(cut_arr) else None, len(cut_arr),
+                                           early.ctypes.data_as(N._i64p) if len(early) else None, len(early) // 2, ctypes.byref(handle))
         if nbytes < 0:
             return None
         dev = merger.device
@@ -253,6 +258,25 @@ class _DeferredBand:
         w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).to(dev).reshape(1, th, tw).contiguous()
         band = _DeferredBand(handle, table, groups, (merger.channels, bottom - top, W), norm, w, mine, top, merger.channels, th, tw)
         band.final = final
+        # the outgoing rectangles in the plan's rows + their send buffers, for ptb_band_plan_submit_rank (submit + pack in one C call)
+        sends = merger.sends
+        band.n_sends = len(sends)
+        band.rects = np.ascontiguousarray(np.array([[r0 - top, r1 - top, c0, c1] for _d, r0, r1, c0, c1 in sends], dtype=np.int64).reshape(-1))
+        band.send_ptrs = (ctypes.c_void_p * max(len(sends), 1))(*[b.data_ptr() for b in merger._send_buf])
+        band.packed = (ctypes.c_int * max(len(sends), 1))()
+        band.all_packed = ctypes.c_int(0)
+        band.ready_event = torch.cuda.Event()      # recorded (by the C call) behind the pack of the last outgoing rectangle
+        # ... and what ptb_band_plan_finish_rank needs: the incoming rectangles + the owned row ranges that hold partial sums
+        recvs = merger.recvs
+        band.n_recvs = len(recvs)
+        band.recv_rects = np.ascontiguousarray(np.array([[r0 - top, r1 - top, c0, c1] for _s, r0, r1, c0, c1 in recvs], dtype=np.int64).reshape(-1))
+        band.recv_ptrs = (ctypes.c_void_p * max(len(recvs), 1))(*[b.data_ptr() for b in merger._recv_buf])
+        f0, f1 = final
+        ranges = [(o0, o1)] if f1 <= f0 else [(o0, f0), (f1, o1)]
+        ranges = [(a_ - top, b_ - top) for a_, b_ in ranges if b_ > a_]
+        band.n_ranges = len(ranges)
+        band.ranges = np.ascontiguousarray(np.array(ranges, dtype=np.int64).reshape(-1))
+        band.fast = {}            # (group, reduction) -> (views array, number of views, reduction code)
         return band
 
     def reset(self):
@@ -260,10 +284,15 @@ class _DeferredBand:
 
         N.load().ptb_band_plan_reset(self.handle)
         self.pos, self.held, self.cfg, self.launched = 0, [], None, 0
+        for k in range(self.n_sends):
+            self.packed[k] = 0
+        self.all_packed.value = 1 if self.n_sends == 0 else 0
         self.out = None              # (the previous image's buffer now belongs to whoever merge() gave it to)
 
     def submit(self, batch, coords_abs, views, reduction):
         """Take the next planned tiles; returns the number of launches.  The tiles must arrive in ``merger.tiles`` order."""
+        import ctypes
+
         from . import _native as N
 
         B = len(coords_abs)
@@ -287,13 +316,17 @@ class _DeferredBand:
         from .inference.tiles import _check_held, _held_entry
 
         span = _held_entry(batch)
-        due = self.launched < len(self.groups) and self.pos + B > self.groups[self.launched][2]
+        due = any(self.pos <= last < self.pos + B for _y0, _y1, last in self.groups)
         _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
         if self.out is None:
             self.out = torch.empty(self.out_shape, device=dev, dtype=torch.float32)
         with N.on_device(dev):
-            rc = N.load().ptb_band_plan_submit(self.handle, self.pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype], n_views,
-                                               varr, reduction, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(), N.stream_ptr(dev))
+            # one C call: take the batch, launch the groups it completes, pack every outgoing rectangle whose rows are now written
+            rc = N.load().ptb_band_plan_submit_rank(self.handle, self.pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype],
+                                                    n_views, varr, reduction, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(),
+                                                    self.n_sends, self.rects.ctypes.data_as(N._i64p), self.send_ptrs, self.packed,
+                                                    self.ready_event.cuda_event if self.n_sends else None, ctypes.byref(self.all_packed),
+                                                    N.stream_ptr(dev))
         N.bump()
         if rc < 0:
             N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
@@ -302,10 +335,52 @@ class _DeferredBand:
         self.launched += rc
         return rc
 
+    def submit_fast(self, batch, coords_abs, key, views, code):
+        """The common call with everything per-call already validated by the caller (a contiguous device tensor of a kernel dtype, an
+        int64 [B, 4] array of the next planned crops): one array compare + ONE C call."""
+        import ctypes
+
+        from . import _native as N
+
+        B, pos = coords_abs.shape[0], self.pos
+        ent = self.fast.get(key)
+        if ent is None:
+            ent = self.fast[key] = (N.int_array(list(views)) if views is not None else N.int_array([N.IDENT]), len(views) if views is not None else 1)
+        varr, n_views = ent
+        if (pos + B > self.xy_abs.shape[1] or batch.shape != (B * n_views, self.channels, self.th, self.tw)
+                or not np.array_equal(coords_abs[:, :2], self.xy_abs_rows[pos:pos + B])):
+            return None          # (the general path reports what is wrong)
+        from .inference.tiles import _check_held, _held_entry
+
+        span = _held_entry(batch)
+        due = False
+        for _y0, _y1, last in self.groups:
+            if pos <= last < pos + B:
+                due = True
+        _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
+        dev = self.norm.device
+        if self.out is None:
+            self.out = torch.empty(self.out_shape, device=dev, dtype=torch.float32)
+        per_tile = self.channels * self.th * self.tw
+        with N.on_device(dev):
+            rc = N.load().ptb_band_plan_submit_rank(self.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype],
+                                                    n_views, varr, code, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(),
+                                                    self.n_sends, self.rects.ctypes.data_as(N._i64p), self.send_ptrs, self.packed,
+                                                    self.ready_event.cuda_event if self.n_sends else None, ctypes.byref(self.all_packed),
+                                                    N.stream_ptr(dev))
+        N.bump()
+        if rc < 0:
+            N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
+        self.held.append((batch,) + span)
+        self.pos = pos + B
+        self.launched += rc
+        return rc
+
     def rows_launched(self, r0, r1):
         """Every launch group that writes absolute rows r0:r1 has been issued (its last tile is in)."""
-        l0, l1 = r0 - self.top, r1 - self.top
-        return all(last < self.pos for y0, y1, last in self.groups if y0 < l1 and y1 > l0)
+        from . import _native as N
+
+        return N.load().ptb_band_plan_rows_launched(self.handle, r0 - self.top, r1 - self.top) == 1
 
     def complete(self):
         return self.pos == self.xy_abs.shape[1]
@@ -322,7 +397,7 @@ class ShardedTileMerger:
     """
 
     def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=False,
-                 defer_rows=None):
+                 defer_rows=None, two_phase=True):
         """``defer=True`` (opt-in, like ``TileMerger``): the rank's tiles are merged band by band straight from the model outputs
         (no accumulator).  The contract that comes with it: the batches are kept by reference and read by a LATER launch, so they
         must stay alive and unmodified until ``merge()`` (a reused output buffer or an in-place edit raises), and the tiles must
@@ -331,6 +406,7 @@ class ShardedTileMerger:
             import torch.distributed as dist
         self.dist = dist
         self.group = group
+        self.two_phase = bool(two_phase)     # deferred plan: one early launch for the rows neighbours wait for + the rest (else: cut by cut)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.ops = ops or _HipOps
@@ -433,8 +509,8 @@ class ShardedTileMerger:
         N.require_device(batch, "ShardedTileMerger")
         coords = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4)
         launched = self._deferred.submit(batch, coords, views, code)
-        if launched and not self._exchanged and all(self._deferred.rows_launched(r0, r1) for _d, r0, r1, _c0, _c1 in self.sends):
-            self._start_exchange()      # every row a neighbour waits for has been written by its launch: hand them over now
+        if launched and not self._exchanged and self._deferred.all_packed.value:
+            self._start_exchange()      # every outgoing rectangle has been written by its launch and packed (in the same C call)
 
     def integrate_batch(self, batch, crop_coords):
         if len(batch) != len(crop_coords):
@@ -458,7 +534,20 @@ class ShardedTileMerger:
 
     def integrate_batch_deaugment(self, batch, crop_coords, group="d4", reduction="mean"):
         if self._deferred is not None:
+            from . import _native as N
             from .inference.tta import DEAUGMENT_VIEWS, _reduction_code
+
+            d = self._deferred
+            if (type(crop_coords) is np.ndarray and crop_coords.ndim == 2 and crop_coords.dtype == np.int64 and type(reduction) is str
+                    and batch.is_cuda and batch.is_contiguous() and not batch.requires_grad and batch.dtype in N.DTYPE_CODES and len(crop_coords)):
+                code = _reduction_code(reduction)
+                views = DEAUGMENT_VIEWS.get(group)
+                if code is not None and views is not None:
+                    launched = d.submit_fast(batch, crop_coords, (group, code), views, code)
+                    if launched is not None:
+                        if launched and not self._exchanged and d.all_packed.value:
+                            self._start_exchange()
+                        return
 
             views = DEAUGMENT_VIEWS[group]
             if len(batch) != len(crop_coords) * len(views):
@@ -493,8 +582,10 @@ class ShardedTileMerger:
             return
         dist = self.dist
         ops = []
-        for buf, (dst, r0, r1, c0, c1) in zip(self._send_buf, self.sends):
-            buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)
+        d = self._deferred
+        for k, (buf, (dst, r0, r1, c0, c1)) in enumerate(zip(self._send_buf, self.sends)):
+            if d is None or not d.packed[k]:
+                buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
         for buf, (src, *_rect) in zip(self._recv_buf, self.recvs):
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
@@ -544,17 +635,18 @@ class ShardedTileMerger:
     def _merge_deferred(self, o0, o1):
         """Owned rows from the band plan's output: the rows finished alone already hold ``sum / norm``; the others hold this
         rank's partial sums, get the neighbours' partial sums added and are divided in place (<= 2 row ranges)."""
+        from . import _native as N
+
         d = self._deferred
         if not d.complete():
             raise RuntimeError("ShardedTileMerger.merge(): not all of this rank's tiles were integrated")
-        for buf, (_src, r0, r1, c0, c1) in zip(self._recv_buf, self.recvs):
-            self.ops.add_rect(d.out, self.top, (r0, r1, c0, c1), buf)
-        f0, f1 = d.final
-        ranges = [(o0, o1)] if f1 <= f0 else [(o0, f0), (f1, o1)]
-        for r0, r1 in ranges:
-            if r1 > r0:
-                rows = d.out[:, r0 - self.top:r1 - self.top]
-                self.ops.merge_rows(rows, d.norm[0, r0 - self.top:r1 - self.top], rows)
+        # add the neighbours' partial sums, divide the rows that held partial sums: one C call (ptb_rect_add + ptb_merge_div_ex launches)
+        with N.on_device(self.device):
+            rc = N.load().ptb_band_plan_finish_rank(d.handle, d.out.data_ptr(), d.norm.data_ptr(), d.n_recvs,
+                                                    d.recv_rects.ctypes.data_as(N._i64p) if d.n_recvs else None, d.recv_ptrs if d.n_recvs else None,
+                                                    d.n_ranges, d.ranges.ctypes.data_as(N._i64p) if d.n_ranges else None, N.stream_ptr(self.device))
+        N.bump()
+        N.check(rc, "ShardedTileMerger.merge (deferred band)")
         d.held = []
         return d.out[:, o0 - self.top:o1 - self.top]
 

@@ -335,3 +335,53 @@ def test_deferred_geometry_of_every_rank(world, partition):
             final_rows += f1 - f0
     assert (covered == 1).all()
     assert final_rows >= (5120 - world * 1024)     # at most ~2 tile heights per rank are shared with neighbours
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rank_band_plan_launches_by_class(world):
+    """ptb_band_plan_create2 (host-side planning, runs without a GPU): with the outgoing rectangles' rows given as `early` ranges a
+    rank's plan has ONE launch group for all of them -- complete as soon as the tiles feeding them are in, which the rank issues
+    first -- and the other rows in groups that do not break at the cuts (2 launches per rank at N = 8 instead of 6);
+    ptb_band_plan_rows_launched follows the exact rows of each group."""
+    import ctypes
+
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.parallel import deferred_geometry
+
+    lib = N.load()
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    crops = geom["crops"]
+    plan = band_plan(crops, world, 5120, "tiles")
+    for r in range(world):
+        me = plan[r]
+        a, b = me["band"]
+        o0, o1 = me["owned"]
+        top, bottom = min(a, o0), max(b, o1)
+        final, cuts = deferred_geometry(plan, r, crops, 5120)
+        local = np.ascontiguousarray(crops[me["tiles"], :2].T.astype(np.int64))
+        local[1] -= top
+        cut_arr = np.ascontiguousarray(np.array([c - top for c in cuts if top < c < bottom], dtype=np.int64))
+        spans = sorted({(int(r0) - top, int(r1) - top) for _d, r0, r1, _c0, _c1 in me["sends"]})
+        early = np.ascontiguousarray(np.array(spans, dtype=np.int64).reshape(-1))
+        counts = {}
+        for two_phase in (False, True):
+            handle = ctypes.c_void_p()
+            e = early if two_phase else np.zeros(0, dtype=np.int64)
+            nbytes = lib.ptb_band_plan_create2(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], 4, 512, 512,
+                                               bottom - top, 5120, 1024, final[0] - top, final[1] - top, cut_arr.ctypes.data_as(N._i64p), len(cut_arr),
+                                               e.ctypes.data_as(N._i64p) if len(e) else None, len(e) // 2, ctypes.byref(handle))
+            assert nbytes > 0
+            ng = ctypes.c_int()
+            lib.ptb_band_plan_info(handle, ctypes.byref(ng), None, None, None, None)
+            rows = np.zeros(3 * ng.value, dtype=np.int64)
+            last_group = np.zeros(local.shape[1], dtype=np.int64)
+            lib.ptb_band_plan_info(handle, None, None, None, last_group.ctypes.data_as(N._i64p), rows.ctypes.data_as(N._i64p))
+            counts[two_phase] = ng.value
+            if two_phase and spans:
+                n_boundary = len(me["boundary"])
+                assert rows[2] < n_boundary, "the early group must be complete once the boundary tiles (issued first) are in"
+                assert all(lib.ptb_band_plan_rows_launched(handle, s0, s1) == 0 for s0, s1 in spans)      # nothing launched yet
+            lib.ptb_band_plan_destroy(handle)
+        assert counts[True] <= counts[False]
+        if world == 8:
+            assert counts[True] == 2, counts
