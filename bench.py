@@ -138,10 +138,15 @@ def cpu_baseline(slicer, max_seconds=25.0):
     }
 
 
-def _gpu_ms(fn, reps, warm=3):
+def _gpu_ms(fn, reps, warm=3, ramp_ms=0.0):
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ramp_ms:     # (the GPU idled during the CPU baseline: back to its clocks first)
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -177,14 +182,14 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     bwd_bytes = fwd_bytes + x.numel() * 4                               # + one more read of logits and labels, the gradient written
     crit = L.FocalDiceJaccardLoss("multiclass")
     with torch.no_grad():
-        t_f = _gpu_ms(lambda: crit(x, labels), 30)
+        t_f = _gpu_ms(lambda: crit(x, labels), 100, ramp_ms=400.0)
     xg = x.clone().requires_grad_(True)
 
     def fwd_bwd():
         xg.grad = None
         crit(xg, labels).backward()
 
-    t_fb = _gpu_ms(fwd_bwd, 20)
+    t_fb = _gpu_ms(fwd_bwd, 40)
     out["cfg4_fwd"] = entry(t_f, fwd_bytes, what="FocalDiceJaccardLoss('multiclass') forward, [32,16,512,512] fp32 logits + int64 labels, per module call")
     out["cfg4_fwd_bwd"] = entry(t_fb, fwd_bytes + bwd_bytes, what="same, forward + backward (gradient wrt the logits)")
     seps = {"BinaryFocalLoss": L.BinaryFocalLoss(), "DiceLoss": L.DiceLoss("multiclass"), "JaccardLoss": L.JaccardLoss("multiclass")}
@@ -197,14 +202,14 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     lov = L.LovaszLoss()
     lov_in = probs.numel() * 4 + lab4.numel() * 8
     with torch.no_grad():
-        t_lf = _gpu_ms(lambda: lov(probs, lab4), 10)
+        t_lf = _gpu_ms(lambda: lov(probs, lab4), 20)
     pg = probs.clone().requires_grad_(True)
 
     def lov_fb():
         pg.grad = None
         lov(pg, lab4).backward()
 
-    t_lfb = _gpu_ms(lov_fb, 10)
+    t_lfb = _gpu_ms(lov_fb, 20)
     out["lovasz_fwd"] = entry(t_lf, lov_in, what="LovaszLoss() forward on [4,16,512,512] probabilities (16 segments of 1 M sorted; sort-bound, the "
                                                  "fraction counts the inputs once)")
     out["lovasz_fwd_bwd"] = entry(t_lfb, lov_in + probs.numel() * 4, what="same, forward + backward")
@@ -215,7 +220,8 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     ys = [torch.rand((2, c5, n + o, n + o), device=dev, generator=g) * 0.9 + 0.05 for o in offs]
     alg5 = sum(y.numel() for y in ys) * 4 + c5 * n * n * 4               # 1 946 157 056
     for name, red in (("cfg5_gmean", "gmean"), ("cfg5_mean", "mean")):
-        t_one = _gpu_ms(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=red, reduction=red, align_corners=False), 20)
+        t_one = _gpu_ms(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=red, reduction=red, align_corners=False), 40,
+                        ramp_ms=100.0)
         t_lit = _gpu_ms(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=red) for y in ys], offs, reduction=red,
                                                        align_corners=False), 10)
         out[name] = entry(t_one, alg5, what=f"multiscale 0.75/1.0/1.25 + fliplr on 4096x4096, C=4, {red}: tta.ms_flips_image_deaugment (one pass)",
@@ -905,15 +911,15 @@ def main():
                 "avg_launch_ms": round(launch_ms, 5),
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(slicer)
-        if world == 1 and not use_dist and not args.no_secondary:
+        if world == 1 and not use_dist and not args.no_secondary:     # (before the CPU baseline: the GPU is still at its clocks)
             del batch_tensors, _keep
             torch.cuda.empty_cache()
             try:
                 line["config"]["secondary"] = secondary_workloads(dev, with_cpu=not args.no_cpu_baseline)
             except Exception as exc:  # noqa: BLE001  (the headline line must survive a failing side measurement)
                 line["config"]["secondary"] = {"error": repr(exc)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(slicer)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -135,7 +135,13 @@ class ImageSlicer:
             yield self._lazy_tile(image, box, border_type, value), coords
 
     def split(self, image, border_type=BORDER_CONSTANT, value=0) -> List[np.ndarray]:
-        """Pad the whole image by the margins once, return the N tiles as views of the padded copy."""
+        """Pad the whole image by the margins once, return the N tiles as views of the padded copy.
+
+        ``border_type`` takes OpenCV's codes like the reference (which forwards them to ``cv2.copyMakeBorder``,
+        inference/tiles.py:161-182).  Only ``BORDER_CONSTANT`` (0, the default) is pinned against the reference's outputs; the
+        other codes are mapped to the numpy padding mode with OpenCV's documented semantics (1 replicate -> "edge", 2 reflect ->
+        "symmetric", 3 wrap, 4 reflect_101 -> "reflect") and are NOT parity-tested: OpenCV is not available where the goldens are
+        generated."""
         assert image.shape[0] == self.image_height
         assert image.shape[1] == self.image_width
         padded = _pad2d(image, self.margin_top, self.margin_bottom, self.margin_left, self.margin_right, border_type, value)

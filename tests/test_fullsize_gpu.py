@@ -219,6 +219,9 @@ def test_cfg4_losses_32x16x512x512(dev, full):
     fused.backward()
     grad = xg.grad.cpu().numpy()
     sub, sums = SY.digest(grad, 37, 41)
+    # absolute 1e-5 (north_star) holds trivially for O(1e-9) gradient elements and is asserted; the relative bound is the test
+    # that bites: 2e-4 = the spread of correct fp32 evaluations of this chain on 1.3e8 elements (see tests/test_losses_gpu.py)
+    assert float(np.abs(sub - full["cfg4_grad_sub"]).max()) <= TOL
     np.testing.assert_allclose(sub, full["cfg4_grad_sub"], rtol=2e-4, atol=1e-12)
     assert sums[1] == pytest.approx(float(full["cfg4_grad_sums"][1]), rel=1e-5)
     # fp64 oracle on the same tensors (a quarter of the batch at a time for the focal sums)

@@ -102,7 +102,13 @@ def test_golden_gradients(case, dev):
     crit = GRAD_CASES[case["fn"]](_L(), dict(case["kwargs"]))
     x = _t(GL[case["inputs"][0]], dev).requires_grad_(True)
     crit(x, _t(GL[case["inputs"][1]], dev)).backward()
-    np.testing.assert_allclose(x.grad.cpu().numpy(), GL[case["output"]], rtol=1e-4, atol=1e-7)
+    got, want = x.grad.cpu().numpy(), GL[case["output"]]
+    # north_star's bound is ABSOLUTE ("within 1e-5 of reference"); gradients of a mean-reduced loss are O(1 / N), so it holds with
+    # orders of magnitude to spare and is asserted first.  The RELATIVE bound below is the real test: 1e-4 is what separates two
+    # correct fp32 evaluations of these chains (the reference's own fp32 autograd differs from its fp64 run by up to ~5e-5
+    # relative on the small elements: sigmoid / log-softmax saturate there and every op rounds once).
+    assert np.abs(got - want).max() <= 1e-5
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-7)
 
 
 # --------------------------------------------------------------------------------------- larger shapes vs the oracle

@@ -2,6 +2,7 @@ import os, sys, torch
 sys.path.insert(0, "/root/repo")
 from pytorch_toolbelt_amd import losses as L, _native as N
 dev = torch.device("cuda:0")
+pads = [torch.empty(int(os.environ.get("PAD_GB", "0")) << 30, dtype=torch.uint8, device=dev)] if os.environ.get("PAD_GB") else []
 g = torch.Generator(device=dev).manual_seed(0)
 x = torch.randn((32, 16, 512, 512), device=dev, generator=g)
 labels = torch.randint(0, 16, (32, 512, 512), device=dev, generator=g)
