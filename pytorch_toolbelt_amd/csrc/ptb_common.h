@@ -32,6 +32,7 @@ extern int g_chunk_rows;    // 16 | 32 | 64
 extern int g_force_scalar;  // 0 | 1
 extern int g_loss_grid_cap;  // workgroups per loss-kernel launch
 extern int g_ms_tiled;       // 0 | 1: LDS-staged multiscale kernel
+extern int g_ms_tile_w;      // 64 | 128: output tile width of the fused multiscale kernel
 extern int g_focal_pk_grid;  // workgroups of the packed-fp32 fused loss forward
 extern int g_focal_pk;       // 0 | 1: A/B of the packed-fp32 instance of the fused loss forward
 extern int g_fused_pix2;     // 0 | 1: A/B of the fused loss forward with 2 pixels per lane

@@ -221,6 +221,11 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_focal_pk = value;
         return PTB_OK;
     }
+    if (key == 15) {
+        if (value != 64 && value != 128) return PTB_EINVAL;
+        g_ms_tile_w = value;
+        return PTB_OK;
+    }
     if (key == 13) {
         if (value < 1) return PTB_EINVAL;
         g_focal_pk_grid = value;

@@ -318,11 +318,17 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
         return make_float4(s.x / div, s.y / div, s.z / div, s.w / div);
     }
     if (INNER == 2 && NV == 2) {
-        // gmean of exactly two views: exp(mean(log a, log b)) = sqrt(a) * sqrt(b) -- two quarter-rate instructions per element
-        // instead of three (2 x v_log + v_exp), and no reciprocal / multiplies; sqrt of each factor first, so tiny probabilities
-        // whose product would underflow stay exact to rounding
-        return make_float4(__builtin_amdgcn_sqrtf(x[0].x) * __builtin_amdgcn_sqrtf(x[1].x), __builtin_amdgcn_sqrtf(x[0].y) * __builtin_amdgcn_sqrtf(x[1].y),
-                           __builtin_amdgcn_sqrtf(x[0].z) * __builtin_amdgcn_sqrtf(x[1].z), __builtin_amdgcn_sqrtf(x[0].w) * __builtin_amdgcn_sqrtf(x[1].w));
+        // gmean of exactly two views: exp(mean(log a, log b)) = sqrt(a b) -- ONE quarter-rate instruction per element instead of
+        // three (2 x v_log + v_exp).  The product is formed as (a 2^64) b and the root scaled back by 2^-32, which keeps every
+        // pair of probabilities down to ~1e-29 each exact to rounding; a wave that holds a product outside [2^-100, 2^120) --
+        // vanishing probabilities, or inputs that are no probabilities at all -- takes sqrt(a) sqrt(b) instead (never on sane data).
+        const float S = 0x1p64f, Si = 0x1p-32f, lo = 0x1p-100f, hi = 0x1p120f;
+        const float4 t = make_float4(x[0].x * S * x[1].x, x[0].y * S * x[1].y, x[0].z * S * x[1].z, x[0].w * S * x[1].w);
+        const bool odd = !(t.x >= lo && t.x < hi && t.y >= lo && t.y < hi && t.z >= lo && t.z < hi && t.w >= lo && t.w < hi);
+        if (__any(odd))
+            return make_float4(__builtin_amdgcn_sqrtf(x[0].x) * __builtin_amdgcn_sqrtf(x[1].x), __builtin_amdgcn_sqrtf(x[0].y) * __builtin_amdgcn_sqrtf(x[1].y),
+                               __builtin_amdgcn_sqrtf(x[0].z) * __builtin_amdgcn_sqrtf(x[1].z), __builtin_amdgcn_sqrtf(x[0].w) * __builtin_amdgcn_sqrtf(x[1].w));
+        return make_float4(__builtin_amdgcn_sqrtf(t.x) * Si, __builtin_amdgcn_sqrtf(t.y) * Si, __builtin_amdgcn_sqrtf(t.z) * Si, __builtin_amdgcn_sqrtf(t.w) * Si);
     }
     if (INNER == 2) {   // gmean, branch-free (the run-time switch over all reductions costs more than the loads it sits between)
         // in the log2 domain: exp2(mean(log2 x)) == exp(mean(log x)) without the two constant multiplies per value
@@ -344,10 +350,17 @@ __device__ __forceinline__ float4 fz_inner(const float4 (&x)[NV], int nv, int op
 
 // (the mean / mean and gmean / gmean instances of the default tile height are pinned at 6 waves per SIMD: 80 VGPRs is an occupancy cliff, and a two-register
 // drift of the allocator -- 82 VGPRs, 5 waves -- cost them 7 %; the other instances keep whatever the allocator chooses)
-template <int NV, int INNER, int OUTER, int ALIGN, int TH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NV <= 2 && TH == 32 && ((INNER == 2 && OUTER == 2) || (INNER == 0 && OUTER == 0))) ? 6 : 1)))
+// TW = 128 (with TH = 16): the same 2048 output pixels per workgroup as the default 64 x 32 tile, but twice as wide -- the 16-byte
+// alignment slack of every window row and the taps' extra column are paid once per 128 instead of per 64 columns, and a row of
+// tiles is half as many source bytes, so the two halo rows a tile shares with the tile below it are still in the XCD's L2 when
+// that one runs (ptb_set_tunable key 15).
+template <int NV, int INNER, int OUTER, int ALIGN, int TH, int TW = 64>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NV <= 2 && ((TH == 32 && TW == 64) || (TH == 16 && TW == 128)) && ((INNER == 2 && OUTER == 2) || (INNER == 0 && OUTER == 0))) ? 6 : 1)))
 void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
-    constexpr int R = TH / 16;                          // output rows per thread (tile = 64 columns x TH rows)
+    constexpr int LX = TW / 4, RPP = 256 / LX;          // lanes across a tile row (4 columns each), output rows per pass of the workgroup
+    constexpr int R = TH / RPP;                         // output rows per thread (tile = TW columns x TH rows)
+    constexpr int FZ_T = TW, FZ_LC = TW == 128 ? 168 : ptb::FZ_LC, FZ_LP = TW == 128 ? 176 : ptb::FZ_LP;
+    static_assert(TH % RPP == 0 && R >= 1, "tile shape");
     constexpr int LR = TH == 64 ? FZ_LR : (TH == 32 ? FZ_LR32 : FZ_LR16);      // LDS window rows
     constexpr int FZ_U = NV <= 2 ? 3 : 2;   // window slots a lane has in flight at once (x NV views)
     __shared__ __attribute__((aligned(16))) float lds[LR * FZ_LP];
@@ -378,7 +391,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
         tyi = bid % tiles_y;
         p = bid / tiles_y;
     }
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x, lx = tid & (LX - 1), ly = tid / LX;
     const int ox0 = txi * FZ_T, oy0 = tyi * TH, ox = ox0 + 4 * lx;
     const bool col_ok = ox < a.wout;
     float acc[R][4];
@@ -400,7 +413,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
             float4 xs[R][NV];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int oy = oy0 + ly + 16 * j;
+                const int oy = oy0 + ly + RPP * j;
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     xs[j][k] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -447,7 +460,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
             for (int m = 0; m < 4; ++m) tx[m] = ctap[4 * lx + m];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int oy = min(oy0 + ly + 16 * j, a.hout - 1);   // rows past the bottom edge: computed from the last row, never stored
+                const int oy = min(oy0 + ly + RPP * j, a.hout - 1);   // rows past the bottom edge: computed from the last row, never stored
                 const Taps ty = taps<ALIGN>(oy, a.sh[s], hin, a.align_corners);
                 const float* l0 = lds + min(ty.i0 - r_lo, LR - 1) * FZ_LP - c_lo;
                 const float* l1 = lds + min(ty.i1 - r_lo, LR - 1) * FZ_LP - c_lo;
@@ -471,7 +484,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
     if (!col_ok) return;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-        const int oy = oy0 + ly + 16 * j;
+        const int oy = oy0 + ly + RPP * j;
         if (oy < a.hout) {
             float r[4];
 #pragma unroll
@@ -718,7 +731,7 @@ extern "C" int ptb_ms_deaug_reduce_strip(const float* const* inputs, const int* 
 // gmean / fused mean / plain merge: row-major 434 / 412 / 224 us; strips of 2: 467 / 446 / 240, 4: 456 / 431 / 232, 8: 468 / 446 / 239,
 // 16: 428 / 399 / 217, 64 (= whole tile rows: every XCD walks its own contiguous eighth of the tiles row-major): 414 / 391 / 211.
 // Keeping neighbours on one L2 pays; narrow strips cost more in DRAM page locality than the vertical halo reuse returns.
-namespace ptb { int g_ms_tile_rows = 32; int g_ms_strip = 64; }
+namespace ptb { int g_ms_tile_rows = 32; int g_ms_strip = 64; int g_ms_tile_w = 128; }   // key 15: 128 (default) = 128 x 16 output tiles when the windows fit (NV <= 2), 64 = 64 x g_ms_tile_rows
 
 template <int NV, int INNER, int TH>
 static void launch_fz_th(const FzArgs& a, float* out, unsigned blocks, hipStream_t st) {
@@ -729,6 +742,21 @@ static void launch_fz_th(const FzArgs& a, float* out, unsigned blocks, hipStream
     else if (a.op_outer >= PTB_RED_GMEAN) PTB_FZ(1);
     else PTB_FZ(0);
 #undef PTB_FZ
+}
+
+template <int NV, int INNER, int TH>
+static void launch_fz_wide(const FzArgs& a, float* out, hipStream_t st) {   // 128 x TH tiles
+    const long long tiles = (long long)a.planes * ((a.hout + TH - 1) / TH) * ((a.wout + 127) / 128);
+    FzArgs b = a;
+    b.strip = 64;
+    b.total_tiles = tiles;
+    const dim3 grid((unsigned)(8 * ((tiles + 7) / 8))), block(256);
+#define PTB_FZW(OUTER) do { if (a.align_corners) hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 1, TH, 128>), grid, block, 0, st, b, out); \
+                            else hipLaunchKernelGGL((ms_flip_reduce_kernel<NV, INNER, OUTER, 0, TH, 128>), grid, block, 0, st, b, out); } while (0)
+    if (a.op_outer == PTB_RED_GMEAN) PTB_FZW(2);
+    else if (a.op_outer >= PTB_RED_GMEAN) PTB_FZW(1);
+    else PTB_FZW(0);
+#undef PTB_FZW
 }
 
 template <int NV, int INNER>
@@ -751,6 +779,7 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
     if (planes == 0) return PTB_OK;
     if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     FzArgs a{};
+    bool wide_ok = true;
     for (int k = 0; k < V; ++k) {
         if (views[k] < 0 || views[k] > 7) return PTB_EINVAL;
         if (views[k] & 1) return PTB_EUNSUPPORTED;           // transposing views: not combined with multiscale here
@@ -774,6 +803,7 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
         const int th_ = g_ms_tile_rows;
         const int need_r = std::min((int)ceilf(th_ * a.sh[s]) + 3, hs[s]), need_c = std::min((int)ceilf(FZ_T * a.sw[s]) + 6, ws[s] + 3);
         if (need_r > (th_ == 16 ? FZ_LR16 : (th_ == 32 ? FZ_LR32 : FZ_LR)) || need_c > FZ_LC) return PTB_EUNSUPPORTED;
+        wide_ok = wide_ok && std::min((int)ceilf(16 * a.sh[s]) + 3, hs[s]) <= FZ_LR16 && std::min((int)ceilf(128 * a.sw[s]) + 6, ws[s] + 3) <= 168;
     }
     a.n = n; a.nviews = V; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners;
     a.op_outer = reduction; a.op_inner = inner_reduction;
@@ -786,6 +816,14 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
     if (planes * ((hout + th - 1) / th) * ((wout + FZ_T - 1) / FZ_T) > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int inner = inner_reduction == PTB_RED_GMEAN ? 2 : (inner_reduction > PTB_RED_GMEAN ? 1 : 0);
+    if (g_ms_tile_w == 128 && wide_ok && V <= 2 && planes * ((hout + 15) / 16) * ((wout + 127) / 128) <= 0x7fffffffLL) {
+        // (128 x 32 tiles measured slower: 363 / 520 us mean / gmean at cfg5 against 337 / 385 us for 128 x 16)
+        if (V == 1) launch_fz_wide<1, 0, 16>(a, out, st);
+        else if (inner == 2) launch_fz_wide<2, 2, 16>(a, out, st);
+        else if (inner) launch_fz_wide<2, 1, 16>(a, out, st);
+        else launch_fz_wide<2, 0, 16>(a, out, st);
+        return check_launch();
+    }
     if (V == 1) launch_fz<1, 0>(a, out, th, st);
     else if (V == 2) { if (inner == 2) launch_fz<2, 2>(a, out, th, st); else if (inner) launch_fz<2, 1>(a, out, th, st); else launch_fz<2, 0>(a, out, th, st); }
     else { if (inner == 2) launch_fz<4, 2>(a, out, th, st); else if (inner) launch_fz<4, 1>(a, out, th, st); else launch_fz<4, 0>(a, out, th, st); }

@@ -418,6 +418,60 @@ def test_ms_flips_fused_equals_composition_at_scale(dev):
         tta.ms_image_augment(ys[1], [8], mode="area")
 
 
+@pytest.mark.parametrize("shape", [(1024, 1024), (500, 700), (330, 260)])
+def test_ms_flips_tile_shapes_are_bit_identical(shape, dev):
+    """The fused flips + multiscale kernel gives the same bits whatever output tile a workgroup owns (64 x 32, 64 x 16, 64 x 64, the
+    wide 128 x 16 of ptb_set_tunable(15, 128)): a pixel's arithmetic never depends on the tiling; ragged borders included."""
+    from pytorch_toolbelt_amd import _native as N
+
+    tta = _tta()
+    lib = N.load()
+    H, W = shape
+    offs = [(-(H // 4) // 4 * 4, -(W // 4) // 4 * 4), 0, ((H // 4) // 4 * 4, (W // 4) // 4 * 4)]
+    g = torch.Generator(device=dev).manual_seed(3)
+    try:
+        for group, V in (("fliplr", 2), ("flipud", 2)):
+            ys = [torch.rand((V * 2, 3, H + (o[0] if o else 0), W + (o[1] if o else 0)), device=dev, generator=g) * 0.9 + 0.05 for o in offs]
+            for inner, outer, ac in (("gmean", "gmean", False), ("mean", "mean", True), ("mean", "gmean", False)):
+                outs = {}
+                for name, (w_, rows) in {"64x32": (64, 32), "64x16": (64, 16), "64x64": (64, 64), "128x16": (128, 32)}.items():
+                    assert lib.ptb_set_tunable(15, w_) == 0 and lib.ptb_set_tunable(6, rows) == 0
+                    before = N.calls
+                    outs[name] = tta.ms_flips_image_deaugment(ys, offs, group=group, inner_reduction=inner, reduction=outer, align_corners=ac)
+                    assert N.calls == before + 1
+                comp = tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac)
+                assert float((outs["64x32"] - comp).abs().max()) <= 2e-6
+                for name, o in outs.items():
+                    assert torch.equal(o, outs["64x32"]), (group, inner, outer, name)
+    finally:
+        lib.ptb_set_tunable(15, 128)
+        lib.ptb_set_tunable(6, 32)
+
+
+def test_ms_flips_gmean_of_extreme_values(dev):
+    """The two-view gmean inside the fused kernel is sqrt(a b) with a scaled product; pairs whose product leaves the safe range --
+    vanishing probabilities, zeros, values that are no probabilities -- take sqrt(a) sqrt(b): same result as the composed path's
+    exp(mean(log)) to rounding, no underflow to 0, no overflow to inf."""
+    tta = _tta()
+    offs = [-64, 0, 64]
+    g = torch.Generator(device=dev).manual_seed(8)
+    ys = [torch.rand((2, 2, 256 + o, 256 + o), device=dev, generator=g) * 0.9 + 0.05 for o in offs]
+    for y in ys:      # sprinkle extremes over whole regions (a wave takes the exact branch as soon as one of its pairs is odd)
+        y[0, :, 10:40, 20:90] = 1e-30
+        y[1, :, 10:40, 20:90] = 3e-31
+        y[:, :, 100:120, 5:60] = 1e-38
+        y[0, :, 150:170, 100:160] = 0.0
+        y[:, :, 200:220, 30:80] = 4e19
+    fused = tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction="gmean", reduction="mean", align_corners=False)
+    comp = tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys], offs, reduction="mean", align_corners=False)
+    assert torch.isfinite(fused).all()
+    torch.testing.assert_close(fused, comp, rtol=2e-5, atol=1e-37)
+    # a region that is 1e-38 in both views of the same-size scale comes out as 1e-38 from the inner gmean (not 0): check it directly
+    same = torch.full((2, 1, 64, 64), 1e-38, device=dev)
+    inner = tta.ms_flips_image_deaugment([same], [0], group="fliplr", inner_reduction="gmean", reduction="mean")
+    assert float(inner.min()) > 0.9e-38 and float(inner.max()) < 1.1e-38
+
+
 # ------------------------------------------------------------------ stacks longer than 8, reductions with their eps argument
 GT3 = load_golden("tta3.npz")
 

@@ -36,6 +36,9 @@ from pytorch_toolbelt_amd import _native as N  # noqa: E402
 if os.environ.get("PTB_MS_TILE_ROWS"):
     assert N.load().ptb_set_tunable(6, int(os.environ["PTB_MS_TILE_ROWS"])) == 0
     print("fused multiscale kernel: output tiles of 64 x", os.environ["PTB_MS_TILE_ROWS"])
+if os.environ.get("PTB_MS_TILE_W"):
+    assert N.load().ptb_set_tunable(15, int(os.environ["PTB_MS_TILE_W"])) == 0
+    print("fused multiscale kernel: output tile width", os.environ["PTB_MS_TILE_W"])
 if os.environ.get("PTB_MS_STRIP"):
     assert N.load().ptb_set_tunable(9, int(os.environ["PTB_MS_STRIP"])) == 0
     print("fused multiscale kernel: XCD-aware tile order, strip width", os.environ["PTB_MS_STRIP"], "(0 = row-major)")
