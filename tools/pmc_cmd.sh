@@ -12,6 +12,6 @@ OUT=/root/repo/gpurun_out/pmc
 mkdir -p $OUT
 i=0
 for G in "${GROUPS_[@]}"; do
-  rocprofv3 --pmc $G --kernel-trace -d $OUT/${TAG}_$i -o run -- "$@" > $OUT/${TAG}_$i.log 2>&1
+  timeout 400 rocprofv3 --pmc $G --kernel-trace -d $OUT/${TAG}_$i -o run -- "$@" > $OUT/${TAG}_$i.log 2>&1
   i=$((i+1))
 done
