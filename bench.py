@@ -600,6 +600,8 @@ def main():
         per_cand, chosen = rep["by_candidate"], rep["chosen"]
         torch.cuda.empty_cache()      # (the first pool was still referenced from here while the search ran)
         placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen, "steps_run_by_the_search": search_steps,
+                     # (for tools/profile_report.py: the probe step, the first-allocation timing and the search all come before the chosen pool)
+                     "steps_before_the_chosen_pool": search_steps + 1 + (60 + 3 * args.steps if first_alloc is not None else 0),
                      "note": "untimed set-up: candidate pools for the model outputs are allocated side by side, a few steps are run on each, the "
                              "fastest is kept and the rest freed -- which device memory backs the pool decides 10-15 % of the loop's speed"}
     # power management: keep a GPU that has been idle (a fresh box, the seconds this process spent importing torch) busy for a

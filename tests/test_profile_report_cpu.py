@@ -41,7 +41,7 @@ def test_report_separates_the_placement_search(tmp_path):
         r = subprocess.run([sys.executable, str(ROOT / "tools" / "profile_report.py"), "t00"], env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-2000:]
         text = (out / "t00_kernel_stats.md").read_text()
-        assert "The first 50 belong to the placement search" in text
+        assert "The first 50 belong to the untimed set-up before the chosen pool" in text
         assert "average 460.00 us" in text and "average **400.00 us**" in text
     finally:
         if backup is not None:

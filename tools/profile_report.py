@@ -68,12 +68,13 @@ def main():
         skip = 0
         try:
             line = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-            skip = 5 * int(line["config"]["placement"].get("steps_run_by_the_search", 0))
+            pl = line["config"]["placement"]
+            skip = 5 * int(pl.get("steps_before_the_chosen_pool", pl.get("steps_run_by_the_search", 0)))
         except Exception:
             pass
         head, rest = full[:skip], full[skip:] or full
         lines += ["", f"Dominant kernel `{short(band[0])}`: {len(seq)} launches, of which {len(full)} are 1024-row launch groups of the headline "
-                      f"configuration (5 per image).  The first {len(head)} belong to the placement search of the untimed set-up (candidate pools: "
+                      f"configuration (5 per image).  The first {len(head)} belong to the untimed set-up before the chosen pool (probe step, first-allocation timing, placement search over candidate pools: "
                       f"average {sum(head) / max(len(head), 1) / 1e3:.2f} us, min {min(head or [0]) / 1e3:.2f}, max {max(head or [0]) / 1e3:.2f}); the {len(rest)} "
                       f"after it (ramp, warm-up, timed steps, variants -- all on the chosen pool): average **{sum(rest) / len(rest) / 1e3:.2f} us**, "
                       f"as in bench.py's roofline block."]
