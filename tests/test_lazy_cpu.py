@@ -1,0 +1,121 @@
+"""CPU: the protocol of the lazy de-augmentation handle (inference/_lazy.py) and the held-batch guard of the deferred mergers
+(inference/tiles.py:_check_held) -- the parts of the drop-in path that are plain Python and need no GPU.  The kernels behind them are
+covered in tests/test_dropin_gpu.py."""
+import copy
+import gc
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from pytorch_toolbelt_amd.inference import _lazy as L
+
+
+def _mean_views(src, views, code):          # stands in for ptb_deaug_reduce: chunk-major [V*B, ...] -> mean over the views
+    V = len(views)
+    return src.view(V, src.shape[0] // V, *src.shape[1:]).mean(0)
+
+
+def _handle(src=None):
+    src = torch.randn(8, 2, 4, 4) if src is None else src
+    return L.LazyDeaugment(src, "fliplr", (0, 4), 1, _mean_views), src
+
+
+def test_metadata_does_not_evaluate_and_everything_else_does():
+    h, src = _handle()
+    before = L.evaluations
+    assert isinstance(h, torch.Tensor) and type(h) is L.LazyDeaugment
+    assert h.shape == (4, 2, 4, 4) and h.dtype == torch.float32 and h.device.type == "cpu" and len(h) == 4 and h.dim() == 4
+    assert h.numel() == 128 and h.size(1) == 2 and not h.requires_grad and h.is_contiguous() and not h.is_cuda
+    assert L.evaluations == before and h._value is None
+    want = _mean_views(src, (0, 4), 1)
+    assert torch.equal(h + 1, want + 1) and L.evaluations == before + 1        # evaluated once ...
+    assert torch.equal(h * 2, want * 2) and torch.equal(h[1], want[1]) and L.evaluations == before + 1   # ... and cached
+    assert torch.equal(torch.cat([h, h]), torch.cat([want, want])) and torch.equal(torch.stack((h,)), torch.stack((want,)))
+    assert torch.equal(torch.add(input=h, other=h), want * 2)
+    assert np.array_equal(np.asarray(h), want.numpy()) and np.array_equal(h.numpy(), want.numpy())
+    assert h.to(torch.float64).dtype == torch.float64 and float(h.sum()) == pytest.approx(float(want.sum()))
+    assert torch.equal(torch.nn.functional.interpolate(h, scale_factor=2), torch.nn.functional.interpolate(want, scale_factor=2))
+    assert "tensor(" in repr(h) and h.data_ptr() == h._evaluate().data_ptr()
+    assert type(copy.deepcopy(h)) is torch.Tensor and torch.equal(pickle.loads(pickle.dumps(h)), want)
+
+
+def test_in_place_operations_act_on_the_cached_value():
+    h, src = _handle()
+    want = _mean_views(src, (0, 4), 1)
+    h.mul_(3.0)
+    h.add_(1.0)
+    assert torch.equal(h, want * 3 + 1)
+    h[0] = 0.0
+    assert float(h[0].abs().max()) == 0.0
+
+
+def test_take_source_is_what_a_merger_fuses_and_the_handle_stays_usable():
+    h, src = _handle()
+    taken = h._take_source()
+    assert taken is not None and taken[0] is src and taken[1] == "fliplr" and taken[2] == (0, 4) and taken[3] == 1
+    assert torch.equal(h, _mean_views(src, (0, 4), 1))      # evaluated later from the same source
+    assert h._take_source() is None                         # ... after which there is nothing left to fuse
+
+
+def test_an_edited_source_is_reported_not_used():
+    h, src = _handle()
+    src.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        h + 0
+    with pytest.raises(RuntimeError, match="modified in place"):
+        h._take_source()
+    with torch.inference_mode():                            # tensors without a version counter are taken as they are
+        s2 = torch.randn(8, 2, 4, 4)
+        h2 = L.LazyDeaugment(s2, "fliplr", (0, 4), 1, _mean_views)
+        assert torch.equal(h2 * 1, _mean_views(s2, (0, 4), 1))
+
+
+def test_pending_sources_are_bounded():
+    old = L._BUDGET
+    try:
+        src = torch.randn(8, 2, 4, 4)
+        L._BUDGET = L._pending_bytes + 3 * src.numel() * 4
+        hs = [L.LazyDeaugment(src, "fliplr", (0, 4), 1, _mean_views) for _ in range(6)]
+        assert [x._value is not None for x in hs] == [True, True, True, False, False, False]   # the oldest were evaluated to make room
+        pending = L._pending_bytes
+        del hs
+        gc.collect()
+        assert L._pending_bytes == pending - 3 * src.numel() * 4
+    finally:
+        L._BUDGET = old
+
+
+def test_maybe_lazy_only_takes_inference_shaped_gpu_calls():
+    x = torch.randn(8, 2, 4, 4)
+    assert L.maybe_lazy(x, "fliplr", (0, 4), 1, _mean_views) is None            # CPU tensor: evaluated on the spot (and refused downstream)
+    prev = L.set_enabled(False)
+    try:
+        assert not L.enabled()
+    finally:
+        L.set_enabled(prev)
+
+
+def test_held_batch_guard():
+    from pytorch_toolbelt_amd.inference.tiles import _check_held, _held_entry
+
+    pool = torch.zeros(6, 2, 4, 4)
+    a, b = pool[0:4], pool[2:6]
+    held = [(a, "coords", None, 0, 0) + _held_entry(a)]
+    with pytest.raises(RuntimeError, match="occupies memory of an earlier batch"):
+        _check_held(held, b, _held_entry(b), False, "TileMerger(defer=True)")
+    with pytest.raises(RuntimeError, match="occupies memory"):               # the same tensor again: a refilled static buffer looks like this
+        _check_held(held, a, _held_entry(a), False, "TileMerger(defer=True)")
+    c = torch.zeros(4, 2, 4, 4)
+    _check_held(held, c, _held_entry(c), True, "TileMerger(defer=True)")      # disjoint memory, nothing edited: fine
+    a.mul_(2.0)
+    _check_held(held, c, _held_entry(c), False, "TileMerger(defer=True)")     # versions are only compared when a launch is due ...
+    with pytest.raises(RuntimeError, match="held batch 0 .* modified in place"):
+        _check_held(held, c, _held_entry(c), True, "TileMerger(defer=True)")
+    with torch.inference_mode():
+        d = torch.zeros(4, 2, 4, 4)
+        entry = _held_entry(d)
+        assert entry[2] is None                                               # no version counter: accepted, never compared
+        d.add_(1.0)
+        _check_held([(d,) + entry], c, _held_entry(c), True, "x")
