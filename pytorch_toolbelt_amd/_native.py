@@ -156,7 +156,14 @@ def require_device(t, what):
         )
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device):
+    """The current HIP stream of ``device`` as a ``void*`` (the raw-handle query: 0.3 us instead of 4 us for a Stream object)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _vp(_raw_stream(idx if idx is not None else torch.cuda.current_device()))
     return _vp(torch.cuda.current_stream(device).cuda_stream)
 
 

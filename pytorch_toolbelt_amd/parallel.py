@@ -183,6 +183,20 @@ def deferred_geometry(plan, rank: int, crops: np.ndarray, image_height: int):
     return final, sorted(int(c) for c in cuts)
 
 
+def _held_entry(batch):
+    from .inference.tiles import _held_entry as f
+
+    globals()["_held_entry"] = f      # (bound on first use: parallel.py must stay importable without the inference package loaded first)
+    return f(batch)
+
+
+def _check_held(*a):
+    from .inference.tiles import _check_held as f
+
+    globals()["_check_held"] = f
+    return f(*a)
+
+
 class _DeferredBand:
     """One rank's band merged without an accumulator: the C band plan of ``TileMerger(defer=True)`` over the rank's own tiles
     (csrc/ptb_bandplan.hip), in the rank's issue order and local row coordinates.  ``out`` [C, rows, W] receives ``sum / norm``
@@ -277,6 +291,12 @@ class _DeferredBand:
         band.n_ranges = len(ranges)
         band.ranges = np.ascontiguousarray(np.array(ranges, dtype=np.int64).reshape(-1))
         band.fast = {}            # (group, reduction) -> (views array, number of views, reduction code)
+        # ctypes views made once (a .ctypes.data_as per call costs ~3 us each)
+        band.rects_p = band.rects.ctypes.data_as(N._i64p) if band.n_sends else None
+        band.event_p = band.ready_event.cuda_event if band.n_sends else None
+        band.all_packed_ref = ctypes.byref(band.all_packed)
+        band.recv_rects_p = band.recv_rects.ctypes.data_as(N._i64p) if band.n_recvs else None
+        band.ranges_p = band.ranges.ctypes.data_as(N._i64p) if band.n_ranges else None
         return band
 
     def reset(self):
@@ -313,8 +333,6 @@ class _DeferredBand:
             varr = self._varr[key] = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
         per_tile = self.channels * self.th * self.tw
         dev = self.norm.device
-        from .inference.tiles import _check_held, _held_entry
-
         span = _held_entry(batch)
         due = any(self.pos <= last < self.pos + B for _y0, _y1, last in self.groups)
         _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
@@ -338,8 +356,6 @@ class _DeferredBand:
     def submit_fast(self, batch, coords_abs, key, views, code):
         """The common call with everything per-call already validated by the caller (a contiguous device tensor of a kernel dtype, an
         int64 [B, 4] array of the next planned crops): one array compare + ONE C call."""
-        import ctypes
-
         from . import _native as N
 
         B, pos = coords_abs.shape[0], self.pos
@@ -350,8 +366,6 @@ class _DeferredBand:
         if (pos + B > self.xy_abs.shape[1] or batch.shape != (B * n_views, self.channels, self.th, self.tw)
                 or not np.array_equal(coords_abs[:, :2], self.xy_abs_rows[pos:pos + B])):
             return None          # (the general path reports what is wrong)
-        from .inference.tiles import _check_held, _held_entry
-
         span = _held_entry(batch)
         due = False
         for _y0, _y1, last in self.groups:
@@ -365,8 +379,7 @@ class _DeferredBand:
         with N.on_device(dev):
             rc = N.load().ptb_band_plan_submit_rank(self.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype],
                                                     n_views, varr, code, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(),
-                                                    self.n_sends, self.rects.ctypes.data_as(N._i64p), self.send_ptrs, self.packed,
-                                                    self.ready_event.cuda_event if self.n_sends else None, ctypes.byref(self.all_packed),
+                                                    self.n_sends, self.rects_p, self.send_ptrs, self.packed, self.event_p, self.all_packed_ref,
                                                     N.stream_ptr(dev))
         N.bump()
         if rc < 0:
@@ -642,9 +655,8 @@ class ShardedTileMerger:
             raise RuntimeError("ShardedTileMerger.merge(): not all of this rank's tiles were integrated")
         # add the neighbours' partial sums, divide the rows that held partial sums: one C call (ptb_rect_add + ptb_merge_div_ex launches)
         with N.on_device(self.device):
-            rc = N.load().ptb_band_plan_finish_rank(d.handle, d.out.data_ptr(), d.norm.data_ptr(), d.n_recvs,
-                                                    d.recv_rects.ctypes.data_as(N._i64p) if d.n_recvs else None, d.recv_ptrs if d.n_recvs else None,
-                                                    d.n_ranges, d.ranges.ctypes.data_as(N._i64p) if d.n_ranges else None, N.stream_ptr(self.device))
+            rc = N.load().ptb_band_plan_finish_rank(d.handle, d.out.data_ptr(), d.norm.data_ptr(), d.n_recvs, d.recv_rects_p,
+                                                    d.recv_ptrs if d.n_recvs else None, d.n_ranges, d.ranges_p, N.stream_ptr(self.device))
         N.bump()
         N.check(rc, "ShardedTileMerger.merge (deferred band)")
         d.held = []
