@@ -226,6 +226,52 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
                                                        align_corners=False), 10)
         out[name] = entry(t_one, alg5, what=f"multiscale 0.75/1.0/1.25 + fliplr on 4096x4096, C=4, {red}: tta.ms_flips_image_deaugment (one pass)",
                           reference_call_sequence_ms=round(t_lit, 4))
+    # ---- SURVEY 8d secondary region, end to end: uint8 image -> (H2D) -> tiles + d4 augment -> model -> de-augment + integrate ->
+    # merge + crop -> (D2H), the README loop written literally (a new TileMerger per image, integrate_batch(d4_image_deaugment(y))),
+    # with a stand-in model that costs next to nothing (the config's "dummy UNet" would be 90 % of the time and is not this library)
+    ys_cpu = [y[:, :1].cpu() for y in ys] if with_cpu else None
+    del ys
+    torch.cuda.empty_cache()
+    try:
+        import numpy as np_
+
+        from pytorch_toolbelt_amd.inference.tiles import CudaTileMerger, ImageSlicer
+
+        image = torch.from_numpy(np_.random.default_rng(0).integers(0, 256, IMAGE, dtype=np_.uint8)).pin_memory()
+        tiler = ImageSlicer(IMAGE, TILE, STEP, weight="pyramid")
+        inv255 = [1.0 / 255.0] * 3
+
+        def stand_in_model(xb):        # [8 views * B, 3, 512, 512] -> [.., 4, 512, 512]: three channels passed through + their mean
+            yb = torch.empty((xb.shape[0], CHANNELS, TILE, TILE), device=dev)
+            yb[:, :3] = xb
+            torch.mean(xb, dim=1, out=yb[:, 3])
+            return yb
+
+        def e2e_image():
+            dimg = image.to(dev, non_blocking=True)
+            merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight)
+            for b0 in range(0, len(tiler.crops), BATCH):
+                xb = tiler.split_device(dimg, slice(b0, b0 + BATCH), augment="d4", scale=inv255, bias=[0.0] * 3)
+                merger.integrate_batch(tta.d4_image_deaugment(stand_in_model(xb)), tiler.crops[b0:b0 + BATCH])
+            return merger.merge_crop(tiler, argmax=True, dtype=torch.uint8).cpu()
+
+        with torch.no_grad():
+            for _ in range(3):
+                lab_img = e2e_image()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                lab_img = e2e_image()
+            t_e2e = (time.perf_counter() - t0) / 3
+        assert lab_img.shape == (IMAGE[0], IMAGE[1]) and int(lab_img.max()) < CHANNELS
+        out["e2e_5000_stand_in_model"] = {
+            "ms": round(t_e2e * 1e3, 2), "MP_s": round(IMAGE[0] * IMAGE[1] / 1e6 / t_e2e, 1),
+            "what": "wall clock per 5000x5000x3 uint8 image, host to host: pinned H2D of the image (75 MB), ImageSlicer.split_device (tiles + "
+                    "normalise + d4 augment, one launch per 8 tiles), a stand-in model (channel copy + mean: elementwise torch ops), the literal "
+                    "integrate_batch(tta.d4_image_deaugment(y), crops) on a new TileMerger per image, merge_crop(argmax, uint8) and its D2H (25 MB)"}
+        del image, lab_img
+    except Exception as exc:  # noqa: BLE001
+        out["e2e_5000_stand_in_model"] = {"error": repr(exc)}
     if with_cpu:
         from oracle import torch_chain as TC
 
@@ -248,7 +294,6 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
             out["lovasz_fwd"]["cpu_baseline"] = {"ms": round(t_lv * 1e3, 1), "cores": used, "kind": "port",
                                                  "sample": "1 of 4 images (16 classes: sort + cumsum + dot per class), x4"}
             if time.perf_counter() - t0 < cpu_budget_s:
-                ys_cpu = [y[:, :1].cpu() for y in ys]
                 t0 = time.perf_counter()
                 TC.ms_fliplr_deaugment(ys_cpu, offs, "gmean", align_corners=False)
                 t_c5 = (time.perf_counter() - t0) * c5
