@@ -222,10 +222,17 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     for name, red in (("cfg5_gmean", "gmean"), ("cfg5_mean", "mean")):
         t_one = _gpu_ms(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=red, reduction=red, align_corners=False), 40,
                         ramp_ms=100.0)
-        t_lit = _gpu_ms(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=red) for y in ys], offs, reduction=red,
-                                                       align_corners=False), 10)
+        lit = lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=red) for y in ys], offs, reduction=red, align_corners=False)  # noqa: E731
+        t_lit = _gpu_ms(lit, 20)
+        prev_lazy = tta.set_lazy_deaugment(False)
+        try:
+            t_eager = _gpu_ms(lit, 10)
+        finally:
+            tta.set_lazy_deaugment(prev_lazy)
         out[name] = entry(t_one, alg5, what=f"multiscale 0.75/1.0/1.25 + fliplr on 4096x4096, C=4, {red}: tta.ms_flips_image_deaugment (one pass)",
-                          reference_call_sequence_ms=round(t_lit, 4))
+                          literal_composition_ms=round(t_lit, 4), literal_composition_eager_ms=round(t_eager, 4),
+                          note="literal_composition = the reference's calls ms_image_deaugment([fliplr_image_deaugment(y_s) ...]): the lazy "
+                               "handles are fused into the same one-pass kernel; _eager = lazy handles off (3 de-augment launches + the merge)")
     # ---- SURVEY 8d secondary region, end to end: uint8 image -> (H2D) -> tiles + d4 augment -> model -> de-augment + integrate ->
     # merge + crop -> (D2H), the README loop written literally (a new TileMerger per image, integrate_batch(d4_image_deaugment(y))),
     # with a stand-in model that costs next to nothing (the config's "dummy UNet" would be 90 % of the time and is not this library)

@@ -340,6 +340,34 @@ def ms_image_deaugment(images: List[Tensor], size_offsets: List[Union[int, Tuple
     """Resize every scale's prediction back to ``rows - offset // stride`` (floor division, like the reference) and reduce."""
     if len(images) != len(size_offsets):
         raise ValueError("Number of images must be equal to number of size offsets")
+    fused = _ms_fuse_lazy(images, size_offsets, reduction, mode, align_corners, stride)
+    if fused is not None:
+        return fused
+    return _ms_image_deaugment(images, size_offsets, reduction, mode, align_corners, stride)
+
+
+def _ms_fuse_lazy(images, size_offsets, reduction, mode, align_corners, stride):
+    """The reference's composition for multiscale + flip TTA, ``ms_image_deaugment([<group>_image_deaugment(y_s) for s ...])``
+    (tta.py:287-316 feeding :645-689; what ``MultiscaleTTA`` around a flip-TTA model computes): when every scale arrives as a lazy
+    de-augmentation handle of the same flip group and reduction, nothing has been computed yet and the whole thing is ONE pass over
+    every view of every scale (``ptb_ms_flip_deaug_reduce``) instead of a launch per scale that writes a map and one more that
+    reads them back.  None: not that shape (the caller evaluates the handles and composes)."""
+    if mode != "bilinear" or _reduction_code(reduction) is None or not images or not all(type(t) is _lazy.LazyDeaugment for t in images):
+        return None
+    first = images[0]
+    if first._value is not None or any(t._value is not None or t._group != first._group or t._code != first._code for t in images):
+        return None
+    if any(v & 1 for v in first._views):
+        return None                       # transposing groups are not combined with multiscale in the one-pass kernel
+    taken = [t._take_source() for t in images]
+    if any(x is None for x in taken):
+        return None
+    _lazy.fused += len(images)
+    return ms_flips_image_deaugment([x[0] for x in taken], size_offsets, group=first._group, inner_reduction=V.REDUCTION_NAMES[first._code],
+                                    reduction=reduction, mode=mode, align_corners=align_corners, stride=stride)
+
+
+def _ms_image_deaugment(images, size_offsets, reduction, mode, align_corners, stride):
     code = _reduction_code(reduction)
     if code is not None and mode == "bilinear" and 1 <= len(images) <= 8:
         # fused path: every scale is sampled at the target grid and reduced in registers (one HIP launch)
@@ -389,8 +417,12 @@ def ms_flips_image_deaugment(images: List[Tensor], size_offsets: List[Union[int,
             out = _resample.ms_flip_reduce(list(images), views, sizes.pop(), align_corners, inner, outer)
             if out is not None:
                 return out
-    per_scale = [_image_deaugment(y, group, inner_reduction) for y in images]
-    return ms_image_deaugment(per_scale, size_offsets, reduction=reduction, mode=mode, align_corners=align_corners, stride=stride)
+    prev = _lazy.set_enabled(False)       # (the composed path wants the maps themselves: no handles that would come straight back here)
+    try:
+        per_scale = [_image_deaugment(y, group, inner_reduction) for y in images]
+    finally:
+        _lazy.set_enabled(prev)
+    return _ms_image_deaugment(per_scale, size_offsets, reduction, mode, align_corners, stride)
 
 
 def _resize(x: Tensor, size, mode, align_corners):

@@ -240,8 +240,14 @@ def test_cfg5_multiscale_fliplr_gmean_4096(dev, full, align_corners):
 
     offs = [-1024, 0, 1024]
     ys = [SY.synth_torch((2, 4, 4096 + o, 4096 + o), 5000 + i, "unit", device=dev) for i, o in enumerate(offs)]
-    per_scale = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
-    out = tta.ms_image_deaugment(per_scale, offs, reduction="gmean", mode="bilinear", align_corners=align_corners)
+    from pytorch_toolbelt_amd.inference import _lazy
+
+    prev = _lazy.set_enabled(False)      # the composed path first: call by call, the flip-reduced maps go through HBM
+    try:
+        per_scale = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
+        out = tta.ms_image_deaugment(per_scale, offs, reduction="gmean", mode="bilinear", align_corners=align_corners)
+    finally:
+        _lazy.set_enabled(prev)
     assert out.shape == (1, 4, 4096, 4096)
     got = out.cpu().numpy()
     _digest_check(full, f"cfg5_ac{int(align_corners)}", got)
@@ -254,6 +260,11 @@ def test_cfg5_multiscale_fliplr_gmean_4096(dev, full, align_corners):
     before = N.calls
     fused = tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction="gmean", reduction="gmean", align_corners=align_corners)
     assert N.calls == before + 1, "the fused flips + multiscale kernel did not run"
+    # ... and the reference's literal composition with lazy handles on is that same single launch
+    before = N.calls
+    literal = tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys], offs, reduction="gmean", mode="bilinear",
+                                     align_corners=align_corners)
+    assert N.calls == before + 1 and torch.equal(literal, fused), "the literal multiscale + flip composition was not fused"
     fz = fused.cpu().numpy()
     _digest_check(full, f"cfg5_ac{int(align_corners)}", fz)
     err = float(np.abs(fz - want).max())

@@ -29,6 +29,18 @@ def native():
     lib.ptb_set_tunable(1, 0)
 
 
+def _composed(fn):
+    """Evaluate ``fn()`` with lazy de-augmentation off: the reference's call-by-call composition (the comparison partner of the
+    fused kernels; with lazy handles on, the same calls would be fused into the one-pass kernel themselves)."""
+    from pytorch_toolbelt_amd.inference import _lazy
+
+    prev = _lazy.set_enabled(False)
+    try:
+        return fn()
+    finally:
+        _lazy.set_enabled(prev)
+
+
 def _tta():
     from pytorch_toolbelt_amd.inference import tta
 
@@ -403,8 +415,13 @@ def test_ms_flips_fused_equals_composition_at_scale(dev):
         ys = [torch.rand((V, 4, N_ + o, N_ + o), device=dev) * 0.9 + 0.05 for o in offs]
         for inner, outer, ac in (("gmean", "gmean", False), ("mean", "mean", True)):
             fused = tta.ms_flips_image_deaugment(ys, offs, group=group, inner_reduction=inner, reduction=outer, align_corners=ac)
-            comp = tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac)
+            comp = _composed(lambda: tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac))
             assert float((fused - comp).abs().max()) <= 2e-6
+            # the same composition written with lazy handles on IS the one-pass kernel (row-preserving groups): one launch, same bits
+            from pytorch_toolbelt_amd import _native as N
+            before = N.calls
+            lit = tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac)
+            assert N.calls == before + 1 and torch.equal(lit, fused), (group, inner)
     ys = [torch.rand((8, 2, 64 + o, 64 + o), device=dev) * 0.9 + 0.05 for o in (-16, 0, 16)]
     comp = tta.ms_image_deaugment([tta.d4_image_deaugment(y) for y in ys], [-16, 0, 16])
     assert torch.allclose(tta.ms_flips_image_deaugment(ys, [-16, 0, 16], group="d4"), comp)
@@ -439,7 +456,7 @@ def test_ms_flips_tile_shapes_are_bit_identical(shape, dev):
                     before = N.calls
                     outs[name] = tta.ms_flips_image_deaugment(ys, offs, group=group, inner_reduction=inner, reduction=outer, align_corners=ac)
                     assert N.calls == before + 1
-                comp = tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac)
+                comp = _composed(lambda: tta.ms_image_deaugment([getattr(tta, f"{group}_image_deaugment")(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=ac))
                 assert float((outs["64x32"] - comp).abs().max()) <= 2e-6
                 for name, o in outs.items():
                     assert torch.equal(o, outs["64x32"]), (group, inner, outer, name)
@@ -463,7 +480,7 @@ def test_ms_flips_gmean_of_extreme_values(dev):
         y[0, :, 150:170, 100:160] = 0.0
         y[:, :, 200:220, 30:80] = 4e19
     fused = tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction="gmean", reduction="mean", align_corners=False)
-    comp = tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys], offs, reduction="mean", align_corners=False)
+    comp = _composed(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys], offs, reduction="mean", align_corners=False))
     assert torch.isfinite(fused).all()
     torch.testing.assert_close(fused, comp, rtol=2e-5, atol=1e-37)
     # the smallest normal probabilities survive the inner gmean (their product, 4e-76, is far below fp32): check it directly

@@ -59,11 +59,13 @@ if tries > 1:
     del cands, pads
     torch.cuda.empty_cache()
 for inner, outer in (("gmean", "gmean"), ("mean", "mean")):
+    prev = tta.set_lazy_deaugment(False)     # the composed sequence proper (with lazy handles on, these calls ARE the fused kernel)
     comp = timeit(lambda: tta.ms_image_deaugment([tta.fliplr_image_deaugment(y, reduction=inner) for y in ys], offs, reduction=outer, align_corners=False))
+    tta.set_lazy_deaugment(prev)
     fused = timeit(lambda: tta.ms_flips_image_deaugment(ys, offs, group="fliplr", inner_reduction=inner, reduction=outer, align_corners=False))
     print(f"cfg5 {inner}/{outer}: composed {comp:7.1f} us = {alg / comp / 1e6:5.2f} TB/s ({alg / comp / 8e6 * 100:4.1f} % of 8 TB/s) | "
           f"fused one pass {fused:7.1f} us = {alg / fused / 1e6:5.2f} TB/s ({alg / fused / 8e6 * 100:4.1f} %)")
-maps = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
+maps = [tta.fliplr_image_deaugment(y, reduction="gmean").clone() for y in ys]       # (real tensors, not lazy handles)
 plain = timeit(lambda: tta.ms_image_deaugment(maps, offs, reduction="gmean", align_corners=False))
 alg1 = sum(m.numel() for m in maps) * 4 + C * N_ * N_ * 4
 print(f"ms_image_deaugment alone (3 maps -> 1): {plain:7.1f} us = {alg1 / plain / 1e6:5.2f} TB/s of {alg1 / 1e6:.0f} MB")
