@@ -1011,10 +1011,16 @@ class TileMerger:
             if taken is not None:
                 source, _group, views, code = taken
                 _lazy.fused += 1
-                if self._defer_active and self._defer_fast(source, crop_coords, (_group, code), views, code):
+                if self._defer_active:
+                    if self._defer_fast(source, crop_coords, (_group, code), views, code):
+                        return
+                elif self._plan is not None and self._planned_fast(source, crop_coords, (_group, code), views, code):
                     return
                 return self._accumulate(self._prep(source), _coords_xy(crop_coords), list(views), code)
-        if self._defer_active and self._defer_fast(batch, crop_coords, None, None, N.RED_SUM):
+        if self._defer_active:
+            if self._defer_fast(batch, crop_coords, None, None, N.RED_SUM):
+                return
+        elif self._plan is not None and self._planned_fast(batch, crop_coords, None, None, N.RED_SUM):
             return
         self._accumulate(self._prep(batch), _coords_xy(crop_coords), None, N.RED_SUM)
 
@@ -1067,6 +1073,60 @@ class TileMerger:
                     held.pop(0)
         return True
 
+    def _planned_fast(self, batch, crop_coords, key, views, code):
+        """Planned (not deferred) mode, the common call -- a contiguous model output on this device for exactly the next planned
+        crops: everything constant per merger / per (group, reduction) is cached and the rest is one C call (``ptb_accumulate_planned``):
+        ~12 us of host time instead of ~40.  False: the general path decides (and reports)."""
+        plan = self._plan
+        if (plan is None or not plan.active or self._defer_active or self._eager_norm or type(crop_coords) is not np.ndarray or crop_coords.ndim != 2
+                or crop_coords.dtype != np.int64 or not batch.is_cuda or not batch.is_contiguous() or batch.requires_grad or self._window_edited()):
+            return False
+        dcode = N.DTYPE_CODES.get(batch.dtype)
+        B, pos = crop_coords.shape[0], plan.pos
+        if (dcode is None or B == 0 or batch.device != self._image.device or pos + B > plan.xy.shape[1]
+                or not np.array_equal(crop_coords, plan.crops4[pos:pos + B])):
+            return False
+        cache = self._fast_cache
+        ent = cache.get(key)
+        if ent is None:
+            ent = cache[key] = (N.int_array(list(views)) if views is not None else N.int_array([N.IDENT]), len(views) if views is not None else 1)
+        varr, n_views = ent
+        th, tw = self.weight.shape[1], self.weight.shape[2]
+        if batch.shape != (B * n_views, self.channels, th, tw) or self._image.dtype != torch.float32:
+            return False
+        if self._merged is None:
+            self._merged = torch.empty_like(self._image)
+        import ctypes
+
+        base = plan.xy.ctypes.data            # [2, N] int64, C order: row 0 = xs, row 1 = ys
+        xs = ctypes.cast(base + 8 * pos, N._i64p)
+        ys = ctypes.cast(base + 8 * (plan.xy.shape[1] + pos), N._i64p)
+        lib = N.load()
+        dev = self._image.device
+        fresh = self._fresh
+
+        def launch(fresh_ptr):
+            return lib.ptb_accumulate_planned(self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
+                                              batch.data_ptr(), dcode, n_views, varr, code, xs, ys, B, self.channels, th, tw, self.image_height,
+                                              self.image_width, fresh_ptr, _FRESH_ROWS, plan.remaining.ctypes.data, plan.done.ctypes.data,
+                                              N.stream_ptr(dev))
+
+        with N.on_device(dev):
+            rc = launch(fresh.ctypes.data if fresh.any() else None)
+            if rc == N.EFRESH:
+                N.fresh_fallbacks += 1
+                self._materialize()
+                rc = launch(None)
+        N.bump()
+        if rc == 0:
+            plan.pos = pos + B
+            self._log.append(plan.xy[:, pos:pos + B])
+            return True
+        if rc == N.PTB_EUNSUPPORTED:
+            return False                      # (nothing was launched: the general path takes this batch the ordinary way)
+        N.check(rc, "TileMerger.integrate_batch")
+        return False
+
     def integrate_batch_deaugment(self, batch: torch.Tensor, crop_coords, group: str = "d4", reduction="mean"):
         """Fused ``integrate_batch(tta.<group>_image_deaugment(batch, reduction), crop_coords)``.
 
@@ -1076,10 +1136,14 @@ class TileMerger:
         from .tta import DEAUGMENT_VIEWS, _reduction_code
 
         views = DEAUGMENT_VIEWS[group]
-        if self._defer_active and type(reduction) is str:
+        if (self._defer_active or self._plan is not None) and type(reduction) is str:
             code = _reduction_code(reduction)
-            if code is not None and self._defer_fast(batch, crop_coords, (group, code), views, code):
-                return
+            if code is not None:
+                if self._defer_active:
+                    if self._defer_fast(batch, crop_coords, (group, code), views, code):
+                        return
+                elif self._planned_fast(batch, crop_coords, (group, code), views, code):
+                    return
         if len(batch) != len(crop_coords) * len(views):
             raise ValueError("Number of images in batch does not correspond to number of coordinates x views")
         code = _reduction_code(reduction)
