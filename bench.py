@@ -487,8 +487,13 @@ def main():
     if not sharded:
         my_tiles = np.arange(n_tiles)
     else:
+        exchange = None
+        if os.environ.get("PTB_BENCH_EXCHANGE", "torch") == "rccl":      # A/B: the exchange posted from C as one ncclGroup (ptb_halo_exchange)
+            from pytorch_toolbelt_amd.parallel import RcclExchange
+
+            exchange = RcclExchange(dev)
         sharded_merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev, partition=partition,
-                                           defer=os.environ.get("PTB_BENCH_SHARDED_DEFER", "1") == "1")
+                                           defer=os.environ.get("PTB_BENCH_SHARDED_DEFER", "1") == "1", exchange=exchange)
         my_tiles = sharded_merger.tiles
     crops = slicer.crops[my_tiles]
     batches = [(b0, min(len(crops), b0 + BATCH)) for b0 in range(0, len(crops), BATCH)]

@@ -208,6 +208,18 @@ void ptb_band_plan_destroy(ptb_band_plan* plan);
  * ptb_band_plan_finish_rank: the end of a rank's image -- adds the n_recvs received rectangles of partial sums ({r0, r1, c0, c1} in
  * the plan's rows, packed [C][rows][cols] buffers) to `merged` and divides the n_ranges row ranges {r0, r1} that held partial sums by
  * `norm` [H][W] in place (launches only). */
+/* The exchange itself over RCCL, bound at run time (dlopen of the process's librccl: no link-time dependency).
+ * ptb_rccl_available: 1 when an RCCL library could be bound.  ptb_rccl_unique_id: 128 bytes produced on ONE rank and handed to the
+ * others by the job's own channel.  ptb_rccl_comm_init: collective over the nranks processes (HIP current device = the rank's GPU).
+ * ptb_halo_exchange: all outgoing (ptb_halo_pack'ed) and incoming rectangles of this rank -- contiguous fp32 buffers, element counts,
+ * peer ranks -- as ONE ncclGroup of ncclSend / ncclRecv on `stream` (every pair concurrently, each on its own xGMI link; stream-ordered,
+ * returns at once).  PTB_EUNSUPPORTED: no RCCL library; PTB_ELAUNCH: RCCL reported an error (text in ptb_last_hip_error()). */
+int ptb_rccl_available(void);
+int ptb_rccl_unique_id(void* id128);
+int ptb_rccl_comm_init(const void* id128, int nranks, int rank, void** comm);
+int ptb_rccl_comm_destroy(void* comm);
+int ptb_halo_exchange(void* comm, int n_sends, const float* const* send_bufs, const int64_t* send_counts, const int* send_peers, int n_recvs,
+                      float* const* recv_bufs, const int64_t* recv_counts, const int* recv_peers, ptb_stream_t stream);
 int64_t ptb_band_plan_create2(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
                               int final_lo, int final_hi, const int64_t* cuts, int ncuts, const int64_t* early, int n_early,
                               ptb_band_plan** out);

@@ -9,6 +9,7 @@ namespace ptb {
 
 // thread-local text of the last failing HIP call (ptb_last_hip_error)
 void set_hip_error(hipError_t e);
+void set_error_text(const char* text);   // the text ptb_last_hip_error() returns for PTB_ELAUNCH (non-HIP failures: RCCL)
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();

@@ -16,6 +16,7 @@ int g_band_rows = 64; // ptb_set_tunable key 11: 64-row work items (1024-thread 
 int g_ms_tiled = 1;
 
 void set_hip_error(hipError_t e) { g_last_error = hipGetErrorString(e); }
+void set_error_text(const char* text) { g_last_error = text ? text : ""; }
 
 // out[c][p] = (image[c][p] [+ extra[c][p] for p < extra_n]) / norm[p]; IEEE division, no eps clamp (uncovered pixels
 // give NaN like the reference).  Streaming elementwise: 16 B/lane, grid-stride; the norm float4 is reused across the

@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
+__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
            "ms_image_deaugment_strip"]
 
 
@@ -399,6 +399,75 @@ class _DeferredBand:
         return self.pos == self.xy_abs.shape[1]
 
 
+class RcclExchange:
+    """An RCCL communicator of this library's own for the halo exchange (``ptb_halo_exchange``: all of a rank's sends and receives as
+    one ncclGroup posted from C on a side stream), instead of ``torch.distributed.batch_isend_irecv``.  Collective: every rank of
+    ``group`` constructs it (rank 0 creates the unique id, ``torch.distributed`` carries it to the others).  One per process and
+    group is enough; hand it to every ``ShardedTileMerger(..., exchange=...)``."""
+
+    def __init__(self, device, group=None, dist=None):
+        import ctypes
+
+        from . import _native as N
+
+        if dist is None:
+            import torch.distributed as dist
+        lib = N.load()
+        if not lib.ptb_rccl_available():
+            raise RuntimeError("RcclExchange: no RCCL library could be bound (librccl.so.1)")
+        self.device = torch.device(device)
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            N.check(lib.ptb_rccl_unique_id(ident), "ptb_rccl_unique_id")
+        box = [ident.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = ctypes.create_string_buffer(box[0], 128)
+        comm = ctypes.c_void_p()
+        with N.on_device(self.device):
+            N.check(lib.ptb_rccl_comm_init(ident, self.world, self.rank, ctypes.byref(comm)), "ptb_rccl_comm_init")
+        self.comm = comm
+        self.stream = torch.cuda.Stream(device=self.device)       # the exchange runs here, beside the merge kernels
+
+    def post(self, sends, recvs, after_event=None):
+        """sends / recvs: [(tensor, peer rank in the group)].  Waits (on its own stream) for ``after_event`` -- or for everything
+        queued on the current stream so far -- then posts all transfers as one group.  ``wait()`` joins the current stream."""
+        import ctypes
+
+        from . import _native as N
+
+        cur = torch.cuda.current_stream(self.device)
+        if after_event is not None:
+            self.stream.wait_event(after_event)
+        else:
+            self.stream.wait_stream(cur)
+
+        def table(items):
+            n = len(items)
+            return ((ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t, _p in items]), (ctypes.c_int64 * max(n, 1))(*[t.numel() for t, _p in items]),
+                    (ctypes.c_int * max(n, 1))(*[int(p) for _t, p in items]))
+
+        sp, sc, sr = table(sends)
+        rp, rc_, rr = table(recvs)
+        with N.on_device(self.device):
+            rc = N.load().ptb_halo_exchange(self.comm, len(sends), sp, sc, sr, len(recvs), rp, rc_, rr, ctypes.c_void_p(self.stream.cuda_stream))
+        N.bump()
+        N.check(rc, "ptb_halo_exchange")
+        for t, _p in list(sends) + list(recvs):
+            t.record_stream(self.stream)
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def close(self):
+        from . import _native as N
+
+        if self.comm:
+            N.load().ptb_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
 class ShardedTileMerger:
     """Drop-in shaped like ``TileMerger`` for one rank of a sharded merge of ONE image.
 
@@ -410,7 +479,7 @@ class ShardedTileMerger:
     """
 
     def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=False,
-                 defer_rows=None, two_phase=True):
+                 defer_rows=None, two_phase=True, exchange=None):
         """``defer=True`` (opt-in, like ``TileMerger``): the rank's tiles are merged band by band straight from the model outputs
         (no accumulator).  The contract that comes with it: the batches are kept by reference and read by a LATER launch, so they
         must stay alive and unmodified until ``merge()`` (a reused output buffer or an in-place edit raises), and the tiles must
@@ -420,6 +489,7 @@ class ShardedTileMerger:
         self.dist = dist
         self.group = group
         self.two_phase = bool(two_phase)     # deferred plan: one early launch for the rows neighbours wait for + the rest (else: cut by cut)
+        self.exchange = exchange             # an RcclExchange: the halo exchange as one ncclGroup posted from C (default: torch.distributed p2p)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.ops = ops or _HipOps
@@ -596,6 +666,16 @@ class ShardedTileMerger:
         dist = self.dist
         ops = []
         d = self._deferred
+        if self.exchange is not None:
+            for k, (buf, (_dst, r0, r1, c0, c1)) in enumerate(zip(self._send_buf, self.sends)):
+                if d is None or not d.packed[k]:
+                    buf.copy_(self._rect(r0, r1, c0, c1))
+            all_packed_in_c = d is not None and d.n_sends and all(d.packed[k] for k in range(d.n_sends))
+            self.exchange.post([(buf, dst) for buf, (dst, *_r) in zip(self._send_buf, self.sends)],
+                               [(buf, src) for buf, (src, *_r) in zip(self._recv_buf, self.recvs)],
+                               after_event=d.ready_event if all_packed_in_c else None)
+            self._pending = [self.exchange]
+            return
         for k, (buf, (dst, r0, r1, c0, c1)) in enumerate(zip(self._send_buf, self.sends)):
             if d is None or not d.packed[k]:
                 buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)

@@ -118,3 +118,53 @@ def test_rect_add_and_partial_zero_fill():
     assert m._fresh[1:3, :4].sum() == 0 and m._fresh.sum() == m._fresh.size - 8
     full = m.image                           # the rest is zero-filled on the first public read
     assert float(full.sum()) == 2 * 64 * 64
+
+
+def test_halo_exchange_over_rccl_single_rank():
+    """ptb_halo_exchange (one ncclGroup of ncclSend / ncclRecv posted from C, RCCL bound at run time) with the only topology a
+    one-GPU box offers: a one-rank communicator sending two rectangles to itself.  Through the C ABI and through
+    parallel.RcclExchange (side stream, event hand-off).  More than one rank has never been run (no multi-GPU box in the pool)."""
+    import ctypes
+
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.parallel import RcclExchange
+
+    lib = N.load()
+    assert lib.ptb_rccl_available() == 1
+    dev = torch.device("cuda:0")
+    ident = ctypes.create_string_buffer(128)
+    assert lib.ptb_rccl_unique_id(ident) == 0 and any(ident.raw)
+    comm = ctypes.c_void_p()
+    assert lib.ptb_rccl_comm_init(ident, 1, 0, ctypes.byref(comm)) == 0 and comm.value
+    a, b = torch.randn((4, 64, 320), device=dev), torch.randn((4, 32, 128), device=dev)
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    ptrs = lambda ts: (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])            # noqa: E731
+    counts = lambda ts: (ctypes.c_int64 * len(ts))(*[t.numel() for t in ts])                # noqa: E731
+    peers = (ctypes.c_int * 2)(0, 0)
+    rc = lib.ptb_halo_exchange(comm, 2, ptrs([a, b]), counts([a, b]), peers, 2, ptrs([ra, rb]), counts([ra, rb]), peers, N.stream_ptr(dev))
+    assert rc == 0, lib.ptb_last_hip_error()
+    torch.cuda.synchronize()
+    assert torch.equal(ra, a) and torch.equal(rb, b)
+    assert lib.ptb_halo_exchange(comm, 0, None, None, None, 0, None, None, None, N.stream_ptr(dev)) == 0
+    assert lib.ptb_halo_exchange(None, 0, None, None, None, 0, None, None, None, N.stream_ptr(dev)) == -1
+    assert lib.ptb_rccl_comm_destroy(comm) == 0
+
+    class _One:
+        @staticmethod
+        def get_rank(group=None):
+            return 0
+
+        @staticmethod
+        def get_world_size(group=None):
+            return 1
+
+    ex = RcclExchange(dev, dist=_One)
+    src = torch.randn((4, 16, 256), device=dev)
+    dst = torch.zeros_like(src)
+    ev = torch.cuda.Event()
+    src.mul_(2.0)
+    ev.record()
+    ex.post([(src, 0)], [(dst, 0)], after_event=ev)
+    ex.wait()
+    assert torch.equal(dst, src)          # (the current stream waited for the side stream)
+    ex.close()
