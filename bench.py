@@ -340,7 +340,7 @@ def main_cfg5(args):
     if use_dist:
         dist.barrier()
     from pytorch_toolbelt_amd.inference import tta
-    from pytorch_toolbelt_amd.parallel import ms_image_deaugment_strip, ms_strip_plan
+    from pytorch_toolbelt_amd.parallel import ms_flips_image_deaugment_strip, ms_strip_plan
 
     n, C, V = 4096, 4, 2
     offs = [-n // 4, 0, n // 4]
@@ -357,9 +357,9 @@ def main_cfg5(args):
         # this rank's rows of every scale's (fliplr-augmented) model output: the strip the model would have produced here
         ys = [torch.rand((V, C, s1 - s0, h), device=dev, generator=g) * 0.9 + 0.05 for (s0, s1), h in zip(plan["src"], heights)]
 
-        def step():
-            maps = [tta.fliplr_image_deaugment(y, reduction="gmean") for y in ys]
-            return ms_image_deaugment_strip(maps, heights, plan["src"], plan["out"], (n, n), reduction="gmean", align_corners=False)
+        def step():      # the same one-pass kernel on this rank's rows (every view of every scale's strip read once)
+            return ms_flips_image_deaugment_strip(ys, heights, plan["src"], plan["out"], (n, n), group="fliplr", inner_reduction="gmean",
+                                                  reduction="gmean", align_corners=False)
 
     def sync():
         if use_dist:
@@ -396,10 +396,10 @@ def main_cfg5(args):
                                    "gmean / gmean, C=4 model outputs resident in HBM; " +
                                    ("one pass (tta.ms_flips_image_deaugment)" if world == 1 else
                                     f"output rows split over {world} ranks (parallel.ms_strip_plan: np.linspace rows, each rank holds the source rows "
-                                    "its taps touch), per rank 3 x fliplr_image_deaugment on its strips + ms_image_deaugment_strip; no collective"),
+                                    "its taps touch), per rank ONE launch of the one-pass kernel on its strips (ms_flips_image_deaugment_strip); no collective"),
                        "parallelism": "single GPU" if world == 1 else f"row strips over {world} ranks", "rank0_out_rows": [r0, r1],
                        "repeat_ms_per_step": [round(w / args.steps * 1e3, 4) for w in runs]},
-            "roofline": {"kernel": "ms_flip_reduce_kernel (one pass)" if world == 1 else "rank 0's step: fliplr de-augment launches + ms_reduce strip kernel",
+            "roofline": {"kernel": "ms_flip_reduce_kernel (one pass)" if world == 1 else "ms_flip_reduce_kernel on rank 0's row strip (one pass)",
                          "bound": "hbm", "achieved": round(my_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(my_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "algorithmic_bytes_per_launch": my_bytes, "avg_launch_ms": round(ms_per_step, 5)},

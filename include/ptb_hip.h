@@ -369,6 +369,15 @@ int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const in
                              int inner_reduction, float* out, int64_t planes, int hout, int wout, int align_corners, int reduction,
                              ptb_stream_t stream);
 
+/* One rank's rows of the same pass (BASELINE configs[4] over several GPUs: output row strips, no collective): inputs[s] holds rows
+ * src_row0[s] .. src_row0[s] + src_rows[s] - 1 of every view plane of scale s ([V * planes, src_rows[s], ws[s]]; hs_full[s] is the full
+ * height: the taps are those of the full-size call, so the strips of the result concatenate to it bit for bit); out receives rows
+ * out_row0 .. out_row0 + out_rows - 1 of the [planes, hout_full, wout] result.  PTB_EBOUNDS when a strip lacks a source row the taps of
+ * those output rows read; views that flip rows do not come in strips (PTB_EUNSUPPORTED). */
+int ptb_ms_flip_deaug_reduce_strip(const float* const* inputs, const int* hs_full, const int* ws, const int* src_row0, const int* src_rows,
+                                   int n, int V, const int* views, int inner_reduction, float* out, int64_t planes, int hout_full, int wout,
+                                   int out_row0, int out_rows, int align_corners, int reduction, ptb_stream_t stream);
+
 /* ================================= segmentation losses (pytorch_toolbelt.losses) =================================
  * logits [B, C, HW] fp32; targets are either labels int64 [B, HW] (one-hot is formed on the fly, never materialised)
  * or dense fp32 [B, C, HW]; exactly one of `labels` / `dense` is non-NULL.  Scalars are accumulated in fp64.

@@ -296,6 +296,12 @@ struct FzArgs {
     float inner_mul, outer_mul;
     int strip;                         // > 0: XCD-aware tile order, strips of this many tile columns (see the kernel); 0: row-major
     long long total_tiles;
+    // Row strips (one rank of a multi-GPU multiscale merge): the launch produces output rows oy_base .. oy_base + hout - 1 of a
+    // hout_full-row map from the source rows row0[s] .. row0[s] + hs[s] - 1 of every scale; h[s] stays the FULL height (the taps are
+    // those of the full-size call, so the strips of the result concatenate to it bit for bit).  Whole maps: oy_base = 0, row0 = 0,
+    // hs = h, hout_full = hout.  Views that flip rows do not come in strips.
+    int hs[MS_MAX], row0[MS_MAX];
+    int oy_base, hout_full;
 };
 
 // 4 consecutive de-augmented values of view `code` of a [h, w] plane at (row, col) (col % 4 == 0, w % 4 == 0)
@@ -401,14 +407,14 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
         for (int m = 0; m < 4; ++m) acc[j][m] = 0.f;
     for (int s = 0; s < a.n; ++s) {
         const int hin = a.h[s], win = a.w[s];
-        const long long plane_sz = (long long)hin * win, vstride = (long long)a.planes * plane_sz;
+        const long long plane_sz = (long long)a.hs[s] * win, vstride = (long long)a.planes * plane_sz;
         const float* src = a.in[s] + p * plane_sz;
         float v[R][4];
 #pragma unroll
         for (int j = 0; j < R; ++j)
 #pragma unroll
             for (int m = 0; m < 4; ++m) v[j][m] = 1.f;
-        if (hin == a.hout && win == a.wout) {
+        if (hin == a.hout_full && win == a.wout) {
             // same size: the reference skips F.interpolate (offset 0) -- reduce the views straight from registers
             float4 xs[R][NV];
 #pragma unroll
@@ -417,7 +423,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {
                     xs[j][k] = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (k < a.nviews && col_ok && oy < a.hout) xs[j][k] = fz_load(src + k * vstride, hin, win, oy, ox, (a.codes >> (3 * k)) & 7);
+                    if (k < a.nviews && col_ok && oy < a.hout) xs[j][k] = fz_load(src + k * vstride, a.hs[s], win, a.oy_base + oy - a.row0[s], ox, (a.codes >> (3 * k)) & 7);
                 }
             }
 #pragma unroll
@@ -427,7 +433,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
             }
         } else {
             const int oy_last = min(oy0 + TH, a.hout) - 1, ox_last = min(ox0 + FZ_T, a.wout) - 1;
-            const int r_lo = taps<ALIGN>(oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps<ALIGN>(oy_last, a.sh[s], hin, a.align_corners).i1;
+            const int r_lo = taps<ALIGN>(a.oy_base + oy0, a.sh[s], hin, a.align_corners).i0, r_hi = taps<ALIGN>(a.oy_base + oy_last, a.sh[s], hin, a.align_corners).i1;
             const int c_lo = taps<ALIGN>(ox0, a.sw[s], win, a.align_corners).i0 & ~3, c_hi = taps<ALIGN>(ox_last, a.sw[s], win, a.align_corners).i1;
             const int nr = min(r_hi - r_lo + 1, LR), nc = min(c_hi - c_lo + 1, FZ_LC);   // (the host only launches shapes that fit)
             // every lane takes 16-byte slots tid, tid + 256, ... of the window (row-major, q_per_row slots per row: all lanes busy,
@@ -446,7 +452,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
 #pragma unroll
                     for (int k = 0; k < NV; ++k) {
                         x[u][k] = make_float4(1.f, 1.f, 1.f, 1.f);
-                        if (k < a.nviews && slot < total) x[u][k] = fz_load(src + k * vstride, hin, win, r_lo + row[u], c_lo + 4 * qq[u], (a.codes >> (3 * k)) & 7);
+                        if (k < a.nviews && slot < total) x[u][k] = fz_load(src + k * vstride, a.hs[s], win, r_lo + row[u] - a.row0[s], c_lo + 4 * qq[u], (a.codes >> (3 * k)) & 7);
                     }
                 }
 #pragma unroll
@@ -461,7 +467,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
 #pragma unroll
             for (int j = 0; j < R; ++j) {
                 const int oy = min(oy0 + ly + RPP * j, a.hout - 1);   // rows past the bottom edge: computed from the last row, never stored
-                const Taps ty = taps<ALIGN>(oy, a.sh[s], hin, a.align_corners);
+                const Taps ty = taps<ALIGN>(a.oy_base + oy, a.sh[s], hin, a.align_corners);
                 const float* l0 = lds + min(ty.i0 - r_lo, LR - 1) * FZ_LP - c_lo;
                 const float* l1 = lds + min(ty.i1 - r_lo, LR - 1) * FZ_LP - c_lo;
                 float t[4][4];
@@ -771,10 +777,46 @@ static void launch_fz(const FzArgs& a, float* out, int th, hipStream_t st) {
     else launch_fz_th<NV, INNER, 64>(b, out, (unsigned)blocks, st);
 }
 
+static int ms_flip_impl(const float* const* inputs, const int* hs, const int* ws, const int* src_row0, const int* src_rows, int n, int V,
+                        const int* views, int inner_reduction, float* out, int64_t planes, int hout_full, int wout, int out_row0, int out_rows,
+                        int align_corners, int reduction, ptb_stream_t stream);
+
 extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* hs, const int* ws, int n, int V, const int* views,
                                         int inner_reduction, float* out, int64_t planes, int hout, int wout, int align_corners,
                                         int reduction, ptb_stream_t stream) {
+    return ms_flip_impl(inputs, hs, ws, nullptr, nullptr, n, V, views, inner_reduction, out, planes, hout, wout, 0, hout, align_corners, reduction, stream);
+}
+
+// One rank's rows of the same pass: inputs[s] = rows src_row0[s] .. src_row0[s] + src_rows[s] - 1 of scale s's [V * planes, hs_full[s], ws[s]]
+// views (every view plane holds the same row range); out = rows out_row0 .. out_row0 + out_rows - 1 of the [planes, hout_full, wout] result.
+// The strips must contain every source row the taps of those output rows touch (checked: PTB_EBOUNDS); row-flipping views are refused.
+extern "C" int ptb_ms_flip_deaug_reduce_strip(const float* const* inputs, const int* hs_full, const int* ws, const int* src_row0,
+                                              const int* src_rows, int n, int V, const int* views, int inner_reduction, float* out,
+                                              int64_t planes, int hout_full, int wout, int out_row0, int out_rows, int align_corners,
+                                              int reduction, ptb_stream_t stream) {
+    if (!src_row0 || !src_rows) return PTB_EINVAL;
+    return ms_flip_impl(inputs, hs_full, ws, src_row0, src_rows, n, V, views, inner_reduction, out, planes, hout_full, wout, out_row0, out_rows,
+                        align_corners, reduction, stream);
+}
+
+static Taps host_taps(int dst, float scale, int n_in, bool align_corners) {     // the device's taps(), evaluated on the host (same fp32 ops)
+    float src;
+    if (align_corners) src = scale * (float)dst;
+    else { src = scale * ((float)dst + 0.5f) - 0.5f; src = src < 0.f ? 0.f : src; }
+    Taps t;
+    t.i0 = std::min((int)src, n_in - 1);
+    t.i1 = t.i0 + (t.i0 < n_in - 1 ? 1 : 0);
+    t.l1 = 0.f; t.l0 = 0.f;
+    return t;
+}
+
+static int ms_flip_impl(const float* const* inputs, const int* hs, const int* ws, const int* src_row0, const int* src_rows, int n, int V,
+                        const int* views, int inner_reduction, float* out, int64_t planes, int hout_full, int wout, int out_row0, int out_rows,
+                        int align_corners, int reduction, ptb_stream_t stream) {
+    const int hout = hout_full;     // (the scales and the "same size" test are those of the full-size call)
     if (!inputs || !hs || !ws || !out || !views || n < 1 || n > MS_MAX || V < 1 || V > FZ_VMAX || planes < 0 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (out_row0 < 0 || out_rows < 0 || out_row0 + out_rows > hout_full) return PTB_EINVAL;
+    if (out_rows == 0) return PTB_OK;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || inner_reduction < PTB_RED_SUM || inner_reduction > PTB_RED_LOG1P) return PTB_EINVAL;
     if (planes == 0) return PTB_OK;
     if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
@@ -805,7 +847,19 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
         if (need_r > (th_ == 16 ? FZ_LR16 : (th_ == 32 ? FZ_LR32 : FZ_LR)) || need_c > FZ_LC) return PTB_EUNSUPPORTED;
         wide_ok = wide_ok && std::min((int)ceilf(16 * a.sh[s]) + 3, hs[s]) <= FZ_LR16 && std::min((int)ceilf(128 * a.sw[s]) + 6, ws[s] + 3) <= 168;
     }
-    a.n = n; a.nviews = V; a.planes = (int)planes; a.hout = hout; a.wout = wout; a.align_corners = align_corners;
+    a.n = n; a.nviews = V; a.planes = (int)planes; a.hout = out_rows; a.wout = wout; a.align_corners = align_corners;
+    a.hout_full = hout_full; a.oy_base = out_row0;
+    for (int s = 0; s < n; ++s) {
+        a.hs[s] = src_rows ? src_rows[s] : hs[s];
+        a.row0[s] = src_row0 ? src_row0[s] : 0;
+        if (!src_row0) continue;
+        if (a.codes & 0x492) return PTB_EUNSUPPORTED;          // bit 1 of some view: rows flipped -- such views do not come in strips
+        if (a.hs[s] < 1 || a.row0[s] < 0 || a.row0[s] + a.hs[s] > hs[s]) return PTB_EINVAL;
+        const bool same = hs[s] == hout && ws[s] == wout;
+        const int lo = same ? out_row0 : host_taps(out_row0, a.sh[s], hs[s], align_corners != 0).i0;
+        const int hi = same ? out_row0 + out_rows - 1 : host_taps(out_row0 + out_rows - 1, a.sh[s], hs[s], align_corners != 0).i1;
+        if (lo < a.row0[s] || hi >= a.row0[s] + a.hs[s]) return PTB_EBOUNDS;     // the strip lacks a row the taps read
+    }
     a.op_outer = reduction; a.op_inner = inner_reduction;
     a.inner_div = inner_reduction == PTB_RED_SUM ? 1.0f : (float)V;
     a.inner_mul = inner_reduction == PTB_RED_SUM ? 1.0f : ((V & (V - 1)) == 0 ? 1.0f / (float)V : 0.f);
@@ -813,10 +867,10 @@ extern "C" int ptb_ms_flip_deaug_reduce(const float* const* inputs, const int* h
     for (int s = 0; s < n; ++s) resized = resized || hs[s] != hout || ws[s] != wout;
     a.outer_mul = reduction == PTB_RED_SUM ? 1.0f : ((resized || reduction == PTB_RED_GMEAN || (n & (n - 1)) == 0) ? 1.0f / (float)n : 0.f);
     const int th = g_ms_tile_rows;
-    if (planes * ((hout + th - 1) / th) * ((wout + FZ_T - 1) / FZ_T) > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    if (planes * ((out_rows + th - 1) / th) * ((wout + FZ_T - 1) / FZ_T) > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const int inner = inner_reduction == PTB_RED_GMEAN ? 2 : (inner_reduction > PTB_RED_GMEAN ? 1 : 0);
-    if (g_ms_tile_w == 128 && wide_ok && V <= 2 && planes * ((hout + 15) / 16) * ((wout + 127) / 128) <= 0x7fffffffLL) {
+    if (g_ms_tile_w == 128 && wide_ok && V <= 2 && planes * ((out_rows + 15) / 16) * ((wout + 127) / 128) <= 0x7fffffffLL) {
         // (128 x 32 tiles measured slower: 363 / 520 us mean / gmean at cfg5 against 337 / 385 us for 128 x 16)
         if (V == 1) launch_fz_wide<1, 0, 16>(a, out, st);
         else if (inner == 2) launch_fz_wide<2, 2, 16>(a, out, st);

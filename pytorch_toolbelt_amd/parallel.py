@@ -23,7 +23,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan",
+__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
            "ms_image_deaugment_strip"]
 
 
@@ -879,4 +879,48 @@ def ms_image_deaugment_strip(strips, source_heights, src_rows, out_rows, out_siz
                                            N.stream_ptr(first.device))
     N.bump()
     N.check(rc, "ptb_ms_deaug_reduce_strip")
+    return out
+
+
+def ms_flips_image_deaugment_strip(strips, source_heights, src_rows, out_rows, out_size, group="fliplr", inner_reduction="mean",
+                                   reduction="mean", align_corners: bool = True):
+    """This rank's rows ``out_rows = (r0, r1)`` of ``tta.ms_flips_image_deaugment`` -- multiscale TTA whose every scale is itself
+    flip-augmented (BASELINE configs[4]) -- in ONE pass: ``strips[s]`` holds rows ``src_rows[s] = (s0, s1)`` of the model output of
+    scale s for the ``<group>_image_augment``-ed input (``[V*B, C, s1 - s0, w_s]``, chunk-major).  Same arithmetic as the full-size
+    call (the taps are computed against ``source_heights``), so the concatenated strips equal it bit for bit.  Groups whose views
+    flip rows (flipud, flips, d2) do not come in row strips: compose ``<group>_image_deaugment`` + ``ms_image_deaugment_strip`` there."""
+    import ctypes
+
+    from . import _native as N
+    from .inference.tta import DEAUGMENT_VIEWS, _reduction_code
+
+    views = DEAUGMENT_VIEWS[group]
+    inner, outer = _reduction_code(inner_reduction), _reduction_code(reduction)
+    if inner is None or outer is None:
+        raise NotImplementedError("the fused strip kernel takes string reductions")
+    V = len(views)
+    first = strips[0]
+    N.require_device(first, "multiscale TTA")
+    if first.shape[0] % V:
+        raise RuntimeError(f"Input batch size ({first.size(0)}) must be divisible by {V}.")
+    B, C = int(first.shape[0]) // V, int(first.shape[1])
+    ms = []
+    for m, (s0, s1) in zip(strips, src_rows):
+        N.require_device(m, "multiscale TTA")
+        if m.dim() != 4 or m.dtype != torch.float32 or m.shape[0] != V * B or m.shape[1] != C or m.shape[2] != s1 - s0:
+            raise ValueError("every strip must be float32 [V*B, C, s1 - s0, w_s]")
+        ms.append(m.contiguous())
+    r0, r1 = int(out_rows[0]), int(out_rows[1])
+    ho, wo = int(out_size[0]), int(out_size[1])
+    out = torch.empty((B, C, r1 - r0, wo), device=first.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
+    ptrs = (ctypes.c_void_p * len(ms))(*[m.data_ptr() for m in ms])
+    with N.on_device(first.device):
+        rc = N.load().ptb_ms_flip_deaug_reduce_strip(ptrs, N.int_array([int(h) for h in source_heights]), N.int_array([int(m.shape[3]) for m in ms]),
+                                                     N.int_array([int(s0) for s0, _ in src_rows]), N.int_array([int(s1 - s0) for s0, s1 in src_rows]),
+                                                     len(ms), V, N.int_array(list(views)), inner, out.data_ptr(), B * C, ho, wo, r0, r1 - r0,
+                                                     1 if align_corners else 0, outer, N.stream_ptr(first.device))
+    N.bump()
+    N.check(rc, "ptb_ms_flip_deaug_reduce_strip")
     return out

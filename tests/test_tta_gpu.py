@@ -350,6 +350,42 @@ def test_multiscale_row_strips_equal_the_full_result(world, align_corners, reduc
     assert torch.equal(torch.cat(pieces, dim=2), full)
 
 
+@pytest.mark.parametrize("world", [2, 4, 7])
+@pytest.mark.parametrize("align_corners", [True, False])
+@pytest.mark.parametrize("inner,outer", [("mean", "mean"), ("gmean", "gmean")])
+def test_flips_multiscale_row_strips_equal_the_full_result(world, align_corners, inner, outer, dev):
+    """BASELINE configs[4] over several GPUs with the ONE-PASS kernel: every rank reduces its strip of output rows from the row
+    strips of every view of every scale (`ptb_ms_flip_deaug_reduce_strip`); concatenated, the strips equal the single-GPU one-pass call
+    bit for bit (ragged sizes, four scales incl. the same-size one); a strip that lacks a row its taps read is refused, and so are
+    groups whose views flip rows."""
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.parallel import ms_flips_image_deaugment_strip, ms_strip_plan
+
+    torch.manual_seed(world)
+    H, W = 200, 264
+    offsets = [-48, 0, 52, 24]
+    ys = [torch.rand((2 * 2, 3, H + o, W + o), device=dev) * 0.9 + 0.05 for o in offsets]       # fliplr: 2 views x batch 2
+    full = tta.ms_flips_image_deaugment(ys, offsets, group="fliplr", inner_reduction=inner, reduction=outer, align_corners=align_corners)
+    heights = [y.shape[2] for y in ys]
+    plan = ms_strip_plan(heights, H, world, align_corners)
+    pieces = []
+    for entry in plan:
+        strips = [y[:, :, s0:s1].contiguous() for y, (s0, s1) in zip(ys, entry["src"])]
+        pieces.append(ms_flips_image_deaugment_strip(strips, heights, entry["src"], entry["out"], (H, W), group="fliplr", inner_reduction=inner,
+                                                     reduction=outer, align_corners=align_corners))
+    assert torch.equal(torch.cat(pieces, dim=2), full)
+    entry = plan[1]
+    short = [(s0 + 2, s1) for s0, s1 in entry["src"]]
+    strips = [y[:, :, s0:s1].contiguous() for y, (s0, s1) in zip(ys, short)]
+    with pytest.raises(RuntimeError, match="outside"):
+        ms_flips_image_deaugment_strip(strips, heights, short, entry["out"], (H, W), group="fliplr", inner_reduction=inner, reduction=outer,
+                                       align_corners=align_corners)
+    strips = [y[:, :, s0:s1].contiguous() for y, (s0, s1) in zip(ys, entry["src"])]
+    with pytest.raises(NotImplementedError):
+        ms_flips_image_deaugment_strip(strips, heights, entry["src"], entry["out"], (H, W), group="flipud", inner_reduction=inner, reduction=outer,
+                                       align_corners=align_corners)
+
+
 # ------------------------------------------------------------------ multiscale: nearest mode, gradients, flips fused per scale
 GT2 = load_golden("tta2.npz")
 
