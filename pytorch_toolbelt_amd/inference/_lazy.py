@@ -28,6 +28,7 @@ everything else is evaluated on the spot exactly as before.  ``tta.set_lazy_deau
 switch it off.
 """
 import os
+import threading
 import weakref
 from collections import OrderedDict
 
@@ -38,6 +39,7 @@ _ENABLED = os.environ.get("PTB_LAZY_DEAUG", "1") != "0"
 _BUDGET = int(os.environ.get("PTB_LAZY_DEAUG_BYTES", str(4 << 30)))
 _pending = OrderedDict()      # id(handle) -> (weakref, bytes of its source), creation order
 _pending_bytes = 0
+_lock = threading.RLock()     # the bookkeeping is shared by every thread that de-augments (weakref callbacks run wherever a handle dies)
 evaluations = 0               # handles that had to be evaluated by themselves (diagnostics / tests)
 fused = 0                     # handles a merger consumed through the fused path (diagnostics / tests)
 
@@ -62,16 +64,20 @@ def _source_version(t):
 
 def _forget(key):
     global _pending_bytes
-    ent = _pending.pop(key, None)
-    if ent is not None:
-        _pending_bytes -= ent[1]
+    with _lock:
+        ent = _pending.pop(key, None)
+        if ent is not None:
+            _pending_bytes -= ent[1]
 
 
 def _admit(handle, nbytes):
     """Register a new pending handle; evaluate the oldest ones while the sources kept alive exceed the budget."""
     global _pending_bytes
-    while _pending and _pending_bytes + nbytes > _BUDGET:
-        key, (ref, _n) = next(iter(_pending.items()))
+    while True:
+        with _lock:
+            if not _pending or _pending_bytes + nbytes <= _BUDGET:
+                break
+            key, (ref, _n) = next(iter(_pending.items()))
         old = ref()
         if old is None:
             _forget(key)
@@ -81,8 +87,9 @@ def _admit(handle, nbytes):
             except RuntimeError:  # its source was modified: that is for ITS user to hear about, not for this unrelated call
                 _forget(key)
     key = id(handle)
-    _pending[key] = (weakref.ref(handle, lambda _r, k=key: _forget(k)), nbytes)
-    _pending_bytes += nbytes
+    with _lock:
+        _pending[key] = (weakref.ref(handle, lambda _r, k=key: _forget(k)), nbytes)
+        _pending_bytes += nbytes
 
 
 # attribute getters / methods that only look at metadata the wrapper itself carries: answered without evaluating

@@ -298,6 +298,7 @@ _AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "1") != "0"
 _AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser in HBM once planned)
 _auto = __import__("collections").OrderedDict()   # key -> _AutoEntry
 _weight_sigs = {}        # id(weight array) -> (weakref, signature)
+_auto_lock = __import__("threading").RLock()   # mergers of several threads (one inference loop each) share the cache
 
 
 def set_auto_plan(flag: bool) -> bool:
@@ -357,14 +358,15 @@ class _AutoEntry:
 
 
 def _auto_entry(key, create=False):
-    ent = _auto.get(key)
-    if ent is None and create:
-        while len(_auto) >= _AUTO_MAX:
-            _auto.popitem(last=False)
-        ent = _auto[key] = _AutoEntry()
-    elif ent is not None:
-        _auto.move_to_end(key)
-    return ent
+    with _auto_lock:
+        ent = _auto.get(key)
+        if ent is None and create:
+            while len(_auto) >= _AUTO_MAX:
+                _auto.popitem(last=False)
+            ent = _auto[key] = _AutoEntry()
+        elif ent is not None:
+            _auto.move_to_end(key)
+        return ent
 
 
 class _Plan:

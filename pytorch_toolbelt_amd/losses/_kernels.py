@@ -93,6 +93,8 @@ def host_flag_slot():
     global _flag_ring, _flag_next
     if _flag_ring is None:
         _flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+    if len(_pending) >= 192:      # a slot must not come round again before its check has been read: drain the backlog first
+        _poll(block=True)
     _flag_next = (_flag_next + 1) % 256
     return _flag_ring[_flag_next:_flag_next + 1]
 
@@ -119,9 +121,12 @@ def region_workspace(device, C):
     need = int(N.load().ptb_region_workspace_bytes(C))
     if need < 0:
         return None
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, N._raw_stream(device.index) if N._raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < need:
+        if len(_workspaces) >= 64:            # (streams come and go: forget the oldest half; a workspace is recreated zeroed on demand)
+            for k in list(_workspaces)[:32]:
+                del _workspaces[k]
         ws = _workspaces[key] = torch.zeros(max(need, 1 << 16), dtype=torch.uint8, device=device)
     return ws
 
