@@ -83,9 +83,9 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
     }
     if (act) {
         float* o = a.merged + (long long)c * a.dst_chan_stride + pix;
-        if (partial) *reinterpret_cast<float4*>(o) = acc;
-        else *reinterpret_cast<float4*>(o) = make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z),
-                                                         __fdiv_rn(acc.w, nfull.w));   // tiles.py:346
+        if (partial) *reinterpret_cast<float4*>(o) = acc;          // (partial sums are read back soon: plain store)
+        else out_store4(o, make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z),
+                                       __fdiv_rn(acc.w, nfull.w)));   // tiles.py:346
     }
 }
 

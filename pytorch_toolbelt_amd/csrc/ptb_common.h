@@ -20,6 +20,21 @@ inline int check_launch() {
     return PTB_OK;
 }
 
+// Results that are written once and not read again by the same launch (merged maps, de-augmented tiles, augmented batches,
+// gradients): non-temporal 16-byte stores, so that hundreds of MB of output do not displace the lines the kernel still reads from
+// L2 / Infinity Cache.  -DPTB_NT_OUT=0 builds the plain-store variant for A/B runs (tools/build_variant.sh).
+#ifndef PTB_NT_OUT
+#define PTB_NT_OUT 1
+#endif
+__device__ __forceinline__ void out_store4(float* p, const float4 v) {
+#if PTB_NT_OUT
+    typedef float ptb_v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(ptb_v4f{v.x, v.y, v.z, v.w}, reinterpret_cast<ptb_v4f*>(p));
+#else
+    *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
 // Index of the wave inside its workgroup as a SCALAR: every lane of a wave computes the same threadIdx.x >> 6, but only through
 // readfirstlane does the compiler know it, and everything derived from it (grid-stride group index, image / plane offsets, base
 // addresses) then runs on the scalar unit and the loads take an SGPR base -- on the loss kernels that was 7 of 25 vector
@@ -34,6 +49,7 @@ extern int g_force_scalar;  // 0 | 1
 extern int g_loss_grid_cap;  // workgroups per loss-kernel launch
 extern int g_ms_tiled;       // 0 | 1: LDS-staged multiscale kernel
 extern int g_ms_tile_w;      // 64 | 128: output tile width of the fused multiscale kernel
+extern int g_nt_grad_stores; // 0 | 1: non-temporal gradient stores in the fused loss backward
 extern int g_focal_pk_grid;  // workgroups of the packed-fp32 fused loss forward
 extern int g_focal_pk;       // 0 | 1: A/B of the packed-fp32 instance of the fused loss forward
 extern int g_fused_pix2;     // 0 | 1: A/B of the fused loss forward with 2 pixels per lane

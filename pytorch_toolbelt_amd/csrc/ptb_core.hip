@@ -43,7 +43,11 @@ __global__ __launch_bounds__(256) void merge_div_kernel(const float* __restrict_
             }
             v4f o;
             o.x = __fdiv_rn(v.x, n.x); o.y = __fdiv_rn(v.y, n.y); o.z = __fdiv_rn(v.z, n.z); o.w = __fdiv_rn(v.w, n.w);
+#if PTB_NT_OUT
+            __builtin_nontemporal_store(o, &o4[c * ocs4 + i]);
+#else
             o4[c * ocs4 + i] = o;
+#endif
         }
     }
 }
@@ -225,6 +229,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
     if (key == 15) {
         if (value != 64 && value != 128) return PTB_EINVAL;
         g_ms_tile_w = value;
+        return PTB_OK;
+    }
+    if (key == 16) {
+        g_nt_grad_stores = value ? 1 : 0;
         return PTB_OK;
     }
     if (key == 13) {

@@ -115,7 +115,7 @@ __device__ __forceinline__ void load_px4(const float* p, int nv, bool vec, float
 }
 
 __device__ __forceinline__ void store_f32x4(float* p, const float* v, int nv) {
-    if (nv == 4 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    if (nv == 4 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) out_store4(p, make_float4(v[0], v[1], v[2], v[3]));
     else for (int m = 0; m < nv; ++m) p[m] = v[m];
 }
 __device__ __forceinline__ void store_u8x4(uint8_t* p, const uint8_t* v, int nv) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void ensemble_kernel(const EnsembleArgs a) {
             v = pre4<OPK>(v, a.op);
             s = t ? add4(s, v) : v;
         }
-        *reinterpret_cast<float4*>(a.out + 4 * i) = post4<OPK>(s, a.op, a.divisor);
+        out_store4(a.out + 4 * i, post4<OPK>(s, a.op, a.divisor));
     }
 }
 
@@ -121,7 +121,7 @@ __device__ __forceinline__ void ld_pix(const float* p, float* o) {
 }
 template <int PIX>
 __device__ __forceinline__ void st_pix(float* p, const float* v) {
-    if (PIX == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    if (PIX == 4) out_store4(p, make_float4(v[0], v[1], v[2], v[3]));
     else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
 }
 

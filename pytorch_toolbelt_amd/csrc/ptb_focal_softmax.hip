@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void focal_softmax_kernel(const FsmArgs fa, co
                     }
                 }
                 if (MODE == 0) { if (elem) store_px<PIX>(a.elem_out + off, out, G.ok); }
-                else if (final) store_px<PIX>(grad + off, out, G.ok);
+                else if (final) store_px_nt<PIX>(grad + off, out, G.ok);
             }
         };
         walk(false);

@@ -20,6 +20,7 @@ enum {
     SEG_MASK_FOCAL_TERM = 32,  // normalised focal: ignored elements contribute 0 to sums[1]
     SEG_ELEMWISE = 64,         // also write the per-element focal loss
     SEG_NO_TERM = 128,         // the caller will not read sums[1] (focal loss without normalized=True): kernels may skip it
+    SEG_NT_STORES = 256,       // (internal) non-temporal stores of the gradient
 };
 enum { PROB_SOFTMAX = 0, PROB_SIGMOID = 1, PROB_IDENTITY = 2 };
 
@@ -76,6 +77,21 @@ __device__ __forceinline__ void store_px(float* __restrict__ p, const float (&x)
     } else {
 #pragma unroll
         for (int k = 0; k < PIX; ++k) p[k] = x[k];
+    }
+}
+
+// streamed-once results (gradients): non-temporal stores, so that 0.5 GB of output does not displace what the kernel still reads
+template <int PIX>
+__device__ __forceinline__ void store_px_nt(float* __restrict__ p, const float (&x)[PIX], bool ok) {
+    if (!ok) return;
+    if constexpr (PIX == 4) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f{x[0], x[1], x[2], x[3]}, reinterpret_cast<v4f*>(p));
+    } else if constexpr (PIX == 2) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        __builtin_nontemporal_store(v2f{x[0], x[1]}, reinterpret_cast<v2f*>(p));
+    } else {
+        store_px<PIX>(p, x, ok);
     }
 }
 

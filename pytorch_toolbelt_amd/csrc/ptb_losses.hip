@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const SegArgs a, const f
                             out[k] = g1 * dL + k2 * df;
                         }
                     }
-                    store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                    store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
                 }
             }
         }
@@ -941,7 +941,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PIX == 4 &
                             else out[k] = Gc;
                         }
                     }
-                    store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+#ifndef PTB_STATS_BWD_NT
+#define PTB_STATS_BWD_NT 0
+#endif
+                    // (the pinned C <= 16 label instance keeps the plain store: the non-temporal one needs its 4 values in consecutive
+                    // registers, which costs that instance a 44-byte spill at 5 waves per SIMD)
+                    if constexpr (PIX == 4 && CREG == 16 && !DENSE && !PTB_STATS_BWD_NT) store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                    else store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
                 }
             }
         } else {
@@ -991,7 +997,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((PIX == 4 &
                         else out[k] = Gc;
                     }
                 }
-                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             }
         }
     }
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__(256) void seg_fused_bwd_kernel(const SegArgs a, con
                     else gx += Gc;
                     out[k] = gx;
                 }
-                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             }
         }
     }
@@ -1170,7 +1176,7 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_shared_kernel(const SegA
                     out[k] = gx;
                     redo[k] = redo[k] || (t && ps < 1e-36f);
                 }
-                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             }
         }
         if (G.ok) {   // exact rewrite of the elements the fast formulas cannot represent (never on sane logits)
@@ -1270,7 +1276,7 @@ __global__ __launch_bounds__(256, 3) void seg_fused_bwd_lean_kernel(const SegArg
                 out[k] = gx;
                 redo[k] = redo[k] || (t && ps < 1e-36f);
             }
-            if (c < C) store_px<4>(grad + base + (long long)c * a.HW, out, true);
+            if (c < C) { if (a.flags & SEG_NT_STORES) store_px_nt<4>(grad + base + (long long)c * a.HW, out, true); else store_px<4>(grad + base + (long long)c * a.HW, out, true); }
         }
         bool any_redo = false;
 #pragma unroll
@@ -1342,7 +1348,7 @@ __global__ __launch_bounds__(256) void seg_dense_bwd_lean_kernel(const SegArgs a
                 }
                 out[k] = ig ? 0.f : gx;
             }
-            store_px<4>(grad + off + u * 256, out, true);
+            store_px_nt<4>(grad + off + u * 256, out, true);
         }
     }
 }
@@ -1540,7 +1546,7 @@ __global__ __launch_bounds__(256) void softmax_focal_kernel(const SmfArgs a, con
                     const float gf = p * (df - dd[k]);
                     out[k] = g1 * gl + k2 * gf;
                 }
-                store_px<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
+                store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, G.ok);
             };
             if constexpr (CREG > 0) {
                 if (fast) {
@@ -1678,7 +1684,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIX == 2 ? 
             float out[PIX];
 #pragma unroll
             for (int k = 0; k < PIX; ++k) out[k] = T[c][k] - xr[c][k] * S[k];
-            store_px<PIX>(grad + base + (long long)c * a.HW, out, true);
+            store_px_nt<PIX>(grad + base + (long long)c * a.HW, out, true);
         }
     }
 }
@@ -1847,7 +1853,7 @@ __global__ __launch_bounds__(256, 3) void softmax_focal_lean_kernel(const SmfArg
                     const float gl = __builtin_fmaf(p, bce * df - dh[k], pt * pt * (hit ? -qs : ps));
                     out[k] = __builtin_fmaf(g1[k], gl, k2 * (p * (df - dd[k])));
                 }
-                if (c < C) store_px<4>(grad + base + (long long)c * a.HW, out, true);
+                if (c < C) store_px_nt<4>(grad + base + (long long)c * a.HW, out, true);
                 __builtin_amdgcn_sched_barrier(0);   // one class at a time (interleaving all 64 element chains spills)
             }
         }
@@ -1947,6 +1953,7 @@ __global__ __launch_bounds__(256) void region_epilogue_kernel(const EpiArgs a) {
 int g_loss_grid_cap = 0;  // 0 = per-kernel default; otherwise workgroups per launch (ptb_set_tunable key 4)
 int g_loss_prefetch = 0;   // ptb_set_tunable key 8: register double buffering in the fused loss forward (measured: no gain, 0.146 vs 0.141-0.145 ms)
 int g_smf_bwd_stash = 4;  // ptb_set_tunable key 7: 4 pixels per lane (251 VGPRs, 2 waves per SIMD) measured 0.372 ms fwd+bwd at cfg4, 2 pixels 0.54, the two-pass kernel 0.41-0.48
+int g_nt_grad_stores = 1;    // ptb_set_tunable key 16: non-temporal stores of the gradient in the fused backward (A/B: 333 -> 315 us fwd+bwd at cfg4; the other backward kernels always use them)
 int g_focal_pk_grid = 512;   // ptb_set_tunable key 13: workgroups of seg_focal_pk_kernel (2 per CU measured best: per-workgroup prologue / epilogue / slot atomics)
 int g_focal_pk = 1;       // ptb_set_tunable key 12 (2 = with register prefetch of the next pixel group): packed-fp32 / per-pixel-correction instance of the fused forward (seg_focal_pk_kernel); 0 = seg_fwd_lean_kernel
 int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
@@ -2234,6 +2241,7 @@ extern "C" int ptb_seg_fused_bwd(const float* logits, const int64_t* labels, con
     if (labels && prob == PROB_SOFTMAX) {
         const bool plain = g2 && !class_weights && !(flags & (SEG_HAS_IGNORE | SEG_HAS_ALPHA | SEG_REDUCED));
         if (plain && !g_force_scalar && HW % 256 == 0) {
+            if (g_nt_grad_stores) a.flags |= SEG_NT_STORES;
             const dim3 lgrid(grid_for_groups(HW / 256 * B, kGridStats));
             if (C <= 4) hipLaunchKernelGGL((seg_fused_bwd_lean_kernel<4>), lgrid, block, 0, s, a, coef, gI, gP, grad);
             else if (C <= 8) hipLaunchKernelGGL((seg_fused_bwd_lean_kernel<8>), lgrid, block, 0, s, a, coef, gI, gP, grad);

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void pw_fwd_kernel(const PwArgs a) {
 #pragma unroll
             for (int k = 0; k < PIX; ++k) pw_forward<KIND>(x[u][k], t[u][k], w, pw, a, s, l[k]);
             if (a.out) {
-                if (VEC) *reinterpret_cast<float4*>(a.out + i) = make_float4(l[0], l[PIX > 1 ? 1 : 0], l[PIX > 2 ? 2 : 0], l[PIX > 3 ? 3 : 0]);
+                if (VEC) out_store4(a.out + i, make_float4(l[0], l[PIX > 1 ? 1 : 0], l[PIX > 2 ? 2 : 0], l[PIX > 3 ? 3 : 0]));
                 else a.out[i] = l[0];
             }
         }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void pw_apply_kernel(const PwArgs a, const flo
         }
 #pragma unroll
         for (int k = 0; k < PIX; ++k) o[k] = pw_backward<KIND, LOSS>(x[k], t[k], w, pw, ge[k], k0, k1, a);
-        if (VEC) *reinterpret_cast<float4*>(a.out + i) = make_float4(o[0], o[PIX > 1 ? 1 : 0], o[PIX > 2 ? 2 : 0], o[PIX > 3 ? 3 : 0]);
+        if (VEC) out_store4(a.out + i, make_float4(o[0], o[PIX > 1 ? 1 : 0], o[PIX > 2 ? 2 : 0], o[PIX > 3 ? 3 : 0]));
         else a.out[i] = o[0];
     }
 }
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void soft_ce_kernel(const SceArgs a, const flo
                         const float p = x[c][k] * rz[k];
                         o[k] = gk[k] * ((1.f - a.eps) * (p - (lab[k] == c ? 1.f : 0.f)) + epsC * ((float)a.C * p - 1.f));
                     }
-                    if (PIX == 4) *reinterpret_cast<float4*>(grad + base + (long long)c * a.HW) = make_float4(o[0], o[PIX > 1 ? 1 : 0], o[PIX > 2 ? 2 : 0], o[PIX > 3 ? 3 : 0]);
+                    if (PIX == 4) out_store4(grad + base + (long long)c * a.HW, make_float4(o[0], o[PIX > 1 ? 1 : 0], o[PIX > 2 ? 2 : 0], o[PIX > 3 ? 3 : 0]));
                     else grad[base + (long long)c * a.HW] = o[0];
                 }
             }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
         }
         float* o = out + (p * hout + oy) * (long long)wout + 4 * q;
         if ((wout & 3) == 0) {
-            *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+            out_store4(o, make_float4(res[0], res[1], res[2], res[3]));
         } else {
 #pragma unroll
             for (int m = 0; m < 4; ++m) if (4 * q + m < wout) o[m] = res[m];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void ms_reduce_kernel(const MsArgs a, float* _
 #pragma unroll
         for (int m = 0; m < 4; ++m) res[m] = ms_post(acc[m], a.op, (float)a.n);
         float* o = out + (p * a.hout + oy) * (long long)a.wout + 4 * q;
-        if (vec_out) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+        if (vec_out) out_store4(o, make_float4(res[0], res[1], res[2], res[3]));
         else for (int m = 0; m < 4; ++m) if (4 * q + m < a.wout) o[m] = res[m];
     }
 }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void ms_reduce_tiled_kernel(const MsArgs a, fl
 #pragma unroll
     for (int m = 0; m < 4; ++m) res[m] = OPK == 2 ? ms_exp(acc[m] / (float)a.n) : ms_post(acc[m], a.op, (float)a.n);
     float* o = out + (p * a.hout + oy) * (long long)a.wout + ox;
-    if ((a.wout & 3) == 0 && ox + 3 < a.wout) *reinterpret_cast<float4*>(o) = make_float4(res[0], res[1], res[2], res[3]);
+    if ((a.wout & 3) == 0 && ox + 3 < a.wout) out_store4(o, make_float4(res[0], res[1], res[2], res[3]));
     else for (int m = 0; m < 4; ++m) if (ox + m < a.wout) o[m] = res[m];
 }
 
@@ -499,7 +499,7 @@ void ms_flip_reduce_kernel(const FzArgs a, float* __restrict__ out) {
                 else if (OUTER == 0) r[m] = a.outer_mul != 0.f ? acc[j][m] * a.outer_mul : acc[j][m] / (float)a.n;
                 else r[m] = ms_post(acc[j][m], a.op_outer, (float)a.n);
             }
-            *reinterpret_cast<float4*>(out + (p * a.hout + oy) * (long long)a.wout + ox) = make_float4(r[0], r[1], r[2], r[3]);
+            out_store4(out + (p * a.hout + oy) * (long long)a.wout + ox, make_float4(r[0], r[1], r[2], r[3]));
         }
     }
 }

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void stack_reduce_kernel(const float* __restri
         float r[W];
 #pragma unroll
         for (int k = 0; k < W; ++k) r[k] = post(s[k], op, (float)T, e);
-        if constexpr (VEC) *reinterpret_cast<float4*>(out + off) = make_float4(r[0], r[1 % W], r[2 % W], r[3 % W]);
+        if constexpr (VEC) out_store4(out + off, make_float4(r[0], r[1 % W], r[2 % W], r[3 % W]));
         else out[off] = r[0];
     }
 }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void scatter_chunk(const ViewArgs& a, int B, int b, i
                 const float4 x4 = ld16<true>(a.weight + off);
                 w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
             }
-            *reinterpret_cast<float4*>(a.dst + off) = w;
+            out_store4(a.dst + off, w);
         }
     }
     if (!any_t) return;
@@ -224,7 +224,7 @@ __device__ __forceinline__ void scatter_chunk(const ViewArgs& a, int B, int b, i
                 const float4 x4 = ld16<true>(a.weight + off);
                 w.x *= red_dpre(x4.x, a.op); w.y *= red_dpre(x4.y, a.op); w.z *= red_dpre(x4.z, a.op); w.w *= red_dpre(x4.w, a.op);
             }
-            *reinterpret_cast<float4*>(a.dst + off) = w;
+            out_store4(a.dst + off, w);
         }
     }
 }

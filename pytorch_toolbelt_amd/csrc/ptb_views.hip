@@ -57,7 +57,7 @@ __global__ __launch_bounds__(CH * 16) void view_plain_kernel(const ViewArgs a) {
     if (r < ch && 4 * q < cw) {
         float* o = a.dst + (long long)t * a.dst_tile_stride + (long long)c * a.dst_chan_stride +
                    (long long)(cy0 + r) * a.dst_row_stride + cx0 + 4 * q;
-        *reinterpret_cast<float4*>(o) = val;
+        out_store4(o, val);
     }
 }
 
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
             // last touch of a planned cell: the weighted sum is complete, so the merged value (tiles.py:346) is written
             // right away and the accumulator is never stored -- the separate merge pass over this cell disappears
             const long long off = (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
-            *reinterpret_cast<float4*>(a.merged + off) =
-                make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w));
+            out_store4(a.merged + off,
+                       make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w)));
         } else {
             *reinterpret_cast<float4*>(ip) = acc;
             if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
