@@ -541,7 +541,12 @@ int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabel
                    int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                    unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                    double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream);
-/* grad[pred layout] = coef[s] * grad_at_pixel * d(error)/d(pred); coef = DEVICE float[S]. */
+/* The scalar the modules return from seg_loss / fg_total (losses/lovasz.py:92-108, :110-140): per group the mean of seg_loss over
+ * the classes with fg_total > 0 (present_only = 1, classes="present") or over all classes (0; the hinge loss is C = 1), 0 when none
+ * is selected; then the mean over the groups.  loss_out = DEVICE float; coef_out = DEVICE float[groups*C] = d(loss)/d(seg_loss). */
+int ptb_lovasz_reduce(const double* seg_loss, const unsigned* fg_total, int groups, int C, int present_only, float* loss_out,
+                      float* coef_out, ptb_stream_t stream);
+/* grad[pred layout] = coef[s] * grad_at_pixel * d(error)/d(pred); coef = DEVICE float[S].  Every element of grad is written. */
 int ptb_lovasz_bwd(const float* pred, const int64_t* labels, const float* flabels, const float* coef,
                    const float* grad_at_pixel, float* grad, int B, int C, int64_t HW, int mode, int per_image,
                    int has_ignore, int64_t ignore_label, float ignore_value, ptb_stream_t stream);

@@ -235,6 +235,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_nt_grad_stores = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 17) {
+        g_rs_xcd_map = value ? 1 : 0;
+        return PTB_OK;
+    }
     if (key == 13) {
         if (value < 1) return PTB_EINVAL;
         g_focal_pk_grid = value;

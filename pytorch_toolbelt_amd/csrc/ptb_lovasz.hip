@@ -5,7 +5,8 @@
 // cumsums, a division, a first difference and a dot product -- a Python loop over classes with a host sync each
 // (`fg.sum() == 0`).  Here every (group, class) pair is one *segment* of a single pipeline:
 //   1. error kernel:   key = ~(order-preserving bits of the error) (ignored pixels get -inf so they sort last and contribute
-//      0), value = index<<1 | fg
+//      0), value = index<<1 | fg; it is also the histogram step of the first sort pass (the keys are in registers) and reads a
+//      pixel's int64 label once for all the classes it handles
 //   2. a hand-written segmented LSD radix sort for gfx950 (below): every segment is sorted by its 32-bit keys in four 8-bit
 //      passes; a pass = per-tile digit histograms (wave-private LDS counters), a scan over the tiles of every segment, and a
 //      stable scatter that ranks the 4096 keys of a tile with ballot-matched lane groups (no atomics where order matters), stages them by digit in LDS and writes every digit run coalesced (tile-major histograms, scanned in spans
@@ -39,34 +40,6 @@ struct LovArgs {
     int S;        // segments = groups * C
 };
 
-__device__ __forceinline__ void locate(const LovArgs& a, int s, long long i, long long& pred_off, long long& lab_off, int& c) {
-    const int j = s / a.C;
-    c = s % a.C;
-    const long long b = a.per_image ? j : i / a.HW;
-    const long long px = a.per_image ? i : i - b * a.HW;
-    pred_off = (b * a.C + c) * a.HW + px;
-    lab_off = b * a.HW + px;
-}
-
-// error, foreground bit, validity of element i of segment s
-__device__ __forceinline__ void error_of(const LovArgs& a, int s, long long i, float& e, unsigned& fg, bool& valid) {
-    long long po, lo;
-    int c;
-    locate(a, s, i, po, lo, c);
-    const float p = a.pred[po];
-    if (a.mode == LOVASZ_SOFTMAX) {
-        const long long lab = a.labels[lo];
-        valid = !(a.has_ignore && lab == a.ignore_label);
-        fg = lab == c ? 1u : 0u;
-        e = fabsf((float)fg - p);                         // lovasz.py:133
-    } else {
-        const float y = a.flabels[lo];
-        valid = !(a.has_ignore && y == a.ignore_value);
-        fg = y != 0.f ? 1u : 0u;
-        e = 1.0f - p * (2.0f * y - 1.0f);                 // lovasz.py:65-66
-    }
-}
-
 __device__ __forceinline__ unsigned ordered_bits(float e) {  // monotone float -> uint map (larger float => larger uint)
     const unsigned u = __float_as_uint(e);
     return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
@@ -75,26 +48,14 @@ __device__ __forceinline__ float from_ordered_bits(unsigned u) {
     return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-__global__ __launch_bounds__(256) void lovasz_error_kernel(const LovArgs a, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
-    const long long n = a.P * a.S;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int s = (int)(t / a.P);
-        const long long i = t - (long long)s * a.P;
-        float e;
-        unsigned fg;
-        bool valid;
-        error_of(a, s, i, e, fg, valid);
-        keys[t] = ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
-        vals[t] = ((unsigned)i << 1) | (valid ? fg : 0u);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ segmented radix sort
 // S segments of P (key, value) pairs each, contiguous; ascending by the 32-bit key, stable, four passes of 8 bits.
 // Tile = 4096 elements per 256-thread workgroup; wave w of a tile owns elements w*1024 .. w*1024+1023 and its item j covers the
 // 64 consecutive elements w*1024 + j*64 + lane (every load instruction of a wave reads 256 contiguous bytes).
-constexpr int RS_ITEMS = 16, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 64 * RS_ITEMS;
+#ifndef PTB_RS_ITEMS
+#define PTB_RS_ITEMS 16
+#endif
+constexpr int RS_ITEMS = PTB_RS_ITEMS, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 64 * RS_ITEMS;
 
 // Lanes of this wave whose digit equals mine: per bit one ballot (a scalar pair) folded into the lane's mask halves with
 // XNOR against the sign-extended bit -- 6 vector instructions per bit (a per-lane select between the ballot and its complement
@@ -130,6 +91,17 @@ __device__ __forceinline__ unsigned block_inclusive_scan(unsigned v, unsigned* w
     for (int w = 0; w < wave; ++w) off += wave_tot[w];
     total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     return incl + off;
+}
+
+// Workgroup -> linear tile.  Workgroups go to the 8 XCDs round-robin by blockIdx, and every XCD has its own L2: with the identity
+// mapping the tiles t, t+1, ... whose digit runs are neighbours in the output are written through 8 different L2s and every 64-byte
+// run reaches HBM as its own partial line.  xcd_map gives XCD x a contiguous range of tiles, so neighbouring runs meet in one
+// write-back L2 and leave as whole lines.
+__device__ __forceinline__ unsigned tile_of_block(int xcd_map) {
+    const unsigned bid = blockIdx.x, nb = gridDim.x;
+    if (!xcd_map || nb < 16) return bid;
+    const unsigned per = nb >> 3, rem = nb & 7u, x = bid & 7u, slot = bid >> 3;
+    return x * per + (x < rem ? x : rem) + slot;
 }
 
 // pass step 1: digit histogram of every tile -> hist[(seg * T + tile) * 256 + digit]  (one coalesced 1 KiB row per tile)
@@ -176,6 +148,95 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
     hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
 }
 
+// The error kernel and the first pass's histogram kernel in one: a workgroup owns the 4096 pixels of one tile position of a group
+// (image, or the whole batch) and a chunk of classes.  The pixels' labels are read once (int64: read per class they are twice the
+// bytes of the probabilities) and every class of the chunk is a pass over the same pixels: error -> key / value written, digit 0
+// counted in LDS, the tile's histogram row written.  Element i of a segment is pixel (b = i / HW, i % HW) of the batch, or pixel i of
+// image j when per_image; n < 2^31, so offsets into pred fit 32 bits.
+template <int MODE>
+__global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a, int T, int cchunk, unsigned* __restrict__ keys,
+                                                                unsigned* __restrict__ vals, unsigned* __restrict__ hist) {
+    __shared__ unsigned h[4][4][256];
+    const int j = blockIdx.x / T, tile = blockIdx.x % T;
+    const int c0 = blockIdx.y * cchunk, c1 = min(a.C, c0 + cchunk);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h[w][c][threadIdx.x] = 0;
+    const long long t0 = (long long)tile * RS_TILE;
+    const long long left = a.P - t0;
+    const unsigned HW = (unsigned)a.HW;
+    unsigned off0[RS_ITEMS];                 // offset of the pixel in class 0's plane of its image
+    int lab[MODE == LOVASZ_SOFTMAX ? RS_ITEMS : 1];      // class label, -1 = no class of this call, -2 = ignored
+    float yv[MODE == LOVASZ_HINGE ? RS_ITEMS : 1];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int jj = 0; jj < RS_ITEMS; ++jj) {
+        const int idx = wave * RS_WAVE_SPAN + jj * 64 + lane;
+        const bool ok = idx < left;
+        const unsigned i = (unsigned)(t0 + idx);
+        const unsigned b = a.per_image ? (unsigned)j : (ok ? i / HW : 0u);
+        const unsigned px = a.per_image ? i : i - b * HW;
+        off0[jj] = b * (unsigned)a.C * HW + px;
+        okmask |= ok ? 1u << jj : 0u;
+        const long long lo = (long long)b * a.HW + px;
+        if constexpr (MODE == LOVASZ_SOFTMAX) {
+            const long long L = ok ? a.labels[lo] : 0;
+            lab[jj] = (a.has_ignore && L == a.ignore_label) ? -2 : ((L >= 0 && L < a.C) ? (int)L : -1);
+        } else {
+            yv[jj] = ok ? a.flabels[lo] : 0.f;
+        }
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const int s = j * a.C + c;
+        const long long sbase = (long long)s * a.P + t0;
+        float p[RS_ITEMS];
+#pragma unroll
+        for (int jj = 0; jj < RS_ITEMS; ++jj) p[jj] = (okmask >> jj & 1u) ? a.pred[off0[jj] + (unsigned)c * HW] : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < RS_ITEMS; ++jj) {
+            const int idx = wave * RS_WAVE_SPAN + jj * 64 + lane;
+            const bool ok = okmask >> jj & 1u;
+            float e;
+            unsigned fg;
+            bool valid;
+            if constexpr (MODE == LOVASZ_SOFTMAX) {
+                valid = lab[jj] != -2;
+                fg = lab[jj] == c ? 1u : 0u;
+                e = fabsf((float)fg - p[jj]);                         // lovasz.py:133
+            } else {
+                const float y = yv[jj];
+                valid = !(a.has_ignore && y == a.ignore_value);
+                fg = y != 0.f ? 1u : 0u;
+                e = 1.0f - p[jj] * (2.0f * y - 1.0f);                 // lovasz.py:65-66
+            }
+            const unsigned key = ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
+            if (ok) {
+                keys[sbase + idx] = key;
+                vals[sbase + idx] = ((unsigned)(t0 + idx) << 1) | (valid ? fg : 0u);
+            }
+            const unsigned d = key & 255u;
+            const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+            const bool full = wave * RS_WAVE_SPAN + jj * 64 + 63 < left;      // (wave-uniform)
+            if (full && __all(d == d0)) {
+                if (lane == 0) atomicAdd(&h[wave][0][d0], 64u);
+            } else if (ok) {
+                atomicAdd(&h[wave][lane & 3][d], 1u);
+            }
+        }
+        __syncthreads();
+        unsigned tot = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) { tot += h[w][cc][threadIdx.x]; h[w][cc][threadIdx.x] = 0; }
+        hist[((long long)s * T + tile) * 256 + threadIdx.x] = tot;
+        __syncthreads();
+    }
+}
+
 // pass step 2: one workgroup per (segment, span of RS_SPAN tiles); thread = digit: running count over the span's tiles in place
 // (every access is a coalesced 1 KiB row, the loads of a span are independent of each other), span total -> span_tot
 constexpr int RS_SPAN = 32;
@@ -199,13 +260,14 @@ __global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__
 __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                          unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
                                                          int shift, const unsigned* __restrict__ hist, int spans,
-                                                         const unsigned* __restrict__ span_tot) {
+                                                         const unsigned* __restrict__ span_tot, int xcd_map) {
     __shared__ unsigned wave_hist[4][256];   // per wave: running digit counts, then the wave's start inside the tile's digit run
     __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
     __shared__ unsigned wave_tot[4];
     __shared__ unsigned skey[RS_TILE], sval[RS_TILE];
-    const int seg = blockIdx.x / T, tile = blockIdx.x % T;
+    const unsigned lin = tile_of_block(xcd_map);
+    const int seg = lin / T, tile = lin % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long t0 = (long long)tile * RS_TILE;
     const long long base = (long long)seg * P;
@@ -269,7 +331,11 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
     }
 }
 
-// phase a: foreground count of every CHUNK of the sorted order
+// (Measured and dropped: the same pass with one 16 KiB staging buffer used twice and packed 12-bit slots -- 22 KB of LDS, 80 VGPRs, 6
+// workgroups per CU instead of 4 -- is 1 % slower: the pass is not waiting for occupancy.  2048-element tiles: +8 %; 8192: no change.)
+// phase a: foreground count of every CHUNK of the sorted order.  (Counting inside the last scatter pass instead -- one atomic per wave
+// of staged slots, 262 k device-scope atomics on 8 192 counters -- made that pass 68 -> 176 us: atomics between XCDs execute at the
+// memory side.)
 __global__ __launch_bounds__(256) void lovasz_count_kernel(const unsigned* __restrict__ vals, long long P, int chunks_per_seg,
                                                            unsigned* __restrict__ chunk_count) {
     const int s = blockIdx.x / chunks_per_seg, k = blockIdx.x % chunks_per_seg;
@@ -408,32 +474,79 @@ __global__ __launch_bounds__(256) void lovasz_segsum_kernel(const double* __rest
     if (threadIdx.x == 0) seg_loss[s] = wacc[0] + wacc[1] + wacc[2] + wacc[3];
 }
 
+// backward: one thread per pixel (b, px), all classes: the label is read once (per class it is twice the bytes of a probability),
+// every class is one coalesced read of pred and of the gradient at the pixel's rank and one streamed write.
+template <int MODE>
 __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const LovArgs a, const float* __restrict__ coef,
                                                          const float* __restrict__ grad_at_pixel, float* __restrict__ grad) {
-    const long long n = a.P * a.S;
+    const long long npx = (long long)a.B * a.HW;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) {
-        const int s = (int)(t / a.P);
-        const long long i = t - (long long)s * a.P;
-        long long po, lo;
-        int c;
-        locate(a, s, i, po, lo, c);
-        float e;
-        unsigned fg;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < npx; q += stride) {
+        const long long b = q / a.HW, px = q - b * a.HW;
+        const long long i = a.per_image ? px : q;                 // element of its segment
+        const long long j = a.per_image ? b : 0;                  // group
         bool valid;
-        error_of(a, s, i, e, fg, valid);
-        float gx = 0.f;
-        if (valid && e > 0.f) {
-            const float g = coef[s] * grad_at_pixel[t];
-            if (a.mode == LOVASZ_SOFTMAX) {
-                const float d = a.pred[po] - (float)fg;      // d|fg - p|/dp = sign(p - fg)
-                gx = d > 0.f ? g : (d < 0.f ? -g : 0.f);
-            } else {
-                gx = -g * (2.0f * a.flabels[lo] - 1.0f);     // d(1 - x*sign)/dx
-            }
+        long long lab = 0;
+        float y = 0.f;
+        if constexpr (MODE == LOVASZ_SOFTMAX) {
+            lab = a.labels[q];
+            valid = !(a.has_ignore && lab == a.ignore_label);
+        } else {
+            y = a.flabels[q];
+            valid = !(a.has_ignore && y == a.ignore_value);
         }
-        grad[po] = gx;
+#pragma unroll 4
+        for (int c = 0; c < a.C; ++c) {
+            const long long po = (b * a.C + c) * a.HW + px;
+            const long long s = j * a.C + c;
+            const float p = a.pred[po];
+            const float gp = grad_at_pixel[s * a.P + i];
+            float gx = 0.f;
+            if constexpr (MODE == LOVASZ_SOFTMAX) {
+                const float fg = lab == c ? 1.f : 0.f;
+                const float e = fabsf(fg - p);
+                if (valid && e > 0.f) {
+                    const float g = coef[s] * gp;
+                    const float d = p - fg;                       // d|fg - p|/dp = sign(p - fg)
+                    gx = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+                }
+            } else {
+                const float sg = 2.0f * y - 1.0f;
+                const float e = 1.0f - p * sg;
+                if (valid && e > 0.f) gx = -(coef[s] * gp) * sg;  // d(1 - x*sign)/dx
+            }
+            __builtin_nontemporal_store(gx, &grad[po]);
+        }
     }
+}
+
+// loss = mean over the groups of (sum over the selected classes of seg_loss / number of selected classes), and its derivative with
+// respect to every seg_loss (losses/lovasz.py:92-108, :110-140: classes = "present" | "all"; the hinge loss is C = 1, "all").  One
+// workgroup; thread = group, fixed summation order.
+__global__ __launch_bounds__(256) void lovasz_reduce_kernel(const double* __restrict__ seg_loss, const unsigned* __restrict__ fg_total, int groups,
+                                                            int C, int present_only, float* __restrict__ loss_out, float* __restrict__ coef_out) {
+    __shared__ double part[256];
+    double acc = 0.0;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+        double sum = 0.0, cnt = 0.0;
+        for (int c = 0; c < C; ++c) {
+            const bool use = !present_only || fg_total[g * C + c] > 0u;
+            if (use) { sum += seg_loss[g * C + c]; cnt += 1.0; }
+        }
+        const double den = cnt < 1.0 ? 1.0 : cnt;
+        acc += sum / den;
+        for (int c = 0; c < C; ++c) {
+            const bool use = !present_only || fg_total[g * C + c] > 0u;
+            coef_out[g * C + c] = use ? (float)(1.0 / (den * groups)) : 0.f;
+        }
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = (float)(part[0] / groups);
 }
 
 static int fill(LovArgs& a, const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
@@ -448,6 +561,8 @@ static int fill(LovArgs& a, const float* pred, const int64_t* labels, const floa
     if (a.P >= (1LL << 31)) return PTB_EUNSUPPORTED;
     return PTB_OK;
 }
+
+int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in the radix scatter
 
 static int blocks_for(long long n) {
     const long long want = (n + 255) / 256;
@@ -482,29 +597,42 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;  // offsets / packed indices are 32-bit
     if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(lovasz_error_kernel, dim3(blocks_for(n)), dim3(256), 0, s, a, keys_a, vals_a);
-    if (int rc = check_launch()) return rc;
-    // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
     const int T = (int)((a.P + RS_TILE - 1) / RS_TILE);
     const long long tiles = (long long)T * a.S;
     if (tiles > 0x7fffffffLL) return PTB_EUNSUPPORTED;
     unsigned* hist = static_cast<unsigned*>(temp);
     unsigned* span_tot = hist + (long long)a.S * 256 * T;
     const int spans = (T + RS_SPAN - 1) / RS_SPAN;
+    const int cps = (int)((a.P + CHUNK - 1) / CHUNK);
+    const long long total_chunks = (long long)cps * a.S;
+    if (total_chunks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    // errors -> (key, value) pairs + the first pass's tile histograms; classes are split over blockIdx.y until ~2048 workgroups exist
+    {
+        const long long gt = (long long)(a.S / a.C) * T;
+        int nch = (int)((2048 + gt - 1) / gt);
+        nch = nch < 1 ? 1 : (nch > a.C ? a.C : nch);
+        const int cchunk = (a.C + nch - 1) / nch;
+        nch = (a.C + cchunk - 1) / cchunk;
+        if (nch > 65535) return PTB_EUNSUPPORTED;
+        const dim3 grid((unsigned)gt, (unsigned)nch);
+        if (a.mode == LOVASZ_SOFTMAX)
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, vals_a, hist);
+        else
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_HINGE>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, vals_a, hist);
+        if (int rc = check_launch()) return rc;
+    }
+    // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
     unsigned *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     for (int shift = 0; shift < 32; shift += 8) {
-        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
+        if (shift) hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
     }
     // (an even number of passes: the sorted pairs are back in keys_a / vals_a)
-    const int cps = (int)((a.P + CHUNK - 1) / CHUNK);
-    const long long total_chunks = (long long)cps * a.S;
-    if (total_chunks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
-    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin == keys_a ? vals_a : vals_b, a.P, cps, chunk);
+    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vin, a.P, cps, chunk);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
     double* partial = static_cast<double*>(temp);      // (the sort is done with its histograms: 1 KB per 4096-element tile, 16 B needed)
     hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial,
@@ -521,6 +649,17 @@ extern "C" int ptb_lovasz_bwd(const float* pred, const int64_t* labels, const fl
     if (!coef || !grad_at_pixel || !grad) return PTB_EINVAL;
     const long long n = a.P * a.S;
     if (n == 0) return PTB_OK;
-    hipLaunchKernelGGL(lovasz_bwd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, coef, grad_at_pixel, grad);
+    const int blocks = blocks_for((long long)a.B * a.HW);
+    if (a.mode == LOVASZ_SOFTMAX)
+        hipLaunchKernelGGL(lovasz_bwd_kernel<LOVASZ_SOFTMAX>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, coef, grad_at_pixel, grad);
+    else
+        hipLaunchKernelGGL(lovasz_bwd_kernel<LOVASZ_HINGE>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, coef, grad_at_pixel, grad);
+    return check_launch();
+}
+
+extern "C" int ptb_lovasz_reduce(const double* seg_loss, const unsigned* fg_total, int groups, int C, int present_only, float* loss_out,
+                                 float* coef_out, ptb_stream_t stream) {
+    if (!seg_loss || !fg_total || !loss_out || !coef_out || groups < 1 || C < 1) return PTB_EINVAL;
+    hipLaunchKernelGGL(lovasz_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seg_loss, fg_total, groups, C, present_only, loss_out, coef_out);
     return check_launch();
 }

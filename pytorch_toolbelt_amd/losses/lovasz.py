@@ -20,10 +20,12 @@ _CHUNK = 2048
 
 
 class _LovaszSegments(torch.autograd.Function):
-    """Per-segment Lovasz dot products [S] (float64) and per-segment foreground counts [S] (int32)."""
+    """Per-segment Lovasz dot products [S] (float64) and per-segment foreground counts [S] (int32).  With ``present_only`` set
+    (True: classes="present", False: all classes) the first result is the module's scalar instead (float32): the mean over
+    the selected classes and over the groups is one more kernel (``ptb_lovasz_reduce``), not a dozen [S]-sized torch launches."""
 
     @staticmethod
-    def forward(ctx, pred, labels, flabels, mode, per_image, has_ignore, ignore_label, ignore_value, want_grad=True):
+    def forward(ctx, pred, labels, flabels, mode, per_image, has_ignore, ignore_label, ignore_value, want_grad=True, present_only=None):
         if mode == _SOFTMAX:
             B, C, HW = pred.shape
         else:
@@ -55,18 +57,27 @@ class _LovaszSegments(torch.autograd.Function):
                                         seg_loss.data_ptr(), gpix.data_ptr() if want_grad else None, temp.data_ptr(), int(tb), N.stream_ptr(dev))
             N.bump()
             N.check(rc, "ptb_lovasz_fwd")
-        ctx.save_for_backward(pred, labels, flabels, gpix)
+        coef_unit = None
+        if present_only is not None:
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            coef_unit = torch.empty(S, dtype=torch.float32, device=dev)
+            with N.on_device(dev):
+                rc = N.load().ptb_lovasz_reduce(seg_loss.data_ptr(), fg_total.data_ptr(), groups, C, 1 if present_only else 0, loss.data_ptr(),
+                                                coef_unit.data_ptr(), N.stream_ptr(dev))
+            N.check(rc, "ptb_lovasz_reduce")
+            seg_loss = loss
+        ctx.save_for_backward(pred, labels, flabels, gpix, coef_unit)
         ctx.cfg = (B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)
         ctx.mark_non_differentiable(fg_total)
         return seg_loss, fg_total
 
     @staticmethod
     def backward(ctx, g_loss, _g_fg):
-        pred, labels, flabels, gpix = ctx.saved_tensors
+        pred, labels, flabels, gpix, coef_unit = ctx.saved_tensors
         B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value = ctx.cfg
-        grad = torch.zeros_like(pred)
+        grad = torch.empty_like(pred)          # (the kernel writes every element)
         if pred.numel():
-            coef = g_loss.to(torch.float32).contiguous()
+            coef = (g_loss.to(torch.float32) * coef_unit if coef_unit is not None else g_loss.to(torch.float32)).contiguous()
             lib = N.load()
             with N.on_device(pred.device):
                 rc = lib.ptb_lovasz_bwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), gpix.data_ptr(), grad.data_ptr(),
@@ -74,7 +85,7 @@ class _LovaszSegments(torch.autograd.Function):
                                         N.stream_ptr(pred.device))
             N.bump()
             N.check(rc, "ptb_lovasz_bwd")
-        return grad, None, None, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None, None, None
 
 
 def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
@@ -86,9 +97,13 @@ def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
     y = labels.to(device=x.device, dtype=torch.float32).reshape(B, -1).contiguous()
     if y.shape[1] != x.shape[1]:
         raise RuntimeError(f"target shape {tuple(labels.shape)} does not match logits shape {tuple(logits.shape)}")
-    seg_loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
-                                          float(ignore_index) if ignore_index is not None else 0.0, torch.is_grad_enabled() and x.requires_grad)
-    return seg_loss.mean().float() if per_image else seg_loss[0].float()
+    if x.numel() == 0:
+        seg_loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
+                                              float(ignore_index) if ignore_index is not None else 0.0, torch.is_grad_enabled() and x.requires_grad)
+        return seg_loss.mean().float() if per_image else seg_loss[0].float()
+    loss, _fg = _LovaszSegments.apply(x, None, y, _HINGE, bool(per_image), ignore_index is not None, 0,
+                                      float(ignore_index) if ignore_index is not None else 0.0, torch.is_grad_enabled() and x.requires_grad, False)
+    return loss
 
 
 def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_index=None):
@@ -104,6 +119,11 @@ def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_i
     lab = labels.to(device=x.device, dtype=torch.int64).reshape(B, -1).contiguous()
     if lab.shape[1] != x.shape[2]:
         raise RuntimeError(f"target shape {tuple(labels.shape)} does not match probabilities shape {tuple(probas.shape)}")
+    if classes in ("present", "all") and x.numel() > 0:
+        loss, _fg = _LovaszSegments.apply(x, lab, None, _SOFTMAX, bool(per_image), ignore_index is not None,
+                                          int(ignore_index) if ignore_index is not None else 0, 0.0, torch.is_grad_enabled() and x.requires_grad,
+                                          classes == "present")
+        return loss
     seg_loss, fg = _LovaszSegments.apply(x, lab, None, _SOFTMAX, bool(per_image), ignore_index is not None,
                                          int(ignore_index) if ignore_index is not None else 0, 0.0, torch.is_grad_enabled() and x.requires_grad)
     groups = B if per_image else 1

@@ -388,3 +388,52 @@ def test_one_launch_region_loss_matches_the_two_launch_path(dev):
     side.synchronize()
     assert len(K._workspaces) == n_ws + 1 and float(other) == float(good) and torch.isfinite(good)
     K.flush_label_check()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(3, 5, 37, 29), (2, 3, 64, 70), (1, 2, 5, 3), (4, 16, 96, 96)])
+def test_lovasz_reduce_kernel_and_pixel_backward(B, C, H, W, dev):
+    """The scalar of LovaszLoss / BinaryLovaszLoss comes from ptb_lovasz_reduce (mean over present / all classes, mean over images) and
+    the backward from the one-thread-per-pixel kernel: values against the fp64 oracle (losses/lovasz.py:92-140, :37-72), gradients
+    against the path that returns the per-segment dot products and lets torch do the [S]-sized algebra (classes as a list)."""
+    from oracle import losses_oracle as LO
+    from pytorch_toolbelt_amd.losses import lovasz as LV
+
+    g = torch.Generator().manual_seed(B * 100 + C)
+    probs = torch.softmax(torch.randn((B, C, H, W), generator=g) * 2, 1)
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab[lab == C - 1] = 0                      # the last class is absent everywhere: "present" and "all" differ
+    if B > 1:
+        lab[1][lab[1] == 0] = 1                # ... and class 0 is absent in image 1 only
+    lab[0, 0, : W // 2] = 255
+    for per_image in (False, True):
+        for ignore in (None, 255):
+            labs = lab if ignore is not None else lab.clamp_max(C - 1)
+            for classes in ("present", "all"):
+                want = LO.lovasz_softmax(probs.numpy(), labs.numpy(), classes=classes, per_image=per_image, ignore_index=ignore)
+                xa = probs.to(dev).requires_grad_(True)
+                la = LV._lovasz_softmax(xa, labs.to(dev), classes=classes, per_image=per_image, ignore_index=ignore)
+                assert la.dtype == torch.float32 and la.dim() == 0
+                assert float(la) == pytest.approx(float(want), rel=2e-6, abs=1e-7), (per_image, ignore, classes)
+                (la * 3.0).backward()
+                if classes == "all":           # the same classes as a list: the torch-side algebra
+                    xb = probs.to(dev).requires_grad_(True)
+                    lb = LV._lovasz_softmax(xb, labs.to(dev), classes=list(range(C)), per_image=per_image, ignore_index=ignore)
+                    assert float(lb) == pytest.approx(float(la), rel=1e-6, abs=1e-8)
+                    (lb * 3.0).backward()
+                    torch.testing.assert_close(xa.grad, xb.grad, rtol=1e-6, atol=1e-12)
+                assert bool(torch.isfinite(xa.grad).all())
+    # hinge: values vs the oracle; gradient = -sign * g where the error is positive (finite-difference check of one direction)
+    x = torch.randn((B, H, W), generator=g)
+    y = (torch.rand((B, H, W), generator=g) < 0.4).float()
+    y[0, 0, :3] = 255.0
+    for per_image in (False, True):
+        for ignore in (None, 255):
+            yy = y if ignore is not None else y.clamp_max(1.0)
+            want = LO.lovasz_hinge(x.numpy(), yy.numpy(), per_image=per_image, ignore_index=ignore)
+            xa = x.to(dev).requires_grad_(True)
+            la = LV._lovasz_hinge(xa, yy.to(dev), per_image=per_image, ignore_index=ignore)
+            assert float(la) == pytest.approx(float(want), rel=2e-6, abs=1e-6), (per_image, ignore)
+            la.backward()
+            d = torch.randn(xa.shape, generator=g).to(dev) * 1e-4
+            lb = LV._lovasz_hinge(xa.detach() + d, yy.to(dev), per_image=per_image, ignore_index=ignore)
+            assert float(lb - la) == pytest.approx(float((xa.grad * d).sum()), rel=5e-2, abs=2e-7)

@@ -13,9 +13,11 @@ probs = torch.softmax(torch.randn((4, 16, 512, 512), device=dev), 1).requires_gr
 lab = torch.randint(0, 16, (4, 512, 512), device=dev)
 x = torch.randn((4, 512, 512), device=dev, requires_grad=True)
 t = (torch.rand((4, 512, 512), device=dev) < 0.3).float()
+BIG_ONLY = os.environ.get("PTB_PROF_BIG_ONLY") == "1"      # only the multi-class case (per-kernel averages of ONE problem size)
 for _ in range(20):
     L.LovaszLoss()(probs, lab).backward()
-    L.BinaryLovaszLoss(per_image=True)(x, t).backward()
+    if not BIG_ONLY:
+        L.BinaryLovaszLoss(per_image=True)(x, t).backward()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
