@@ -18,6 +18,7 @@ cd $R
 { for w in 8 4 2; do timeout 200 python tools/shard_sim.py --world $w 2>/dev/null | grep -v amdgpu; echo; done; echo "--- incremental accumulate + exchange path (round 1) for comparison"; timeout 200 python tools/shard_sim.py --world 8 --no-defer 2>/dev/null | grep -v amdgpu; } > $O/${TAG}_shard_sim.txt
 timeout 200 python tools/bench_losses.py 2>/dev/null | grep -v amdgpu > $O/${TAG}_losses_microbench.txt
 tools/build/valu_probe > $O/${TAG}_valu_probe.txt 2>&1
+[ "${PTB_PROFILE_LIGHT:-0}" = "1" ] && { ls -la $O; exit 0; }      # (no --pmc passes: ~2 minutes of box time each)
 # PMC (own passes, kernel trace only): vector-ALU occupancy of the two loss kernels section 3.4 of DESIGN.md discusses
 for w in "fused" "cefocal bwd"; do t=$(echo $w | tr " " "_"); bash tools/pmc_cmd.sh $t "VALUBusy" "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU" "MemUnitBusy" -- python $R/tools/prof_one_loss.py $w; done
 { echo "# $TAG: rocprofv3 --pmc <group> --kernel-trace -- python tools/prof_one_loss.py {fused | cefocal bwd}  (cfg4 shape; one counter group per run)"; echo;
