@@ -519,9 +519,54 @@ extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const
     return rc;
 }
 
+int ptb::g_rank_finish_fused = 1;   // ptb_set_tunable key 18: 0 = ptb_rect_add + ptb_merge_div_ex launches (A/B, bit-identity test)
+
+// The end of a rank's image in one launch: over <= 2 row ranges of `merged` (full width, the rows that held partial sums),
+// value = (merged + recv_0 + recv_1 + ...) / norm with the received rectangles added in their order -- the arithmetic of ptb_rect_add
+// per rectangle followed by ptb_merge_div_ex per range, without storing and re-reading the sums in between.
+struct FinishArgs {
+    float* merged;
+    const float* norm;
+    int C, W;
+    long long plane;
+    int n_recvs, n_ranges;
+    int r0[4], r1[4], c0[4], c1[4];
+    const float* buf[4];
+    int q0[2], q1[2];
+};
+
+__global__ __launch_bounds__(256) void band_finish_kernel(const FinishArgs a) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int w4 = a.W >> 2;
+    const int rows0 = a.q1[0] - a.q0[0];
+    const long long total = (long long)(rows0 + (a.n_ranges > 1 ? a.q1[1] - a.q0[1] : 0)) * w4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / w4), x = (int)(i - (long long)t * w4) * 4;
+        const int r = t < rows0 ? a.q0[0] + t : a.q0[1] + (t - rows0);
+        const v4f n = *reinterpret_cast<const v4f*>(a.norm + (long long)r * a.W + x);
+        for (int c = 0; c < a.C; ++c) {
+            float* mp = a.merged + c * a.plane + (long long)r * a.W + x;
+            v4f v = *reinterpret_cast<const v4f*>(mp);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < a.n_recvs && r >= a.r0[k] && r < a.r1[k] && x >= a.c0[k] && x < a.c1[k]) {       // (c0, c1 are multiples of 4 on this path)
+                    const int cols = a.c1[k] - a.c0[k];
+                    const v4f e = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(
+                        a.buf[k] + ((long long)c * (a.r1[k] - a.r0[k]) + (r - a.r0[k])) * cols + (x - a.c0[k])));
+                    v.x = __fadd_rn(v.x, e.x); v.y = __fadd_rn(v.y, e.y); v.z = __fadd_rn(v.z, e.z); v.w = __fadd_rn(v.w, e.w);
+                }
+            }
+            v4f o;
+            o.x = __fdiv_rn(v.x, n.x); o.y = __fdiv_rn(v.y, n.y); o.z = __fdiv_rn(v.z, n.z); o.w = __fdiv_rn(v.w, n.w);
+            __builtin_nontemporal_store(o, reinterpret_cast<v4f*>(mp));
+        }
+    }
+}
+
 // The end of a rank's image as ONE host call: the partial sums received from the neighbours (n_recvs rectangles {r0, r1, c0, c1} in
 // the plan's rows, packed [C][r1 - r0][c1 - c0] buffers) are added to `merged`, then the row ranges that held partial sums
-// (n_ranges x {r0, r1}) are divided by `norm` in place (tiles.py:346).  Launches only: ptb_rect_add + ptb_merge_div_ex per item.
+// (n_ranges x {r0, r1}) are divided by `norm` in place (tiles.py:346).  One launch (band_finish_kernel) for the shapes a row-band
+// partition produces, else ptb_rect_add + ptb_merge_div_ex per item; the same additions in the same order either way.
 extern "C" int ptb_band_plan_finish_rank(const ptb_band_plan* p, float* merged, const float* norm, int n_recvs, const int64_t* rects,
                                          const float* const* recv_bufs, int n_ranges, const int64_t* ranges, ptb_stream_t stream) {
     if (!p || !merged || !norm || n_recvs < 0 || n_ranges < 0 || (n_recvs && (!rects || !recv_bufs)) || (n_ranges && !ranges)) return PTB_EINVAL;
@@ -529,6 +574,35 @@ extern "C" int ptb_band_plan_finish_rank(const ptb_band_plan* p, float* merged, 
     for (int k = 0; k < n_recvs; ++k) {
         const int64_t r0 = rects[4 * k], r1 = rects[4 * k + 1], c0 = rects[4 * k + 2], c1 = rects[4 * k + 3];
         if (r0 < 0 || r1 > p->H || c0 < 0 || c1 > p->W || r1 < r0 || c1 < c0 || !recv_bufs[k]) return PTB_EINVAL;
+    }
+    for (int k = 0; k < n_ranges; ++k)
+        if (ranges[2 * k] < 0 || ranges[2 * k + 1] > p->H || ranges[2 * k + 1] < ranges[2 * k]) return PTB_EINVAL;
+    // one launch when the shapes allow it: <= 4 rectangles, <= 2 ranges, 16-byte columns, every rectangle inside one of the ranges
+    // (a rectangle outside them would only be added, not divided: the launches below do that)
+    bool fused = g_rank_finish_fused && !g_force_scalar && n_recvs <= 4 && n_ranges >= 1 && n_ranges <= 2 && p->W % 4 == 0 && aligned16(merged) && aligned16(norm);
+    for (int k = 0; fused && k < n_recvs; ++k) {
+        const int64_t r0 = rects[4 * k], r1 = rects[4 * k + 1], c0 = rects[4 * k + 2], c1 = rects[4 * k + 3];
+        bool inside = r1 == r0;
+        for (int q = 0; q < n_ranges; ++q) inside = inside || (r0 >= ranges[2 * q] && r1 <= ranges[2 * q + 1]);
+        fused = inside && c0 % 4 == 0 && c1 % 4 == 0 && aligned16(recv_bufs[k]);
+    }
+    if (fused && n_ranges == 2 && ranges[0] < ranges[3] && ranges[2] < ranges[1]) fused = false;      // overlapping ranges: divided twice by the launches below
+    if (fused) {
+        FinishArgs a{};
+        a.merged = merged; a.norm = norm; a.C = p->C; a.W = p->W; a.plane = plane; a.n_recvs = n_recvs; a.n_ranges = n_ranges;
+        for (int k = 0; k < n_recvs; ++k) {
+            a.r0[k] = (int)rects[4 * k]; a.r1[k] = (int)rects[4 * k + 1]; a.c0[k] = (int)rects[4 * k + 2]; a.c1[k] = (int)rects[4 * k + 3];
+            a.buf[k] = recv_bufs[k];
+        }
+        long long rows = 0;
+        for (int q = 0; q < n_ranges; ++q) { a.q0[q] = (int)ranges[2 * q]; a.q1[q] = (int)ranges[2 * q + 1]; rows += ranges[2 * q + 1] - ranges[2 * q]; }
+        if (rows == 0) return PTB_OK;
+        const long long want = (rows * (p->W / 4) + 255) / 256;
+        hipLaunchKernelGGL(band_finish_kernel, dim3((unsigned)(want < 256 * 16 ? want : 256 * 16)), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch();
+    }
+    for (int k = 0; k < n_recvs; ++k) {
+        const int64_t r0 = rects[4 * k], r1 = rects[4 * k + 1], c0 = rects[4 * k + 2], c1 = rects[4 * k + 3];
         const int rc = ptb_rect_add(merged + r0 * p->W + c0, recv_bufs[k], p->C, (int)(r1 - r0), (int)(c1 - c0), plane, p->W, stream);
         if (rc != PTB_OK) return rc;
     }

@@ -56,6 +56,21 @@ def _worker(rank, world, port, partition, defer, q):
                 first_band = band.clone()      # the result of image 0 must survive image 1 (no shared output buffer)
                 kept = band
         assert torch.equal(kept, first_band), "the band returned for the first image was overwritten by the second"
+        if m._deferred is not None:
+            # the one-launch finish (received partial sums added + division, ptb_band_plan_finish_rank) against its separate
+            # ptb_rect_add / ptb_merge_div_ex launches: the same additions in the same order, so the same bits
+            from pytorch_toolbelt_amd import _native as N
+
+            assert N.load().ptb_set_tunable(18, 0) == 0
+            try:
+                m.reset()
+                for b0 in range(0, len(mine), 4):
+                    idx = mine[b0:b0 + 4]
+                    m.integrate_batch_deaugment(views[idx].transpose(0, 1).reshape(-1, C, 256, 256).to(dev) * 2, crops[idx], group="d4")
+                again = m.merge()
+            finally:
+                N.load().ptb_set_tunable(18, 1)
+            assert torch.equal(again, band), "fused finish differs from the separate launches"
         if rank == 0:
             from oracle import tta_oracle as AO
 

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--partition", default="tiles")
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--placement-tries", type=int, default=6, help="candidate placements of the rank's model outputs (1 = first allocation)")
+    ap.add_argument("--ranks", default="", help="comma-separated ranks to play (default: all)")
     ap.add_argument("--no-defer", action="store_true", help="incremental accumulate + exchange path (round-1 behaviour) instead of the band plan")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -66,7 +67,7 @@ def main():
     gc.freeze()
     gc.disable()   # a generation-2 pass (30-45 ms) inside one rank's loop would masquerade as a slow rank
     worst = 0.0
-    for r in range(args.world):
+    for r in ([int(x) for x in args.ranks.split(",")] if args.ranks else range(args.world)):
         m = ShardedTileMerger(slicer.target_shape, C, slicer.weight, slicer.crops, device=dev, dist=FakeDist(r, args.world), partition=args.partition, defer=not args.no_defer)
         for buf in m._recv_buf:
             buf.zero_()
