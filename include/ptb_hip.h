@@ -541,6 +541,18 @@ int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabel
                    int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                    unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                    double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream);
+/* ptb_lovasz_fwd with the gradient left BINNED instead of scattered to pixel order (16.7 M random 4-byte writes at [4,16,512,512]
+ * become one more pass of the sort's scatter): on return keys_b[] holds (index << 1 | fg) and vals_b[] the fp32 gradient bits of the
+ * same element, grouped by blocks of 2^r pixels, r = the RETURN VALUE (12..14): the pairs of block b of segment s are at
+ * s*P + (b << r) ..., in arbitrary order inside the block.  scratch = float[n] (overwritten).  PTB_EUNSUPPORTED when a segment
+ * has more than 256 * 2^14 elements (use ptb_lovasz_fwd).  ptb_lovasz_bwd_binned consumes (keys_b, vals_b, r). */
+int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                          int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
+                          unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
+                          double* seg_loss, float* scratch, void* temp, int64_t temp_bytes, ptb_stream_t stream);
+int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const uint32_t* binned_vals,
+                          const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode, int per_image, int has_ignore,
+                          int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream);
 /* The scalar the modules return from seg_loss / fg_total (losses/lovasz.py:92-108, :110-140): per group the mean of seg_loss over
  * the classes with fg_total > 0 (present_only = 1, classes="present") or over all classes (0; the hinge loss is C = 1), 0 when none
  * is selected; then the mean over the groups.  loss_out = DEVICE float; coef_out = DEVICE float[groups*C] = d(loss)/d(seg_loss). */

@@ -101,6 +101,8 @@ SIGNATURES = {
     "ptb_softmax_focal_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_i64, _vp]),
     "ptb_lovasz_temp_bytes": (_c_i64, [_c_i64, _c_int]),
     "ptb_lovasz_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
+    "ptb_lovasz_fwd_binned": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
+    "ptb_lovasz_bwd_binned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_int, _vp]),
     "ptb_lovasz_reduce": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
     "ptb_lovasz_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _vp]),
     "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),

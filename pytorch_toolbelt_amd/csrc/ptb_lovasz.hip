@@ -394,7 +394,7 @@ __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // 
 __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
                                                          const unsigned* __restrict__ fg_total, double* __restrict__ partial,
-                                                         float* __restrict__ grad_at_pixel) {
+                                                         float* __restrict__ grad_at_pixel, float* __restrict__ grad_sorted) {
     const int s = blockIdx.x / chunks_per_seg, k = blockIdx.x % chunks_per_seg;
     const long long base = (long long)s * P, i0 = (long long)k * CHUNK;
     const float G = (float)fg_total[s];
@@ -448,6 +448,16 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
             const float g = jk - jprev;                       // lovasz.py:32-33
             acc += (double)(fmaxf(e[u], 0.0f) * g);           // dot(relu(errors_sorted), grad), lovasz.py:71 / :139
             if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
+            e[u] = g;
+        }
+    }
+    if (grad_sorted) {      // the gradient in SORTED order (coalesced): binned by pixel block afterwards (ptb_lovasz_fwd_binned)
+        if (first + 8 <= P && ((base + first) & 3) == 0) {
+            *reinterpret_cast<float4*>(grad_sorted + base + first) = make_float4(e[0], e[1], e[2], e[3]);
+            *reinterpret_cast<float4*>(grad_sorted + base + first + 4) = make_float4(e[4], e[5], e[6], e[7]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (first + u < P) grad_sorted[base + first + u] = e[u];
         }
     }
     // One partial sum per workgroup, added up per segment by lovasz_segsum_kernel.  (Consecutive workgroups belong to the same
@@ -520,6 +530,59 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const LovArgs a, const 
     }
 }
 
+// backward from the BINNED gradient (ptb_lovasz_fwd_binned): block b of segment s -- its pixels b * bs .. b * bs + bs - 1 -- holds the
+// (index << 1 | fg, gradient at the pixel's rank) pairs of exactly these pixels in arbitrary order; a workgroup puts them in pixel order
+// in LDS and streams pred / grad like lovasz_bwd_kernel.  grid.x = group * blocks, grid.y = chunks of classes.
+template <int MODE>
+__global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a, const float* __restrict__ coef, const unsigned* __restrict__ bvals,
+                                                                const float* __restrict__ bgrad, float* __restrict__ grad, int bs_log2,
+                                                                int nblocks, int cchunk) {
+    extern __shared__ float gl[];
+    const int j = blockIdx.x / nblocks, blk = blockIdx.x % nblocks;
+    const int c0 = blockIdx.y * cchunk, c1 = min(a.C, c0 + cchunk);
+    const unsigned bs = 1u << bs_log2;
+    const long long i0 = (long long)blk << bs_log2;
+    const int cnt = (int)min((long long)bs, a.P - i0);
+    const unsigned HW = (unsigned)a.HW;
+    for (int c = c0; c < c1; ++c) {
+        const long long s = (long long)j * a.C + c;
+        const long long sb = s * a.P + i0;
+#pragma unroll 4
+        for (int u = threadIdx.x; u < cnt; u += 256) gl[(bvals[sb + u] >> 1) & (bs - 1u)] = bgrad[sb + u];
+        __syncthreads();
+        const float cf = coef[s];
+#pragma unroll 4
+        for (int u = threadIdx.x; u < cnt; u += 256) {
+            const unsigned i = (unsigned)(i0 + u);
+            const unsigned b = a.per_image ? (unsigned)j : i / HW;
+            const unsigned px = a.per_image ? i : i - b * HW;
+            const long long po = ((long long)b * a.C + c) * a.HW + px, lo = (long long)b * a.HW + px;
+            const float p = a.pred[po];
+            const float gp = gl[u];
+            float gx = 0.f;
+            if constexpr (MODE == LOVASZ_SOFTMAX) {
+                const long long lab = a.labels[lo];
+                const bool valid = !(a.has_ignore && lab == a.ignore_label);
+                const float fg = lab == c ? 1.f : 0.f;
+                const float e = fabsf(fg - p);
+                if (valid && e > 0.f) {
+                    const float g = cf * gp;
+                    const float d = p - fg;
+                    gx = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+                }
+            } else {
+                const float y = a.flabels[lo];
+                const bool valid = !(a.has_ignore && y == a.ignore_value);
+                const float sg = 2.0f * y - 1.0f;
+                const float e = 1.0f - p * sg;
+                if (valid && e > 0.f) gx = -(cf * gp) * sg;
+            }
+            __builtin_nontemporal_store(gx, &grad[po]);
+        }
+        __syncthreads();
+    }
+}
+
 // loss = mean over the groups of (sum over the selected classes of seg_loss / number of selected classes), and its derivative with
 // respect to every seg_loss (losses/lovasz.py:92-108, :110-140: classes = "present" | "all"; the hinge loss is C = 1, "all").  One
 // workgroup; thread = group, fixed summation order.
@@ -585,10 +648,17 @@ extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
 // chunk u32[S*ceil(P/2048)]; fg_total u32[S]; seg_loss double[S] (written here);
 // grad_at_pixel float[n] (kept for backward; NULL when no gradient will be asked for); temp = ptb_lovasz_temp_bytes bytes.
-extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
-                              int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
-                              unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
-                              double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
+// pixels per block of the binned gradient: >= 4096 and <= 256 blocks per segment; -1 when a block would not fit the LDS budget
+static int binned_block_log2(long long P) {
+    int l = 12;
+    while (((P + (1LL << l) - 1) >> l) > 256) ++l;
+    return l <= 14 ? l : -1;
+}
+
+static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                           int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
+                           unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
+                           double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream, bool binned) {
     LovArgs a{};
     if (int rc = fill(a, pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)) return rc;
     if (!keys_a || !keys_b || !vals_a || !vals_b || !chunk || !fg_total || !seg_loss) return PTB_EINVAL;
@@ -635,9 +705,73 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
     hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vin, a.P, cps, chunk);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
     double* partial = static_cast<double*>(temp);      // (the sort is done with its histograms: 1 KB per 4096-element tile, 16 B needed)
+    const int bl = binned ? binned_block_log2(a.P) : -1;
+    if (binned && (bl < 0 || !grad_at_pixel)) return PTB_EUNSUPPORTED;
     hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial,
-                       grad_at_pixel);
+                       binned ? (float*)nullptr : grad_at_pixel, binned ? grad_at_pixel : (float*)nullptr);
     hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
+    if (int rc = check_launch()) return rc;
+    if (binned) {
+        // one more scatter pass of the sort's own kernels, keyed by the pixel block: (index << 1 | fg, gradient) pairs sorted by error ->
+        // grouped by block of 2^bl pixels (positions s * P + block * 2^bl ...: every pixel occurs once).  16.7 M random 4-byte writes
+        // (177 us at [4,16,512,512]) become 64-byte runs (18 + 5 + 68 us) and an LDS placement in the backward kernel.
+        const int shift = bl + 1;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist);
+        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, vin, reinterpret_cast<const unsigned*>(grad_at_pixel), keys_b, vals_b,
+                           a.P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
+        if (int rc = check_launch()) return rc;
+        return bl;
+    }
+    return PTB_OK;
+}
+
+extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                              int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
+                              unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
+                              double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
+    return lovasz_fwd_impl(pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value, keys_a, keys_b, vals_a, vals_b,
+                           chunk, fg_total, seg_loss, grad_at_pixel, temp, temp_bytes, stream, false);
+}
+
+// Same, with the gradient left BINNED instead of scattered to pixel order: on return keys_b holds (index << 1 | fg) and vals_b the
+// gradient bits of the same element, grouped by blocks of 2^r pixels (r = the return value, 12..14; the pairs of block b of segment s
+// are at s * P + (b << r) ...).  `scratch` (float[n], required) is overwritten.  PTB_EUNSUPPORTED when a segment has more than
+// 256 * 2^14 elements: use ptb_lovasz_fwd.  ptb_lovasz_bwd_binned is its backward.
+extern "C" int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                                     int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
+                                     unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
+                                     double* seg_loss, float* scratch, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
+    if (!scratch) return PTB_EINVAL;
+    return lovasz_fwd_impl(pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value, keys_a, keys_b, vals_a, vals_b,
+                           chunk, fg_total, seg_loss, scratch, temp, temp_bytes, stream, true);
+}
+
+extern "C" int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const uint32_t* binned_vals,
+                                     const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode, int per_image, int has_ignore,
+                                     int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream) {
+    LovArgs a{};
+    if (int rc = fill(a, pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)) return rc;
+    if (!coef || !binned_vals || !binned_grad || !grad || block_log2 < 12 || block_log2 > 14) return PTB_EINVAL;
+    const long long n = a.P * a.S;
+    if (n == 0) return PTB_OK;
+    if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;
+    const long long nblocks = (a.P + (1LL << block_log2) - 1) >> block_log2;
+    if (nblocks > 256) return PTB_EINVAL;
+    const long long gx = (long long)(a.S / a.C) * nblocks;
+    int nch = (int)((2048 + gx - 1) / gx);
+    nch = nch < 1 ? 1 : (nch > a.C ? a.C : nch);
+    const int cchunk = (a.C + nch - 1) / nch;
+    nch = (a.C + cchunk - 1) / cchunk;
+    if (gx > 0x7fffffffLL || nch > 65535) return PTB_EUNSUPPORTED;
+    const size_t lds = sizeof(float) << block_log2;
+    const dim3 grid((unsigned)gx, (unsigned)nch);
+    if (a.mode == LOVASZ_SOFTMAX)
+        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, binned_vals, binned_grad, grad,
+                           block_log2, (int)nblocks, cchunk);
+    else
+        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_HINGE>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, binned_vals, binned_grad, grad,
+                           block_log2, (int)nblocks, cchunk);
     return check_launch();
 }
 

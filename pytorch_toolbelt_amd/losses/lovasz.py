@@ -17,6 +17,7 @@ __all__ = ["BinaryLovaszLoss", "LovaszLoss"]
 
 _SOFTMAX, _HINGE = 0, 1
 _CHUNK = 2048
+BINNED_GRADIENT = True     # False: the gradient is scattered to pixel order in the forward (ptb_lovasz_fwd / ptb_lovasz_bwd; A/B and tests)
 
 
 class _LovaszSegments(torch.autograd.Function):
@@ -41,6 +42,7 @@ class _LovaszSegments(torch.autograd.Function):
         # want_grad False (the caller saw no_grad / a detached input): forward only, the per-pixel gradient is never written
         want_grad = bool(want_grad and ctx.needs_input_grad[0])
         gpix = torch.empty(max(n, 1) if want_grad else 0, dtype=torch.float32, device=dev)
+        binned = None
         if n > 0:
             lib = N.load()
             keys = torch.empty((2, n), dtype=torch.int32, device=dev)
@@ -51,10 +53,21 @@ class _LovaszSegments(torch.autograd.Function):
                 if tb < 0:
                     raise RuntimeError("ptb_lovasz_temp_bytes failed")
                 temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
-                rc = lib.ptb_lovasz_fwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
-                                        1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
-                                        vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
-                                        seg_loss.data_ptr(), gpix.data_ptr() if want_grad else None, temp.data_ptr(), int(tb), N.stream_ptr(dev))
+                args = (pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
+                        1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
+                        vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
+                        seg_loss.data_ptr(), gpix.data_ptr() if want_grad else None, temp.data_ptr(), int(tb), N.stream_ptr(dev))
+                rc = N.PTB_EUNSUPPORTED
+                if want_grad and BINNED_GRADIENT:
+                    # the gradient stays binned by pixel block (one more pass of the sort's scatter instead of n random writes);
+                    # keys[1] / vals[1] hold the pairs for the backward kernel, gpix was only scratch
+                    rc = lib.ptb_lovasz_fwd_binned(*args)
+                    if rc >= 0:
+                        binned = (vals[1], keys[1], int(rc))
+                        gpix = torch.empty(0, dtype=torch.float32, device=dev)
+                        rc = 0
+                if rc == N.PTB_EUNSUPPORTED:
+                    rc = lib.ptb_lovasz_fwd(*args)
             N.bump()
             N.check(rc, "ptb_lovasz_fwd")
         coef_unit = None
@@ -66,21 +79,33 @@ class _LovaszSegments(torch.autograd.Function):
                                                 coef_unit.data_ptr(), N.stream_ptr(dev))
             N.check(rc, "ptb_lovasz_reduce")
             seg_loss = loss
-        ctx.save_for_backward(pred, labels, flabels, gpix, coef_unit)
+        if binned is not None:
+            ctx.save_for_backward(pred, labels, flabels, gpix, coef_unit, binned[0], binned[1])
+        else:
+            ctx.save_for_backward(pred, labels, flabels, gpix, coef_unit)
+        ctx.block_log2 = binned[2] if binned is not None else None
         ctx.cfg = (B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)
         ctx.mark_non_differentiable(fg_total)
         return seg_loss, fg_total
 
     @staticmethod
     def backward(ctx, g_loss, _g_fg):
-        pred, labels, flabels, gpix, coef_unit = ctx.saved_tensors
+        if ctx.block_log2 is not None:
+            pred, labels, flabels, gpix, coef_unit, bgrad, bvals = ctx.saved_tensors
+        else:
+            pred, labels, flabels, gpix, coef_unit = ctx.saved_tensors
         B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value = ctx.cfg
         grad = torch.empty_like(pred)          # (the kernel writes every element)
         if pred.numel():
             coef = (g_loss.to(torch.float32) * coef_unit if coef_unit is not None else g_loss.to(torch.float32)).contiguous()
             lib = N.load()
             with N.on_device(pred.device):
-                rc = lib.ptb_lovasz_bwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), gpix.data_ptr(), grad.data_ptr(),
+                if ctx.block_log2 is not None:
+                    rc = lib.ptb_lovasz_bwd_binned(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), bvals.data_ptr(), bgrad.data_ptr(),
+                                                   grad.data_ptr(), B, C, HW, mode, 1 if per_image else 0, 1 if has_ignore else 0, ignore_label,
+                                                   ignore_value, ctx.block_log2, N.stream_ptr(pred.device))
+                else:
+                    rc = lib.ptb_lovasz_bwd(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), gpix.data_ptr(), grad.data_ptr(),
                                         B, C, HW, mode, 1 if per_image else 0, 1 if has_ignore else 0, ignore_label, ignore_value,
                                         N.stream_ptr(pred.device))
             N.bump()

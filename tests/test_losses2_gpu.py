@@ -437,3 +437,35 @@ def test_lovasz_reduce_kernel_and_pixel_backward(B, C, H, W, dev):
             d = torch.randn(xa.shape, generator=g).to(dev) * 1e-4
             lb = LV._lovasz_hinge(xa.detach() + d, yy.to(dev), per_image=per_image, ignore_index=ignore)
             assert float(lb - la) == pytest.approx(float((xa.grad * d).sum()), rel=5e-2, abs=2e-7)
+
+
+@pytest.mark.parametrize("B,C,H,W,per_image", [(3, 5, 37, 29, False), (2, 3, 64, 70, True), (1, 2, 5, 3, False), (2, 4, 96, 96, False), (1, 2, 1024, 1030, False)])
+def test_lovasz_binned_gradient_equals_scattered_gradient(B, C, H, W, per_image, dev):
+    """The gradient at every pixel's rank reaches the backward kernel either scattered to pixel order by the forward (ptb_lovasz_fwd /
+    ptb_lovasz_bwd) or binned by blocks of 2^12 .. 2^14 pixels by one more pass of the sort's scatter and put in order in LDS
+    (ptb_lovasz_fwd_binned / ptb_lovasz_bwd_binned; 1024 x 1030 pixels: 2^13).  The same values either way: equal bits."""
+    from pytorch_toolbelt_amd.losses import lovasz as LV
+
+    g = torch.Generator().manual_seed(B * 10 + C)
+    probs = torch.softmax(torch.randn((B, C, H, W), generator=g) * 2, 1).to(dev)
+    lab = torch.randint(0, C, (B, H, W), generator=g).to(dev)
+    lab[0, 0, : W // 2] = 255
+    x = torch.randn((B, H, W), generator=g).to(dev)
+    y = (torch.rand((B, H, W), generator=g) < 0.4).float().to(dev)
+    y[0, -1, :2] = 255.0
+    grads = {}
+    for binned in (True, False):
+        prev, LV.BINNED_GRADIENT = LV.BINNED_GRADIENT, binned
+        try:
+            xa = probs.clone().requires_grad_(True)
+            la = LV._lovasz_softmax(xa, lab, per_image=per_image, ignore_index=255)
+            (la * 1.5).backward()
+            xb = x.clone().requires_grad_(True)
+            lb = LV._lovasz_hinge(xb, y, per_image=per_image, ignore_index=255)
+            lb.backward()
+            grads[binned] = (float(la), xa.grad, float(lb), xb.grad)
+        finally:
+            LV.BINNED_GRADIENT = prev
+    assert grads[True][0] == grads[False][0] and grads[True][2] == grads[False][2]
+    assert torch.equal(grads[True][1], grads[False][1]) and torch.equal(grads[True][3], grads[False][3])
+    assert float(grads[True][1].abs().sum()) > 0 and float(grads[True][3].abs().sum()) > 0
