@@ -544,6 +544,63 @@ __global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a,
     const long long i0 = (long long)blk << bs_log2;
     const int cnt = (int)min((long long)bs, a.P - i0);
     const unsigned HW = (unsigned)a.HW;
+    if (bs_log2 == 12 && cnt == 4096) {
+        // the common block (4096 pixels, 16 per thread): everything a class needs is requested before it is used, and the pixel's
+        // label / offset is computed once for all the classes of the chunk
+        unsigned off0[16];
+        int labv[MODE == LOVASZ_SOFTMAX ? 16 : 1];
+        float yv[MODE == LOVASZ_HINGE ? 16 : 1];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const unsigned i = (unsigned)i0 + threadIdx.x + 256u * m;
+            const unsigned b = a.per_image ? (unsigned)j : i / HW;
+            const unsigned px = a.per_image ? i : i - b * HW;
+            off0[m] = b * (unsigned)a.C * HW + px;
+            const long long lo = (long long)b * a.HW + px;
+            if constexpr (MODE == LOVASZ_SOFTMAX) {
+                const long long L = a.labels[lo];
+                labv[m] = (a.has_ignore && L == a.ignore_label) ? -2 : ((L >= 0 && L < a.C) ? (int)L : -1);
+            } else {
+                yv[m] = a.flabels[lo];
+            }
+        }
+        for (int c = c0; c < c1; ++c) {
+            const long long s = (long long)j * a.C + c;
+            const long long sb = s * a.P + i0;
+            unsigned bv[16];
+            float bg[16], pv[16];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) { bv[m] = bvals[sb + threadIdx.x + 256 * m]; bg[m] = bgrad[sb + threadIdx.x + 256 * m]; }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) pv[m] = a.pred[off0[m] + (unsigned)c * HW];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) gl[(bv[m] >> 1) & 4095u] = bg[m];
+            __syncthreads();
+            const float cf = coef[s];
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                const float p = pv[m], gp = gl[threadIdx.x + 256 * m];
+                float gx = 0.f;
+                if constexpr (MODE == LOVASZ_SOFTMAX) {
+                    const float fg = labv[m] == c ? 1.f : 0.f;
+                    const float e = fabsf(fg - p);
+                    if (labv[m] != -2 && e > 0.f) {
+                        const float g = cf * gp;
+                        const float d = p - fg;
+                        gx = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+                    }
+                } else {
+                    const float y = yv[m];
+                    const float sg = 2.0f * y - 1.0f;
+                    const float e = 1.0f - p * sg;
+                    if (!(a.has_ignore && y == a.ignore_value) && e > 0.f) gx = -(cf * gp) * sg;
+                }
+                __builtin_nontemporal_store(gx, &grad[off0[m] + (unsigned)c * HW]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (int c = c0; c < c1; ++c) {
         const long long s = (long long)j * a.C + c;
         const long long sb = s * a.P + i0;
