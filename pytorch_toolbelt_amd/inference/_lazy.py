@@ -23,6 +23,10 @@ What a caller could observe, and how it is bounded:
 * evaluation happens on the stream that is current *then*; when that is not the stream of the call the source is
   ``record_stream``-ed.
 
+Code that takes the storage of a tensor without passing through the dispatcher or ``__torch_function__`` -- a pybind11 function
+with an ``at::Tensor`` argument, the legacy ``torch.utils.dlpack.to_dlpack`` (guarded here, see ``_guard_legacy_dlpack``) -- sees a
+tensor without storage, as with every wrapper subclass (``FakeTensor``, ``DTensor``); hand it ``handle + 0`` or switch the handles off.
+
 Only inference-shaped calls are lazy (float32 CUDA source, string reduction, no autograd, no tracing / compiling);
 everything else is evaluated on the spot exactly as before.  ``tta.set_lazy_deaugment(False)`` / ``PTB_LAZY_DEAUG=0``
 switch it off.
@@ -171,7 +175,8 @@ class LazyDeaugment(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        if func in _META_FUNCS:
+        if func in _META_FUNCS and args and type(args[0]) is LazyDeaugment and args[0]._value is None:
+            # (only while nothing was computed: afterwards requires_grad / grad / grad_fn / is_leaf are those of the value)
             with torch._C.DisableTorchFunctionSubclass():
                 return func(*args, **kwargs)
         # (flat argument lists -- almost every call -- are unwrapped by hand: tree_map costs ~10 us per call)
@@ -192,6 +197,29 @@ class LazyDeaugment(torch.Tensor):
 
 def _unwrap(x):
     return x._evaluate() if type(x) is LazyDeaugment else x
+
+
+def _guard_legacy_dlpack():
+    """``torch.utils.dlpack.to_dlpack`` is a bare C function: it reads the storage of what it is given without passing
+    ``__torch_function__``, and a handle has none (the capsule would carry a null pointer).  The module attribute is replaced by a
+    wrapper that evaluates a handle first; ``torch.from_dlpack(handle)`` / ``handle.__dlpack__()`` never needed it."""
+    import torch.utils.dlpack as D
+
+    orig = D.to_dlpack
+    if getattr(orig, "_ptb_lazy_guard", False):
+        return
+
+    def to_dlpack(tensor):
+        return orig(tensor._evaluate() if type(tensor) is LazyDeaugment else tensor)
+
+    to_dlpack.__doc__ = getattr(orig, "__doc__", None)
+    to_dlpack._ptb_lazy_guard = True
+    D.to_dlpack = to_dlpack
+    if getattr(torch, "to_dlpack", None) is orig:
+        torch.to_dlpack = to_dlpack
+
+
+_guard_legacy_dlpack()
 
 
 def maybe_lazy(source, group, views, code, compute):
