@@ -68,10 +68,13 @@ def _source_version(t):
 
 def _forget(key):
     global _pending_bytes
-    with _lock:
-        ent = _pending.pop(key, None)
-        if ent is not None:
-            _pending_bytes -= ent[1]
+    try:
+        with _lock:
+            ent = _pending.pop(key, None)
+            if ent is not None:
+                _pending_bytes -= ent[1]
+    except TypeError:      # interpreter shutdown: the module's globals are already gone when the last handles die
+        pass
 
 
 def _admit(handle, nbytes):
@@ -152,14 +155,17 @@ class LazyDeaugment(torch.Tensor):
         value = self._value
         if value is None:
             global evaluations
-            self._check_source()
-            self._note_stream()
-            with torch._C.DisableTorchFunctionSubclass():
-                value = self._compute(self._src, self._views, self._code)
-            self._value = value
-            self._src = None
-            _forget(id(self))
-            evaluations += 1
+            with _lock:                      # two threads using one handle must end up with ONE value (in-place operations act on it)
+                value = self._value
+                if value is None:
+                    self._check_source()
+                    self._note_stream()
+                    with torch._C.DisableTorchFunctionSubclass():
+                        value = self._compute(self._src, self._views, self._code)
+                    self._value = value
+                    self._src = None
+                    _forget(id(self))
+                    evaluations += 1
         return value
 
     def _take_source(self):
