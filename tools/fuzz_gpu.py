@@ -7,7 +7,10 @@
    against the oracle (the test function of tests/test_tiles_gpu.py with more seeds);
 2. fused de-augment merges over random groups x reductions x input dtypes x planned-or-not, 2e-5 relative;
 3. the elementwise losses and soft cross entropy over random (odd) shapes and options against the float64 oracle;
-4. deferred band merging vs the incremental merger (bit-exact), 5. Dice / Jaccard / fused region losses vs the fp64 oracle.
+4. deferred band merging vs the incremental merger (bit-exact), 5. Dice / Jaccard / fused region losses vs the fp64 oracle;
+6. Lovasz losses (value vs the fp64 oracle, gradient vs torch-CPU autograd through the reference's op chain, binned vs scattered
+   gradient); 7. the reference's literal calls (lazy handle + self-planning merger) vs the eager unplanned path, bit for bit.
+   A third argument selects fuzzers: modes,fused,losses,deferred,region,lovasz,literal.
 Prints one line per failure and a summary; exit code 1 on any failure."""
 import os
 import sys
@@ -216,10 +219,125 @@ def fuzz_region_losses(seeds):
     return bad
 
 
+def fuzz_lovasz(seeds):
+    """LovaszLoss / BinaryLovaszLoss over random shapes and options: the value against the fp64 oracle, the gradient against torch-CPU
+    autograd through the reference's op chain (oracle/torch_chain.py), binned against scattered gradient bit for bit."""
+    from oracle import losses_oracle as LO
+    from oracle import torch_chain as TC
+    from pytorch_toolbelt_amd.losses import lovasz as LV
+
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        B, C = int(rng.integers(1, 4)), int(rng.integers(2, 9))
+        H, W = (int(rng.integers(1, 30)), int(rng.integers(1, 30))) if seed % 3 else (int(rng.integers(60, 100)), int(rng.integers(60, 100)))
+        per_image, ign = bool(seed % 2), [None, 255][(seed // 2) % 2]
+        classes = ["present", "all"][(seed // 4) % 2]
+        logits = (rng.standard_normal((B, C, H, W)) * rng.choice([1.0, 4.0])).astype(np.float32)
+        probs = torch.softmax(torch.from_numpy(logits), 1)
+        lab = rng.integers(0, C, (B, H, W))
+        lab[lab == C - 1] = 0
+        if ign is not None:
+            lab[rng.random((B, H, W)) < 0.1] = 255
+        labt = torch.from_numpy(lab)
+        try:
+            want = LO.lovasz_softmax(probs.numpy(), lab, classes=classes, per_image=per_image, ignore_index=ign)
+            grads = {}
+            for binned in (True, False):
+                prev, LV.BINNED_GRADIENT = LV.BINNED_GRADIENT, binned
+                try:
+                    xg = probs.to(dev).requires_grad_(True)
+                    got = LV._lovasz_softmax(xg, labt.to(dev), classes=classes, per_image=per_image, ignore_index=ign)
+                    got.backward()
+                    grads[binned] = xg.grad
+                finally:
+                    LV.BINNED_GRADIENT = prev
+            assert abs(float(got.detach()) - float(want)) <= 1e-5 * (1 + abs(float(want))), ("value", float(got.detach()), float(want))
+            assert torch.equal(grads[True], grads[False]), "binned gradient differs from the scattered one"
+            if classes == "present":      # (the op chain of the reference skips absent classes)
+                xc = probs.clone().requires_grad_(True)
+                groups = [(xc[b:b + 1], labt[b:b + 1]) for b in range(B)] if per_image else [(xc, labt)]
+                total, ties = 0.0, False
+                for pg, lg in groups:
+                    flat = pg.movedim(1, -1).reshape(-1, C)
+                    ll = lg.reshape(-1)
+                    if ign is not None:
+                        keep = ll != ign
+                        flat, ll = flat[keep], ll[keep]
+                    if flat.numel():
+                        total = total + TC.lovasz_softmax(flat.t().reshape(1, C, -1, 1), ll.reshape(1, -1, 1))
+                        with torch.no_grad():      # equal errors inside a class: which of the tied pixels gets which gradient is the sort's choice
+                            for c in range(C):
+                                err = ((ll == c).float() - flat[:, c]).abs()
+                                ties = ties or err.unique().numel() < err.numel()
+                if torch.is_tensor(total) and not ties:
+                    (total / len(groups)).backward()
+                    # (a gradient element is J_k - J_{k-1} of two fp32 Jaccard values near 0.5: a few ulps of those, up to ~6e-7, in absolute terms)
+                    assert torch.allclose(grads[True].cpu(), xc.grad, rtol=1e-3, atol=1e-6), ("gradient", float((grads[True].cpu() - xc.grad).abs().max()))
+            x = (rng.standard_normal((B, H, W)) * 2).astype(np.float32)
+            y = (rng.random((B, H, W)) < 0.4).astype(np.float32)
+            if ign is not None:
+                y[rng.random((B, H, W)) < 0.1] = 255.0
+            wantb = LO.lovasz_hinge(x, y, per_image=per_image, ignore_index=ign)
+            gotb = LV._lovasz_hinge(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), per_image=per_image, ignore_index=ign)
+            assert abs(float(gotb) - float(wantb)) <= 1e-5 * (1 + abs(float(wantb))), ("hinge", float(gotb), float(wantb))
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("lovasz FAIL seed", seed, (B, C, H, W), per_image, ign, classes, repr(e)[:300])
+    return bad
+
+
+def fuzz_literal(seeds):
+    """The reference's literal calls (lazy de-augment handle into a self-planning TileMerger, a new merger per image) over random
+    geometries: bit for bit against the eager unplanned path, three images per geometry (the plan is used from the second on)."""
+    import test_dropin_gpu as D
+    from pytorch_toolbelt_amd.inference import _lazy, tiles
+
+    bad = 0
+    prev_l, prev_a = _lazy.set_enabled(True), tiles.set_auto_plan(True)
+    try:
+        for seed in seeds:
+            rng = np.random.default_rng(seed)
+            group = ["d4", "d2", "flips", "fliplr", "flipud"][seed % 5]
+            red = ["mean", "sum", "gmean", "hmean"][seed % 4]
+            th = int(rng.choice([32, 64, 96, 128]))
+            tw = th if group == "d4" else int(rng.choice([32, 64, 128]))
+            step = (int(rng.choice([v for v in (16, 32, 48, 64, 128) if v <= th])), int(rng.choice([v for v in (16, 32, 64, 128) if v <= tw])))
+            shape = (int(rng.integers(th, 3 * th + 20)), int(rng.integers(tw, 3 * tw + 20)))
+            C, batch = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+            V = D.GROUPS[group]
+            geom = TO.slicer_geometry(shape, (th, tw), step)
+            crops, n = geom["crops"], len(geom["crops"])
+            w = TO.pyramid_window(th, tw)[0]
+            try:
+                for image in range(3):
+                    g = torch.Generator(device="cpu").manual_seed(seed * 10 + image)
+                    outputs = (torch.rand((V * n, C, th, tw), generator=g) * 0.9 + 0.05).to(dev)
+                    _lazy.set_enabled(True)
+                    tiles.set_auto_plan(True)
+                    got = D._run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch, True, group, red)
+                    _lazy.set_enabled(False)
+                    tiles.set_auto_plan(False)
+                    want = D._run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch, True, group, red)
+                    same = torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+                    assert same, ("image", image, float((got - want).abs().nan_to_num().max()))
+            except Exception as e:  # noqa: BLE001
+                bad += 1
+                print("literal FAIL seed", seed, group, red, shape, (th, tw), step, C, batch, repr(e)[:300])
+    finally:
+        _lazy.set_enabled(prev_l)
+        tiles.set_auto_plan(prev_a)
+    return bad
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     seeds = range(first, first + count)
-    total = fuzz_merger_modes(seeds) + fuzz_fused(seeds) + fuzz_losses(seeds) + fuzz_deferred(seeds) + fuzz_region_losses(seeds)
-    print(f"fuzz: {5 * count} cases, {total} failures")
+    only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
+    fuzzers = {"modes": fuzz_merger_modes, "fused": fuzz_fused, "losses": fuzz_losses, "deferred": fuzz_deferred, "region": fuzz_region_losses,
+               "lovasz": fuzz_lovasz, "literal": fuzz_literal}
+    run = [f for k, f in fuzzers.items() if only is None or k in only]
+    total = sum(f(seeds) for f in run)
+    print(f"fuzz: {len(run) * count} cases, {total} failures")
     sys.exit(1 if total else 0)
