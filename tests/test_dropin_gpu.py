@@ -295,6 +295,49 @@ def test_new_merger_per_image_plans_itself_from_the_second_image(dev, lazy, auto
     assert np.nanmax(np.abs(got.cpu().numpy() - _oracle_image(geom, C, w, outputs, batch))) <= 1e-5
 
 
+def test_literal_loop_from_two_threads_on_two_streams(dev, lazy, autoplan):
+    """Two threads, each on its own stream, run the literal loop on the SAME geometry at the same time (a new merger per image: they
+    share the module's plan cache, the window cache and the lazy bookkeeping); every image equals the serial, eager result."""
+    import threading
+
+    geom = TO.slicer_geometry((700, 900), (128, 128), (64, 64))
+    crops, w = geom["crops"], TO.pyramid_window(128, 128)[0]
+    C, images = 3, 8
+    outs = [torch.rand((8 * len(crops), C, 128, 128), device=dev) for _ in range(images)]
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+
+    lazy.set_enabled(False)
+    autoplan.set_auto_plan(False)
+    serial = [_run_image(TileMerger(geom["target_shape"], C, w, device=dev), o, crops, 8) for o in outs]
+    lazy.set_enabled(True)
+    autoplan.set_auto_plan(True)
+    torch.cuda.synchronize()
+    results, errors = {}, []
+
+    def worker(t):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                for rep in range(3):
+                    for k in range(t, images, 2):
+                        results[(rep, k)] = _run_image(TileMerger(geom["target_shape"], C, w, device=dev), outs[k], crops, 8)
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert len(results) == 3 * images
+    for (rep, k), got in results.items():
+        assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(serial[k], nan=-7.0)), (rep, k)
+
+
 def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((384, 384), 128, 64)
