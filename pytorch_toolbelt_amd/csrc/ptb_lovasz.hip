@@ -75,24 +75,6 @@ __device__ __forceinline__ unsigned match_digit(unsigned d, int lane, unsigned& 
     return __popc(m_lo) + __popc(m_hi);
 }
 
-// inclusive scan of one value per thread over the 256 threads of the workgroup (wave shuffles + 4 wave totals in LDS)
-__device__ __forceinline__ unsigned block_inclusive_scan(unsigned v, unsigned* wave_tot /* [4] LDS */, unsigned& total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    __syncthreads();                       // (wave_tot may still be read from a previous call)
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    unsigned off = 0;
-    for (int w = 0; w < wave; ++w) off += wave_tot[w];
-    total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    return incl + off;
-}
-
 // Workgroup -> linear tile.  Workgroups go to the 8 XCDs round-robin by blockIdx, and every XCD has its own L2: with the identity
 // mapping the tiles t, t+1, ... whose digit runs are neighbours in the output are written through 8 different L2s and every 64-byte
 // run reaches HBM as its own partial line.  xcd_map gives XCD x a contiguous range of tiles, so neighbouring runs meet in one
@@ -256,12 +238,32 @@ __global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__
     span_tot[((long long)seg * spans + span) * 256 + threadIdx.x] = run;
 }
 
-// pass step 3: stable scatter of one tile
-__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
-                                                         unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
-                                                         int shift, const unsigned* __restrict__ hist, int spans,
-                                                         const unsigned* __restrict__ span_tot, int xcd_map) {
-    __shared__ unsigned wave_hist[4][256];   // per wave: running digit counts, then the wave's start inside the tile's digit run
+// pass step 3: stable scatter of one tile.  NW waves per workgroup share the tile's 4096 elements: wave w owns elements
+// w * 4096/NW ..., its item j the 64 consecutive ones behind j * 64 (rank order = (wave, item, lane) = index order).
+template <int NW>
+__device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned* wave_tot /* [NW] LDS */) {   // over the first 256 threads' values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    __syncthreads();                       // (wave_tot may still be read from a previous call)
+    if (lane == 63 && wave < 4) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned off = 0;
+    for (int w = 0; w < wave && w < 4; ++w) off += wave_tot[w];
+    return incl + off;
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
+                                                             unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
+                                                             int shift, const unsigned* __restrict__ hist, int spans,
+                                                             const unsigned* __restrict__ span_tot, int xcd_map) {
+    constexpr int ITEMS = RS_TILE / (NW * 64), SPAN = 64 * ITEMS, NT = NW * 64;
+    __shared__ unsigned wave_hist[NW][256];  // per wave: running digit counts, then the wave's start inside the tile's digit run
     __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
     __shared__ unsigned wave_tot[4];
@@ -273,12 +275,14 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
     const long long base = (long long)seg * P;
     const long long left = P - t0;
     const int count = left < RS_TILE ? (int)left : RS_TILE;
+    if (threadIdx.x < 256) {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wave_hist[w][threadIdx.x] = 0;
-    unsigned k[RS_ITEMS], v[RS_ITEMS], rank[RS_ITEMS];
+        for (int w = 0; w < NW; ++w) wave_hist[w][threadIdx.x] = 0;
+    }
+    unsigned k[ITEMS], v[ITEMS], rank[ITEMS];
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = wave * SPAN + j * 64 + lane;
         // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
         // (they are the last in tile order and the sort is stable) and are never written
         k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
         unsigned below;
         const unsigned group = match_digit(d, lane, below);
@@ -297,33 +301,40 @@ __global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restr
         rank[j] = old + below;                                      // rank among the wave's elements with this digit, in order
     }
     __syncthreads();
-    // per digit (thread = digit): waves' starts inside the run, the tile's count, the run's start inside the tile and in the output
-    const unsigned c0 = wave_hist[0][threadIdx.x], c1 = wave_hist[1][threadIdx.x], c2 = wave_hist[2][threadIdx.x], c3 = wave_hist[3][threadIdx.x];
-    wave_hist[0][threadIdx.x] = 0; wave_hist[1][threadIdx.x] = c0; wave_hist[2][threadIdx.x] = c0 + c1; wave_hist[3][threadIdx.x] = c0 + c1 + c2;
-    const unsigned tot = c0 + c1 + c2 + c3;
-    unsigned total;
-    const unsigned excl = block_inclusive_scan(tot, wave_tot, total) - tot;
-    // this digit's elements in earlier spans of the segment, and in the whole segment
-    unsigned before = 0, rs = 0;
-    const int my_span = tile / RS_SPAN;
-    for (int sp = 0; sp < spans; ++sp) {
-        const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
-        before += sp < my_span ? c : 0u;
-        rs += c;
+    // per digit (thread = digit, the first 256 threads): waves' starts inside the run, the tile's count, the run's start inside the tile
+    // and in the output
+    unsigned tot = 0, rs = 0, before = 0;
+    if (threadIdx.x < 256) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned c = wave_hist[w][threadIdx.x];
+            wave_hist[w][threadIdx.x] = tot;
+            tot += c;
+        }
+        // this digit's elements in earlier spans of the segment, and in the whole segment
+        const int my_span = tile / RS_SPAN;
+        for (int sp = 0; sp < spans; ++sp) {
+            const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
+            before += sp < my_span ? c : 0u;
+            rs += c;
+        }
     }
-    const unsigned dstart = block_inclusive_scan(rs, wave_tot, total) - rs;   // elements of the segment with a smaller digit
-    tile_off[threadIdx.x] = excl;
-    digit_base[threadIdx.x] = dstart + before + hist[((long long)seg * T + tile) * 256 + threadIdx.x] - excl;
+    const unsigned excl = block_inclusive_scan_n<NW>(tot, wave_tot) - tot;
+    const unsigned dstart = block_inclusive_scan_n<NW>(rs, wave_tot) - rs;   // elements of the segment with a smaller digit
+    if (threadIdx.x < 256) {
+        tile_off[threadIdx.x] = excl;
+        digit_base[threadIdx.x] = dstart + before + hist[((long long)seg * T + tile) * 256 + threadIdx.x] - excl;
+    }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
         const unsigned slot = tile_off[d] + wave_hist[wave][d] + rank[j];
         skey[slot] = k[j];
         sval[slot] = v[j];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < count; i += 256) {
+    for (int i = threadIdx.x; i < count; i += NT) {
         const unsigned kk = skey[i];
         const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
         keys_out[pos] = kk;
@@ -683,6 +694,11 @@ static int fill(LovArgs& a, const float* pred, const int64_t* labels, const floa
 }
 
 int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in the radix scatter
+static void launch_scatter(unsigned tiles, hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, long long P, int T,
+                           int shift, const unsigned* hist, int spans, const unsigned* span_tot) {
+    // (8 waves per workgroup -- 8 items per thread, 64 VGPRs, 24 waves per CU instead of 16 -- measured 4 % slower: more waves do not help this pass)
+    hipLaunchKernelGGL(rs_scatter_kernel<4>, dim3(tiles), dim3(256), 0, s, kin, vin, kout, vout, P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
+}
 
 static int blocks_for(long long n) {
     const long long want = (n + 255) / 256;
@@ -753,7 +769,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
     for (int shift = 0; shift < 32; shift += 8) {
         if (shift) hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
+        launch_scatter((unsigned)tiles, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
@@ -775,8 +791,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         const int shift = bl + 1;
         hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3((unsigned)tiles), dim3(256), 0, s, vin, reinterpret_cast<const unsigned*>(grad_at_pixel), keys_b, vals_b,
-                           a.P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
+        launch_scatter((unsigned)tiles, s, vin, reinterpret_cast<const unsigned*>(grad_at_pixel), keys_b, vals_b, a.P, T, shift, hist, spans, span_tot);
         if (int rc = check_launch()) return rc;
         return bl;
     }
