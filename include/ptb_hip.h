@@ -544,7 +544,7 @@ int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabel
 /* ptb_lovasz_fwd with the gradient left BINNED instead of scattered to pixel order (16.7 M random 4-byte writes at [4,16,512,512]
  * become one more pass of the sort's scatter): on return keys_b[] holds (index << 1 | fg) and vals_b[] the fp32 gradient bits of the
  * same element, grouped by blocks of 2^r pixels, r = the RETURN VALUE (12..14): the pairs of block b of segment s are at
- * s*P + (b << r) ..., in arbitrary order inside the block.  scratch = float[n] (overwritten).  PTB_EUNSUPPORTED when a segment
+ * s*P + (b << r) ..., in arbitrary order inside the block.  scratch is unused (may be NULL).  PTB_EUNSUPPORTED when a segment
  * has more than 256 * 2^14 elements (use ptb_lovasz_fwd).  ptb_lovasz_bwd_binned consumes (keys_b, vals_b, r). */
 int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                           int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,

@@ -87,7 +87,12 @@ __device__ __forceinline__ unsigned tile_of_block(int xcd_map) {
 }
 
 // pass step 1: digit histogram of every tile -> hist[(seg * T + tile) * 256 + digit]  (one coalesced 1 KiB row per tile)
-__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist) {
+// COUNT (the binning pass of the gradient, keys = the sorted index << 1 | fg values): also the foreground count of the tile's two
+// CHUNKs -> chunk_count (what lovasz_count_kernel computes from one more read of the same array).
+template <bool COUNT>
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist,
+                                                      unsigned* __restrict__ chunk_count, int chunks_per_seg) {
+    static_assert(RS_TILE == 2 * CHUNK && RS_WAVE_SPAN * 2 == CHUNK, "a tile is two chunks, a chunk two waves");
     // counts only, no order: LDS atomics (ds_add_u32 without return).  Four copies per wave (lane & 3) keep the same-address
     // serialisation short when the digit is nearly constant (the exponent byte of probabilities); a wave whose 64 keys share
     // one digit adds 64 from a single lane.
@@ -121,6 +126,13 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
             atomicAdd(&h[wave][lane & 3][d], 1u);
         }
     }
+    __shared__ unsigned wfg[4];
+    if constexpr (COUNT) {
+        unsigned fgs = 0;
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) fgs += (unsigned)__popcll(__ballot((wave * RS_WAVE_SPAN + j * 64 + lane < left) && (k[j] & 1u)));
+        if (lane == 0) wfg[wave] = fgs;
+    }
     __syncthreads();
     unsigned tot = 0;
 #pragma unroll
@@ -128,6 +140,10 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
 #pragma unroll
         for (int c = 0; c < 4; ++c) tot += h[w][c][threadIdx.x];
     hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
+    if constexpr (COUNT) {
+        if (threadIdx.x < 2 && tile * 2 + (int)threadIdx.x < chunks_per_seg)
+            chunk_count[(long long)seg * chunks_per_seg + tile * 2 + threadIdx.x] = wfg[2 * threadIdx.x] + wfg[2 * threadIdx.x + 1];
+    }
 }
 
 // The error kernel and the first pass's histogram kernel in one: a workgroup owns the 4096 pixels of one tile position of a group
@@ -238,6 +254,12 @@ __global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__
     span_tot[((long long)seg * spans + span) * 256 + threadIdx.x] = run;
 }
 
+__device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // lovasz.py:29-31 at sorted position k (k1 = k+1)
+    const float inter = G - cum;
+    const float uni = G + (k1 - cum);
+    return 1.0f - inter / uni;
+}
+
 // pass step 3: stable scatter of one tile.  NW waves per workgroup share the tile's 4096 elements: wave w owns elements
 // w * 4096/NW ..., its item j the 64 consecutive ones behind j * 64 (rank order = (wave, item, lane) = index order).
 template <int NW>
@@ -257,11 +279,17 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
     return incl + off;
 }
 
-template <int NW>
+// GRAD (the binning pass of the gradient: keys_in = the sorted index << 1 | fg values): the value carried with a key is not loaded
+// but computed -- the Lovasz gradient at the element's sorted position, from the foreground count before it (chunk_off + the count
+// inside the tile) exactly as lovasz_dot_kernel computes it.
+template <int NW, bool GRAD>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                              unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
                                                              int shift, const unsigned* __restrict__ hist, int spans,
-                                                             const unsigned* __restrict__ span_tot, int xcd_map) {
+                                                             const unsigned* __restrict__ span_tot, int xcd_map,
+                                                             const unsigned* __restrict__ chunk_off, const unsigned* __restrict__ fg_total,
+                                                             int chunks_per_seg) {
+    static_assert(!GRAD || NW == 4, "the gradient variant counts foreground per pair of waves (= one CHUNK)");
     constexpr int ITEMS = RS_TILE / (NW * 64), SPAN = 64 * ITEMS, NT = NW * 64;
     __shared__ unsigned wave_hist[NW][256];  // per wave: running digit counts, then the wave's start inside the tile's digit run
     __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
@@ -286,9 +314,36 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
         // (they are the last in tile order and the sort is stable) and are never written
         k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
-        v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+        if constexpr (!GRAD) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+    }
+    __shared__ unsigned wfg[NW];
+    if constexpr (GRAD) {
+        unsigned fgs = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) fgs += (unsigned)__popcll(__ballot((wave * SPAN + j * 64 + lane < count) && (k[j] & 1u)));
+        if (lane == 0) wfg[wave] = fgs;
     }
     __syncthreads();
+    if constexpr (GRAD) {
+        const int chunk = tile * 2 + (wave >> 1);
+        unsigned cum = (chunk < chunks_per_seg ? chunk_off[(long long)seg * chunks_per_seg + chunk] : 0u) + ((wave & 1) ? wfg[wave - 1] : 0u);
+        const float G = (float)fg_total[seg];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = wave * SPAN + j * 64 + lane;
+            const bool ok = idx < count;
+            const unsigned fg = ok ? (k[j] & 1u) : 0u;
+            const unsigned long long bal = __ballot(fg != 0u);
+            const unsigned before_u = cum + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            cum += (unsigned)__popcll(bal);
+            const long long i = t0 + idx;
+            const float before = (float)before_u;
+            const float kf = (float)(i + 1);
+            const float jk = jaccard_at(G, kf, (float)(before_u + fg));
+            const float jprev = i == 0 ? 0.0f : jaccard_at(G, kf - 1.0f, before);
+            v[j] = __float_as_uint(jk - jprev);                  // lovasz.py:32-33
+        }
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
@@ -391,11 +446,6 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
     if (threadIdx.x == 0) fg_total[blockIdx.x] = carry;
 }
 
-__device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // lovasz.py:29-31 at sorted position k (k1 = k+1)
-    const float inter = G - cum;
-    const float uni = G + (k1 - cum);
-    return 1.0f - inter / uni;
-}
 
 // phase c: per element of the sorted order: cum fg -> grad_k = J_k - J_{k-1}; accumulate relu(e_k) * grad_k; scatter grad_k back
 // to pixel order.  The scatter is 16.7 M four-byte writes to random addresses at [4,16,512,512].  Measured alternatives to the
@@ -405,7 +455,7 @@ __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // 
 __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
                                                          const unsigned* __restrict__ fg_total, double* __restrict__ partial,
-                                                         float* __restrict__ grad_at_pixel, float* __restrict__ grad_sorted) {
+                                                         float* __restrict__ grad_at_pixel) {
     const int s = blockIdx.x / chunks_per_seg, k = blockIdx.x % chunks_per_seg;
     const long long base = (long long)s * P, i0 = (long long)k * CHUNK;
     const float G = (float)fg_total[s];
@@ -459,16 +509,6 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
             const float g = jk - jprev;                       // lovasz.py:32-33
             acc += (double)(fmaxf(e[u], 0.0f) * g);           // dot(relu(errors_sorted), grad), lovasz.py:71 / :139
             if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
-            e[u] = g;
-        }
-    }
-    if (grad_sorted) {      // the gradient in SORTED order (coalesced): binned by pixel block afterwards (ptb_lovasz_fwd_binned)
-        if (first + 8 <= P && ((base + first) & 3) == 0) {
-            *reinterpret_cast<float4*>(grad_sorted + base + first) = make_float4(e[0], e[1], e[2], e[3]);
-            *reinterpret_cast<float4*>(grad_sorted + base + first + 4) = make_float4(e[4], e[5], e[6], e[7]);
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) if (first + u < P) grad_sorted[base + first + u] = e[u];
         }
     }
     // One partial sum per workgroup, added up per segment by lovasz_segsum_kernel.  (Consecutive workgroups belong to the same
@@ -697,7 +737,8 @@ int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in 
 static void launch_scatter(unsigned tiles, hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, long long P, int T,
                            int shift, const unsigned* hist, int spans, const unsigned* span_tot) {
     // (8 waves per workgroup -- 8 items per thread, 64 VGPRs, 24 waves per CU instead of 16 -- measured 4 % slower: more waves do not help this pass)
-    hipLaunchKernelGGL(rs_scatter_kernel<4>, dim3(tiles), dim3(256), 0, s, kin, vin, kout, vout, P, T, shift, hist, spans, span_tot, g_rs_xcd_map);
+    hipLaunchKernelGGL((rs_scatter_kernel<4, false>), dim3(tiles), dim3(256), 0, s, kin, vin, kout, vout, P, T, shift, hist, spans, span_tot, g_rs_xcd_map,
+                       (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
 }
 
 static int blocks_for(long long n) {
@@ -710,12 +751,14 @@ static int blocks_for(long long n) {
 using namespace ptb;
 
 // bytes of sort workspace for `segments` segments of `per_segment` elements: the per-tile digit histograms
-// u32[segments][tiles][256] followed by the span totals u32[segments][ceil(tiles / 32)][256]
+// u32[segments][tiles][256] followed by the span totals u32[segments][ceil(tiles / 32)][256] and the dot kernel's partial sums
+// double[segments][ceil(per_segment / 2048)]
 extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
     if (per_segment < 0 || segments < 0) return -1;
     const int64_t tiles = (per_segment + RS_TILE - 1) / RS_TILE;
     const int64_t spans = (tiles + RS_SPAN - 1) / RS_SPAN;
-    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256 * spans) * (int64_t)sizeof(unsigned);
+    const int64_t chunks = (per_segment + CHUNK - 1) / CHUNK;
+    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256 * spans) * (int64_t)sizeof(unsigned) + (int64_t)segments * chunks * (int64_t)sizeof(double);
 }
 
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
@@ -767,7 +810,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
     // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
     unsigned *kin = keys_a, *kout = keys_b, *vin = vals_a, *vout = vals_b;
     for (int shift = 0; shift < 32; shift += 8) {
-        if (shift) hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist);
+        if (shift) hipLaunchKernelGGL(rs_hist_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist, (unsigned*)nullptr, 0);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
         launch_scatter((unsigned)tiles, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot);
         if (int rc = check_launch()) return rc;
@@ -775,27 +818,31 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         unsigned* tv = vin; vin = vout; vout = tv;
     }
     // (an even number of passes: the sorted pairs are back in keys_a / vals_a)
-    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vin, a.P, cps, chunk);
-    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-    double* partial = static_cast<double*>(temp);      // (the sort is done with its histograms: 1 KB per 4096-element tile, 16 B needed)
     const int bl = binned ? binned_block_log2(a.P) : -1;
-    if (binned && (bl < 0 || !grad_at_pixel)) return PTB_EUNSUPPORTED;
-    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial,
-                       binned ? (float*)nullptr : grad_at_pixel, binned ? grad_at_pixel : (float*)nullptr);
-    hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
-    if (int rc = check_launch()) return rc;
+    if (binned && bl < 0) return PTB_EUNSUPPORTED;
+    double* partial = reinterpret_cast<double*>(span_tot + (long long)a.S * 256 * spans);      // (behind the histograms: the binning pass needs them while the partial sums exist)
     if (binned) {
-        // one more scatter pass of the sort's own kernels, keyed by the pixel block: (index << 1 | fg, gradient) pairs sorted by error ->
-        // grouped by block of 2^bl pixels (positions s * P + block * 2^bl ...: every pixel occurs once).  16.7 M random 4-byte writes
-        // (177 us at [4,16,512,512]) become 64-byte runs (18 + 5 + 68 us) and an LDS placement in the backward kernel.
+        // The gradient is BINNED, not scattered: one more pass of the sort's own kernels, keyed by the pixel block, groups the
+        // (index << 1 | fg, gradient) pairs by block of 2^bl pixels (positions s * P + block * 2^bl ...: every pixel occurs once).
+        // 16.7 M random 4-byte writes (177 us at [4,16,512,512]) become 64-byte runs and an LDS placement in the backward kernel.
+        // Its histogram kernel also counts the foreground per chunk (no lovasz_count_kernel), its scatter kernel computes the
+        // gradient it carries (the dot kernel writes none).
         const int shift = bl + 1;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist);
+        hipLaunchKernelGGL(rs_hist_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist, chunk, cps);
+        hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
+        hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
+        hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        launch_scatter((unsigned)tiles, s, vin, reinterpret_cast<const unsigned*>(grad_at_pixel), keys_b, vals_b, a.P, T, shift, hist, spans, span_tot);
+        hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift, hist,
+                           spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps);
         if (int rc = check_launch()) return rc;
         return bl;
     }
-    return PTB_OK;
+    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vin, a.P, cps, chunk);
+    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
+    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, grad_at_pixel);
+    hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
+    return check_launch();
 }
 
 extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
@@ -808,13 +855,12 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
 
 // Same, with the gradient left BINNED instead of scattered to pixel order: on return keys_b holds (index << 1 | fg) and vals_b the
 // gradient bits of the same element, grouped by blocks of 2^r pixels (r = the return value, 12..14; the pairs of block b of segment s
-// are at s * P + (b << r) ...).  `scratch` (float[n], required) is overwritten.  PTB_EUNSUPPORTED when a segment has more than
+// are at s * P + (b << r) ...).  `scratch` is not used any more (may be NULL).  PTB_EUNSUPPORTED when a segment has more than
 // 256 * 2^14 elements: use ptb_lovasz_fwd.  ptb_lovasz_bwd_binned is its backward.
 extern "C" int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                                      int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                                      unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
                                      double* seg_loss, float* scratch, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
-    if (!scratch) return PTB_EINVAL;
     return lovasz_fwd_impl(pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value, keys_a, keys_b, vals_a, vals_b,
                            chunk, fg_total, seg_loss, scratch, temp, temp_bytes, stream, true);
 }

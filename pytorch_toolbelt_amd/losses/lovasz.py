@@ -41,7 +41,7 @@ class _LovaszSegments(torch.autograd.Function):
         fg_total = alloc(S, dtype=torch.int32, device=dev)
         # want_grad False (the caller saw no_grad / a detached input): forward only, the per-pixel gradient is never written
         want_grad = bool(want_grad and ctx.needs_input_grad[0])
-        gpix = torch.empty(max(n, 1) if want_grad else 0, dtype=torch.float32, device=dev)
+        gpix = torch.empty(0, dtype=torch.float32, device=dev)       # (only the scattered-gradient path fills one: n floats)
         binned = None
         if n > 0:
             lib = N.load()
@@ -53,21 +53,22 @@ class _LovaszSegments(torch.autograd.Function):
                 if tb < 0:
                     raise RuntimeError("ptb_lovasz_temp_bytes failed")
                 temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
-                args = (pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
+                head = (pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
                         1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
-                        vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(),
-                        seg_loss.data_ptr(), gpix.data_ptr() if want_grad else None, temp.data_ptr(), int(tb), N.stream_ptr(dev))
+                        vals[0].data_ptr(), vals[1].data_ptr(), chunk.data_ptr(), fg_total.data_ptr(), seg_loss.data_ptr())
+                tail = (temp.data_ptr(), int(tb), N.stream_ptr(dev))
                 rc = N.PTB_EUNSUPPORTED
                 if want_grad and BINNED_GRADIENT:
                     # the gradient stays binned by pixel block (one more pass of the sort's scatter instead of n random writes);
-                    # keys[1] / vals[1] hold the pairs for the backward kernel, gpix was only scratch
-                    rc = lib.ptb_lovasz_fwd_binned(*args)
+                    # keys[1] / vals[1] hold the pairs for the backward kernel
+                    rc = lib.ptb_lovasz_fwd_binned(*head, None, *tail)
                     if rc >= 0:
                         binned = (vals[1], keys[1], int(rc))
-                        gpix = torch.empty(0, dtype=torch.float32, device=dev)
                         rc = 0
                 if rc == N.PTB_EUNSUPPORTED:
-                    rc = lib.ptb_lovasz_fwd(*args)
+                    if want_grad:
+                        gpix = torch.empty(n, dtype=torch.float32, device=dev)
+                    rc = lib.ptb_lovasz_fwd(*head, gpix.data_ptr() if want_grad else None, *tail)
             N.bump()
             N.check(rc, "ptb_lovasz_fwd")
         coef_unit = None
