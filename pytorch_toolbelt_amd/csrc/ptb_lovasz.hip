@@ -89,48 +89,65 @@ __device__ __forceinline__ unsigned tile_of_block(int xcd_map) {
 // pass step 1: digit histogram of every tile -> hist[(seg * T + tile) * 256 + digit]  (one coalesced 1 KiB row per tile)
 // COUNT (the binning pass of the gradient, keys = the sorted index << 1 | fg values): also the foreground count of the tile's two
 // CHUNKs -> chunk_count (what lovasz_count_kernel computes from one more read of the same array).
-template <bool COUNT>
+#ifndef PTB_RS_HIST_COPIES
+#define PTB_RS_HIST_COPIES 4
+#endif
+constexpr int RS_HIST_COPIES = PTB_RS_HIST_COPIES;   // wave-private counter copies (power of two)
+template <bool COUNT, bool HIST = true>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist,
                                                       unsigned* __restrict__ chunk_count, int chunks_per_seg) {
     static_assert(RS_TILE == 2 * CHUNK && RS_WAVE_SPAN * 2 == CHUNK, "a tile is two chunks, a chunk two waves");
     // counts only, no order: LDS atomics (ds_add_u32 without return).  Four copies per wave (lane & 3) keep the same-address
     // serialisation short when the digit is nearly constant (the exponent byte of probabilities); a wave whose 64 keys share
     // one digit adds 64 from a single lane.
-    __shared__ unsigned h[4][4][256];
+    __shared__ unsigned h[4][RS_HIST_COPIES][256];
     const int seg = blockIdx.x / T, tile = blockIdx.x % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) h[w][c][threadIdx.x] = 0;
+        for (int c = 0; c < RS_HIST_COPIES; ++c) h[w][c][threadIdx.x] = 0;
     __syncthreads();
     const long long t0 = (long long)tile * RS_TILE;
     const unsigned* kp = keys + (long long)seg * P + t0;
     const long long left = P - t0;
     unsigned k[RS_ITEMS];
+    // counting is order-free: a full, 16-byte aligned tile is read with 4 x 16-byte loads per thread (item j = elements j/4 * 256 +
+    // lane * 4 + j%4 of the wave's span) instead of 16 x 4-byte ones -- this kernel is all load issue: 18 -> 13 us for 67 MB
+    const bool vec = left >= RS_TILE && ((((long long)seg * P + t0) & 3) == 0) && ((reinterpret_cast<uintptr_t>(keys) & 15u) == 0);
+    if (vec) {
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
-        k[j] = idx < left ? kp[idx] : 0u;
+        for (int q = 0; q < RS_ITEMS / 4; ++q) {
+            const uint4 u = *reinterpret_cast<const uint4*>(kp + wave * RS_WAVE_SPAN + q * 256 + lane * 4);
+            k[4 * q] = u.x; k[4 * q + 1] = u.y; k[4 * q + 2] = u.z; k[4 * q + 3] = u.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RS_ITEMS; ++j) {
+            const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
+            k[j] = idx < left ? kp[idx] : 0u;
+        }
     }
 #pragma unroll
     for (int j = 0; j < RS_ITEMS; ++j) {
         const int idx = wave * RS_WAVE_SPAN + j * 64 + lane;
-        const bool valid = idx < left;
-        const unsigned d = (k[j] >> shift) & 255u;
-        const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-        const bool full = wave * RS_WAVE_SPAN + j * 64 + 63 < left;      // (wave-uniform)
-        if (full && __all(d == d0)) {
-            if (lane == 0) atomicAdd(&h[wave][0][d0], 64u);
-        } else if (valid) {
-            atomicAdd(&h[wave][lane & 3][d], 1u);
+        const bool valid = vec || idx < left;
+        if constexpr (HIST) {
+            const unsigned d = (k[j] >> shift) & 255u;
+            const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
+            const bool full = vec || wave * RS_WAVE_SPAN + j * 64 + 63 < left;      // (wave-uniform)
+            if (full && __all(d == d0)) {
+                if (lane == 0) atomicAdd(&h[wave][0][d0], 64u);
+            } else if (valid) {
+                atomicAdd(&h[wave][lane & (RS_HIST_COPIES - 1)][d], 1u);
+            }
         }
     }
     __shared__ unsigned wfg[4];
     if constexpr (COUNT) {
         unsigned fgs = 0;
 #pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) fgs += (unsigned)__popcll(__ballot((wave * RS_WAVE_SPAN + j * 64 + lane < left) && (k[j] & 1u)));
+        for (int j = 0; j < RS_ITEMS; ++j) fgs += (unsigned)__popcll(__ballot((vec || wave * RS_WAVE_SPAN + j * 64 + lane < left) && (k[j] & 1u)));
         if (lane == 0) wfg[wave] = fgs;
     }
     __syncthreads();
@@ -138,8 +155,8 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) tot += h[w][c][threadIdx.x];
-    hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
+        for (int c = 0; c < RS_HIST_COPIES; ++c) tot += h[w][c][threadIdx.x];
+    if constexpr (HIST) hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
     if constexpr (COUNT) {
         if (threadIdx.x < 2 && tile * 2 + (int)threadIdx.x < chunks_per_seg)
             chunk_count[(long long)seg * chunks_per_seg + tile * 2 + threadIdx.x] = wfg[2 * threadIdx.x] + wfg[2 * threadIdx.x + 1];
@@ -399,26 +416,8 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
 
 // (Measured and dropped: the same pass with one 16 KiB staging buffer used twice and packed 12-bit slots -- 22 KB of LDS, 80 VGPRs, 6
 // workgroups per CU instead of 4 -- is 1 % slower: the pass is not waiting for occupancy.  2048-element tiles: +8 %; 8192: no change.)
-// phase a: foreground count of every CHUNK of the sorted order.  (Counting inside the last scatter pass instead -- one atomic per wave
-// of staged slots, 262 k device-scope atomics on 8 192 counters -- made that pass 68 -> 176 us: atomics between XCDs execute at the
-// memory side.)
-__global__ __launch_bounds__(256) void lovasz_count_kernel(const unsigned* __restrict__ vals, long long P, int chunks_per_seg,
-                                                           unsigned* __restrict__ chunk_count) {
-    const int s = blockIdx.x / chunks_per_seg, k = blockIdx.x % chunks_per_seg;
-    const long long base = (long long)s * P, i0 = (long long)k * CHUNK;
-    unsigned cnt = 0;
-    for (int u = threadIdx.x; u < CHUNK; u += 256) {
-        const long long i = i0 + u;
-        if (i < P) cnt += vals[base + i] & 1u;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-    __shared__ unsigned w[4];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) chunk_count[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
-}
-
+// phase a (foreground count of every CHUNK of the sorted order) is rs_hist_kernel<COUNT>.  (Counting inside the last scatter pass instead
+// -- one atomic per wave of staged slots, 262 k device-scope atomics on 8 192 counters -- made that pass 68 -> 176 us.)
 // phase b: exclusive scan of the chunk counts of each segment (one workgroup per segment), total -> fg_total[s]
 __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_count, int chunks_per_seg,
                                                                 unsigned* __restrict__ fg_total) {
@@ -838,7 +837,9 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         if (int rc = check_launch()) return rc;
         return bl;
     }
-    hipLaunchKernelGGL(lovasz_count_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, vin, a.P, cps, chunk);
+    // (foreground per chunk: the tile-shaped kernel in its count-only form, 16 loads in flight per thread -- the chunk-shaped
+    // lovasz_count_kernel it replaces took 21 us for the same 67 MB)
+    hipLaunchKernelGGL((rs_hist_kernel<true, false>), dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, 0, hist, chunk, cps);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
     hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, grad_at_pixel);
     hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
