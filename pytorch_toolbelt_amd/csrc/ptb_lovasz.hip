@@ -781,6 +781,8 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
     if (n == 0) return PTB_OK;
     if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;  // offsets / packed indices are 32-bit
     if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
+    const int bl = binned ? binned_block_log2(a.P) : -1;
+    if (binned && bl < 0) return PTB_EUNSUPPORTED;      // (before anything is launched: the caller falls back to the scattered gradient)
     hipStream_t s = (hipStream_t)stream;
     const int T = (int)((a.P + RS_TILE - 1) / RS_TILE);
     const long long tiles = (long long)T * a.S;
@@ -817,8 +819,6 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         unsigned* tv = vin; vin = vout; vout = tv;
     }
     // (an even number of passes: the sorted pairs are back in keys_a / vals_a)
-    const int bl = binned ? binned_block_log2(a.P) : -1;
-    if (binned && bl < 0) return PTB_EUNSUPPORTED;
     double* partial = reinterpret_cast<double*>(span_tot + (long long)a.S * 256 * spans);      // (behind the histograms: the binning pass needs them while the partial sums exist)
     if (binned) {
         // The gradient is BINNED, not scattered: one more pass of the sort's own kernels, keyed by the pixel block, groups the

@@ -439,11 +439,12 @@ def test_lovasz_reduce_kernel_and_pixel_backward(B, C, H, W, dev):
             assert float(lb - la) == pytest.approx(float((xa.grad * d).sum()), rel=5e-2, abs=2e-7)
 
 
-@pytest.mark.parametrize("B,C,H,W,per_image", [(3, 5, 37, 29, False), (2, 3, 64, 70, True), (1, 2, 5, 3, False), (2, 4, 96, 96, False), (1, 2, 1024, 1030, False)])
+@pytest.mark.parametrize("B,C,H,W,per_image", [(3, 5, 37, 29, False), (2, 3, 64, 70, True), (1, 2, 5, 3, False), (2, 4, 96, 96, False), (1, 2, 1024, 1030, False), (1, 2, 1500, 1501, False), (1, 2, 2100, 2100, False)])
 def test_lovasz_binned_gradient_equals_scattered_gradient(B, C, H, W, per_image, dev):
     """The gradient at every pixel's rank reaches the backward kernel either scattered to pixel order by the forward (ptb_lovasz_fwd /
     ptb_lovasz_bwd) or binned by blocks of 2^12 .. 2^14 pixels by one more pass of the sort's scatter and put in order in LDS
-    (ptb_lovasz_fwd_binned / ptb_lovasz_bwd_binned; 1024 x 1030 pixels: 2^13).  The same values either way: equal bits."""
+    (ptb_lovasz_fwd_binned / ptb_lovasz_bwd_binned; 1024 x 1030 pixels: 2^13, 1500 x 1501: 2^14 = all 64 KB of LDS; 2100 x 2100 is more than 256 such blocks:
+    ptb_lovasz_fwd_binned declines and the module falls back to the scatter).  The same values either way: equal bits."""
     from pytorch_toolbelt_amd.losses import lovasz as LV
 
     g = torch.Generator().manual_seed(B * 10 + C)
