@@ -45,8 +45,9 @@ class _LovaszSegments(torch.autograd.Function):
         binned = None
         if n > 0:
             lib = N.load()
-            keys = torch.empty((2, n), dtype=torch.int32, device=dev)
-            vals = torch.empty((2, n), dtype=torch.int32, device=dev)
+            # (four allocations, not two [2, n] ones: the backward keeps only the binned pair keys[1] / vals[1] alive)
+            keys = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+            vals = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
             chunk = torch.empty(S * ((P + _CHUNK - 1) // _CHUNK), dtype=torch.int32, device=dev)
             with N.on_device(dev):
                 tb = lib.ptb_lovasz_temp_bytes(P, S)
