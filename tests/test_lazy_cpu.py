@@ -119,3 +119,34 @@ def test_held_batch_guard():
         assert entry[2] is None                                               # no version counter: accepted, never compared
         d.add_(1.0)
         _check_held([(d,) + entry], c, _held_entry(c), True, "x")
+
+
+def test_autograd_on_an_evaluated_handle_and_the_legacy_dlpack_guard():
+    """Once evaluated, requires_grad / grad / is_leaf are those of the value (they were answered by the storage-less wrapper:
+    `y.requires_grad_(); ...backward(); y.grad` gave None); torch.utils.dlpack.to_dlpack -- a bare C function that would read the
+    wrapper's null storage -- evaluates a handle first and is untouched for ordinary tensors."""
+    import threading
+
+    import torch.utils.dlpack as D
+
+    h, src = _handle()
+    want = _mean_views(src, (0, 4), 1)
+    assert not h.requires_grad and h.grad is None and h._value is None          # metadata of an unevaluated handle: no evaluation
+    h.requires_grad_(True)
+    (h * 2).sum().backward()
+    assert h.requires_grad and h.is_leaf and torch.equal(h.grad, torch.full_like(want, 2.0))
+    assert getattr(D.to_dlpack, "_ptb_lazy_guard", False)
+    h2, src2 = _handle()
+    assert torch.equal(D.from_dlpack(D.to_dlpack(h2)), _mean_views(src2, (0, 4), 1))
+    plain = torch.arange(6.0)
+    assert torch.equal(D.from_dlpack(D.to_dlpack(plain)), plain)
+    assert torch.equal(torch.from_dlpack(_handle(src2)[0]), _mean_views(src2, (0, 4), 1))
+    # two threads using one handle end up with ONE value
+    h3, _ = _handle()
+    got = []
+    ts = [threading.Thread(target=lambda: got.append(h3._evaluate())) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert all(g is got[0] for g in got)
