@@ -8,7 +8,7 @@ needs d(loss)/d(sum), handed to the kernels as device arrays -- nothing synchron
 import torch
 
 from .. import _native as N
-from ._kernels import SUM_SLOTS, _ptr, check_labels, finalize, new_sums
+from ._kernels import _ptr, check_labels, finalize, new_sums
 
 SOFT_BCE, BALANCED_BCE, QFL, WING, LOGCOSH, SOFT_F1 = range(6)
 F_IGNORE, F_SMOOTH = 1, 2

@@ -8,7 +8,7 @@ import math
 from typing import Optional
 
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F  # noqa: F401  (module attribute of the reference's functional.py)
 
 from ..utils.support import pytorch_toolbelt_deprecated
 from . import _kernels as K

@@ -1,5 +1,5 @@
 """Quality Focal Loss (https://arxiv.org/abs/2006.04388; reference losses/quality_focal_loss.py) as one fused HIP pass."""
-import torch
+import torch  # noqa: F401  (module attribute of the reference's file)
 from torch import Tensor, nn
 
 from . import _pointwise as P

@@ -18,7 +18,7 @@ The reference has no multi-GPU tile path; the single-device ``TileMerger`` resul
 * ``merge()`` adds what it received and divides (a full-width strip is folded into the division kernel), returning
   this rank's band.
 """
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Sequence
 
 import numpy as np
 import torch

@@ -1,6 +1,5 @@
 """The search logic of pytorch_toolbelt_amd.placement.choose_placement, driven without a device (free memory and the gap
 allocations are injected): stopping rules, fixed counts for distributed ranks, out-of-memory handling, spacing of the candidates."""
-import pytest
 
 from pytorch_toolbelt_amd.placement import REGION_BYTES, choose_placement
 

@@ -1,4 +1,6 @@
-import os, sys, torch
+import sys
+
+import torch
 sys.path.insert(0, "/root/repo")
 from pytorch_toolbelt_amd import losses as L, _native as N
 dev = torch.device("cuda:0")

@@ -103,7 +103,6 @@ def main():
         print(f"{name:34s} {tf:8.3f} {fwd_bytes / tf / 1e6:9.1f}")
     # CPU reference point: the numpy oracle (one core) on a 1/16 sample of the batch, extrapolated
     import time
-    import numpy as np
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import losses_oracle as LO
     xs, ls = x[:2].cpu().numpy(), labels[:2].cpu().numpy()
