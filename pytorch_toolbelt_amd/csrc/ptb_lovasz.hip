@@ -299,6 +299,9 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
     return incl + off;
 }
 
+// (Measured and dropped: a first-pass instance that COMPUTES its pairs from pred / labels instead of loading what the error kernel wrote --
+// 134 MB less written and read, but the int64 labels per class and the index arithmetic inside this already VALU-heavy kernel made the
+// forward 30 us slower.)
 // GRAD (the binning pass of the gradient: keys_in = the sorted index << 1 | fg values): the value carried with a key is not loaded
 // but computed -- the Lovasz gradient at the element's sorted position, from the foreground count before it (chunk_off + the count
 // inside the tile) exactly as lovasz_dot_kernel computes it.
