@@ -71,7 +71,12 @@ const char* ptb_last_hip_error(void);
  * 9 = XCD-aware tile order of the fused multiscale kernel: strip width in tile columns (0 = row-major order over all XCDs, default 64),
  * 10 = workgroup order of the band plan kernel (A/B): 0 = channels of a work item adjacent (default, fastest), 1 = every XCD a contiguous
  * eighth of the list, 2 = channel-major,
- * 11 = rows per work item of band plans created afterwards (32 | 64, default 64). */
+ * 11 = rows per work item of band plans created afterwards (32 | 64, default 64),
+ * 12 = fused focal + Dice + Jaccard forward: 0 = lean kernel, 1 = packed-fp32 kernel (default), 2 = packed-fp32 with prefetch,
+ * 13 = workgroups of the packed-fp32 forward (default 512), 15 = output tile width of the fused multiscale kernel (64 | 128, default 128),
+ * 16 = non-temporal gradient stores in the fused loss backward (0|1, default 1), 17 = XCD-contiguous tile order of the Lovasz radix
+ * scatter (0|1, default 1), 18 = one-launch finish of a rank's image in ptb_band_plan_finish_rank (0|1, default 1).
+ * Every setting computes the same values; the keys exist for same-box A/B runs and for tests that compare two code paths bit for bit. */
 int ptb_set_tunable(int key, int value);
 
 /* ---- TileMerger.integrate_batch / accumulate_single (inference/tiles.py:310-339) -------------------------------
