@@ -758,6 +758,51 @@ def gen_losses4():
 
 
 # ----------------------------------------------------------------------------------------------- 3-D tiles (8f-4)
+def gen_losses5():
+    """Lovasz at sizes that span several 4096-element tiles and pixel blocks of the HIP sort (70 x 61 pixels: 8 540 per batch segment),
+    every `classes` form of _lovasz_softmax (losses/lovasz.py:92-140) and the hinge form, values AND the reference's autograd gradients."""
+    from pytorch_toolbelt.losses import lovasz as rlv
+
+    g = torch.Generator().manual_seed(20260924)
+    A, cases = {}, []
+    B, C, H, W = 2, 4, 70, 61
+    probs = torch.softmax(torch.randn((B, C, H, W), generator=g) * 2, 1)
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels[labels == C - 1] = 0                       # class 3 absent everywhere: "present" and "all" differ
+    labels[1][labels[1] == 0] = 1                     # class 0 absent in image 1
+    labels_ign = labels.clone()
+    labels_ign[torch.rand((B, H, W), generator=g) < 0.1] = 255
+    bl = torch.randn((B, H, W), generator=g) * 2
+    bt = (torch.rand((B, H, W), generator=g) < 0.4).float()
+    bti = bt.clone()
+    bti[torch.rand((B, H, W), generator=g) < 0.1] = 255.0
+    A.update(probs=t2n(probs), labels=t2n(labels), labels_ign=t2n(labels_ign), bl=t2n(bl), bt=t2n(bt), bti=t2n(bti))
+
+    def add(name, fn, kw, inputs, value, grad):
+        A[name], A[name + "_grad"] = t2n(value), t2n(grad)
+        cases.append(dict(name=name, fn=fn, kwargs=kw, inputs=inputs, output=name, grad=name + "_grad"))
+
+    i = 0
+    for classes in ("present", "all", [0, 2], [1]):
+        for per_image in (False, True):
+            for ign in (None, 255):
+                x = probs.clone().requires_grad_(True)
+                val = rlv._lovasz_softmax(x, labels_ign if ign is not None else labels, classes=classes, per_image=per_image, ignore_index=ign)
+                val.backward()
+                add(f"lovasz_softmax_{i}", "lovasz_softmax", dict(classes=classes, per_image=per_image, ignore_index=ign),
+                    ["probs", "labels_ign" if ign is not None else "labels"], val, x.grad)
+                i += 1
+    i = 0
+    for per_image in (False, True):
+        for ign in (None, 255):
+            x = bl.clone().requires_grad_(True)
+            val = rlv._lovasz_hinge(x, bti if ign is not None else bt, per_image=per_image, ignore_index=ign)
+            val.backward()
+            add(f"lovasz_hinge_{i}", "lovasz_hinge", dict(per_image=per_image, ignore_index=ign), ["bl", "bti" if ign is not None else "bt"], val, x.grad)
+            i += 1
+    save("losses5.npz", A, cases)
+
+
 def gen_volumes():
     from pytorch_toolbelt.inference import tiles_3d as rt3
 
@@ -900,6 +945,7 @@ if __name__ == "__main__":
     gen_losses2()
     gen_losses3()
     gen_losses4()
+    gen_losses5()
     gen_tta2()
     gen_tta3()
     gen_tta4()

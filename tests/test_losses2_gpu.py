@@ -470,3 +470,28 @@ def test_lovasz_binned_gradient_equals_scattered_gradient(B, C, H, W, per_image,
     assert grads[True][0] == grads[False][0] and grads[True][2] == grads[False][2]
     assert torch.equal(grads[True][1], grads[False][1]) and torch.equal(grads[True][3], grads[False][3])
     assert float(grads[True][1].abs().sum()) > 0 and float(grads[True][3].abs().sum()) > 0
+
+
+GL5 = load_golden("losses5.npz")
+
+
+@pytest.mark.parametrize("case", GL5.cases, ids=lambda c: c["name"])
+def test_lovasz_against_larger_reference_cases_with_gradients(case, dev):
+    """losses5.npz (generated from the unmodified reference by oracle/make_golden.py:gen_losses5): _lovasz_softmax with every
+    `classes` form, per_image, ignore_index and _lovasz_hinge at 2 x 4 x 70 x 61 (several sort tiles and gradient blocks per
+    segment) -- the HIP value AND the gradient against the reference's autograd."""
+    from pytorch_toolbelt_amd.losses import lovasz as LV
+
+    kw = dict(case["kwargs"])
+    x = torch.from_numpy(GL5[case["inputs"][0]]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(GL5[case["inputs"][1]]).to(dev)
+    if case["fn"] == "lovasz_softmax":
+        out = LV._lovasz_softmax(x, t, classes=kw["classes"], per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+    else:
+        out = LV._lovasz_hinge(x, t, per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+    np.testing.assert_allclose(out.detach().cpu().numpy(), GL5[case["output"]], rtol=1e-5, atol=1e-6)
+    out.backward()
+    got, want = x.grad.cpu().numpy(), GL5[case["grad"]]
+    assert np.abs(got - want).max() <= 1e-5                      # north_star's absolute bound
+    # an element is J_k - J_{k-1} of two fp32 Jaccard values (a few ulps of ~0.5 in absolute terms), scaled by 1 / #classes / #images
+    np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6)

@@ -426,3 +426,19 @@ def test_multiscale_bicubic_oracle(case):
     else:
         out = AO.ms_image_deaugment([GT4[f"fm_{i}"] for i in range(len(offs))], offs, kw["reduction"], kw["align_corners"], mode="bicubic")
         np.testing.assert_allclose(out, GT4[case["name"]], rtol=1e-5, atol=2e-6)
+
+
+GL5 = load_golden("losses5.npz")
+
+
+@pytest.mark.parametrize("case", GL5.cases, ids=lambda c: c["name"])
+def test_lovasz_oracle_against_larger_reference_cases(case):
+    """losses5.npz: _lovasz_softmax with every `classes` form / per_image / ignore_index and _lovasz_hinge of the unmodified reference
+    (losses/lovasz.py:37-49, :92-140) at 2 x 4 x 70 x 61 -- the numpy restatement reproduces the values."""
+    a, b = GL5[case["inputs"][0]], GL5[case["inputs"][1]]
+    kw = dict(case["kwargs"])
+    if case["fn"] == "lovasz_softmax":
+        out = LO.lovasz_softmax(a, b, classes=kw["classes"], per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+    else:
+        out = LO.lovasz_hinge(a, b, per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+    np.testing.assert_allclose(out, GL5[case["output"]], rtol=1e-5, atol=1e-6)
