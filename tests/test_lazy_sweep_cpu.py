@@ -122,3 +122,29 @@ def test_every_tensor_attribute_and_torch_function_sees_the_eager_value():
         if not ok:
             bad.append((f"torch.{name}", ra[0], str(ra[1])[:60], rb[0], str(rb[1])[:60]))
     assert swept > 1000 and not bad, bad
+
+
+def test_torch_nn_functional_sees_the_eager_value():
+    """The same sweep over torch.nn.functional (activations, pooling, interpolate, normalisation ...: what usually follows a TTA merge)."""
+    import torch.nn.functional as F
+
+    warnings.filterwarnings("ignore")
+    src = torch.rand(8, 2, 4, 4) + 0.1
+    want = _mean_views(src, (0, 4), 1)
+    random_or_introspective = {"dropout", "dropout1d", "dropout2d", "dropout3d", "alpha_dropout", "feature_alpha_dropout", "rrelu", "gumbel_softmax",
+                               "fractional_max_pool2d", "fractional_max_pool3d", "fractional_max_pool2d_with_indices",
+                               "fractional_max_pool3d_with_indices", "has_torch_function_unary", "has_torch_function_variadic", "has_torch_function"}
+    bad, succeeded = [], 0
+    for name in dir(F):
+        f = getattr(F, name)
+        if name.startswith("_") or name in random_or_introspective or not callable(f) or inspect.isclass(f) or inspect.ismodule(f):
+            continue
+        for args in ((), (2,), ((2, 2),), (1,)):           # the first argument form the eager tensor accepts
+            h, w = L.LazyDeaugment(src.clone(), "fliplr", (0, 4), 1, _mean_views), want.clone()
+            ok, ra, rb = _compare(lambda: f(h, *args), lambda: f(w, *args))
+            if rb[0] == "ok":
+                succeeded += 1
+                if not ok:
+                    bad.append((name, args, ra[0], str(ra[1])[:60]))
+                break
+    assert succeeded >= 50 and not bad, bad
