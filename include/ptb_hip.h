@@ -209,7 +209,8 @@ void ptb_band_plan_destroy(ptb_band_plan* plan);
  * ptb_halo_pack: strided rectangle -> contiguous send buffer, dst[c][r][x] = src[c * chan_stride + r * row_stride + x].
  * ptb_band_plan_submit_rank: ptb_band_plan_submit, then packs every outgoing rectangle (rects: n_sends x {r0, r1, c0, c1}, the plan's
  * rows) whose rows are complete into send_bufs[k] (`packed` [n_sends] in/out, zero at the start of an image) and, when the last one
- * has just been packed, records ready_event (a hipEvent_t, may be NULL) on the stream.  Returns the band launches issued (>= 0).
+ * has just been packed, records ready_event (a hipEvent_t; NULL only when n_sends == 0: a communication stream that did not wait
+ * for it would send rectangles the pack kernels have not written yet -> PTB_EINVAL) on the stream.  Returns the band launches issued (>= 0).
  * ptb_band_plan_finish_rank: the end of a rank's image -- adds the n_recvs received rectangles of partial sums ({r0, r1, c0, c1} in
  * the plan's rows, packed [C][rows][cols] buffers) to `merged` and divides the n_ranges row ranges {r0, r1} that held partial sums by
  * `norm` [H][W] in place (launches only). */
@@ -227,6 +228,13 @@ int ptb_halo_exchange(void* comm, int n_sends, const float* const* send_bufs, co
                       float* const* recv_bufs, const int64_t* recv_counts, const int* recv_peers, ptb_stream_t stream);
 int64_t ptb_band_plan_create2(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
                               int final_lo, int final_hi, const int64_t* cuts, int ncuts, const int64_t* early, int n_early,
+                              ptb_band_plan** out);
+/* ptb_band_plan_create3 = ptb_band_plan_create2 + flags.  PTB_PLAN_CLIP_ROWS (bit 0): the plan's rows [0, H) are a window of the image;
+ * tiles may hang over its top / bottom (ys < 0, ys + th > H) and only what lies inside is read and merged -- a rank that owns a range
+ * of PIXEL rows and holds every tile touching them merges exactly those rows with no exchange (parallel: partition="pixel_rows"). */
+#define PTB_PLAN_CLIP_ROWS 1
+int64_t ptb_band_plan_create3(const int64_t* xs, const int64_t* ys, int n, int C, int th, int tw, int H, int W, int rows_per_launch,
+                              int final_lo, int final_hi, const int64_t* cuts, int ncuts, const int64_t* early, int n_early, int flags,
                               ptb_band_plan** out);
 int ptb_band_plan_rows_launched(const ptb_band_plan* plan, int r0, int r1);
 int ptb_halo_pack(const float* src, int64_t chan_stride, int64_t row_stride, int C, int rows, int cols, float* dst, ptb_stream_t stream);

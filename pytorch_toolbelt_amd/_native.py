@@ -65,6 +65,8 @@ SIGNATURES = {
     "ptb_rccl_comm_destroy": (_c_int, [_vp]),
     "ptb_halo_exchange": (_c_int, [_vp, _c_int, _vpp, _i64p, _ip, _c_int, _vpp, _i64p, _ip, _vp]),
     "ptb_band_plan_create2": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _i64p, _c_int, _i64p, _c_int, _vpp]),
+    "ptb_band_plan_create3": (_c_i64, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _i64p, _c_int, _i64p, _c_int, _c_int,
+                                       _vpp]),
     "ptb_band_plan_rows_launched": (_c_int, [_vp, _c_int, _c_int]),
     "ptb_halo_pack": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _c_int, _c_int, _vp, _vp]),
     "ptb_band_plan_finish_rank": (_c_int, [_vp, _vp, _vp, _c_int, _i64p, _vpp, _c_int, _i64p, _vp]),

@@ -207,6 +207,18 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
 extern "C" int64_t ptb_band_plan_create2(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
                                          int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
                                          const int64_t* early, int n_early, ptb_band_plan** out) {
+    return ptb_band_plan_create3(xs64, ys64, n, C, th, tw, H, W, rows_per_launch, final_lo, final_hi, cuts, ncuts, early, n_early, 0, out);
+}
+
+// flags bit 0 (PTB_PLAN_CLIP_ROWS): the plan's rows [0, H) are a WINDOW of the image -- tiles may hang over its top / bottom edge
+// (ys < 0, ys + th > H, even entirely outside) and only the rows inside are merged: the rank of a communication-free sharded merge
+// (parallel.band_plan(partition="pixel_rows")) reads, of every tile that touches the pixel rows it owns, exactly the part that lies
+// on them, and writes nothing else.
+extern "C" int64_t ptb_band_plan_create3(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
+                                         int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
+                                         const int64_t* early, int n_early, int flags, ptb_band_plan** out) {
+    const bool clip = (flags & 1) != 0;
+    if (flags & ~1) return PTB_EINVAL;
     if (!xs64 || !ys64 || !out || n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || ncuts < 0 || (ncuts && !cuts)) return PTB_EINVAL;
     if (n_early < 0 || (n_early && !early)) return PTB_EINVAL;
     *out = nullptr;
@@ -217,10 +229,12 @@ extern "C" int64_t ptb_band_plan_create2(const int64_t* xs64, const int64_t* ys6
     p->xs.resize(n); p->ys.resize(n);
     std::vector<int> edges{0, H};
     for (int t = 0; t < n; ++t) {
-        if (xs64[t] < 0 || ys64[t] < 0 || xs64[t] + tw > W || ys64[t] + th > H) { delete p; return PTB_EBOUNDS; }
+        if (xs64[t] < 0 || xs64[t] + tw > W) { delete p; return PTB_EBOUNDS; }
+        if (!clip && (ys64[t] < 0 || ys64[t] + th > H)) { delete p; return PTB_EBOUNDS; }
+        if (ys64[t] < -(int64_t)0x3fffffff || ys64[t] > (int64_t)0x3fffffff) { delete p; return PTB_EBOUNDS; }
         if (xs64[t] % 4 || ys64[t] % 4) { delete p; return PTB_EUNSUPPORTED; }
         p->xs[t] = (int)xs64[t]; p->ys[t] = (int)ys64[t];
-        edges.push_back(p->ys[t]); edges.push_back(p->ys[t] + th);
+        edges.push_back(std::min(std::max(p->ys[t], 0), H)); edges.push_back(std::min(std::max(p->ys[t] + th, 0), H));
     }
     // caller-given row cuts (multi-GPU: ownership boundaries, rows other ranks also cover): band edges AND launch-group breaks
     std::vector<int> breaks;
@@ -487,13 +501,13 @@ extern "C" int ptb_halo_pack(const float* src, int64_t chan_stride, int64_t row_
 // One rank's step of a sharded merge as ONE host call: ptb_band_plan_submit, then every outgoing halo rectangle whose rows have all
 // been written by their launches is packed into its send buffer (rects: n_sends x {r0, r1, c0, c1} in the plan's local rows;
 // `packed` [n_sends] in/out, 0 at the start of an image), and -- when the last of them has just been packed -- `ready_event`
-// (a hipEvent_t, may be NULL) is recorded on the stream: the communication stream waits for it and posts the sends.
+// (a hipEvent_t; NULL only without sends) is recorded on the stream: the communication stream waits for it and posts the sends.
 // Returns the number of band launches (>= 0) or a negative code; *all_packed (may be NULL) = every rectangle is in its buffer.
 extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride,
                                          int in_dtype, int V, const int* views, int reduction, float* merged, const float* norm_full,
                                          const float* weight, int n_sends, const int64_t* rects, float* const* send_bufs, int* packed,
                                          void* ready_event, int* all_packed, ptb_stream_t stream) {
-    if (n_sends < 0 || (n_sends && (!rects || !send_bufs || !packed))) return PTB_EINVAL;
+    if (n_sends < 0 || (n_sends && (!rects || !send_bufs || !packed || !ready_event))) return PTB_EINVAL;
     const int rc = ptb_band_plan_submit(p, pos, B, batch, tile_stride, view_stride, in_dtype, V, views, reduction, merged, norm_full, weight, stream);
     if (rc < 0) return rc;
     int done = 0, fresh = 0;

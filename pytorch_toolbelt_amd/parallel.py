@@ -23,7 +23,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "band_plan", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
+__all__ = ["tile_row_partition", "tile_range_partition", "pixel_row_partition", "pixel_row_cuts", "band_plan", "PendingBand", "shared_exchange", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
            "ms_image_deaugment_strip"]
 
 
@@ -51,6 +51,30 @@ def tile_range_partition(crops: np.ndarray, world: int) -> List[np.ndarray]:
 PARTITIONS = {"tiles": tile_range_partition, "rows": tile_row_partition}
 
 
+def pixel_row_cuts(image_height: int, world: int) -> List[int]:
+    """``world + 1`` row positions that split ``image_height`` rows evenly: on the 64-row grid of the band kernel's work items when
+    that keeps every share non-empty, else on its 4-row grid, else (tiny images) wherever ``np.linspace`` puts them."""
+    for grid in (64, 4, 1):
+        cuts = [int(round(v / grid)) * grid for v in np.linspace(0, image_height, world + 1)]
+        cuts[0], cuts[-1] = 0, int(image_height)
+        if all(b > a for a, b in zip(cuts[:-1], cuts[1:])) or grid == 1:
+            return [min(max(c, 0), int(image_height)) for c in cuts]
+    return cuts
+
+
+def pixel_row_partition(crops: np.ndarray, world: int, image_height: int) -> List[np.ndarray]:
+    """Communication-free sharding (SURVEY 8e "communication-free alternative"): rank r owns the PIXEL rows
+    ``pixel_row_cuts(...)[r:r + 2]`` and gets every tile that touches them, in row-major order -- tiles that straddle a cut are
+    handed to both neighbours (their model outputs are computed twice: at the headline geometry 76 tiles per middle rank instead
+    of 45), and nothing is ever exchanged: every covering tile of an owned pixel is local, summed in the single-device order."""
+    crops = np.asarray(crops)
+    order = np.lexsort((crops[:, 0], crops[:, 1]))
+    cuts = pixel_row_cuts(image_height, world)
+    th = int(crops[0, 3])
+    ys = crops[order, 1]
+    return [order[(ys < cuts[r + 1]) & (ys + th > cuts[r])].astype(np.int64) for r in range(world)]
+
+
 def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str = "tiles"):
     """Who accumulates, owns and exchanges what.  Per rank a dict with
 
@@ -66,6 +90,8 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
 
     Ranks without tiles have ``band`` = ``owned`` = None."""
     crops = np.asarray(crops)
+    if partition == "pixel_rows":
+        return _pixel_row_plan(crops, world, image_height)
     parts = PARTITIONS[partition](crops, world)
     tw, th = int(crops[0, 2]), int(crops[0, 3])
     step = np.diff(np.unique(crops[:, 1]))
@@ -101,6 +127,23 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
             feeding |= hit
         plan[s]["boundary"] = parts[s][feeding]
         plan[s]["tiles"] = np.concatenate([parts[s][feeding], parts[s][~feeding]])
+    return plan
+
+
+def _pixel_row_plan(crops, world, image_height):
+    """``band_plan`` of ``partition="pixel_rows"``: no sends, no receives, overlapping tile sets.  A rank whose rows no tile touches
+    hands them to the live rank above it (or below, for the first ranks): the owned rows of the live ranks tile the image."""
+    parts = pixel_row_partition(crops, world, image_height)
+    cuts = pixel_row_cuts(image_height, world)
+    th = int(crops[0, 3])
+    plan = [dict(rank=r, tiles=parts[r], band=None, owned=None, sends=[], recvs=[], boundary=np.zeros(0, dtype=np.int64)) for r in range(world)]
+    live = [r for r in range(world) if len(parts[r])]
+    for i, r in enumerate(live):
+        ys = crops[parts[r], 1]
+        plan[r]["band"] = (int(ys.min()), int(ys.max()) + th)
+        o0 = 0 if i == 0 else cuts[r]
+        o1 = image_height if i == len(live) - 1 else cuts[live[i + 1]]
+        plan[r]["owned"] = (int(o0), int(o1))
     return plan
 
 
@@ -228,15 +271,25 @@ class _DeferredBand:
             pass
 
     @staticmethod
-    def build(merger, crops, weight, rows):
+    def build(merger, crops, weight, rows, send_buf, recv_buf, shared=None):
+        """``send_buf`` / ``recv_buf``: the packed rectangles of the image slot this plan serves; ``shared``: another slot's
+        ``_DeferredBand`` of the same merger (its normaliser and window are reused)."""
         import ctypes
 
         from . import _native as N
 
         me = merger.plan[merger.rank]
-        top, bottom, W = merger.top, merger.bottom, merger.image_width
+        W = merger.image_width
         th, tw = int(crops[0, 3]), int(crops[0, 2])
-        final, cuts = deferred_geometry(merger.plan, merger.rank, crops, merger.image_height)
+        o0, o1 = merger.owned_rows
+        if merger.partition == "pixel_rows":
+            # communication-free: the plan's rows are exactly the owned pixel rows; tiles hang over both ends and are clipped
+            top, bottom = o0, o1
+            final, cuts, flags = (o0, o1), [], 1
+        else:
+            top, bottom = merger.top, merger.bottom
+            final, cuts = deferred_geometry(merger.plan, merger.rank, crops, merger.image_height)
+            flags = 0
         mine = np.ascontiguousarray(crops[me["tiles"], :2].T.astype(np.int64))        # [2, n] absolute, issue order
         local = mine.copy()
         local[1] -= top
@@ -247,11 +300,11 @@ class _DeferredBand:
         early = np.ascontiguousarray(np.array(spans, dtype=np.int64).reshape(-1)) if (spans and merger.two_phase) else np.zeros(0, dtype=np.int64)
         lib = N.load()
         handle = ctypes.c_void_p()
-        nbytes = lib.ptb_band_plan_create2(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], merger.channels,
+        nbytes = lib.ptb_band_plan_create3(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], merger.channels,
                                            th, tw, bottom - top, W, int(rows), final[0] - top if final[1] > final[0] else 0,
                                            final[1] - top if final[1] > final[0] else 0,
                                            cut_arr.ctypes.data_as(N._i64p) if len(cut_arr) else None, len(cut_arr),
-                                           early.ctypes.data_as(N._i64p) if len(early) else None, len(early) // 2, ctypes.byref(handle))
+                                           early.ctypes.data_as(N._i64p) if len(early) else None, len(early) // 2, flags, ctypes.byref(handle))
         if nbytes < 0:
             return None
         dev = merger.device
@@ -265,26 +318,35 @@ class _DeferredBand:
         rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
         lib.ptb_band_plan_info(handle, None, None, None, None, rows_arr.ctypes.data_as(N._i64p))
         groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
-        norm = torch.zeros((1, bottom - top, W), device=dev, dtype=torch.float32)
-        o0, o1 = merger.owned_rows
-        if merger.norm_owned is not None:
-            norm[:, o0 - top:o1 - top] = merger.norm_owned
-        w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).to(dev).reshape(1, th, tw).contiguous()
+        if shared is not None:
+            norm, w = shared.norm, shared.weight
+        else:
+            norm = torch.zeros((1, bottom - top, W), device=dev, dtype=torch.float32)
+            if merger.norm_owned is not None:
+                norm[:, o0 - top:o1 - top] = merger.norm_owned
+            w = torch.from_numpy(np.ascontiguousarray(weight, dtype=np.float32)).to(dev).reshape(1, th, tw).contiguous()
         band = _DeferredBand(handle, table, groups, (merger.channels, bottom - top, W), norm, w, mine, top, merger.channels, th, tw)
         band.final = final
         # the outgoing rectangles in the plan's rows + their send buffers, for ptb_band_plan_submit_rank (submit + pack in one C call)
         sends = merger.sends
         band.n_sends = len(sends)
         band.rects = np.ascontiguousarray(np.array([[r0 - top, r1 - top, c0, c1] for _d, r0, r1, c0, c1 in sends], dtype=np.int64).reshape(-1))
-        band.send_ptrs = (ctypes.c_void_p * max(len(sends), 1))(*[b.data_ptr() for b in merger._send_buf])
+        band.send_ptrs = (ctypes.c_void_p * max(len(sends), 1))(*[b.data_ptr() for b in send_buf])
         band.packed = (ctypes.c_int * max(len(sends), 1))()
         band.all_packed = ctypes.c_int(0)
-        band.ready_event = torch.cuda.Event()      # recorded (by the C call) behind the pack of the last outgoing rectangle
+        # recorded (by the C call, on the raw handle) behind the pack of the last outgoing rectangle.  torch creates the hipEvent
+        # lazily with the first record(): record once here so that `cuda_event` is a real handle (a NULL handle made
+        # the C side skip its record and the communication stream wait for nothing)
+        band.ready_event = torch.cuda.Event()
+        with torch.cuda.device(dev):
+            band.ready_event.record(torch.cuda.current_stream(dev))
+        if band.n_sends and not band.ready_event.cuda_event:
+            raise RuntimeError("ShardedTileMerger: could not create the pack-complete event of the halo exchange")
         # ... and what ptb_band_plan_finish_rank needs: the incoming rectangles + the owned row ranges that hold partial sums
         recvs = merger.recvs
         band.n_recvs = len(recvs)
         band.recv_rects = np.ascontiguousarray(np.array([[r0 - top, r1 - top, c0, c1] for _s, r0, r1, c0, c1 in recvs], dtype=np.int64).reshape(-1))
-        band.recv_ptrs = (ctypes.c_void_p * max(len(recvs), 1))(*[b.data_ptr() for b in merger._recv_buf])
+        band.recv_ptrs = (ctypes.c_void_p * max(len(recvs), 1))(*[b.data_ptr() for b in recv_buf])
         f0, f1 = final
         ranges = [(o0, o1)] if f1 <= f0 else [(o0, f0), (f1, o1)]
         ranges = [(a_ - top, b_ - top) for a_, b_ in ranges if b_ > a_]
@@ -293,7 +355,7 @@ class _DeferredBand:
         band.fast = {}            # (group, reduction) -> (views array, number of views, reduction code)
         # ctypes views made once (a .ctypes.data_as per call costs ~3 us each)
         band.rects_p = band.rects.ctypes.data_as(N._i64p) if band.n_sends else None
-        band.event_p = band.ready_event.cuda_event if band.n_sends else None
+        band.event_p = ctypes.c_void_p(band.ready_event.cuda_event) if band.n_sends else None
         band.all_packed_ref = ctypes.byref(band.all_packed)
         band.recv_rects_p = band.recv_rects.ctypes.data_as(N._i64p) if band.n_recvs else None
         band.ranges_p = band.ranges.ctypes.data_as(N._i64p) if band.n_ranges else None
@@ -343,7 +405,7 @@ class _DeferredBand:
             rc = N.load().ptb_band_plan_submit_rank(self.handle, self.pos, B, batch.data_ptr(), per_tile, B * per_tile, N.DTYPE_CODES[batch.dtype],
                                                     n_views, varr, reduction, self.out.data_ptr(), self.norm.data_ptr(), self.weight.data_ptr(),
                                                     self.n_sends, self.rects.ctypes.data_as(N._i64p), self.send_ptrs, self.packed,
-                                                    self.ready_event.cuda_event if self.n_sends else None, ctypes.byref(self.all_packed),
+                                                    self.event_p, ctypes.byref(self.all_packed),
                                                     N.stream_ptr(dev))
         N.bump()
         if rc < 0:
@@ -399,11 +461,25 @@ class _DeferredBand:
         return self.pos == self.xy_abs.shape[1]
 
 
+class _StreamWork:
+    """Handle of one posted exchange: ``wait()`` makes the CURRENT stream wait for exactly that exchange (an event recorded behind it
+    on the communication stream), not for whatever else has been posted there since -- a pipelined merger posts the next image's
+    exchange before it completes this one."""
+
+    __slots__ = ("event", "device")
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+
+
 class RcclExchange:
     """An RCCL communicator of this library's own for the halo exchange (``ptb_halo_exchange``: all of a rank's sends and receives as
     one ncclGroup posted from C on a side stream), instead of ``torch.distributed.batch_isend_irecv``.  Collective: every rank of
     ``group`` constructs it (rank 0 creates the unique id, ``torch.distributed`` carries it to the others).  One per process and
-    group is enough; hand it to every ``ShardedTileMerger(..., exchange=...)``."""
+    group is enough (``shared_exchange`` keeps one); hand it to every ``ShardedTileMerger(..., exchange=...)``."""
 
     def __init__(self, device, group=None, dist=None):
         import ctypes
@@ -431,14 +507,15 @@ class RcclExchange:
         self.stream = torch.cuda.Stream(device=self.device)       # the exchange runs here, beside the merge kernels
 
     def post(self, sends, recvs, after_event=None):
-        """sends / recvs: [(tensor, peer rank in the group)].  Waits (on its own stream) for ``after_event`` -- or for everything
-        queued on the current stream so far -- then posts all transfers as one group.  ``wait()`` joins the current stream."""
+        """sends / recvs: [(tensor, peer rank in the group)].  The communication stream waits for ``after_event`` when it was
+        recorded (the pack of the last outgoing rectangle), else for everything queued on the current stream so far, then all
+        transfers are posted as one group.  Returns a handle whose ``wait()`` joins the current stream with THIS exchange."""
         import ctypes
 
         from . import _native as N
 
         cur = torch.cuda.current_stream(self.device)
-        if after_event is not None:
+        if after_event is not None and getattr(after_event, "cuda_event", 0):
             self.stream.wait_event(after_event)
         else:
             self.stream.wait_stream(cur)
@@ -456,8 +533,12 @@ class RcclExchange:
         N.check(rc, "ptb_halo_exchange")
         for t, _p in list(sends) + list(recvs):
             t.record_stream(self.stream)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _StreamWork(done, self.device)
 
     def wait(self):
+        """Join the current stream with everything posted so far."""
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
 
     def close(self):
@@ -468,6 +549,75 @@ class RcclExchange:
             self.comm = None
 
 
+_shared_exchanges = {}      # (device index, id of the process group) -> RcclExchange | None (None: tried, every rank fell back together)
+
+
+def shared_exchange(device, group=None, dist=None):
+    """The process's ``RcclExchange`` for ``group`` on ``device``, created on first use -- COLLECTIVE, like constructing a
+    ``ShardedTileMerger`` is: every rank of the group calls it.  Returns None (on every rank alike: the outcome is agreed by an
+    all-reduce) when RCCL cannot be bound or the communicator cannot be set up on some rank; the merger then posts its rectangles
+    with ``torch.distributed.batch_isend_irecv``."""
+    if dist is None:
+        import torch.distributed as dist
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), id(group))
+    if key in _shared_exchanges:
+        return _shared_exchanges[key]
+    ex, err = None, None
+    try:
+        ex = RcclExchange(device, group=group, dist=dist)
+    except Exception as exc:  # noqa: BLE001
+        err = exc
+    ok = torch.tensor([1 if ex is not None else 0], device=device, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0:
+        if ex is not None:
+            ex.close()
+        from .inference.tiles import _warn_once
+
+        _warn_once(("rccl-exchange",), f"ShardedTileMerger: the library's own RCCL communicator is not available on every rank ({err!r}); "
+                                       "the halo exchange is posted with torch.distributed.batch_isend_irecv instead.")
+        ex = None
+    _shared_exchanges[key] = ex
+    return ex
+
+
+class _ImageSlot:
+    """Everything of a ``ShardedTileMerger`` that belongs to ONE image in flight: the band accumulator or the deferred band plan,
+    the packed send / receive rectangles and the handles of the posted exchange.  A pipelined merger alternates between two."""
+
+    __slots__ = ("local", "deferred", "send_buf", "recv_buf", "pending", "exchanged", "remaining", "result", "ticket")
+
+    def __init__(self):
+        self.local = self.deferred = None
+        self.send_buf, self.recv_buf, self.pending = [], [], []
+        self.exchanged, self.remaining, self.result, self.ticket = False, {}, None, None
+
+
+class PendingBand:
+    """What ``ShardedTileMerger.merge_async()`` returns: this rank's band of an image whose halo exchange may still be in flight.
+    ``result()`` completes it (adds the neighbours' partial sums, divides the shared rows) on the current stream and returns the
+    ``[C, o1 - o0, W]`` band (None for a rank that owns no rows); idempotent."""
+
+    __slots__ = ("_merger", "_slot", "_value", "_done")
+
+    def __init__(self, merger, slot):
+        self._merger, self._slot, self._value, self._done = merger, slot, None, slot is None
+
+    @property
+    def done(self) -> bool:
+        return self._done
+
+    def result(self):
+        if not self._done:
+            slot, self._slot = self._slot, None
+            self._value = self._merger._complete(slot)
+            self._done = True
+            if slot.ticket is self:
+                slot.ticket = None
+        return self._value
+
+
 class ShardedTileMerger:
     """Drop-in shaped like ``TileMerger`` for one rank of a sharded merge of ONE image.
 
@@ -475,26 +625,38 @@ class ShardedTileMerger:
     (indices into ``crops``, in the order that lets the exchange overlap the accumulation) -- in absolute coordinates.
     ``merge()`` returns this rank's owned rows ``[C, o1 - o0, W]`` (``owned_rows`` gives the absolute range);
     ``gather()`` assembles the full map on every rank.  ``partition``: ``"tiles"`` (contiguous tile ranges, the
-    reference's ``split_across_nodes`` rule; default) or ``"rows"`` (whole tile rows).
+    reference's ``split_across_nodes`` rule; default), ``"rows"`` (whole tile rows) or ``"pixel_rows"`` (communication-free:
+    every rank owns an equal share of the PIXEL rows and is fed every tile touching them -- boundary tiles are evaluated by
+    both neighbours, nothing is exchanged, and the result equals the single-device merge bit for bit).
+
+    Pipelining (a stream of images): ``merge_async()`` ends an image without waiting for its halo exchange and moves the merger
+    on to a second set of buffers; the exchange of image i then runs beside the kernels of image i + 1 and is only joined when
+    ``PendingBand.result()`` is called (or, at the latest, when image i + 2 needs the buffers back).  ``merge()`` stays the
+    synchronous form (exchange joined inside the same image).
     """
 
     def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=False,
-                 defer_rows=None, two_phase=True, exchange=None):
+                 defer_rows=None, two_phase=True, exchange="auto", pipeline_depth=2):
         """``defer=True`` (opt-in, like ``TileMerger``): the rank's tiles are merged band by band straight from the model outputs
         (no accumulator).  The contract that comes with it: the batches are kept by reference and read by a LATER launch, so they
         must stay alive and unmodified until ``merge()`` (a reused output buffer or an in-place edit raises), and the tiles must
-        be fed in ``self.tiles`` order."""
+        be fed in ``self.tiles`` order.
+
+        ``exchange``: ``"auto"`` (default) -- under the ``nccl`` backend (RCCL) on CUDA devices the rectangles travel as ONE
+        ncclGroup posted from C on the library's own communicator (``shared_exchange``; collective at construction), anywhere
+        else (gloo, CPU stand-ins) as ``torch.distributed.batch_isend_irecv``; ``"torch"`` / None force the latter; or an
+        ``RcclExchange`` of the caller's."""
         if dist is None:
             import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.two_phase = bool(two_phase)     # deferred plan: one early launch for the rows neighbours wait for + the rest (else: cut by cut)
-        self.exchange = exchange             # an RcclExchange: the halo exchange as one ncclGroup posted from C (default: torch.distributed p2p)
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.ops = ops or _HipOps
         self.device = torch.device(device)
         self.channels = channels
+        self.partition = partition
         self.image_height, self.image_width = int(image_shape[0]), int(image_shape[1])
         crops = np.asarray(crops)
         self.plan = band_plan(crops, self.world, self.image_height, partition)
@@ -503,9 +665,10 @@ class ShardedTileMerger:
         self.band = me["band"]
         self.owned_rows = me["owned"]
         self.sends, self.recvs = me["sends"], me["recvs"]
-        self.local = None
-        self._result = None
-        self._pending = []
+        self.exchange = self._resolve_exchange(exchange)
+        self.pipeline_depth = max(1, int(pipeline_depth))
+        self._slots, self._cur = [_ImageSlot()], 0
+        self.images_async = 0        # images ended with merge_async() (diagnostics)
         if self.band is None:
             return
         a, b = self.band
@@ -513,7 +676,6 @@ class ShardedTileMerger:
         # the owned range may start above the band (rank 0 owns from row 0) or end below it (last rank): cover both
         self.top = min(a, o0)
         self.bottom = max(b, o1)
-        self.local = self.ops.new_local((self.bottom - self.top, self.image_width), channels, weight, self.device)
         # global normaliser of the owned rows: accumulate the window of EVERY tile touching them (data independent)
         th = int(crops[0, 3])
         self.norm_owned = None
@@ -532,40 +694,124 @@ class ShardedTileMerger:
         self._boundary = {}
         for x, y in crops[me["boundary"], :2]:
             self._boundary[(int(x), int(y))] = self._boundary.get((int(x), int(y)), 0) + 1
-        self._send_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _d, r0, r1, c0, c1 in self.sends]
-        self._recv_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _s, r0, r1, c0, c1 in self.recvs]
+        self._crops, self._weight, self._defer_cfg = crops, weight, (bool(defer), defer_rows)
+        self._warned_defer = False
+        self._fill_slot(self._slots[0])
+        self.reset()
+
+    def _resolve_exchange(self, exchange):
+        if exchange is None or exchange == "torch":
+            return None
+        if exchange != "auto":
+            return exchange
+        import os
+
+        dist = self.dist
+        if (os.environ.get("PTB_EXCHANGE", "auto") == "torch" or self.ops is not _HipOps or self.device.type != "cuda" or self.world < 2
+                or not hasattr(dist, "get_backend")):
+            return None
+        try:
+            if str(dist.get_backend(self.group)).lower() != "nccl":
+                return None
+        except Exception:  # noqa: BLE001
+            return None
+        return shared_exchange(self.device, self.group, dist)
+
+    def _fill_slot(self, slot):
+        """Buffers of one image in flight (the second set is only made when ``merge_async()`` is first used)."""
+        crops, weight = self._crops, self._weight
+        defer, defer_rows = self._defer_cfg
+        o0, o1 = self.owned_rows
+        channels = self.channels
+        slot.send_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _d, r0, r1, c0, c1 in self.sends]
+        slot.recv_buf = [torch.empty((channels, r1 - r0, c1 - c0), device=self.device) for _s, r0, r1, c0, c1 in self.recvs]
         # Deferred band merging (opt-in): the rank's tiles are merged band by band straight from the model outputs
         # -- no accumulator read-modify-write, partial sums instead of accumulator rectangles on the rows shared with neighbours.
         # Needs the tiles in `self.tiles` order and a geometry on the 4-pixel grid; otherwise the incremental path below is used.
-        self._deferred = None
         if defer and self.ops is _HipOps and o1 > o0:
             from .inference.tiles import _defer_rows_default, _warn_once
 
-            self._deferred = _DeferredBand.build(self, crops, weight, defer_rows if defer_rows is not None else _defer_rows_default())
-            if self._deferred is None:
+            shared = next((s.deferred for s in self._slots if s.deferred is not None), None)
+            slot.deferred = _DeferredBand.build(self, crops, weight, defer_rows if defer_rows is not None else _defer_rows_default(),
+                                                slot.send_buf, slot.recv_buf, shared=shared)
+            if slot.deferred is None:
                 _warn_once(("sharded-defer",), "ShardedTileMerger(defer=True): the band plan does not take this geometry (tile origins / "
                                                "ownership cuts off the 4-pixel grid, more than 4 tiles over a pixel); using the "
                                                "incremental accumulate + exchange path.")
-        self.reset()
+        if slot.deferred is None:
+            slot.local = self.ops.new_local((self.bottom - self.top, self.image_width), channels, weight, self.device)
+        else:
+            slot.local = slot.deferred      # (truthy marker: this rank has a band)
+
+    # ------------------------------------------------------------------ the current image's slot, under the names the code grew up with
+    @property
+    def local(self):
+        return self._slots[self._cur].local
+
+    @property
+    def _deferred(self):
+        return self._slots[self._cur].deferred
+
+    @property
+    def _send_buf(self):
+        return self._slots[self._cur].send_buf
+
+    @property
+    def _recv_buf(self):
+        return self._slots[self._cur].recv_buf
+
+    @property
+    def _pending(self):
+        return self._slots[self._cur].pending
+
+    @_pending.setter
+    def _pending(self, v):
+        self._slots[self._cur].pending = v
+
+    @property
+    def _exchanged(self):
+        return self._slots[self._cur].exchanged
+
+    @_exchanged.setter
+    def _exchanged(self, v):
+        self._slots[self._cur].exchanged = v
+
+    @property
+    def _remaining(self):
+        return self._slots[self._cur].remaining
+
+    @_remaining.setter
+    def _remaining(self, v):
+        self._slots[self._cur].remaining = v
+
+    @property
+    def _result(self):
+        return self._slots[self._cur].result
+
+    @_result.setter
+    def _result(self, v):
+        self._slots[self._cur].result = v
 
     # ------------------------------------------------------------------ per-image cycle
     def reset(self):
-        """Start a new image: zero the band accumulator and re-arm the exchange."""
-        self._wait_pending()
-        self._exchanged = False
-        self._result = None
-        if self.local is None:
+        """Start a new image in the current buffers: zero the band accumulator and re-arm the exchange."""
+        slot = self._slots[self._cur]
+        if slot.ticket is not None:
+            slot.ticket.result()         # an image ended with merge_async() still lives here: complete it first
+        self._wait_pending(slot)
+        slot.exchanged, slot.result = False, None
+        if slot.local is None:
             return
-        if self._deferred is not None:
-            self._deferred.reset()
-            self._remaining = {}
+        if slot.deferred is not None:
+            slot.deferred.reset()
+            slot.remaining = {}
             return
-        if hasattr(self.local, "reset"):
-            self.local.reset()          # first-touch accumulators: no memset
+        if hasattr(slot.local, "reset"):
+            slot.local.reset()          # first-touch accumulators: no memset
         else:
-            self.local.image.zero_()
-            self.local.norm_mask.zero_()
-        self._remaining = dict(self._boundary)
+            slot.local.image.zero_()
+            slot.local.norm_mask.zero_()
+        slot.remaining = dict(self._boundary)
 
     def _shift(self, crop_coords):
         c = np.array(crop_coords.cpu() if torch.is_tensor(crop_coords) else crop_coords, dtype=np.int64).reshape(-1, 4).copy()
@@ -643,12 +889,14 @@ class ShardedTileMerger:
         self.local.integrate_batch_deaugment(batch, c, group=group, reduction=reduction)
         self._after_integrate(origins)
 
-    def _rect(self, r0, r1, c0, c1):
+    def _rect(self, r0, r1, c0, c1, slot=None):
         """View of the band accumulator on an absolute pixel rectangle, valid to READ now: blocks of the rectangle no
         kernel has written yet are zero-filled first (only those -- the interior keeps its first-touch state)."""
-        if self._deferred is not None:      # partial sums written by the band launches (the caller checked rows_launched)
-            return self._deferred.out[:, r0 - self.top:r1 - self.top, c0:c1]
-        loc = self.local
+        slot = slot or self._slots[self._cur]
+        if slot.deferred is not None:      # partial sums written by the band launches (the caller checked rows_launched)
+            d = slot.deferred
+            return d.out[:, r0 - d.top:r1 - d.top, c0:c1]
+        loc = slot.local
         if hasattr(loc, "_zero_fresh"):
             loc._zero_fresh(r0 - self.top, r1 - self.top, c0, c1)
             img = loc._image
@@ -657,67 +905,110 @@ class ShardedTileMerger:
         return img[:, r0 - self.top:r1 - self.top, c0:c1]
 
     def _start_exchange(self):
-        """Post all halo sends / receives as one batch (one ncclGroup: every pair progresses concurrently, each on its
-        own xGMI link, both directions of a link at once) on RCCL's stream; the caller's stream keeps accumulating the
-        remaining tiles."""
-        self._exchanged = True
-        if self.local is None:
+        """Post all halo sends / receives of the current image as one batch (one ncclGroup: every pair progresses concurrently,
+        each on its own xGMI link, both directions of a link at once) on the communication stream; the caller's stream keeps
+        accumulating the remaining tiles -- and, after ``merge_async()``, the next image."""
+        slot = self._slots[self._cur]
+        slot.exchanged = True
+        if slot.local is None:
             return
         dist = self.dist
         ops = []
-        d = self._deferred
+        d = slot.deferred
+        if not self.sends and not self.recvs:
+            return
         if self.exchange is not None:
-            for k, (buf, (_dst, r0, r1, c0, c1)) in enumerate(zip(self._send_buf, self.sends)):
+            for k, (buf, (_dst, r0, r1, c0, c1)) in enumerate(zip(slot.send_buf, self.sends)):
                 if d is None or not d.packed[k]:
                     buf.copy_(self._rect(r0, r1, c0, c1))
             all_packed_in_c = d is not None and d.n_sends and all(d.packed[k] for k in range(d.n_sends))
-            self.exchange.post([(buf, dst) for buf, (dst, *_r) in zip(self._send_buf, self.sends)],
-                               [(buf, src) for buf, (src, *_r) in zip(self._recv_buf, self.recvs)],
-                               after_event=d.ready_event if all_packed_in_c else None)
-            self._pending = [self.exchange]
+            work = self.exchange.post([(buf, dst) for buf, (dst, *_r) in zip(slot.send_buf, self.sends)],
+                                      [(buf, src) for buf, (src, *_r) in zip(slot.recv_buf, self.recvs)],
+                                      after_event=d.ready_event if all_packed_in_c else None)
+            slot.pending = [work if work is not None else self.exchange]
             return
-        for k, (buf, (dst, r0, r1, c0, c1)) in enumerate(zip(self._send_buf, self.sends)):
+        for k, (buf, (dst, r0, r1, c0, c1)) in enumerate(zip(slot.send_buf, self.sends)):
             if d is None or not d.packed[k]:
                 buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
-        for buf, (src, *_rect) in zip(self._recv_buf, self.recvs):
+        for buf, (src, *_rect) in zip(slot.recv_buf, self.recvs):
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
         if ops:
-            self._pending = dist.batch_isend_irecv(ops)
+            slot.pending = dist.batch_isend_irecv(ops)
 
     def _global_rank(self, r):
         if self.group is None:
             return r
         return self.dist.get_global_rank(self.group, r)
 
-    def _wait_pending(self):
-        for w in self._pending:
+    def _wait_pending(self, slot=None):
+        slot = slot or self._slots[self._cur]
+        for w in slot.pending:
             w.wait()
-        self._pending = []
+        slot.pending = []
 
-    def merge(self):
-        """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank that owns no rows)."""
-        if self.local is None:
-            return None
-        if self._result is not None:       # a second merge() of the same image: the same tensor (nothing is added or divided twice)
-            return self._result
-        if not self._exchanged:
+    def _end_of_image(self, slot):
+        """Every tile of the image is in: make sure its exchange has been posted."""
+        if slot.deferred is not None and not slot.deferred.complete():
+            raise RuntimeError("ShardedTileMerger.merge(): not all of this rank's tiles were integrated")
+        if not slot.exchanged:
             self._start_exchange()
-        self._wait_pending()
+
+    def _complete(self, slot):
+        """Join the image's exchange (the current stream waits for it) and finish the owned rows; returns the band."""
+        self._wait_pending(slot)
         o0, o1 = self.owned_rows
         if o1 <= o0:
             return None
-        self._result = self._merge_deferred(o0, o1) if self._deferred is not None else self._merge_incremental(o0, o1)
-        return self._result
+        return self._merge_deferred(slot, o0, o1) if slot.deferred is not None else self._merge_incremental(slot, o0, o1)
 
-    def _merge_incremental(self, o0, o1):
+    def merge(self):
+        """This rank's owned rows of ``image / norm_mask`` as ``[C, o1 - o0, W]`` (None for a rank that owns no rows)."""
+        slot = self._slots[self._cur]
+        if slot.local is None:
+            return None
+        if slot.result is not None:       # a second merge() of the same image: the same tensor (nothing is added or divided twice)
+            return slot.result
+        self._end_of_image(slot)
+        slot.result = self._complete(slot)
+        return slot.result
+
+    def merge_async(self) -> PendingBand:
+        """End the current image WITHOUT joining its halo exchange and start the next one in the other set of buffers (no
+        ``reset()`` needed).  The returned handle's ``result()`` joins the exchange and finishes the band; call it after the next
+        image's tiles have been integrated (that is what hides the exchange) -- at the latest it is called for you when the
+        image after next needs the buffers back.  All ranks must call ``merge_async()`` / ``merge()`` in the same sequence."""
+        slot = self._slots[self._cur]
+        if slot.local is None:
+            return PendingBand(self, None)
+        if slot.result is not None:
+            raise RuntimeError("ShardedTileMerger.merge_async(): this image was already merged with merge(); call reset() first")
+        self._end_of_image(slot)
+        if slot.deferred is not None:
+            slot.deferred.held = []       # every launch that reads the batches has been issued (stream order keeps their memory safe)
+        ticket = slot.ticket = PendingBand(self, slot)
+        self.images_async += 1
+        # move on: the next image lives in the next slot (made on first use); whatever image still sits there is completed first
+        if self.pipeline_depth < 2:
+            ticket.result()
+        else:
+            nxt = (self._cur + 1) % self.pipeline_depth
+            while len(self._slots) <= nxt:
+                new = _ImageSlot()
+                self._fill_slot(new)
+                self._slots.append(new)
+            self._cur = nxt
+        self.reset()
+        return ticket
+
+    def _merge_incremental(self, slot, o0, o1):
         # the band accumulator, readable on the rows this rank owns and on every received rectangle (blocks there that no
         # kernel has written are zero-filled; rows owned by other ranks keep their first-touch state: nobody reads them)
         for _src, r0, r1, c0, c1 in [(None, o0, o1, 0, self.image_width)] + list(self.recvs):
-            self._rect(r0, r1, c0, c1)
-        image = self.local._image if hasattr(self.local, "_zero_fresh") else self.local.image
+            self._rect(r0, r1, c0, c1, slot)
+        image = slot.local._image if hasattr(slot.local, "_zero_fresh") else slot.local.image
         extra, extra_rows = None, 0
-        for buf, (_src, r0, r1, c0, c1) in zip(self._recv_buf, self.recvs):
+        for buf, (_src, r0, r1, c0, c1) in zip(slot.recv_buf, self.recvs):
             if extra is None and r0 == o0 and c0 == 0 and c1 == self.image_width:
                 extra, extra_rows = buf, r1 - r0     # a full-width strip at the top of the band: folded into the division
             else:
@@ -725,22 +1016,23 @@ class ShardedTileMerger:
         out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
         return self.ops.merge_rows(image[:, o0 - self.top:o1 - self.top], self.norm_owned[0], out, extra, extra_rows)
 
-    def _merge_deferred(self, o0, o1):
+    def _merge_deferred(self, slot, o0, o1):
         """Owned rows from the band plan's output: the rows finished alone already hold ``sum / norm``; the others hold this
         rank's partial sums, get the neighbours' partial sums added and are divided in place (<= 2 row ranges)."""
         from . import _native as N
 
-        d = self._deferred
+        d = slot.deferred
         if not d.complete():
             raise RuntimeError("ShardedTileMerger.merge(): not all of this rank's tiles were integrated")
-        # add the neighbours' partial sums, divide the rows that held partial sums: one C call (ptb_rect_add + ptb_merge_div_ex launches)
-        with N.on_device(self.device):
-            rc = N.load().ptb_band_plan_finish_rank(d.handle, d.out.data_ptr(), d.norm.data_ptr(), d.n_recvs, d.recv_rects_p,
-                                                    d.recv_ptrs if d.n_recvs else None, d.n_ranges, d.ranges_p, N.stream_ptr(self.device))
-        N.bump()
-        N.check(rc, "ShardedTileMerger.merge (deferred band)")
+        if d.n_recvs or d.n_ranges:
+            # add the neighbours' partial sums, divide the rows that held partial sums: one C call (ptb_rect_add + ptb_merge_div_ex launches)
+            with N.on_device(self.device):
+                rc = N.load().ptb_band_plan_finish_rank(d.handle, d.out.data_ptr(), d.norm.data_ptr(), d.n_recvs, d.recv_rects_p,
+                                                        d.recv_ptrs if d.n_recvs else None, d.n_ranges, d.ranges_p, N.stream_ptr(self.device))
+            N.bump()
+            N.check(rc, "ShardedTileMerger.merge (deferred band)")
         d.held = []
-        return d.out[:, o0 - self.top:o1 - self.top]
+        return d.out[:, o0 - d.top:o1 - d.top]
 
     def gather(self, band):
         """All-gather the bands into the full ``[C, H, W]`` map on every rank (optional; 52 MB per rank at cfg2)."""

@@ -385,3 +385,172 @@ def test_rank_band_plan_launches_by_class(world):
         assert counts[True] <= counts[False]
         if world == 8:
             assert counts[True] == 2, counts
+
+
+# ------------------------------------------------------------------ pipelined exchange (merge_async) and the communication-free partition
+def _pipeline_worker(rank, world, port, shape, tile, step, C, partition, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        geom = TO.slicer_geometry(shape, tile, step)
+        w = TO.pyramid_window(*tile)[0]
+        crops = geom["crops"]
+        rng = np.random.default_rng(23)
+        outs = rng.standard_normal((len(crops), C, *tile)).astype(np.float32)
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device="cpu", ops=OracleOps, partition=partition)
+        mine = m.tiles
+
+        def feed(image_no):
+            for b0 in range(0, len(mine), 3):
+                idx = mine[b0:b0 + 3]
+                m.integrate_batch(torch.from_numpy(outs[idx] * (image_no + 1)), crops[idx])
+
+        n_images = 5
+        tickets, bands = [], []
+        for image_no in range(n_images):          # image i's exchange is only joined after image i + 1 was fed
+            feed(image_no)
+            tickets.append(m.merge_async())
+            if image_no >= 1:
+                bands.append(tickets[image_no - 1].result())
+        bands.append(tickets[-1].result())
+        assert all(t.done for t in tickets) and tickets[0].result() is bands[0]
+        assert m.images_async == (n_images if m.local is not None else 0)
+        if m.local is not None:
+            assert len(m._slots) == 2, "a pipelined merger alternates between two sets of buffers"
+        # never calling result() in time is fine too: the slot's image is completed when its buffers are needed again
+        lazy_tickets = []
+        for image_no in range(3):
+            feed(image_no)
+            lazy_tickets.append(m.merge_async())
+        if m.local is not None:
+            assert lazy_tickets[0].done and not lazy_tickets[2].done
+        late = [t.result() for t in lazy_tickets]
+        # the synchronous form of the same images: the same bits
+        for image_no in range(n_images):
+            m.reset()
+            feed(image_no)
+            band = m.merge()
+            assert (band is None) == (bands[image_no] is None)
+            if band is not None:
+                assert torch.equal(band, bands[image_no]), f"pipelined image {image_no} differs from the synchronous merge"
+                if image_no < 3:
+                    assert torch.equal(band, late[image_no])
+        full = m.gather(bands[1])
+        if rank == 0:
+            q.put(full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,tile,step,C,partition", [
+    (2, (300, 200), (64, 64), (32, 32), 2, "tiles"),
+    (3, (300, 200), (64, 64), (32, 32), 1, "rows"),
+    (5, (300, 200), (64, 64), (32, 32), 1, "tiles"),
+    (8, (300, 200), (64, 64), (32, 32), 1, "tiles"),
+    (8, (40, 40), (64, 64), (32, 32), 1, "tiles"),        # one tile, eight ranks: seven of them idle through the whole pipeline
+    (3, (300, 200), (64, 64), (32, 32), 2, "pixel_rows"),
+])
+def test_pipelined_merge_equals_synchronous(world, shape, tile, step, C, partition):
+    """merge_async(): image i's halo exchange stays in flight while image i + 1 is integrated (second set of buffers) and is joined
+    by PendingBand.result() -- bit-identical to the synchronous merge() of the same image, and the gathered map equals the
+    single-process merge."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, shape, tile, step, C, partition, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    geom = TO.slicer_geometry(shape, tile, step)
+    w = TO.pyramid_window(*tile)[0]
+    rng = np.random.default_rng(23)
+    outs = rng.standard_normal((len(geom["crops"]), C, *tile)).astype(np.float32) * 2
+    st = TO.merger_new(geom["target_shape"], C, w)
+    TO.merger_integrate(st, outs, geom["crops"])
+    want = TO.merger_merge(st)
+    if partition == "pixel_rows":
+        assert np.array_equal(full, want, equal_nan=True), "the communication-free partition must reproduce the single-device bits"
+    else:
+        np.testing.assert_allclose(full, want, rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5, 8, 16])
+def test_pixel_row_partition_is_bit_identical_to_one_device(world):
+    """partition="pixel_rows": every rank owns an equal share of the pixel rows and holds every tile touching them; no rectangle
+    travels, and because every covering tile of an owned pixel is local and summed in the global order, the assembled map is the
+    single-device merge bit for bit (ragged geometry, uncovered rows included)."""
+    from pytorch_toolbelt_amd.parallel import pixel_row_cuts, pixel_row_partition
+
+    rng = np.random.default_rng(world)
+    for shape, tile, step in [((300, 200), (64, 64), (32, 32)), ((130, 90), (48, 32), (20, 32)), ((64, 64), (64, 64), (64, 64))]:
+        geom = TO.slicer_geometry(shape, tile, step)
+        crops = geom["crops"]
+        H, W = geom["target_shape"]
+        w = TO.pyramid_window(*tile)[0]
+        outs = rng.standard_normal((len(crops), 2, *tile)).astype(np.float32)
+        cuts = pixel_row_cuts(H, world)
+        assert cuts[0] == 0 and cuts[-1] == H and all(b >= a for a, b in zip(cuts, cuts[1:]))
+        parts = pixel_row_partition(crops, world, H)
+        full = np.full((2, H, W), np.nan, dtype=np.float32)
+        owned = np.zeros(H, dtype=int)
+        for r in range(world):
+            m = ShardedTileMerger((H, W), 2, w, crops, device="cpu", ops=OracleOps, dist=_FakeDist(r, world), partition="pixel_rows")
+            assert m.sends == [] and m.recvs == [] and m.tiles.tolist() == parts[r].tolist()
+            if m.local is None:
+                continue
+            for b0 in range(0, len(m.tiles), 4):
+                idx = m.tiles[b0:b0 + 4]
+                m.integrate_batch(torch.from_numpy(outs[idx]), crops[idx])
+            band = m.merge_async().result()
+            o0, o1 = m.owned_rows
+            owned[o0:o1] += 1
+            full[:, o0:o1] = band.numpy()
+        assert (owned == 1).all()
+        st = TO.merger_new((H, W), 2, w)
+        TO.merger_integrate(st, outs, crops)
+        assert np.array_equal(full, TO.merger_merge(st), equal_nan=True)
+    # headline geometry: balanced rows on the 64-row grid, 57 .. 76 tiles per rank at N = 8 (against 45 / 46 when tiles are not shared)
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    if world == 8:
+        parts = pixel_row_partition(geom["crops"], 8, 5120)
+        assert pixel_row_cuts(5120, 8) == [640 * i for i in range(9)]
+        assert [len(p) for p in parts] == [57, 76, 76, 76, 76, 76, 76, 57]
+
+
+def test_rank_band_plan_clips_tiles_to_the_owned_pixel_rows():
+    """ptb_band_plan_create3(PTB_PLAN_CLIP_ROWS) (host-side planning, runs without a GPU): the plan of a pixel-row rank covers exactly
+    its owned rows, accepts tiles that hang over both ends, and is refused without the flag."""
+    import ctypes
+
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.parallel import band_plan
+
+    lib = N.load()
+    geom = TO.slicer_geometry((5000, 5000), 512, 256)
+    crops = geom["crops"]
+    plan = band_plan(crops, 8, 5120, "pixel_rows")
+    for r in (0, 1, 7):
+        o0, o1 = plan[r]["owned"]
+        local = np.ascontiguousarray(crops[plan[r]["tiles"], :2].T.astype(np.int64))
+        local[1] -= o0
+        assert (local[1] < 0).any() or r == 0
+        for flags, ok in ((0, False), (1, True)):
+            handle = ctypes.c_void_p()
+            nbytes = lib.ptb_band_plan_create3(local[0].ctypes.data_as(N._i64p), local[1].ctypes.data_as(N._i64p), local.shape[1], 4, 512, 512,
+                                               o1 - o0, 5120, 1024, 0, o1 - o0, None, 0, None, 0, flags, ctypes.byref(handle))
+            if not ok:
+                assert nbytes == -4, nbytes            # PTB_EBOUNDS: a tile outside the plan's rows
+                continue
+            assert nbytes > 0
+            ng, nb, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+            lib.ptb_band_plan_info(handle, ctypes.byref(ng), ctypes.byref(nb), ctypes.byref(ni), None, None)
+            rows = np.zeros(3 * ng.value, dtype=np.int64)
+            lib.ptb_band_plan_info(handle, None, None, None, None, rows.ctypes.data_as(N._i64p))
+            assert rows[0] == 0 and rows[3 * ng.value - 2] == o1 - o0
+            # 640 owned rows x 5120 columns in 64 x 64 (or 64 x 32) items: every owned pixel exactly once
+            assert ni.value in (640 * 5120 // (64 * 64), 640 * 5120 // (64 * 32))
+            lib.ptb_band_plan_destroy(handle)
+    assert lib.ptb_band_plan_create3(None, None, 1, 1, 4, 4, 4, 4, 4, 0, 4, None, 0, None, 0, 2, None) == -1
