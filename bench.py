@@ -18,16 +18,21 @@ brings its last tile), `--unplanned` (no crop list: accumulate kernels + lazily 
 pass), `--memset-accumulators` (kernel-maintained normaliser, memset accumulators: the reference's literal data flow).
 All four produce bit-identical results (tests/test_tiles_gpu.py).
 
-Untimed set-up (all of it reported in the JSON line): the model-output pool is allocated `--placement-tries` times side by side,
-a few steps are run on each candidate and the fastest is kept (which device memory backs the 12 GB decides 10-15 % of the loop's
-speed on these boxes, tools/placement_map.py); then a ramp until the step time has settled, the W warm-up steps, and EXACTLY K
-timed steps `--repeats` times (value = the median run).
+`value` is measured on the model-output pool exactly as torch's allocator first hands it out: a ramp until the step time has
+settled, the W warm-up steps, and EXACTLY K timed steps `--repeats` times (value = the median run).  Which device memory backs
+the 12 GB decides up to 10-15 % of the loop's speed on some boxes (tools/placement_map.py); what a process that owns its buffers
+could gain by choosing among `--placement-tries` candidate pools is measured AFTER the headline and reported separately as
+`config.best_placement` (never `value`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the 361 tiles of ONE image are sharded over the
 ranks as contiguous tile ranges (45 / 46 tiles each at N = 8), neighbouring ranks exchange their 256-row halo rectangles
-point-to-point over xGMI and every rank merges its own band (strong scaling: total work per step is fixed).  Rank 0 prints one JSON line.
+point-to-point over xGMI (one ncclGroup per image on the library's own communicator) and every rank merges its own band (strong
+scaling: total work per step is fixed).  Steps are pipelined (`merge_async`): image i's exchange runs beside image i+1's kernels;
+the K timed steps are K whole images, the last one completed inside the timed region.  `config.sharded` reports, per rank, the
+compute-only time, the bytes per link and the exchange left exposed in pipelined and in latency mode (PTB_BENCH_SHARDED_MODE=sync
+makes latency mode the headline).  Rank 0 prints one JSON line.
 """
 import argparse
 import gc
@@ -487,11 +492,9 @@ def main():
     if not sharded:
         my_tiles = np.arange(n_tiles)
     else:
-        exchange = None
-        if os.environ.get("PTB_BENCH_EXCHANGE", "torch") == "rccl":      # A/B: the exchange posted from C as one ncclGroup (ptb_halo_exchange)
-            from pytorch_toolbelt_amd.parallel import RcclExchange
-
-            exchange = RcclExchange(dev)
+        # default: under nccl the rectangles travel as ONE ncclGroup posted from C on the library's own communicator (falls back to
+        # torch.distributed p2p on every rank alike when RCCL cannot be bound); PTB_BENCH_EXCHANGE=torch forces batch_isend_irecv
+        exchange = {"auto": "auto", "rccl": "auto", "torch": None}[os.environ.get("PTB_BENCH_EXCHANGE", "auto")]
         sharded_merger = ShardedTileMerger(slicer.target_shape, CHANNELS, slicer.weight, slicer.crops, device=dev, partition=partition,
                                            defer=os.environ.get("PTB_BENCH_SHARDED_DEFER", "1") == "1", exchange=exchange)
         my_tiles = sharded_merger.tiles
@@ -548,12 +551,32 @@ def main():
             for t, c in zip(batch_tensors, batch_crops):
                 merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
             return merger.merge()
+        if pipelined:
+            # one image per step, pipelined: this image's halo exchange stays in flight while the NEXT step's kernels run (second set
+            # of buffers); the previous image is completed here, after this one's tiles were issued.  `drain()` completes the last.
+            for t, c in zip(batch_tensors, batch_crops):
+                merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+            ticket = merger.merge_async()
+            prev, in_flight[0] = in_flight[0], ticket
+            return prev.result() if prev is not None else None
         merger.reset()
         for t, c in zip(batch_tensors, batch_crops):
             merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
         return merger.merge()  # this rank's band of the merged image
 
+    in_flight = [None]
+    pipelined = sharded and os.environ.get("PTB_BENCH_SHARDED_MODE", "pipelined") == "pipelined"
+
+    def drain():
+        """Complete the image still in flight (pipelined sharded steps): part of every timed region, before its closing synchronize."""
+        if in_flight[0] is not None:
+            band = in_flight[0].result()
+            in_flight[0] = None
+            return band
+        return None
+
     def sync():
+        drain()
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -599,68 +622,6 @@ def main():
             print("[bench] falling back to the unplanned merger", file=sys.stderr)
             planned, fallback = False, "planned merger failed its probe step: unplanned merger used instead"
             merger = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev)
-    # Where the 12 GB of model outputs sit in device memory decides 10-15 % of this loop's speed: 16 pools allocated one after the
-    # other and all kept (tools/placement_map.py) run the SAME loop at 1.94 / 2.00 / 2.02 / 2.19 / 2.22 / 2.25 ms per image, each
-    # pool reproducible to 0.2 % round after round -- about half of the device memory is "fast" for this access pattern, and which
-    # half a process gets is the driver's physical placement (not page tables: UTCL1 misses are identical; not the kernel; not
-    # warm-up).  That is the whole 2.0-2.3 ms box-to-box / run-to-run spread of the headline.  A long-lived
-    # serving process picks its buffer pool once, so the benchmark does what such a process can do at start-up: allocate a few
-    # candidate pools one ~36 GB region apart (pytorch_toolbelt_amd/placement.py), run a few untimed steps on each, keep the fastest
-    # and give the others back to the driver.  Every candidate's time is in the JSON line (config.placement); --placement-tries 1
-    # takes the first allocation as it comes.
-    placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
-    first_alloc = None
-    if args.placement_tries > 1 and not use_dist:
-        # what a process that takes its first allocation as it comes would report (the ADVICE of round 2: the search result is
-        # best-of-N placements): a short ramp, then the same K steps timed the same way, on the pool allocated first
-        for _ in range(60):
-            step()
-        torch.cuda.synchronize()
-        fa = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize()
-            fa.append((time.perf_counter() - t0) / args.steps * 1e3)
-        fa_ms = sorted(fa)[1]
-        first_alloc = {"ms_per_step": round(fa_ms, 4), "value_MP_s": round(IMAGE[0] * IMAGE[1] / 1e3 / fa_ms, 1),
-                       "region_hbm_frac": round((VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) / (fa_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "note": "the same K steps on the model-output pool as first allocated, before the placement search (median of 3 runs)"}
-    # N > 1: the per-rank pools are small (1.5 GB at N = 8) and the search moved them by +-4 % in tools/shard_sim.py, inside its own
-    # noise, so it is off unless PTB_BENCH_DIST_PLACEMENT=1 (then every rank tries a fixed number of candidates on its own GPU)
-    if args.placement_tries > 1 and (not use_dist or os.environ.get("PTB_BENCH_DIST_PLACEMENT", "0") == "1"):
-        search_steps = 30
-
-        def run_ms(tensors, k):
-            nonlocal batch_tensors, search_steps
-            search_steps += k + 1
-            batch_tensors = tensors                      # (step() reads the variable)
-            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            step()
-            q0.record()
-            for _ in range(k):
-                step()
-            q1.record()
-            torch.cuda.synchronize()
-            return q0.elapsed_time(q1) / k
-
-        for _ in range(30):      # (leave the idle power state before anything is compared)
-            step()
-        from pytorch_toolbelt_amd.placement import choose_placement
-
-        need = sum(t.numel() * t.element_size() for t in batch_tensors)
-        (batch_tensors, _keep), rep = choose_placement(
-            lambda: alloc_outputs(0), lambda pool: min(run_ms(pool[0], 4), run_ms(pool[0], 4)), need, dev, first=(batch_tensors, _keep),
-            max_tries=args.placement_tries, fixed_count=min(args.placement_tries, 6) if use_dist else None)
-        per_cand, chosen = rep["by_candidate"], rep["chosen"]
-        torch.cuda.empty_cache()      # (the first pool was still referenced from here while the search ran)
-        placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen, "steps_run_by_the_search": search_steps,
-                     # (for tools/profile_report.py: the probe step, the first-allocation timing and the search all come before the chosen pool)
-                     "steps_before_the_chosen_pool": search_steps + 1 + (60 + 3 * args.steps if first_alloc is not None else 0),
-                     "note": "untimed set-up: candidate pools for the model outputs are allocated side by side, a few steps are run on each, the "
-                             "fastest is kept and the rest freed -- which device memory backs the pool decides 10-15 % of the loop's speed"}
     # power management: keep a GPU that has been idle (a fresh box, the seconds this process spent importing torch) busy for a
     # moment before the warm-up (untimed, like the build)
     ramp_groups = []
@@ -713,6 +674,67 @@ def main():
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     elapsed, region_event_ms = runs[order[len(order) // 2]]    # the median run is the reported one
     repeat_ms = [round(r[0] / args.steps * 1e3, 4) for r in runs]
+
+    # ---- N > 1: what the exchange costs, measured (the same fields tools/shard_sim.py predicts from a one-GPU box)
+    sharded_report = None
+    if sharded and world > 1:
+        def sync_step():
+            merger.reset()
+            for t, c in zip(batch_tensors, batch_crops):
+                merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+            return merger.merge()
+
+        def mode_ms(fn):
+            for _ in range(3):
+                fn()
+            return sorted(timed_run(fn, args.steps)[0] for _ in range(3))[1] / args.steps * 1e3
+
+        other_ms = mode_ms(sync_step if pipelined else step)     # the mode that is not the headline
+        # compute only: the same steps with the exchange stubbed out on every rank (rectangles packed, nothing sent, the receive
+        # buffers used as they are -- wrong pixels on the shared rows, same kernels and bytes)
+        real_start = merger._start_exchange
+
+        def stub_exchange():
+            merger._exchanged = True
+
+        merger._start_exchange = stub_exchange
+        try:
+            for _ in range(3):
+                sync_step()
+            torch.cuda.synchronize()
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            for _ in range(args.steps):
+                sync_step()
+            c1.record()
+            torch.cuda.synchronize()
+            compute_ms = c0.elapsed_time(c1) / args.steps
+        finally:
+            del merger._start_exchange
+            assert merger._start_exchange.__func__ is real_start.__func__
+        sync()
+        mine = {"rank": rank, "tiles": int(len(crops)), "owned_rows": list(merger.owned_rows or (0, 0)), "compute_only_ms": round(compute_ms, 4),
+                "out_MB_per_link": {str(d): round((r1 - r0) * (c1_ - c0_) * CHANNELS * 4 / 1e6, 2) for d, r0, r1, c0_, c1_ in merger.sends},
+                "in_MB_per_link": {str(s_): round((r1 - r0) * (c1_ - c0_) * CHANNELS * 4 / 1e6, 2) for s_, r0, r1, c0_, c1_ in merger.recvs}}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        ms_now = elapsed / args.steps * 1e3
+        slowest_compute = max(e["compute_only_ms"] for e in everyone)
+        sharded_report = {
+            "mode": "pipelined (merge_async: image i's exchange under image i+1's kernels)" if pipelined else "latency (merge() joins the exchange inside the image)",
+            "exchange": "ptb_halo_exchange: one ncclGroup per image on the library's own RCCL communicator" if merger.exchange is not None else "torch.distributed.batch_isend_irecv",
+            "partition": partition,
+            "pipelined_ms_per_image": round(ms_now if pipelined else other_ms, 4),
+            "latency_mode_ms_per_image": round(other_ms if pipelined else ms_now, 4),
+            "slowest_rank_compute_only_ms": round(slowest_compute, 4),
+            "exposed_exchange_ms": {"pipelined": round(max((ms_now if pipelined else other_ms) - slowest_compute, 0.0), 4),
+                                    "latency_mode": round(max((other_ms if pipelined else ms_now) - slowest_compute, 0.0), 4)},
+            "per_rank": everyone,
+            "note": "ms per 5000x5000 image over all ranks (max over ranks, barrier + synchronize around K images); compute_only = the same "
+                    "steps with the exchange stubbed out; bytes per link = the partial-sum rectangles one rank sends to / receives from one "
+                    "neighbour (each pair of GPUs has its own xGMI link, both directions at once); tools/shard_sim.py predicts the same "
+                    "fields from one GPU + a link model (profiles/r04_shard_sim.txt)",
+        }
 
     # ---- secondary timings (single GPU): what each API extension of the headline configuration buys, driver-visible
     variants = None
@@ -874,6 +896,50 @@ def main():
             best = max(best, read / (pe0.elapsed_time(pe1) * 1e-3) / 1e9)
         box_ceiling = best
 
+    # ---- placement of the model outputs (reported, NOT the headline).  Where the 12 GB of model outputs sit in device memory decides
+    # up to 10-15 % of this loop's speed on some boxes.  `value` above is measured on the pool exactly as torch's
+    # allocator first handed it out -- what a user of the library gets.  What a process that owns its buffer pool could get by
+    # choosing among candidate pools at start-up (pytorch_toolbelt_amd/placement.py) is measured here, afterwards, as
+    # config.best_placement: candidate pools are allocated one ~36 GB region apart, a few steps are run on each, the fastest is
+    # kept and timed with the same K steps.  --placement-tries 1 skips it.
+    placement = {"max_tries": 1, "ms_per_step_by_candidate": [], "chosen": 0}
+    best_placement = None
+    if args.placement_tries > 1 and not use_dist:
+        search_steps = 0
+
+        def run_ms(tensors, k):
+            nonlocal batch_tensors, search_steps
+            search_steps += k + 1
+            batch_tensors = tensors                      # (step() reads the variable)
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            step()
+            q0.record()
+            for _ in range(k):
+                step()
+            q1.record()
+            torch.cuda.synchronize()
+            return q0.elapsed_time(q1) / k
+
+        from pytorch_toolbelt_amd.placement import choose_placement
+
+        need = sum(t.numel() * t.element_size() for t in batch_tensors)
+        (batch_tensors, _keep), rep = choose_placement(
+            lambda: alloc_outputs(0), lambda pool: min(run_ms(pool[0], 4), run_ms(pool[0], 4)), need, dev, first=(batch_tensors, _keep),
+            max_tries=args.placement_tries)
+        per_cand, chosen = rep["by_candidate"], rep["chosen"]
+        torch.cuda.empty_cache()      # (the first pool was still referenced from here while the search ran)
+        placement = {"max_tries": args.placement_tries, "ms_per_step_by_candidate": per_cand, "chosen": chosen, "steps_run_by_the_search": search_steps,
+                     "steps_after_the_headline": search_steps + 10 + 3 * args.steps,   # (for tools/profile_report.py: search + best-placement timing)
+                     "note": "AFTER the headline was measured: candidate pools for the model outputs are allocated side by side, a few steps are "
+                             "run on each, the fastest is kept and timed (config.best_placement)"}
+        for _ in range(10):
+            step()
+        bp = sorted(timed_run(step, args.steps)[0] for _ in range(3))[1] / args.steps * 1e3
+        best_placement = {"ms_per_step": round(bp, 4), "value_MP_s": round(IMAGE[0] * IMAGE[1] / 1e3 / bp, 1),
+                          "region_hbm_frac": round((VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4) / (bp * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": "the same K steps (median of 3 runs) on the fastest of the candidate pools -- an upper envelope for callers that own "
+                                  "their allocation; NOT `value`"}
+
     mp = IMAGE[0] * IMAGE[1] / 1e6
     ms_per_step = elapsed / args.steps * 1e3
     value = mp * args.steps / elapsed  # one image per step for the whole job (strong scaling for N > 1)
@@ -935,7 +1001,10 @@ def main():
                                                             "(PTB_BENCH_PRIME_POOL=0: 46 separate 256 MiB device allocations)"
                                                             if os.environ.get("PTB_BENCH_PRIME_POOL", "1") == "1" else ", 46 separate device allocations")),
                 "placement": placement,
-                "first_allocation": first_alloc,
+                "first_allocation": {"ms_per_step": round(ms_per_step, 4), "value_MP_s": round(value, 1),
+                                     "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "note": "`value` IS the first-allocation figure: the model-output pool as torch's allocator first handed it out"},
+                "best_placement": best_placement,
                 "fallback": fallback,
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "timing": f"value = median of {len(repeat_ms)} runs of exactly {args.steps} steps, each bracketed by barrier + synchronize",
@@ -943,6 +1012,7 @@ def main():
                 "repeat_min_median_max_ms": [min(repeat_ms), sorted(repeat_ms)[len(repeat_ms) // 2], max(repeat_ms)],
                 "ramp_ms_per_step_groups_of_10": [round(v, 3) for v in ramp_groups],
                 "variants": variants,
+                "sharded": sharded_report,
                 "region_algorithmic_bytes": region_bytes,
                 "region_hbm_frac": round(region_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },

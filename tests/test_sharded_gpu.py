@@ -183,3 +183,140 @@ def test_halo_exchange_over_rccl_single_rank():
     ex.wait()
     assert torch.equal(dst, src)          # (the current stream waited for the side stream)
     ex.close()
+
+
+# ------------------------------------------------------------------ pipelined exchange + communication-free partition with the real kernels
+def _pipeline_worker(rank, world, port, partition, defer, backend, q):
+    import torch.distributed as dist
+
+    from oracle import tiles_oracle as TO
+    from oracle import tta_oracle as AO
+    from pytorch_toolbelt_amd.parallel import RcclExchange, ShardedTileMerger
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    same_gpu = backend == "gloo"
+    dev = torch.device("cuda", 0 if same_gpu else rank)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        geom = TO.slicer_geometry((1100, 900), (256, 256), (128, 128))
+        w = TO.pyramid_window(256, 256)[0]
+        crops = geom["crops"]
+        C = 2
+        g = torch.Generator(device="cpu").manual_seed(9)
+        views = torch.randn((len(crops), 8, C, 256, 256), generator=g)           # identical on every rank
+        m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, partition=partition, defer=defer)
+        if backend == "nccl":
+            assert isinstance(m.exchange, RcclExchange), "under the nccl backend the rectangles must travel as the library's own ncclGroup"
+        mine = m.tiles
+
+        def feed(scale):
+            for b0 in range(0, len(mine), 4):
+                idx = mine[b0:b0 + 4]
+                m.integrate_batch_deaugment(views[idx].transpose(0, 1).reshape(-1, C, 256, 256).to(dev) * scale, crops[idx], group="d4")
+
+        tickets, bands = [], []
+        for i in range(4):
+            feed(i + 1)
+            tickets.append(m.merge_async())
+            if i:
+                bands.append(tickets[i - 1].result())
+        bands.append(tickets[-1].result())
+        kept = [None if b is None else b.clone() for b in bands]
+        for i in range(4):             # the synchronous form: same bits; and the pipelined results were not overwritten meanwhile
+            m.reset()
+            feed(i + 1)
+            band = m.merge()
+            if band is not None:
+                assert torch.equal(band, bands[i]) and torch.equal(bands[i], kept[i]), f"image {i}"
+        full = m.gather(bands[1])
+        if rank == 0:
+            st = TO.merger_new(geom["target_shape"], C, w)
+            for b0 in range(0, len(crops), 4):
+                idx = np.arange(b0, min(b0 + 4, len(crops)))
+                y = (views[idx].transpose(0, 1).reshape(-1, C, 256, 256) * 2).numpy()
+                TO.merger_integrate(st, AO.image_deaugment(y, "d4", "mean"), crops[idx])
+            oracle = torch.from_numpy(TO.merger_merge(st)).to(dev)
+            q.put((bool(torch.isfinite(full).all()), float((full - oracle).abs().max()), len(m._slots)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_pipeline(world, partition, defer, backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, partition, defer, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    finite, maxdiff, slots = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert finite and maxdiff <= 1e-5 and slots == 2, (finite, maxdiff, slots)
+    return maxdiff
+
+
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
+@pytest.mark.parametrize("world,partition", [(2, "tiles"), (3, "tiles"), (3, "pixel_rows")])
+def test_pipelined_sharded_merger_processes_on_one_gpu(world, partition, defer):
+    """merge_async() with the real kernels (processes sharing the GPU, gloo): image i's exchange in flight while image i + 1 is
+    merged into the second set of buffers; results bit-identical to the synchronous merge(), within 1e-5 of the oracle."""
+    _run_pipeline(world, partition, defer, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
+def test_halo_exchange_over_rccl_two_real_ranks(defer):
+    """Two ranks on two GPUs under the nccl backend: the default exchange is the library's own ncclGroup (ptb_halo_exchange on a side
+    stream behind the pack event), pipelined over four images."""
+    _run_pipeline(2, "tiles", defer, "nccl")
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_pixel_row_ranks_reproduce_the_single_device_bits(world):
+    """partition="pixel_rows" on the deferred band plan (ptb_band_plan_create3 with PTB_PLAN_CLIP_ROWS: every tile that touches the
+    owned pixel rows is read on exactly those rows): the assembled map equals the single-device TileMerger bit for bit, nothing
+    is exchanged.  The ranks are played one after the other in this process."""
+    from oracle import tiles_oracle as TO
+    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+    from pytorch_toolbelt_amd.parallel import ShardedTileMerger
+
+    class _One:
+        def __init__(self, rank, world):
+            self.rank, self.world = rank, world
+
+        def get_rank(self, group=None):
+            return self.rank
+
+        def get_world_size(self, group=None):
+            return self.world
+
+    dev = torch.device("cuda:0")
+    geom = TO.slicer_geometry((1100, 900), (256, 256), (128, 128))
+    w = TO.pyramid_window(256, 256)[0]
+    crops = geom["crops"]
+    C = 3
+    g = torch.Generator(device="cpu").manual_seed(3)
+    views = torch.randn((len(crops), 8, C, 256, 256), generator=g).to(dev)
+    ref = TileMerger(geom["target_shape"], C, w, device=dev)
+    for b0 in range(0, len(crops), 4):
+        idx = np.arange(b0, min(b0 + 4, len(crops)))
+        ref.integrate_batch_deaugment(views[idx].transpose(0, 1).reshape(-1, C, 256, 256).contiguous(), crops[idx], group="d4")
+    want = ref.merge()
+    for defer in (True, False):
+        full = torch.full_like(want, float("nan"))
+        for r in range(world):
+            m = ShardedTileMerger(geom["target_shape"], C, w, crops, device=dev, dist=_One(r, world), partition="pixel_rows", defer=defer)
+            assert (m._deferred is not None) == defer and not m.sends and not m.recvs
+            for image_no in range(2):
+                for b0 in range(0, len(m.tiles), 4):
+                    idx = m.tiles[b0:b0 + 4]
+                    m.integrate_batch_deaugment(views[idx].transpose(0, 1).reshape(-1, C, 256, 256).contiguous(), crops[idx], group="d4")
+                band = m.merge_async().result()
+            o0, o1 = m.owned_rows
+            full[:, o0:o1] = band
+        assert torch.equal(full, want), f"defer={defer}: max diff {float((full - want).abs().max())}"

@@ -63,21 +63,20 @@ def main():
         d = sorted(seq)
         med = d[len(d) // 2]
         full = [x for x in seq if x > 0.5 * med]   # (the variants block also runs 256-row launches: they are listed, not averaged here)
-        # bench.py first tries several placements of the model-output pool (config.placement): those launches read candidate pools of
-        # different speed and are reported separately; everything after them reads the pool the timed steps read
-        skip = 0
+        # bench.py measures the headline on the pool as first allocated; AFTER it, config.placement / config.best_placement try
+        # candidate pools of different speed (their launches are at the end of the trace and are reported separately)
+        tail_n = 0
         try:
             line = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_under_rocprof.json")).read().strip().splitlines()[-1])
-            pl = line["config"]["placement"]
-            skip = 5 * int(pl.get("steps_before_the_chosen_pool", pl.get("steps_run_by_the_search", 0)))
+            tail_n = 5 * int(line["config"]["placement"].get("steps_after_the_headline", 0))
         except Exception:
             pass
-        head, rest = full[:skip], full[skip:] or full
+        head, tail = (full[:-tail_n], full[-tail_n:]) if 0 < tail_n < len(full) else (full, [])
         lines += ["", f"Dominant kernel `{short(band[0])}`: {len(seq)} launches, of which {len(full)} are 1024-row launch groups of the headline "
-                      f"configuration (5 per image).  The first {len(head)} belong to the untimed set-up before the chosen pool (probe step, first-allocation timing, placement search over candidate pools: "
-                      f"average {sum(head) / max(len(head), 1) / 1e3:.2f} us, min {min(head or [0]) / 1e3:.2f}, max {max(head or [0]) / 1e3:.2f}); the {len(rest)} "
-                      f"after it (ramp, warm-up, timed steps, variants -- all on the chosen pool): average **{sum(rest) / len(rest) / 1e3:.2f} us**, "
-                      f"as in bench.py's roofline block."]
+                      f"configuration (5 per image).  The first {len(head)} read the model-output pool as first allocated (probe step, ramp, warm-up, "
+                      f"timed steps, variants): average **{sum(head) / max(len(head), 1) / 1e3:.2f} us**, as in bench.py's roofline block; the last "
+                      f"{len(tail)} belong to the placement search that follows the headline (candidate pools + the best one timed: average "
+                      f"{sum(tail) / max(len(tail), 1) / 1e3:.2f} us, min {min(tail or [0]) / 1e3:.2f}, max {max(tail or [0]) / 1e3:.2f})."]
     accum = [n for n in ks if "view_accum_kernel" in n]
     if accum:
         d = sorted(x for x, _ in ks[accum[0]])
