@@ -552,6 +552,8 @@ def main():
                 merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
             return merger.merge()
         if pipelined:
+            if in_flight[0] is None and merger._result is not None:
+                merger.reset()      # (after a synchronous merge() the image still sits in the current buffers)
             # one image per step, pipelined: this image's halo exchange stays in flight while the NEXT step's kernels run (second set
             # of buffers); the previous image is completed here, after this one's tiles were issued.  `drain()` completes the last.
             for t, c in zip(batch_tensors, batch_crops):
@@ -689,7 +691,16 @@ def main():
                 fn()
             return sorted(timed_run(fn, args.steps)[0] for _ in range(3))[1] / args.steps * 1e3
 
-        other_ms = mode_ms(sync_step if pipelined else step)     # the mode that is not the headline
+        def pipe_step():
+            if in_flight[0] is None and merger._result is not None:
+                merger.reset()
+            for t, c in zip(batch_tensors, batch_crops):
+                merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+            ticket = merger.merge_async()
+            prev, in_flight[0] = in_flight[0], ticket
+            return prev.result() if prev is not None else None
+
+        other_ms = mode_ms(sync_step if pipelined else pipe_step)     # the mode that is not the headline
         # compute only: the same steps with the exchange stubbed out on every rank (rectangles packed, nothing sent, the receive
         # buffers used as they are -- wrong pixels on the shared rows, same kernels and bytes)
         real_start = merger._start_exchange

@@ -52,6 +52,8 @@ def set_enabled(flag: bool) -> bool:
     """Switch lazy de-augmentation on / off; returns the previous setting."""
     global _ENABLED
     prev, _ENABLED = _ENABLED, bool(flag)
+    if not _ENABLED:
+        remove_dlpack_guard()
     return prev
 
 
@@ -129,6 +131,8 @@ class LazyDeaugment(torch.Tensor):
         return torch.Tensor._make_wrapper_subclass(cls, shape, dtype=source.dtype, device=source.device, requires_grad=False)
 
     def __init__(self, source, group, views, code, compute):
+        if _dlpack_orig is None:
+            _guard_legacy_dlpack()         # (first handle of the process: from here on to_dlpack(handle) must evaluate it first)
         self._src = source                 # [V*B, C, H, W] contiguous float32 model output (chunk-major)
         self._group = group                # "d4" | "d2" | "flips" | "fliplr" | "flipud"
         self._views = views                # inverse view codes, chunk order
@@ -146,9 +150,14 @@ class LazyDeaugment(torch.Tensor):
                                "used; evaluate the result first, or switch lazy de-augmentation off (tta.set_lazy_deaugment(False))")
 
     def _note_stream(self):
+        """Evaluated / consumed on another stream than the one the handle was made on (budget eviction from another thread's call, a
+        caller that switched streams): that stream first waits for everything queued on the creating stream -- the producer of the
+        source among it -- and the source is ``record_stream``-ed so that its memory outlives this read."""
         src = self._src
         if self._stream is not None and _raw_stream(src.device.index) != self._stream:
-            src.record_stream(torch.cuda.current_stream(src.device))
+            cur = torch.cuda.current_stream(src.device)
+            cur.wait_stream(torch.cuda.ExternalStream(self._stream, device=src.device))
+            src.record_stream(cur)
 
     def _evaluate(self):
         """The real tensor (computed once)."""
@@ -205,10 +214,16 @@ def _unwrap(x):
     return x._evaluate() if type(x) is LazyDeaugment else x
 
 
+_dlpack_orig = None        # torch.utils.dlpack.to_dlpack as it was before the guard went in (None: no guard installed)
+
+
 def _guard_legacy_dlpack():
     """``torch.utils.dlpack.to_dlpack`` is a bare C function: it reads the storage of what it is given without passing
     ``__torch_function__``, and a handle has none (the capsule would carry a null pointer).  The module attribute is replaced by a
-    wrapper that evaluates a handle first; ``torch.from_dlpack(handle)`` / ``handle.__dlpack__()`` never needed it."""
+    wrapper that evaluates a handle first; ``torch.from_dlpack(handle)`` / ``handle.__dlpack__()`` never needed it.  Installed when
+    the FIRST handle is created (importing the package changes nothing in torch), taken out again by ``remove_dlpack_guard()`` /
+    ``set_enabled(False)``."""
+    global _dlpack_orig
     import torch.utils.dlpack as D
 
     orig = D.to_dlpack
@@ -220,12 +235,22 @@ def _guard_legacy_dlpack():
 
     to_dlpack.__doc__ = getattr(orig, "__doc__", None)
     to_dlpack._ptb_lazy_guard = True
+    _dlpack_orig = orig
     D.to_dlpack = to_dlpack
     if getattr(torch, "to_dlpack", None) is orig:
         torch.to_dlpack = to_dlpack
 
 
-_guard_legacy_dlpack()
+def remove_dlpack_guard():
+    """Put ``torch.utils.dlpack.to_dlpack`` back (handles still alive must then not be handed to it)."""
+    global _dlpack_orig
+    import torch.utils.dlpack as D
+
+    if _dlpack_orig is not None and getattr(D.to_dlpack, "_ptb_lazy_guard", False):
+        if getattr(torch, "to_dlpack", None) is D.to_dlpack:
+            torch.to_dlpack = _dlpack_orig
+        D.to_dlpack = _dlpack_orig
+    _dlpack_orig = None
 
 
 def maybe_lazy(source, group, views, code, compute):
@@ -240,5 +265,10 @@ def maybe_lazy(source, group, views, code, compute):
     if any(v & 1 for v in views) and source.shape[2] != source.shape[3]:
         return None
     if torch.jit.is_tracing() or torch.jit.is_scripting() or torch.compiler.is_compiling():
+        return None
+    # A handle reads its source LATER.  That is only safe while an in-place change of the source in between can be noticed: tensors
+    # made under torch.inference_mode() carry no version counter, and a stream that is being captured into a HIP graph replays into
+    # the same (static) output buffers -- both are evaluated here and now, exactly like the reference.
+    if _source_version(source) is None or torch.cuda.is_current_stream_capturing():
         return None
     return LazyDeaugment(source, group, views, code, compute)

@@ -9,6 +9,7 @@ import ctypes
 import torch
 
 from .. import _native as N
+from . import _host
 
 _MODES = ("bilinear", "nearest", "bicubic")
 
@@ -67,7 +68,9 @@ class _Resize(torch.autograd.Function):
 
 def resize(x: torch.Tensor, size, mode: str, align_corners) -> torch.Tensor:
     """``F.interpolate(x, size=size, mode=mode, align_corners=align_corners)`` for a [B, C, H, W] GPU tensor
-    (mode "bilinear" | "bicubic" | "nearest"), differentiable."""
+    (mode "bilinear" | "bicubic" | "nearest"), differentiable.  Host tensors go to ``F.interpolate`` itself (any mode)."""
+    if not x.is_cuda:
+        return _host.resize(x, size, mode, align_corners)
     _check_mode(mode, align_corners)
     y = _Resize.apply(_f32(x), (int(size[0]), int(size[1])), mode, align_corners)
     return y if x.dtype == torch.float32 else y.to(x.dtype)
@@ -125,6 +128,8 @@ def ms_reduce(maps, size, align_corners: bool, code: int) -> torch.Tensor:
     """Fused multiscale de-augmentation: ``reduce_s F.interpolate(maps[s], size, 'bilinear', align_corners)`` in one HIP
     pass (maps already of the target size are read as they are).  maps: [B, C, h_s, w_s] GPU tensors, <= 8.  Differentiable."""
     first = maps[0]
+    if not first.is_cuda:
+        return _host.ms_reduce(maps, size, align_corners, code)
     B, C = first.shape[0], first.shape[1]
     ms = []
     for m in maps:
@@ -142,8 +147,8 @@ def ms_flip_reduce(maps, views, size, align_corners: bool, inner_code: int, code
     composes ``<group>_image_deaugment`` + ``ms_image_deaugment``).  Inference only (no autograd)."""
     first = maps[0]
     V = len(views)
-    if any(v & 1 for v in views) or not 1 <= len(maps) <= 8 or first.size(0) % V:
-        return None
+    if not first.is_cuda or any(v & 1 for v in views) or not 1 <= len(maps) <= 8 or first.size(0) % V:
+        return None           # (host tensors: the caller composes <group>_image_deaugment + ms_image_deaugment)
     B, C = first.shape[0] // V, first.shape[1]
     ms = []
     for m in maps:

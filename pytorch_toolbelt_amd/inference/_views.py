@@ -8,6 +8,7 @@ from typing import Sequence
 import torch
 
 from .. import _native as N
+from . import _host
 
 # inverse of each D4 element: the two quarter turns swap, everything else is an involution
 INVERSE = {
@@ -148,12 +149,16 @@ class _DeaugReduce(torch.autograd.Function):
 
 
 def view_transform(x, views, in_is_batch=True, scale=1.0):
+    if not x.is_cuda:      # a host tensor: the device-agnostic torch path (inference/_host.py), like the reference
+        return _host.view_transform(x, list(views), in_is_batch, scale)
     x, back = _check_image(x, "view transform", ints=True)     # (pure data movement: integer images are fine)
     out = _ViewTransform.apply(x, list(views), in_is_batch, scale)
     return out.to(back) if back is not None else out
 
 
 def deaug_reduce(x, views, code):
+    if not x.is_cuda:
+        return _host.deaug_reduce(x, list(views), code)
     if x.dtype in _LOW_PRECISION and x.is_cuda and x.dim() == 4 and not (x.requires_grad and torch.is_grad_enabled()):
         # inference on half-precision model outputs: read them as they are
         if x.shape[0] % len(views) != 0:
@@ -240,7 +245,12 @@ DEFAULT_EPS = 1e-6
 
 def stack_reduce(x, code, eps=DEFAULT_EPS):
     """Reduce dim 0 of ``x [T, ...]`` (float32, GPU) with the HIP reduction ``code``.  Up to 8 planes with the default eps go through
-    the unrolled view kernels (the TTA groups); longer stacks and a caller-chosen eps through ``ptb_stack_reduce``."""
+    the unrolled view kernels (the TTA groups); longer stacks and a caller-chosen eps through ``ptb_stack_reduce``.  Host tensors
+    take the torch path of ``inference/_host.py`` (any dtype, differentiable)."""
+    if not x.is_cuda:
+        if x.shape[0] < 1:
+            raise RuntimeError("cannot reduce an empty stack")
+        return _host.reduce_stack(x, code, eps)
     N.require_device(x, "TTA reduction")
     if x.dtype in _LOW_PRECISION:
         return stack_reduce(x.float(), code, eps).to(x.dtype)

@@ -91,7 +91,9 @@ def torch_transpose2(x: Tensor) -> Tensor:
 
 def torch_transpose_(x: Tensor) -> Tensor:
     """In-place flavoured transpose of the reference (``x.transpose_(2, 3)``): the result is written back into ``x``
-    (square inputs only, since the storage is reused)."""
+    (square inputs only, since the storage is reused).  Host tensors: ``x.transpose_(2, 3)`` itself."""
+    if not x.is_cuda:
+        return x.transpose_(2, 3)
     y = _one_view(x, N.TRANSPOSE)
     if x.shape[2] != x.shape[3]:
         raise ValueError("torch_transpose_ needs a square input on the native path")

@@ -1,9 +1,10 @@
 """Tiled inference on huge images: host-side slicing + MI355X-side weighted blending.
 
 Drop-in for ``pytorch_toolbelt.inference.tiles`` (reference inference/tiles.py): same class / method / attribute
-names and error behaviour.  ``ImageSlicer`` is host geometry (numpy, integer-exact); ``TileMerger`` keeps its
+names and error behaviour.  ``ImageSlicer`` is host geometry (numpy, integer-exact); ``TileMerger(device="cuda")`` keeps its
 accumulators in HBM and blends with the hand-written HIP kernels of ``libptb_hip.so`` -- there is no torch-op or
-CPU fallback on that path.
+CPU fallback on that path.  ``TileMerger(device="cpu")`` -- the reference's default -- is what it says: accumulators on the
+host in the caller's dtype, blended with torch ops (``inference/_host.py``); the device the caller names decides, nothing else.
 """
 import math
 import warnings
@@ -15,7 +16,7 @@ import torch
 from .. import _native as N
 from . import _lazy
 
-__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "compute_pyramid_patch_weight_loss"]
+__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "HostBackedTileMerger", "compute_pyramid_patch_weight_loss"]
 
 # OpenCV border codes accepted by split/cut_patch (the reference forwards them to cv2.copyMakeBorder,
 # inference/tiles.py:161,182,220).  Only constant padding is pinned by the oracle; the others map to the numpy
@@ -272,19 +273,19 @@ def _warn_once(key, message):
 
 
 def _resolve_device(device, what):
-    """The reference's mergers default to device="cpu" (tiles.py:295).  This package keeps the accumulators in MI355X HBM and
-    has no CPU path, so code written against the reference -- `TileMerger(shape, C, weight)` -- gets the current CUDA device
-    instead (said once, loudly); without a GPU the constructor fails in this one place."""
+    """The device of a HIP-backed merger: a CUDA device, or an error.  (``TileMerger(device="cpu")`` never gets here: it is the
+    host merger of ``inference/_host.py``, like the reference's.)  ``VolumeMerger`` has no host implementation: its reference
+    default ``device="cpu"`` is redirected to the current GPU with a one-time warning."""
     device = torch.device(device)
     if device.type == "cuda":
         return device
-    if device.type == "cpu" and torch.cuda.is_available():
+    if device.type == "cpu" and what == "VolumeMerger" and torch.cuda.is_available():
         _warn_once(("cpu", what), f"{what}(device='cpu'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU path; "
                                   f"using device='cuda:{torch.cuda.current_device()}' instead (pass device='cuda' to silence this).")
         return torch.device("cuda", torch.cuda.current_device())
     raise RuntimeError(
-        f"{what}(device='{device}'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU "
-        "path; construct it with device='cuda' (or use CudaTileMerger) on a machine with a GPU."
+        f"{what}(device='{device}'): this merger keeps its accumulators in MI355X HBM and has no CPU "
+        "path; construct it with device='cuda' on a machine with a GPU."
     )
 
 
@@ -537,6 +538,13 @@ class TileMerger:
     bit-identical to the reference's sequential ``+=`` loop.  ``integrate_batch_deaugment`` additionally fuses the TTA
     de-augmentation (``tta.*_image_deaugment``) so the reduced tile never travels through HBM.
     """
+
+    def __new__(cls, image_shape=None, channels=None, weight=None, device="cpu", *args, **kwargs):
+        # the device the caller names decides the implementation: "cpu" (the reference's default) -> accumulators on the host,
+        # torch ops (HostBackedTileMerger below); "cuda" -> HBM + HIP kernels (this class).  Never the other way round.
+        if cls is TileMerger and torch.device(device).type != "cuda":
+            return object.__new__(HostBackedTileMerger)
+        return object.__new__(cls)
 
     def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None,
                  auto_plan=None):
@@ -1273,6 +1281,87 @@ class TileMerger:
         N.bump()
         N.check(rc, "TileMerger.merge_crop")
         return out
+
+
+class HostBackedTileMerger(TileMerger):
+    """``TileMerger(device="cpu")``: the reference's host merger (inference/tiles.py:290-350) -- ``image`` / ``norm_mask`` /
+    ``weight`` are public tensors of the caller's ``dtype`` on the CPU, accumulated in that dtype (fp64 accumulators accumulate in
+    fp64), ``integrate_batch`` moves / casts what it is given and blends tile by tile in batch order.  The arithmetic lives in
+    ``inference/_host.py``; the extensions of the HIP merger are accepted so that code written for either runs on both:
+    ``integrate_batch_deaugment`` (= ``integrate_batch(tta.<group>_image_deaugment(...))``), ``reset()``, ``merge_crop``;
+    ``crops=`` / ``defer=`` / ``auto_plan=`` change nothing here."""
+
+    def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None,
+                 auto_plan=None):
+        from ._host import HostTileMerger
+
+        device = torch.device(device)
+        if device.type == "cuda":
+            raise RuntimeError("HostBackedTileMerger lives on the host; TileMerger(device='cuda') is the HIP merger")
+        self.dtype = dtype
+        self._host = HostTileMerger(image_shape, channels, weight, device, dtype)
+        self.image_height, self.image_width, self.channels = self._host.image_height, self._host.image_width, channels
+
+    image = property(lambda self: self._host.image, lambda self, v: setattr(self._host, "image", v))
+    norm_mask = property(lambda self: self._host.norm_mask, lambda self, v: setattr(self._host, "norm_mask", v))
+    weight = property(lambda self: self._host.weight, lambda self, v: setattr(self._host, "weight", v))
+
+    @property
+    def device(self) -> torch.device:
+        return self._host.image.device
+
+    @property
+    def mode(self) -> str:
+        return "host"
+
+    def reset(self):
+        self._host.reset()
+
+    def accumulate_single(self, tile: torch.Tensor, coords):
+        self._host.blend(tile.to(device=self.image.device).unsqueeze(0), [coords])
+
+    def integrate_batch(self, batch: torch.Tensor, crop_coords):
+        if len(batch) != len(crop_coords):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        image = self._host.image
+        if batch.device != image.device:
+            batch = batch.to(device=image.device)
+        if batch.dtype != image.dtype:
+            batch = batch.type_as(image)
+        self._host.blend(batch, crop_coords)
+
+    def integrate_batch_deaugment(self, batch: torch.Tensor, crop_coords, group: str = "d4", reduction="mean"):
+        from .tta import DEAUGMENT_VIEWS, _image_deaugment
+
+        if len(batch) != len(crop_coords) * len(DEAUGMENT_VIEWS[group]):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates x views")
+        self.integrate_batch(_image_deaugment(batch.to(device=self.image.device), group, reduction, lazy=False), crop_coords)
+
+    def merge(self) -> torch.Tensor:
+        return self._host.image / self._host.norm_mask
+
+    def merge_(self) -> torch.Tensor:
+        self._host.image /= self._host.norm_mask
+        return self._host.image
+
+    def merge_crop(self, crop, layout: str = "hwc", dtype=torch.float32, argmax: bool = False) -> torch.Tensor:
+        if isinstance(crop, ImageSlicer):
+            top, left, oh, ow = crop.margin_top, crop.margin_left, crop.image_height, crop.image_width
+        else:
+            top, left, oh, ow = (int(v) for v in crop)
+        if layout not in ("hwc", "chw"):
+            raise ValueError(f"layout must be 'hwc' or 'chw', got {layout!r}")
+        if top < 0 or left < 0 or oh < 0 or ow < 0 or top + oh > self.image_height or left + ow > self.image_width:
+            raise ValueError("crop window is outside the accumulator")
+        window = self.merge()[:, top:top + oh, left:left + ow]
+        if argmax:
+            if dtype not in (torch.uint8, torch.int64, torch.float32):
+                raise NotImplementedError(f"merge_crop: dtype {dtype} is not supported")
+            return window.argmax(dim=0).to(torch.uint8 if dtype == torch.uint8 else torch.int64)
+        if dtype not in (torch.float32, torch.uint8):
+            raise NotImplementedError(f"merge_crop: dtype {dtype} is not supported")
+        out = window.permute(1, 2, 0) if layout == "hwc" else window
+        return out.to(dtype).contiguous()
 
 
 class CudaTileMerger(TileMerger):

@@ -111,7 +111,7 @@ def _image_augment(image: Tensor, group: str) -> Tensor:
     return V.view_transform(image, AUGMENT_VIEWS[group], in_is_batch=True)
 
 
-def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable) -> Tensor:
+def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable, lazy: bool = True) -> Tensor:
     views = DEAUGMENT_VIEWS[group]
     if image.size(0) % len(views) != 0:
         raise RuntimeError(f"Input batch size ({image.size(0)}) must be divisible by {len(views)}.")
@@ -119,8 +119,8 @@ def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable) -
     if code is not None:
         # inference-shaped calls come back as a handle that `TileMerger.integrate_batch` fuses into its own launch and that
         # turns into the real tensor on any other use (inference/_lazy.py); everything else is evaluated here and now
-        lazy = _lazy.maybe_lazy(image, group, views, code, V.deaug_reduce)
-        return lazy if lazy is not None else V.deaug_reduce(image, views, code)
+        handle = _lazy.maybe_lazy(image, group, views, code, V.deaug_reduce) if lazy else None
+        return handle if handle is not None else V.deaug_reduce(image, views, code)
     if not (callable(reduction) or reduction in {None, "None", "none"}):
         raise KeyError(f"Unsupported reduction mode {reduction}")
     stack = V.view_transform(image, views, in_is_batch=False)
@@ -417,11 +417,8 @@ def ms_flips_image_deaugment(images: List[Tensor], size_offsets: List[Union[int,
             out = _resample.ms_flip_reduce(list(images), views, sizes.pop(), align_corners, inner, outer)
             if out is not None:
                 return out
-    prev = _lazy.set_enabled(False)       # (the composed path wants the maps themselves: no handles that would come straight back here)
-    try:
-        per_scale = [_image_deaugment(y, group, inner_reduction) for y in images]
-    finally:
-        _lazy.set_enabled(prev)
+    # (the composed path wants the maps themselves: no handles that would come straight back here)
+    per_scale = [_image_deaugment(y, group, inner_reduction, lazy=False) for y in images]
     return _ms_image_deaugment(per_scale, size_offsets, reduction, mode, align_corners, stride)
 
 

@@ -2,6 +2,7 @@
 import torch
 
 from ..utils.torch_utils import to_tensor
+from . import _host as H
 from . import _kernels as K
 
 BINARY_MODE = "binary"
@@ -29,6 +30,10 @@ def region_statistics(y_pred, y_true, mode, from_logits, ignore_index):
     """(I, P, T) per class over batch and pixels: one HIP pass over the logits; the softmax / sigmoid probabilities, the
     one-hot targets and the ignore mask are formed in registers (reference losses/dice.py:68-111)."""
     assert y_true.size(0) == y_pred.size(0)
+    if not y_pred.is_cuda:      # host tensors: torch algebra (losses/_host.py), still summed over the ranks inside sync_region_statistics
+        from ..parallel import sync_region_statistics
+
+        return sync_region_statistics.apply(H.region_statistics(y_pred, y_true, mode, from_logits, ignore_index))
     bs = y_true.size(0)
     x = K._f32c(y_pred, "region loss")
     if mode == MULTICLASS_MODE:
@@ -110,8 +115,8 @@ def fused_region_loss(y_pred, y_true, mode, from_logits, ignore_index, dice_weig
     ``focal`` = None or dict(weight, gamma, alpha): adds ``weight * mean sigmoid focal loss`` from the same pass."""
     from ..parallel import sync_region_statistics
 
-    if sync_region_statistics._active is not None:
-        return None
+    if sync_region_statistics._active is not None or not y_pred.is_cuda:
+        return None           # (host tensors: the caller composes region_statistics + the torch tail)
     x, labels, dense, prob, has_ign, ign_label, ign_value = _inputs(y_pred, y_true, mode, from_logits, ignore_index)
     C = x.size(1)
     mask, n_sel = None, C

@@ -18,6 +18,10 @@ def balanced_binary_cross_entropy_with_logits(logits: Tensor, targets: Tensor, g
     ``gamma`` once more and ``w_neg = (1 - (n_neg / n)^gamma)^gamma`` (the reference applies the power twice,
     balanced_bce.py:30-34), ``n_pos / n_neg`` = number of targets equal to 1 / 0.  Targets are expected to be hard 0/1;
     elements equal to ``ignore_index`` contribute 0.  "mean" | "sum" | otherwise unreduced."""
+    if not logits.is_cuda:
+        from . import _host as H
+
+        return H.balanced_bce(logits, targets, gamma, ignore_index, reduction)
     x = P.as_f32(logits, "balanced_binary_cross_entropy_with_logits")
     t = P.as_f32(targets.detach(), "balanced_binary_cross_entropy_with_logits")
     if x.shape != t.shape:

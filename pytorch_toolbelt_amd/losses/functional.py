@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F  # noqa: F401  (module attribute of the reference's functional.py)
 
 from ..utils.support import pytorch_toolbelt_deprecated
+from . import _host as H
 from . import _kernels as K
 
 __all__ = [
@@ -75,6 +76,9 @@ def _softmax_act_focal(output, labels, dense, softmax_dim, gamma, alpha, reducti
     """``activation="softmax"``: the focal term's probability is ``softmax(output, dim=softmax_dim)`` while the BCE term keeps the
     logits (functional.py:61-78).  The contiguous tensor is handed to the kernel as the [B, C, HW] view whose C is the softmax
     dimension; class_weights keep following dim 1 of the original tensor."""
+    if not output.is_cuda:      # host tensors: plain torch algebra (losses/_host.py); CUDA tensors never go there
+        return H.softmax_act_focal(output, labels, dense, softmax_dim, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index,
+                                   class_weights)
     if softmax_dim is None:
         raise RuntimeError("focal_loss_with_logits(activation='softmax'): softmax_dim must be given (torch.softmax(dim=None) fails too)")
     shape = tuple(output.shape)
@@ -130,6 +134,8 @@ def _softmax_act_focal(output, labels, dense, softmax_dim, gamma, alpha, reducti
 
 
 def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights):
+    if not output.is_cuda:
+        return H.sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, reduced_threshold, eps, ignore_index, class_weights)
     shape = output.shape
     x = K.as_bchw(K._f32c(output, "focal loss"))
     flags = 0
@@ -193,6 +199,8 @@ def softmax_focal_loss_with_logits(
     """Softmax flavour of the focal loss for ``output [B, C, *]`` / ``target [B, *]`` (like nn.CrossEntropyLoss):
     per pixel ``sum_c pt_c^gamma * BCE(x_c, onehot_c) * w_c`` with ``pt`` from the softmax probabilities; pixels whose
     label equals ``ignore_index`` give 0 but still count in the "mean" denominator."""
+    if not output.is_cuda:
+        return H.softmax_focal(output, target, class_weights, gamma, reduction, normalized, reduced_threshold, eps, ignore_index)
     x = K.as_bchw(K._f32c(output, "softmax focal loss"))
     labels = target.to(device=x.device, dtype=torch.int64).reshape(x.shape[0], -1).contiguous()
     if labels.shape[1] != x.shape[2]:
@@ -229,6 +237,8 @@ def reduced_focal_loss(output: torch.Tensor, target: torch.Tensor, threshold=0.5
 
 def _region_sums(output: torch.Tensor, target: torch.Tensor, dims):
     """(intersection, cardinality) = (sum o*t, sum o+t) over ``dims`` via the fused statistics kernel."""
+    if not output.is_cuda:
+        return H.region_sums(output, target, dims)
     assert output.size() == target.size()
     nd = output.dim()
     if dims is None:
@@ -281,6 +291,8 @@ def wing_loss(output: torch.Tensor, target: torch.Tensor, width=5, curvature=0.5
     """Wing loss for landmark regression (https://arxiv.org/pdf/1711.06753.pdf): ``width * log(1 + d / curvature)`` for
     ``d = |target - output| < width``, ``d - C`` beyond (C makes it continuous); "sum" | "mean" | unreduced.  One fused
     HIP pass (reference losses/functional.py:250-277)."""
+    if not output.is_cuda:
+        return H.wing(output, target, width, curvature, reduction)
     from . import _pointwise as P
 
     x = P.as_f32(output, "wing_loss")
@@ -300,6 +312,8 @@ def wing_loss(output: torch.Tensor, target: torch.Tensor, width=5, curvature=0.5
 def log_cosh_loss(y_pred: torch.Tensor, y_true: torch.Tensor) -> torch.Tensor:
     """``mean(log(cosh(y_pred - y_true)))`` evaluated as ``d + softplus(-2 d) - log 2`` (reference
     losses/functional.py:326-342), one fused HIP pass."""
+    if not y_pred.is_cuda:
+        return H.log_cosh(y_pred, y_true)
     from . import _pointwise as P
 
     x = P.as_f32(y_pred, "log_cosh_loss")

@@ -34,6 +34,16 @@ class FocalDiceJaccardLoss(nn.Module):
                                    focal=dict(weight=wf, gamma=self.gamma, alpha=self.alpha))
         if loss is not None:
             return loss
+        if not y_pred.is_cuda:      # host tensors: the three losses composed from their host evaluations
+            from .functional import _sigmoid_focal
+
+            labels, dense = (y_true, None) if self.mode == R.MULTICLASS_MODE else (None, y_true.reshape(y_pred.shape))
+            focal_loss = _sigmoid_focal(y_pred, labels, dense, self.gamma, self.alpha, "mean", False, None, 1e-6, self.ignore_index, None)
+            inter, pred_mass, true_mass = R.region_statistics(y_pred, y_true, self.mode, True, self.ignore_index)
+            dice = (2.0 * inter + self.smooth) / (pred_mass + true_mass + self.smooth).clamp_min(self.eps)
+            jacc = (inter + self.smooth) / (pred_mass + true_mass - inter + self.smooth).clamp_min(self.eps)
+            return (wf * focal_loss + wd * R.finish(dice, true_mass, self.log_loss, self.eps, None)
+                    + wj * R.finish(jacc, true_mass, self.log_loss, self.eps, None))
         bs = y_pred.size(0)
         x = K._f32c(y_pred, "fused loss")
         flags = (K.SEG_HAS_ALPHA if self.alpha is not None else 0) | (K.SEG_HAS_IGNORE if self.ignore_index is not None else 0) | K.SEG_NO_TERM

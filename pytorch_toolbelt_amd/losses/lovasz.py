@@ -11,6 +11,7 @@ import torch
 from torch.nn.modules.loss import _Loss
 
 from .. import _native as N
+from . import _host as H
 from . import _kernels as K
 
 __all__ = ["BinaryLovaszLoss", "LovaszLoss"]
@@ -118,6 +119,8 @@ class _LovaszSegments(torch.autograd.Function):
 def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
     """Binary Lovasz hinge loss: logits [B, H, W] (any real), labels [B, H, W] in {0, 1}; ``ignore_index`` marks void pixels.
     per_image averages the per-image losses; an image with only void pixels contributes 0."""
+    if not logits.is_cuda:
+        return H.lovasz_hinge(logits, labels.to(logits.device), per_image, ignore_index)
     x = K._f32c(logits, "BinaryLovaszLoss")
     B = x.shape[0]
     x = x.reshape(B, -1)
@@ -136,6 +139,8 @@ def _lovasz_hinge(logits, labels, per_image=True, ignore_index=None):
 def _lovasz_softmax(probas, labels, classes="present", per_image=False, ignore_index=None):
     """Multi-class Lovasz-softmax: ``probas`` [B, C, H, W] are class PROBABILITIES (no softmax is applied, as in the
     reference); labels [B, H, W] in [0, C).  classes: "present" (average over classes that occur), "all", or a list."""
+    if not probas.is_cuda:
+        return H.lovasz_softmax(probas, labels.to(probas.device), classes, per_image, ignore_index)
     if probas.dim() == 3:
         probas = probas.unsqueeze(1)
     x = K._f32c(probas, "LovaszLoss")

@@ -19,6 +19,10 @@ class QualityFocalLoss(nn.Module):
         self.reduction = reduction
 
     def forward(self, predictions: Tensor, targets: Tensor) -> Tensor:
+        if not predictions.is_cuda:
+            from . import _host as H
+
+            return H.quality_focal(predictions, targets, self.beta, self.reduction)
         x = P.as_f32(predictions, "QualityFocalLoss")
         t = P.as_f32(targets.detach(), "QualityFocalLoss")
         reduce = self.reduction in ("mean", "sum", "normalized")

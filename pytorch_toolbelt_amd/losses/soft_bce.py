@@ -44,7 +44,7 @@ class SoftBCEWithLogitsLoss(nn.Module):
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
         cw = _per_channel(self.weight, input.shape)
         cpw = _per_channel(self.pos_weight, input.shape)
-        native = (input.shape == target.shape and not target.requires_grad
+        native = (input.is_cuda and input.shape == target.shape and not target.requires_grad
                   and (self.weight is None or cw is not None) and (self.pos_weight is None or cpw is not None))
         if not native:
             return self._composite(input, target)

@@ -26,7 +26,11 @@ class SoftCrossEntropyLoss(nn.Module):
         self.dim = dim
 
     def forward(self, input: Tensor, target: Tensor) -> Tensor:
-        P.N.require_device(input, "SoftCrossEntropyLoss")
+        if not input.is_cuda:      # host tensors: the reference's own composition (soft_ce.py:24-33)
+            from .functional import label_smoothed_nll_loss
+
+            return label_smoothed_nll_loss(torch.log_softmax(input, dim=self.dim), target, epsilon=self.smooth_factor, ignore_index=self.ignore_index,
+                                           reduction=self.reduction, dim=self.dim)
         dim = self.dim % input.dim()
         x = input if dim == 1 else input.movedim(dim, 1)
         if target.dim() == input.dim():

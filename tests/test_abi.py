@@ -41,20 +41,39 @@ def test_argument_validation_without_gpu():
     assert lib.ptb_resize_bilinear(None, None, 1, 4, 4, 8, 8, 0, None) == -1
 
 
-def test_no_cpu_fallback():
-    """The product refuses CPU tensors instead of computing them somewhere else."""
+def test_device_decides_and_the_hip_path_never_falls_back():
+    """The contract of the two implementations: the DEVICE the caller names decides.  CPU tensors / device="cpu" take the host
+    (torch-op) path like the reference does; anything CUDA takes the HIP kernels and fails LOUDLY when they cannot run -- a missing
+    libptb_hip.so is an ImportError, a CUDA device on a box without a GPU is an error, and neither is ever answered by the host path."""
+    import subprocess
+    import sys
+
     import numpy as np
     import torch
 
     from pytorch_toolbelt_amd.inference import tta
-    from pytorch_toolbelt_amd.inference.tiles import TileMerger
+    from pytorch_toolbelt_amd.inference.tiles import HostBackedTileMerger, ImageSlicer, TileMerger
 
-    with pytest.raises(RuntimeError, match="no CPU"):
-        TileMerger((64, 64), 1, np.ones((32, 32), np.float32))
+    m = TileMerger((64, 64), 1, np.ones((32, 32), np.float32))                  # the reference's default device
+    assert type(m) is HostBackedTileMerger and m.device.type == "cpu" and not m.image.is_cuda
+    x = torch.rand(1, 1, 8, 8)
+    assert torch.allclose(tta.d4_image_deaugment(tta.d4_image_augment(x), reduction="sum"), 8 * x)
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):                                          # no GPU here: a CUDA merger cannot be built, and is not faked
+            TileMerger((64, 64), 1, np.ones((32, 32), np.float32), device="cuda")
+    # entry points without a host form keep refusing host tensors
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        tta.d4_image_augment(torch.rand(1, 1, 8, 8))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        tta.fliplr_image_deaugment(torch.rand(2, 1, 8, 8))
+        ImageSlicer((64, 48, 3), (32, 16), (16, 16)).split_device(torch.zeros((64, 48, 3), dtype=torch.uint8))
+    # a missing extension is an ImportError at the first native call -- checked in a fresh interpreter
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['PTB_HIP_LIB'] = '/nonexistent/libptb_hip.so'\n"
+            "from pytorch_toolbelt_amd import _native\n"
+            "try:\n    _native.load()\nexcept ImportError as e:\n    print('IMPORT-ERROR', 'no non-HIP fallback' in str(e).replace('There is no', 'no'))\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "IMPORT-ERROR" in out.stdout, out.stdout + out.stderr
+    # the host modules are torch-only: they import neither the native binding nor the oracle
+    for rel in ("inference/_host.py", "losses/_host.py"):
+        src = open(os.path.join(ROOT, "pytorch_toolbelt_amd", rel)).read()
+        assert not re.search(r"^\s*(from|import)\s+(oracle|ctypes)\b", src, flags=re.M) and "_native" not in src, rel
 
 
 def test_product_never_imports_oracle():

@@ -537,3 +537,35 @@ def test_sharded_merger_fuses_the_literal_calls_too(defer, dev, lazy):
         o0, o1 = m.owned_rows
         full[:, o0:o1] = m.merge()
     torch.testing.assert_close(full, want, rtol=0, atol=2e-6)
+
+
+def test_handles_only_where_a_later_change_of_the_source_would_be_seen(dev, lazy):
+    """a handle reads its source later, so it is only handed out when an in-place change in between can be noticed.
+    Tensors made under torch.inference_mode() have no version counter, and a stream being captured into a HIP graph replays into
+    static buffers: both get the eagerly evaluated tensor, like the reference.  A handle consumed on ANOTHER stream than the one it
+    was created on first waits for that stream (the producer of its source)."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    x = torch.rand((8 * 2, 3, 64, 64), device=dev)
+    assert type(tta.d4_image_deaugment(x)) is lazy.LazyDeaugment
+    with torch.inference_mode():
+        xi = torch.rand((8 * 2, 3, 64, 64), device=dev)
+        yi = tta.d4_image_deaugment(xi)
+        assert type(yi) is torch.Tensor
+        xi.mul_(0.0)                                   # too late to matter: the result was computed from the original values
+        assert float(yi.abs().sum()) > 0
+    # created on a side stream behind a slow producer, evaluated on the default stream
+    side = torch.cuda.Stream(device=dev)
+    big = torch.rand((4096, 4096), device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):
+            big = big @ big * 1e-3                     # keeps the side stream busy
+        src = torch.rand((8 * 2, 3, 64, 64), device=dev) + big[0, 0] * 0.0
+        want_src = src.clone()
+        handle = tta.d4_image_deaugment(src)
+        assert type(handle) is lazy.LazyDeaugment
+    got = handle + 0                                   # evaluated here, on the default stream
+    torch.cuda.synchronize()
+    want = _eager(tta.d4_image_deaugment, want_src)
+    assert torch.equal(got, want)

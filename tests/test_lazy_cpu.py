@@ -150,3 +150,30 @@ def test_autograd_on_an_evaluated_handle_and_the_legacy_dlpack_guard():
     for t in ts:
         t.join()
     assert all(g is got[0] for g in got)
+
+
+def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes():
+    """The to_dlpack guard is installed by the FIRST handle, not by `import pytorch_toolbelt_amd.inference`; switching the handles off
+    (tta.set_lazy_deaugment(False) / pytorch_toolbelt_amd.set_strict_dropin()) takes it out again; strict drop-in mode also stops
+    mergers from planning themselves."""
+    import subprocess
+    import sys
+
+    code = ("import torch, torch.utils.dlpack as D; orig = D.to_dlpack\n"
+            "import pytorch_toolbelt_amd, pytorch_toolbelt_amd.inference, pytorch_toolbelt_amd.losses\n"
+            "assert D.to_dlpack is orig and torch.to_dlpack is getattr(torch, 'to_dlpack')\n"
+            "from pytorch_toolbelt_amd.inference import _lazy as L, tiles as T\n"
+            "h = L.LazyDeaugment(torch.randn(4, 1, 2, 2), 'fliplr', (0, 4), 1, lambda s, v, c: s.view(2, 2, 1, 2, 2).mean(0))\n"
+            "assert D.to_dlpack is not orig and D.to_dlpack._ptb_lazy_guard\n"
+            "prev = pytorch_toolbelt_amd.set_strict_dropin(True)\n"
+            "assert prev == (True, True) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
+            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False) and L.enabled() and T._AUTO_PLAN\n"
+            "print('OK')\n")
+    import os
+
+    env = dict(os.environ)
+    env.pop("PTB_AUTO_PLAN", None)
+    env.pop("PTB_LAZY_DEAUG", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr

@@ -80,10 +80,15 @@ def test_module_surface_and_errors(dev):
     assert torch.allclose(L.BalancedBCEWithLogitsLoss(gamma=2.0)(x, t), L.balanced_binary_cross_entropy_with_logits(x, t, gamma=2.0))
     assert torch.allclose(L.WingLoss(width=3)(x, t), L.functional.wing_loss(x, t, width=3))
     assert torch.allclose(L.LogCoshLoss()(x, t), L.functional.log_cosh_loss(x, t))
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        L.SoftBCEWithLogitsLoss()(x.cpu(), t.cpu())
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        L.SoftCrossEntropyLoss()(x.cpu(), torch.zeros((2, 8, 8), dtype=torch.long))
+    # host tensors take the host evaluation (the device of the prediction decides) and agree with the kernels
+    from pytorch_toolbelt_amd import _native as N
+
+    before = N.calls
+    host = L.SoftBCEWithLogitsLoss()(x.cpu(), t.cpu())
+    host_ce = L.SoftCrossEntropyLoss()(x.cpu(), torch.zeros((2, 8, 8), dtype=torch.long))
+    assert N.calls == before and not host.is_cuda and not host_ce.is_cuda
+    assert abs(float(host) - float(L.SoftBCEWithLogitsLoss()(x, t))) < 1e-5
+    assert abs(float(host_ce) - float(L.SoftCrossEntropyLoss()(x, torch.zeros((2, 8, 8), dtype=torch.long, device=dev)))) < 1e-5
     # half inputs are evaluated in float32
     h = L.SoftBCEWithLogitsLoss(ignore_index=None)(x.half(), t.half())
     assert h.dtype == torch.float16 and abs(float(h) - float(L.SoftBCEWithLogitsLoss(ignore_index=None)(x.half().float(), t))) < 1e-3

@@ -763,21 +763,28 @@ def test_merge_band_c_abi_contract(dev):
 
 
 def test_reference_default_device_and_loud_fallbacks(dev):
-    """Code written against the reference -- TileMerger(shape, C, weight) with its default device="cpu" -- runs on the current
-    GPU (warned once); a defer / crops request the fast kernels cannot honour is announced instead of silently degraded, and
-    `merger.mode` tells which path is live."""
+    """The device the caller names decides: TileMerger(shape, C, weight) with the reference's default device="cpu" is the host
+    merger (accumulators on the CPU, CUDA batches are moved there like the reference does, tiles.py:330-335), device="cuda" the
+    HIP one, and the two agree; a defer / crops request the fast kernels cannot honour is announced instead of silently degraded,
+    and `merger.mode` tells which path is live."""
     import warnings
 
     from pytorch_toolbelt_amd.inference import tiles as T
 
     T._warned.clear()
     s = T.ImageSlicer((400, 360, 3), 128, 64, weight="pyramid")
-    with pytest.warns(RuntimeWarning, match="no CPU path"):
-        m = T.TileMerger(s.target_shape, 2, s.weight)
-    assert m.device.type == "cuda" and m.mode == "incremental"
     with warnings.catch_warnings():
-        warnings.simplefilter("error")          # said once only
-        T.TileMerger(s.target_shape, 2, s.weight)
+        warnings.simplefilter("error")
+        m = T.TileMerger(s.target_shape, 2, s.weight)
+        assert m.device.type == "cpu" and m.mode == "host" and isinstance(m, T.TileMerger) and m.image.dtype == torch.float32
+        hip = T.TileMerger(s.target_shape, 2, s.weight, device=dev)
+        assert hip.device.type == "cuda" and hip.mode == "incremental"
+        yb = torch.rand((len(s.crops), 2, 128, 128), device=dev)
+        m.integrate_batch(yb, s.crops)          # CUDA predictions into the host merger: moved, like the reference
+        hip.integrate_batch(yb, s.crops)
+        assert m.merge().device.type == "cpu" and torch.equal(m.merge(), hip.merge().cpu())
+        with pytest.raises(RuntimeError, match="no CPU"):
+            T.CudaTileMerger(s.target_shape, 2, s.weight, device="cpu")
         d = T.TileMerger(s.target_shape, 2, s.weight, device=dev, crops=s.crops, defer=True)
     assert d.mode == "deferred bands"
     # off the 4-pixel grid: neither planned nor deferred -> one warning each, ordinary path, same numbers

@@ -144,6 +144,7 @@ def play_rank(args, slicer, r, dev, C=4, V=8, B=8):
     finish_ms = float(np.median(finish))
     # ---- pipelined steps: merge_async() per image, the previous image completed after the next one was fed
     pend = None
+    m.reset()                 # (the last synchronous image still sits in the current buffers: merge_async() only resets the NEXT ones)
     for _ in range(5):
         feed()
         t = m.merge_async()
