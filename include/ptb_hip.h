@@ -559,6 +559,13 @@ int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabel
  * same element, grouped by blocks of 2^r pixels, r = the RETURN VALUE (12..14): the pairs of block b of segment s are at
  * s*P + (b << r) ..., in arbitrary order inside the block.  scratch is unused (may be NULL).  PTB_EUNSUPPORTED when a segment
  * has more than 256 * 2^14 elements (use ptb_lovasz_fwd).  ptb_lovasz_bwd_binned consumes (keys_b, vals_b, r). */
+/* ptb_lovasz_fwd_keys: the forward WITHOUT a gradient (evaluation / torch.no_grad()) as a key-only sort -- no (index, fg) value travels
+ * with the key: errors <= 0 and ignored pixels share the key of +0 (they contribute relu(e) * grad = 0 wherever they sort among
+ * themselves), a positive error's 31 significant bits move up by one and the foreground flag takes the freed bit.  Same seg_loss /
+ * fg_total as ptb_lovasz_fwd (the order of equal errors differs, which the loss does not depend on); 4 bytes per element and pass. */
+int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode, int per_image,
+                        int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b, unsigned* chunk,
+                        unsigned* fg_total, double* seg_loss, void* temp, int64_t temp_bytes, ptb_stream_t stream);
 int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                           int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                           unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,

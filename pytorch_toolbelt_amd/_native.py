@@ -103,6 +103,7 @@ SIGNATURES = {
     "ptb_softmax_focal_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_f, _c_f, _c_i64, _vp]),
     "ptb_lovasz_temp_bytes": (_c_i64, [_c_i64, _c_int]),
     "ptb_lovasz_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
+    "ptb_lovasz_fwd_keys": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 6 + [_c_i64, _vp]),
     "ptb_lovasz_fwd_binned": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
     "ptb_lovasz_bwd_binned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_int, _vp]),
     "ptb_lovasz_reduce": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),

@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned tile_of_block(int xcd_map) {
 #define PTB_RS_HIST_COPIES 4
 #endif
 constexpr int RS_HIST_COPIES = PTB_RS_HIST_COPIES;   // wave-private counter copies (power of two)
-template <bool COUNT, bool HIST = true>
+template <bool COUNT, bool HIST = true, bool INV = false>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist,
                                                       unsigned* __restrict__ chunk_count, int chunks_per_seg) {
     static_assert(RS_TILE == 2 * CHUNK && RS_WAVE_SPAN * 2 == CHUNK, "a tile is two chunks, a chunk two waves");
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
     if constexpr (COUNT) {
         unsigned fgs = 0;
 #pragma unroll
-        for (int j = 0; j < RS_ITEMS; ++j) fgs += (unsigned)__popcll(__ballot((vec || wave * RS_WAVE_SPAN + j * 64 + lane < left) && (k[j] & 1u)));
+        for (int j = 0; j < RS_ITEMS; ++j)
+            fgs += (unsigned)__popcll(__ballot((vec || wave * RS_WAVE_SPAN + j * 64 + lane < left) && ((INV ? ~k[j] : k[j]) & 1u)));
         if (lane == 0) wfg[wave] = fgs;
     }
     __syncthreads();
@@ -171,7 +172,17 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
 // bytes of the probabilities) and every class of the chunk is a pass over the same pixels: error -> key / value written, digit 0
 // counted in LDS, the tile's histogram row written.  Element i of a segment is pixel (b = i / HW, i % HW) of the batch, or pixel i of
 // image j when per_image; n < 2^31, so offsets into pred fit 32 bits.
-template <int MODE>
+// KEYONLY (the forward without a gradient, ptb_lovasz_fwd_keys): no (index, fg) value travels with the key.  An error that is not
+// positive contributes relu(e) * grad = 0 wherever it sorts among the non-positive ones, so all of them (and the ignored pixels)
+// share the key of +0; a positive float has a clear sign bit, so its 31 significant bits move up by one and the foreground flag
+// takes the freed bit: kappa = bits(e) << 1 | fg, sorted in decreasing order (key = ~kappa, ascending) -- the order of the errors
+// exactly, ties broken by fg, which the loss does not depend on.  The sort then moves 4 bytes per element and pass instead of 8.
+__device__ __forceinline__ unsigned keyonly_key(float e, unsigned fg, bool valid) {
+    const unsigned m = (valid && !(e <= 0.0f)) ? (__float_as_uint(e) & 0x7FFFFFFFu) : 0u;      // (NaN stays NaN: it sorts first and poisons the sum)
+    return ~((m << 1) | (valid ? fg : 0u));
+}
+
+template <int MODE, bool KEYONLY = false>
 __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a, int T, int cchunk, unsigned* __restrict__ keys,
                                                                 unsigned* __restrict__ vals, unsigned* __restrict__ hist) {
     __shared__ unsigned h[4][4][256];
@@ -230,10 +241,11 @@ __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a,
                 fg = y != 0.f ? 1u : 0u;
                 e = 1.0f - p[jj] * (2.0f * y - 1.0f);                 // lovasz.py:65-66
             }
-            const unsigned key = ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
+            const unsigned key = KEYONLY ? keyonly_key(e, fg, valid)
+                                         : ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
             if (ok) {
                 keys[sbase + idx] = key;
-                vals[sbase + idx] = ((unsigned)(t0 + idx) << 1) | (valid ? fg : 0u);
+                if constexpr (!KEYONLY) vals[sbase + idx] = ((unsigned)(t0 + idx) << 1) | (valid ? fg : 0u);
             }
             const unsigned d = key & 255u;
             const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
@@ -305,7 +317,7 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
 // GRAD (the binning pass of the gradient: keys_in = the sorted index << 1 | fg values): the value carried with a key is not loaded
 // but computed -- the Lovasz gradient at the element's sorted position, from the foreground count before it (chunk_off + the count
 // inside the tile) exactly as lovasz_dot_kernel computes it.
-template <int NW, bool GRAD>
+template <int NW, bool GRAD, bool KEYONLY = false>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                              unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
                                                              int shift, const unsigned* __restrict__ hist, int spans,
@@ -318,7 +330,8 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
     __shared__ unsigned wave_tot[4];
-    __shared__ unsigned skey[RS_TILE], sval[RS_TILE];
+    static_assert(!(GRAD && KEYONLY), "the gradient variant carries a value");
+    __shared__ unsigned skey[RS_TILE], sval[KEYONLY ? 1 : RS_TILE];
     const unsigned lin = tile_of_block(xcd_map);
     const int seg = lin / T, tile = lin % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
         // (they are the last in tile order and the sort is stable) and are never written
         k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
-        if constexpr (!GRAD) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+        if constexpr (!GRAD && !KEYONLY) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
     }
     __shared__ unsigned wfg[NW];
     if constexpr (GRAD) {
@@ -409,14 +422,14 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         const unsigned d = (k[j] >> shift) & 255u;
         const unsigned slot = tile_off[d] + wave_hist[wave][d] + rank[j];
         skey[slot] = k[j];
-        sval[slot] = v[j];
+        if constexpr (!KEYONLY) sval[slot] = v[j];
     }
     __syncthreads();
     for (int i = threadIdx.x; i < count; i += NT) {
         const unsigned kk = skey[i];
         const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
         keys_out[pos] = kk;
-        vals_out[pos] = sval[i];
+        if constexpr (!KEYONLY) vals_out[pos] = sval[i];
     }
 }
 
@@ -457,6 +470,7 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
 // direct scatter, both dropped: keeping a segment's scatter on one XCD (b % 8 placement) so that its lines
 // fill up in one L2: +6 %; returning through 16384-pixel bins (append (pixel, grad) runs to <= 1024 sequential streams, then
 // order each bin in LDS and write it coalesced): 205 + 36 us against 198 us for the direct scatter.
+template <bool KEYONLY = false>
 __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restrict__ keys, const unsigned* __restrict__ vals, long long P,
                                                          int chunks_per_seg, const unsigned* __restrict__ chunk_off,
                                                          const unsigned* __restrict__ fg_total, double* __restrict__ partial,
@@ -469,7 +483,23 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
     unsigned v[8];
     float e[8];
     unsigned local = 0;
-    if (first + 8 <= P && ((base + first) & 3) == 0) {
+    if constexpr (KEYONLY) {       // key = ~(bits(e) << 1 | fg): error and foreground flag come out of the key itself
+        unsigned kk[8];
+        if (first + 8 <= P && ((base + first) & 3) == 0) {
+            const uint4 ka = *reinterpret_cast<const uint4*>(keys + base + first), kb = *reinterpret_cast<const uint4*>(keys + base + first + 4);
+            kk[0] = ka.x; kk[1] = ka.y; kk[2] = ka.z; kk[3] = ka.w; kk[4] = kb.x; kk[5] = kb.y; kk[6] = kb.z; kk[7] = kb.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) kk[u] = first + u < P ? keys[base + first + u] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned kap = ~kk[u];
+            v[u] = kap & 1u;
+            e[u] = __uint_as_float(kap >> 1);
+            local += v[u];
+        }
+    } else if (first + 8 <= P && ((base + first) & 3) == 0) {
         // 2 x 16-byte loads per array: with eight 4-byte loads a wave instruction touches 16 cache lines and uses an eighth of each
         const uint4 va = *reinterpret_cast<const uint4*>(vals + base + first), vb = *reinterpret_cast<const uint4*>(vals + base + first + 4);
         const uint4 ka = *reinterpret_cast<const uint4*>(keys + base + first), kb = *reinterpret_cast<const uint4*>(keys + base + first + 4);
@@ -512,8 +542,10 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
             const float jk = jaccard_at(G, kf, (float)cum);
             const float jprev = i == 0 ? 0.0f : jaccard_at(G, kf - 1.0f, before);
             const float g = jk - jprev;                       // lovasz.py:32-33
-            acc += (double)(fmaxf(e[u], 0.0f) * g);           // dot(relu(errors_sorted), grad), lovasz.py:71 / :139
-            if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
+            acc += (double)((e[u] <= 0.0f ? 0.0f : e[u]) * g);   // dot(relu(errors_sorted), grad), lovasz.py:71 / :139; a NaN error stays NaN (F.relu keeps it) and poisons the loss like the reference's
+            if constexpr (!KEYONLY) {
+                if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
+            }
         }
     }
     // One partial sum per workgroup, added up per segment by lovasz_segsum_kernel.  (Consecutive workgroups belong to the same
@@ -835,7 +867,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         const int shift = bl + 1;
         hipLaunchKernelGGL(rs_hist_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist, chunk, cps);
         hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-        hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
+        hipLaunchKernelGGL(lovasz_dot_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
         hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
         hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift, hist,
@@ -847,7 +879,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
     // lovasz_count_kernel it replaces took 21 us for the same 67 MB)
     hipLaunchKernelGGL((rs_hist_kernel<true, false>), dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, 0, hist, chunk, cps);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-    hipLaunchKernelGGL(lovasz_dot_kernel, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, grad_at_pixel);
+    hipLaunchKernelGGL(lovasz_dot_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, grad_at_pixel);
     hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
     return check_launch();
 }
@@ -858,6 +890,59 @@ extern "C" int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const fl
                               double* seg_loss, float* grad_at_pixel, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
     return lovasz_fwd_impl(pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value, keys_a, keys_b, vals_a, vals_b,
                            chunk, fg_total, seg_loss, grad_at_pixel, temp, temp_bytes, stream, false);
+}
+
+// The forward WITHOUT a gradient (evaluation, torch.no_grad()): a key-only sort.  Nothing but the key travels through the four passes
+// (see keyonly_key): 4 bytes per element and pass instead of 8, half the LDS staging, no value arrays at all.  seg_loss / fg_total as
+// in ptb_lovasz_fwd; keys_a / keys_b u32[n], chunk u32[S * ceil(P / 2048)], temp = ptb_lovasz_temp_bytes bytes.
+extern "C" int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
+                                   int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
+                                   unsigned* chunk, unsigned* fg_total, double* seg_loss, void* temp, int64_t temp_bytes, ptb_stream_t stream) {
+    LovArgs a{};
+    if (int rc = fill(a, pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)) return rc;
+    if (!keys_a || !keys_b || !chunk || !fg_total || !seg_loss) return PTB_EINVAL;
+    const long long n = a.P * a.S;
+    if (n == 0) return PTB_OK;
+    if (n >= (1LL << 31)) return PTB_EUNSUPPORTED;
+    if (!temp || temp_bytes < ptb_lovasz_temp_bytes(a.P, a.S)) return PTB_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int T = (int)((a.P + RS_TILE - 1) / RS_TILE);
+    const long long tiles = (long long)T * a.S;
+    const int spans = (T + RS_SPAN - 1) / RS_SPAN;
+    const int cps = (int)((a.P + CHUNK - 1) / CHUNK);
+    const long long total_chunks = (long long)cps * a.S;
+    if (tiles > 0x7fffffffLL || total_chunks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    unsigned* hist = static_cast<unsigned*>(temp);
+    unsigned* span_tot = hist + (long long)a.S * 256 * T;
+    double* partial = reinterpret_cast<double*>(span_tot + (long long)a.S * 256 * spans);
+    {
+        const long long gt = (long long)(a.S / a.C) * T;
+        int nch = (int)((2048 + gt - 1) / gt);
+        nch = nch < 1 ? 1 : (nch > a.C ? a.C : nch);
+        const int cchunk = (a.C + nch - 1) / nch;
+        nch = (a.C + cchunk - 1) / cchunk;
+        if (nch > 65535) return PTB_EUNSUPPORTED;
+        const dim3 grid((unsigned)gt, (unsigned)nch);
+        if (a.mode == LOVASZ_SOFTMAX)
+            hipLaunchKernelGGL((lovasz_error_hist_kernel<LOVASZ_SOFTMAX, true>), grid, dim3(256), 0, s, a, T, cchunk, keys_a, (unsigned*)nullptr, hist);
+        else
+            hipLaunchKernelGGL((lovasz_error_hist_kernel<LOVASZ_HINGE, true>), grid, dim3(256), 0, s, a, T, cchunk, keys_a, (unsigned*)nullptr, hist);
+        if (int rc = check_launch()) return rc;
+    }
+    unsigned *kin = keys_a, *kout = keys_b;
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (shift) hipLaunchKernelGGL(rs_hist_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist, (unsigned*)nullptr, 0);
+        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
+        hipLaunchKernelGGL((rs_scatter_kernel<4, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr, a.P, T,
+                           shift, hist, spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
+        if (int rc = check_launch()) return rc;
+        unsigned* tk = kin; kin = kout; kout = tk;
+    }
+    hipLaunchKernelGGL((rs_hist_kernel<true, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, 0, hist, chunk, cps);
+    hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
+    hipLaunchKernelGGL(lovasz_dot_kernel<true>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, (const unsigned*)nullptr, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
+    hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
+    return check_launch();
 }
 
 // Same, with the gradient left BINNED instead of scattered to pixel order: on return keys_b holds (index << 1 | fg) and vals_b the

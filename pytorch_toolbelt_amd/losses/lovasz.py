@@ -18,6 +18,7 @@ __all__ = ["BinaryLovaszLoss", "LovaszLoss"]
 
 _SOFTMAX, _HINGE = 0, 1
 _CHUNK = 2048
+KEY_ONLY_FORWARD = True    # False: a forward without gradient also sorts (key, index << 1 | fg) pairs (A/B and tests)
 BINNED_GRADIENT = True     # False: the gradient is scattered to pixel order in the forward (ptb_lovasz_fwd / ptb_lovasz_bwd; A/B and tests)
 
 
@@ -44,7 +45,23 @@ class _LovaszSegments(torch.autograd.Function):
         want_grad = bool(want_grad and ctx.needs_input_grad[0])
         gpix = torch.empty(0, dtype=torch.float32, device=dev)       # (only the scattered-gradient path fills one: n floats)
         binned = None
-        if n > 0:
+        if n > 0 and not want_grad and KEY_ONLY_FORWARD:
+            # evaluation / no_grad: a key-only sort (ptb_lovasz_fwd_keys) -- the foreground flag rides in the key, no (index, fg)
+            # values exist: half the bytes per pass, two work arrays instead of four
+            lib = N.load()
+            keys = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]
+            chunk = torch.empty(S * ((P + _CHUNK - 1) // _CHUNK), dtype=torch.int32, device=dev)
+            with N.on_device(dev):
+                tb = lib.ptb_lovasz_temp_bytes(P, S)
+                if tb < 0:
+                    raise RuntimeError("ptb_lovasz_temp_bytes failed")
+                temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
+                rc = lib.ptb_lovasz_fwd_keys(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
+                                             1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
+                                             chunk.data_ptr(), fg_total.data_ptr(), seg_loss.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
+            N.bump()
+            N.check(rc, "ptb_lovasz_fwd_keys")
+        elif n > 0:
             lib = N.load()
             # (four allocations, not two [2, n] ones: the backward keeps only the binned pair keys[1] / vals[1] alive)
             keys = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(2)]

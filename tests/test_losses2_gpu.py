@@ -500,3 +500,63 @@ def test_lovasz_against_larger_reference_cases_with_gradients(case, dev):
     assert np.abs(got - want).max() <= 1e-5                      # north_star's absolute bound
     # an element is J_k - J_{k-1} of two fp32 Jaccard values (a few ulps of ~0.5 in absolute terms), scaled by 1 / #classes / #images
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ the forward without a gradient: key-only sort (ptb_lovasz_fwd_keys)
+@pytest.mark.parametrize("case", GL5.cases, ids=lambda c: c["name"])
+def test_lovasz_key_only_forward_matches_the_reference(case, dev):
+    """Under torch.no_grad() the Lovasz losses sort keys only (the foreground flag rides in the key, errors <= 0 share the key of +0):
+    the value against the reference's goldens, and against the pair sort of the same call (same errors, same order up to ties)."""
+    from pytorch_toolbelt_amd.losses import lovasz as LV
+
+    kw = dict(case["kwargs"])
+    x = torch.from_numpy(GL5[case["inputs"][0]]).to(dev)
+    t = torch.from_numpy(GL5[case["inputs"][1]]).to(dev)
+
+    def call():
+        if case["fn"] == "lovasz_softmax":
+            return LV._lovasz_softmax(x, t, classes=kw["classes"], per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+        return LV._lovasz_hinge(x, t, per_image=kw["per_image"], ignore_index=kw["ignore_index"])
+
+    assert LV.KEY_ONLY_FORWARD
+    with torch.no_grad():
+        keys_only = call()
+        LV.KEY_ONLY_FORWARD = False
+        try:
+            pairs = call()
+        finally:
+            LV.KEY_ONLY_FORWARD = True
+    np.testing.assert_allclose(keys_only.cpu().numpy(), GL5[case["output"]], rtol=1e-5, atol=1e-6)
+    assert abs(float(keys_only) - float(pairs)) <= 1e-6
+
+
+def test_lovasz_key_only_forward_edge_cases(dev):
+    """Key-only forward: hinge errors of both signs and exact ties, every pixel ignored, NaN predictions poison the loss, ragged
+    segment lengths (not a multiple of the 4096-key tile), and the result of the module under no_grad == with grad enabled."""
+    from pytorch_toolbelt_amd import losses as L
+
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for shape in ((3, 37, 53), (2, 64, 65), (1, 1, 1)):
+        x = (torch.randn(shape, generator=g) * 3).round().to(dev)             # many ties, many errors <= 0
+        y = (torch.rand(shape, generator=g) < 0.4).float().to(dev)
+        for per_image in (False, True):
+            crit = L.BinaryLovaszLoss(per_image=per_image)
+            with torch.no_grad():
+                a = crit(x, y)
+            b = crit(x.clone().requires_grad_(True), y)
+            assert abs(float(a) - float(b)) <= 1e-6, (shape, per_image, float(a), float(b))
+    C = 5
+    p = torch.softmax(torch.randn((2, C, 33, 47), generator=g) * 2, 1).to(dev)
+    lab = torch.randint(0, C, (2, 33, 47), generator=g).to(dev)
+    lab[0, :10] = 255
+    for per_image in (False, True):
+        crit = L.LovaszLoss(per_image=per_image, ignore=255)
+        with torch.no_grad():
+            a = crit(p, lab)
+        b = crit(p.clone().requires_grad_(True), lab)
+        assert abs(float(a) - float(b)) <= 1e-6
+    with torch.no_grad():
+        assert float(L.LovaszLoss(ignore=255)(p, torch.full_like(lab, 255))) == 0.0
+        bad = p.clone()
+        bad[0, 1, 3, 3] = float("nan")
+        assert torch.isnan(L.LovaszLoss()(bad, lab.clamp(max=C - 1)))
