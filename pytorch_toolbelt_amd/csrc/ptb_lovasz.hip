@@ -323,7 +323,8 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
                                                              int shift, const unsigned* __restrict__ hist, int spans,
                                                              const unsigned* __restrict__ span_tot, int xcd_map,
                                                              const unsigned* __restrict__ chunk_off, const unsigned* __restrict__ fg_total,
-                                                             int chunks_per_seg) {
+                                                             int chunks_per_seg, const unsigned* __restrict__ err_keys = nullptr,
+                                                             double* __restrict__ tile_partial = nullptr) {
     static_assert(!GRAD || NW == 4, "the gradient variant counts foreground per pair of waves (= one CHUNK)");
     constexpr int ITEMS = RS_TILE / (NW * 64), SPAN = 64 * ITEMS, NT = NW * 64;
     __shared__ unsigned wave_hist[NW][256];  // per wave: running digit counts, then the wave's start inside the tile's digit run
@@ -364,6 +365,10 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         const int chunk = tile * 2 + (wave >> 1);
         unsigned cum = (chunk < chunks_per_seg ? chunk_off[(long long)seg * chunks_per_seg + chunk] : 0u) + ((wave & 1) ? wfg[wave - 1] : 0u);
         const float G = (float)fg_total[seg];
+        // J at the position before the wave's first element (wave-uniform); afterwards an element's J_{k-1} is its left neighbour's
+        // J_k: the lane below, or lane 63 of the previous item -- one division per element instead of two, the same bits
+        const long long w0 = t0 + (long long)wave * SPAN;
+        float carry = w0 == 0 ? 0.0f : jaccard_at(G, (float)w0, (float)cum);
 #pragma unroll
         for (int j = 0; j < ITEMS; ++j) {
             const int idx = wave * SPAN + j * 64 + lane;
@@ -373,11 +378,36 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
             const unsigned before_u = cum + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
             cum += (unsigned)__popcll(bal);
             const long long i = t0 + idx;
-            const float before = (float)before_u;
             const float kf = (float)(i + 1);
             const float jk = jaccard_at(G, kf, (float)(before_u + fg));
-            const float jprev = i == 0 ? 0.0f : jaccard_at(G, kf - 1.0f, before);
+            const float left_j = __shfl_up(jk, 1);
+            const float jprev = lane == 0 ? carry : left_j;
+            carry = __shfl(jk, 63);
             v[j] = __float_as_uint(jk - jprev);                  // lovasz.py:32-33
+        }
+        if (err_keys) {
+            // the loss itself, from the gradient just computed: sum_k relu(e_k) * grad_k over the tile (lovasz.py:71 / :139) -- what
+            // lovasz_dot_kernel would read the sorted pairs once more for.  One partial sum per tile, added per segment in tile order.
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) {
+                const int idx = wave * SPAN + j * 64 + lane;
+                if (idx < count) {
+                    const float e = from_ordered_bits(~err_keys[base + t0 + idx]);
+                    acc += (double)((e <= 0.0f ? 0.0f : e) * __uint_as_float(v[j]));
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            __shared__ double wacc[NW];
+            if (lane == 0) wacc[wave] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += wacc[w];
+                tile_partial[(long long)seg * T + tile] = t;
+            }
         }
     }
 #pragma unroll
@@ -531,17 +561,19 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
     for (int w = 0; w < wave; ++w) wave_off += wsum[w];
     unsigned cum = chunk_off[blockIdx.x] + wave_off + incl - local;  // fg count strictly before this thread's first element
     double acc = 0.0;
+    // J at the position before this thread's first one; from then on every J_k is the next element's J_{k-1} (one division per
+    // element instead of two: (float)(i + 1) - 1.0f == (float)i, the same bits as evaluating J_{k-1} afresh)
+    float jprev = (first == 0 || first >= P) ? 0.0f : jaccard_at(G, (float)first, (float)cum);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const long long i = first + u;
         if (i < P) {
             const unsigned fg = v[u] & 1u;
-            const float before = (float)cum;
             cum += fg;
             const float kf = (float)(i + 1);
             const float jk = jaccard_at(G, kf, (float)cum);
-            const float jprev = i == 0 ? 0.0f : jaccard_at(G, kf - 1.0f, before);
             const float g = jk - jprev;                       // lovasz.py:32-33
+            jprev = jk;
             acc += (double)((e[u] <= 0.0f ? 0.0f : e[u]) * g);   // dot(relu(errors_sorted), grad), lovasz.py:71 / :139; a NaN error stays NaN (F.relu keeps it) and poisons the loss like the reference's
             if constexpr (!KEYONLY) {
                 if (grad_at_pixel) grad_at_pixel[base + (v[u] >> 1)] = g;      // (NULL: forward only -- the 16.7 M random writes are a quarter of the call)
@@ -771,6 +803,7 @@ static int fill(LovArgs& a, const float* pred, const int64_t* labels, const floa
 }
 
 int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in the radix scatter
+int g_lovasz_fused_dot = 1;   // ptb_set_tunable key 19: the binning scatter of the training path also evaluates the loss (0: lovasz_dot_kernel)
 static void launch_scatter(unsigned tiles, hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, long long P, int T,
                            int shift, const unsigned* hist, int spans, const unsigned* span_tot) {
     // (8 waves per workgroup -- 8 items per thread, 64 VGPRs, 24 waves per CU instead of 16 -- measured 4 % slower: more waves do not help this pass)
@@ -867,11 +900,19 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         const int shift = bl + 1;
         hipLaunchKernelGGL(rs_hist_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist, chunk, cps);
         hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-        hipLaunchKernelGGL(lovasz_dot_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
-        hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift, hist,
-                           spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps);
+        if (g_lovasz_fused_dot) {
+            // the binning scatter also evaluates the loss (it computes every element's gradient anyway and reads its error key):
+            // no lovasz_dot_kernel, the sorted values are read once instead of twice
+            hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift,
+                               hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps, kin, partial);
+            hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, T, seg_loss);
+        } else {
+            hipLaunchKernelGGL(lovasz_dot_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
+            hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
+            hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift,
+                               hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps);
+        }
         if (int rc = check_launch()) return rc;
         return bl;
     }

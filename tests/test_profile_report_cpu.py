@@ -1,6 +1,6 @@
-"""tools/profile_report.py on a synthetic rocpd database: the launches of bench.py's placement search (untimed set-up, candidate pools
-of different speed) must be reported apart from the launches on the chosen pool, whose average is what bench.py's roofline block
-is compared with."""
+"""tools/profile_report.py on a synthetic rocpd database: bench.py measures the headline on the pool as first allocated and runs its
+placement search AFTERWARDS (config.placement / config.best_placement); the search's launches (candidate pools of different speed, at
+the end of the trace) must be reported apart from the headline's, whose average is what bench.py's roofline block is compared with."""
 import json
 import os
 import sqlite3
@@ -26,22 +26,22 @@ def test_report_separates_the_placement_search(tmp_path):
         name = "void ptb::band_plan_kernel<8, 6166440, 0, 1>(ptb::ViewArgs, ptb::BandItem const*, ptb::GroupTiles)"
         t = 0
         rows = []
-        for i in range(50):          # 10 steps of the search on slow / fast candidate pools: 460 us
-            rows.append((name, t, t + 460_000, 10240)); t += 500_000
-        for i in range(100):         # everything after it on the chosen pool: 400 us
+        for i in range(100):         # probe, ramp, warm-up, timed steps, variants on the pool as first allocated: 400 us
             rows.append((name, t, t + 400_000, 10240)); t += 500_000
         for i in range(20):          # a variant with one 256-row band per launch: short launches, not averaged
             rows.append((name, t, t + 100_000, 2560)); t += 200_000
+        for i in range(50):          # 10 steps of the search + best-placement timing on slow / fast candidate pools: 460 us
+            rows.append((name, t, t + 460_000, 10240)); t += 500_000
         con.executemany("insert into kernels (name, start, end, grid_size_x) values (?, ?, ?, ?)", rows)
         con.commit()
         con.close()
-        line_path.write_text(json.dumps({"config": {"placement": {"steps_run_by_the_search": 10}}}) + "\n")
+        line_path.write_text(json.dumps({"config": {"placement": {"steps_run_by_the_search": 4, "steps_after_the_headline": 10}}}) + "\n")
         out = tmp_path / "out"
         env = dict(os.environ, PTB_PROFILE_OUT=str(out))
         r = subprocess.run([sys.executable, str(ROOT / "tools" / "profile_report.py"), "t00"], env=env, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stderr[-2000:]
         text = (out / "t00_kernel_stats.md").read_text()
-        assert "The first 50 belong to the untimed set-up before the chosen pool" in text
+        assert "The first 100 read the model-output pool as first allocated" in text and "the last 50 belong to the placement search" in text
         assert "average 460.00 us" in text and "average **400.00 us**" in text
     finally:
         if backup is not None:
