@@ -76,7 +76,9 @@ const char* ptb_last_hip_error(void);
  * 13 = workgroups of the packed-fp32 forward (default 512), 15 = output tile width of the fused multiscale kernel (64 | 128, default 128),
  * 16 = non-temporal gradient stores in the fused loss backward (0|1, default 1), 17 = XCD-contiguous tile order of the Lovasz radix
  * scatter (0|1, default 1), 18 = one-launch finish of a rank's image in ptb_band_plan_finish_rank (0|1, default 1),
- * 19 = the gradient-binning scatter of the Lovasz training path also evaluates the loss (0|1, default 1; 0: separate lovasz_dot_kernel).
+ * 19 = the gradient-binning scatter of the Lovasz training path also evaluates the loss (0|1, default 1; 0: separate lovasz_dot_kernel),
+ * 20 = Dice / Jaccard statistics (logits + labels, no ignore) and the default BinaryFocalLoss on label maps run as the statistics-only /
+ * focal-only instances of the packed streaming kernel of the fused loss (0|1, default 1; 0: the lean kernels).
  * Every setting computes the same values; the keys exist for same-box A/B runs and for tests that compare two code paths bit for bit. */
 int ptb_set_tunable(int key, int value);
 

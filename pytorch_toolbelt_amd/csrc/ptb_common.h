@@ -53,6 +53,7 @@ extern int g_rank_finish_fused;  // 0 | 1: one-launch finish of a rank's image (
 extern int g_rs_xcd_map;     // 0 | 1: XCD-contiguous tile order in the Lovasz radix scatter
 extern int g_lovasz_fused_dot;   // 0 | 1: the binning scatter of the Lovasz training path also evaluates the loss
 extern int g_nt_grad_stores; // 0 | 1: non-temporal gradient stores in the fused loss backward
+extern int g_stats_pk;       // 0 | 1: statistics-only / focal-only instances of the packed streaming loss kernel
 extern int g_focal_pk_grid;  // workgroups of the packed-fp32 fused loss forward
 extern int g_focal_pk;       // 0 | 1: A/B of the packed-fp32 instance of the fused loss forward
 extern int g_fused_pix2;     // 0 | 1: A/B of the fused loss forward with 2 pixels per lane

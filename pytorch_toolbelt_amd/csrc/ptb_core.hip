@@ -247,6 +247,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_lovasz_fused_dot = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 20) {
+        g_stats_pk = value ? 1 : 0;
+        return PTB_OK;
+    }
     if (key == 13) {
         if (value < 1) return PTB_EINVAL;
         g_focal_pk_grid = value;

@@ -378,8 +378,12 @@ __device__ __forceinline__ v2f lg22(v2f x) { return v2f{lg2(x.x), lg2(x.y)}; }
 __device__ __forceinline__ v2f ex22(v2f x) { return v2f{ex2(x.x), ex2(x.y)}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <int CREG, bool TERM, bool FULL, bool PF = false>   // PF: the next pixel group's loads are in flight while this one is computed
+// FOCAL = false: the same streaming skeleton for the region statistics alone (DiceLoss / JaccardLoss on logits + hard labels): one
+// exp per element, one rcp per pixel, P in packed registers, I and T through the per-lane LDS columns.
+// STATS = false: the focal sums alone (BinaryFocalLoss in its default configuration on label maps): no softmax denominator, no P / I / T.
+template <int CREG, bool TERM, bool FULL, bool PF = false, bool FOCAL = true, bool STATS = true>   // PF: the next pixel group's loads are in flight while this one is computed
 __global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const SegArgs a) {
+    static_assert(FOCAL || STATS, "nothing to compute");
     extern __shared__ float lds[];  // [4 waves][2][CREG][64] per-lane columns of I and T; afterwards [4][3][C] wave sums + the tail's scratch
     const int lane = threadIdx.x & 63, wave = wave_id();
     const int C = a.C;
@@ -419,9 +423,29 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const Seg
 #pragma unroll
         for (int c = 0; c < CREG; ++c) {
             xv[c] = ex22(fma2(xv[c], v2f{kLog2e, kLog2e}, -M));         // u = exp(x - m)
-            d += xv[c];
+            if constexpr (STATS) d += xv[c];
         }
-        const v2f inv = rcp2(d), em = ex22(-M);
+        const v2f inv = STATS ? rcp2(d) : v2f{0.f, 0.f};
+        if constexpr (!FOCAL) {
+#pragma unroll
+            for (int c = 0; c < CREG; ++c) aP[c] = fma2(xv[c], inv, aP[c]);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float sel[CREG];
+#pragma unroll
+                for (int c = 0; c < CREG; ++c) sel[c] = k ? xv[c].y : xv[c].x;
+#pragma unroll
+                for (int w = CREG / 2, bit = 1; w >= 1; w >>= 1, bit <<= 1) {
+                    const bool up = lab[k] & bit;
+#pragma unroll
+                    for (int j = 0; j < w; ++j) sel[j] = up ? sel[2 * j + 1] : sel[2 * j];
+                }
+                atomicAdd(colI + lab[k] * 64, sel[0] * (k ? inv.y : inv.x));      // ds_add_f32 into this lane's own column
+                atomicAdd(colT + lab[k] * 64, 1.0f);
+            }
+            return;
+        }
+        const v2f em = ex22(-M);
         const bool tame = m.x <= 60.f && m.y <= 60.f && lo.x >= -80.f && lo.y >= -80.f && lo.x - m.x >= -80.f && lo.y - m.y >= -80.f;
         v2f FL = v2f{0.f, 0.f}, F = v2f{0.f, 0.f};
 #pragma unroll
@@ -433,7 +457,7 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const Seg
             const v2f f = ps * ps;
             FL = fma2(f, L, FL);
             F += f;
-            aP[c] = fma2(u, inv, aP[c]);
+            if constexpr (STATS) aP[c] = fma2(u, inv, aP[c]);
         }
         // the label's class of each pixel: replace its t = 0 term by the t = 1 one, and feed I_c / T_c
         float lsum = 0.f, fsum = 0.f;
@@ -456,8 +480,10 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const Seg
             // sum_c f_c log2(q_c) = -M F - FL;  label's class: f0 (-M - Lh) out, f1 (lu - Lh) in
             lsum += __builtin_fmaf(f1, lu - Lh, __builtin_fmaf(f0, Mk + Lh, -__builtin_fmaf(Mk, Fk, FLk)));
             if (TERM) fsum += Fk + (f1 - f0);
-            atomicAdd(colI + lab[k] * 64, uh * invk);      // ds_add_f32 into this lane's own column
-            atomicAdd(colT + lab[k] * 64, 1.0f);
+            if constexpr (STATS) {
+                atomicAdd(colI + lab[k] * 64, uh * invk);      // ds_add_f32 into this lane's own column
+                atomicAdd(colT + lab[k] * 64, 1.0f);
+            }
         }
         lsum *= -kLn2;
         if (__any(!tame)) {   // the whole wave: exact focal sums from the re-read logits (never on sane logits)
@@ -495,7 +521,11 @@ __global__ __launch_bounds__(256, PF ? 2 : 4) void seg_focal_pk_kernel(const Seg
         }
     }
     double* slot = a.sums + (size_t)(blockIdx.x % SUM_SLOTS) * (2 + 3 * C);
-    block_add2(f_loss, f_term, slot, lane, wave);
+    if constexpr (FOCAL) block_add2(f_loss, f_term, slot, lane, wave);
+    if constexpr (!STATS) {
+        if (a.tail_counter) region_tail(a, lds);
+        return;
+    }
     // Row sums of the wave's [2 CREG][64] table without 6-step shuffles per value: lane L adds up half (L / 32... for 2 CREG = 32
     // rows; in general 64 / ROWS parts) of row L % ROWS, walking the columns rotated by its row number so that the lanes of one
     // read hit distinct banks; the parts are then combined across lanes.  P (registers) goes through the same table afterwards.
@@ -1955,6 +1985,7 @@ int g_loss_prefetch = 0;   // ptb_set_tunable key 8: register double buffering i
 int g_smf_bwd_stash = 4;  // ptb_set_tunable key 7: 4 pixels per lane (251 VGPRs, 2 waves per SIMD) measured 0.372 ms fwd+bwd at cfg4, 2 pixels 0.54, the two-pass kernel 0.41-0.48
 int g_nt_grad_stores = 1;    // ptb_set_tunable key 16: non-temporal stores of the gradient in the fused backward (A/B: 333 -> 315 us fwd+bwd at cfg4; the other backward kernels always use them)
 int g_focal_pk_grid = 512;   // ptb_set_tunable key 13: workgroups of seg_focal_pk_kernel (2 per CU measured best: per-workgroup prologue / epilogue / slot atomics)
+int g_stats_pk = 1;       // ptb_set_tunable key 20: Dice / Jaccard statistics and the default BinaryFocalLoss on label maps take the packed streaming kernel (0: the lean kernels)
 int g_focal_pk = 1;       // ptb_set_tunable key 12 (2 = with register prefetch of the next pixel group): packed-fp32 / per-pixel-correction instance of the fused forward (seg_focal_pk_kernel); 0 = seg_fwd_lean_kernel
 int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics forward with 2 pixels per lane (120 VGPRs, 4 waves per SIMD,
                           // instead of 4 pixels: 163 VGPRs, 3 waves): 0.164-0.171 vs 0.173-0.186 ms per FocalDiceJaccardLoss forward at cfg4
@@ -1963,6 +1994,14 @@ int g_fused_pix2 = 1;     // ptb_set_tunable key 5: fused focal + statistics for
 using namespace ptb;
 
 static int seg_loss_fwd_launch(SegArgs& a, hipStream_t s);
+
+// BinaryFocalLoss() on label maps in its default configuration (gamma 2, nothing else; mean / sum / normalized): served by the
+// focal-only instance of the packed streaming kernel -- the only focal-only kernel that carries the in-launch tail.
+static bool focal_only_pk(const SegArgs& a) {
+    return (a.flags & (SEG_FOCAL | SEG_STATS)) == SEG_FOCAL && !g_force_scalar && g_stats_pk && a.labels && !a.dense && a.HW % 128 == 0 && a.C <= 16 &&
+           a.gamma == 2.0f && !a.class_weights && !(a.flags & (SEG_HAS_ALPHA | SEG_REDUCED | SEG_ELEMWISE | SEG_HAS_IGNORE)) &&
+           vec_ok(a.HW, {a.logits, a.dense, a.elem_out, a.labels});
+}
 
 extern "C" int ptb_seg_loss_fwd(const float* logits, const int64_t* labels, const float* dense, const float* class_weights,
                                 double* sums, float* elem_out, int* error_flag, int B, int C, int64_t HW, int flags, int prob,
@@ -1996,7 +2035,8 @@ extern "C" int ptb_region_loss_fwd(const float* logits, const int64_t* labels, c
     SegArgs a{};
     if (int rc = fill_seg(a, logits, labels, dense, class_weights, B, C, HW, flags, prob, gamma, alpha, threshold, ignore_label, ignore_value)) return rc;
     if (!workspace || !loss || !coef || n_selected < 1 || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return PTB_EINVAL;
-    if (!(flags & SEG_STATS) || (flags & SEG_ELEMWISE)) return PTB_EINVAL;
+    if (!(flags & (SEG_STATS | SEG_FOCAL)) || (flags & SEG_ELEMWISE)) return PTB_EINVAL;
+    if (!(flags & SEG_STATS) && !focal_only_pk(a)) return PTB_EUNSUPPORTED;      // (focal alone: only the packed instance ends with the tail)
     if (C > 1024) return PTB_EUNSUPPORTED;
     if ((long long)B * HW == 0) return PTB_EUNSUPPORTED;      // (nothing would launch: the caller composes the empty case)
     a.sums = static_cast<double*>(workspace);
@@ -2064,6 +2104,11 @@ static int seg_loss_fwd_launch(SegArgs& a, hipStream_t s) {
                                else if (no_term && C == CR) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, true>), g2, block, shmem, s, a); \
                                else if (no_term) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, false, false>), g2, block, shmem, s, a); \
                                else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, true, false, 2, true, false>), g2, block, shmem, s, a); } \
+            else if (prob == PROB_SOFTMAX && !ign && g_stats_pk && HW % 128 == 0) { \
+                               const size_t pk_lds = std::max(shmem, (size_t)4 * 2 * CR * 64 * sizeof(float)); \
+                               const dim3 gpk(grid_for_groups(HW / 128 * B, g_focal_pk_grid)); \
+                               if (C == CR) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, true, false, false>), gpk, block, pk_lds, s, a); \
+                               else hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, false, false, false>), gpk, block, pk_lds, s, a); } \
             else if (prob == PROB_SOFTMAX) { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, true>), lgrid, block, shmem, s, a); \
                                              else hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_SOFTMAX, false, false>), lgrid, block, shmem, s, a); } \
             else { if (ign) hipLaunchKernelGGL((seg_fwd_lean_kernel<CR, PROB_IDENTITY, false, true>), lgrid, block, shmem, s, a); \
@@ -2073,6 +2118,20 @@ static int seg_loss_fwd_launch(SegArgs& a, hipStream_t s) {
             return check_launch();
         }
 #undef PTB_LEAN
+    }
+    if (focal_only_pk(a)) {
+        // BinaryFocalLoss() on label maps in its default configuration: the packed streaming kernel of the fused loss without its
+        // statistics half (the shared exponent shift max_c x keeps one exp per element for sigmoid and its complement)
+        const bool term = !(flags & SEG_NO_TERM);
+        const dim3 gpk(grid_for_groups(HW / 128 * B, g_focal_pk_grid));
+#define PTB_FPK(CR) do { const size_t pk_lds = std::max(shmem, (size_t)4 * 2 * CR * 64 * sizeof(float)); \
+                         if (term) { if (C == CR) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, true, true, false, true, false>), gpk, block, pk_lds, s, a); \
+                                     else hipLaunchKernelGGL((seg_focal_pk_kernel<CR, true, false, false, true, false>), gpk, block, pk_lds, s, a); } \
+                         else { if (C == CR) hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, true, false, true, false>), gpk, block, pk_lds, s, a); \
+                                else hipLaunchKernelGGL((seg_focal_pk_kernel<CR, false, false, false, true, false>), gpk, block, pk_lds, s, a); } } while (0)
+        if (C <= 4) PTB_FPK(4); else if (C <= 8) PTB_FPK(8); else PTB_FPK(16);
+#undef PTB_FPK
+        return check_launch();
     }
     if (what == SEG_FOCAL && !g_force_scalar && labels && !dense && vec && HW % 256 == 0 && g2 && !class_weights &&
         !(flags & (SEG_HAS_ALPHA | SEG_REDUCED | SEG_ELEMWISE))) {

@@ -199,6 +199,68 @@ class SigmoidFocalSums(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None, None
 
 
+class FocalScalar(torch.autograd.Function):
+    """``scale * sum_i L_i`` of the sigmoid focal loss on label maps as ONE launch (``ptb_region_loss_fwd`` with the focal sums alone:
+    the streaming kernel's last workgroup adds up the slots and writes the scalar; no memset / finalize launches, no torch algebra
+    on scalars).  Returns None when the configuration is not served that way (the caller takes ``SigmoidFocalSums``)."""
+
+    @staticmethod
+    def run(x, labels, flags, gamma, scale):
+        if not ONE_LAUNCH_REGION_LOSS or not (x.requires_grad and torch.is_grad_enabled()):
+            out = FocalScalar._launch(x, labels, flags, gamma, scale)
+            return None if out is None else out[0]
+        try:
+            return FocalScalar.apply(x, labels, flags, gamma, scale)
+        except NotImplementedError:       # (the C side does not serve this shape in one launch: nothing was launched)
+            return None
+
+    @staticmethod
+    def _launch(x, labels, flags, gamma, scale):
+        if not ONE_LAUNCH_REGION_LOSS:
+            return None
+        B, C, HW = x.shape
+        ws = region_workspace(x.device, C)
+        if ws is None:
+            return None
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        coef = torch.empty(2 + 2 * C, dtype=torch.float32, device=x.device)
+        slot = host_flag_slot() if _CHECK_LABELS else None
+        with N.on_device(x.device):
+            rc = N.load().ptb_region_loss_fwd(x.data_ptr(), labels.data_ptr(), None, None, ws.data_ptr(), B, C, HW, flags | SEG_FOCAL, PROB_SIGMOID,
+                                              gamma, 0.0, 0.0, 0, 0.0, scale, 0.0, 0.0, 0.0, 1e-7, 0, None, C, loss.data_ptr(), coef.data_ptr(),
+                                              _ptr(slot), N.stream_ptr(x.device))
+        if rc == N.PTB_EUNSUPPORTED:
+            return None
+        N.check(rc, "ptb_region_loss_fwd (focal)")
+        N.bump()
+        if slot is not None:
+            watch_host_flag(slot, x.device)
+        return loss, coef
+
+    @staticmethod
+    def forward(ctx, x, labels, flags, gamma, scale):
+        out = FocalScalar._launch(x, labels, flags, gamma, scale)
+        if out is None:
+            raise NotImplementedError("focal one-launch path")
+        ctx.save_for_backward(x, labels)
+        ctx.cfg = (flags, gamma, scale)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, labels = ctx.saved_tensors
+        flags, gamma, scale = ctx.cfg
+        B, C, HW = x.shape
+        coef = torch.stack([g.to(torch.float32) * scale, torch.zeros((), device=x.device)]).contiguous()
+        grad = torch.empty_like(x)
+        with N.on_device(x.device):
+            rc = N.load().ptb_focal_bwd(x.data_ptr(), labels.data_ptr(), None, None, coef.data_ptr(), None, grad.data_ptr(), B, C, HW, flags, gamma,
+                                        0.0, 0.0, 0, 0.0, N.stream_ptr(x.device))
+        N.bump()
+        N.check(rc, "ptb_focal_bwd")
+        return grad, None, None, None, None
+
+
 class SoftmaxActFocalSums(torch.autograd.Function):
     """``focal_loss_with_logits(activation="softmax")``: sums[0] = sum_i L_i, sums[1] = sum_i F_i, optionally the unreduced map.
 

@@ -165,6 +165,12 @@ def _sigmoid_focal(output, labels, dense, gamma, alpha, reduction, normalized, r
         cw = class_weights.to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         if cw.numel() != x.shape[1]:
             raise RuntimeError("class_weights must have one entry per channel")
+    if (labels is not None and reduction in ("mean", "sum") and not normalized and cw is None and alpha is None and reduced_threshold is None
+            and ignore_index is None and float(gamma) == 2.0 and x.numel()):
+        # BinaryFocalLoss() as the README uses it: the whole forward is one launch (kernel + in-launch tail)
+        one = K.FocalScalar.run(x, labels, flags, 2.0, 1.0 / x.numel() if reduction == "mean" else 1.0)
+        if one is not None:
+            return one
     sums, elem = K.SigmoidFocalSums.apply(
         x, labels, dense, cw, flags, float(gamma), float(alpha if alpha is not None else 0.0),
         float(reduced_threshold if reduced_threshold is not None else 0.0),
