@@ -297,6 +297,11 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
         del image, lab_img
     except Exception as exc:  # noqa: BLE001
         out["e2e_5000_stand_in_model"] = {"error": repr(exc)}
+    if os.environ.get("PTB_BENCH_UNET", "1") == "1":
+        try:
+            out["e2e_5000_unet"] = e2e_unet(dev)
+        except Exception as exc:  # noqa: BLE001
+            out["e2e_5000_unet"] = {"error": repr(exc)}
     if with_cpu:
         from oracle import torch_chain as TC
 
@@ -327,6 +332,104 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
         finally:
             torch.set_num_threads(prev)
     return out
+
+
+def _unet(width=32, classes=CHANNELS):
+    """BASELINE configs[1]'s "dummy 4-class UNet" as plain torch: the reference's UnetBlock (two conv3x3 without bias, each
+    followed by BatchNorm + ReLU: modules/unet.py:10-47) in a 4-level encoder (32 / 64 / 128 / 256 features, 2 x 2 max-pool between the
+    levels: modules/encoders/unet.py:13-52) and decoder (nearest 2 x up-sampling, concatenation with the skip, UnetBlock:
+    modules/decoders/unet.py:24-129), 1 x 1 head; 3 -> 4 channels, manual_seed(0), eval()."""
+    from torch import nn
+
+    def block(cin, cout):
+        return nn.Sequential(nn.Conv2d(cin, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True),
+                             nn.Conv2d(cout, cout, 3, padding=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+    class UNet(nn.Module):
+        def __init__(self):
+            super().__init__()
+            w = [width, width * 2, width * 4, width * 8]
+            self.enc = nn.ModuleList([block(3, w[0]), block(w[0], w[1]), block(w[1], w[2]), block(w[2], w[3])])
+            self.dec = nn.ModuleList([block(w[3] + w[2], w[2]), block(w[2] + w[1], w[1]), block(w[1] + w[0], w[0])])
+            self.head = nn.Conv2d(w[0], classes, 1)
+
+        def forward(self, x):
+            feats = []
+            for i, e in enumerate(self.enc):
+                x = e(x if i == 0 else nn.functional.max_pool2d(x, 2))
+                feats.append(x)
+            for d, skip in zip(self.dec, feats[-2::-1]):
+                x = d(torch.cat([nn.functional.interpolate(x, scale_factor=2, mode="nearest"), skip], 1))
+            return self.head(x)
+
+    torch.manual_seed(0)
+    return UNet().eval()
+
+
+def e2e_unet(dev):
+    """SURVEY 8d's secondary region with the model BASELINE names: uint8 5000 x 5000 x 3 image host -> (H2D) -> tiles + normalise + d4
+    augment (split_device) -> 4-level UNet (random weights, eval) -> d4 de-augment + integrate -> merge + crop + arg-max -> (D2H), batches
+    of 8 tiles x 8 views, ONE timed image per variant after a two-batch warm-up (MIOpen picks its convolution algorithms there; ~20 s
+    per dtype on a fresh box, untimed).  Variants: the reference's literal calls on a new TileMerger per image (fp32); the planned +
+    deferred merger (crops= known, defer=True; fp32); the same with the model under bf16 autocast, its bfloat16 outputs read natively
+    by the band kernel.  The model is ~99.9 % of the time: MP/s says what a user gets end to end, `merge_share` what the library
+    costs inside it, `peak_GB` what holding batches (defer) adds next to the UNet's activations."""
+    import numpy as np_
+
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.inference.tiles import CudaTileMerger, ImageSlicer
+
+    image = torch.from_numpy(np_.random.default_rng(0).integers(0, 256, IMAGE, dtype=np_.uint8)).pin_memory()
+    tiler = ImageSlicer(IMAGE, TILE, STEP, weight="pyramid")
+    model = _unet().to(dev)
+    inv255 = [1.0 / 255.0] * 3
+    n = len(tiler.crops)
+
+    def run(kind, autocast_dtype, batches=None):
+        dimg = image.to(dev, non_blocking=True)
+        if kind == "literal":
+            merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight)
+        else:
+            merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight, crops=tiler.crops, defer=True)
+        ctx = torch.autocast("cuda", dtype=autocast_dtype) if autocast_dtype is not None else torch.autocast("cuda", enabled=False)
+        for b0 in list(range(0, n, BATCH))[:batches]:
+            xb = tiler.split_device(dimg, slice(b0, b0 + BATCH), augment="d4", scale=inv255, bias=[0.0] * 3)
+            with ctx:
+                yb = model(xb)
+            if kind == "literal":
+                merger.integrate_batch(tta.d4_image_deaugment(yb), tiler.crops[b0:b0 + BATCH])
+            else:
+                merger.integrate_batch_deaugment(yb, tiler.crops[b0:b0 + BATCH], group="d4", reduction="mean")
+        if batches is not None:
+            return None
+        return merger.merge_crop(tiler, argmax=True, dtype=torch.uint8).cpu()
+
+    res = {"what": "wall clock per 5000x5000x3 uint8 image, host to host, through the plain-torch 4-level conv3x3-BN-ReLU UNet (3 -> 4 channels, "
+                   "32/64/128/256 features, manual_seed(0), eval): 46 batches of 8 tiles x 8 d4 views; one timed image per variant"}
+    with torch.no_grad():
+        for name, kind, dt in (("literal_fp32", "literal", None), ("deferred_fp32", "deferred", None), ("deferred_bf16_autocast", "deferred", torch.bfloat16)):
+            run(kind, dt, batches=2)                      # warm-up: MIOpen's algorithm search, allocator
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            labels = run(kind, dt)
+            wall = time.perf_counter() - t0
+            assert labels.shape == (IMAGE[0], IMAGE[1]) and int(labels.max()) < CHANNELS
+            res[name] = {"ms": round(wall * 1e3, 1), "MP_s": round(IMAGE[0] * IMAGE[1] / 1e6 / wall, 2),
+                         "peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)}
+        # the model alone on the same 46 batches (no merger): what is left of the wall clock is slicing, merging and the copies
+        xb = tiler.split_device(image.to(dev), slice(0, BATCH), augment="d4", scale=inv255, bias=[0.0] * 3)
+        for name, dt in (("model_only_fp32_ms", None), ("model_only_bf16_autocast_ms", torch.bfloat16)):
+            ctx = torch.autocast("cuda", dtype=dt) if dt is not None else torch.autocast("cuda", enabled=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with ctx:
+                for _ in range((n + BATCH - 1) // BATCH):
+                    model(xb)
+            torch.cuda.synchronize()
+            res[name] = round((time.perf_counter() - t0) * 1e3, 1)
+    return res
 
 
 def main_cfg5(args):

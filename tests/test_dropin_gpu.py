@@ -197,10 +197,10 @@ def test_lazy_source_edit_is_reported_and_budget_bounds_memory(dev, lazy):
     x.add_(1.0)
     with pytest.raises(RuntimeError, match="modified in place"):
         y + 0
-    with torch.inference_mode():              # no version counters there: the handle still works
+    with torch.inference_mode():              # no version counters there: an edit could not be noticed, so no handle is handed out
         xi = torch.rand((2 * 2, 1, 16, 16), device=dev)
         yi = tta.fliplr_image_deaugment(xi)
-        assert type(yi) is lazy.LazyDeaugment and torch.equal(yi, _eager(tta.fliplr_image_deaugment, xi))
+        assert type(yi) is torch.Tensor and torch.equal(yi, _eager(tta.fliplr_image_deaugment, xi))
     old = lazy._BUDGET
     try:
         src = torch.rand((2 * 4, 2, 32, 32), device=dev)
@@ -569,3 +569,46 @@ def test_handles_only_where_a_later_change_of_the_source_would_be_seen(dev, lazy
     torch.cuda.synchronize()
     want = _eager(tta.d4_image_deaugment, want_src)
     assert torch.equal(got, want)
+
+
+def test_deferred_merger_next_to_a_real_model(dev):
+    """The planned + deferred merger under the allocator churn of a real convolutional model (the 4-level conv-BN-ReLU UNet of
+    bench.py, narrow): every batch is a fresh tensor the caching allocator carved out of memory the previous activations just
+    freed -- held batches must stay intact until their band is merged, so the result equals the plain merger's bit for bit; fp32
+    and bf16-autocast outputs (read natively).  A model that writes into ONE static output buffer (HIP-graph style) is refused."""
+    import bench
+    from pytorch_toolbelt_amd.inference import tta
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    torch.manual_seed(0)
+    model = bench._unet(width=4, classes=3).to(dev)
+    tiler = ImageSlicer((700, 600, 3), 128, 64, weight="pyramid")
+    image = torch.randint(0, 256, (700, 600, 3), dtype=torch.uint8, device=dev)
+    n = len(tiler.crops)
+    for dt in (None, torch.bfloat16):
+        ctx = torch.autocast("cuda", dtype=dt) if dt is not None else torch.autocast("cuda", enabled=False)
+        plain = TileMerger(tiler.target_shape, 3, tiler.weight, device=dev, auto_plan=False)
+        deferred = TileMerger(tiler.target_shape, 3, tiler.weight, device=dev, crops=tiler.crops, defer=True)
+        assert deferred.mode == "deferred bands"
+        with torch.no_grad():
+            for b0 in range(0, n, 5):
+                xb = tiler.split_device(image, slice(b0, b0 + 5), augment="d4", scale=[1 / 255.0] * 3, bias=[0.0] * 3)
+                with ctx:
+                    yb = model(xb)
+                assert yb.dtype == (dt or torch.float32)
+                deferred.integrate_batch_deaugment(yb, tiler.crops[b0:b0 + 5], group="d4", reduction="mean")
+                plain.integrate_batch_deaugment(yb, tiler.crops[b0:b0 + 5], group="d4", reduction="mean")
+                del xb, yb                           # (the only references left are the merger's)
+                junk = torch.rand((64, 3, 128, 128), device=dev)      # churn: whatever was freed is handed out again
+                del junk
+        assert deferred.mode == "deferred bands" and torch.equal(deferred.merge(), plain.merge())
+    # static outputs: the second batch lives in the first one's memory while that one is still held
+    static = torch.empty((8 * 5, 3, 128, 128), device=dev)
+    deferred = TileMerger(tiler.target_shape, 3, tiler.weight, device=dev, crops=tiler.crops, defer=True)
+    with torch.no_grad():
+        xb = tiler.split_device(image, slice(0, 5), augment="d4", scale=[1 / 255.0] * 3, bias=[0.0] * 3)
+        static.copy_(model(xb))
+        deferred.integrate_batch_deaugment(static, tiler.crops[0:5], group="d4", reduction="mean")
+        static.copy_(model(tiler.split_device(image, slice(5, 10), augment="d4", scale=[1 / 255.0] * 3, bias=[0.0] * 3)))
+        with pytest.raises(RuntimeError, match="still held|modified in place"):
+            deferred.integrate_batch_deaugment(static, tiler.crops[5:10], group="d4", reduction="mean")
