@@ -369,8 +369,8 @@ def _unet(width=32, classes=CHANNELS):
 def e2e_unet(dev):
     """SURVEY 8d's secondary region with the model BASELINE names: uint8 5000 x 5000 x 3 image host -> (H2D) -> tiles + normalise + d4
     augment (split_device) -> 4-level UNet (random weights, eval) -> d4 de-augment + integrate -> merge + crop + arg-max -> (D2H), batches
-    of 8 tiles x 8 views, ONE timed image per variant after a two-batch warm-up (MIOpen picks its convolution algorithms there; ~20 s
-    per dtype on a fresh box, untimed).  Variants: the reference's literal calls on a new TileMerger per image (fp32); the planned +
+    of 8 tiles x 8 views, ONE timed image per variant after a warm-up on the first two batches and the ragged last one (MIOpen picks its
+    convolution algorithms per shape there; ~20 s per dtype on a fresh box, untimed).  Variants: the reference's literal calls on a new TileMerger per image (fp32); the planned +
     deferred merger (crops= known, defer=True; fp32); the same with the model under bf16 autocast, its bfloat16 outputs read natively
     by the band kernel.  The model is ~99.9 % of the time: MP/s says what a user gets end to end, `merge_share` what the library
     costs inside it, `peak_GB` what holding batches (defer) adds next to the UNet's activations."""
@@ -392,7 +392,8 @@ def e2e_unet(dev):
         else:
             merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight, crops=tiler.crops, defer=True)
         ctx = torch.autocast("cuda", dtype=autocast_dtype) if autocast_dtype is not None else torch.autocast("cuda", enabled=False)
-        for b0 in list(range(0, n, BATCH))[:batches]:
+        starts = list(range(0, n, BATCH))
+        for b0 in (starts if batches is None else starts[:batches] + starts[-1:]):      # (warm-up: the first batches + the ragged last one)
             xb = tiler.split_device(dimg, slice(b0, b0 + BATCH), augment="d4", scale=inv255, bias=[0.0] * 3)
             with ctx:
                 yb = model(xb)
@@ -870,9 +871,9 @@ def main():
 
         from pytorch_toolbelt_amd.inference import tiles as _tiles
 
-        def variant(make, literal=False, fresh=False, eager=False):
+        def variant(make, literal=False, fresh=False, eager=False, self_plan=False):
             m = make()
-            prev = (_tta.set_lazy_deaugment(not eager), _tiles.set_auto_plan(not eager))
+            prev = (_tta.set_lazy_deaugment(not eager), _tiles.set_auto_plan(self_plan))
             _tiles._auto.clear()
 
             def vstep():
@@ -902,6 +903,7 @@ def main():
         mk = lambda **kw: (lambda: TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, **kw))  # noqa: E731
         lit, lit_mode = variant(mk(), literal=True)
         lit_new, lit_new_mode = variant(mk(), literal=True, fresh=True)
+        lit_sp, lit_sp_mode = variant(mk(), literal=True, self_plan=True)
         variants = {
             "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None))[0],
             "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256))[0],
@@ -911,15 +913,18 @@ def main():
             "dropin_literal_merger_mode": lit_mode,
             "dropin_literal_new_merger_per_image_ms": lit_new,
             "dropin_literal_new_merger_per_image_mode": lit_new_mode,
+            "dropin_literal_self_planned_ms": lit_sp,
+            "dropin_literal_self_planned_mode": lit_sp_mode,
             "dropin_literal_eager_ms": variant(mk(), literal=True, eager=True)[0],
             "note": "ms per 5000x5000 image, median of 3 runs of K steps; deferred_bands = TileMerger(crops=, defer=True) + "
                     "integrate_batch_deaugment (the headline); planned_no_defer = TileMerger(crops=) + integrate_batch_deaugment; "
                     "unplanned_fused = TileMerger(auto_plan=False) + integrate_batch_deaugment + merge(); dropin_literal = the reference's "
                     "literal calls, no API extension: TileMerger(shape, C, weight) + integrate_batch(tta.d4_image_deaugment(y), crops) + "
-                    "merge() -- the de-augmentation comes back as a lazy handle the merger fuses into its launch, and the merger plans "
-                    "itself from the crop sequence of the previous image (reset() per image; _new_merger_per_image: a new TileMerger "
-                    "per image as in the README); dropin_literal_eager = the same calls with both switched off (round 2's behaviour: "
-                    "the reduced tile travels through HBM, separate merge pass)",
+                    "merge() -- the de-augmentation comes back as a lazy handle the merger fuses into its launch (reset() per image; "
+                    "_new_merger_per_image: a new TileMerger per image as in the README); _self_planned: the same with "
+                    "set_auto_plan(True) (opt-in: the merger plans itself from the crop sequence of the previous image and keeps its "
+                    "accumulators exact); dropin_literal_eager = lazy handles switched off, pytorch_toolbelt_amd.set_strict_dropin(): "
+                    "the reduced tile travels through HBM, separate merge pass",
         }
 
     if args.diag and rank == 0 and not use_dist:   # (extra steps on one rank only would leave the others' halo exchanges unmatched)

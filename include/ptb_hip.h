@@ -110,6 +110,12 @@ int ptb_tile_accumulate(float* image, float* norm, const float* weight, const fl
 int ptb_accumulate_planned(float* image, const float* norm_full, float* merged, const float* weight, const void* in, int in_dtype,
                            int V, const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw,
                            int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, ptb_stream_t stream);
+/* ptb_accumulate_planned2 = ptb_accumulate_planned + flags.  PTB_PLANNED_KEEP_SUMS (bit 0): a finalised block also stores its weighted
+ * sum in `image` -- the accumulator stays complete and exact whenever it is read (TileMerger.image of a merger that planned itself). */
+#define PTB_PLANNED_KEEP_SUMS 1
+int ptb_accumulate_planned2(float* image, const float* norm_full, float* merged, const float* weight, const void* in, int in_dtype,
+                           int V, const int* views, int reduction, const int64_t* xs, const int64_t* ys, int B, int C, int th, int tw,
+                           int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, int flags, ptb_stream_t stream);
 /* out[c] = image[c] / norm on the blocks (64 columns x rows rows, row-major grid) whose byte in the DEVICE map `mask` is
  * non-zero; other blocks of `out` are left untouched. */
 int ptb_merge_div_masked(const float* image, const float* norm, float* out, int C, int H, int W, const uint8_t* mask, int rows,

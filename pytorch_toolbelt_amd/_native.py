@@ -47,6 +47,8 @@ SIGNATURES = {
     "ptb_deaug_accumulate_t": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_accumulate_planned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                         _vp, _c_int, _vp, _vp, _vp]),
+    "ptb_accumulate_planned2": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                         _vp, _c_int, _vp, _vp, _c_int, _vp]),
     "ptb_merge_div_masked": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_norm_accumulate": (_c_int, [_vp, _vp, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),
     "ptb_debug_plan": (_c_int, [_i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _ip, _c_int]),

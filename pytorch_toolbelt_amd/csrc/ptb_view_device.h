@@ -61,6 +61,7 @@ struct ViewArgs {
     int chunks_x, chunks_y;  // plain modes: chunks per tile
     int ncells, total_chunks;
     int in_dtype;        // element type of src: PTB_F32 | PTB_F16 | PTB_BF16 (reduce / accumulate kernels)
+    int keep_acc;        // planned accumulate: a finalised cell ALSO stores its weighted sum in the accumulator (PTB_PLANNED_KEEP_SUMS)
 };
 
 enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };

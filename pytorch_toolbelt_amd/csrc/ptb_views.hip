@@ -119,6 +119,7 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
             const long long off = (long long)c * a.dst_chan_stride + (long long)(ay + r) * a.dst_row_stride + ax + 4 * q;
             out_store4(a.merged + off,
                        make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w)));
+            if (a.keep_acc) *reinterpret_cast<float4*>(ip) = acc;     // (self-planned mergers: `image` stays readable, exactly)
         } else {
             *reinterpret_cast<float4*>(ip) = acc;
             if (do_norm) *reinterpret_cast<float4*>(np) = nacc;
@@ -351,6 +352,7 @@ __global__ __launch_bounds__(256) void view_accum_scalar_kernel(const ViewArgs a
         }
         if (cell.final_) {
             a.merged[(long long)c * a.dst_chan_stride + off] = __fdiv_rn(acc, a.norm_full[off]);
+            if (a.keep_acc) a.dst[(long long)c * a.dst_chan_stride + off] = acc;
         } else {
             a.dst[(long long)c * a.dst_chan_stride + off] = acc;
             if (do_norm) a.norm[off] = nacc;
@@ -869,6 +871,18 @@ extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, floa
                                       int in_dtype, int V, const int* views, int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th,
                                       int tw, int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done,
                                       ptb_stream_t stream) {
+    return ptb_accumulate_planned2(image, norm_full, merged, weight, in, in_dtype, V, views, reduction, xs64, ys64, B, C, th, tw, H, W, fresh, fresh_rows,
+                                   remaining, done, 0, stream);
+}
+
+// flags bit 0 (PTB_PLANNED_KEEP_SUMS): a block that is finalised (merged = sum / norm written) ALSO stores its weighted sum in
+// `image`, so the accumulator stays complete and exact at any time (+ one store of the image per image): what a merger that planned
+// ITSELF from the previous image's crop sequence uses -- its caller never asked for a plan and may read `.image` whenever it likes.
+extern "C" int ptb_accumulate_planned2(float* image, const float* norm_full, float* merged, const float* weight, const void* in,
+                                       int in_dtype, int V, const int* views, int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th,
+                                       int tw, int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, int flags,
+                                       ptb_stream_t stream) {
+    if (flags & ~1) return PTB_EINVAL;
     if (!image || !norm_full || !merged || !weight || !in || !xs64 || !ys64 || !remaining || !done) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || fresh_rows < 1) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
@@ -884,6 +898,7 @@ extern "C" int ptb_accumulate_planned(float* image, const float* norm_full, floa
     ViewArgs a{};
     a.src = static_cast<const float*>(in); a.dst = image; a.norm = nullptr; a.weight = weight; a.merged = merged; a.norm_full = norm_full;
     a.in_dtype = in_dtype;
+    a.keep_acc = flags & 1;
     a.H = th; a.W = tw; a.C = C;
     a.src_view_stride = (long long)B * C * th * tw;
     a.src_tile_stride = (long long)C * th * tw;

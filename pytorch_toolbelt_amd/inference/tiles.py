@@ -295,37 +295,37 @@ def _resolve_device(device, what):
 # (at `merge()`), and the NEXT merger of the same geometry and window (or the same one after `reset()`) plans itself from it:
 # normaliser precomputed, every block divided in the launch that brings its last tile, no separate merge pass.  Any deviation
 # from the remembered sequence drops back to the ordinary path for the rest of that image (bit-identical results either way).
-_AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "1") != "0"
+# Opt-in since round 4 (PTB_AUTO_PLAN=1 / set_auto_plan(True)): with the lazy de-augmentation handle already fusing the two reference
+# calls into one launch, and self-planned mergers keeping their accumulators exact (one more store of the image), planning from the
+# previous image buys ~0.5 % over the ordinary fused path at the headline geometry -- not worth module-level caches by default.
+_AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "0") == "1"
 _AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser in HBM once planned)
 _auto = __import__("collections").OrderedDict()   # key -> _AutoEntry
-_weight_sigs = {}        # id(weight array) -> (weakref, signature)
 _auto_lock = __import__("threading").RLock()   # mergers of several threads (one inference loop each) share the cache
 
 
 def set_auto_plan(flag: bool) -> bool:
-    """Switch self-planning of ``TileMerger`` without ``crops=`` on / off (default on; ``PTB_AUTO_PLAN=0``); returns the previous setting."""
+    """Switch self-planning of ``TileMerger`` without ``crops=`` on / off (default off; ``PTB_AUTO_PLAN=1``); returns the previous setting."""
     global _AUTO_PLAN
     prev, _AUTO_PLAN = _AUTO_PLAN, bool(flag)
     return prev
 
 
 def _weight_signature(weight: np.ndarray):
-    """Content signature of a blending window, O(1) when the same array object comes back (``tiler.weight`` every image)."""
-    import hashlib
-    import weakref
-
-    probe = weight.reshape(-1)[::4099][:64].tobytes()
-    ent = _weight_sigs.get(id(weight))
-    if ent is not None and ent[0]() is weight and ent[2] == probe:
-        return ent[1]
-    sig = (weight.shape, weight.dtype.str, hashlib.blake2b(np.ascontiguousarray(weight).tobytes(), digest_size=12).digest())
+    """Content signature of a blending window: shape, dtype and a hash of ALL its bytes, computed on every call (a
+    cache keyed by the array's identity plus a sample of its values returned a stale signature -- and with it a stale device copy
+    of the window -- after an in-place edit at positions the sample missed).  xxh3-128 runs at ~10 GB/s: 0.2 ms for the 2 MB of a
+    512 x 512 float64 window; blake2b (~1.5 ms) when the xxhash module is missing."""
+    data = np.ascontiguousarray(weight)
     try:
-        if len(_weight_sigs) > 64:
-            _weight_sigs.clear()
-        _weight_sigs[id(weight)] = (weakref.ref(weight), sig, probe)
-    except TypeError:
-        pass
-    return sig
+        import xxhash
+
+        digest = xxhash.xxh3_128_digest(data)
+    except ImportError:
+        import hashlib
+
+        digest = hashlib.blake2b(data.tobytes(), digest_size=16).digest()
+    return (weight.shape, weight.dtype.str, digest)
 
 
 _device_windows = __import__("collections").OrderedDict()   # (device index, window signature) -> float32 [1, h, w] device tensor
@@ -336,14 +336,19 @@ def _device_window(weight: np.ndarray, device):
     the same window from pageable host memory every time -- a synchronous copy that also waits for the GPU to drain; uploaded
     windows are kept per device (a handful of MB) and every merger gets its own device-side copy of the cached one."""
     key = (device.index if device.index is not None else torch.cuda.current_device(),) + _weight_signature(weight)
-    cached = _device_windows.get(key)
-    if cached is None:
-        cached = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=torch.float32).contiguous()
-        while len(_device_windows) >= 16:
-            _device_windows.popitem(last=False)
-        _device_windows[key] = cached
-    else:
-        _device_windows.move_to_end(key)
+    with _auto_lock:
+        ent = _device_windows.get(key)
+        if ent is None:
+            cached = torch.from_numpy(np.expand_dims(weight, axis=0)).to(device=device, dtype=torch.float32).contiguous()
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(device))
+            while len(_device_windows) >= 16:
+                _device_windows.popitem(last=False)
+            ent = _device_windows[key] = (cached, ready)
+        else:
+            _device_windows.move_to_end(key)
+    cached, ready = ent
+    torch.cuda.current_stream(device).wait_event(ready)      # (the upload may have been issued on another thread's stream)
     return cached.clone()
 
 
@@ -557,11 +562,11 @@ class TileMerger:
         horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
         ``_Bands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024).
 
-        Without ``crops`` the merger plans itself (``auto_plan``, default on: ``set_auto_plan`` / ``PTB_AUTO_PLAN``): the crop
+        Without ``crops`` the merger can plan itself (``auto_plan``, opt-in: ``set_auto_plan(True)`` / ``PTB_AUTO_PLAN=1``): the crop
         sequence an image ended with at ``merge()`` is remembered per geometry + window, and the next merger of that geometry
         (or this one after ``reset()``) runs planned from it -- the reference's per-image ``TileMerger(shape, C, weight)``
         gets the planned kernels from the second image on.  A deviating batch, a read of ``image`` / ``norm_mask`` or
-        ``merge_()`` drop back to the ordinary path (see ``_unfinalise`` for the one case that is not bit-exact)."""
+        ``merge_()`` drop back to the ordinary path, bit-exactly (a self-planned merger keeps its accumulators complete: ``_unfinalise``)."""
         device = _resolve_device(device, "TileMerger")
         # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
         # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
@@ -736,8 +741,11 @@ class TileMerger:
                 ent.disabled = True
                 self._plan, self._auto_planned = None, False
                 return
-            ent.parts = (plan.xy, plan.remaining0, plan.norm_full, plan.crops4)
-        xy, remaining0, norm_full, crops4 = ent.parts
+            built = torch.cuda.Event()
+            built.record(torch.cuda.current_stream(plan.norm_full.device))
+            ent.parts = (plan.xy, plan.remaining0, plan.norm_full, plan.crops4, built)
+        xy, remaining0, norm_full, crops4, built = ent.parts
+        torch.cuda.current_stream(norm_full.device).wait_event(built)      # (the normaliser may have been built on another stream)
         plan = _Plan(xy, remaining0, norm_full)
         plan.crops4 = crops4
         self._plan, self._auto_planned = plan, True
@@ -778,19 +786,14 @@ class TileMerger:
             ent.log, ent.seen, ent.parts = log, 1, None
 
     def _unfinalise(self, what):
-        """Self-planned merger only: somebody needs the accumulators of blocks the planned kernels have already turned into
-        results (their sums were never stored).  They are rebuilt as ``result * normaliser`` -- the one place where a value
-        can differ from the reference's in the last bit (fl(fl(s / n) * n) vs s) -- the merger goes back to the ordinary path
-        and its geometry stops planning itself, so it happens once."""
+        """Self-planned merger only: somebody needs the accumulators of blocks the planned kernels have already turned into results.
+        A merger that planned ITSELF stores the weighted sum of a block next to its merged value (PTB_PLANNED_KEEP_SUMS: one more
+        store of the image per image), so the accumulators are complete and exact -- the same bits the unplanned kernels would have
+        left; the merger simply goes back to the ordinary path and its geometry stops planning itself."""
         plan = self._plan
         _warn_once(("unfinalise", self._auto_key), f"TileMerger: {what} after the self-planned kernels had finalised part of the image; the "
-                                                   "accumulators of those blocks are rebuilt as merged * norm_mask (last-bit differences possible, "
-                                                   "this once); mergers of this geometry use the ordinary accumulate + merge path from now on "
-                                                   "(TileMerger(..., auto_plan=False) avoids this).")
-        dev = self._image.device
-        done = torch.from_numpy(plan.done.astype(np.bool_)).to(dev)
-        mask = done.repeat_interleave(_FRESH_ROWS, 0).repeat_interleave(64, 1)[:self.image_height, :self.image_width]
-        torch.where(mask, self._merged * plan.norm_full, self._image, out=self._image)
+                                                   "accumulators are complete (self-planned mergers keep them), mergers of this geometry use the "
+                                                   "ordinary accumulate + merge path from now on (TileMerger(..., auto_plan=False) avoids the switch).")
         plan.done[:] = 0
         plan.active = False
         self._auto_opt_out()
@@ -966,11 +969,12 @@ class TileMerger:
                 if self._merged is None:
                     self._merged = torch.empty_like(self._image)
                 def launch_planned(fresh_ptr):
-                    return lib.ptb_accumulate_planned(
+                    # (a self-planned merger keeps the weighted sums of finalised blocks as well: PTB_PLANNED_KEEP_SUMS)
+                    return lib.ptb_accumulate_planned2(
                         self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
                         batch.data_ptr(), dcode, n_views, varr, reduction, xs, ys, B, self.channels, th, tw,
                         self.image_height, self.image_width, fresh_ptr, _FRESH_ROWS,
-                        plan.remaining.ctypes.data, plan.done.ctypes.data, N.stream_ptr(dev))
+                        plan.remaining.ctypes.data, plan.done.ctypes.data, 1 if self._auto_planned else 0, N.stream_ptr(dev))
 
                 with N.on_device(dev):
                     rc = launch_planned(self._fresh.ctypes.data if self._fresh.any() else None)
@@ -1115,11 +1119,13 @@ class TileMerger:
         dev = self._image.device
         fresh = self._fresh
 
+        keep = 1 if self._auto_planned else 0      # (a self-planned merger keeps the sums of finalised blocks: `.image` stays exact)
+
         def launch(fresh_ptr):
-            return lib.ptb_accumulate_planned(self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
-                                              batch.data_ptr(), dcode, n_views, varr, code, xs, ys, B, self.channels, th, tw, self.image_height,
-                                              self.image_width, fresh_ptr, _FRESH_ROWS, plan.remaining.ctypes.data, plan.done.ctypes.data,
-                                              N.stream_ptr(dev))
+            return lib.ptb_accumulate_planned2(self._image.data_ptr(), plan.norm_full.data_ptr(), self._merged.data_ptr(), self.weight.data_ptr(),
+                                               batch.data_ptr(), dcode, n_views, varr, code, xs, ys, B, self.channels, th, tw, self.image_height,
+                                               self.image_width, fresh_ptr, _FRESH_ROWS, plan.remaining.ctypes.data, plan.done.ctypes.data,
+                                               keep, N.stream_ptr(dev))
 
         with N.on_device(dev):
             rc = launch(fresh.ctypes.data if fresh.any() else None)

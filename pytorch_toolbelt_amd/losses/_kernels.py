@@ -89,14 +89,19 @@ _workspaces = {}         # (device index, stream) -> zeroed uint8 workspace of p
 
 def host_flag_slot():
     """One int32 of pinned host memory (a ring of 256) for a kernel to write its label flag into -- no device-to-host copy on the
-    stream; the slot is valid once the event recorded after the launch has completed."""
+    stream; the slot is valid once the event recorded after the launch has completed.  Slots are handed out under the lock that
+    guards the pending list (two threads must never get the same one), and a slot is not reused while a pending check still reads
+    it: when half the ring is in flight the backlog is drained first."""
     global _flag_ring, _flag_next
-    if _flag_ring is None:
-        _flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
-    if len(_pending) >= 192:      # a slot must not come round again before its check has been read: drain the backlog first
+    with _pending_lock:
+        if _flag_ring is None:
+            _flag_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+        backlog = len(_pending)
+    if backlog >= 128:      # a slot must not come round again before its check has been read
         _poll(block=True)
-    _flag_next = (_flag_next + 1) % 256
-    return _flag_ring[_flag_next:_flag_next + 1]
+    with _pending_lock:
+        _flag_next = (_flag_next + 1) % 256
+        return _flag_ring[_flag_next:_flag_next + 1]
 
 
 def watch_host_flag(slot, device):

@@ -372,8 +372,9 @@ def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
 
 
 def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan):
-    """Reading ``image`` after the planned kernels finalised blocks: rebuilt (within an ulp), warned about once, and the
-    geometry stays on the exact path afterwards."""
+    """Reading ``image`` after the self-planned kernels finalised blocks: the accumulators are COMPLETE and EXACT (a self-planned
+    merger stores the weighted sum of a block next to its merged value, PTB_PLANNED_KEEP_SUMS) -- array_equal with the unplanned
+    path, the reference's sequential sums; said once, and the geometry stays on the ordinary path afterwards."""
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((256, 256), 128, 64)
     crops, C, batch = geom["crops"], 2, 3
@@ -388,10 +389,10 @@ def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan):
     assert m.mode == "planned"
     got = _run_image(m, outputs, crops, batch)
     assert torch.equal(got, exact)
-    with pytest.warns(RuntimeWarning, match="rebuilt"):
+    with pytest.warns(RuntimeWarning, match="accumulators are complete"):
         img = m.image
-    assert torch.allclose(img, exact_image, rtol=2.4e-7, atol=0) and torch.equal(m.norm_mask, exact_norm)
-    assert torch.allclose(m.merge(), exact, rtol=4e-7, atol=0)
+    assert torch.equal(img, exact_image) and torch.equal(m.norm_mask, exact_norm)
+    assert torch.equal(m.merge(), exact)
     m2 = TileMerger(geom["target_shape"], C, w, device=dev)
     assert m2.mode == "incremental"                      # this geometry's user reads accumulators: exact path from now on
     assert torch.equal(_run_image(m2, outputs, crops, batch), exact) and torch.equal(m2.image, exact_image)
@@ -410,12 +411,12 @@ def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan):
     m = TileMerger(geom["target_shape"], C, w, device=dev)
     assert m.mode == "planned"
     m.integrate_batch(outputs, crops)
-    with pytest.warns(RuntimeWarning, match="rebuilt"):
+    with pytest.warns(RuntimeWarning, match="accumulators are complete"):
         m.integrate_batch(outputs[:1], crops[4:5])       # one more tile over pixels that were already merged
     st = TO.merger_new(geom["target_shape"], C, w)
     TO.merger_integrate(st, outputs.cpu().numpy(), crops)
     TO.merger_integrate(st, outputs[:1].cpu().numpy(), crops[4:5])
-    assert np.abs(m.merge().cpu().numpy() - TO.merger_merge(st)).max() <= 1e-5
+    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))        # exact: the same sums in the same order
 
 
 # ------------------------------------------------------------------------------------------------ deferred merger: the contract
