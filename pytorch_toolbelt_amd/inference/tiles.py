@@ -139,10 +139,10 @@ class ImageSlicer:
         """Pad the whole image by the margins once, return the N tiles as views of the padded copy.
 
         ``border_type`` takes OpenCV's codes like the reference (which forwards them to ``cv2.copyMakeBorder``,
-        inference/tiles.py:161-182).  Only ``BORDER_CONSTANT`` (0, the default) is pinned against the reference's outputs; the
-        other codes are mapped to the numpy padding mode with OpenCV's documented semantics (1 replicate -> "edge", 2 reflect ->
-        "symmetric", 3 wrap, 4 reflect_101 -> "reflect") and are NOT parity-tested: OpenCV is not available where the goldens are
-        generated."""
+        inference/tiles.py:161-182).  ``BORDER_CONSTANT`` (0, the default) is pinned against the reference's outputs; the other
+        codes are mapped to the numpy padding mode with the same extension rule (1 replicate -> "edge", 2 reflect -> "symmetric",
+        3 wrap, 4 reflect_101 -> "reflect") and pinned to the tables of OpenCV's documentation (``aaaaaa|abcdefgh|hhhhhhh`` ...:
+        tests/test_slicer_cpu.py) -- OpenCV itself is not available where the goldens are generated."""
         assert image.shape[0] == self.image_height
         assert image.shape[1] == self.image_width
         padded = _pad2d(image, self.margin_top, self.margin_bottom, self.margin_left, self.margin_right, border_type, value)
@@ -547,8 +547,12 @@ class TileMerger:
     def __new__(cls, image_shape=None, channels=None, weight=None, device="cpu", *args, **kwargs):
         # the device the caller names decides the implementation: "cpu" (the reference's default) -> accumulators on the host,
         # torch ops (HostBackedTileMerger below); "cuda" -> HBM + HIP kernels (this class).  Never the other way round.
-        if cls is TileMerger and torch.device(device).type != "cuda":
-            return object.__new__(HostBackedTileMerger)
+        if cls is TileMerger:
+            dtype = kwargs.get("dtype", args[0] if args else torch.float32)
+            # float64 accumulators (reference tiles.py:306-308 accumulates in the caller's dtype): the HIP kernels sum in float32, so a
+            # float64 merger -- on any device -- is the torch-op one, whose sums ARE float64 (said once for CUDA devices).
+            if torch.device(device).type != "cuda" or dtype == torch.float64:
+                return object.__new__(HostBackedTileMerger)
         return object.__new__(cls)
 
     def __init__(self, image_shape, channels, weight, device="cpu", dtype=torch.float32, crops=None, defer=False, defer_rows=None,
@@ -571,7 +575,7 @@ class TileMerger:
         # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
         # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
         # of that dtype are read as they are, and merge() / image / norm_mask hand out tensors of that dtype.  For float16 / bfloat16
-        # that is a strictly more accurate sum than the reference's, for float64 a less accurate one (about 1e-7 relative).
+        # that is a strictly more accurate sum than the reference's.  (float64 never gets here: __new__ hands it to the torch-op merger.)
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
         self.dtype = dtype
@@ -1290,7 +1294,7 @@ class TileMerger:
 
 
 class HostBackedTileMerger(TileMerger):
-    """``TileMerger(device="cpu")``: the reference's host merger (inference/tiles.py:290-350) -- ``image`` / ``norm_mask`` /
+    """``TileMerger(device="cpu")`` (and ``dtype=torch.float64`` on any device): the reference's torch-op merger (inference/tiles.py:290-350) -- ``image`` / ``norm_mask`` /
     ``weight`` are public tensors of the caller's ``dtype`` on the CPU, accumulated in that dtype (fp64 accumulators accumulate in
     fp64), ``integrate_batch`` moves / casts what it is given and blends tile by tile in batch order.  The arithmetic lives in
     ``inference/_host.py``; the extensions of the HIP merger are accepted so that code written for either runs on both:
@@ -1303,7 +1307,10 @@ class HostBackedTileMerger(TileMerger):
 
         device = torch.device(device)
         if device.type == "cuda":
-            raise RuntimeError("HostBackedTileMerger lives on the host; TileMerger(device='cuda') is the HIP merger")
+            if dtype != torch.float64:
+                raise RuntimeError("the torch-op merger serves CUDA devices for float64 accumulators only; TileMerger(device='cuda') is the HIP merger")
+            _warn_once(("fp64-cuda",), "TileMerger(device='cuda', dtype=torch.float64): the HIP kernels accumulate in float32; float64 accumulators "
+                                       "are kept with torch ops on the device (exact float64 sums like the reference's, not the fused kernels).")
         self.dtype = dtype
         self._host = HostTileMerger(image_shape, channels, weight, device, dtype)
         self.image_height, self.image_width, self.channels = self._host.image_height, self._host.image_width, channels

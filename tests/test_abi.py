@@ -28,6 +28,28 @@ def test_build_and_symbols():
     assert lib.ptb_version() >= 100
 
 
+def test_forced_rebuild_of_every_translation_unit(tmp_path):
+    """build(force=True): every .hip translation unit is really recompiled for gfx950 and linked (the content-hashed
+    build() otherwise reuses the shipped library, so a compile error would go unnoticed) -- into a scratch directory, so the library
+    this process has loaded is not overwritten.  The fresh library exports every symbol of include/ptb_hip.h."""
+    import ctypes
+    import glob
+
+    import __graft_entry__ as g
+
+    out = str(tmp_path / "lib")
+    g.build(force=True, out_dir=out)
+    objs = glob.glob(os.path.join(out, "obj", "*.o"))
+    assert len(objs) == len(g._sources()) >= 12
+    fresh = ctypes.CDLL(os.path.join(out, "libptb_hip.so"))
+    for n in _header_symbols():
+        assert hasattr(fresh, n), f"{n} missing from the freshly built library"
+    fresh.ptb_version.restype = ctypes.c_int
+    assert fresh.ptb_version() >= 100
+    shipped = os.path.getsize(g.LIB)
+    assert abs(os.path.getsize(os.path.join(out, "libptb_hip.so")) - shipped) <= 0.02 * shipped, "the shipped library is not what the sources build"
+
+
 def test_argument_validation_without_gpu():
     """Entry points validate arguments before touching the device, so these calls are safe without a GPU."""
     from pytorch_toolbelt_amd import _native as N
