@@ -56,3 +56,17 @@ def golden_tta():
 @pytest.fixture(scope="session")
 def golden_losses():
     return load_golden("losses.npz")
+
+
+@pytest.fixture(scope="session")
+def forced_build(tmp_path_factory):
+    """ONE forced rebuild of every HIP translation unit per test session (into a scratch directory: the library the process has loaded
+    is not touched), with the compiler's kernel-resource remarks kept -- shared by tests/test_abi.py (does everything still compile,
+    link and export the header's symbols?) and tests/test_kernel_resources.py (register / scratch / occupancy budgets)."""
+    import __graft_entry__ as g
+
+    out = tmp_path_factory.mktemp("forced_build")
+    remarks = out / "remarks"
+    remarks.mkdir()
+    g.build(force=True, out_dir=str(out / "lib"), remarks_dir=str(remarks))
+    return {"lib_dir": str(out / "lib"), "remarks_dir": str(remarks)}

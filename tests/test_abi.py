@@ -28,7 +28,7 @@ def test_build_and_symbols():
     assert lib.ptb_version() >= 100
 
 
-def test_forced_rebuild_of_every_translation_unit(tmp_path):
+def test_forced_rebuild_of_every_translation_unit(forced_build):
     """build(force=True): every .hip translation unit is really recompiled for gfx950 and linked (the content-hashed
     build() otherwise reuses the shipped library, so a compile error would go unnoticed) -- into a scratch directory, so the library
     this process has loaded is not overwritten.  The fresh library exports every symbol of include/ptb_hip.h."""
@@ -37,8 +37,7 @@ def test_forced_rebuild_of_every_translation_unit(tmp_path):
 
     import __graft_entry__ as g
 
-    out = str(tmp_path / "lib")
-    g.build(force=True, out_dir=out)
+    out = forced_build["lib_dir"]
     objs = glob.glob(os.path.join(out, "obj", "*.o"))
     assert len(objs) == len(g._sources()) >= 12
     fresh = ctypes.CDLL(os.path.join(out, "libptb_hip.so"))

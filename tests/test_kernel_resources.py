@@ -3,7 +3,7 @@
 The kernels of the benchmarked paths sit right at occupancy cliffs: the fused multiscale kernel at 80 VGPRs (6 waves per SIMD; a
 two-register drift once cost its gmean instance 7 %), the band-plan kernel must not touch scratch memory (run-time indexing of a
 by-value struct once put 52 B per lane there: 2.58 instead of 2.19 ms per image), the straight-line loss kernels must not spill.
-This test recompiles the three translation units with -Rpass-analysis=kernel-resource-usage and checks those budgets."""
+The budgets are read from the -Rpass-analysis=kernel-resource-usage remarks of the session's forced rebuild (tests/conftest.py)."""
 import re
 import subprocess
 from concurrent.futures import ThreadPoolExecutor
@@ -16,12 +16,10 @@ import __graft_entry__ as entry
 CSRC = Path(entry.CSRC)
 
 
-def _report(src):
-    cmd = [entry.HIPCC] + [f for f in entry.FLAGS if f != "-shared"] + ["-c", str(CSRC / src), "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
+def _report(path):
+    """Per-kernel resource usage parsed from the compiler's -Rpass-analysis=kernel-resource-usage remarks of one translation unit."""
     kernels, cur = {}, None
-    for line in out.stderr.splitlines():
+    for line in open(path).read().splitlines():
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             cur = kernels.setdefault(m.group(1), {})
@@ -33,10 +31,9 @@ def _report(src):
 
 
 @pytest.fixture(scope="module")
-def reports():
-    with ThreadPoolExecutor(3) as pool:
-        r = list(pool.map(_report, ["ptb_resample.hip", "ptb_bandplan.hip", "ptb_losses.hip"]))
-    return dict(resample=r[0], bandplan=r[1], losses=r[2])
+def reports(forced_build):
+    d = Path(forced_build["remarks_dir"])      # (the session's one forced rebuild of every translation unit: tests/conftest.py)
+    return dict(resample=_report(d / "ptb_resample.hip.txt"), bandplan=_report(d / "ptb_bandplan.hip.txt"), losses=_report(d / "ptb_losses.hip.txt"))
 
 
 def _find(kernels, *needles):
