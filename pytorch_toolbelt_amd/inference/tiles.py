@@ -273,16 +273,11 @@ def _warn_once(key, message):
 
 
 def _resolve_device(device, what):
-    """The device of a HIP-backed merger: a CUDA device, or an error.  (``TileMerger(device="cpu")`` never gets here: it is the
-    host merger of ``inference/_host.py``, like the reference's.)  ``VolumeMerger`` has no host implementation: its reference
-    default ``device="cpu"`` is redirected to the current GPU with a one-time warning."""
+    """The device of a HIP-backed merger: a CUDA device, or an error.  (``TileMerger(device="cpu")`` / ``VolumeMerger(device="cpu")``
+    never get here: they are the torch-op mergers, like the reference's.)"""
     device = torch.device(device)
     if device.type == "cuda":
         return device
-    if device.type == "cpu" and what == "VolumeMerger" and torch.cuda.is_available():
-        _warn_once(("cpu", what), f"{what}(device='cpu'): pytorch_toolbelt_amd keeps the accumulators in MI355X HBM and has no CPU path; "
-                                  f"using device='cuda:{torch.cuda.current_device()}' instead (pass device='cuda' to silence this).")
-        return torch.device("cuda", torch.cuda.current_device())
     raise RuntimeError(
         f"{what}(device='{device}'): this merger keeps its accumulators in MI355X HBM and has no CPU "
         "path; construct it with device='cuda' on a machine with a GPU."

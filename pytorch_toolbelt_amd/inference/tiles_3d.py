@@ -128,10 +128,19 @@ class VolumeMerger:
     ``volume`` ``[C, D, H, W]``, ``norm_mask`` ``[1, D, H, W]`` and ``weight`` ``[1, d, h, w]`` are public fp32 tensors
     on the GPU.  ``integrate_batch`` adds ``tile * weight`` tile after tile (bit-identical to the reference's loop)."""
 
+    def __new__(cls, volume_shape=None, channels=None, weight=None, device="cpu", *args, **kwargs):
+        # like TileMerger: the device the caller names decides -- "cpu" (the reference's default) and float64 accumulators are the
+        # torch-op merger, "cuda" the HIP one
+        if cls is VolumeMerger:
+            dtype = kwargs.get("dtype", args[0] if args else torch.float32)
+            if torch.device(device).type != "cuda" or dtype == torch.float64:
+                return object.__new__(HostBackedVolumeMerger)
+        return object.__new__(cls)
+
     def __init__(self, volume_shape, channels: int, weight, device="cpu", dtype=torch.float32):
         from .tiles import _resolve_device
 
-        device = _resolve_device(device, "VolumeMerger")   # the reference's default "cpu" -> current CUDA device, warned once
+        device = _resolve_device(device, "VolumeMerger")
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"VolumeMerger: dtype must be a floating point type, got {dtype}")
         self.dtype = dtype          # honoured by merge(); the accumulators themselves are float32 (see TileMerger)
@@ -184,3 +193,42 @@ class VolumeMerger:
         N.bump()
         N.check(rc, "VolumeMerger.merge")
         return out if self.dtype == torch.float32 else out.to(self.dtype)
+
+
+class HostBackedVolumeMerger(VolumeMerger):
+    """``VolumeMerger(device="cpu")`` (and ``dtype=torch.float64`` on any device): the reference's torch-op merger
+    (inference/tiles_3d.py:169-211) -- ``volume`` / ``norm_mask`` / ``weight`` in the caller's dtype, tiles blended one after the
+    other (``volume[:, roi] += tile * weight``), ``merge()`` without an eps clamp."""
+
+    def __init__(self, volume_shape, channels: int, weight, device="cpu", dtype=torch.float32):
+        self.dtype = dtype
+        self.channels = channels
+        shape = tuple(int(s) for s in volume_shape)
+        self.weight = torch.from_numpy(np.expand_dims(np.asarray(weight), axis=0)).to(device=device, dtype=dtype)
+        self.volume = torch.zeros((channels, *shape), device=device, dtype=dtype)
+        self.norm_mask = torch.zeros((1, *shape), device=device, dtype=dtype)
+
+    def _blend(self, tiles, rois):
+        d, h, w = (int(s) for s in self.weight.shape[1:])
+        if tuple(tiles.shape[1:]) != (self.channels, d, h, w):
+            raise RuntimeError(f"tile batch of shape {tuple(tiles.shape)} does not match [B, {self.channels}, {d}, {h}, {w}]")
+        starts = _roi_starts(rois, (d, h, w))          # (validates the ROIs like the HIP merger: 3 slices of the window's extent)
+        D, H, W = (int(s) for s in self.volume.shape[1:])
+        for tile, z, y, x in zip(tiles, starts[0], starts[1], starts[2]):
+            z, y, x = int(z), int(y), int(x)
+            if z < 0 or y < 0 or x < 0 or z + d > D or y + h > H or x + w > W:
+                raise RuntimeError("VolumeMerger.integrate_batch: tile rectangle outside the accumulator")
+            roi = (slice(None), slice(z, z + d), slice(y, y + h), slice(x, x + w))
+            self.volume[roi] += tile * self.weight
+            self.norm_mask[roi] += self.weight
+
+    def accumulate_single(self, tile: torch.Tensor, roi):
+        self._blend(tile.to(device=self.volume.device, dtype=self.volume.dtype).unsqueeze(0), [roi])
+
+    def integrate_batch(self, batch: torch.Tensor, rois):
+        if len(batch) != len(rois):
+            raise ValueError("Number of images in batch does not correspond to number of coordinates")
+        self._blend(batch.to(device=self.volume.device, dtype=self.volume.dtype), rois)
+
+    def merge(self) -> torch.Tensor:
+        return self.volume / self.norm_mask

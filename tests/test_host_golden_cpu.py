@@ -299,3 +299,25 @@ def test_host_fused_loss_equals_its_parts():
     fused = L.FocalDiceJaccardLoss("multiclass")(x, y)
     parts = L.BinaryFocalLoss()(x, y) + L.DiceLoss("multiclass")(x, y) + L.JaccardLoss("multiclass")(x, y)
     assert abs(float(fused) - float(parts)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ 3-D tiles
+GV = load_golden("volumes.npz")
+
+
+@pytest.mark.parametrize("case", GV.by_fn("vmerger"), ids=lambda c: c["name"])
+def test_host_volume_merger_bit_exact(case):
+    from pytorch_toolbelt_amd.inference.tiles_3d import HostBackedVolumeMerger, VolumeMerger, VolumeSlicer
+
+    kw, n = case["kwargs"], case["name"]
+    s = VolumeSlicer(kw["volume_shape"], kw["voxel_size"], kw["voxel_step"])
+    m = VolumeMerger(s.target_shape, kw["channels"], GV[f"{n}_weight"])          # the reference's default device="cpu"
+    assert type(m) is HostBackedVolumeMerger and isinstance(m, VolumeMerger)
+    pred = _t(GV[f"{n}_pred"])
+    for b0 in range(0, len(pred), kw["batch"]):
+        m.integrate_batch(pred[b0:b0 + kw["batch"]], s.crops[b0:b0 + kw["batch"]])
+    assert np.array_equal(m.volume.numpy(), GV[f"{n}_volume"])
+    assert np.array_equal(m.norm_mask.numpy(), GV[f"{n}_norm"])
+    assert np.array_equal(m.merge().numpy(), GV[f"{n}_merged"])
+    with pytest.raises(ValueError):
+        m.integrate_batch(pred[:1], list(s.crops[:1]) * 2)
