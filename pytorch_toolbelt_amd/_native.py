@@ -1,7 +1,9 @@
 """ctypes binding of libptb_hip.so (the C ABI declared in include/ptb_hip.h).
 
-There is deliberately NO fallback: if the shared library is missing or a tensor is not on the MI355X,
-the call fails loudly.  PyTorch is used only for device memory, the current HIP stream and autograd glue.
+There is deliberately NO fallback behind this binding: if the shared library is missing, or a tensor that reaches an entry point
+is not on the MI355X, the call fails loudly.  (Host tensors never reach it: the public functions route them -- by their device, and
+by nothing else -- to the separate torch-op modules ``inference/_host.py`` / ``losses/_host.py``, like the device-agnostic
+reference.)  PyTorch is used only for device memory, the current HIP stream and autograd glue.
 """
 import ctypes
 import os
@@ -162,7 +164,8 @@ def check(rc, what):
 
 
 def require_device(t, what):
-    """The native path runs on the GPU only; CPU tensors are refused instead of silently computed elsewhere."""
+    """The native path runs on the GPU only; a CPU tensor that gets this far (entry points without a host form: split_device, the
+    sharded mergers' deferred plan, the strip kernels) is refused instead of silently computed elsewhere."""
     if not t.is_cuda:
         raise RuntimeError(
             f"{what}: tensor is on '{t.device}', but pytorch_toolbelt_amd runs its hot path as HIP kernels on the "

@@ -1,7 +1,8 @@
 """Autograd-aware Python front of the view kernels (ptb_view_transform / ptb_deaug_reduce).
 
-A *view code* is 3 bits (transpose, flip source rows, flip source cols) -- see include/ptb_hip.h.  Everything here
-launches hand-written HIP kernels on the current stream; tensors must be float32 and live on the GPU.
+A *view code* is 3 bits (transpose, flip source rows, flip source cols) -- see include/ptb_hip.h.  CUDA tensors launch the
+hand-written HIP kernels on the current stream (evaluated in float32); host tensors are handed to ``_host`` at the three public
+entry points (``view_transform``, ``deaug_reduce``, ``stack_reduce``) and never touch the binding.
 """
 from typing import Sequence
 
