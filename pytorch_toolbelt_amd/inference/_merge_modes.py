@@ -1,0 +1,671 @@
+"""The execution strategies of the HIP ``TileMerger`` (inference/tiles.py), one class each.
+
+``TileMerger`` owns what every strategy shares -- the accumulators in HBM, their first-touch bitmap, the crop log the lazy
+normaliser is built from, the reference's public API (reference inference/tiles.py:290-350) -- and asks its strategies, in this
+order, whether they take a batch:
+
+    DeferredBands   ``TileMerger(crops=, defer=True)``: holds the model outputs and merges a band of rows in ONE launch when its last
+                    tile is in; no accumulator traffic at all (csrc/ptb_bandplan.hip)
+    PlannedBlocks   ``TileMerger(crops=)`` (or a self-planned merger): accumulates, and divides every 64 x 32 block by the
+                    precomputed normaliser in the launch that brings its last tile -- ``merge()`` has nothing left to do
+    Incremental     the reference's semantics literally: accumulate now, divide in ``merge()``
+
+A strategy that cannot take a batch (a deviation from the planned crop sequence, a caller that reads ``norm_mask``, a geometry
+off the kernels' grid) says so and the next one does, bit-identically; ``SelfPlanning`` is the (opt-in) policy that gives a merger
+constructed WITHOUT ``crops=`` a plan from the crop sequence of the previous image.  ``HeldBatches`` -- the custody contract of
+model outputs that are read by a later launch -- is shared with ``parallel.ShardedTileMerger``'s deferred bands.
+"""
+import collections
+import ctypes
+import threading
+import warnings
+
+import numpy as np
+import torch
+
+from .. import _native as N
+
+FRESH_ROWS = 32  # rows of a first-touch block = default chunk rows of the view kernels (64 columns wide)
+
+_warned = set()
+
+
+def warn_once(key, message):
+    if key not in _warned:
+        _warned.add(key)
+        warnings.warn(message, RuntimeWarning, stacklevel=3)
+
+
+def coords_xy(crop_coords):
+    """crop_coords: ndarray [B,4], list of 4-sequences, or the CPU int64 tensor default_collate builds."""
+    if torch.is_tensor(crop_coords):
+        arr = crop_coords.detach().cpu().numpy()
+    else:
+        arr = np.asarray([[int(v) for v in c] for c in crop_coords] if not isinstance(crop_coords, np.ndarray) else crop_coords)
+    return np.ascontiguousarray(arr, dtype=np.int64).reshape(-1, 4)
+
+
+# ------------------------------------------------------------------------------------------------ custody of held model outputs
+def tensor_version(t):
+    try:
+        return t._version
+    except RuntimeError:      # inference tensors carry no version counter: in-place edits of them cannot be seen
+        return None
+
+
+def held_entry(batch):
+    """(first byte, one past the last byte, version counter) of a batch a deferred merger is about to keep a reference to."""
+    p0 = batch.data_ptr()
+    return p0, p0 + batch.numel() * batch.element_size(), tensor_version(batch)
+
+
+def check_held(held, batch, span, launches, what):
+    """The contract of deferred merging, enforced: a held batch is read by a LATER launch, so (1) a new batch must not live in
+    the memory of one that is still held -- a model writing into a static output buffer (HIP graphs, ``out=``, preallocated
+    outputs) has then already overwritten data the merger has not read, which no fallback can bring back -- and (2) a held batch
+    must not have been modified in place since it was handed in (checked when its launch is due).  ``held`` rows start with the
+    tensor and end with (p0, p1, version); ``span`` = ``held_entry(batch)``."""
+    p0, p1, _v = span
+    for h in held:
+        if h[-3] < p1 and p0 < h[-2]:
+            raise RuntimeError(f"{what}: this batch occupies memory of an earlier batch that is still held for a later launch (bytes "
+                               f"{max(p0, h[-3]):#x}..{min(p1, h[-2]):#x}) -- the model writes its outputs into a reused buffer, so the earlier "
+                               "predictions are already gone.  Deferred merging needs every batch to stay alive and unmodified until its rows "
+                               "are merged: hand over fresh tensors (or clones), or construct the merger without defer=True.")
+    if launches:
+        for i, h in enumerate(held):
+            if h[-1] is not None and tensor_version(h[0]) != h[-1]:
+                raise RuntimeError(f"{what}: held batch {i} of the rows about to be merged was modified in place after it was handed to the "
+                                   "merger (its version counter moved).  Deferred merging reads the batches later: keep them unmodified, "
+                                   "or construct the merger without defer=True.")
+
+
+class HeldBatches:
+    """The model outputs a deferred merger has taken into custody, in integration order: rows ``(tensor, replay, last launch group
+    that reads it, p0, p1, version)``.  One object per merger / per rank band; ``admit`` is the contract check above."""
+
+    __slots__ = ("rows", "what")
+
+    def __init__(self, what):
+        self.rows, self.what = [], what
+
+    def admit(self, batch, launch_due):
+        """Check a batch against everything still held; returns its span for ``keep``."""
+        span = held_entry(batch)
+        check_held(self.rows, batch, span, launch_due, self.what)
+        return span
+
+    def keep(self, batch, span, replay=None, last_group=0):
+        self.rows.append((batch, replay, last_group) + span)
+
+    def release_before(self, groups_done):
+        """Launch groups 0 .. groups_done-1 are out (and complete in index order): let go of what no later group reads."""
+        rows = self.rows
+        while rows and rows[0][2] < groups_done:
+            rows.pop(0)
+
+    def take_all(self):
+        rows, self.rows = self.rows, []
+        return rows
+
+    def clear(self):
+        self.rows = []
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __iter__(self):
+        return iter(self.rows)
+
+
+# ------------------------------------------------------------------------------------------------ plans
+class Plan:
+    """State of a *planned* TileMerger (constructed with the complete ``crops`` of the image).
+
+    ``remaining[b]`` = planned tiles that have not touched accumulator block ``b`` (64 columns x 32 rows) yet,
+    ``done[b]`` = the block has been written to the merge result.  Finalisation is only performed while the integrate
+    calls follow the planned sequence exactly (then every partial sum, including the normaliser's, has the reference's
+    order of additions); the first deviating batch switches it off for the rest of the image and everything not yet
+    finalised goes through the ordinary accumulate + merge.  Restrictions while planned blocks are finalised: a tile
+    that touches a finished block raises, ``merger.image`` is not readable (the accumulators of finished blocks are
+    never stored) and ``merge_()`` is unavailable."""
+
+    def __init__(self, xy, remaining0, norm_full):
+        self.xy = xy                    # [2, N] int64 origins in integration order
+        self.remaining0 = remaining0
+        self.norm_full = norm_full      # [1, H, W] complete normaliser (device)
+        self.remaining = remaining0.copy()
+        self.done = np.zeros_like(remaining0)
+        self.pos = 0
+        self.active = True
+        self.crops4 = None              # the planned (x, y, w, h) rows (what callers' crop arrays are compared with)
+
+    @staticmethod
+    def build(merger, crops):
+        crops = coords_xy(crops)
+        th, tw = int(merger.weight.shape[1]), int(merger.weight.shape[2])
+        H, W = merger.image_height, merger.image_width
+        if len(crops) == 0 or np.any(crops[:, 2] != tw) or np.any(crops[:, 3] != th):
+            return None
+        aligned = (tw % 64 == 0 and th % FRESH_ROWS == 0 and not np.any(crops[:, 0] % 64) and not np.any(crops[:, 1] % FRESH_ROWS)
+                   and np.all(crops[:, 0] >= 0) and np.all(crops[:, 1] >= 0) and np.all(crops[:, 0] + tw <= W) and np.all(crops[:, 1] + th <= H))
+        if not aligned:
+            return None   # geometry off the block grid: the ordinary path is used
+        remaining = np.zeros(((H + FRESH_ROWS - 1) // FRESH_ROWS, (W + 63) // 64), dtype=np.int32)
+        for x, y in crops[:, :2]:
+            remaining[y // FRESH_ROWS:(y + th) // FRESH_ROWS, x // 64:(x + tw) // 64] += 1
+        if remaining.max() > 255:
+            return None
+        xy = np.ascontiguousarray(crops[:, :2].T)
+        norm_full = torch.zeros((1, H, W), device=merger.weight.device, dtype=torch.float32)
+        lib = N.load()
+        dev = norm_full.device
+        with N.on_device(dev):
+            rc = lib.ptb_norm_accumulate(norm_full.data_ptr(), merger.weight.data_ptr(), xy[0].ctypes.data_as(N._i64p),
+                                         xy[1].ctypes.data_as(N._i64p), xy.shape[1], th, tw, H, W, None, 0, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger(crops=...)")
+        plan = Plan(xy, remaining.astype(np.uint8), norm_full)
+        plan.crops4 = np.ascontiguousarray(crops, dtype=np.int64)
+        return plan
+
+    def restart(self):
+        self.remaining = self.remaining0.copy()
+        self.done[:] = 0
+        self.pos = 0
+        self.active = True
+
+    def follows(self, xy, B):
+        """Are these ``B`` origins ([2, B] int64, C order) exactly the next planned ones?"""
+        pos = self.pos
+        return (pos + B <= self.xy.shape[1] and xy[0].data == self.xy[0, pos:pos + B].data and xy[1].data == self.xy[1, pos:pos + B].data)
+
+    def touches_done(self, xy, th, tw):
+        for x, y in xy.T:
+            if self.done[y // FRESH_ROWS:(y + th + FRESH_ROWS - 1) // FRESH_ROWS, x // 64:(x + tw + 63) // 64].any():
+                return True
+        return False
+
+
+class Bands:
+    """The C-side band plan of a deferred merger (``ptb_band_plan_*``, csrc/ptb_bandplan.hip), planned once.
+
+    A *band* is the rows between two consecutive tile edges; every tile that touches a band covers all of its rows.  Consecutive
+    bands form a *launch group* of about ``rows`` rows (default 1024; ``defer_rows=`` / ``PTB_DEFER_ROWS``)."""
+
+    def __init__(self, handle, table, bands, n_bands, last_group, monotone):
+        self.handle = handle            # ptb_band_plan*
+        self.table = table              # uint8 device tensor holding the work-item table (owned here)
+        self.bands = bands              # [(y0, y1, last tile)] per launch group, top to bottom
+        self.n_bands = n_bands
+        self.last_group = last_group    # plan index of a tile -> the last launch group that reads it
+        self.monotone = monotone        # groups complete in index order (row-major crops): batches can be released early
+
+    def __del__(self):
+        try:
+            if self.handle:
+                N.load().ptb_band_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    @staticmethod
+    def build(plan, channels, th, tw, H, W, device, rows):
+        lib = N.load()
+        handle = ctypes.c_void_p()
+        n = plan.xy.shape[1]
+        nbytes = lib.ptb_band_plan_create(plan.xy[0].ctypes.data_as(N._i64p), plan.xy[1].ctypes.data_as(N._i64p), n, channels, th, tw, H, W,
+                                          int(rows), 0, H, None, 0, ctypes.byref(handle))
+        if nbytes < 0:
+            return None
+        table = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+        with N.on_device(device):
+            rc = lib.ptb_band_plan_upload(handle, table.data_ptr(), N.stream_ptr(device))
+        N.bump()
+        N.check(rc, "TileMerger(defer=True)")
+        ng, nb, ni = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        lib.ptb_band_plan_info(handle, ctypes.byref(ng), ctypes.byref(nb), ctypes.byref(ni), None, None)
+        last_group = np.zeros(n, dtype=np.int64)
+        rows_arr = np.zeros(3 * ng.value, dtype=np.int64)
+        lib.ptb_band_plan_info(handle, None, None, None, last_group.ctypes.data_as(N._i64p), rows_arr.ctypes.data_as(N._i64p))
+        groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
+        lasts = [g[2] for g in groups]
+        return Bands(handle, table, groups, nb.value, last_group, all(a <= b for a, b in zip(lasts, lasts[1:])))
+
+
+# ------------------------------------------------------------------------------------------------ strategies
+def _fast_call(merger, batch, crop_coords):
+    """The common call -- a contiguous model output on the merger's device that needs no autograd detach, crops as an int64 [B, 4]
+    array (a numpy slice of ``tiler.crops``): everything per call can then be validated with a handful of comparisons."""
+    return (type(crop_coords) is np.ndarray and crop_coords.ndim == 2 and crop_coords.dtype == np.int64 and batch.is_cuda
+            and batch.is_contiguous() and not batch.requires_grad and not merger._eager_norm and not merger._window_edited())
+
+
+class DeferredBands:
+    """Strategy "deferred bands" (``TileMerger(..., crops=tiler.crops, defer=True)``).
+
+    The merger only keeps references to the model outputs it is handed, and when the last tile of a launch group has arrived ONE
+    launch reads all covering tiles of its rows, de-augments, reduces, blends in integration order and writes ``sum / norm`` to the
+    result -- the accumulator image never travels through HBM (the incremental path re-reads and re-writes every pixel once per
+    overlapping tile row).  The fp32 operation order per pixel is the incremental path's, so the result is bit-identical.  Cost:
+    the batches of the last ``rows / step + 1`` tile rows stay alive until their group is done, and they must not be modified in
+    place in the meantime -- which is why this is opt-in.
+
+    Until the first group is launched any deviation from the plan simply replays the held batches through the incremental path;
+    afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
+
+    def __init__(self, merger, bands):
+        self.m = merger
+        self.bands = bands               # Bands, or None: this merger does not defer (the strategy is never active)
+        self.held = HeldBatches("TileMerger(defer=True)")
+        self.done = 0                    # launch groups issued for this image
+        self.active = False
+        self.reset()
+
+    def reset(self):
+        self.active = self.bands is not None
+        self.held.clear()
+        self.done = 0
+        if self.bands is not None:
+            N.load().ptb_band_plan_reset(self.bands.handle)
+
+    @property
+    def complete(self):
+        return self.bands is not None and self.done == len(self.bands.bands)
+
+    def flush(self, what, keep_plan=False):
+        """Leave deferred mode: replay the held batches through the incremental path (only before the first band) --
+        the planned one when ``keep_plan`` (nothing deviated from the plan), else the ordinary one."""
+        if not self.active:
+            return
+        if self.done:
+            raise RuntimeError(f"TileMerger(defer=True): {what} is not available after bands of the image were merged; "
+                               "integrate the planned tiles and call merge(), or construct the merger without defer=True")
+        m = self.m
+        held = self.held.take_all()
+        self.active = False
+        m._plan.restart()
+        m._plan.active = keep_plan
+        m._log, m._applied = [], 0
+        for batch, (coords, views, reduction), *_rest in held:
+            m._accumulate(batch, coords, views, reduction)
+
+    def launch_due(self, end):
+        """Will a submit that brings the planned tiles up to index ``end`` (exclusive) launch a group?  (Only then are the held
+        batches' version counters compared; groups of a row-major crop list complete in index order.)"""
+        bands = self.bands
+        if not bands.monotone:
+            return True
+        return self.done < len(bands.bands) and end > bands.bands[self.done][2]
+
+    def _submit(self, batch, coords, views, pos, B, dcode, n_views, varr, code):
+        """Take the planned tiles ``pos .. pos+B-1`` into custody and merge the launch groups they complete
+        (``ptb_band_plan_submit``: the pointer bookkeeping and the launches happen in C).  Returns its code: < 0 nothing was taken."""
+        m, bands = self.m, self.bands
+        plan = m._plan
+        span = self.held.admit(batch, self.launch_due(pos + B))
+        if m._merged is None:
+            m._merged = torch.empty_like(m._image)
+        per_tile = m.channels * int(m.weight.shape[1]) * int(m.weight.shape[2])
+        dev = m._image.device
+        with N.on_device(dev):
+            rc = N.load().ptb_band_plan_submit(bands.handle, pos, B, batch.data_ptr(), per_tile, B * per_tile, dcode, n_views, varr, code,
+                                               m._merged.data_ptr(), plan.norm_full.data_ptr(), m.weight.data_ptr(), N.stream_ptr(dev))
+        N.bump()
+        if rc < 0:
+            return rc
+        self.held.keep(batch, span, (coords, views, code), int(bands.last_group[pos:pos + B].max()))
+        plan.pos = pos + B
+        if rc:
+            done = self.done = self.done + rc
+            if done == len(bands.bands):
+                self.held.clear()
+            elif bands.monotone:      # groups 0 .. done-1 are out: batches no later group reads can go
+                self.held.release_before(done)
+        return rc
+
+    def take_fast(self, batch, crop_coords, key, views, code):
+        """The common call (see ``_fast_call``) for exactly the next planned crops: everything constant per merger / per
+        (group, reduction) is cached, the rest is one C call: ~10 us of host time instead of ~20.  False: ``take`` decides (and
+        reports)."""
+        m = self.m
+        plan = m._plan
+        if not (self.active and plan.active and _fast_call(m, batch, crop_coords)):
+            return False
+        dcode = N.DTYPE_CODES.get(batch.dtype)
+        B, pos = crop_coords.shape[0], plan.pos
+        if dcode is None or B == 0 or batch.device != m._image.device or not np.array_equal(crop_coords, plan.crops4[pos:pos + B]):
+            return False
+        varr, n_views = m._view_array(key, views)
+        if batch.shape != (B * n_views, m.channels, m.weight.shape[1], m.weight.shape[2]):
+            return False
+        rc = self._submit(batch, crop_coords, views, pos, B, dcode, n_views, varr, code)
+        if rc < 0:
+            if rc == N.PTB_EUNSUPPORTED:
+                return False       # (nothing was launched: the general path warns and replays)
+            N.check(rc, "TileMerger.integrate_batch (deferred bands)")
+        m.fast_submits += 1
+        m._log.append(np.ascontiguousarray(crop_coords[:, :2].T))
+        return True
+
+    def take(self, batch, coords, xy, views, reduction, dcode):
+        """Any validated batch.  False: not deferrable -- the held batches were replayed and the caller goes on with the next
+        strategy."""
+        m = self.m
+        plan = m._plan
+        B = xy.shape[1]
+        rc = N.PTB_EUNSUPPORTED
+        if plan.active and not m._eager_norm and plan.follows(xy, B):
+            varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
+            rc = self._submit(batch, coords, views, plan.pos, B, dcode, len(views) if views is not None else 1, varr, reduction)
+        if rc == N.PTB_EUNSUPPORTED:
+            warn_once(("defer-deviation",), "TileMerger(defer=True): a batch deviates from the planned crop sequence / configuration (or "
+                                            "norm_mask was read); leaving deferred mode for this image, the held batches are replayed incrementally.")
+            self.flush("an unplanned tile batch")
+            return False
+        if rc < 0:
+            N.check(rc, "TileMerger.integrate_batch (deferred bands)")
+        m._log.append(xy)
+        return True
+
+    def finish(self):
+        """At ``merge()``: the finished result, or None after handing an incomplete image back to the planned strategy."""
+        if self.complete:
+            return self.m._merged          # every band was merged by the launch that completed it
+        self.flush("merge() before all planned tiles were integrated", keep_plan=True)
+        return None
+
+
+class PlannedBlocks:
+    """Strategy "planned" (``TileMerger(..., crops=tiler.crops)`` and self-planned mergers): ``ptb_accumulate_planned2`` accumulates
+    a batch and writes ``sum / norm`` of every block whose last planned tile this batch brings -- see ``Plan`` for what that
+    restricts.  A self-planned merger asks the kernel to keep the weighted sums of finalised blocks as well
+    (PTB_PLANNED_KEEP_SUMS), so its accumulators stay exact."""
+
+    def __init__(self, merger):
+        self.m = merger
+
+    def _launch(self, batch, dcode, n_views, varr, code, xs, ys, B):
+        m = self.m
+        plan = m._plan
+        if m._merged is None:
+            m._merged = torch.empty_like(m._image)
+        lib = N.load()
+        dev = m._image.device
+        th, tw = int(m.weight.shape[1]), int(m.weight.shape[2])
+        keep = 1 if m._selfplan.planned else 0
+        fresh = m._fresh
+
+        def launch(fresh_ptr):
+            return lib.ptb_accumulate_planned2(m._image.data_ptr(), plan.norm_full.data_ptr(), m._merged.data_ptr(), m.weight.data_ptr(),
+                                               batch.data_ptr(), dcode, n_views, varr, code, xs, ys, B, m.channels, th, tw, m.image_height,
+                                               m.image_width, fresh_ptr, FRESH_ROWS, plan.remaining.ctypes.data, plan.done.ctypes.data,
+                                               keep, N.stream_ptr(dev))
+
+        with N.on_device(dev):
+            rc = launch(fresh.ctypes.data if fresh.any() else None)
+            if rc == N.EFRESH:  # a cell straddles written and never-written blocks: zero-fill once, then plain RMW
+                N.fresh_fallbacks += 1
+                m._materialize()
+                rc = launch(None)
+        N.bump()
+        return rc
+
+    def take_fast(self, batch, crop_coords, key, views, code):
+        """The common call (see ``_fast_call``) for exactly the next planned crops: ~12 us of host time instead of ~40.  False:
+        ``take`` decides (and reports)."""
+        m = self.m
+        plan = m._plan
+        if plan is None or not plan.active or m._deferred.active or not _fast_call(m, batch, crop_coords):
+            return False
+        dcode = N.DTYPE_CODES.get(batch.dtype)
+        B, pos = crop_coords.shape[0], plan.pos
+        if (dcode is None or B == 0 or batch.device != m._image.device or pos + B > plan.xy.shape[1]
+                or not np.array_equal(crop_coords, plan.crops4[pos:pos + B])):
+            return False
+        varr, n_views = m._view_array(key, views)
+        if batch.shape != (B * n_views, m.channels, m.weight.shape[1], m.weight.shape[2]) or m._image.dtype != torch.float32:
+            return False
+        base = plan.xy.ctypes.data            # [2, N] int64, C order: row 0 = xs, row 1 = ys
+        xs = ctypes.cast(base + 8 * pos, N._i64p)
+        ys = ctypes.cast(base + 8 * (plan.xy.shape[1] + pos), N._i64p)
+        rc = self._launch(batch, dcode, n_views, varr, code, xs, ys, B)
+        if rc == 0:
+            plan.pos = pos + B
+            m._log.append(plan.xy[:, pos:pos + B])
+            return True
+        if rc == N.PTB_EUNSUPPORTED:
+            return False                      # (nothing was launched: the general path takes this batch the ordinary way)
+        N.check(rc, "TileMerger.integrate_batch")
+        return False
+
+    def take(self, batch, xy, xs, ys, n_views, varr, reduction, dcode):
+        """Any validated batch.  False: the ordinary path takes it (and the rest of the image)."""
+        m = self.m
+        plan = m._plan
+        B = xy.shape[1]
+        if plan.active and not m._eager_norm and plan.follows(xy, B):
+            rc = self._launch(batch, dcode, n_views, varr, reduction, xs, ys, B)
+            if rc == 0:
+                plan.pos += B
+                m._log.append(xy)
+                return True
+            if rc != -2:
+                N.check(rc, "TileMerger.integrate_batch")
+            # nothing was launched: this batch (and the rest of the image) takes the ordinary path
+        plan.active = False
+        if plan.done.any():
+            th, tw = int(m.weight.shape[1]), int(m.weight.shape[2])
+            if plan.touches_done(xy, th, tw):
+                if not m._selfplan.planned:
+                    raise RuntimeError("TileMerger(crops=...): a tile touches pixels that were already finalised -- every planned "
+                                       "tile may be integrated once; construct the merger without crops= for free-form accumulation")
+                m._selfplan.unfinalise("a tile over pixels that were already merged")
+        return False
+
+    def off(self, what):
+        """Leave planned mode for this image; impossible once blocks were finalised (their accumulators were never stored) --
+        unless the merger planned itself and kept them."""
+        m = self.m
+        m._deferred.flush(what)
+        plan = m._plan
+        if plan is not None:
+            if plan.done.any():
+                if not m._selfplan.planned:
+                    raise RuntimeError(f"TileMerger(crops=...): {what} is not available after planned blocks were finalised; "
+                                       "call merge(), or construct the merger without crops=")
+                m._selfplan.unfinalise(what)
+            plan.active = False
+        m._selfplan.opt_out()
+
+    def finish(self):
+        """At ``merge()``: divide whatever the accumulate launches have not finalised themselves; returns the result."""
+        m = self.m
+        plan, out = m._plan, m._merged
+        pending = plan.done == 0
+        if pending.any():
+            m._norm_ready()
+            m._materialize()
+            m._check_state()
+            mask = torch.from_numpy(pending.astype(np.uint8)).to(m._image.device)
+            lib = N.load()
+            dev = m._image.device
+            with N.on_device(dev):
+                rc = lib.ptb_merge_div_masked(m._image.data_ptr(), m._norm.data_ptr(), out.data_ptr(), m.channels,
+                                              m.image_height, m.image_width, mask.data_ptr(), FRESH_ROWS, N.stream_ptr(dev))
+            N.bump()
+            N.check(rc, "TileMerger.merge")
+        return out
+
+
+class Incremental:
+    """Strategy "incremental": the reference's semantics literally (inference/tiles.py:321-346) -- one ``ptb_deaug_accumulate_t``
+    launch per batch adds the weighted tiles to the accumulator in batch order, ``merge()`` divides."""
+
+    def __init__(self, merger):
+        self.m = merger
+
+    def take(self, batch, coords, xy, xs, ys, views, n_views, varr, reduction, dcode):
+        m = self.m
+        B = xy.shape[1]
+        lib = N.load()
+        dev = m._image.device
+        th, tw = int(m.weight.shape[1]), int(m.weight.shape[2])
+        norm_ptr = m._norm.data_ptr() if m._eager_norm else None
+
+        def launch(fresh_ptr):
+            return lib.ptb_deaug_accumulate_t(m._image.data_ptr(), norm_ptr, m.weight.data_ptr(), batch.data_ptr(), dcode, n_views, varr,
+                                              reduction, xs, ys, B, m.channels, th, tw, m.image_height, m.image_width, fresh_ptr,
+                                              FRESH_ROWS, N.stream_ptr(dev))
+
+        with N.on_device(dev):
+            rc = launch(m._fresh.ctypes.data if m._fresh.any() else None)
+            if rc == N.EFRESH:  # geometry not block aligned (or a non-default chunk size): zero-fill once, then plain RMW
+                N.fresh_fallbacks += 1
+                m._materialize()
+                rc = launch(None)
+        N.bump()
+        if rc == -2 and dcode != N.F32:   # shape needs the scalar kernels: take the reference's route (cast, then accumulate)
+            return m._accumulate(batch.float(), coords, views, reduction)
+        N.check(rc, "TileMerger.integrate_batch")
+        if not m._eager_norm and B:
+            m._log.append(xy)
+
+    def merge_into(self, out):
+        m = self.m
+        m._norm_ready()
+        m._materialize()
+        m._check_state()
+        lib = N.load()
+        dev = m._image.device
+        with N.on_device(dev):
+            rc = lib.ptb_merge_div(m._image.data_ptr(), m._norm.data_ptr(), out.data_ptr(), m.channels,
+                                   m.image_height * m.image_width, N.stream_ptr(dev))
+        N.bump()
+        N.check(rc, "TileMerger.merge")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------ self-planning mergers
+# The reference's loop builds `TileMerger(tiler.target_shape, C, tiler.weight)` -- no crop list -- for every image and feeds it the
+# same crops in the same order (README.md:201-226).  A merger without `crops=` therefore records the crop sequence it saw
+# (at `merge()`), and the NEXT merger of the same geometry and window (or the same one after `reset()`) plans itself from it:
+# normaliser precomputed, every block divided in the launch that brings its last tile, no separate merge pass.  Any deviation
+# from the remembered sequence drops back to the ordinary path for the rest of that image (bit-identical results either way).
+# Opt-in since round 4 (PTB_AUTO_PLAN=1 / tiles.set_auto_plan(True)): with the lazy de-augmentation handle already fusing the two
+# reference calls into one launch, and self-planned mergers keeping their accumulators exact (one more store of the image), planning
+# from the previous image buys ~0.5 % over the ordinary fused path at the headline geometry -- not worth module-level caches by default.
+AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser in HBM once planned)
+auto_cache = collections.OrderedDict()   # key -> AutoEntry
+auto_lock = threading.RLock()            # mergers of several threads (one inference loop each) share the cache
+
+
+class AutoEntry:
+    __slots__ = ("log", "seen", "need", "parts", "disabled")
+
+    def __init__(self):
+        self.log = None        # bytes of the [n, 4] int64 crop sequence of the last merged image
+        self.seen = 0          # consecutive merged images that ended with exactly this sequence
+        self.need = 1          # repeats required before planning (grows when a planned image deviated)
+        self.parts = None      # (xy, remaining0, norm_full, crops4, built event) shared by the mergers planned from `log`
+        self.disabled = False  # this geometry cannot be planned / its user reads accumulators or merges partially
+
+
+def auto_entry(key, create=False):
+    with auto_lock:
+        ent = auto_cache.get(key)
+        if ent is None and create:
+            while len(auto_cache) >= AUTO_MAX:
+                auto_cache.popitem(last=False)
+            ent = auto_cache[key] = AutoEntry()
+        elif ent is not None:
+            auto_cache.move_to_end(key)
+        return ent
+
+
+class SelfPlanning:
+    """The policy that gives a merger constructed without ``crops=`` a ``Plan`` (see the comment above).  ``key`` None: this merger
+    never plans itself and every method is a no-op."""
+
+    def __init__(self, merger, key):
+        self.m, self.key = merger, key
+        self.planned = False      # merger._plan was made here (from the previous image's crops), not by the caller
+        self.noted = None         # log length at the last merge() of this image
+
+    def attach(self):
+        """(Re)plan the merger from the crop sequence its geometry ended the last image(s) with, when there is a stable one."""
+        if self.key is None:
+            return
+        m = self.m
+        ent = auto_entry(self.key)
+        usable = (ent is not None and not ent.disabled and ent.log is not None and ent.seen >= ent.need and not m._window_edited())
+        if not usable:
+            if self.planned:
+                m._plan, self.planned = None, False
+            return
+        if self.planned and ent.parts is not None and ent.parts[0] is m._plan.xy:
+            m._plan.restart()
+            return
+        if ent.parts is None:
+            plan = Plan.build(m, np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4))
+            if plan is None:          # off the block grid: this geometry never plans
+                ent.disabled = True
+                m._plan, self.planned = None, False
+                return
+            built = torch.cuda.Event()
+            built.record(torch.cuda.current_stream(plan.norm_full.device))
+            ent.parts = (plan.xy, plan.remaining0, plan.norm_full, plan.crops4, built)
+        xy, remaining0, norm_full, crops4, built = ent.parts
+        torch.cuda.current_stream(norm_full.device).wait_event(built)      # (the normaliser may have been built on another stream)
+        plan = Plan(xy, remaining0, norm_full)
+        plan.crops4 = crops4
+        m._plan, self.planned = plan, True
+
+    def opt_out(self):
+        """The caller touched the accumulators themselves: this geometry stays on the ordinary (exact, unplanned) path from now on."""
+        if self.key is not None:
+            auto_entry(self.key, create=True).disabled = True
+
+    def note(self):
+        """At merge(): remember the crop sequence this image was made of (what the next image of this geometry is planned from)."""
+        if self.key is None:
+            return
+        m = self.m
+        n = len(m._log)
+        if self.noted == n:
+            return
+        ent = auto_entry(self.key, create=True)
+        if self.noted is not None or m._eager_norm or m._window_edited():
+            ent.disabled = True       # tiles after a merge() / a caller-visible norm_mask / an edited window: not the README loop
+            return
+        self.noted = n
+        if n == 0:
+            return
+        plan = m._plan
+        if self.planned and plan.active and plan.pos == plan.xy.shape[1] and ent.parts is not None and ent.parts[0] is plan.xy:
+            ent.seen += 1             # the planned sequence, start to end
+            return
+        xy = np.concatenate(m._log, axis=1)
+        crops4 = np.empty((xy.shape[1], 4), dtype=np.int64)
+        crops4[:, 0], crops4[:, 1] = xy[0], xy[1]
+        crops4[:, 2], crops4[:, 3] = int(m.weight.shape[2]), int(m.weight.shape[1])
+        log = crops4.tobytes()
+        if self.planned:              # a planned image that went another way: ask for more evidence before planning again
+            ent.need = min(ent.need + 1, 4)
+        if ent.log == log:
+            ent.seen += 1
+        else:
+            ent.log, ent.seen, ent.parts = log, 1, None
+
+    def unfinalise(self, what):
+        """Somebody needs the accumulators of blocks the planned kernels have already turned into results.  A merger that planned
+        ITSELF stores the weighted sum of a block next to its merged value (PTB_PLANNED_KEEP_SUMS: one more store of the image per
+        image), so the accumulators are complete and exact -- the same bits the unplanned kernels would have left; the merger simply
+        goes back to the ordinary path and its geometry stops planning itself."""
+        plan = self.m._plan
+        warn_once(("unfinalise", self.key), f"TileMerger: {what} after the self-planned kernels had finalised part of the image; the "
+                                            "accumulators are complete (self-planned mergers keep them), mergers of this geometry use the "
+                                            "ordinary accumulate + merge path from now on (TileMerger(..., auto_plan=False) avoids the switch).")
+        plan.done[:] = 0
+        plan.active = False
+        self.opt_out()

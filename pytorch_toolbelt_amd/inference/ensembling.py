@@ -162,35 +162,29 @@ class Ensembler(nn.Module):
         preds = [_activate(p, *a) for p, a in zip(preds, acts)]
         return _deaugment_averaging(torch.stack(preds), self.reduction)
 
-    def forward(self, *input, **kwargs):  # skipcq: PYL-W0221
-        ran = [self._run(model, input, kwargs) for model in self.models]
-        outputs = [r[0] for r in ran]
-        owed = [r[1] for r in ran]
-        none = (_ACT_NONE, 1.0, 1)
-        output_is_dict = isinstance(outputs[0], dict)
-        output_is_list = isinstance(outputs[0], (list, tuple))
-
+    def _selected(self, first):
+        """What of the models' outputs is reduced, decided by the first model's output like the reference (ensembling.py:94-107):
+        (keys, builder of the result container); keys None = the output is one tensor."""
+        as_dict = isinstance(first, dict)
+        as_seq = isinstance(first, (list, tuple))
         if self.return_some_outputs:
-            keys = self.outputs
-        elif output_is_dict:
-            keys = outputs[0].keys()
-        elif output_is_list:
-            keys = list(range(len(outputs[0])))
-        elif torch.is_tensor(outputs[0]):
-            keys = None
-        else:
-            raise RuntimeError()
+            return self.outputs, as_dict
+        if as_dict:
+            return first.keys(), True
+        if as_seq:
+            return range(len(first)), False
+        if torch.is_tensor(first):
+            return None, False
+        raise RuntimeError()
 
+    def forward(self, *input, **kwargs):  # skipcq: PYL-W0221
+        outputs, owed = zip(*(self._run(model, input, kwargs) for model in self.models))
+        plain = (_ACT_NONE, 1.0, 1)
+        keys, as_dict = self._selected(outputs[0])
         if keys is None:
-            return self._reduce(outputs, [none] * len(outputs))
-        averaged_output = {} if output_is_dict else []
-        for key in keys:
-            value = self._reduce([output[key] for output in outputs], [o.get(key, none) for o in owed])
-            if output_is_dict:
-                averaged_output[key] = value
-            else:
-                averaged_output.append(value)
-        return averaged_output
+            return self._reduce(list(outputs), [plain] * len(outputs))
+        reduced = [(key, self._reduce([out[key] for out in outputs], [o.get(key, plain) for o in owed])) for key in keys]
+        return dict(reduced) if as_dict else [value for _key, value in reduced]
 
 
 class PickModelOutput(nn.Module):

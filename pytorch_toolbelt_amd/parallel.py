@@ -313,20 +313,6 @@ def deferred_geometry(plan, rank: int, crops: np.ndarray, image_height: int):
     return final, sorted(int(c) for c in cuts)
 
 
-def _held_entry(batch):
-    from .inference.tiles import _held_entry as f
-
-    globals()["_held_entry"] = f      # (bound on first use: parallel.py must stay importable without the inference package loaded first)
-    return f(batch)
-
-
-def _check_held(*a):
-    from .inference.tiles import _check_held as f
-
-    globals()["_check_held"] = f
-    return f(*a)
-
-
 class _DeferredBand:
     """One rank's band merged without an accumulator: the C band plan of ``TileMerger(defer=True)`` over the rank's own tiles
     (csrc/ptb_bandplan.hip), in the rank's issue order and local row coordinates.  ``out`` [C, rows, W] receives ``sum / norm``
@@ -344,7 +330,9 @@ class _DeferredBand:
         self._varr = {}
         self.channels, self.th, self.tw = channels, th, tw
         self.pos = 0
-        self.held = []
+        from .inference._merge_modes import HeldBatches      # (the custody contract of TileMerger(defer=True), shared)
+
+        self.held = HeldBatches("ShardedTileMerger(defer=True)")
         self.cfg = None
 
     def __del__(self):
@@ -452,7 +440,8 @@ class _DeferredBand:
         from . import _native as N
 
         N.load().ptb_band_plan_reset(self.handle)
-        self.pos, self.held, self.cfg, self.launched = 0, [], None, 0
+        self.pos, self.cfg, self.launched = 0, None, 0
+        self.held.clear()
         for k in range(self.n_sends):
             self.packed[k] = 0
         self.all_packed.value = 1 if self.n_sends == 0 else 0
@@ -482,9 +471,7 @@ class _DeferredBand:
             varr = self._varr[key] = N.int_array(list(views)) if views is not None else N.int_array([N.IDENT])
         per_tile = self.channels * self.th * self.tw
         dev = self.norm.device
-        span = _held_entry(batch)
-        due = any(self.pos <= last < self.pos + B for _y0, _y1, last in self.groups)
-        _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
+        span = self.held.admit(batch, any(self.pos <= last < self.pos + B for _y0, _y1, last in self.groups))
         if self.out is None:
             self.out = torch.empty(self.out_shape, device=dev, dtype=torch.float32)
         with N.on_device(dev):
@@ -497,7 +484,7 @@ class _DeferredBand:
         N.bump()
         if rc < 0:
             N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
-        self.held.append((batch,) + span)
+        self.held.keep(batch, span)
         self.pos += B
         self.launched += rc
         return rc
@@ -515,12 +502,11 @@ class _DeferredBand:
         if (pos + B > self.xy_abs.shape[1] or batch.shape != (B * n_views, self.channels, self.th, self.tw)
                 or not np.array_equal(coords_abs[:, :2], self.xy_abs_rows[pos:pos + B])):
             return None          # (the general path reports what is wrong)
-        span = _held_entry(batch)
         due = False
         for _y0, _y1, last in self.groups:
             if pos <= last < pos + B:
                 due = True
-        _check_held(self.held, batch, span, due, "ShardedTileMerger(defer=True)")
+        span = self.held.admit(batch, due)
         dev = self.norm.device
         if self.out is None:
             self.out = torch.empty(self.out_shape, device=dev, dtype=torch.float32)
@@ -533,7 +519,7 @@ class _DeferredBand:
         N.bump()
         if rc < 0:
             N.check(rc, "ShardedTileMerger.integrate_batch (deferred band)")
-        self.held.append((batch,) + span)
+        self.held.keep(batch, span)
         self.pos = pos + B
         self.launched += rc
         return rc
@@ -1082,7 +1068,7 @@ class ShardedTileMerger:
             raise RuntimeError("ShardedTileMerger.merge_async(): this image was already merged with merge(); call reset() first")
         self._end_of_image(slot)
         if slot.deferred is not None:
-            slot.deferred.held = []       # every launch that reads the batches has been issued (stream order keeps their memory safe)
+            slot.deferred.held.clear()       # every launch that reads the batches has been issued (stream order keeps their memory safe)
         ticket = slot.ticket = PendingBand(self, slot)
         self.images_async += 1
         # move on: the next image lives in the next slot (made on first use); whatever image still sits there is completed first
@@ -1130,7 +1116,7 @@ class ShardedTileMerger:
                                                         d.recv_ptrs if d.n_recvs else None, d.n_ranges, d.ranges_p, N.stream_ptr(self.device))
             N.bump()
             N.check(rc, "ShardedTileMerger.merge (deferred band)")
-        d.held = []
+        d.held.clear()
         return d.out[:, o0 - d.top:o1 - d.top]
 
     def gather(self, band):

@@ -121,6 +121,31 @@ def test_held_batch_guard():
         _check_held([(d,) + entry], c, _held_entry(c), True, "x")
 
 
+def test_held_batches_custody_is_one_class_for_both_deferred_mergers():
+    """``HeldBatches`` (inference/_merge_modes.py) is the custody list of ``TileMerger(defer=True)`` and of the sharded merger's
+    deferred band: admit = the contract check, keep / release_before / take_all = the bookkeeping both used to do by hand."""
+    from pytorch_toolbelt_amd.inference._merge_modes import HeldBatches
+
+    h = HeldBatches("X(defer=True)")
+    pool = torch.zeros(6, 2, 4, 4)
+    a, b, c = pool[0:2], pool[2:4], pool[1:3]
+    h.keep(a, h.admit(a, False), ("crops a", None, 0), last_group=0)
+    h.keep(b, h.admit(b, True), ("crops b", None, 0), last_group=1)
+    assert len(h) == 2 and bool(h) and [r[0] is t for r, t in zip(h, (a, b))] == [True, True]
+    with pytest.raises(RuntimeError, match=r"X\(defer=True\): this batch occupies memory"):
+        h.admit(c, False)
+    h.release_before(1)                       # group 0 is out: a goes, b (read by group 1) stays
+    assert len(h) == 1 and next(iter(h))[0] is b and next(iter(h))[1] == ("crops b", None, 0)
+    b.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        h.admit(torch.zeros(1), True)
+    rows = h.take_all()
+    assert len(rows) == 1 and len(h) == 0 and not h
+    h.keep(a, h.admit(a, True))
+    h.clear()
+    assert len(h) == 0
+
+
 def test_autograd_on_an_evaluated_handle_and_the_legacy_dlpack_guard():
     """Once evaluated, requires_grad / grad / is_leaf are those of the value (they were answered by the storage-less wrapper:
     `y.requires_grad_(); ...backward(); y.grad` gave None); torch.utils.dlpack.to_dlpack -- a bare C function that would read the
