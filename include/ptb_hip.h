@@ -555,8 +555,9 @@ int ptb_bitempered_rows(const float* activations, const float* onehot, const flo
  * seg_loss[s] (double, zeroed by this call) = dot(relu(errors_sorted), lovasz_grad(fg_sorted)); fg_total[s] = number
  * of foreground pixels (class presence); grad_at_pixel[s*P + i] = Lovasz gradient at the rank of pixel i (for backward;
  * may be NULL when no backward will follow: the scatter of the gradients to pixel order is then skipped).
- * Workspaces are caller-provided device buffers: keys_a/keys_b u32[n] (complemented order-preserving error bits),
- * vals_a/vals_b u32[n], chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (digit histograms of the
+ * Workspaces are caller-provided device buffers: keys_a/keys_b u32[n] (key = ~kappa, kappa = bits(max(error, +0)) << 1 | fg: the
+ * errors in descending order, ties by fg, then by index -- the reference's torch.sort leaves the order of ties open),
+ * vals_a/vals_b u32[n] (index << 1 | fg), chunk u32[S*ceil(P/2048)], temp of ptb_lovasz_temp_bytes(P, S) bytes (digit histograms of the
  * hand-written segmented radix sort: four stable 8-bit passes per segment). */
 int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments);
 int ptb_lovasz_fwd(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
@@ -582,6 +583,12 @@ int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float*
 int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const uint32_t* binned_vals,
                           const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode, int per_image, int has_ignore,
                           int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream);
+/* ptb_lovasz_bwd_binned with the incoming gradient of the scalar loss as a DEVICE scalar gscale and ptb_lovasz_reduce's coef_out as
+ * coef_unit: coefficient of segment s = gscale[0] * coef_unit[s], formed inside the kernel (the rounding of the [S]-sized product the
+ * caller would otherwise launch in front of it). */
+int ptb_lovasz_bwd_binned2(const float* pred, const int64_t* labels, const float* flabels, const float* coef_unit, const float* gscale,
+                           const uint32_t* binned_vals, const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode,
+                           int per_image, int has_ignore, int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream);
 /* The scalar the modules return from seg_loss / fg_total (losses/lovasz.py:92-108, :110-140): per group the mean of seg_loss over
  * the classes with fg_total > 0 (present_only = 1, classes="present") or over all classes (0; the hinge loss is C = 1), 0 when none
  * is selected; then the mean over the groups.  loss_out = DEVICE float; coef_out = DEVICE float[groups*C] = d(loss)/d(seg_loss). */

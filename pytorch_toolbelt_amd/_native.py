@@ -110,6 +110,7 @@ SIGNATURES = {
     "ptb_lovasz_fwd_keys": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 6 + [_c_i64, _vp]),
     "ptb_lovasz_fwd_binned": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f] + [_vp] * 9 + [_c_i64, _vp]),
     "ptb_lovasz_bwd_binned": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_int, _vp]),
+    "ptb_lovasz_bwd_binned2": (_c_int, [_vp] * 8 + [_c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _c_int, _vp]),
     "ptb_lovasz_reduce": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp]),
     "ptb_lovasz_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _c_f, _vp]),
     "ptb_deaug_accumulate": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _i64p, _i64p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _c_int, _vp]),

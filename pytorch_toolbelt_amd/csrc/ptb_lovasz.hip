@@ -4,9 +4,10 @@
 // Per class (and per image with per_image=True) the reference sorts the errors, gathers the ground truth, runs two
 // cumsums, a division, a first difference and a dot product -- a Python loop over classes with a host sync each
 // (`fg.sum() == 0`).  Here every (group, class) pair is one *segment* of a single pipeline:
-//   1. error kernel:   key = ~(order-preserving bits of the error) (ignored pixels get -inf so they sort last and contribute
-//      0), value = index<<1 | fg; it is also the histogram step of the first sort pass (the keys are in registers) and reads a
-//      pixel's int64 label once for all the classes it handles
+//   1. error kernel:   key = ~kappa, kappa = bits(max(error, +0)) << 1 | fg (ignored pixels: 0 -- they sort last and contribute 0);
+//      it is also the histogram step of the first sort pass (the keys are in registers) and reads a
+//      pixel's int64 label once for all the classes it handles.  No value is written: the first scatter pass makes index << 1 | fg
+//      from the element's position and its key
 //   2. a hand-written segmented LSD radix sort for gfx950 (below): every segment is sorted by its 32-bit keys in four 8-bit
 //      passes; a pass = per-tile digit histograms (wave-private LDS counters), a scan over the tiles of every segment, and a
 //      stable scatter that ranks the 4096 keys of a tile with ballot-matched lane groups (no atomics where order matters), stages them by digit in LDS and writes every digit run coalesced (tile-major histograms, scanned in spans
@@ -42,14 +43,6 @@ struct LovArgs {
     long long P;  // elements per segment
     int S;        // segments = groups * C
 };
-
-__device__ __forceinline__ unsigned ordered_bits(float e) {  // monotone float -> uint map (larger float => larger uint)
-    const unsigned u = __float_as_uint(e);
-    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(unsigned u) {
-    return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-}
 
 // ------------------------------------------------------------------------------------------------ segmented radix sort
 // S segments of P (key, value) pairs each, contiguous; ascending by the 32-bit key, stable, four passes of 8 bits.
@@ -169,22 +162,24 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
 
 // The error kernel and the first pass's histogram kernel in one: a workgroup owns the 4096 pixels of one tile position of a group
 // (image, or the whole batch) and a chunk of classes.  The pixels' labels are read once (int64: read per class they are twice the
-// bytes of the probabilities) and every class of the chunk is a pass over the same pixels: error -> key / value written, digit 0
+// bytes of the probabilities) and every class of the chunk is a pass over the same pixels: error -> key written, digit 0
 // counted in LDS, the tile's histogram row written.  Element i of a segment is pixel (b = i / HW, i % HW) of the batch, or pixel i of
 // image j when per_image; n < 2^31, so offsets into pred fit 32 bits.
-// KEYONLY (the forward without a gradient, ptb_lovasz_fwd_keys): no (index, fg) value travels with the key.  An error that is not
-// positive contributes relu(e) * grad = 0 wherever it sorts among the non-positive ones, so all of them (and the ignored pixels)
-// share the key of +0; a positive float has a clear sign bit, so its 31 significant bits move up by one and the foreground flag
-// takes the freed bit: kappa = bits(e) << 1 | fg, sorted in decreasing order (key = ~kappa, ascending) -- the order of the errors
-// exactly, ties broken by fg, which the loss does not depend on.  The sort then moves 4 bytes per element and pass instead of 8.
+// The key ("kappa"): an error that is not positive contributes relu(e) * grad = 0 and has a zero gradient wherever it sorts among the
+// non-positive ones, so all of them (and the ignored pixels) share the key of +0; a positive float has a clear sign bit, so its 31
+// significant bits move up by one and the foreground flag takes the freed bit: kappa = bits(e) << 1 | fg, sorted in decreasing
+// order (key = ~kappa, ascending).  That is the order of the errors exactly, ties broken by fg and then (the sort is stable) by
+// index -- the reference's torch.sort leaves the order of ties open and the loss does not depend on it.  Everything downstream reads
+// the error AND the foreground flag out of the key: the forward without a gradient sorts keys alone (4 bytes per element and pass
+// instead of 8), the training path makes its (index << 1 | fg) values in the first scatter pass instead of loading them (IOTA).
 __device__ __forceinline__ unsigned keyonly_key(float e, unsigned fg, bool valid) {
     const unsigned m = (valid && !(e <= 0.0f)) ? (__float_as_uint(e) & 0x7FFFFFFFu) : 0u;      // (NaN stays NaN: it sorts first and poisons the sum)
     return ~((m << 1) | (valid ? fg : 0u));
 }
 
-template <int MODE, bool KEYONLY = false>
+template <int MODE>
 __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a, int T, int cchunk, unsigned* __restrict__ keys,
-                                                                unsigned* __restrict__ vals, unsigned* __restrict__ hist) {
+                                                                unsigned* __restrict__ hist) {
     __shared__ unsigned h[4][4][256];
     const int j = blockIdx.x / T, tile = blockIdx.x % T;
     const int c0 = blockIdx.y * cchunk, c1 = min(a.C, c0 + cchunk);
@@ -241,12 +236,8 @@ __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a,
                 fg = y != 0.f ? 1u : 0u;
                 e = 1.0f - p[jj] * (2.0f * y - 1.0f);                 // lovasz.py:65-66
             }
-            const unsigned key = KEYONLY ? keyonly_key(e, fg, valid)
-                                         : ~ordered_bits(valid ? e : -INFINITY);   // ascending sort of the complement = descending errors
-            if (ok) {
-                keys[sbase + idx] = key;
-                if constexpr (!KEYONLY) vals[sbase + idx] = ((unsigned)(t0 + idx) << 1) | (valid ? fg : 0u);
-            }
+            const unsigned key = keyonly_key(e, fg, valid);      // ascending sort of the complement = descending errors
+            if (ok) keys[sbase + idx] = key;
             const unsigned d = key & 255u;
             const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
             const bool full = wave * RS_WAVE_SPAN + jj * 64 + 63 < left;      // (wave-uniform)
@@ -270,8 +261,8 @@ __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a,
 // pass step 2: one workgroup per (segment, span of RS_SPAN tiles); thread = digit: running count over the span's tiles in place
 // (every access is a coalesced 1 KiB row, the loads of a span are independent of each other), span total -> span_tot
 constexpr int RS_SPAN = 32;
-__global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot) {
-    const int seg = blockIdx.x / spans, span = blockIdx.x % spans;
+__device__ __forceinline__ void tilescan_block(unsigned block, unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot) {
+    const int seg = block / spans, span = block % spans;
     const int t0 = span * RS_SPAN, t1 = min(T, t0 + RS_SPAN);
     unsigned* row = hist + ((long long)seg * T + t0) * 256 + threadIdx.x;
     unsigned v[RS_SPAN];
@@ -284,6 +275,9 @@ __global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__
         run += v[t];
     }
     span_tot[((long long)seg * spans + span) * 256 + threadIdx.x] = run;
+}
+__global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot) {
+    tilescan_block(blockIdx.x, hist, T, spans, span_tot);
 }
 
 __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // lovasz.py:29-31 at sorted position k (k1 = k+1)
@@ -317,7 +311,10 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
 // GRAD (the binning pass of the gradient: keys_in = the sorted index << 1 | fg values): the value carried with a key is not loaded
 // but computed -- the Lovasz gradient at the element's sorted position, from the foreground count before it (chunk_off + the count
 // inside the tile) exactly as lovasz_dot_kernel computes it.
-template <int NW, bool GRAD, bool KEYONLY = false>
+// IOTA (the first pass of the training path): the keys are the key-only kappa keys (error bits << 1 | fg, see keyonly_key) and the value
+// of element i is not loaded but made here: i << 1 | fg, the fg taken from its key -- the error kernel writes no values and this
+// pass reads none (134 MB of the training path's traffic at [4,16,512,512]).
+template <int NW, bool GRAD, bool KEYONLY = false, bool IOTA = false>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                              unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
                                                              int shift, const unsigned* __restrict__ hist, int spans,
@@ -332,8 +329,10 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
     __shared__ unsigned wave_tot[4];
     static_assert(!(GRAD && KEYONLY), "the gradient variant carries a value");
+    static_assert(!IOTA || (!GRAD && !KEYONLY), "IOTA is the pair sort's first pass");
     __shared__ unsigned skey[RS_TILE], sval[KEYONLY ? 1 : RS_TILE];
-    const unsigned lin = tile_of_block(xcd_map);
+    const unsigned lin = tile_of_block(xcd_map & 1);
+    const bool late = (xcd_map & 2) != 0;     // (A/B: ptb_set_tunable(17, 3) puts the histogram loads back behind the ranking)
     const int seg = lin / T, tile = lin % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long t0 = (long long)tile * RS_TILE;
@@ -344,6 +343,19 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
 #pragma unroll
         for (int w = 0; w < NW; ++w) wave_hist[w][threadIdx.x] = 0;
     }
+    // what the digit threads need from the scanned histograms does not depend on the keys: requested first, consumed after the
+    // ranking (issued behind the barrier these loads were ~2 us of exposed latency per tile)
+    unsigned rs = 0, before = 0, tile_before = 0;
+    if (threadIdx.x < 256 && !late) {
+        // this digit's elements in earlier spans of the segment, and in the whole segment
+        const int my_span = tile / RS_SPAN;
+        for (int sp = 0; sp < spans; ++sp) {
+            const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
+            before += sp < my_span ? c : 0u;
+            rs += c;
+        }
+        tile_before = hist[((long long)seg * T + tile) * 256 + threadIdx.x];
+    }
     unsigned k[ITEMS], v[ITEMS], rank[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -351,7 +363,8 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
         // (they are the last in tile order and the sort is stable) and are never written
         k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
-        if constexpr (!GRAD && !KEYONLY) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+        if constexpr (IOTA) v[j] = ((unsigned)(t0 + idx) << 1) | (~k[j] & 1u);
+        else if constexpr (!GRAD && !KEYONLY) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
     }
     __shared__ unsigned wfg[NW];
     if constexpr (GRAD) {
@@ -393,8 +406,8 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
             for (int j = 0; j < ITEMS; ++j) {
                 const int idx = wave * SPAN + j * 64 + lane;
                 if (idx < count) {
-                    const float e = from_ordered_bits(~err_keys[base + t0 + idx]);
-                    acc += (double)((e <= 0.0f ? 0.0f : e) * __uint_as_float(v[j]));
+                    const float e = __uint_as_float((~err_keys[base + t0 + idx]) >> 1);      // kappa key: error bits << 1 | fg (never negative)
+                    acc += (double)(e * __uint_as_float(v[j]));
                 }
             }
 #pragma unroll
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     __syncthreads();
     // per digit (thread = digit, the first 256 threads): waves' starts inside the run, the tile's count, the run's start inside the tile
     // and in the output
-    unsigned tot = 0, rs = 0, before = 0;
+    unsigned tot = 0;
     if (threadIdx.x < 256) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -432,19 +445,21 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
             wave_hist[w][threadIdx.x] = tot;
             tot += c;
         }
-        // this digit's elements in earlier spans of the segment, and in the whole segment
-        const int my_span = tile / RS_SPAN;
-        for (int sp = 0; sp < spans; ++sp) {
-            const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
-            before += sp < my_span ? c : 0u;
-            rs += c;
+        if (late) {
+            const int my_span = tile / RS_SPAN;
+            for (int sp = 0; sp < spans; ++sp) {
+                const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
+                before += sp < my_span ? c : 0u;
+                rs += c;
+            }
+            tile_before = hist[((long long)seg * T + tile) * 256 + threadIdx.x];
         }
     }
     const unsigned excl = block_inclusive_scan_n<NW>(tot, wave_tot) - tot;
     const unsigned dstart = block_inclusive_scan_n<NW>(rs, wave_tot) - rs;   // elements of the segment with a smaller digit
     if (threadIdx.x < 256) {
         tile_off[threadIdx.x] = excl;
-        digit_base[threadIdx.x] = dstart + before + hist[((long long)seg * T + tile) * 256 + threadIdx.x] - excl;
+        digit_base[threadIdx.x] = dstart + before + tile_before - excl;
     }
     __syncthreads();
 #pragma unroll
@@ -468,11 +483,11 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
 // phase a (foreground count of every CHUNK of the sorted order) is rs_hist_kernel<COUNT>.  (Counting inside the last scatter pass instead
 // -- one atomic per wave of staged slots, 262 k device-scope atomics on 8 192 counters -- made that pass 68 -> 176 us.)
 // phase b: exclusive scan of the chunk counts of each segment (one workgroup per segment), total -> fg_total[s]
-__global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_count, int chunks_per_seg,
-                                                                unsigned* __restrict__ fg_total) {
+__device__ __forceinline__ void chunk_scan_block(unsigned seg, unsigned* __restrict__ chunk_count, int chunks_per_seg,
+                                                 unsigned* __restrict__ fg_total) {
     __shared__ unsigned sh[256];
     __shared__ unsigned carry;
-    unsigned* cc = chunk_count + (long long)blockIdx.x * chunks_per_seg;
+    unsigned* cc = chunk_count + (long long)seg * chunks_per_seg;
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     for (int k0 = 0; k0 < chunks_per_seg; k0 += 256) {
@@ -491,7 +506,19 @@ __global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __rest
         if (threadIdx.x == 255) carry += sh[255];
         __syncthreads();
     }
-    if (threadIdx.x == 0) fg_total[blockIdx.x] = carry;
+    if (threadIdx.x == 0) fg_total[seg] = carry;
+}
+__global__ __launch_bounds__(256) void lovasz_chunk_scan_kernel(unsigned* __restrict__ chunk_count, int chunks_per_seg,
+                                                                unsigned* __restrict__ fg_total) {
+    chunk_scan_block(blockIdx.x, chunk_count, chunks_per_seg, fg_total);
+}
+// The two scans between the binning pass's histogram kernel and its scatter -- the tiles of every span, the chunks of every segment --
+// are independent of each other: one launch (a launch in this chain costs ~5 us whatever it does).
+__global__ __launch_bounds__(256) void lovasz_scans_kernel(unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot,
+                                                           unsigned n_tilescan, unsigned* __restrict__ chunk_count, int chunks_per_seg,
+                                                           unsigned* __restrict__ fg_total) {
+    if (blockIdx.x < n_tilescan) tilescan_block(blockIdx.x, hist, T, spans, span_tot);
+    else chunk_scan_block(blockIdx.x - n_tilescan, chunk_count, chunks_per_seg, fg_total);
 }
 
 
@@ -536,13 +563,13 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
         v[0] = va.x; v[1] = va.y; v[2] = va.z; v[3] = va.w; v[4] = vb.x; v[5] = vb.y; v[6] = vb.z; v[7] = vb.w;
         const unsigned kk[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { e[u] = from_ordered_bits(~kk[u]); local += v[u] & 1u; }
+        for (int u = 0; u < 8; ++u) { e[u] = __uint_as_float((~kk[u]) >> 1); local += v[u] & 1u; }
     } else {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const long long i = first + u;
             v[u] = i < P ? vals[base + i] : 0u;
-            e[u] = i < P ? from_ordered_bits(~keys[base + i]) : -INFINITY;
+            e[u] = i < P ? __uint_as_float((~keys[base + i]) >> 1) : 0.0f;
             local += v[u] & 1u;
         }
     }
@@ -654,7 +681,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_kernel(const LovArgs a, const 
 // (index << 1 | fg, gradient at the pixel's rank) pairs of exactly these pixels in arbitrary order; a workgroup puts them in pixel order
 // in LDS and streams pred / grad like lovasz_bwd_kernel.  grid.x = group * blocks, grid.y = chunks of classes.
 template <int MODE>
-__global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a, const float* __restrict__ coef, const unsigned* __restrict__ bvals,
+__global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a, const float* __restrict__ coef, const float* __restrict__ gscale,
+                                                                const unsigned* __restrict__ bvals,
                                                                 const float* __restrict__ bgrad, float* __restrict__ grad, int bs_log2,
                                                                 int nblocks, int cchunk) {
     extern __shared__ float gl[];
@@ -696,7 +724,7 @@ __global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a,
 #pragma unroll
             for (int m = 0; m < 16; ++m) gl[(bv[m] >> 1) & 4095u] = bg[m];
             __syncthreads();
-            const float cf = coef[s];
+            const float cf = gscale ? gscale[0] * coef[s] : coef[s];      // (= the [S]-sized torch product, same rounding)
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
                 const float p = pv[m], gp = gl[threadIdx.x + 256 * m];
@@ -727,7 +755,7 @@ __global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a,
 #pragma unroll 4
         for (int u = threadIdx.x; u < cnt; u += 256) gl[(bvals[sb + u] >> 1) & (bs - 1u)] = bgrad[sb + u];
         __syncthreads();
-        const float cf = coef[s];
+        const float cf = gscale ? gscale[0] * coef[s] : coef[s];      // (= the [S]-sized torch product, same rounding)
 #pragma unroll 4
         for (int u = threadIdx.x; u < cnt; u += 256) {
             const unsigned i = (unsigned)(i0 + u);
@@ -763,8 +791,8 @@ __global__ __launch_bounds__(256) void lovasz_bwd_binned_kernel(const LovArgs a,
 // loss = mean over the groups of (sum over the selected classes of seg_loss / number of selected classes), and its derivative with
 // respect to every seg_loss (losses/lovasz.py:92-108, :110-140: classes = "present" | "all"; the hinge loss is C = 1, "all").  One
 // workgroup; thread = group, fixed summation order.
-__global__ __launch_bounds__(256) void lovasz_reduce_kernel(const double* __restrict__ seg_loss, const unsigned* __restrict__ fg_total, int groups,
-                                                            int C, int present_only, float* __restrict__ loss_out, float* __restrict__ coef_out) {
+__device__ __forceinline__ void reduce_block(const double* seg_loss, const unsigned* __restrict__ fg_total, int groups,
+                                             int C, int present_only, float* __restrict__ loss_out, float* __restrict__ coef_out) {
     __shared__ double part[256];
     double acc = 0.0;
     for (int g = threadIdx.x; g < groups; g += 256) {
@@ -788,7 +816,10 @@ __global__ __launch_bounds__(256) void lovasz_reduce_kernel(const double* __rest
     }
     if (threadIdx.x == 0) *loss_out = (float)(part[0] / groups);
 }
-
+__global__ __launch_bounds__(256) void lovasz_reduce_kernel(const double* __restrict__ seg_loss, const unsigned* __restrict__ fg_total, int groups,
+                                                            int C, int present_only, float* __restrict__ loss_out, float* __restrict__ coef_out) {
+    reduce_block(seg_loss, fg_total, groups, C, present_only, loss_out, coef_out);
+}
 static int fill(LovArgs& a, const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                 int per_image, int has_ignore, int64_t ignore_label, float ignore_value) {
     if (!pred || B < 0 || C < 1 || HW < 0) return PTB_EINVAL;
@@ -805,7 +836,12 @@ static int fill(LovArgs& a, const float* pred, const int64_t* labels, const floa
 int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in the radix scatter
 int g_lovasz_fused_dot = 1;   // ptb_set_tunable key 19: the binning scatter of the training path also evaluates the loss (0: lovasz_dot_kernel)
 static void launch_scatter(unsigned tiles, hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, long long P, int T,
-                           int shift, const unsigned* hist, int spans, const unsigned* span_tot) {
+                           int shift, const unsigned* hist, int spans, const unsigned* span_tot, bool iota = false) {
+    if (iota) {
+        hipLaunchKernelGGL((rs_scatter_kernel<4, false, false, true>), dim3(tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, vout, P, T, shift, hist,
+                           spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
+        return;
+    }
     // (8 waves per workgroup -- 8 items per thread, 64 VGPRs, 24 waves per CU instead of 16 -- measured 4 % slower: more waves do not help this pass)
     hipLaunchKernelGGL((rs_scatter_kernel<4, false>), dim3(tiles), dim3(256), 0, s, kin, vin, kout, vout, P, T, shift, hist, spans, span_tot, g_rs_xcd_map,
                        (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
@@ -873,10 +909,11 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         nch = (a.C + cchunk - 1) / cchunk;
         if (nch > 65535) return PTB_EUNSUPPORTED;
         const dim3 grid((unsigned)gt, (unsigned)nch);
+        // kappa keys (keyonly_key), no values written: the first scatter pass makes them (IOTA)
         if (a.mode == LOVASZ_SOFTMAX)
-            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, vals_a, hist);
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, hist);
         else
-            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_HINGE>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, vals_a, hist);
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_HINGE>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, hist);
         if (int rc = check_launch()) return rc;
     }
     // four stable 8-bit passes, ping-ponging a -> b -> a -> b -> a
@@ -884,7 +921,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
     for (int shift = 0; shift < 32; shift += 8) {
         if (shift) hipLaunchKernelGGL(rs_hist_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist, (unsigned*)nullptr, 0);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        launch_scatter((unsigned)tiles, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot);
+        launch_scatter((unsigned)tiles, s, kin, vin, kout, vout, a.P, T, shift, hist, spans, span_tot, shift == 0);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
         unsigned* tv = vin; vin = vout; vout = tv;
@@ -899,8 +936,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         // gradient it carries (the dot kernel writes none).
         const int shift = bl + 1;
         hipLaunchKernelGGL(rs_hist_kernel<true>, dim3((unsigned)tiles), dim3(256), 0, s, vin, a.P, T, shift, hist, chunk, cps);
-        hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);
-        hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
+        hipLaunchKernelGGL(lovasz_scans_kernel, dim3(a.S * spans + a.S), dim3(256), 0, s, hist, T, spans, span_tot, (unsigned)(a.S * spans), chunk, cps, fg_total);
         if (g_lovasz_fused_dot) {
             // the binning scatter also evaluates the loss (it computes every element's gradient anyway and reads its error key):
             // no lovasz_dot_kernel, the sorted values are read once instead of twice
@@ -908,7 +944,7 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
                                hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps, kin, partial);
             hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, T, seg_loss);
         } else {
-            hipLaunchKernelGGL(lovasz_dot_kernel<false>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, vin, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
+            hipLaunchKernelGGL(lovasz_dot_kernel<true>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, (const unsigned*)nullptr, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
             hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, cps, seg_loss);
             hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift,
                                hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps);
@@ -965,9 +1001,9 @@ extern "C" int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, con
         if (nch > 65535) return PTB_EUNSUPPORTED;
         const dim3 grid((unsigned)gt, (unsigned)nch);
         if (a.mode == LOVASZ_SOFTMAX)
-            hipLaunchKernelGGL((lovasz_error_hist_kernel<LOVASZ_SOFTMAX, true>), grid, dim3(256), 0, s, a, T, cchunk, keys_a, (unsigned*)nullptr, hist);
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, hist);
         else
-            hipLaunchKernelGGL((lovasz_error_hist_kernel<LOVASZ_HINGE, true>), grid, dim3(256), 0, s, a, T, cchunk, keys_a, (unsigned*)nullptr, hist);
+            hipLaunchKernelGGL(lovasz_error_hist_kernel<LOVASZ_HINGE>, grid, dim3(256), 0, s, a, T, cchunk, keys_a, hist);
         if (int rc = check_launch()) return rc;
     }
     unsigned *kin = keys_a, *kout = keys_b;
@@ -986,10 +1022,7 @@ extern "C" int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, con
     return check_launch();
 }
 
-// Same, with the gradient left BINNED instead of scattered to pixel order: on return keys_b holds (index << 1 | fg) and vals_b the
-// gradient bits of the same element, grouped by blocks of 2^r pixels (r = the return value, 12..14; the pairs of block b of segment s
-// are at s * P + (b << r) ...).  `scratch` is not used any more (may be NULL).  PTB_EUNSUPPORTED when a segment has more than
-// 256 * 2^14 elements: use ptb_lovasz_fwd.  ptb_lovasz_bwd_binned is its backward.
+
 extern "C" int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, const float* flabels, int B, int C, int64_t HW, int mode,
                                      int per_image, int has_ignore, int64_t ignore_label, float ignore_value, uint32_t* keys_a, uint32_t* keys_b,
                                      unsigned* vals_a, unsigned* vals_b, unsigned* chunk, unsigned* fg_total,
@@ -998,9 +1031,9 @@ extern "C" int ptb_lovasz_fwd_binned(const float* pred, const int64_t* labels, c
                            chunk, fg_total, seg_loss, scratch, temp, temp_bytes, stream, true);
 }
 
-extern "C" int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const uint32_t* binned_vals,
-                                     const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode, int per_image, int has_ignore,
-                                     int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream) {
+static int lovasz_bwd_binned_impl(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const float* gscale,
+                                  const uint32_t* binned_vals, const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode,
+                                  int per_image, int has_ignore, int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream) {
     LovArgs a{};
     if (int rc = fill(a, pred, labels, flabels, B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value)) return rc;
     if (!coef || !binned_vals || !binned_grad || !grad || block_log2 < 12 || block_log2 > 14) return PTB_EINVAL;
@@ -1018,12 +1051,29 @@ extern "C" int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, c
     const size_t lds = sizeof(float) << block_log2;
     const dim3 grid((unsigned)gx, (unsigned)nch);
     if (a.mode == LOVASZ_SOFTMAX)
-        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, binned_vals, binned_grad, grad,
+        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_SOFTMAX>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, gscale, binned_vals, binned_grad, grad,
                            block_log2, (int)nblocks, cchunk);
     else
-        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_HINGE>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, binned_vals, binned_grad, grad,
+        hipLaunchKernelGGL(lovasz_bwd_binned_kernel<LOVASZ_HINGE>, grid, dim3(256), lds, (hipStream_t)stream, a, coef, gscale, binned_vals, binned_grad, grad,
                            block_log2, (int)nblocks, cchunk);
     return check_launch();
+}
+
+extern "C" int ptb_lovasz_bwd_binned(const float* pred, const int64_t* labels, const float* flabels, const float* coef, const uint32_t* binned_vals,
+                                     const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode, int per_image, int has_ignore,
+                                     int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream) {
+    return lovasz_bwd_binned_impl(pred, labels, flabels, coef, nullptr, binned_vals, binned_grad, grad, B, C, HW, mode, per_image, has_ignore, ignore_label,
+                                  ignore_value, block_log2, stream);
+}
+
+// ptb_lovasz_bwd_binned with the incoming gradient of the scalar loss as a DEVICE scalar: coefficient of segment s = gscale[0] * coef_unit[s]
+// (coef_unit = ptb_lovasz_reduce's coef_out), multiplied inside the kernel instead of by an [S]-sized launch in front of it
+extern "C" int ptb_lovasz_bwd_binned2(const float* pred, const int64_t* labels, const float* flabels, const float* coef_unit, const float* gscale,
+                                      const uint32_t* binned_vals, const float* binned_grad, float* grad, int B, int C, int64_t HW, int mode,
+                                      int per_image, int has_ignore, int64_t ignore_label, float ignore_value, int block_log2, ptb_stream_t stream) {
+    if (!gscale) return PTB_EINVAL;
+    return lovasz_bwd_binned_impl(pred, labels, flabels, coef_unit, gscale, binned_vals, binned_grad, grad, B, C, HW, mode, per_image, has_ignore,
+                                  ignore_label, ignore_value, block_log2, stream);
 }
 
 extern "C" int ptb_lovasz_bwd(const float* pred, const int64_t* labels, const float* flabels, const float* coef,

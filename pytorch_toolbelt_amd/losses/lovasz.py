@@ -19,6 +19,7 @@ __all__ = ["BinaryLovaszLoss", "LovaszLoss"]
 _SOFTMAX, _HINGE = 0, 1
 _CHUNK = 2048
 KEY_ONLY_FORWARD = True    # False: a forward without gradient also sorts (key, index << 1 | fg) pairs (A/B and tests)
+FUSED_TAIL = True          # False: the gscale * coef product and the zero "gradient" of fg_total as launches in front of the backward kernel (A/B and tests)
 BINNED_GRADIENT = True     # False: the gradient is scattered to pixel order in the forward (ptb_lovasz_fwd / ptb_lovasz_bwd; A/B and tests)
 
 
@@ -45,6 +46,7 @@ class _LovaszSegments(torch.autograd.Function):
         want_grad = bool(want_grad and ctx.needs_input_grad[0])
         gpix = torch.empty(0, dtype=torch.float32, device=dev)       # (only the scattered-gradient path fills one: n floats)
         binned = None
+        ctx.set_materialize_grads(not FUSED_TAIL)      # (no zero tensor for the int32 fg_total output's "gradient": one launch less per backward)
         if n > 0 and not want_grad and KEY_ONLY_FORWARD:
             # evaluation / no_grad: a key-only sort (ptb_lovasz_fwd_keys) -- the foreground flag rides in the key, no (index, fg)
             # values exist: half the bytes per pass, two work arrays instead of four
@@ -56,9 +58,10 @@ class _LovaszSegments(torch.autograd.Function):
                 if tb < 0:
                     raise RuntimeError("ptb_lovasz_temp_bytes failed")
                 temp = torch.empty(max(int(tb), 1), dtype=torch.uint8, device=dev)
-                rc = lib.ptb_lovasz_fwd_keys(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
-                                             1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
-                                             chunk.data_ptr(), fg_total.data_ptr(), seg_loss.data_ptr(), temp.data_ptr(), int(tb), N.stream_ptr(dev))
+                args = (pred.data_ptr(), K._ptr(labels), K._ptr(flabels), B, C, HW, mode, 1 if per_image else 0,
+                        1 if has_ignore else 0, ignore_label, ignore_value, keys[0].data_ptr(), keys[1].data_ptr(),
+                        chunk.data_ptr(), fg_total.data_ptr(), seg_loss.data_ptr(), temp.data_ptr(), int(tb))
+                rc = lib.ptb_lovasz_fwd_keys(*args, N.stream_ptr(dev))
             N.bump()
             N.check(rc, "ptb_lovasz_fwd_keys")
         elif n > 0:
@@ -115,10 +118,23 @@ class _LovaszSegments(torch.autograd.Function):
         else:
             pred, labels, flabels, gpix, coef_unit = ctx.saved_tensors
         B, C, HW, mode, per_image, has_ignore, ignore_label, ignore_value = ctx.cfg
+        if g_loss is None:                     # (set_materialize_grads(False): nothing flows into the loss)
+            return (None,) * 10
         grad = torch.empty_like(pred)          # (the kernel writes every element)
         if pred.numel():
-            coef = (g_loss.to(torch.float32) * coef_unit if coef_unit is not None else g_loss.to(torch.float32)).contiguous()
             lib = N.load()
+            g32 = g_loss.to(torch.float32)
+            if FUSED_TAIL and ctx.block_log2 is not None and coef_unit is not None and g32.numel() == 1 and g32.device == pred.device:
+                # the incoming gradient of the scalar loss stays a device scalar: the kernel forms gscale * coef_unit[s] itself
+                g32 = g32.contiguous()
+                with N.on_device(pred.device):
+                    rc = lib.ptb_lovasz_bwd_binned2(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef_unit.data_ptr(), g32.data_ptr(),
+                                                    bvals.data_ptr(), bgrad.data_ptr(), grad.data_ptr(), B, C, HW, mode, 1 if per_image else 0,
+                                                    1 if has_ignore else 0, ignore_label, ignore_value, ctx.block_log2, N.stream_ptr(pred.device))
+                N.bump()
+                N.check(rc, "ptb_lovasz_bwd_binned2")
+                return grad, None, None, None, None, None, None, None, None, None
+            coef = (g32 * coef_unit if coef_unit is not None else g32).contiguous()
             with N.on_device(pred.device):
                 if ctx.block_log2 is not None:
                     rc = lib.ptb_lovasz_bwd_binned(pred.data_ptr(), K._ptr(labels), K._ptr(flabels), coef.data_ptr(), bvals.data_ptr(), bgrad.data_ptr(),

@@ -736,7 +736,9 @@ def test_focal_softmax_activation_errors_and_big(dev):
 def test_lovasz_radix_sort_is_a_stable_descending_sort(B, C, H, W, per_image, dev):
     """The hand-written segmented radix sort behind the Lovasz losses (csrc/ptb_lovasz.hip), checked on its own through the C
     ABI workspaces: after ptb_lovasz_fwd, keys_a / vals_a hold every segment's (key, index << 1 | fg) pairs in EXACTLY the order
-    a stable descending torch.sort of the errors gives -- segment sizes off the 4096-element tile grid, ties, ignored pixels."""
+    a stable descending torch.sort of kappa = bits(max(error, +0)) << 1 | fg gives (csrc/ptb_lovasz.hip: the errors in descending
+    order, ties broken by fg, then by index; ignored pixels and non-positive errors share kappa 0) -- segment sizes off the
+    4096-element tile grid, ties, ignored pixels."""
     from pytorch_toolbelt_amd import _native as N
 
     lib = N.load()
@@ -775,12 +777,16 @@ def test_lovasz_radix_sort_is_a_stable_descending_sort(B, C, H, W, per_image, de
     valid = lab_seg != 255
     fg = ((lab_seg == cls) & valid)
     err = torch.where(valid, (fg.float() - p_seg).abs(), torch.full_like(p_seg, float("-inf")))
-    order = torch.sort(err, dim=1, descending=True, stable=True).indices
+    positive = valid & (err > 0)
+    kappa = (torch.where(positive, err, torch.zeros_like(err)).contiguous().view(torch.int32).long() << 1) | fg.long()
+    order = torch.sort(kappa, dim=1, descending=True, stable=True).indices
     want_vals = (order << 1) | torch.gather(fg.long(), 1, order)
     got_vals = vals[0].view(S, P).long() & 0xFFFFFFFF
     assert torch.equal(got_vals, want_vals)
-    got_err = torch.gather(err, 1, got_vals >> 1)
-    assert bool((got_err[:, 1:] <= got_err[:, :-1]).all())
+    got_keys = keys[0].view(S, P).long() & 0xFFFFFFFF
+    assert torch.equal(got_keys ^ 0xFFFFFFFF, torch.gather(kappa, 1, order))          # the sorted keys are ~kappa
+    got_err = torch.gather(torch.where(positive, err, torch.zeros_like(err)), 1, got_vals >> 1)
+    assert bool((got_err[:, 1:] <= got_err[:, :-1]).all())                            # = the errors in descending order
     assert torch.equal(fg_total.long(), fg.sum(1))
 
 

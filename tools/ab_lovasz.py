@@ -50,6 +50,8 @@ for rnd in range(3):
     for v in values:
         if key == 0:         # key 0: binned (1) / scattered (0) gradient (a Python switch, not a tunable of the library)
             LV.BINNED_GRADIENT = bool(v)
+        elif key == -2:      # key -2: gscale * coef inside the backward kernel, no materialised zero gradient for fg_total (1) / separate launches (0)
+            LV.FUSED_TAIL = bool(v)
         elif key == -1:      # key -1: key-only sort (1) / pair sort (0) for the forward without gradient
             LV.KEY_ONLY_FORWARD = bool(v)
         else:
