@@ -236,7 +236,7 @@ extern "C" int ptb_set_tunable(int key, int value) {
         return PTB_OK;
     }
     if (key == 17) {
-        g_rs_xcd_map = value & 3;       // bit 0: XCD-contiguous tile order; bit 1 (A/B only): histogram loads behind the ranking
+        g_rs_xcd_map = value & 7;       // bit 0: XCD-contiguous tile order; bit 1 (A/B only): histogram loads behind the ranking
         return PTB_OK;
     }
     if (key == 18) {

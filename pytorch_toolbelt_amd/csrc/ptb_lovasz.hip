@@ -391,11 +391,20 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
             const unsigned before_u = cum + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
             cum += (unsigned)__popcll(bal);
             const long long i = t0 + idx;
-            const float kf = (float)(i + 1);
+            const float kf = (float)(unsigned)(i + 1);           // (positions are < 2^31: one v_cvt_f32_u32 instead of the int64 conversion sequence)
             const float jk = jaccard_at(G, kf, (float)(before_u + fg));
-            const float left_j = __shfl_up(jk, 1);
+            // the left neighbour's J_k: one DPP move (wave_shr:1) and a v_readlane for the carry -- as ds_bpermute shuffles these were two
+            // more trips through the LDS pipeline per item, next to the ranking's own
+            float left_j, last_j;
+            if (xcd_map & 4) {       // (A/B: ptb_set_tunable(17, 5) = the ds_bpermute shuffles)
+                left_j = __shfl_up(jk, 1);
+                last_j = __shfl(jk, 63);
+            } else {
+                left_j = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(jk), __float_as_int(jk), 0x138, 0xF, 0xF, false));
+                last_j = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jk), 63));
+            }
             const float jprev = lane == 0 ? carry : left_j;
-            carry = __shfl(jk, 63);
+            carry = last_j;
             v[j] = __float_as_uint(jk - jprev);                  // lovasz.py:32-33
         }
         if (err_keys) {
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
         if (i < P) {
             const unsigned fg = v[u] & 1u;
             cum += fg;
-            const float kf = (float)(i + 1);
+            const float kf = (float)(unsigned)(i + 1);
             const float jk = jaccard_at(G, kf, (float)cum);
             const float g = jk - jprev;                       // lovasz.py:32-33
             jprev = jk;
