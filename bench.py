@@ -389,7 +389,7 @@ def e2e_unet(dev):
 
     def run(kind, autocast_dtype, batches=None):
         dimg = image.to(dev, non_blocking=True)
-        if kind == "literal":
+        if kind == "literal" or batches is not None:      # (the warm-up skips batches: not a sequence a planned merger may see)
             merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight)
         else:
             merger = CudaTileMerger(tiler.target_shape, CHANNELS, tiler.weight, crops=tiler.crops, defer=True)
