@@ -54,8 +54,8 @@ struct LovArgs {
 constexpr int RS_ITEMS = PTB_RS_ITEMS, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 64 * RS_ITEMS;
 
 // Lanes of this wave whose digit equals mine: per bit one ballot (a scalar pair) folded into the lane's mask halves with
-// XNOR against the sign-extended bit -- 6 vector instructions per bit (a per-lane select between the ballot and its complement
-// costs twice that: two scalar operands in one VOP3 are not encodable).  Returns the group size; `below` = members in lower lanes.
+// XNOR against the sign-extended bit (a per-lane select between the ballot and its complement costs three times that: two scalar
+// operands in one VOP3 are not encodable).  Returns the group size; `below` = members in lower lanes.
 __device__ __forceinline__ unsigned match_digit(unsigned d, int lane, unsigned& below) {
     unsigned m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
 #pragma unroll
@@ -67,9 +67,7 @@ __device__ __forceinline__ unsigned match_digit(unsigned d, int lane, unsigned& 
         m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (unsigned)bal, (unsigned)sb, 0x90);
         m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (unsigned)(bal >> 32), (unsigned)sb, 0x90);
     }
-    const unsigned lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
-    const unsigned lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
-    below = __popc(m_lo & lt_lo) + __popc(m_hi & lt_hi);
+    below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));      // set bits of the mask below this lane (v_mbcnt: no lane masks needed)
     return __popc(m_lo) + __popc(m_hi);
 }
 
