@@ -548,6 +548,26 @@ class _StreamWork:
         torch.cuda.current_stream(self.device).wait_event(self.event)
 
 
+class _HostStagedWork:
+    """Point-to-point transfers of DEVICE rectangles under a backend that is not RCCL (gloo: the CPU tests' stand-in, also used with
+    real kernels by the one-GPU process tests): staged through host tensors explicitly.  (torch's gloo send / recv take a tensor's raw
+    data pointer; handed a device tensor they read and write HBM from a CPU thread, through the BAR, with no ordering against the
+    stream that packs or consumes the rectangle -- an intermittent wrong answer, seen as a 1-in-10 failure of the pipelined process
+    test.)  ``wait()``: the transfers are done and the received rectangles are in their device buffers, in stream order."""
+
+    __slots__ = ("works", "host_recv", "dev_recv", "host_send")
+
+    def __init__(self, works, host_recv, dev_recv, host_send):
+        self.works, self.host_recv, self.dev_recv, self.host_send = works, host_recv, dev_recv, host_send
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for h, d in zip(self.host_recv, self.dev_recv):
+            d.copy_(h)
+        self.works, self.host_send = [], None
+
+
 class RcclExchange:
     """An RCCL communicator of this library's own for the halo exchange (``ptb_halo_exchange``: all of a rank's sends and receives as
     one ncclGroup posted from C on a side stream), instead of ``torch.distributed.batch_isend_irecv``.  Collective: every rank of
@@ -1010,14 +1030,34 @@ class ShardedTileMerger:
                                       after_event=d.ready_event if all_packed_in_c else None)
             slot.pending = [work if work is not None else self.exchange]
             return
+        staged = self.device.type == "cuda" and self._p2p_through_host()
+        host_send, host_recv = [], []
         for k, (buf, (dst, r0, r1, c0, c1)) in enumerate(zip(slot.send_buf, self.sends)):
             if d is None or not d.packed[k]:
                 buf.copy_(self._rect(r0, r1, c0, c1))     # pack the strided rectangle (its tiles are all in)
+            if staged:
+                buf = buf.cpu()                           # (stream-ordered behind the pack, done when it returns)
+                host_send.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, self._global_rank(dst), self.group))
         for buf, (src, *_rect) in zip(slot.recv_buf, self.recvs):
+            if staged:
+                buf = torch.empty(buf.shape, dtype=buf.dtype)
+                host_recv.append(buf)
             ops.append(dist.P2POp(dist.irecv, buf, self._global_rank(src), self.group))
         if ops:
-            slot.pending = dist.batch_isend_irecv(ops)
+            works = dist.batch_isend_irecv(ops)
+            slot.pending = [_HostStagedWork(works, host_recv, slot.recv_buf, host_send)] if staged else works
+
+    def _p2p_through_host(self):
+        """Device rectangles under a backend other than RCCL travel through host tensors (see ``_HostStagedWork``)."""
+        cached = getattr(self, "_p2p_host", None)
+        if cached is None:
+            try:
+                cached = str(self.dist.get_backend(self.group)).lower() != "nccl"
+            except Exception:  # noqa: BLE001  (a stand-in without backends: whatever it does with the tensors is its business)
+                cached = False
+            self._p2p_host = cached
+        return cached
 
     def _global_rank(self, r):
         if self.group is None:
