@@ -585,3 +585,29 @@ def test_rank_grid_plan_at_the_headline_geometry():
     assert (cover == 1).all()
     tiles_plan = band_plan(crops, 8, 5120, "tiles")
     assert max((r1 - r0) * (c1 - c0) * 16 for p in tiles_plan for _d, r0, r1, c0, c1 in p["sends"]) > 18.8e6
+
+
+def test_host_staged_work_delivers_after_the_transfers():
+    """``_HostStagedWork`` (device rectangles under a non-RCCL backend travel through host tensors): ``wait()`` first joins every
+    transfer, then copies what was received into the device-side buffers -- never the other way round."""
+    from pytorch_toolbelt_amd.parallel import _HostStagedWork
+
+    order = []
+    host = [torch.zeros(2, 3), torch.zeros(4)]
+    dev = [torch.full((2, 3), -1.0), torch.full((4,), -1.0)]
+
+    class _W:
+        def __init__(self, k):
+            self.k = k
+
+        def wait(self):
+            order.append(self.k)
+            host[self.k].fill_(float(self.k + 1))      # the data arrives with the transfer's completion
+
+    w = _HostStagedWork([_W(0), _W(1)], host, dev, [torch.ones(1)])
+    assert float(dev[0].max()) == -1.0
+    w.wait()
+    assert order == [0, 1] and float(dev[0].min()) == 1.0 and float(dev[1].min()) == 2.0
+    assert w.works == [] and w.host_send is None
+    w.wait()                                           # idempotent: nothing left to join, the same data again
+    assert float(dev[1].max()) == 2.0
