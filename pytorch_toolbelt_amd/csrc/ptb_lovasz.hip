@@ -56,11 +56,11 @@ constexpr int RS_ITEMS = PTB_RS_ITEMS, RS_TILE = 256 * RS_ITEMS, RS_WAVE_SPAN = 
 // Lanes of this wave whose digit equals mine: per bit one ballot (a scalar pair) folded into the lane's mask halves with
 // XNOR against the sign-extended bit (a per-lane select between the ballot and its complement costs three times that: two scalar
 // operands in one VOP3 are not encodable).  Returns the group size; `below` = members in lower lanes.
-__device__ __forceinline__ unsigned match_digit(unsigned d, int lane, unsigned& below) {
+__device__ __forceinline__ unsigned match_digit(unsigned key, int shift, unsigned& below) {      // digit = bits shift .. shift+7 of key
     unsigned m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-        const int sb = ((int)(d << (31 - b))) >> 31;              // 0 or ~0 (v_bfe_i32)
+        const int sb = __builtin_amdgcn_sbfe((int)key, (unsigned)(shift + b), 1u);      // 0 or ~0: v_bfe_i32 straight from the key
         const unsigned long long bal = __ballot(sb < 0);
         // m &= ~(ballot ^ sb) as ONE gfx950 three-input bit operation per mask half (truth table 0x90 = a & ~(b ^ c)): 4 vector
         // instructions per bit instead of the 6-7 the two-input forms compile to
@@ -325,7 +325,6 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     static_assert(!GRAD || NW == 4, "the gradient variant counts foreground per pair of waves (= one CHUNK)");
     constexpr int ITEMS = RS_TILE / (NW * 64), SPAN = 64 * ITEMS, NT = NW * 64;
     __shared__ unsigned wave_hist[NW][256];  // per wave: running digit counts, then the wave's start inside the tile's digit run
-    __shared__ unsigned tile_off[256];       // start of every digit run inside the staged tile
     __shared__ unsigned digit_base[256];     // global position of slot i of digit d = digit_base[d] + i
     __shared__ unsigned wave_tot[4];
     static_assert(!(GRAD && KEYONLY), "the gradient variant carries a value");
@@ -436,7 +435,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
         unsigned below;
-        const unsigned group = match_digit(d, lane, below);
+        const unsigned group = match_digit(k[j], shift, below);
         const unsigned old = wave_hist[wave][d];                    // every lane of the group reads the counter ...
         __builtin_amdgcn_wave_barrier();
         if (below == 0) wave_hist[wave][d] = old + group;           // ... before its first lane advances it
@@ -467,14 +466,16 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     const unsigned excl = block_inclusive_scan_n<NW>(tot, wave_tot) - tot;
     const unsigned dstart = block_inclusive_scan_n<NW>(rs, wave_tot) - rs;   // elements of the segment with a smaller digit
     if (threadIdx.x < 256) {
-        tile_off[threadIdx.x] = excl;
+        // (the run's start inside the staged tile goes into every wave's start: the staging below reads ONE table per element)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) wave_hist[w][threadIdx.x] += excl;
         digit_base[threadIdx.x] = dstart + before + tile_before - excl;
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
-        const unsigned slot = tile_off[d] + wave_hist[wave][d] + rank[j];
+        const unsigned slot = wave_hist[wave][d] + rank[j];
         skey[slot] = k[j];
         if constexpr (!KEYONLY) sval[slot] = v[j];
     }
