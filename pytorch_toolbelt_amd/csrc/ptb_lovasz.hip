@@ -356,14 +356,29 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         tile_before = hist[((long long)seg * T + tile) * 256 + threadIdx.x];
     }
     unsigned k[ITEMS], v[ITEMS], rank[ITEMS];
+    const bool full_tile = count == RS_TILE;       // (all but a segment's last tile: no per-element guards, the loads issue back to back)
+    if (full_tile) {
+        const unsigned* kp = keys_in + base + t0 + wave * SPAN + lane;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int idx = wave * SPAN + j * 64 + lane;
-        // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
-        // (they are the last in tile order and the sort is stable) and are never written
-        k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
-        if constexpr (IOTA) v[j] = ((unsigned)(t0 + idx) << 1) | (~k[j] & 1u);
-        else if constexpr (!GRAD && !KEYONLY) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+        for (int j = 0; j < ITEMS; ++j) k[j] = kp[j * 64];
+        if constexpr (!GRAD && !KEYONLY && !IOTA) {
+            const unsigned* vp = vals_in + base + t0 + wave * SPAN + lane;
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) v[j] = vp[j * 64];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = wave * SPAN + j * 64 + lane;
+            // elements beyond the segment end are padded with the largest key: they rank behind every real element of the tile
+            // (they are the last in tile order and the sort is stable) and are never written
+            k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;
+            if constexpr (!GRAD && !KEYONLY && !IOTA) v[j] = idx < count ? vals_in[base + t0 + idx] : 0u;
+        }
+    }
+    if constexpr (IOTA) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) v[j] = ((unsigned)(t0 + wave * SPAN + j * 64 + lane) << 1) | (~k[j] & 1u);
     }
     __shared__ unsigned wfg[NW];
     if constexpr (GRAD) {
@@ -480,6 +495,17 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         if constexpr (!KEYONLY) sval[slot] = v[j];
     }
     __syncthreads();
+    if (full_tile) {
+#pragma unroll
+        for (int u = 0; u < ITEMS; ++u) {
+            const int i = threadIdx.x + u * NT;
+            const unsigned kk = skey[i];
+            const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
+            keys_out[pos] = kk;
+            if constexpr (!KEYONLY) vals_out[pos] = sval[i];
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < count; i += NT) {
         const unsigned kk = skey[i];
         const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
