@@ -227,6 +227,8 @@ def _hinge_flat(logits, labels):
         return F64(0.0)
     lab = np.asarray(labels, dtype=F64)
     err = 1.0 - np.asarray(logits, dtype=F64) * (2.0 * lab - 1.0)
+    # (equal errors: the reference's torch.sort leaves their order open and the loss does not depend on it; stable here, by the
+    # foreground flag and then by index in the HIP sort -- tests compare gradients of tied elements with a tolerance, not bits)
     order = np.argsort(-err, kind="stable")
     return float(np.dot(np.maximum(err[order], 0.0), lovasz_grad(lab[order])))
 
