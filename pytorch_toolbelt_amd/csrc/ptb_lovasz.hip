@@ -10,15 +10,16 @@
 //      from the element's position and its key
 //   2. a hand-written segmented LSD radix sort for gfx950 (below): every segment is sorted by its 32-bit keys in four 8-bit
 //      passes; a pass = per-tile digit histograms (wave-private LDS counters), a scan over the tiles of every segment, and a
-//      stable scatter that ranks the 4096 keys of a tile with ballot-matched lane groups (no atomics where order matters), stages them by digit in LDS and writes every digit run coalesced (tile-major histograms, scanned in spans
-//      of 32 tiles, so every histogram access is a coalesced 1 KiB row).  No inter-workgroup communication,
-//      so it is deterministic and needs no forward-progress assumptions.  (Round 1 used rocPRIM's radix sort over 64-bit
+//      stable scatter that ranks the 4096 keys of a tile with ballot-matched lane groups (no atomics where order matters; the
+//      match folds each ballot into the lane's mask with gfx950's three-input v_bitop3_b32), stages them by digit in LDS and
+//      writes every digit run coalesced (tile-major histograms, scanned in spans of 32 tiles, so every histogram access is a
+//      coalesced 1 KiB row).  No inter-workgroup communication, so it is deterministic and needs no forward-progress assumptions.  (Round 1 used rocPRIM's radix sort over 64-bit
 //      composite keys here: 0.72 ms of the 1.29 ms for 16 segments of 1 M.)
 //   3. foreground count per 2048-element chunk of the sorted order (the tile-shaped histogram kernel in count form) -> chunk scan ->
 //      dot kernel: Jaccard gradient grad_k = J_k - J_{k-1} from the prefix count, sum_k relu(e_k) * grad_k as one partial sum per
 //      workgroup, added per segment in a fixed order; ptb_lovasz_reduce: the class / image means as one kernel
 //   4. for the backward the gradient at every element's rank is BINNED: one more pass of the sort's three kernels, keyed by the
-//      pixel block (index >> 12..14), whose scatter kernel computes grad_k on the way; the backward kernel puts a block's pairs in
+//      pixel block (index >> 12..14), whose scatter kernel computes grad_k -- and the segment's loss -- on the way; the backward kernel puts a block's pairs in
 //      pixel order in LDS: d(loss)/d(pred) = coef[segment] * grad_at_pixel * d(error)/d(pred).  (ptb_lovasz_fwd / ptb_lovasz_bwd keep
 //      the older form -- the dot kernel scatters grad_k to pixel order word by word -- for segments of more than 4 M elements.)
 // No host synchronisation anywhere: class presence (G > 0) is a device array.
