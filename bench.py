@@ -868,15 +868,16 @@ def main():
 
     # ---- secondary timings (single GPU): what each API extension of the headline configuration buys, driver-visible
     variants = None
+    region_bytes_all = VIEWS * n_tiles * CHANNELS * TILE * TILE * 4 + CHANNELS * 5120 * 5120 * 4   # 12 532 580 352 B
     if not sharded and not args.no_variants:
         from pytorch_toolbelt_amd.inference import tta as _tta
 
         from pytorch_toolbelt_amd.inference import tiles as _tiles
 
-        def variant(make, literal=False, fresh=False, eager=False, self_plan=False):
-            m = make()
+        def variant(make, literal=False, fresh=False, eager=False, self_plan=True):
             prev = (_tta.set_lazy_deaugment(not eager), _tiles.set_auto_plan(self_plan))
             _tiles._auto.clear()
+            m = make()            # (after the switches: a merger reads the self-planning setting when it is constructed)
 
             def vstep():
                 nonlocal m
@@ -899,13 +900,15 @@ def main():
             finally:
                 _tta.set_lazy_deaugment(prev[0])
                 _tiles.set_auto_plan(prev[1])
+                _tiles._auto.clear()
             del m
             return round(vr[1] / args.steps * 1e3, 4), mode
 
         mk = lambda **kw: (lambda: TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, **kw))  # noqa: E731
         lit, lit_mode = variant(mk(), literal=True)
         lit_new, lit_new_mode = variant(mk(), literal=True, fresh=True)
-        lit_sp, lit_sp_mode = variant(mk(), literal=True, self_plan=True)
+        lit_inc, lit_inc_mode = variant(mk(), literal=True, self_plan=False)
+        frac = lambda ms: round(region_bytes_all / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # noqa: E731
         variants = {
             "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None))[0],
             "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256))[0],
@@ -913,20 +916,23 @@ def main():
             "unplanned_fused_ms": variant(mk(auto_plan=False))[0],
             "dropin_literal_ms": lit,
             "dropin_literal_merger_mode": lit_mode,
+            "dropin_literal_hbm_frac": frac(lit),
             "dropin_literal_new_merger_per_image_ms": lit_new,
             "dropin_literal_new_merger_per_image_mode": lit_new_mode,
-            "dropin_literal_self_planned_ms": lit_sp,
-            "dropin_literal_self_planned_mode": lit_sp_mode,
-            "dropin_literal_eager_ms": variant(mk(), literal=True, eager=True)[0],
+            "dropin_literal_new_merger_per_image_hbm_frac": frac(lit_new),
+            "dropin_literal_no_self_planning_ms": lit_inc,
+            "dropin_literal_no_self_planning_mode": lit_inc_mode,
+            "dropin_literal_eager_ms": variant(mk(), literal=True, eager=True, self_plan=False)[0],
             "note": "ms per 5000x5000 image, median of 3 runs of K steps; deferred_bands = TileMerger(crops=, defer=True) + "
                     "integrate_batch_deaugment (the headline); planned_no_defer = TileMerger(crops=) + integrate_batch_deaugment; "
                     "unplanned_fused = TileMerger(auto_plan=False) + integrate_batch_deaugment + merge(); dropin_literal = the reference's "
-                    "literal calls, no API extension: TileMerger(shape, C, weight) + integrate_batch(tta.d4_image_deaugment(y), crops) + "
-                    "merge() -- the de-augmentation comes back as a lazy handle the merger fuses into its launch (reset() per image; "
-                    "_new_merger_per_image: a new TileMerger per image as in the README); _self_planned: the same with "
-                    "set_auto_plan(True) (opt-in: the merger plans itself from the crop sequence of the previous image and keeps its "
-                    "accumulators exact); dropin_literal_eager = lazy handles switched off, pytorch_toolbelt_amd.set_strict_dropin(): "
-                    "the reduced tile travels through HBM, separate merge pass",
+                    "literal calls, no API extension, library defaults: TileMerger(shape, C, weight) + integrate_batch(tta.d4_image_deaugment(y), "
+                    "crops) + merge() -- the de-augmentation comes back as a lazy handle the merger fuses into its launch, and from the second "
+                    "image of a geometry on the merger plans itself into deferred bands from the crop sequence of the previous image (reset() per "
+                    "image; _new_merger_per_image: a new TileMerger per image as in the README); _no_self_planning: tiles.set_auto_plan(False) "
+                    "(round 4's default: lazy handle fused, accumulator in HBM, separate merge pass); dropin_literal_eager = "
+                    "pytorch_toolbelt_amd.set_strict_dropin(): no lazy handles, no self-planning -- the reduced tile travels through HBM; "
+                    "_hbm_frac = the region's 12 532 580 352 algorithmic bytes / ms / 8 TB/s",
         }
 
     if args.diag and rank == 0 and not use_dist:   # (extra steps on one rank only would leave the others' halo exchanges unmatched)
@@ -1140,6 +1146,14 @@ def main():
                                      "note": "`value` IS the first-allocation figure: the model-output pool as torch's allocator first handed it out"},
                 "best_placement": best_placement,
                 "fallback": fallback,
+                "dropin_literal": None if variants is None else {
+                    "ms_per_step": variants["dropin_literal_new_merger_per_image_ms"],
+                    "value_MP_s": round(IMAGE[0] * IMAGE[1] / 1e3 / variants["dropin_literal_new_merger_per_image_ms"], 1),
+                    "region_hbm_frac": variants["dropin_literal_new_merger_per_image_hbm_frac"],
+                    "merger_mode": variants["dropin_literal_new_merger_per_image_mode"],
+                    "note": "the reference's loop verbatim on this library's defaults (README.md:201-226: a new TileMerger(shape, C, weight) per "
+                            "image, integrate_batch(tta.d4_image_deaugment(y), crops), merge()) -- no crops=, no defer=, no "
+                            "integrate_batch_deaugment; `value` above is the same kernels reached through the explicit extensions"},
                 "host_issue_ms_per_step": round(host_ms, 4),
                 "timing": f"value = median of {len(repeat_ms)} runs of exactly {args.steps} steps, each bracketed by barrier + synchronize",
                 "repeat_ms_per_step": repeat_ms,

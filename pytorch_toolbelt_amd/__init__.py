@@ -10,10 +10,9 @@ def set_strict_dropin(flag: bool = True):
     """Strict drop-in mode (extension, env-free): every call is evaluated where and when the reference evaluates it --
     ``*_image_deaugment`` return real tensors (no lazy handles: ``inference/_lazy.py``) and a ``TileMerger`` without ``crops=`` never
     plans itself from the previous image (``inference/tiles.py``).  Results are the same either way; what changes is that nothing
-    is fused across the two calls of ``merger.integrate_batch(tta.d4_image_deaugment(y), crops)``.  ``flag=False`` switches the lazy
-    handles back on (self-planning stays opt-in: ``tiles.set_auto_plan(True)``).  Returns the previous ``(lazy de-augmentation,
-    self-planning)`` settings."""
+    is fused across the two calls of ``merger.integrate_batch(tta.d4_image_deaugment(y), crops)``, and no model output is read
+    after the ``integrate_batch`` call that was handed it.  ``flag=False`` switches both back on (the defaults).  Returns the previous
+    ``(lazy de-augmentation, self-planning)`` settings."""
     from .inference import _lazy, tiles
 
-    prev_plan = tiles.set_auto_plan(False) if flag else tiles._AUTO_PLAN
-    return _lazy.set_enabled(not flag), prev_plan
+    return _lazy.set_enabled(not flag), tiles.set_auto_plan(not flag)

@@ -19,6 +19,7 @@ import collections
 import ctypes
 import threading
 import warnings
+import weakref
 
 import numpy as np
 import torch
@@ -26,6 +27,12 @@ import torch
 from .. import _native as N
 
 FRESH_ROWS = 32  # rows of a first-touch block = default chunk rows of the view kernels (64 columns wide)
+
+
+def default_defer_rows():
+    import os
+
+    return int(os.environ.get("PTB_DEFER_ROWS", "1024"))
 
 _warned = set()
 
@@ -59,7 +66,7 @@ def held_entry(batch):
     return p0, p0 + batch.numel() * batch.element_size(), tensor_version(batch)
 
 
-def check_held(held, batch, span, launches, what):
+def check_held(held, batch, span, launches, what, hint="construct the merger without defer=True"):
     """The contract of deferred merging, enforced: a held batch is read by a LATER launch, so (1) a new batch must not live in
     the memory of one that is still held -- a model writing into a static output buffer (HIP graphs, ``out=``, preallocated
     outputs) has then already overwritten data the merger has not read, which no fallback can bring back -- and (2) a held batch
@@ -71,28 +78,28 @@ def check_held(held, batch, span, launches, what):
             raise RuntimeError(f"{what}: this batch occupies memory of an earlier batch that is still held for a later launch (bytes "
                                f"{max(p0, h[-3]):#x}..{min(p1, h[-2]):#x}) -- the model writes its outputs into a reused buffer, so the earlier "
                                "predictions are already gone.  Deferred merging needs every batch to stay alive and unmodified until its rows "
-                               "are merged: hand over fresh tensors (or clones), or construct the merger without defer=True.")
+                               f"are merged: hand over fresh tensors (or clones), or {hint}.")
     if launches:
         for i, h in enumerate(held):
             if h[-1] is not None and tensor_version(h[0]) != h[-1]:
                 raise RuntimeError(f"{what}: held batch {i} of the rows about to be merged was modified in place after it was handed to the "
                                    "merger (its version counter moved).  Deferred merging reads the batches later: keep them unmodified, "
-                                   "or construct the merger without defer=True.")
+                                   f"or {hint}.")
 
 
 class HeldBatches:
     """The model outputs a deferred merger has taken into custody, in integration order: rows ``(tensor, replay, last launch group
     that reads it, p0, p1, version)``.  One object per merger / per rank band; ``admit`` is the contract check above."""
 
-    __slots__ = ("rows", "what")
+    __slots__ = ("rows", "what", "hint")
 
     def __init__(self, what):
-        self.rows, self.what = [], what
+        self.rows, self.what, self.hint = [], what, "construct the merger without defer=True"
 
     def admit(self, batch, launch_due):
         """Check a batch against everything still held; returns its span for ``keep``."""
         span = held_entry(batch)
-        check_held(self.rows, batch, span, launch_due, self.what)
+        check_held(self.rows, batch, span, launch_due, self.what, self.hint)
         return span
 
     def keep(self, batch, span, replay=None, last_group=0):
@@ -200,6 +207,22 @@ class Bands:
         self.n_bands = n_bands
         self.last_group = last_group    # plan index of a tile -> the last launch group that reads it
         self.monotone = monotone        # groups complete in index order (row-major crops): batches can be released early
+        self.ready = None               # event behind the table upload (a plan shared through the self-planning cache is used on other streams)
+        self.rows = None                # rows per launch group it was built with
+
+    def peak_tiles(self):
+        """The most tiles in custody at any launch: when group g goes out, every tile handed in so far that g or a later group reads
+        is still held (row-major crops: a contiguous index range); a crop order whose groups do not complete in index order holds
+        everything to the end."""
+        n = len(self.last_group)
+        if not self.monotone:
+            return n
+        peak, first = 0, 0
+        for g, (_y0, _y1, last) in enumerate(self.bands):
+            while first < n and self.last_group[first] < g:
+                first += 1
+            peak = max(peak, last + 1 - first)
+        return peak
 
     def __del__(self):
         try:
@@ -230,7 +253,11 @@ class Bands:
         lib.ptb_band_plan_info(handle, None, None, None, last_group.ctypes.data_as(N._i64p), rows_arr.ctypes.data_as(N._i64p))
         groups = [tuple(int(v) for v in rows_arr[3 * g:3 * g + 3]) for g in range(ng.value)]
         lasts = [g[2] for g in groups]
-        return Bands(handle, table, groups, nb.value, last_group, all(a <= b for a, b in zip(lasts, lasts[1:])))
+        out = Bands(handle, table, groups, nb.value, last_group, all(a <= b for a, b in zip(lasts, lasts[1:])))
+        out.rows = int(rows)
+        out.ready = torch.cuda.Event()
+        out.ready.record(torch.cuda.current_stream(device))
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ strategies
@@ -254,18 +281,29 @@ class DeferredBands:
     Until the first group is launched any deviation from the plan simply replays the held batches through the incremental path;
     afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
 
-    def __init__(self, merger, bands):
-        self.m = merger
+    def __init__(self, merger, bands, soft=False):
+        self.m = weakref.proxy(merger)   # (strategies never own their merger: no reference cycle, a dropped merger frees its HBM at once)
         self.bands = bands               # Bands, or None: this merger does not defer (the strategy is never active)
+        self.soft = soft                 # the merger planned ITSELF into this mode: nothing it was never asked for may raise (see soften)
         self.held = HeldBatches("TileMerger(defer=True)")
         self.done = 0                    # launch groups issued for this image
         self.active = False
+        self.budget_checked = False
+        self.rebind(bands, soft)
         self.reset()
+
+    def rebind(self, bands, soft):
+        """Another band plan (or none) for the next image: a self-planned merger gets its plan from the geometry's cache at reset()."""
+        self.bands, self.soft = bands, soft
+        self.held.what = "TileMerger (self-planned deferred bands)" if soft else "TileMerger(defer=True)"
+        self.held.hint = ("construct it with TileMerger(..., auto_plan=False) (or call pytorch_toolbelt_amd.set_strict_dropin()): every batch "
+                          "is then read inside integrate_batch") if soft else "construct the merger without defer=True"
 
     def reset(self):
         self.active = self.bands is not None
         self.held.clear()
         self.done = 0
+        self.budget_checked = False
         if self.bands is not None:
             N.load().ptb_band_plan_reset(self.bands.handle)
 
@@ -279,6 +317,8 @@ class DeferredBands:
         if not self.active:
             return
         if self.done:
+            if self.soft:
+                return self.soften(what)
             raise RuntimeError(f"TileMerger(defer=True): {what} is not available after bands of the image were merged; "
                                "integrate the planned tiles and call merge(), or construct the merger without defer=True")
         m = self.m
@@ -289,6 +329,40 @@ class DeferredBands:
         m._log, m._applied = [], 0
         for batch, (coords, views, reduction), *_rest in held:
             m._accumulate(batch, coords, views, reduction)
+
+    def soften(self, what):
+        """A merger that deferred ON ITS OWN ACCOUNT (self-planned) is asked for something deferred merging cannot serve after bands
+        of the image went out -- a tile off the remembered sequence, ``merge()`` of an image that ends early, a read of ``image``.
+        The caller never opted into that restriction, so nothing raises: the merger turns back into the ordinary accumulating one.
+        Rows already merged get ``merged * norm`` as their weighted sums (every tile over them has been blended: the one place where
+        this library's result can differ from the sequential sums, by the rounding of one multiply -- far inside the 1e-5 contract,
+        said once), the batches still held are replayed onto the rest, and the image carries on incrementally."""
+        m, bands = self.m, self.bands
+        warn_once(("soften", m._selfplan.key), f"TileMerger: {what} after the self-planned merger had already merged rows of the image from held "
+                                               "model outputs; continuing on the ordinary accumulate + merge path (rows merged so far are carried over "
+                                               "as merged * norm_mask: equal to the sequential sums within one float32 rounding).  "
+                                               "TileMerger(..., auto_plan=False) or pytorch_toolbelt_amd.set_strict_dropin() keep every image on that path.")
+        lib = N.load()
+        launched = [(y0, y1) for (y0, y1, _last) in bands.bands if y1 > y0 and lib.ptb_band_plan_rows_launched(bands.handle, y0, y1) == 1]
+        held = self.held.take_all()
+        self.active = False
+        merged, m._merged = m._merged, None
+        plan = m._plan
+        plan.restart()
+        plan.active = False
+        log = list(m._log)                 # every crop of the image so far (the normaliser is built from it); the replay must not log twice
+        m._materialize()
+        for batch, (coords, views, reduction), *_rest in held:
+            m._accumulate(batch, coords, views, reduction)
+        m._log = log
+        m._norm_ready()
+        for y0, y1 in launched:
+            norm = m._norm[:, y0:y1]
+            m._image[:, y0:y1] = torch.where(norm == 0, torch.zeros_like(norm), merged[:, y0:y1] * norm)
+
+    def over_budget(self, per_tile_bytes, B):
+        """Would this image keep more model outputs alive than the byte budget of self-planned deferral (``PTB_DEFER_BYTES``)?"""
+        return (self.bands.peak_tiles() + B) * per_tile_bytes > defer_budget()
 
     def launch_due(self, end):
         """Will a submit that brings the planned tiles up to index ``end`` (exclusive) launch a group?  (Only then are the held
@@ -303,6 +377,12 @@ class DeferredBands:
         (``ptb_band_plan_submit``: the pointer bookkeeping and the launches happen in C).  Returns its code: < 0 nothing was taken."""
         m, bands = self.m, self.bands
         plan = m._plan
+        if self.soft and not self.budget_checked:
+            self.budget_checked = True
+            per_tile = n_views * m.channels * int(m.weight.shape[1]) * int(m.weight.shape[2]) * batch.element_size()
+            if self.over_budget(per_tile, B):
+                m._selfplan.too_big(per_tile, B)
+                return N.PTB_EUNSUPPORTED
         span = self.held.admit(batch, self.launch_due(pos + B))
         if m._merged is None:
             m._merged = torch.empty_like(m._image)
@@ -359,9 +439,11 @@ class DeferredBands:
             varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
             rc = self._submit(batch, coords, views, plan.pos, B, dcode, len(views) if views is not None else 1, varr, reduction)
         if rc == N.PTB_EUNSUPPORTED:
-            warn_once(("defer-deviation",), "TileMerger(defer=True): a batch deviates from the planned crop sequence / configuration (or "
-                                            "norm_mask was read); leaving deferred mode for this image, the held batches are replayed incrementally.")
-            self.flush("an unplanned tile batch")
+            if not self.soft:
+                warn_once(("defer-deviation",), "TileMerger(defer=True): a batch deviates from the planned crop sequence / configuration (or "
+                                                "norm_mask was read); leaving deferred mode for this image, the held batches are replayed incrementally.")
+            self.flush("a tile batch off the remembered crop sequence" if self.soft else "an unplanned tile batch", keep_plan=self.soft and self.done == 0
+                       and plan.active and not m._eager_norm and plan.follows(xy, B))
             return False
         if rc < 0:
             N.check(rc, "TileMerger.integrate_batch (deferred bands)")
@@ -383,7 +465,7 @@ class PlannedBlocks:
     (PTB_PLANNED_KEEP_SUMS), so its accumulators stay exact."""
 
     def __init__(self, merger):
-        self.m = merger
+        self.m = weakref.proxy(merger)
 
     def _launch(self, batch, dcode, n_views, varr, code, xs, ys, B):
         m = self.m
@@ -503,7 +585,7 @@ class Incremental:
     launch per batch adds the weighted tiles to the accumulator in batch order, ``merge()`` divides."""
 
     def __init__(self, merger):
-        self.m = merger
+        self.m = weakref.proxy(merger)
 
     def take(self, batch, coords, xy, xs, ys, views, n_views, varr, reduction, dcode):
         m = self.m
@@ -549,19 +631,35 @@ class Incremental:
 # ------------------------------------------------------------------------------------------------ self-planning mergers
 # The reference's loop builds `TileMerger(tiler.target_shape, C, tiler.weight)` -- no crop list -- for every image and feeds it the
 # same crops in the same order (README.md:201-226).  A merger without `crops=` therefore records the crop sequence it saw
-# (at `merge()`), and the NEXT merger of the same geometry and window (or the same one after `reset()`) plans itself from it:
-# normaliser precomputed, every block divided in the launch that brings its last tile, no separate merge pass.  Any deviation
-# from the remembered sequence drops back to the ordinary path for the rest of that image (bit-identical results either way).
-# Opt-in since round 4 (PTB_AUTO_PLAN=1 / tiles.set_auto_plan(True)): with the lazy de-augmentation handle already fusing the two
-# reference calls into one launch, and self-planned mergers keeping their accumulators exact (one more store of the image), planning
-# from the previous image buys ~0.5 % over the ordinary fused path at the headline geometry -- not worth module-level caches by default.
-AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser in HBM once planned)
+# (at `merge()`), and the NEXT merger of the same geometry and window (or the same one after `reset()`) plans itself from it.
+# Round 5: the plan it gets is the one `TileMerger(crops=, defer=True)` gets -- deferred bands: the merger keeps references to the
+# model outputs of one launch group and merges every band in the launch that brings its last tile, no accumulator in HBM -- so the
+# reference's literal calls reach the headline kernel from the second image of a geometry on.  What the caller never asked for is
+# kept away from them:
+#   * the FIRST image of a geometry always runs incrementally, and while it does the merger watches the model outputs it is handed
+#     (`SelfPlanning.observe`): a batch that lives in the memory of the previous, still referenced one means the model writes into a
+#     static buffer (HIP graphs, `out=`) -- such a geometry never defers (its mergers take the planned-block kernels, which read
+#     every batch inside `integrate_batch`);
+#   * the model outputs kept alive are bounded (`PTB_DEFER_BYTES`, default 4 GiB: rows per launch are halved until the peak fits,
+#     else planned blocks);
+#   * any deviation -- a batch off the remembered sequence, an image that ends early, a read of `image` / `norm_mask`, `merge_()` --
+#     turns the merger back into the ordinary one (`DeferredBands.soften`), without an exception.
+# On by default since round 5; `TileMerger(auto_plan=False)`, `tiles.set_auto_plan(False)`, `PTB_AUTO_PLAN=0` or
+# `pytorch_toolbelt_amd.set_strict_dropin()` switch it off.
+AUTO_MAX = 8            # geometries remembered (each keeps a [1, H', W'] normaliser and <= 4 band tables in HBM once planned)
 auto_cache = collections.OrderedDict()   # key -> AutoEntry
 auto_lock = threading.RLock()            # mergers of several threads (one inference loop each) share the cache
+POOL_MAX = 4            # band plans kept per geometry (a plan carries per-image state: one merger at a time uses it)
+
+
+def defer_budget():
+    import os
+
+    return int(os.environ.get("PTB_DEFER_BYTES", str(4 << 30)))
 
 
 class AutoEntry:
-    __slots__ = ("log", "seen", "need", "parts", "disabled")
+    __slots__ = ("log", "seen", "need", "parts", "disabled", "static", "tile_bytes", "batch_tiles", "pool", "rows", "no_defer")
 
     def __init__(self):
         self.log = None        # bytes of the [n, 4] int64 crop sequence of the last merged image
@@ -569,6 +667,12 @@ class AutoEntry:
         self.need = 1          # repeats required before planning (grows when a planned image deviated)
         self.parts = None      # (xy, remaining0, norm_full, crops4, built event) shared by the mergers planned from `log`
         self.disabled = False  # this geometry cannot be planned / its user reads accumulators or merges partially
+        self.static = False    # its model outputs were seen to share memory while alive (static output buffer): never deferred
+        self.tile_bytes = 0    # bytes of model output per tile (views x channels x h x w x element size) of the last image
+        self.batch_tiles = 0   # tiles per integrate call of the last image (custody is released batch-wise)
+        self.pool = []         # free Bands built for `parts` with `rows` rows per launch
+        self.rows = None       # rows per launch the budget allows (None: not decided; 0: deferral does not fit / not available)
+        self.no_defer = False  # the band kernel does not take this geometry, or an image was over the byte budget
 
 
 def auto_entry(key, create=False):
@@ -584,28 +688,102 @@ def auto_entry(key, create=False):
 
 
 class SelfPlanning:
-    """The policy that gives a merger constructed without ``crops=`` a ``Plan`` (see the comment above).  ``key`` None: this merger
-    never plans itself and every method is a no-op."""
+    """The policy that gives a merger constructed without ``crops=`` a ``Plan`` -- and, where the geometry and the byte budget allow,
+    the band plan of deferred merging (see the comment above).  ``key`` None: this merger never plans itself and every method is a
+    no-op."""
 
     def __init__(self, merger, key):
-        self.m, self.key = merger, key
+        self.m, self.key = weakref.proxy(merger), key
         self.planned = False      # merger._plan was made here (from the previous image's crops), not by the caller
         self.noted = None         # log length at the last merge() of this image
+        self.bands = None         # the Bands this merger has checked out of its geometry's pool
+        self.prev = None          # learning pass: the previous batch, kept alive for one call (observe)
+        self.tile_bytes = self.batch_tiles = 0
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    # ---------------------------------------------------------------- band plans: a pool per geometry
+    def release(self):
+        """Hand the band plan back to the geometry's pool (the merger is done with it: dropped, re-planned or degraded)."""
+        bands, self.bands = self.bands, None
+        if bands is None or self.key is None:
+            return
+        with auto_lock:
+            ent = auto_cache.get(self.key)
+            if ent is not None and ent.parts is not None and getattr(bands, "parts_id", None) is ent.parts[0] and len(ent.pool) < POOL_MAX:
+                ent.pool.append(bands)
+
+    def _acquire(self, ent, plan):
+        """A band plan for ``plan`` whose custody fits the byte budget, or None (then the merger runs planned blocks)."""
+        m = self.m
+        if ent.static or ent.no_defer or ent.rows == 0:
+            return None
+        with auto_lock:
+            if ent.pool:
+                bands = ent.pool.pop()
+                torch.cuda.current_stream(bands.table.device).wait_event(bands.ready)
+                return bands
+        th, tw = int(m.weight.shape[1]), int(m.weight.shape[2])
+        dev = m._image.device
+        rows = ent.rows
+        candidates = [rows] if rows else []
+        if not candidates:
+            r = default_defer_rows()
+            while r >= max(4, min(th, 256) // 2):
+                candidates.append(r)
+                r //= 2
+        budget = defer_budget()
+        for r in candidates:
+            bands = Bands.build(plan, m.channels, th, tw, m.image_height, m.image_width, dev, r)
+            if bands is None:
+                ent.no_defer = True      # off the band kernel's grid (tile origins / sizes, > 224 tiles per group, > 4 tiles per pixel)
+                return None
+            bands.parts_id = ent.parts[0]
+            if ent.tile_bytes and (bands.peak_tiles() + ent.batch_tiles) * ent.tile_bytes > budget:
+                continue
+            ent.rows = r
+            return bands
+        ent.rows = 0
+        return None
+
+    def too_big(self, per_tile, B):
+        """First batch of a self-deferred image: the model outputs it would keep alive exceed the budget (more views / a wider dtype
+        / larger batches than the image the plan was sized for).  Nothing is held yet: this image runs planned blocks, the geometry
+        re-sizes its launch groups for what it has seen now."""
+        m = self.m
+        m._deferred.active = False
+        with auto_lock:
+            ent = auto_cache.get(self.key)
+            if ent is not None:
+                ent.rows, ent.pool = None, []
+                ent.tile_bytes, ent.batch_tiles = max(ent.tile_bytes, per_tile), max(ent.batch_tiles, B)
+        self.tile_bytes, self.batch_tiles = max(self.tile_bytes, per_tile), max(self.batch_tiles, B)
+        self.bands = None
+        m._deferred.rebind(None, False)
 
     def attach(self):
         """(Re)plan the merger from the crop sequence its geometry ended the last image(s) with, when there is a stable one."""
         if self.key is None:
             return
         m = self.m
+        self.prev = None
         ent = auto_entry(self.key)
         usable = (ent is not None and not ent.disabled and ent.log is not None and ent.seen >= ent.need and not m._window_edited())
         if not usable:
+            self.release()
             if self.planned:
                 m._plan, self.planned = None, False
             return
         if self.planned and ent.parts is not None and ent.parts[0] is m._plan.xy:
             m._plan.restart()
+            if self.bands is None:
+                self.bands = self._acquire(ent, m._plan)
             return
+        self.release()
         if ent.parts is None:
             plan = Plan.build(m, np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4))
             if plan is None:          # off the block grid: this geometry never plans
@@ -615,22 +793,42 @@ class SelfPlanning:
             built = torch.cuda.Event()
             built.record(torch.cuda.current_stream(plan.norm_full.device))
             ent.parts = (plan.xy, plan.remaining0, plan.norm_full, plan.crops4, built)
+            ent.pool, ent.rows = [], None
         xy, remaining0, norm_full, crops4, built = ent.parts
         torch.cuda.current_stream(norm_full.device).wait_event(built)      # (the normaliser may have been built on another stream)
         plan = Plan(xy, remaining0, norm_full)
         plan.crops4 = crops4
         m._plan, self.planned = plan, True
+        self.bands = self._acquire(ent, plan)
 
     def opt_out(self):
         """The caller touched the accumulators themselves: this geometry stays on the ordinary (exact, unplanned) path from now on."""
         if self.key is not None:
             auto_entry(self.key, create=True).disabled = True
 
+    def observe(self, batch, n_views):
+        """Learning pass (an image of a keyed merger that is not planned): remember how much model output a tile brings, and notice
+        model outputs that share memory while alive.  The previous batch is kept referenced for the length of one call -- with a
+        model that returns fresh tensors the allocator then cannot hand its block out again, so an overlap means a static buffer."""
+        if self.key is None or self.planned:
+            return
+        per_tile = n_views * int(np.prod(batch.shape[1:])) * batch.element_size()
+        if per_tile > self.tile_bytes:
+            self.tile_bytes = per_tile
+        self.batch_tiles = max(self.batch_tiles, batch.shape[0] // n_views)
+        prev, self.prev = self.prev, batch
+        if prev is not None:
+            p0, p1, _v = held_entry(batch)
+            q0, q1, _v = held_entry(prev)
+            if p0 < q1 and q0 < p1:
+                auto_entry(self.key, create=True).static = True
+
     def note(self):
         """At merge(): remember the crop sequence this image was made of (what the next image of this geometry is planned from)."""
         if self.key is None:
             return
         m = self.m
+        self.prev = None
         n = len(m._log)
         if self.noted == n:
             return
@@ -641,6 +839,8 @@ class SelfPlanning:
         self.noted = n
         if n == 0:
             return
+        if self.tile_bytes:
+            ent.tile_bytes, ent.batch_tiles = self.tile_bytes, self.batch_tiles
         plan = m._plan
         if self.planned and plan.active and plan.pos == plan.xy.shape[1] and ent.parts is not None and ent.parts[0] is plan.xy:
             ent.seen += 1             # the planned sequence, start to end
@@ -655,7 +855,7 @@ class SelfPlanning:
         if ent.log == log:
             ent.seen += 1
         else:
-            ent.log, ent.seen, ent.parts = log, 1, None
+            ent.log, ent.seen, ent.parts, ent.pool, ent.rows, ent.no_defer = log, 1, None, [], None, False
 
     def unfinalise(self, what):
         """Somebody needs the accumulators of blocks the planned kernels have already turned into results.  A merger that planned

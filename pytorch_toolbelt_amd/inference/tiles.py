@@ -22,6 +22,7 @@ from ._merge_modes import auto_cache as _auto
 from ._merge_modes import auto_lock as _auto_lock
 from ._merge_modes import check_held as _check_held
 from ._merge_modes import coords_xy as _coords_xy
+from ._merge_modes import default_defer_rows as _defer_rows_default
 from ._merge_modes import held_entry as _held_entry
 from ._merge_modes import tensor_version as _tensor_version
 from ._merge_modes import _warned  # noqa: F401  (tests reset the once-only warnings)
@@ -275,12 +276,13 @@ def _resolve_device(device, what):
     )
 
 
-# Self-planning of mergers constructed without `crops=` (see _merge_modes.SelfPlanning): opt-in.
-_AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "0") == "1"
+# Self-planning of mergers constructed without `crops=` (see _merge_modes.SelfPlanning): on unless PTB_AUTO_PLAN=0 / set_auto_plan(False) /
+# pytorch_toolbelt_amd.set_strict_dropin().
+_AUTO_PLAN = __import__("os").environ.get("PTB_AUTO_PLAN", "1") != "0"
 
 
 def set_auto_plan(flag: bool) -> bool:
-    """Switch self-planning of ``TileMerger`` without ``crops=`` on / off (default off; ``PTB_AUTO_PLAN=1``); returns the previous setting."""
+    """Switch self-planning of ``TileMerger`` without ``crops=`` on / off (default on; ``PTB_AUTO_PLAN=0``); returns the previous setting."""
     global _AUTO_PLAN
     prev, _AUTO_PLAN = _AUTO_PLAN, bool(flag)
     return prev
@@ -327,10 +329,6 @@ def _device_window(weight: np.ndarray, device):
     return cached.clone()
 
 
-def _defer_rows_default():
-    import os
-
-    return int(os.environ.get("PTB_DEFER_ROWS", "1024"))
 
 
 class TileMerger:
@@ -436,7 +434,10 @@ class TileMerger:
         elif defer:
             _warn_once(("defer-noplan",), "TileMerger(defer=True) needs the complete crop list (crops=tiler.crops) on the planned block "
                                           "grid; the ordinary path is used.")
-        self._deferred = DeferredBands(self, bands)
+        soft = False
+        if bands is None and self._selfplan.bands is not None:      # planned from the previous image of this geometry, band plan included
+            bands, soft = self._selfplan.bands, True
+        self._deferred = DeferredBands(self, bands, soft)
 
     # ------------------------------------------------------------------ strategy state under its former names (tests, bench, tools)
     _bands = property(lambda self: self._deferred.bands)
@@ -499,6 +500,7 @@ class TileMerger:
         self._selfplan.noted = None
         if self._selfplan.key is not None:
             self._selfplan.attach()   # plan from what the last image(s) looked like / restart / drop a plan that no longer holds
+            self._deferred.rebind(self._selfplan.bands, self._selfplan.bands is not None)
         elif self._plan is not None:
             self._plan.restart()
         self._deferred.reset()
@@ -604,6 +606,8 @@ class TileMerger:
             raise RuntimeError("crop size in crop_coords does not match the tile / weight size")
         xy = np.ascontiguousarray(coords[:, :2].T)          # [2, B] int64: xs row, ys row (host arrays for the C ABI)
         dcode = N.DTYPE_CODES[batch.dtype]
+        if B:
+            self._selfplan.observe(batch, n_views)
         if B and self._deferred.active and self._deferred.take(batch, coords, xy, views, reduction, dcode):
             return
         xs = xy[0].ctypes.data_as(N._i64p)

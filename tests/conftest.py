@@ -11,9 +11,17 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
-# The suites choose their merger path explicitly (plain / planned / deferred) and read accumulators bit for bit, so mergers do not
-# plan themselves behind the tests' backs; tests/test_dropin_gpu.py switches self-planning on for the tests that are about it.
-os.environ.setdefault("PTB_AUTO_PLAN", "0")
+
+
+@pytest.fixture(autouse=True)
+def _fresh_self_planning_cache():
+    """The suites run on the library's defaults (lazy de-augmentation handles, self-planning mergers); what a merger has learnt about
+    a geometry must not travel from one test into the next."""
+    yield
+    mod = sys.modules.get("pytorch_toolbelt_amd.inference._merge_modes")
+    if mod is not None:
+        with mod.auto_lock:
+            mod.auto_cache.clear()
 
 
 def pytest_configure(config):

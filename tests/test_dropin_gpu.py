@@ -3,7 +3,9 @@ inference/tiles.py:321-346), and the deferred merger enforces its contract.
 
 * ``tta.*_image_deaugment`` returns a lazy handle (inference/_lazy.py) that ``TileMerger.integrate_batch`` fuses into its launch
   and that behaves like the evaluated tensor everywhere else;
-* ``TileMerger(shape, C, weight)`` without ``crops=`` plans itself from the second image of a geometry on;
+* ``TileMerger(shape, C, weight)`` without ``crops=`` plans itself from the second image of a geometry on -- into deferred bands
+  where the geometry, the byte budget and what it saw of the model's outputs allow, else into planned blocks -- and never raises for
+  something the caller did not opt into;
 * ``TileMerger(defer=True)`` refuses a batch that lives in a held batch's memory and notices in-place edits of held batches.
 
 Everything is compared bit for bit with the eager, unplanned path of the same library (itself pinned to the reference's goldens in
@@ -45,6 +47,14 @@ def autoplan():
     yield tiles
     tiles._auto.clear()
     tiles.set_auto_plan(prev)
+
+
+@pytest.fixture(params=["deferred bands", "planned"])
+def flavour(request, monkeypatch):
+    """What a self-planned merger turns into: deferred bands (default), or -- with a byte budget no image fits -- planned blocks."""
+    if request.param == "planned":
+        monkeypatch.setenv("PTB_DEFER_BYTES", "1")
+    return request.param
 
 
 GROUPS = {"fliplr": 2, "flipud": 2, "flips": 3, "d2": 4, "d4": 8}
@@ -274,7 +284,7 @@ def test_literal_loop_is_fused_and_bit_identical(group, reduction, shape, tile, 
 
 
 # ------------------------------------------------------------------------------------------------ self-planning mergers
-def test_new_merger_per_image_plans_itself_from_the_second_image(dev, lazy, autoplan):
+def test_new_merger_per_image_plans_itself_from_the_second_image(dev, lazy, autoplan, flavour):
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((500, 420), 128, 64)
     crops, C, batch = geom["crops"], 3, 8
@@ -289,10 +299,19 @@ def test_new_merger_per_image_plans_itself_from_the_second_image(dev, lazy, auto
         modes.append(m.mode)
         got = _run_image(m, outputs, crops, batch)
         assert torch.equal(got, exact), f"image {image} ({modes[-1]})"
-        if m._plan is not None:
+        assert m.mode == modes[-1]
+        if m.mode == "deferred bands":
+            assert m._deferred.soft and m._deferred.complete and not len(m._held) and m._plan.pos == n
+        elif m._plan is not None:
             assert m._plan.done.all() and m._plan.pos == n
-    assert modes == ["incremental", "planned", "planned", "planned"]
+    assert modes == ["incremental", flavour, flavour, flavour]
     assert np.nanmax(np.abs(got.cpu().numpy() - _oracle_image(geom, C, w, outputs, batch))) <= 1e-5
+    if flavour == "deferred bands":   # band plans are pooled per geometry: mergers that follow each other share them
+        from pytorch_toolbelt_amd.inference import _merge_modes as MM
+
+        ent = next(iter(MM.auto_cache.values()))
+        del m
+        assert 1 <= len(ent.pool) <= 2 and ent.rows
 
 
 def test_literal_loop_from_two_threads_on_two_streams(dev, lazy, autoplan):
@@ -338,7 +357,7 @@ def test_literal_loop_from_two_threads_on_two_streams(dev, lazy, autoplan):
         assert torch.equal(torch.nan_to_num(got, nan=-7.0), torch.nan_to_num(serial[k], nan=-7.0)), (rep, k)
 
 
-def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
+def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan, flavour):
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((384, 384), 128, 64)
     crops, C, batch = geom["crops"], 2, 4
@@ -350,14 +369,14 @@ def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
     m = TileMerger(geom["target_shape"], C, w, device=dev)
     assert m.mode == "incremental" and torch.equal(_run_image(m, outputs, crops, batch), exact)
     m.reset()
-    assert m.mode == "planned" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    assert m.mode == flavour and torch.equal(_run_image(m, outputs, crops, batch), exact)
     # an image that skips tiles (content-dependent loops do): correct, and planning asks for more evidence afterwards
     keep = np.array([i for i in range(n) if i not in (3, 7, 8)])
     sub = torch.cat([outputs[k * n + keep] for k in range(8)])
     sub_geom = {"crops": crops[keep], "target_shape": geom["target_shape"]}
     exact_sub = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), sub, crops[keep], batch, literal=False)
     m.reset()
-    assert m.mode == "planned"
+    assert m.mode == flavour
     got = _run_image(m, sub, crops[keep], batch)
     assert m.mode == "incremental"                       # it left the plan at the first deviating batch
     assert torch.equal(got, exact_sub)
@@ -368,13 +387,15 @@ def test_reset_flow_plans_itself_and_survives_deviations(dev, lazy, autoplan):
     m.reset()
     assert m.mode == "incremental" and torch.equal(_run_image(m, outputs, crops, batch), exact)
     m.reset()
-    assert m.mode == "planned" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    assert m.mode == flavour and torch.equal(_run_image(m, outputs, crops, batch), exact)
 
 
-def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan):
-    """Reading ``image`` after the self-planned kernels finalised blocks: the accumulators are COMPLETE and EXACT (a self-planned
-    merger stores the weighted sum of a block next to its merged value, PTB_PLANNED_KEEP_SUMS) -- array_equal with the unplanned
-    path, the reference's sequential sums; said once, and the geometry stays on the ordinary path afterwards."""
+def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan, flavour):
+    """Reading ``image`` after a self-planned merger has turned (part of) the image into results.  Planned blocks: the accumulators are
+    COMPLETE and EXACT (a self-planned merger stores the weighted sum of a block next to its merged value, PTB_PLANNED_KEEP_SUMS) --
+    array_equal with the unplanned path.  Deferred bands: no accumulator was ever stored, merged rows come back as merged * norm_mask
+    (one float32 rounding away from the sequential sums).  Either way nothing raises, it is said once, and the geometry stays on the
+    ordinary path afterwards."""
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((256, 256), 128, 64)
     crops, C, batch = geom["crops"], 2, 3
@@ -386,19 +407,27 @@ def test_self_planned_merger_hands_out_accumulators(dev, lazy, autoplan):
     exact_image, exact_norm = ref.image.clone(), ref.norm_mask.clone()
     _run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch)        # image 1: remembered
     m = TileMerger(geom["target_shape"], C, w, device=dev)
-    assert m.mode == "planned"
+    assert m.mode == flavour
     got = _run_image(m, outputs, crops, batch)
     assert torch.equal(got, exact)
-    with pytest.warns(RuntimeWarning, match="accumulators are complete"):
-        img = m.image
-    assert torch.equal(img, exact_image) and torch.equal(m.norm_mask, exact_norm)
-    assert torch.equal(m.merge(), exact)
+    if flavour == "planned":
+        with pytest.warns(RuntimeWarning, match="accumulators are complete"):
+            img = m.image
+        assert torch.equal(img, exact_image) and torch.equal(m.norm_mask, exact_norm)
+        assert torch.equal(m.merge(), exact)
+    else:
+        with pytest.warns(RuntimeWarning, match="continuing on the ordinary accumulate"):
+            img = m.image
+        torch.testing.assert_close(img, exact_image, rtol=2e-7, atol=1e-9)
+        assert torch.equal(m.norm_mask, exact_norm)
+        torch.testing.assert_close(m.merge(), exact, rtol=3e-7, atol=1e-9)
+    assert m.mode == "incremental"
     m2 = TileMerger(geom["target_shape"], C, w, device=dev)
     assert m2.mode == "incremental"                      # this geometry's user reads accumulators: exact path from now on
     assert torch.equal(_run_image(m2, outputs, crops, batch), exact) and torch.equal(m2.image, exact_image)
 
 
-def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan):
+def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan, flavour):
     TileMerger = autoplan.TileMerger
     geom = TO.slicer_geometry((256, 256), 128, 64)
     crops, C = geom["crops"], 1
@@ -409,14 +438,172 @@ def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan):
     first.integrate_batch(outputs, crops)
     first.merge()
     m = TileMerger(geom["target_shape"], C, w, device=dev)
-    assert m.mode == "planned"
+    assert m.mode == flavour
     m.integrate_batch(outputs, crops)
-    with pytest.warns(RuntimeWarning, match="accumulators are complete"):
+    with pytest.warns(RuntimeWarning, match="accumulators are complete" if flavour == "planned" else "continuing on the ordinary accumulate"):
         m.integrate_batch(outputs[:1], crops[4:5])       # one more tile over pixels that were already merged
     st = TO.merger_new(geom["target_shape"], C, w)
     TO.merger_integrate(st, outputs.cpu().numpy(), crops)
     TO.merger_integrate(st, outputs[:1].cpu().numpy(), crops[4:5])
-    assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))        # exact: the same sums in the same order
+    if flavour == "planned":
+        assert np.array_equal(m.merge().cpu().numpy(), TO.merger_merge(st))        # exact: the same sums in the same order
+    else:
+        np.testing.assert_allclose(m.merge().cpu().numpy(), TO.merger_merge(st), rtol=5e-7, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ self-planned deferral: what the caller never asked for
+def _learn(TileMerger, geom, C, w, dev, outputs, batch, **kw):
+    first = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert first.mode == "incremental"
+    return _run_image(first, outputs, geom["crops"], batch, **kw)
+
+
+def test_self_deferred_merger_degrades_without_raising(dev, lazy, autoplan, monkeypatch):
+    """After bands of the image went out a self-deferred merger is asked for things deferred merging cannot serve: tiles off the
+    remembered sequence, merge() of an image that ends early, a read of ``image`` in the middle.  ``TileMerger(defer=True)`` raises
+    there (the caller opted in); a merger that deferred on its own account carries on as the ordinary one, inside 1e-6 of it."""
+    monkeypatch.setenv("PTB_DEFER_ROWS", "128")       # six launch groups on this image
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((700, 420), 128, 64)
+    crops, C, batch = geom["crops"], 2, 4
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(21))
+    exact = _learn(TileMerger, geom, C, w, dev, outputs, batch)
+
+    def feed(m, idx, b):
+        from pytorch_toolbelt_amd.inference import tta
+
+        for b0 in range(0, len(idx), b):
+            sel = idx[b0:b0 + b]
+            m.integrate_batch(tta.d4_image_deaugment(torch.cat([outputs[k * n + sel] for k in range(8)])), crops[sel])
+
+    def plain(idx, b):
+        p = TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False)
+        feed(p, idx, b)
+        return p
+
+    def close(a, b):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        np.testing.assert_allclose(np.nan_to_num(a), np.nan_to_num(b), rtol=1e-6, atol=1e-6)
+
+    every = np.arange(n)
+    # (1) a late deviation: the last third of the image arrives in another order
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands" and len(m._bands.bands) >= 3, "the geometry must give several launch groups"
+    cut = (2 * n // 3) // batch * batch
+    order = np.concatenate([every[:cut], every[cut:][::-1]])
+    with pytest.warns(RuntimeWarning, match="continuing on the ordinary accumulate"):
+        feed(m, order, batch)
+    assert m.mode == "incremental"
+    close(m.merge(), plain(order, batch).merge())
+    # (2) the image ends early: merge() with the lower rows missing -> NaN there, like the reference
+    autoplan._auto.clear()          # (a planned image that deviated asks for more evidence: start this geometry over)
+    _learn(TileMerger, geom, C, w, dev, outputs, batch)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands"
+    feed(m, every[:cut], batch)
+    assert m._bands_done > 0
+    close(m.merge(), plain(every[:cut], batch).merge())
+    # (3) accumulators read in the middle of an image, then the rest of the tiles
+    autoplan._auto.clear()
+    _learn(TileMerger, geom, C, w, dev, outputs, batch)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    feed(m, every[:cut], batch)
+    assert m.mode == "deferred bands" and m._bands_done > 0
+    p = plain(every[:cut], batch)
+    close(m.image, p.image)
+    assert torch.equal(m.norm_mask, p.norm_mask) and m.mode == "incremental"
+    feed(m, every[cut:], batch)
+    close(m.merge(), exact)
+
+
+def test_self_deferred_merger_and_static_model_outputs(dev, lazy, autoplan):
+    """A model that writes every batch into ONE buffer (HIP graphs, out=): the first image of a geometry runs incrementally and
+    notices (the previous batch is still referenced when the next one arrives in the same memory), so its mergers never defer --
+    they plan into blocks, which read every batch inside integrate_batch; results exact.  A model that SWITCHES to a static buffer
+    after its geometry was learnt with fresh outputs is refused loudly (the held predictions are already overwritten)."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((384, 384), 128, 64)
+    crops, C, batch = geom["crops"], 2, 4
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(31))
+    exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch)
+    static = torch.empty((8 * batch, C, 128, 128), device=dev)
+
+    def static_image(m):
+        for b0 in range(0, n, batch):
+            b1 = min(n, b0 + batch)
+            buf = static[:8 * (b1 - b0)]
+            buf.copy_(torch.cat([outputs[k * n + b0:k * n + b1] for k in range(8)]))
+            m.integrate_batch(tta.d4_image_deaugment(buf), crops[b0:b1])
+        return m.merge()
+
+    modes = []
+    for _ in range(3):
+        m = TileMerger(geom["target_shape"], C, w, device=dev)
+        modes.append(m.mode)
+        assert torch.equal(static_image(m), exact)
+    assert modes == ["incremental", "planned", "planned"]
+    autoplan._auto.clear()
+    assert torch.equal(_run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch), exact)     # learnt with fresh outputs
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands"
+    with pytest.raises(RuntimeError, match="occupies memory of an earlier batch.*auto_plan=False"):
+        static_image(m)
+
+
+def test_self_deferred_merger_keeps_to_its_byte_budget(dev, lazy, autoplan, monkeypatch):
+    """PTB_DEFER_BYTES bounds the model outputs a self-deferred merger keeps alive: rows per launch are halved until the peak custody
+    fits, below that the merger plans into blocks; an image that brings more bytes per tile than the plan was sized for (more views)
+    runs planned and the geometry re-sizes.  Results are bit-identical throughout."""
+    from pytorch_toolbelt_amd.inference import _merge_modes as MM
+
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((900, 420), 128, 64)
+    crops, C, batch = geom["crops"], 2, 4
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    per_row = len({int(x) for x in crops[:, 0]})
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(41))
+    exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch)
+    tile_bytes = 8 * C * 128 * 128 * 4
+    # (a) room for ~4 tile rows: the default 1024 rows per launch (the whole image in one group) do not fit, 128 or fewer do
+    monkeypatch.setenv("PTB_DEFER_BYTES", str((4 * per_row + batch) * tile_bytes))
+    assert torch.equal(_run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch), exact)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands" and m._bands.rows < 1024 and (m._bands.peak_tiles() + batch) * tile_bytes <= MM.defer_budget()
+    peak = 0
+    from pytorch_toolbelt_amd.inference import tta
+    for b0 in range(0, n, batch):
+        b1 = min(n, b0 + batch)
+        m.integrate_batch(tta.d4_image_deaugment(torch.cat([outputs[k * n + b0:k * n + b1] for k in range(8)])), crops[b0:b1])
+        peak = max(peak, sum(h[0].numel() * 4 for h in m._held))
+    assert torch.equal(m.merge(), exact) and 0 < peak <= MM.defer_budget()
+    # (b) nothing fits: planned blocks
+    autoplan._auto.clear()
+    monkeypatch.setenv("PTB_DEFER_BYTES", str(tile_bytes))
+    assert torch.equal(_run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs, crops, batch), exact)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "planned" and torch.equal(_run_image(m, outputs, crops, batch), exact)
+    # (c) sized on fliplr outputs (2 views), then a d4 image (8 views) arrives: over budget at its first batch -> planned, re-sized
+    autoplan._auto.clear()
+    flip_exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs[:2 * n], crops, batch, group="fliplr")
+    monkeypatch.setenv("PTB_DEFER_BYTES", str((n + batch) * tile_bytes // 4))          # the whole image of 2-view outputs, a quarter of it at 8 views
+    assert torch.equal(_run_image(TileMerger(geom["target_shape"], C, w, device=dev), outputs[:2 * n], crops, batch, group="fliplr"), flip_exact)
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands" and m._bands.rows == 1024
+    assert torch.equal(_run_image(m, outputs[:2 * n], crops, batch, group="fliplr"), flip_exact) and m.mode == "deferred bands"
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands"
+    assert torch.equal(_run_image(m, outputs, crops, batch), exact) and m.mode == "planned"
+    m = TileMerger(geom["target_shape"], C, w, device=dev)
+    assert m.mode == "deferred bands" and m._bands.rows < 1024
+    assert torch.equal(_run_image(m, outputs, crops, batch), exact) and m.mode == "deferred bands"
 
 
 # ------------------------------------------------------------------------------------------------ deferred merger: the contract

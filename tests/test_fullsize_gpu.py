@@ -121,15 +121,29 @@ def test_cfg2_5000_d4_merge_all_paths_vs_reference_and_oracle(dev, full):
         literal_lazy.integrate_batch(tta.d4_image_deaugment(y), crops[b0:b0 + nb])
         _lazy.set_enabled(prev)
     assert _lazy.fused - fused0 == 46 and _lazy.evaluations == eval0, "the literal calls were not fused into the merger's launches"
+    # ... and the README loop verbatim on the library's defaults, a new TileMerger(shape, C, weight) per image: the mergers above were
+    # this geometry's first image (incremental); the next one plans itself into deferred bands from the crop sequence they ended with
+    assert all(m.mode == "incremental" for m in (fused["plain"], literal, literal_lazy))
+    literal_lazy.merge()
+    second = TileMerger(slicer.target_shape, C, slicer.weight, device=dev)
+    assert second.mode == "deferred bands" and second._deferred.soft, "the second image of a geometry did not plan itself into deferred bands"
+    held_peak = 0
+    for k, b0 in enumerate(range(0, 361, 8)):
+        nb = min(8, 361 - b0)
+        second.integrate_batch(tta.d4_image_deaugment(SY.synth_torch((8 * nb, C, 512, 512), 2000 + k, device=dev)), crops[b0:b0 + nb])
+        held_peak = max(held_peak, sum(h[0].numel() * 4 for h in second._held))
+    assert second.mode == "deferred bands" and second._deferred.complete and not second._held
+    assert 0 < held_peak <= 4 << 30, f"custody of model outputs peaked at {held_peak / 2**30:.2f} GiB (budget: PTB_DEFER_BYTES, 4 GiB)"
     d = fused["deferred"]
     assert d._bands is not None and d._bands_done == len(d._bands.bands) and not d._held, "the deferred band path did not run"
     want = _cfg2_oracle(dev)
     outs = {k: m.merge().cpu().numpy() for k, m in fused.items()}
     outs["literal"] = literal.merge().cpu().numpy()
     outs["literal_lazy"] = literal_lazy.merge().cpu().numpy()
+    outs["literal_self_deferred"] = second.merge().cpu().numpy()
     for k, got in outs.items():
         _check_cfg2_result(full, k, got, want)
-    for k in ("deferred", "planned", "literal", "literal_lazy"):
+    for k in ("deferred", "planned", "literal", "literal_lazy", "literal_self_deferred"):
         assert np.array_equal(outs[k], outs["plain"]), k
     # the cropped original-size map (tiler.crop_to_orignal_size) from the device and from the host agree
     cropped = slicer.crop_to_orignal_size(np.moveaxis(outs["deferred"], 0, -1))

@@ -191,9 +191,9 @@ def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes()
             "h = L.LazyDeaugment(torch.randn(4, 1, 2, 2), 'fliplr', (0, 4), 1, lambda s, v, c: s.view(2, 2, 1, 2, 2).mean(0))\n"
             "assert D.to_dlpack is not orig and D.to_dlpack._ptb_lazy_guard\n"
             "prev = pytorch_toolbelt_amd.set_strict_dropin(True)\n"
-            "assert prev == (True, False) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
+            "assert prev == (True, True) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
             "T.set_auto_plan(True); assert pytorch_toolbelt_amd.set_strict_dropin(True) == (False, True) and not T._AUTO_PLAN\n"
-            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False) and L.enabled()\n"
+            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False) and L.enabled() and T._AUTO_PLAN\n"
             "print('OK')\n")
     import os
 
