@@ -31,10 +31,10 @@ def native():
     lib.ptb_set_tunable(1, 0)
 
 
-def _merger(shape, C, weight, dev):
+def _merger(shape, C, weight, dev, **kw):
     from pytorch_toolbelt_amd.inference.tiles import TileMerger
 
-    return TileMerger(shape, C, weight, device=dev)
+    return TileMerger(shape, C, weight, device=dev, **kw)
 
 
 def _window(kw):
@@ -344,7 +344,7 @@ def test_lazy_norm_mask_cache_and_eager_switch(dev, native):
     crops, n = geom["crops"], len(geom["crops"])
     rng = np.random.default_rng(11)
     imgs = [rng.standard_normal((n, 2, 256, 256)).astype(np.float32) for _ in range(3)]
-    m = _merger(geom["target_shape"], 2, w, dev)
+    m = _merger(geom["target_shape"], 2, w, dev, auto_plan=False)      # (this test counts the launches of the ordinary path)
 
     def run(pred, order=None, batch=5):
         idx = np.arange(n) if order is None else order
