@@ -26,7 +26,10 @@ could gain by choosing among `--placement-tries` candidate pools is measured AFT
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): the 361 tiles of ONE image are sharded over the
+N > 1 runs one rank per GPU over RCCL; started without WORLD_SIZE in the environment, `python bench.py --gpus N` launches itself
+under torch.distributed.run (127.0.0.1, a free port).  Before anything is timed every rank checks the rows it owns against the
+SINGLE-DEVICE merge of the same (per-tile seeded) model outputs; the JSON line carries `config.sharded.parity_max_abs_diff` and
+`rccl_ranks` (ranks whose exchange is the library's own RCCL communicator), and a parity failure fails the run.  The 361 tiles of ONE image are sharded over the
 ranks as contiguous tile ranges (45 / 46 tiles each at N = 8), neighbouring ranks exchange their 256-row halo rectangles
 point-to-point over xGMI (one ncclGroup per image on the library's own communicator) and every rank merges its own band (strong
 scaling: total work per step is fixed).  Steps are pipelined (`merge_async`): image i's exchange runs beside image i+1's kernels;
@@ -81,6 +84,21 @@ def parse():
     ap.add_argument("--defer-rows", type=int, default=0, help="rows of the image merged per deferred launch (0: the library default, 1024)")
     ap.add_argument("--diag", action="store_true", help="print per-step / per-call timing diagnostics to stderr")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one per GPU, this node) and hand
+    their exit code on; the ranks' stdout -- rank 0's JSON line last -- passes through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus", args.gpus, "without WORLD_SIZE: launching", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, cwd=ROOT).returncode
 
 
 def cpu_baseline(slicer, max_seconds=25.0):
@@ -553,12 +571,18 @@ def main_cfg5(args):
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if parity is not None and not parity["parity_max_abs_diff"] <= parity["parity_tolerance"]:
+        print(f"[bench] rank {rank}: the sharded merge differs from the single-device merge by {parity['parity_max_abs_diff']:.3g} "
+              f"(tolerance {parity['parity_tolerance']}): the timing above is not a valid result", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 def main():
     args = parse()
     if args.workload == "cfg5":
         return main_cfg5(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -639,10 +663,22 @@ def main():
             for i in order:
                 b0, b1 = batches[i]
                 tensors[i] = torch.empty((VIEWS * (b1 - b0), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
-        g = torch.Generator(device=dev).manual_seed(1234 + rank)
-        for t in tensors:
-            t.normal_(generator=g)
+        for t, (b0, b1) in zip(tensors, batches):
+            fill_outputs(t, my_tiles[b0:b1])
         return tensors, keep
+
+    def fill_outputs(t, tiles):
+        """Model outputs of the given tiles (global indices) into the chunk-major batch tensor ``t``: every tile's 8 views x C x 512 x 512
+        values come from a generator seeded with the TILE's index, so any rank can reproduce any tile (the parity check below feeds
+        a single-device merger the tiles its neighbours own)."""
+        nb = len(tiles)
+        by_view = t.view(VIEWS, nb, CHANNELS, TILE, TILE)
+        tmp = torch.empty((VIEWS, CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
+        g = torch.Generator(device=dev)
+        for j, tile in enumerate(tiles):
+            g.manual_seed(1234 + int(tile))
+            tmp.normal_(generator=g)
+            by_view[:, j] = tmp
 
     batch_tensors, _keep = alloc_outputs(int(os.environ.get("PTB_BENCH_PAD_MB", "0")))   # (the pad: a placement diagnostic)
     batch_crops = [crops[b0:b1] for b0, b1 in batches]
@@ -701,6 +737,50 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- N > 1: parity before anything is timed.  This rank's band of ONE synchronously merged image against the rows the plain
+    # single-device merger produces for the same model outputs (every tile that touches the owned rows, regenerated from its seed,
+    # integrated in the single-device order).  "pixel_rows" is bit-identical by construction; tile partitions add the neighbours'
+    # partial sums in another association: a few 1e-7 on O(1) values, against the 1e-5 of BASELINE.json.
+    parity = None
+    if sharded:
+        merger.reset()
+        for t, c in zip(batch_tensors, batch_crops):
+            merger.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+        band = merger.merge()
+        merger.reset()
+        diff, checked = 0.0, 0
+        owned = merger.owned_rows
+        if band is not None and owned is not None and owned[1] > owned[0]:
+            o0, o1 = owned
+            ys = slicer.crops[:, 1]
+            touching = np.nonzero((ys < o1) & (ys + TILE > o0))[0]
+            single = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, auto_plan=False)
+            for b0 in range(0, len(touching), BATCH):
+                sel = touching[b0:b0 + BATCH]
+                y = torch.empty((VIEWS * len(sel), CHANNELS, TILE, TILE), device=dev, dtype=torch.float32)
+                fill_outputs(y, sel)
+                single.integrate_batch_deaugment(y, slicer.crops[sel], group="d4", reduction="mean")
+            want = single.merge()[:, o0:o1]
+            assert bool(torch.isfinite(want).all()), "the single-device merge of the tiles over this rank's rows has uncovered pixels"
+            diff = float((band.reshape(want.shape) - want).abs().nan_to_num(nan=float("inf")).max())
+            checked = int(want.numel())
+            del single, want, y
+        torch.cuda.synchronize()
+        stats = torch.tensor([diff, float(checked), 1.0 if getattr(merger, "exchange", None) is not None else 0.0], device=dev, dtype=torch.float64)
+        worst = stats.clone()
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        total = stats.clone()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        torch.cuda.empty_cache()
+        from pytorch_toolbelt_amd import parallel as _par
+
+        parity = {"parity_max_abs_diff": float(worst[0].item()), "parity_tolerance": 1e-5, "parity_values_checked": int(total[1].item()),
+                  "parity_against": "TileMerger (single device, incremental) over every tile touching the rank's rows, same seeded model outputs",
+                  "rccl_ranks": int(total[2].item()), "rccl_error": _par.last_exchange_error()}
+        if rank == 0:
+            print(f"[bench] sharded parity: max|band - single-device| = {parity['parity_max_abs_diff']:.3g} over {parity['parity_values_checked']} values; "
+                  f"{parity['rccl_ranks']}/{world} ranks on the library's RCCL exchange", file=sys.stderr, flush=True)
 
     # Host hygiene: a generation-2 Python GC pass over the ~10^5 objects torch leaves behind takes 30-45 ms (ten
     # steps' worth) and used to land inside the timed region; collect once and freeze the survivors, as a serving loop
@@ -851,8 +931,11 @@ def main():
         ms_now = elapsed / args.steps * 1e3
         slowest_compute = max(e["compute_only_ms"] for e in everyone)
         sharded_report = {
+            **parity,
             "mode": "pipelined (merge_async: image i's exchange under image i+1's kernels)" if pipelined else "latency (merge() joins the exchange inside the image)",
-            "exchange": "ptb_halo_exchange: one ncclGroup per image on the library's own RCCL communicator" if merger.exchange is not None else "torch.distributed.batch_isend_irecv",
+            "exchange": ("ptb_halo_exchange: one ncclGroup per image on the library's own RCCL communicator" if merger.exchange is not None else
+                         "torch.distributed.batch_isend_irecv" + ("" if backend == "nccl" and os.environ.get("PTB_BENCH_EXCHANGE", "auto") == "torch" else
+                                                                 " (the library's RCCL communicator was NOT used: " + (parity["rccl_error"] or f"backend {backend}") + ")")),
             "partition": partition,
             "pipelined_ms_per_image": round(ms_now if pipelined else other_ms, 4),
             "latency_mode_ms_per_image": round(other_ms if pipelined else ms_now, 4),
@@ -865,6 +948,9 @@ def main():
                     "neighbour (each pair of GPUs has its own xGMI link, both directions at once); tools/shard_sim.py predicts the same "
                     "fields from one GPU + a link model (profiles/r04_shard_sim.txt)",
         }
+
+    if sharded_report is None and parity is not None:      # (PTB_BENCH_FORCE_SHARDED with one rank)
+        sharded_report = parity
 
     # ---- secondary timings (single GPU): what each API extension of the headline configuration buys, driver-visible
     variants = None
@@ -1211,6 +1297,10 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if parity is not None and not parity["parity_max_abs_diff"] <= parity["parity_tolerance"]:
+        print(f"[bench] rank {rank}: the sharded merge differs from the single-device merge by {parity['parity_max_abs_diff']:.3g} "
+              f"(tolerance {parity['parity_tolerance']}): the timing above is not a valid result", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

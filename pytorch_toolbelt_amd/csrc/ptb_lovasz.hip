@@ -394,7 +394,9 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         unsigned cum = (chunk < chunks_per_seg ? chunk_off[(long long)seg * chunks_per_seg + chunk] : 0u) + ((wave & 1) ? wfg[wave - 1] : 0u);
         const float G = (float)fg_total[seg];
         // J at the position before the wave's first element (wave-uniform); afterwards an element's J_{k-1} is its left neighbour's
-        // J_k: the lane below, or lane 63 of the previous item -- one division per element instead of two, the same bits
+        // J_k: the lane below, or lane 63 of the previous item -- one division per element instead of two.  This telescoping form IS the
+        // reference's jaccard[1:] - jaccard[:-1] (lovasz.py:32-33); up to position 2^24 it also has the bits of evaluating J_{k-1}
+        // afresh from (float)(i + 1) - 1.0f, beyond that (float)(i + 1) rounds and only the telescoping form matches the reference
         const long long w0 = t0 + (long long)wave * SPAN;
         float carry = w0 == 0 ? 0.0f : jaccard_at(G, (float)w0, (float)cum);
 #pragma unroll
@@ -626,7 +628,9 @@ __global__ __launch_bounds__(256) void lovasz_dot_kernel(const unsigned* __restr
     unsigned cum = chunk_off[blockIdx.x] + wave_off + incl - local;  // fg count strictly before this thread's first element
     double acc = 0.0;
     // J at the position before this thread's first one; from then on every J_k is the next element's J_{k-1} (one division per
-    // element instead of two: (float)(i + 1) - 1.0f == (float)i, the same bits as evaluating J_{k-1} afresh)
+    // element instead of two).  The telescoping difference is the reference's jaccard[1:] - jaccard[:-1]; re-evaluating J_{k-1} from
+    // (float)(i + 1) - 1.0f has the same bits only while positions stay below 2^24 (segments above 16.7 M elements: the A/B
+    // settings of tunables 17 / 19 may then differ in the last bits, the telescoping one being the reference's)
     float jprev = (first == 0 || first >= P) ? 0.0f : jaccard_at(G, (float)first, (float)cum);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {

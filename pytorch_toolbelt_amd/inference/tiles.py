@@ -325,7 +325,9 @@ def _device_window(weight: np.ndarray, device):
         else:
             _device_windows.move_to_end(key)
     cached, ready = ent
-    torch.cuda.current_stream(device).wait_event(ready)      # (the upload may have been issued on another thread's stream)
+    cur = torch.cuda.current_stream(device)
+    cur.wait_event(ready)            # (the upload may have been issued on another thread's stream)
+    cached.record_stream(cur)        # ... and the LRU may drop the cached tensor while this stream's clone() is still reading it
     return cached.clone()
 
 
@@ -378,6 +380,11 @@ class TileMerger:
         # that is a strictly more accurate sum than the reference's.  (float64 never gets here: __new__ hands it to the torch-op merger.)
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
+        if dtype == torch.float64:
+            # (TileMerger / CudaTileMerger route float64 to the torch-op merger in __new__; any other subclass of the HIP merger would
+            # silently sum in float32 and cast -- ADVICE round 4)
+            raise TypeError(f"{type(self).__name__}: float64 accumulators are kept by the torch-op merger (TileMerger(..., dtype=torch.float64) / "
+                            "HostBackedTileMerger); the HIP kernels of this class accumulate in float32")
         self.dtype = dtype
         dtype = torch.float32
         N.load()
@@ -848,6 +855,13 @@ class HostBackedTileMerger(TileMerger):
 
 class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
+
+    def __new__(cls, image_shape=None, channels=None, weight=None, device="cuda", *args, **kwargs):
+        # float64 accumulators (and a caller who names the CPU after all) get the torch-op merger, exactly like TileMerger(...) does
+        dtype = kwargs.get("dtype", args[0] if args else torch.float32)
+        if cls is CudaTileMerger and (torch.device(device).type != "cuda" or dtype == torch.float64):
+            return HostBackedTileMerger(image_shape, channels, weight, device, *args, **kwargs)      # (not a CudaTileMerger: __init__ is not run again)
+        return object.__new__(cls)
 
     def __init__(self, image_shape, channels, weight, device="cuda", dtype=torch.float32, crops=None, defer=False, defer_rows=None, auto_plan=None):
         super().__init__(image_shape, channels, weight, device=device, dtype=dtype, crops=crops, defer=defer, defer_rows=defer_rows,

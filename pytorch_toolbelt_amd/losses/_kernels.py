@@ -204,6 +204,11 @@ class SigmoidFocalSums(torch.autograd.Function):
         return grad, None, None, None, None, None, None, None, None, None
 
 
+class _NotOneLaunch(Exception):
+    """FocalScalar.forward: the C side does not serve this configuration in one launch and NOTHING was launched.  A private type: a
+    genuine NotImplementedError out of torch / ctypes must not be mistaken for it."""
+
+
 class FocalScalar(torch.autograd.Function):
     """``scale * sum_i L_i`` of the sigmoid focal loss on label maps as ONE launch (``ptb_region_loss_fwd`` with the focal sums alone:
     the streaming kernel's last workgroup adds up the slots and writes the scalar; no memset / finalize launches, no torch algebra
@@ -216,7 +221,7 @@ class FocalScalar(torch.autograd.Function):
             return None if out is None else out[0]
         try:
             return FocalScalar.apply(x, labels, flags, gamma, scale)
-        except NotImplementedError:       # (the C side does not serve this shape in one launch: nothing was launched)
+        except _NotOneLaunch:             # (raised before anything was saved or launched)
             return None
 
     @staticmethod
@@ -246,7 +251,7 @@ class FocalScalar(torch.autograd.Function):
     def forward(ctx, x, labels, flags, gamma, scale):
         out = FocalScalar._launch(x, labels, flags, gamma, scale)
         if out is None:
-            raise NotImplementedError("focal one-launch path")
+            raise _NotOneLaunch
         ctx.save_for_backward(x, labels)
         ctx.cfg = (flags, gamma, scale)
         return out[0]

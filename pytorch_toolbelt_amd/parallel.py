@@ -642,20 +642,63 @@ class RcclExchange:
             self.comm = None
 
 
-_shared_exchanges = {}      # (device index, id of the process group) -> RcclExchange | None (None: tried, every rank fell back together)
+_shared_exchanges = {}      # device index -> [(weak reference to the process group | None, RcclExchange | None)]  (None: tried, every rank fell back)
+_last_exchange_error = None
+
+
+def last_exchange_error():
+    """Why the last ``shared_exchange`` call fell back to ``torch.distributed`` p2p (a string), or None."""
+    return _last_exchange_error
+
+
+def _group_object(group, dist):
+    """The process-group OBJECT a cache entry belongs to (the default group when ``group`` is None); None when it cannot be named
+    (a stand-in ``dist`` of the tests)."""
+    if group is not None:
+        return group
+    try:
+        return dist.distributed_c10d._get_default_group()
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def close_shared_exchanges():
+    """Close and forget every cached ``RcclExchange`` (call it before ``destroy_process_group()``; entries whose group has died are
+    also dropped whenever ``shared_exchange`` runs)."""
+    for entries in _shared_exchanges.values():
+        for _ref, ex in entries:
+            if ex is not None:
+                ex.close()
+    _shared_exchanges.clear()
 
 
 def shared_exchange(device, group=None, dist=None):
     """The process's ``RcclExchange`` for ``group`` on ``device``, created on first use -- COLLECTIVE, like constructing a
     ``ShardedTileMerger`` is: every rank of the group calls it.  Returns None (on every rank alike: the outcome is agreed by an
     all-reduce) when RCCL cannot be bound or the communicator cannot be set up on some rank; the merger then posts its rectangles
-    with ``torch.distributed.batch_isend_irecv``."""
+    with ``torch.distributed.batch_isend_irecv`` (``last_exchange_error()`` says why).  Entries are kept per process-group OBJECT
+    through a weak reference and checked on every hit: a group that was destroyed takes its communicator with it, and a new group that
+    happens to get the dead one's ``id()`` never sees a stale exchange."""
+    global _last_exchange_error
+    import weakref
+
     if dist is None:
         import torch.distributed as dist
     device = torch.device(device)
-    key = (device.index if device.index is not None else torch.cuda.current_device(), id(group))
-    if key in _shared_exchanges:
-        return _shared_exchanges[key]
+    dev_key = device.index if device.index is not None else torch.cuda.current_device()
+    pg = _group_object(group, dist)
+    entries = _shared_exchanges.setdefault(dev_key, [])
+    alive = []
+    for ref, ex in entries:
+        if ref is not None and ref() is None:          # its group is gone: so is the communicator
+            if ex is not None:
+                ex.close()
+            continue
+        alive.append((ref, ex))
+    entries[:] = alive
+    for ref, ex in entries:
+        if (ref() if ref is not None else None) is pg:
+            return ex
     ex, err = None, None
     try:
         ex = RcclExchange(device, group=group, dist=dist)
@@ -668,10 +711,17 @@ def shared_exchange(device, group=None, dist=None):
             ex.close()
         from .inference.tiles import _warn_once
 
+        _last_exchange_error = repr(err) if err is not None else "another rank of the group could not set up its communicator"
         _warn_once(("rccl-exchange",), f"ShardedTileMerger: the library's own RCCL communicator is not available on every rank ({err!r}); "
                                        "the halo exchange is posted with torch.distributed.batch_isend_irecv instead.")
         ex = None
-    _shared_exchanges[key] = ex
+    else:
+        _last_exchange_error = None
+    try:
+        ref = weakref.ref(pg) if pg is not None else None
+    except TypeError:      # (a group object that cannot be weakly referenced: keyed by the object itself, kept alive with its entry)
+        ref = (lambda obj: (lambda: obj))(pg)
+    entries.append((ref, ex))
     return ex
 
 

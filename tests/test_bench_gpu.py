@@ -53,3 +53,23 @@ def test_two_ranks_on_one_gpu_take_the_sharded_pipelined_path():
         assert e["compute_only_ms"] > 0 and e["out_MB_per_link"] and e["in_MB_per_link"]
     assert sh["pipelined_ms_per_image"] > 0 and sh["latency_mode_ms_per_image"] > 0
     assert "cpu_baseline" not in d            # rank 0 at N = 1 only
+
+
+def test_gpus_2_launches_itself_and_checks_its_band_against_the_single_device_merge():
+    """`python bench.py --gpus 2` as the driver types it -- no torch.distributed.run around it, no WORLD_SIZE: bench.py starts its two
+    ranks itself (here both on the box's one GPU, over gloo).  Before timing, every rank compares the rows it owns with the single-device
+    merge of the same per-tile seeded model outputs; the line carries the worst difference and how many ranks run the library's RCCL
+    exchange (none under gloo, and the line says why)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PTB_BENCH_SAME_GPU="1", PTB_BENCH_BACKEND="gloo")
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--repeats", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    assert "launching" in run.stderr and "torch.distributed.run" in run.stderr
+    d = _line(run.stdout)
+    assert all(k in d for k in CONTRACT) and d["n_gpus"] == 2 and d["steps"] == 2
+    sh = d["config"]["sharded"]
+    assert 0.0 <= sh["parity_max_abs_diff"] <= sh["parity_tolerance"] == 1e-5
+    assert sh["parity_values_checked"] == 4 * 5120 * 5120, "the two bands together are the whole merged map"
+    assert sh["rccl_ranks"] == 0 and "NOT used" in sh["exchange"]
+    assert len(sh["per_rank"]) == 2

@@ -185,6 +185,36 @@ def test_halo_exchange_over_rccl_single_rank():
     ex.close()
 
 
+def test_shared_exchange_belongs_to_the_group_object_not_to_its_id():
+    """the per-process cache of RcclExchange objects was keyed by id(group); a destroyed group's id can be handed to a
+    new group, which then got a communicator bound to the dead one (or a stale "fell back" None).  Entries hold a weak reference to the
+    group OBJECT: same group -> same exchange, another group -> another one, a destroyed group -> its exchange is closed and gone."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from pytorch_toolbelt_amd import parallel as P\n"
+        "dev = torch.device('cuda:0'); torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "e1 = P.shared_exchange(dev); assert isinstance(e1, P.RcclExchange) and P.shared_exchange(dev) is e1 and P.last_exchange_error() is None\n"
+        "g = dist.new_group([0]); e2 = P.shared_exchange(dev, g); assert isinstance(e2, P.RcclExchange) and e2 is not e1 and P.shared_exchange(dev, g) is e2\n"
+        "del g\n"
+        "dist.destroy_process_group()\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)\n"
+        "e3 = P.shared_exchange(dev); assert isinstance(e3, P.RcclExchange) and e3 is not e1 and e3 is not e2\n"
+        "assert e1.comm is None, 'the exchange of the destroyed default group must have been closed'\n"
+        "a = torch.randn(1024, device=dev); b = torch.zeros_like(a); e3.post([(a, 0)], [(b, 0)]); e3.wait(); torch.cuda.synchronize(); assert torch.equal(a, b)\n"
+        "P.close_shared_exchanges(); assert e3.comm is None and not P._shared_exchanges\n"
+        "dist.destroy_process_group(); print('OK')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
 # ------------------------------------------------------------------ pipelined exchange + communication-free partition with the real kernels
 def _pipeline_worker(rank, world, port, partition, defer, backend, q):
     import torch.distributed as dist

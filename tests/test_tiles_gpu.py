@@ -869,6 +869,27 @@ def test_tile_merger_dtype_argument(dtype, dev):
         TileMerger(slicer.target_shape, 2, slicer.weight, device=dev, dtype=torch.int32)
     vm = VolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=dtype)
     assert vm.merge().dtype == dtype
+    if dtype == torch.float64:
+        # float64 accumulators are float64 SUMS under every name the HIP merger goes by (CudaTileMerger / subclasses fell
+        # through to float32 sums cast afterwards)
+        from pytorch_toolbelt_amd.inference.tiles import CudaTileMerger, HostBackedTileMerger
+
+        cm = CudaTileMerger(slicer.target_shape, 2, slicer.weight, dtype=torch.float64)
+        assert isinstance(cm, HostBackedTileMerger) and cm.mode == "host" and cm.image.dtype == torch.float64 and cm.image.is_cuda
+        cm.integrate_batch(pred.to(dev).double(), crops)
+        assert torch.equal(cm.merge(), m.merge())
+        assert type(CudaTileMerger(slicer.target_shape, 2, slicer.weight)) is CudaTileMerger
+
+        class MyMerger(TileMerger):
+            pass
+
+        class MyVolumeMerger(VolumeMerger):
+            pass
+
+        with pytest.raises(TypeError, match="float64 accumulators"):
+            MyMerger(slicer.target_shape, 2, slicer.weight, device=dev, dtype=torch.float64)
+        with pytest.raises(TypeError, match="float64 accumulators"):
+            MyVolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=torch.float64)
 
 
 @pytest.mark.parametrize("group,reduction,dtype", [("d4", "mean", torch.float32), ("d4", "gmean", torch.float32), ("fliplr", "sum", torch.float32),
