@@ -857,9 +857,10 @@ class CudaTileMerger(TileMerger):
     """The name the reference README uses (README.md:201,215): a TileMerger that defaults to the GPU."""
 
     def __new__(cls, image_shape=None, channels=None, weight=None, device="cuda", *args, **kwargs):
-        # float64 accumulators (and a caller who names the CPU after all) get the torch-op merger, exactly like TileMerger(...) does
+        # float64 accumulators get the torch-op merger on the device, exactly like TileMerger(..., device="cuda", dtype=torch.float64) does
+        # (device="cpu" stays an error: this is the name of the GPU merger)
         dtype = kwargs.get("dtype", args[0] if args else torch.float32)
-        if cls is CudaTileMerger and (torch.device(device).type != "cuda" or dtype == torch.float64):
+        if cls is CudaTileMerger and torch.device(device).type == "cuda" and dtype == torch.float64:
             return HostBackedTileMerger(image_shape, channels, weight, device, *args, **kwargs)      # (not a CudaTileMerger: __init__ is not run again)
         return object.__new__(cls)
 
