@@ -332,6 +332,16 @@ int ptb_stack_reduce_bwd(const float* src, const float* out, const float* grad_o
 int ptb_view_transform(const float* in, float* out, int V, const int* views, int in_is_batch, float scale, int B, int C,
                        int H, int W, ptb_stream_t stream);
 
+/* The same views as pure data movement for elements of ANY type: torch_fliplr ... torch_rot180_transpose, *_image_augment and
+ * *_image_deaugment(reduction=None) on integer / boolean / float64 / half tensors and on tensors of more than four dims
+ * (inference/functional.py:47-132: x.flip(3), x.flip(2), x.rot90(k, dims=(2, 3)), x.transpose(2, 3) -- index permutations of dims 2
+ * and 3 whatever the dtype, dims beyond the fourth ride along with their pixel).  in [planes or V*planes, H, W, run] elements of
+ * elem_bytes (1 | 2 | 4 | 8 | 16) bytes, planes = B * C, run = product of the dims beyond the fourth (1 for 4-D tensors);
+ * out [V*planes, Ho, Wo, run] with (Ho, Wo) = (W, H) for transposing views -- non-square planes are fine when the views of one call
+ * agree on the output shape (all transposing or none; PTB_EINVAL otherwise).  Bit-exact by construction. */
+int ptb_view_permute(const void* in, void* out, int V, const int* views, int in_is_batch, int64_t planes, int H, int W,
+                     int elem_bytes, int64_t run, ptb_stream_t stream);
+
 /* ---- fused: de-augment + reduce + TileMerger.integrate_batch (tta.py:442-467 feeding tiles.py:321-339) ----------
  * image[:, y:y+th, x:x+tw] += reduce_k view_k(in[k*B+b]) * weight ; norm += weight.  The reduced tile never goes
  * to HBM.  Same tensors as ptb_deaug_reduce (H=th, W=tw) and ptb_tile_accumulate (incl. the first-touch bitmap). */

@@ -695,6 +695,57 @@ def gen_tta4():
     save("tta4.npz", A, cases)
 
 
+def gen_tta5():
+    """The view ops as index permutations of ANY dtype and rank >= 4 (inference/functional.py:47-132: x.flip(3), x.rot90(k, dims=(2, 3)),
+    x.transpose(2, 3)), and the augment / de-augment(reduction=None) groups built on them (inference/tta.py:257-524): outputs of the
+    unmodified reference for integer, boolean, half, float64 and complex inputs, 4-D / 5-D, square and non-square planes.  Stored as raw
+    bytes (uint8 views) so that bfloat16 / complex survive the npz; a case names its dtype and shape."""
+    A, cases = {}, []
+    ops = ["torch_fliplr", "torch_flipud", "torch_rot90_ccw", "torch_rot90_cw", "torch_rot180", "torch_transpose", "torch_transpose2",
+           "torch_rot90_ccw_transpose", "torch_rot90_cw_transpose", "torch_rot180_transpose", "torch_transpose_rot90_ccw",
+           "torch_transpose_rot90_cw", "torch_transpose_rot180"]
+    dtypes = ["uint8", "int8", "int16", "int32", "int64", "bool", "float16", "bfloat16", "float32", "float64", "complex64"]
+
+    def raw(t):
+        return t.detach().contiguous().cpu().view(torch.uint8).numpy() if t.dtype != torch.bool else t.detach().contiguous().cpu().numpy().view(np.uint8)
+
+    def make(shape, name, seed):
+        dt = getattr(torch, name)
+        g = torch.Generator().manual_seed(seed)
+        if dt == torch.bool:
+            return torch.rand(shape, generator=g) < 0.5
+        if dt.is_complex:
+            return torch.complex(torch.randn(shape, generator=g), torch.randn(shape, generator=g)).to(dt)
+        if dt.is_floating_point:
+            return torch.randn(shape, generator=g, dtype=torch.float64).to(dt)
+        info = torch.iinfo(dt)
+        return torch.randint(max(info.min, -2**62), min(info.max, 2**62), shape, generator=g, dtype=torch.int64).to(dt)
+
+    for di, name in enumerate(dtypes):
+        for si, shape in enumerate(((2, 2, 12, 12), (1, 2, 9, 14), (1, 1, 6, 10, 3))):
+            x = make(shape, name, 500 + 10 * di + si)
+            xin = f"x_{name}_{si}"
+            A[xin] = raw(x)
+            for op in ops:
+                y = getattr(rfn, op)(x)
+                key = f"{op}_{name}_{si}"
+                A[key] = raw(y)
+                cases.append(dict(name=key, fn=op, kwargs=dict(dtype=name, shape=list(shape), out_shape=list(y.shape)), inputs=[xin], output=key))
+            if shape[2] == shape[3]:
+                for group in ("fliplr", "flipud", "flips", "d2", "d4"):
+                    aug = getattr(rtta, f"{group}_image_augment")(x)
+                    key = f"{group}_image_augment_{name}_{si}"
+                    A[key] = raw(aug)
+                    cases.append(dict(name=key, fn=f"{group}_image_augment", kwargs=dict(dtype=name, shape=list(shape), out_shape=list(aug.shape)),
+                                      inputs=[xin], output=key))
+                    back = getattr(rtta, f"{group}_image_deaugment")(aug, reduction=None)
+                    key = f"{group}_image_deaugment_none_{name}_{si}"
+                    A[key] = raw(back)
+                    cases.append(dict(name=key, fn=f"{group}_image_deaugment_none", kwargs=dict(dtype=name, shape=list(aug.shape), out_shape=list(back.shape)),
+                                      inputs=[f"{group}_image_augment_{name}_{si}"], output=key))
+    save("tta5.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -949,5 +1000,6 @@ if __name__ == "__main__":
     gen_tta2()
     gen_tta3()
     gen_tta4()
+    gen_tta5()
     gen_volumes()
     gen_fullsize()

@@ -81,6 +81,7 @@ SIGNATURES = {
     "ptb_deaug_reduce": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_deaug_reduce_bwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _ip, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_view_transform": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_f, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_view_permute": (_c_int, [_vp, _vp, _c_int, _ip, _c_int, _c_i64, _c_int, _c_int, _c_int, _c_i64, _vp]),
     "ptb_resize_bilinear": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_deaug_reduce": (_c_int, [_vp, _ip, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_deaug_reduce_strip": (_c_int, [_vp, _ip, _ip, _ip, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),

@@ -1,0 +1,146 @@
+// ptb_permute.hip -- the eight D4 image views as pure data movement for ANY element width (gfx950 / MI355X).
+//
+// Reference: inference/functional.py:47-132 -- torch_fliplr / torch_flipud / torch_rot90_cw / ... are x.flip(3), x.flip(2),
+// x.rot90(k, dims=(2, 3)), x.transpose(2, 3): index permutations of dims 2 and 3 of a tensor of any dtype and of any rank >= 4
+// (dims beyond the fourth ride along with their pixel).  The fp32 view kernels of ptb_views.hip multiply by a scale and reduce; a
+// label mask (int64), a boolean mask, a float64 map or a 5-D tensor must come out with exactly the bits it went in with, so this
+// kernel moves opaque elements of 1 / 2 / 4 / 8 / 16 bytes:
+//
+//     out[k*B*C + p][i][j][e] = in[src plane][si][sj][e],   (a, b) = transpose_k ? (j, i) : (i, j),
+//                               si = flip_rows_k ? H-1-a : a,   sj = flip_cols_k ? W-1-b : b,   e < run
+//
+// with the library's 3-bit view code (bit 0 transpose, bit 1 flip source rows, bit 2 flip source cols, include/ptb_hip.h).  The
+// source is [planes or V*planes][H][W][run], the output [V*planes][Ho][Wo][run] with (Ho, Wo) = (W, H) for transposing views -- non-square
+// planes are fine, like x.rot90 on a non-square tensor.
+//
+// One workgroup moves one TS x TS tile of one output plane through LDS: the source region of the tile (TS source rows of TS
+// elements, or what the plane's edge leaves of them) is read row by row -- consecutive lanes read consecutive elements, whatever the
+// view -- into a padded tile, and written out row by row of the OUTPUT, each lane picking its element's source position in the
+// tile.  Both sides are coalesced for all eight views; the pad keeps the transposed read spread over the banks.  HBM-bound: every
+// element is read once and written once.
+#include "ptb_common.h"
+
+namespace ptb {
+
+typedef unsigned int E16 __attribute__((ext_vector_type(4)));     // an opaque 16-byte element (complex128, or 2 x 8 bytes of trailing dims)
+
+template <typename T> struct TileSize { static constexpr int value = 64; };
+template <> struct TileSize<E16> { static constexpr int value = 32; };
+
+struct PermArgs {
+    const void* in;
+    void* out;
+    int V, codes;              // 3 bits per view
+    int in_is_batch;           // 1: every view reads plane p; 0: view k reads plane k * planes + p
+    long long planes;          // B * C
+    int H, W;                  // source plane
+    int tiles_y, tiles_x;      // of the OUTPUT plane
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void view_permute_kernel(const PermArgs a) {
+    constexpr int TS = TileSize<T>::value;
+    __shared__ T tile[TS][TS + 1];
+    const int tid = threadIdx.x;
+    long long bid = blockIdx.x;
+    const int tx = (int)(bid % a.tiles_x); bid /= a.tiles_x;
+    const int ty = (int)(bid % a.tiles_y); bid /= a.tiles_y;
+    const long long p = bid % a.planes;
+    const int k = (int)(bid / a.planes);
+    const int code = (a.codes >> (3 * k)) & 7;
+    const bool tr = code & 1, fr = code & 2, fc = code & 4;
+    const int Ho = tr ? a.W : a.H, Wo = tr ? a.H : a.W;
+    const int i0 = ty * TS, j0 = tx * TS;
+    const int th = min(TS, Ho - i0), tw = min(TS, Wo - j0);       // extent of the output tile
+    // the source rectangle of this tile: output rows (cols) map to source rows (cols), or -- transposed -- to source cols (rows)
+    const int ah = tr ? tw : th, aw = tr ? th : tw;                // extent in source orientation
+    const int a0 = tr ? j0 : i0, b0 = tr ? i0 : j0;                // un-flipped origin (a, b)
+    const int sr0 = fr ? a.H - a0 - ah : a0;                       // first source row / col of the rectangle (ascending addresses)
+    const int sc0 = fc ? a.W - b0 - aw : b0;
+    const T* __restrict__ src = static_cast<const T*>(a.in) + ((a.in_is_batch ? p : (long long)k * a.planes + p) * a.H + sr0) * (long long)a.W + sc0;
+    for (int e = tid; e < ah * TS; e += 256) {                     // row-major over the rectangle, TS lanes per source row
+        const int r = e / TS, c = e - r * TS;
+        if (c < aw) tile[r][c] = __builtin_nontemporal_load(src + (long long)r * a.W + c);
+    }
+    __syncthreads();
+    T* __restrict__ dst = static_cast<T*>(a.out) + (((long long)k * a.planes + p) * Ho + i0) * (long long)Wo + j0;
+    for (int e = tid; e < th * TS; e += 256) {
+        const int i = e / TS, j = e - i * TS;
+        if (j < tw) {
+            const int aa = tr ? j : i, bb = tr ? i : j;            // position in the un-flipped rectangle
+            const int r = fr ? ah - 1 - aa : aa, c = fc ? aw - 1 - bb : bb;
+            __builtin_nontemporal_store(tile[r][c], dst + (long long)i * Wo + j);
+        }
+    }
+}
+
+// run > 1 (dims beyond the fourth): one lane per output element, the pixel's `run` elements stay together
+template <typename T>
+__global__ __launch_bounds__(256) void view_permute_run_kernel(const PermArgs a, long long run, long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        long long rest = o;
+        const long long e = rest % run; rest /= run;
+        const int code0 = a.codes & 7;
+        const int Wo = (code0 & 1) ? a.H : a.W, Ho = (code0 & 1) ? a.W : a.H;      // (all views of one call share the output shape)
+        const int j = (int)(rest % Wo); rest /= Wo;
+        const int i = (int)(rest % Ho); rest /= Ho;
+        const long long p = rest % a.planes;
+        const int k = (int)(rest / a.planes);
+        const int code = (a.codes >> (3 * k)) & 7;
+        const int aa = (code & 1) ? j : i, bb = (code & 1) ? i : j;
+        const int si = (code & 2) ? a.H - 1 - aa : aa, sj = (code & 4) ? a.W - 1 - bb : bb;
+        const long long sp = a.in_is_batch ? p : (long long)k * a.planes + p;
+        static_cast<T*>(a.out)[o] = static_cast<const T*>(a.in)[((sp * a.H + si) * (long long)a.W + sj) * run + e];
+    }
+}
+
+template <typename T>
+static int launch_permute(const PermArgs& a, long long run, hipStream_t s) {
+    const int tr0 = a.codes & 1;
+    const int Ho = tr0 ? a.W : a.H, Wo = tr0 ? a.H : a.W;
+    if (run == 1) {
+        constexpr int TS = TileSize<T>::value;
+        PermArgs b = a;
+        b.tiles_y = (Ho + TS - 1) / TS;
+        b.tiles_x = (Wo + TS - 1) / TS;
+        const long long blocks = (long long)a.V * a.planes * b.tiles_y * b.tiles_x;
+        if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+        hipLaunchKernelGGL(view_permute_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, b);
+    } else {
+        const long long total = (long long)a.V * a.planes * Ho * Wo * run;
+        const long long want = (total + 255) / 256;
+        hipLaunchKernelGGL(view_permute_run_kernel<T>, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, s, a, run, total);
+    }
+    return check_launch();
+}
+
+}  // namespace ptb
+
+using namespace ptb;
+
+extern "C" int ptb_view_permute(const void* in, void* out, int V, const int* views, int in_is_batch, int64_t planes, int H, int W,
+                                int elem_bytes, int64_t run, ptb_stream_t stream) {
+    if (!in || !out || !views || V < 1 || V > 8 || planes < 0 || H < 0 || W < 0 || run < 1) return PTB_EINVAL;
+    int codes = 0, nT = 0;
+    for (int k = 0; k < V; ++k) {
+        if (views[k] < 0 || views[k] > 7) return PTB_EINVAL;
+        codes |= views[k] << (3 * k);
+        nT += views[k] & 1;
+    }
+    if (nT != 0 && nT != V && H != W) return PTB_EINVAL;      // transposing and row-preserving views of one call share one output shape
+    if (elem_bytes != 1 && elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return PTB_EINVAL;
+    if (planes == 0 || H == 0 || W == 0) return PTB_OK;
+    const uintptr_t both = reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out);
+    if (both & (uintptr_t)(elem_bytes - 1)) return PTB_EUNSUPPORTED;      // (elements must be naturally aligned: torch storage is)
+    PermArgs a{};
+    a.in = in; a.out = out; a.V = V; a.codes = codes; a.in_is_batch = in_is_batch ? 1 : 0; a.planes = planes; a.H = H; a.W = W;
+    hipStream_t s = (hipStream_t)stream;
+    switch (elem_bytes) {
+        case 1: return launch_permute<unsigned char>(a, run, s);
+        case 2: return launch_permute<unsigned short>(a, run, s);
+        case 4: return launch_permute<unsigned int>(a, run, s);
+        case 8: return launch_permute<unsigned long long>(a, run, s);
+        case 16: return launch_permute<E16>(a, run, s);
+        default: return PTB_EINVAL;
+    }
+}

@@ -21,14 +21,19 @@ RED_SUM, RED_MEAN, RED_GMEAN, RED_HMEAN, RED_HARMONIC1P, RED_LOGODD, RED_LOG1P =
 
 
 def apply_view(x: torch.Tensor, code: int) -> torch.Tensor:
-    """One element of D4 acting on the last two dims (a strided view of ``x``, like the reference's rot90 / transpose chains)."""
-    flips = [d for d, bit in ((-2, 2), (-1, 4)) if code & bit]
+    """One element of D4 acting on dims (2, 3) of a tensor of rank >= 4 -- ``x.flip(2)`` / ``x.flip(3)`` / ``x.transpose(2, 3)`` like
+    the reference's chains (inference/functional.py:47-132); dims beyond the fourth ride along, a tensor of lower rank raises what
+    torch raises for a dim that does not exist.  A strided view of ``x``."""
+    flips = [d for d, bit in ((2, 2), (3, 4)) if code & bit]
     y = x.flip(flips) if flips else x
-    return y.transpose(-1, -2) if code & 1 else y
+    return y.transpose(2, 3) if code & 1 else y
 
 
 def _needs_square(views, x):
-    if any(v & 1 for v in views) and x.shape[-1] != x.shape[-2]:
+    """Views that transpose and views that do not give different shapes on a non-square plane: they cannot share one batch
+    (d4_image_augment says so, inference/tta.py:399-403).  A call whose views all transpose -- or none -- is fine on any plane."""
+    n_t = sum(v & 1 for v in views)
+    if n_t and n_t != len(views) and x.dim() >= 4 and x.shape[2] != x.shape[3]:
         raise ValueError(f"Input tensor must have number of rows equal to number of cols. Got input tensor of shape {x.size()}")
 
 
@@ -42,7 +47,7 @@ def view_transform(x: torch.Tensor, views: Sequence[int], in_is_batch: bool = Tr
         if x.shape[0] % V:
             raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {V}.")
         parts = [apply_view(chunk, c) for chunk, c in zip(torch.chunk(x, V), views)]
-    out = torch.cat(parts, dim=0)
+    out = torch.cat(parts, dim=0) if V > 1 else parts[0]
     return out if scale == 1.0 else out * scale
 
 

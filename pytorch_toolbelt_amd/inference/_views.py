@@ -149,26 +149,99 @@ class _DeaugReduce(torch.autograd.Function):
         return _raw_view_transform(g.contiguous(), inv, True, scale), None, None
 
 
+def _raw_permute(x, views: Sequence[int], in_is_batch: bool):
+    """``ptb_view_permute``: the views as pure data movement -- any dtype, any rank >= 4 (dims beyond the fourth ride along with their
+    pixel), non-square planes when the views agree on the output shape.  ``x`` contiguous on the GPU; the result has its dtype and
+    exactly its bits."""
+    V = len(views)
+    n, C, H, W = (int(v) for v in x.shape[:4])
+    rest = tuple(int(v) for v in x.shape[4:])
+    B = n if in_is_batch else n // V
+    n_t = sum(v & 1 for v in views)
+    if n_t and n_t != V and H != W:
+        raise ValueError(f"Input tensor must have number of rows equal to number of cols. Got input tensor of shape {x.size()}")
+    Ho, Wo = (W, H) if n_t else (H, W)
+    out = torch.empty((V * B, C, Ho, Wo) + rest, device=x.device, dtype=x.dtype)
+    if out.numel() == 0:
+        return out
+    payload = x.element_size()
+    for r in rest:
+        payload *= r
+    align = x.data_ptr() | out.data_ptr()
+    elem = next(e for e in (16, 8, 4, 2, 1) if payload % e == 0 and align % e == 0)
+    lib = N.load()
+    with N.on_device(x.device):
+        rc = lib.ptb_view_permute(x.data_ptr(), out.data_ptr(), V, N.int_array(views), 1 if in_is_batch else 0, B * C, H, W, elem,
+                                  payload // elem, N.stream_ptr(x.device))
+    N.bump()
+    N.check(rc, "ptb_view_permute")
+    return out
+
+
+class _Permute(torch.autograd.Function):
+    """The permutation path with a gradient (float64 / half / complex tensors, tensors of more than four dims): the backward moves
+    the incoming gradient back with the inverse views -- and sums the V copies of an augmented batch, in the gradient's own dtype."""
+
+    @staticmethod
+    def forward(ctx, x, views, in_is_batch):
+        ctx.views, ctx.in_is_batch = tuple(views), in_is_batch
+        return _raw_permute(x.contiguous(), views, in_is_batch)
+
+    @staticmethod
+    def backward(ctx, g):
+        inv = [INVERSE[v] for v in ctx.views]
+        back = _raw_permute(g.contiguous(), inv, False)
+        if ctx.in_is_batch and len(inv) > 1:
+            back = back.view(len(inv), back.shape[0] // len(inv), *back.shape[1:]).sum(dim=0)
+        return back, None, None
+
+
 def view_transform(x, views, in_is_batch=True, scale=1.0):
+    views = list(views)
     if not x.is_cuda:      # a host tensor: the device-agnostic torch path (inference/_host.py), like the reference
-        return _host.view_transform(x, list(views), in_is_batch, scale)
-    x, back = _check_image(x, "view transform", ints=True)     # (pure data movement: integer images are fine)
-    out = _ViewTransform.apply(x, list(views), in_is_batch, scale)
-    return out.to(back) if back is not None else out
+        return _host.view_transform(x, views, in_is_batch, scale)
+    N.require_device(x, "view transform")
+    if x.dim() < 4:        # dims 2 and 3 do not exist: raise what x.flip(3) / x.rot90(dims=(2, 3)) / x.transpose(2, 3) raise (functional.py:47-132)
+        return _host.view_transform(x, views, in_is_batch, scale)
+    if not in_is_batch and x.shape[0] % len(views) != 0:
+        raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
+    square = x.shape[2] == x.shape[3] or not any(v & 1 for v in views)
+    if x.dim() == 4 and x.dtype == torch.float32 and square:
+        return _ViewTransform.apply(x, views, in_is_batch, scale)          # the fp32 kernels of the hot path
+    # every other dtype / rank / a non-square plane under transposing views only: an index permutation is index work -- the elements
+    # move as opaque 1 / 2 / 4 / 8 / 16-byte words and come out with the bits they went in with (float64 stays float64)
+    if x.requires_grad and torch.is_grad_enabled() and (x.is_floating_point() or x.is_complex()):
+        out = _Permute.apply(x, views, in_is_batch)
+    else:
+        out = _raw_permute(x.detach().contiguous(), views, in_is_batch)
+    return out if scale == 1.0 else out * scale
 
 
 def deaug_reduce(x, views, code):
+    views = list(views)
     if not x.is_cuda:
-        return _host.deaug_reduce(x, list(views), code)
-    if x.dtype in _LOW_PRECISION and x.is_cuda and x.dim() == 4 and not (x.requires_grad and torch.is_grad_enabled()):
+        return _host.deaug_reduce(x, views, code)
+    if x.dim() != 4 or x.dtype not in (torch.float32,) + _LOW_PRECISION:
+        # float64 (evaluated IN float64, like the reference), integer tensors (whatever torch says to a mean of integers) and tensors
+        # of more than four dims: the inverse views as a bit-exact permutation, then the reduction over the stack -- the HIP stack
+        # kernel for fp32 / half, torch's own ops in the tensor's dtype otherwise
+        V = len(views)
+        if x.dim() >= 4 and x.shape[0] % V != 0:
+            raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {V}.")
+        stack = view_transform(x, views, in_is_batch=False)
+        stack = stack.view(V, stack.shape[0] // V, *stack.shape[1:])
+        if stack.dtype in (torch.float32,) + _LOW_PRECISION:
+            return stack_reduce(stack, code)
+        return _host.reduce_stack(stack, code)
+    if x.dtype in _LOW_PRECISION and not (x.requires_grad and torch.is_grad_enabled()):
         # inference on half-precision model outputs: read them as they are
         if x.shape[0] % len(views) != 0:
             raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
-        return _raw_deaug_reduce(x.contiguous(), list(views), code).to(x.dtype)
+        return _raw_deaug_reduce(x.contiguous(), views, code).to(x.dtype)
     x, back = _check_image(x, "de-augment")
     if x.shape[0] % len(views) != 0:
         raise RuntimeError(f"Input batch size ({x.size(0)}) must be divisible by {len(views)}.")
-    out = _DeaugReduce.apply(x, list(views), code)
+    out = _DeaugReduce.apply(x, views, code)
     return out.to(back) if back is not None else out
 
 
@@ -256,7 +329,11 @@ def stack_reduce(x, code, eps=DEFAULT_EPS):
     if x.dtype in _LOW_PRECISION:
         return stack_reduce(x.float(), code, eps).to(x.dtype)
     if x.dtype != torch.float32:
-        raise NotImplementedError(f"TTA reduction: the native path is float32 (half / bfloat16 are converted), got {x.dtype}")
+        # float64 is reduced IN float64 (the HIP kernels are float32: a double-precision caller wants the reference's double-precision
+        # result, not speed); integer stacks get whatever torch answers to the reference's op chain on them
+        if x.shape[0] < 1:
+            raise RuntimeError("cannot reduce an empty stack")
+        return _host.reduce_stack(x, code, eps)
     T = x.shape[0]
     if T < 1:
         raise RuntimeError("cannot reduce an empty stack")

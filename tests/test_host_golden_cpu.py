@@ -321,3 +321,33 @@ def test_host_volume_merger_bit_exact(case):
     assert np.array_equal(m.merge().numpy(), GV[f"{n}_merged"])
     with pytest.raises(ValueError):
         m.integrate_batch(pred[:1], list(s.crops[:1]) * 2)
+
+
+def test_host_view_ops_of_any_dtype_and_rank_bit_exact():
+    """tests/golden/tta5.npz through the host path: the views act on dims (2, 3) of a tensor of any dtype and any rank >= 4, like the
+    reference's x.flip(3) / x.rot90(k, dims=(2, 3)) / x.transpose(2, 3) (inference/functional.py:47-132)."""
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    tta = _tta()
+    G = load_golden("tta5.npz")
+
+    def tensor(key, dtype_name, shape):
+        dt = getattr(torch, dtype_name)
+        raw = torch.from_numpy(np.ascontiguousarray(G[key]))
+        return (raw.view(torch.bool) if dt == torch.bool else raw.view(dt)).reshape(shape)
+
+    assert len(G.cases) >= 500
+    for case in G.cases:
+        kw = case["kwargs"]
+        x = tensor(case["inputs"][0], kw["dtype"], kw["shape"])
+        fn = case["fn"]
+        if fn.endswith("_deaugment_none"):
+            got = getattr(tta, fn[:-5])(x, reduction=None)
+        elif fn.endswith("_image_augment"):
+            got = getattr(tta, fn)(x)
+        else:
+            got = getattr(F, fn)(x)
+        want = tensor(case["output"], kw["dtype"], kw["out_shape"])
+        assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape) and torch.equal(got, want), case["name"]
+    with pytest.raises(IndexError):
+        F.torch_fliplr(torch.zeros((3, 8, 8)))

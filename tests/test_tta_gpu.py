@@ -279,13 +279,141 @@ def test_half_precision_inputs(dev):
         np.testing.assert_allclose(out.float().cpu().numpy(), want, atol=tol, rtol=tol)
         lab = tta.d2_labels_deaugment(torch.rand((8, 5), device=dev).to(dt))
         assert lab.dtype == dt
-    with pytest.raises(NotImplementedError):
-        tta.d4_image_augment(torch.zeros((1, 1, 8, 8), device=dev, dtype=torch.int32))
-    # 8 / 16-bit integer and float64 images go through float32 exactly (the reference's view ops take any dtype)
-    for dt in (torch.uint8, torch.int16, torch.float64):
+    # integer and float64 images: the views are permutations -- any dtype, exactly its bits (test_view_ops_take_every_dtype_and_rank)
+    for dt in (torch.uint8, torch.int16, torch.int32, torch.float64):
         xi = (torch.rand((2, 3, 16, 16), device=dev) * 200).to(dt)
         got = tta.d4_image_augment(xi)
         assert got.dtype == dt and torch.equal(got.float(), tta.d4_image_augment(xi.float()))
+
+
+_VIEW_OPS = {   # the reference's chains, inference/functional.py:47-132
+    "torch_none": lambda x: x,
+    "torch_fliplr": lambda x: x.flip(3),
+    "torch_flipud": lambda x: x.flip(2),
+    "torch_rot90_ccw": lambda x: x.rot90(k=1, dims=(2, 3)),
+    "torch_rot90_cw": lambda x: x.rot90(k=-1, dims=(2, 3)),
+    "torch_rot180": lambda x: torch.rot90(x, k=2, dims=(2, 3)),
+    "torch_transpose": lambda x: x.transpose(2, 3),
+    "torch_transpose2": lambda x: x.transpose(3, 2),
+    "torch_rot90_ccw_transpose": lambda x: x.rot90(k=1, dims=(2, 3)).transpose(2, 3),
+    "torch_rot90_cw_transpose": lambda x: x.rot90(k=-1, dims=(2, 3)).transpose(2, 3),
+    "torch_rot180_transpose": lambda x: x.rot90(k=2, dims=(2, 3)).transpose(2, 3),
+    "torch_transpose_rot90_ccw": lambda x: x.transpose(2, 3).rot90(k=1, dims=(2, 3)),
+    "torch_transpose_rot90_cw": lambda x: x.transpose(2, 3).rot90(k=-1, dims=(2, 3)),
+    "torch_transpose_rot180": lambda x: x.transpose(2, 3).rot90(k=2, dims=(2, 3)),
+}
+_ALL_DTYPES = [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool, torch.float16, torch.bfloat16, torch.float32,
+               torch.float64, torch.complex64, torch.complex128]
+
+
+def _any_dtype(shape, dt, dev, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    if dt == torch.bool:
+        return (torch.rand(shape, generator=g) < 0.5).to(dev)
+    if dt.is_complex:
+        return torch.complex(torch.randn(shape, generator=g, dtype=torch.float64), torch.randn(shape, generator=g, dtype=torch.float64)).to(dt).to(dev)
+    if dt.is_floating_point:
+        return torch.randn(shape, generator=g, dtype=torch.float64).to(dt).to(dev)
+    info = torch.iinfo(dt)
+    return torch.randint(max(info.min, -2**62), min(info.max, 2**62), shape, generator=g, dtype=torch.int64).to(dt).to(dev)
+
+
+@pytest.mark.parametrize("dt", _ALL_DTYPES, ids=lambda d: str(d).replace("torch.", ""))
+def test_view_ops_take_every_dtype_and_rank(dt, dev):
+    """torch_fliplr ... torch_transpose_rot180, *_image_augment and *_image_deaugment(reduction=None) are index permutations of dims 2
+    and 3 (inference/functional.py:47-132: x.flip(3), x.rot90(k, dims=(2, 3)), x.transpose(2, 3)): every dtype, every rank >= 4
+    (dims beyond the fourth ride along), non-square planes -- torch.equal with the reference's own torch ops on the same CUDA tensor."""
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    tta = _tta()
+    for shape in ((2, 3, 24, 24), (1, 2, 70, 37), (2, 1, 9, 130), (1, 2, 12, 20, 3), (1, 1, 6, 6, 2, 5)):
+        x = _any_dtype(shape, dt, dev, seed=len(shape) + shape[2])
+        for name, ref in _VIEW_OPS.items():
+            got = getattr(F, name)(x)
+            want = ref(x)
+            assert got.dtype == dt and got.shape == want.shape and torch.equal(got, want), (name, shape)
+            assert name == "torch_none" or got.is_contiguous()
+    # the augment / de-augment groups on square planes (d4 needs them square: tta.py:399-406), 4-D and 5-D
+    def chunks(x):      # the reference's torch.cat lists, inference/tta.py:257-284, 319-341, 385-422, 470-484
+        xt = x.transpose(2, 3)
+        return {"fliplr": [x, x.flip(3)], "flipud": [x, x.flip(2)], "flips": [x, x.flip(3), x.flip(2)],
+                "d2": [x, x.flip(3), x.flip(2), x.flip(2).flip(3)],
+                "d4": [x, x.rot90(-1, (2, 3)), x.rot90(2, (2, 3)), x.rot90(1, (2, 3)), xt, xt.rot90(-1, (2, 3)), xt.rot90(2, (2, 3)), xt.rot90(1, (2, 3))]}
+
+    for shape in ((2, 2, 16, 16), (1, 2, 10, 10, 3)):
+        x = _any_dtype(shape, dt, dev, seed=7)
+        for group, want in chunks(x).items():
+            aug = getattr(tta, f"{group}_image_augment")(x)
+            V = len(want)
+            assert aug.dtype == dt and aug.shape[0] == V * shape[0]
+            assert torch.equal(aug, torch.cat(want)), (group, shape)
+            # de-augment without a reduction undoes every view: V copies of x, bit for bit
+            back = getattr(tta, f"{group}_image_deaugment")(aug, reduction=None)
+            assert back.dtype == dt and tuple(back.shape) == (V,) + tuple(shape) and all(torch.equal(back[k], x) for k in range(V)), (group, shape)
+    with pytest.raises(ValueError, match="rows equal to number of cols"):
+        tta.d4_image_augment(_any_dtype((1, 1, 8, 12), dt, dev))
+    for bad in (torch.zeros((3, 8, 8), device=dev).to(dt), torch.zeros((8,), device=dev).to(dt)):      # dims 2 / 3 do not exist: torch's own error
+        with pytest.raises(IndexError):
+            F.torch_fliplr(bad)
+
+
+def golden_tensor(G, key, dtype_name, shape):
+    """An array of tests/golden/tta5.npz (raw bytes of the reference's tensor) as a torch tensor of its dtype and shape."""
+    dt = getattr(torch, dtype_name)
+    raw = torch.from_numpy(np.ascontiguousarray(G[key]))
+    return (raw.view(torch.bool) if dt == torch.bool else raw.view(dt)).reshape(shape)
+
+
+def test_view_ops_of_any_dtype_against_the_reference_goldens(dev):
+    """tests/golden/tta5.npz: outputs of the UNMODIFIED reference's view ops / augment / de-augment(reduction=None) on integer, boolean,
+    half, float64 and complex tensors, 4-D and 5-D, square and not (oracle/make_golden.py gen_tta5) -- replayed through the HIP
+    permutation kernel: same dtype, same shape, same bytes."""
+    from pytorch_toolbelt_amd.inference import functional as F
+
+    tta = _tta()
+    G = load_golden("tta5.npz")
+    assert len(G.cases) >= 500
+    for case in G.cases:
+        kw = case["kwargs"]
+        src_shape = kw["shape"]
+        x = golden_tensor(G, case["inputs"][0], kw["dtype"], src_shape).to(dev)
+        fn = case["fn"]
+        if fn.endswith("_deaugment_none"):
+            got = getattr(tta, fn[:-5])(x, reduction=None)
+        elif fn.endswith("_image_augment"):
+            got = getattr(tta, fn)(x)
+        else:
+            got = getattr(F, fn)(x)
+        want = golden_tensor(G, case["output"], kw["dtype"], kw["out_shape"])
+        assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape), case["name"]
+        assert torch.equal(got.cpu().contiguous().view(torch.uint8) if got.dtype != torch.bool else got.cpu(), want.contiguous().view(torch.uint8) if want.dtype != torch.bool else want), case["name"]
+
+
+def test_float64_and_nd_tta_reductions_on_the_device(dev):
+    """float64 model outputs are de-augmented and reduced IN float64 (the reference is dtype-agnostic; round 4 computed them in
+    float32), 5-D float32 outputs go through the permutation + the HIP stack reduction; gradients flow through both."""
+    tta = _tta()
+    y = torch.rand((16, 2, 12, 12), device=dev, dtype=torch.float64) * 0.9 + 0.05
+    for red in ("mean", "sum", "gmean", "hmean", "logodd"):
+        got = tta.d4_image_deaugment(y, reduction=red)
+        want = AO.image_deaugment(y.cpu().numpy(), "d4", red)
+        assert got.dtype == torch.float64 and want.dtype == np.float64
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-12, atol=1e-13)
+    y5 = torch.rand((8, 2, 10, 10, 3), device=dev) * 0.9 + 0.05
+    got = tta.d4_image_deaugment(y5, reduction="gmean")
+    want = np.stack([AO.image_deaugment(y5[..., k].cpu().numpy(), "d4", "gmean") for k in range(3)], axis=-1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-6)
+    for t in (y.clone().requires_grad_(True), y5.clone().requires_grad_(True)):
+        out = tta.d4_image_deaugment(t, reduction="mean")
+        (out * out).sum().backward()
+        ref = t.detach().clone().requires_grad_(True)
+        from pytorch_toolbelt_amd.inference import _host
+
+        o2 = _host.deaug_reduce(ref, list(tta.DEAUGMENT_VIEWS["d4"]), 1)
+        (o2 * o2).sum().backward()
+        torch.testing.assert_close(t.grad, ref.grad, rtol=1e-5, atol=1e-6)
+        a = tta.d4_image_augment(t[:1])
+        assert a.requires_grad
 
 
 @pytest.mark.parametrize("reduction", ["gmean", "hmean", "harmonic1p", "logodd", "log1p"])
