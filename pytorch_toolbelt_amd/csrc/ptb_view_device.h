@@ -142,6 +142,23 @@ __device__ __forceinline__ float red_dpre(float x, int op) {
 // scatter (lanes walk rows) spreads over banks and the b128 gather (16 lanes per row) stays conflict-free.
 __device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + (j & 3); }
 
+// The same tile as the transposing views of gather_reduce write it.  A ds_write_b32 is serviced in two 32-lane groups over 32 banks:
+// with 64-row blocks (16 lanes per source row, rows 4 apart in i for consecutive lanes) lanes qq and qq + 8 of a group fall on one
+// bank under swz -- a 2-way conflict on every scalar store of the four transposing d4 views (round 4 PMC: SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 40 % in band_plan_kernel).  Rows 32..63 therefore keep the two halves of their 16-byte slots swapped
+// (position-in-slot bit 1 ^= row bit 5): the 32 lanes of a group then cover 32 banks, the ds_read_b128 still fetches whole slots
+// (its bank pattern is unchanged) and un-swaps in registers (unswz4).  32-row blocks (8 lanes per source row) never had the conflict.
+template <int CH>
+__device__ __forceinline__ int swzg(int i, int j) {
+    const int within = CH == 64 ? ((j & 3) ^ ((i >> 4) & 2)) : (j & 3);
+    return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + within;
+}
+template <int CH>
+__device__ __forceinline__ float4 unswz4(const float4 t, int i) {
+    if (CH == 64 && (i & 32)) return make_float4(t.z, t.w, t.x, t.y);
+    return t;
+}
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // 16-byte global load; NT = non-temporal (streamed once: do not keep the line in L2 / Infinity Cache, which is left to
@@ -294,7 +311,7 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
                 for (int m = 0; m < 4; ++m) {
                     const int cc = 4 * qq + m;
                     const int il = (code & 4) ? ch - 1 - cc : cc;
-                    buf[swz(il, jl)] = comp(v[k], m);
+                    buf[swzg<CH>(il, jl)] = comp(v[k], m);
                 }
             }
         }
@@ -307,7 +324,7 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
             if (k < nv && ((codes >> (3 * k)) & 1)) {
                 const float* buf = lds + tb * (CW * CH);
                 ++tb;
-                v[k] = act ? *reinterpret_cast<const float4*>(buf + swz(r, 4 * q)) : make_float4(1.f, 1.f, 1.f, 1.f);
+                v[k] = act ? unswz4<CH>(*reinterpret_cast<const float4*>(buf + swz(r, 4 * q)), r) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
         }
         if (more_entries) __syncthreads();  // LDS tiles are reused by the next covering tile
