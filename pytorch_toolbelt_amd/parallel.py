@@ -23,7 +23,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "tile_grid_partition", "rank_grid", "pixel_row_partition", "pixel_row_cuts", "band_plan", "PendingBand", "shared_exchange", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
+__all__ = ["tile_row_partition", "tile_range_partition", "pixel_row_partition", "pixel_row_cuts", "band_plan", "PendingBand", "shared_exchange", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
            "ms_image_deaugment_strip"]
 
 
@@ -75,7 +75,7 @@ def pixel_row_partition(crops: np.ndarray, world: int, image_height: int) -> Lis
     return [order[(ys < cuts[r + 1]) & (ys + th > cuts[r])].astype(np.int64) for r in range(world)]
 
 
-def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str = "tiles", image_width: int = None, grid=None):
+def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str = "tiles"):
     """Who accumulates, owns and exchanges what.  Per rank a dict with
 
     * ``tiles``: its tile indices in ISSUE order -- the tiles feeding an outgoing rectangle first, so that the exchange
@@ -92,10 +92,6 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
     crops = np.asarray(crops)
     if partition == "pixel_rows":
         return _pixel_row_plan(crops, world, image_height)
-    if partition == "grid":
-        if image_width is None:
-            image_width = int((crops[:, 0] + crops[:, 2]).max())
-        return _grid_plan(crops, world, image_height, int(image_width), grid)
     parts = PARTITIONS[partition](crops, world)
     tw, th = int(crops[0, 2]), int(crops[0, 3])
     step = np.diff(np.unique(crops[:, 1]))
@@ -126,89 +122,6 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
             if not hit.any():
                 continue
             c0, c1 = int(mine[hit, 0].min()), int(mine[hit, 0].max()) + tw
-            plan[s]["sends"].append((d, r0, r1, c0, c1))
-            plan[d]["recvs"].append((s, r0, r1, c0, c1))
-            feeding |= hit
-        plan[s]["boundary"] = parts[s][feeding]
-        plan[s]["tiles"] = np.concatenate([parts[s][feeding], parts[s][~feeding]])
-    return plan
-
-
-def rank_grid(world: int, n_tile_rows: int, n_tile_cols: int):
-    """(grid rows, grid columns) of a 2-D rank grid: the most square factorisation of ``world`` whose column count does not exceed
-    the tile columns (8 -> 4 x 2, 4 -> 2 x 2, 6 -> 3 x 2, primes -> world x 1 = whole tile rows)."""
-    best = (world, 1)
-    for gc in range(1, int(world ** 0.5) + 1):
-        if world % gc == 0 and gc <= max(n_tile_cols, 1):
-            best = (world // gc, gc)
-    return best
-
-
-def tile_grid_partition(crops: np.ndarray, world: int, grid=None) -> List[np.ndarray]:
-    """Tile indices per rank of a 2-D rank grid (rank = grid row * grid columns + grid column): the tile rows are cut by
-    ``np.linspace(0, n_rows, grid rows + 1)``, the tile columns likewise, and a rank gets the tiles of one row group x one column group
-    in row-major order.  At the headline geometry on 4 x 2 ranks: 5 x 10 = 50 tiles at most (speed-up bound 7.2x) and a rank's
-    largest neighbour rectangle is 11.5 MB instead of the 18.9 MB of contiguous tile ranges."""
-    crops = np.asarray(crops)
-    ys, xs = np.unique(crops[:, 1]), np.unique(crops[:, 0])
-    gr, gc = grid if grid is not None else rank_grid(world, len(ys), len(xs))
-    if gr * gc != world:
-        raise ValueError(f"a {gr} x {gc} rank grid does not have {world} ranks")
-    rcut, ccut = np.linspace(0, len(ys), gr + 1, dtype=int), np.linspace(0, len(xs), gc + 1, dtype=int)
-    order = np.lexsort((crops[:, 0], crops[:, 1]))
-    parts = []
-    for i in range(gr):
-        in_rows = np.isin(crops[order, 1], ys[rcut[i]:rcut[i + 1]])
-        for j in range(gc):
-            parts.append(order[in_rows & np.isin(crops[order, 0], xs[ccut[j]:ccut[j + 1]])].astype(np.int64))
-    return parts
-
-
-def _grid_plan(crops, world, image_height, image_width, grid=None):
-    """``band_plan`` of ``partition="grid"``: every rank owns a RECTANGLE of the result (``owned`` rows x ``owned_cols``); the cut
-    between two neighbouring groups lies at the top / left edge of the second group's first tile, so a rank's tiles reach at most one
-    overlap (tile size - tile step) into the rectangles below, to the right and diagonally below-right of its own, and those three
-    rectangles of partial sums travel to their owners.  Groups without tiles (more grid rows than tile rows) own nothing."""
-    ys, xs = np.unique(crops[:, 1]), np.unique(crops[:, 0])
-    gr, gc = grid if grid is not None else rank_grid(world, len(ys), len(xs))
-    parts = tile_grid_partition(crops, world, (gr, gc))
-    tw, th = int(crops[0, 2]), int(crops[0, 3])
-    plan = [dict(rank=r, tiles=parts[r], band=None, owned=None, owned_cols=None, sends=[], recvs=[], boundary=np.zeros(0, dtype=np.int64)) for r in range(world)]
-
-    def cuts(groups_first, size):          # ownership cut positions of the live groups along one axis
-        live = [g for g, first in enumerate(groups_first) if first is not None]
-        edges = {}
-        for k, g in enumerate(live):
-            lo = 0 if k == 0 else int(groups_first[g])
-            hi = size if k == len(live) - 1 else int(groups_first[live[k + 1]])
-            edges[g] = (lo, max(lo, hi))
-        return edges
-
-    row_first = [int(crops[parts[i * gc + next((j for j in range(gc) if len(parts[i * gc + j])), 0)], 1].min())
-                 if any(len(parts[i * gc + j]) for j in range(gc)) else None for i in range(gr)]
-    col_first = [int(crops[parts[next((i for i in range(gr) if len(parts[i * gc + j])), 0) * gc + j], 0].min())
-                 if any(len(parts[i * gc + j]) for i in range(gr)) else None for j in range(gc)]
-    row_own, col_own = cuts(row_first, image_height), cuts(col_first, image_width)
-    live = [r for r in range(world) if len(parts[r])]
-    for r in live:
-        mine = crops[parts[r]]
-        plan[r]["band"] = (int(mine[:, 1].min()), int(mine[:, 1].max()) + th)
-        plan[r]["cols"] = (int(mine[:, 0].min()), int(mine[:, 0].max()) + tw)
-        plan[r]["owned"], plan[r]["owned_cols"] = row_own[r // gc], col_own[r % gc]
-    for s in live:
-        (a, b), (ca, cb) = plan[s]["band"], plan[s]["cols"]
-        mine = crops[parts[s]]
-        feeding = np.zeros(len(mine), dtype=bool)
-        for d in live:
-            if d == s:
-                continue
-            (o0, o1), (p0, p1) = plan[d]["owned"], plan[d]["owned_cols"]
-            r0, r1, c0, c1 = max(a, o0), min(b, o1), max(ca, p0), min(cb, p1)
-            if r0 >= r1 or c0 >= c1:
-                continue
-            hit = (mine[:, 1] < r1) & (mine[:, 1] + th > r0) & (mine[:, 0] < c1) & (mine[:, 0] + tw > c0)
-            if not hit.any():
-                continue
             plan[s]["sends"].append((d, r0, r1, c0, c1))
             plan[d]["recvs"].append((s, r0, r1, c0, c1))
             feeding |= hit
@@ -770,10 +683,8 @@ class ShardedTileMerger:
     ``gather()`` assembles the full map on every rank.  ``partition``: ``"tiles"`` (contiguous tile ranges, the
     reference's ``split_across_nodes`` rule; default), ``"rows"`` (whole tile rows) or ``"pixel_rows"`` (communication-free:
     every rank owns an equal share of the PIXEL rows and is fed every tile touching them -- boundary tiles are evaluated by
-    both neighbours, nothing is exchanged, and the result equals the single-device merge bit for bit) or ``"grid"`` (a 2-D rank grid,
-    ``grid=(rows, cols)`` or the most square factorisation: every rank owns a rectangle ``owned_rows x owned_cols`` and ``merge()``
-    returns ``[C, rows, cols]``; fewer bytes per neighbour -- 11.5 MB instead of 18.9 MB at the headline geometry on 4 x 2 ranks --
-    for up to 50 instead of 46 tiles per rank; accumulates incrementally).
+    both neighbours, nothing is exchanged, and the result equals the single-device merge bit for bit).  (A 2-D rank grid --
+    ``partition="grid"`` of round 4 -- had no deferred band plan and was removed in round 5: 5.4x simulated at N = 8 against 6.6x.)
 
     Pipelining (a stream of images): ``merge_async()`` ends an image without waiting for its halo exchange and moves the merger
     on to a second set of buffers; the exchange of image i then runs beside the kernels of image i + 1 and is only joined when
@@ -782,7 +693,7 @@ class ShardedTileMerger:
     """
 
     def __init__(self, image_shape, channels, weight, crops, device, group=None, ops=None, dist=None, partition="tiles", defer=False,
-                 defer_rows=None, two_phase=True, exchange="auto", pipeline_depth=2, grid=None):
+                 defer_rows=None, two_phase=True, exchange="auto", pipeline_depth=2):
         """``defer=True`` (opt-in, like ``TileMerger``): the rank's tiles are merged band by band straight from the model outputs
         (no accumulator).  The contract that comes with it: the batches are kept by reference and read by a LATER launch, so they
         must stay alive and unmodified until ``merge()`` (a reused output buffer or an in-place edit raises), and the tiles must
@@ -805,13 +716,11 @@ class ShardedTileMerger:
         self.partition = partition
         self.image_height, self.image_width = int(image_shape[0]), int(image_shape[1])
         crops = np.asarray(crops)
-        self.plan = band_plan(crops, self.world, self.image_height, partition, image_width=self.image_width, grid=grid)
+        self.plan = band_plan(crops, self.world, self.image_height, partition)
         me = self.plan[self.rank]
         self.tiles = me["tiles"]
         self.band = me["band"]
         self.owned_rows = me["owned"]
-        # partition="grid": the rank owns a rectangle (rows x columns) of the result; every other partition owns full-width rows
-        self.owned_cols = me.get("owned_cols") or (0, self.image_width)
         self.sends, self.recvs = me["sends"], me["recvs"]
         self.exchange = self._resolve_exchange(exchange)
         self.pipeline_depth = max(1, int(pipeline_depth))
@@ -876,12 +785,7 @@ class ShardedTileMerger:
         # Deferred band merging (opt-in): the rank's tiles are merged band by band straight from the model outputs
         # -- no accumulator read-modify-write, partial sums instead of accumulator rectangles on the rows shared with neighbours.
         # Needs the tiles in `self.tiles` order and a geometry on the 4-pixel grid; otherwise the incremental path below is used.
-        if defer and self.partition == "grid":
-            from .inference.tiles import _warn_once
-
-            _warn_once(("sharded-defer-grid",), "ShardedTileMerger(partition='grid', defer=True): the deferred band plan cuts by rows only; a rank "
-                                                "grid accumulates incrementally (accumulator + rectangle exchange).")
-        elif defer and self.ops is _HipOps and o1 > o0:
+        if defer and self.ops is _HipOps and o1 > o0:
             from .inference.tiles import _defer_rows_default, _warn_once
 
             shared = next((s.deferred for s in self._slots if s.deferred is not None), None)
@@ -1187,9 +1091,7 @@ class ShardedTileMerger:
             else:
                 self.ops.add_rect(image, self.top, (r0, r1, c0, c1), buf)
         out = torch.empty((self.channels, o1 - o0, self.image_width), device=self.device)
-        out = self.ops.merge_rows(image[:, o0 - self.top:o1 - self.top], self.norm_owned[0], out, extra, extra_rows)
-        p0, p1 = self.owned_cols
-        return out if (p0, p1) == (0, self.image_width) else out[:, :, p0:p1]      # (a grid rank: its rectangle of the owned rows)
+        return self.ops.merge_rows(image[:, o0 - self.top:o1 - self.top], self.norm_owned[0], out, extra, extra_rows)
 
     def _merge_deferred(self, slot, o0, o1):
         """Owned rows from the band plan's output: the rows finished alone already hold ``sum / norm``; the others hold this
@@ -1214,12 +1116,11 @@ class ShardedTileMerger:
         full = torch.empty((self.channels, self.image_height, self.image_width), device=self.device)
         for r in range(self.world):
             owned = self.plan[r]["owned"]
-            cols = self.plan[r].get("owned_cols") or (0, self.image_width)
-            if owned is None or owned[1] <= owned[0] or cols[1] <= cols[0]:
+            if owned is None or owned[1] <= owned[0]:
                 continue
-            piece = band.contiguous() if r == self.rank else torch.empty((self.channels, owned[1] - owned[0], cols[1] - cols[0]), device=self.device)
+            piece = band.contiguous() if r == self.rank else torch.empty((self.channels, owned[1] - owned[0], self.image_width), device=self.device)
             self.dist.broadcast(piece, self._global_rank(r), group=self.group)
-            full[:, owned[0]:owned[1], cols[0]:cols[1]] = piece
+            full[:, owned[0]:owned[1]] = piece
         return full
 
 

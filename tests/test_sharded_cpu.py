@@ -272,11 +272,11 @@ def _simulate(shape, tile, step, world, partition, C=1, seed=0):
             buf.copy_(ranks[src]._rect(r0, r1, c0, c1))
         m._exchanged = True
         band = m.merge()
-        (o0, o1), (p0, p1) = m.owned_rows, m.owned_cols
-        owned[o0:o1, p0:p1] += 1
+        o0, o1 = m.owned_rows
+        owned[o0:o1] += 1
         if band is not None:
-            assert tuple(band.shape) == (C, o1 - o0, p1 - p0)
-            full[:, o0:o1, p0:p1] = band
+            assert tuple(band.shape) == (C, o1 - o0, W)
+            full[:, o0:o1] = band
     assert (owned == 1).all()
     st = TO.merger_new(geom["target_shape"], C, w)
     TO.merger_integrate(st, outs, crops)
@@ -291,7 +291,7 @@ def test_plan_fuzz_in_process():
         sh, sw = int(rng.integers(max(1, th // 4), th + 1)), int(rng.integers(max(1, tw // 4), tw + 1))
         shape = (int(rng.integers(th, 6 * th)), int(rng.integers(tw, 6 * tw)))
         world = int(rng.integers(1, 9))
-        partition = {0: "rows", 1: "tiles", 2: "grid"}[case % 3]
+        partition = {0: "rows", 1: "tiles", 2: "pixel_rows"}[case % 3]
         try:
             _simulate(shape, (th, tw), (sh, sw), world, partition, C=int(rng.integers(1, 3)), seed=case)
         except Exception as e:
@@ -450,8 +450,6 @@ def _pipeline_worker(rank, world, port, shape, tile, step, C, partition, q):
     (8, (300, 200), (64, 64), (32, 32), 1, "tiles"),
     (8, (40, 40), (64, 64), (32, 32), 1, "tiles"),        # one tile, eight ranks: seven of them idle through the whole pipeline
     (3, (300, 200), (64, 64), (32, 32), 2, "pixel_rows"),
-    (4, (300, 200), (64, 64), (32, 32), 1, "grid"),           # 2 x 2 ranks: down, right and diagonal rectangles
-    (8, (300, 260), (64, 64), (32, 32), 1, "grid"),           # 4 x 2
 ])
 def test_pipelined_merge_equals_synchronous(world, shape, tile, step, C, partition):
     """merge_async(): image i's halo exchange stays in flight while image i + 1 is integrated (second set of buffers) and is joined
@@ -557,34 +555,6 @@ def test_rank_band_plan_clips_tiles_to_the_owned_pixel_rows():
             assert ni.value in (640 * 5120 // (64 * 64), 640 * 5120 // (64 * 32))
             lib.ptb_band_plan_destroy(handle)
     assert lib.ptb_band_plan_create3(None, None, 1, 1, 4, 4, 4, 4, 4, 0, 4, None, 0, None, 0, 2, None) == -1
-
-
-def test_rank_grid_plan_at_the_headline_geometry():
-    """partition="grid" on 8 ranks = 4 x 2: every rank owns a rectangle, the rectangles tile the image, a rank sends at most three
-    rectangles (below, right, diagonal) and the largest one is 11.5 MB (4 channels) -- against 18.9 MB per neighbour for contiguous
-    tile ranges -- for at most 50 tiles per rank."""
-    from pytorch_toolbelt_amd.parallel import rank_grid, tile_grid_partition
-
-    geom = TO.slicer_geometry((5000, 5000), 512, 256)
-    crops = geom["crops"]
-    assert rank_grid(8, 19, 19) == (4, 2) and rank_grid(4, 19, 19) == (2, 2) and rank_grid(7, 19, 19) == (7, 1) and rank_grid(6, 19, 1) == (6, 1)
-    parts = tile_grid_partition(crops, 8)
-    assert sorted(np.concatenate(parts).tolist()) == list(range(361)) and max(len(p) for p in parts) == 50
-    plan = band_plan(crops, 8, 5120, "grid", image_width=5120)
-    cover = np.zeros((5120, 5120), dtype=np.int8)
-    for r, p in enumerate(plan):
-        (o0, o1), (p0, p1) = p["owned"], p["owned_cols"]
-        cover[o0:o1, p0:p1] += 1
-        assert sorted(p["tiles"].tolist()) == sorted(parts[r].tolist()) and len(p["sends"]) <= 3
-        for d, r0, r1, c0, c1 in p["sends"]:
-            (q0, q1), (s0, s1) = plan[d]["owned"], plan[d]["owned_cols"]
-            assert q0 <= r0 < r1 <= q1 and s0 <= c0 < c1 <= s1 and (r, r0, r1, c0, c1) in plan[d]["recvs"]
-            assert (r1 - r0) * (c1 - c0) * 4 * 4 <= 11.6e6
-        nb = len(p["boundary"])
-        assert p["tiles"][:nb].tolist() == p["boundary"].tolist()
-    assert (cover == 1).all()
-    tiles_plan = band_plan(crops, 8, 5120, "tiles")
-    assert max((r1 - r0) * (c1 - c0) * 16 for p in tiles_plan for _d, r0, r1, c0, c1 in p["sends"]) > 18.8e6
 
 
 def test_host_staged_work_delivers_after_the_transfers():

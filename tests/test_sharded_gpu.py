@@ -291,7 +291,7 @@ def _run_pipeline(world, partition, defer, backend):
 
 
 @pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
-@pytest.mark.parametrize("world,partition", [(2, "tiles"), (3, "tiles"), (3, "pixel_rows"), (4, "grid")])
+@pytest.mark.parametrize("world,partition", [(2, "tiles"), (3, "tiles"), (3, "pixel_rows"), (4, "rows")])
 def test_pipelined_sharded_merger_processes_on_one_gpu(world, partition, defer):
     """merge_async() with the real kernels (processes sharing the GPU, gloo): image i's exchange in flight while image i + 1 is
     merged into the second set of buffers; results bit-identical to the synchronous merge(), within 1e-5 of the oracle."""
