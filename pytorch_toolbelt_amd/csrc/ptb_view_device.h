@@ -148,15 +148,13 @@ __device__ __forceinline__ int swz(int i, int j) { return i * CW + ((((j >> 2) ^
 // SQ_LDS_IDX_ACTIVE = 40 % in band_plan_kernel).  Rows 32..63 therefore keep the two halves of their 16-byte slots swapped
 // (position-in-slot bit 1 ^= row bit 5): the 32 lanes of a group then cover 32 banks, the ds_read_b128 still fetches whole slots
 // (its bank pattern is unchanged) and un-swaps in registers (unswz4).  32-row blocks (8 lanes per source row) never had the conflict.
-template <int CH>
+// (Used by the 64-row instances whose view codes are compile-time constants -- every TTA group; the run-time-codes instance sits at its
+// 128-register ceiling and keeps the plain swizzle, its code untouched.)
 __device__ __forceinline__ int swzg(int i, int j) {
-    const int within = CH == 64 ? ((j & 3) ^ ((i >> 4) & 2)) : (j & 3);
-    return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + within;
+    return i * CW + ((((j >> 2) ^ (i >> 2)) & 15) << 2) + ((j & 3) ^ ((i >> 4) & 2));
 }
-template <int CH>
 __device__ __forceinline__ float4 unswz4(const float4 t, int i) {
-    if (CH == 64 && (i & 32)) return make_float4(t.z, t.w, t.x, t.y);
-    return t;
+    return (i & 32) ? make_float4(t.z, t.w, t.x, t.y) : t;
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -311,7 +309,8 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
                 for (int m = 0; m < 4; ++m) {
                     const int cc = 4 * qq + m;
                     const int il = (code & 4) ? ch - 1 - cc : cc;
-                    buf[swzg<CH>(il, jl)] = comp(v[k], m);
+                    if constexpr (CH == 64 && CODES >= 0) buf[swzg(il, jl)] = comp(v[k], m);
+                    else buf[swz(il, jl)] = comp(v[k], m);
                 }
             }
         }
@@ -324,7 +323,8 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
             if (k < nv && ((codes >> (3 * k)) & 1)) {
                 const float* buf = lds + tb * (CW * CH);
                 ++tb;
-                v[k] = act ? unswz4<CH>(*reinterpret_cast<const float4*>(buf + swz(r, 4 * q)), r) : make_float4(1.f, 1.f, 1.f, 1.f);
+                v[k] = act ? *reinterpret_cast<const float4*>(buf + swz(r, 4 * q)) : make_float4(1.f, 1.f, 1.f, 1.f);
+                if constexpr (CH == 64 && CODES >= 0) v[k] = unswz4(v[k], r);
             }
         }
         if (more_entries) __syncthreads();  // LDS tiles are reused by the next covering tile
