@@ -139,6 +139,9 @@ class Plan:
 
     def __init__(self, xy, remaining0, norm_full):
         self.xy = xy                    # [2, N] int64 origins in integration order
+        self.blocks = remaining0 is not None      # False: a plan for deferred bands only (a geometry off the 64 x 32 block grid of PlannedBlocks)
+        if remaining0 is None:
+            remaining0 = np.zeros((0, 0), dtype=np.uint8)
         self.remaining0 = remaining0
         self.norm_full = norm_full      # [1, H, W] complete normaliser (device)
         self.remaining = remaining0.copy()
@@ -148,21 +151,26 @@ class Plan:
         self.crops4 = None              # the planned (x, y, w, h) rows (what callers' crop arrays are compared with)
 
     @staticmethod
-    def build(merger, crops):
+    def build(merger, crops, blocks=True):
+        """``blocks=False``: a plan for the deferred band merger alone -- the crop sequence and the normaliser, no block bookkeeping: any
+        geometry inside the image will do here (whether the band kernel takes it -- the 4-pixel grid -- is ``Bands.build``'s answer)."""
         crops = coords_xy(crops)
         th, tw = int(merger.weight.shape[1]), int(merger.weight.shape[2])
         H, W = merger.image_height, merger.image_width
         if len(crops) == 0 or np.any(crops[:, 2] != tw) or np.any(crops[:, 3] != th):
             return None
-        aligned = (tw % 64 == 0 and th % FRESH_ROWS == 0 and not np.any(crops[:, 0] % 64) and not np.any(crops[:, 1] % FRESH_ROWS)
-                   and np.all(crops[:, 0] >= 0) and np.all(crops[:, 1] >= 0) and np.all(crops[:, 0] + tw <= W) and np.all(crops[:, 1] + th <= H))
-        if not aligned:
+        inside = np.all(crops[:, 0] >= 0) and np.all(crops[:, 1] >= 0) and np.all(crops[:, 0] + tw <= W) and np.all(crops[:, 1] + th <= H)
+        aligned = inside and tw % 64 == 0 and th % FRESH_ROWS == 0 and not np.any(crops[:, 0] % 64) and not np.any(crops[:, 1] % FRESH_ROWS)
+        if not (aligned if blocks else inside):
             return None   # geometry off the block grid: the ordinary path is used
-        remaining = np.zeros(((H + FRESH_ROWS - 1) // FRESH_ROWS, (W + 63) // 64), dtype=np.int32)
-        for x, y in crops[:, :2]:
-            remaining[y // FRESH_ROWS:(y + th) // FRESH_ROWS, x // 64:(x + tw) // 64] += 1
-        if remaining.max() > 255:
-            return None
+        remaining = None
+        if blocks:
+            remaining = np.zeros(((H + FRESH_ROWS - 1) // FRESH_ROWS, (W + 63) // 64), dtype=np.int32)
+            for x, y in crops[:, :2]:
+                remaining[y // FRESH_ROWS:(y + th) // FRESH_ROWS, x // 64:(x + tw) // 64] += 1
+            if remaining.max() > 255:
+                return None
+            remaining = remaining.astype(np.uint8)
         xy = np.ascontiguousarray(crops[:, :2].T)
         norm_full = torch.zeros((1, H, W), device=merger.weight.device, dtype=torch.float32)
         lib = N.load()
@@ -172,7 +180,7 @@ class Plan:
                                          xy[1].ctypes.data_as(N._i64p), xy.shape[1], th, tw, H, W, None, 0, N.stream_ptr(dev))
         N.bump()
         N.check(rc, "TileMerger(crops=...)")
-        plan = Plan(xy, remaining.astype(np.uint8), norm_full)
+        plan = Plan(xy, remaining, norm_full)
         plan.crops4 = np.ascontiguousarray(crops, dtype=np.int64)
         return plan
 
@@ -325,7 +333,8 @@ class DeferredBands:
         held = self.held.take_all()
         self.active = False
         m._plan.restart()
-        m._plan.active = keep_plan
+        m._plan.active = keep_plan and m._plan.blocks      # (a band-only plan has no block strategy to hand the image to)
+        m._merged = None                                   # (nothing was launched into it; the planned strategy makes its own)
         m._log, m._applied = [], 0
         for batch, (coords, views, reduction), *_rest in held:
             m._accumulate(batch, coords, views, reduction)
@@ -498,7 +507,7 @@ class PlannedBlocks:
         ``take`` decides (and reports)."""
         m = self.m
         plan = m._plan
-        if plan is None or not plan.active or m._deferred.active or not _fast_call(m, batch, crop_coords):
+        if plan is None or not plan.active or not plan.blocks or m._deferred.active or not _fast_call(m, batch, crop_coords):
             return False
         dcode = N.DTYPE_CODES.get(batch.dtype)
         B, pos = crop_coords.shape[0], plan.pos
@@ -526,6 +535,9 @@ class PlannedBlocks:
         m = self.m
         plan = m._plan
         B = xy.shape[1]
+        if not plan.blocks:         # a band-only plan that is no longer deferring: the ordinary path from here on
+            plan.active = False
+            return False
         if plan.active and not m._eager_norm and plan.follows(xy, B):
             rc = self._launch(batch, dcode, n_views, varr, reduction, xs, ys, B)
             if rc == 0:
@@ -782,11 +794,16 @@ class SelfPlanning:
             m._plan.restart()
             if self.bands is None:
                 self.bands = self._acquire(ent, m._plan)
+            if self.bands is None and not m._plan.blocks:
+                m._plan, self.planned = None, False
             return
         self.release()
         if ent.parts is None:
-            plan = Plan.build(m, np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4))
-            if plan is None:          # off the block grid: this geometry never plans
+            crops4 = np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4)
+            plan = Plan.build(m, crops4)
+            if plan is None and not ent.static:
+                plan = Plan.build(m, crops4, blocks=False)      # off the 64 x 32 block grid: deferred bands or nothing
+            if plan is None:          # this geometry never plans
                 ent.disabled = True
                 m._plan, self.planned = None, False
                 return
@@ -796,10 +813,15 @@ class SelfPlanning:
             ent.pool, ent.rows = [], None
         xy, remaining0, norm_full, crops4, built = ent.parts
         torch.cuda.current_stream(norm_full.device).wait_event(built)      # (the normaliser may have been built on another stream)
-        plan = Plan(xy, remaining0, norm_full)
+        plan = Plan(xy, remaining0 if len(remaining0) else None, norm_full)
         plan.crops4 = crops4
+        bands = self._acquire(ent, plan)
+        if bands is None and not plan.blocks:      # a band-only plan without bands (budget, static outputs, the band kernel's grid): no plan at all
+            ent.disabled = ent.disabled or ent.no_defer or ent.static
+            m._plan, self.planned = None, False
+            return
         m._plan, self.planned = plan, True
-        self.bands = self._acquire(ent, plan)
+        self.bands = bands
 
     def opt_out(self):
         """The caller touched the accumulators themselves: this geometry stays on the ordinary (exact, unplanned) path from now on."""

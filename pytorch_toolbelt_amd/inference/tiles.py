@@ -425,22 +425,26 @@ class TileMerger:
                         int(self.image_width)) + _weight_signature(weight)
         self._selfplan = SelfPlanning(self, auto_key)
         self._selfplan.attach()
-        if crops is not None and self._plan is None:
-            _warn_once(("plan", tuple(self.weight.shape), self.image_height, self.image_width),
-                       "TileMerger(crops=...): this geometry is off the 64 x 32 block grid of the planned kernels (tile size / origins); "
-                       "the ordinary accumulate + merge path is used (same results, one more pass).")
         bands = None
-        if defer and self._plan is not None:
-            bands = _Bands.build(self._plan, channels, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height,
+        band_only = _Plan.build(self, crops, blocks=False) if (defer and crops is not None and self._plan is None) else None
+        if defer and (self._plan is not None or band_only is not None):
+            bands = _Bands.build(self._plan or band_only, channels, int(self.weight.shape[1]), int(self.weight.shape[2]), self.image_height,
                                  self.image_width, device, defer_rows if defer_rows is not None else _defer_rows_default())
-            if bands is None:
+            if bands is not None and self._plan is None:
+                self._plan = band_only       # off the 64 x 32 block grid but on the band kernel's 4-pixel grid: deferred bands, no block strategy behind them
+            if bands is None and self._plan is not None:
                 _warn_once(("defer", tuple(self.weight.shape), self.image_height, self.image_width),
                            "TileMerger(defer=True): the deferred band kernel does not take this geometry (tile origins, tile size or image width "
                            "off the 4-pixel grid, more than 224 tiles per launch group or more than 4 tiles over a pixel); the planned incremental "
                            "path is used (same results, slower).")
         elif defer:
-            _warn_once(("defer-noplan",), "TileMerger(defer=True) needs the complete crop list (crops=tiler.crops) on the planned block "
+            _warn_once(("defer-noplan",), "TileMerger(defer=True) needs the complete crop list (crops=tiler.crops) on the band kernel's 4-pixel "
                                           "grid; the ordinary path is used.")
+        if crops is not None and self._plan is None:
+            _warn_once(("plan", tuple(self.weight.shape), self.image_height, self.image_width),
+                       "TileMerger(crops=...): this geometry is off the 64 x 32 block grid of the planned kernels (tile size / origins)"
+                       + (" and off the 4-pixel grid of the deferred band kernel" if defer else "") + "; "
+                       "the ordinary accumulate + merge path is used (same results, one more pass).")
         soft = False
         if bands is None and self._selfplan.bands is not None:      # planned from the previous image of this geometry, band plan included
             bands, soft = self._selfplan.bands, True

@@ -451,6 +451,42 @@ def test_self_planned_merger_takes_an_extra_tile(dev, lazy, autoplan, flavour):
         np.testing.assert_allclose(m.merge().cpu().numpy(), TO.merger_merge(st), rtol=5e-7, atol=1e-7)
 
 
+def test_geometries_off_the_block_grid_defer_too(dev, lazy, autoplan):
+    """Tile origins that are multiples of 4 but not of the planned kernels' 64 x 32 blocks (tile 96, step 48; tile 224 / 112 of the
+    ImageNet-sized models): there is no block plan for them, but the band kernel takes them -- self-planned from the second image,
+    and with crops=, defer=True from the first; bit-identical to the plain merger; a deviation simply goes back to it."""
+    TileMerger = autoplan.TileMerger
+    for shape, tile, step, C, batch in (((500, 420), 96, 48, 2, 5), ((700, 500), 224, 112, 3, 4)):
+        geom = TO.slicer_geometry(shape, tile, step)
+        crops = geom["crops"]
+        assert np.any(crops[:, 0] % 64) and not np.any(crops[:, :2] % 4)
+        w = TO.pyramid_window(tile, tile)[0]
+        n = len(crops)
+        outputs = torch.randn((8 * n, C, tile, tile), device=dev, generator=torch.Generator(device=dev).manual_seed(tile))
+        exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch, literal=False)
+        modes = []
+        for _ in range(3):
+            m = TileMerger(geom["target_shape"], C, w, device=dev)
+            modes.append(m.mode)
+            assert torch.equal(_run_image(m, outputs, crops, batch), exact)
+            assert m.mode == modes[-1]
+        assert modes == ["incremental", "deferred bands", "deferred bands"] and not m._plan.blocks
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            explicit = TileMerger(geom["target_shape"], C, w, device=dev, crops=crops, defer=True)
+        assert explicit.mode == "deferred bands" and torch.equal(_run_image(explicit, outputs, crops, batch, literal=False), exact)
+        # off the remembered sequence before / after bands went out: the ordinary path, no block strategy in between
+        m = TileMerger(geom["target_shape"], C, w, device=dev)
+        order = np.concatenate([np.arange(n)[:n // 2], np.arange(n)[n // 2:][::-1]])
+        sub = torch.cat([outputs[k * n + order] for k in range(8)])
+        want = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), sub, crops[order], batch, literal=False)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = _run_image(m, sub, crops[order], batch)
+        assert m.mode == "incremental"
+        torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-6, equal_nan=True)
+
+
 # ------------------------------------------------------------------------------------------------ self-planned deferral: what the caller never asked for
 def _learn(TileMerger, geom, C, w, dev, outputs, batch, **kw):
     first = TileMerger(geom["target_shape"], C, w, device=dev)

@@ -330,13 +330,125 @@ def fuzz_literal(seeds):
     return bad
 
 
+def fuzz_self_deferred(seeds):
+    """Self-planning mergers under callers that do NOT repeat themselves (round 5: mergers without crops= plan themselves into deferred
+    bands by default).  Per seed a random geometry and a stream of images through new TileMerger(shape, C, weight) objects, every image
+    with a random twist -- none, tiles skipped, tiles in another order from a random point on, an extra tile at the end, merge() early,
+    a read of .image / .norm_mask in the middle, another batch size, a static output buffer, fp16 outputs -- against the plain merger
+    (auto_plan=False) fed the same tiles in the same order: bit-identical while nothing forces a self-deferred merger to degrade
+    mid-image, within 1e-6 relative + the same NaN pattern when it does; never an exception except the one refusal (a model that
+    switches to a static buffer after its geometry was learnt with fresh outputs)."""
+    import warnings
+
+    import test_dropin_gpu as D
+    from pytorch_toolbelt_amd.inference import _lazy, tiles, tta
+
+    bad = 0
+    stats = {"images": 0, "started deferred": 0, "started planned": 0, "degraded (not bit-identical)": 0, "refused static": 0}
+    prev_l, prev_a = _lazy.set_enabled(True), tiles.set_auto_plan(True)
+    os.environ["PTB_DEFER_ROWS"] = "128"
+    try:
+        for seed in seeds:
+            rng = np.random.default_rng(seed)
+            tiles._auto.clear()
+            th = int(rng.choice([64, 128]))
+            step = int(rng.choice([v for v in (32, 64, 128) if v <= th]))
+            shape = (int(rng.integers(2 * th, 6 * th)), int(rng.integers(th, 4 * th)))
+            C, batch = int(rng.integers(1, 4)), int(rng.integers(1, 9))
+            geom = TO.slicer_geometry(shape, (th, th), (step, step))
+            crops, n = geom["crops"], len(geom["crops"])
+            w = TO.pyramid_window(th, th)[0]
+            static = torch.empty((8 * 8, C, th, th), device=dev)
+            try:
+                for image in range(10):
+                    g = torch.Generator(device="cpu").manual_seed(seed * 16 + image)
+                    outputs = (torch.rand((8 * n, C, th, th), generator=g) * 0.9 + 0.05).to(dev)
+                    # even images repeat the regular loop (the geometry is forgotten first: a twisted image makes it ask for more evidence),
+                    # odd images bring a twist to a merger that -- mostly -- starts in deferred bands
+                    if image % 2 == 0:
+                        tiles._auto.clear()
+                    twist = ["skip", "reorder", "extra", "early", "peek", "batch", "static", "half", "late-reorder", "late-early"][int(rng.integers(0, 10))] if image % 2 else "none"
+                    order = np.arange(n)
+                    b = batch
+                    if twist == "skip":
+                        order = order[rng.random(n) > 0.15]
+                    elif twist == "reorder":
+                        cut = int(rng.integers(0, n))
+                        order = np.concatenate([order[:cut], rng.permutation(order[cut:])])
+                    elif twist == "extra":
+                        order = np.concatenate([order, order[int(rng.integers(0, n)):][:1]])
+                    elif twist == "early":
+                        order = order[:int(rng.integers(1, n + 1))]
+                    elif twist == "late-reorder":
+                        cut = int(rng.integers(n // 2, n))
+                        order = np.concatenate([order[:cut], order[cut:][::-1]])
+                    elif twist == "late-early":
+                        order = order[:int(rng.integers(n // 2, n + 1))]
+                    elif twist == "batch":
+                        b = int(rng.integers(1, 9))
+                    peek_at = int(rng.integers(0, len(order))) if twist == "peek" else -1
+                    mergers = {"self": tiles.TileMerger(geom["target_shape"], C, w, device=dev), "plain": tiles.TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False)}
+                    started = mergers["self"].mode
+                    stats["images"] += 1
+                    stats["started deferred"] += started == "deferred bands"
+                    stats["started planned"] += started == "planned"
+                    peeked, refused = {}, False
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        for name, m in mergers.items():
+                            for b0 in range(0, len(order), b):
+                                sel = order[b0:b0 + b]
+                                y = torch.cat([outputs[k * n + sel] for k in range(8)])
+                                if twist == "half":
+                                    y = y.half()
+                                if twist == "static":
+                                    buf = static[:8 * len(sel)]
+                                    buf.copy_(y)
+                                    y = buf
+                                try:
+                                    m.integrate_batch(tta.d4_image_deaugment(y), crops[sel])
+                                except RuntimeError as e:
+                                    if name == "self" and twist == "static" and started == "deferred bands" and "occupies memory" in str(e):
+                                        refused = True
+                                        break
+                                    raise
+                                if b0 <= peek_at < b0 + b:
+                                    peeked[name] = (m.image.clone(), m.norm_mask.clone())
+                            if refused:
+                                break
+                        if refused:
+                            stats["refused static"] += 1
+                            continue
+                        got, want = mergers["self"].merge(), mergers["plain"].merge()
+                    gn, wn = got.float().cpu().numpy(), want.float().cpu().numpy()
+                    assert np.array_equal(np.isnan(gn), np.isnan(wn)), ("nan pattern", image, twist, started)
+                    exact = np.array_equal(np.nan_to_num(gn, nan=-7.0), np.nan_to_num(wn, nan=-7.0))
+                    if not exact:
+                        stats["degraded (not bit-identical)"] += 1
+                        assert started == "deferred bands" and twist in ("skip", "reorder", "extra", "early", "peek", "late-reorder", "late-early"), ("not bit-identical", image, twist, started)
+                        np.testing.assert_allclose(np.nan_to_num(gn), np.nan_to_num(wn), rtol=1e-6, atol=1e-6)
+                    if peeked:
+                        np.testing.assert_allclose(peeked["self"][0].cpu().numpy(), peeked["plain"][0].cpu().numpy(), rtol=1e-6, atol=1e-6)
+                        assert torch.equal(peeked["self"][1], peeked["plain"][1])
+            except Exception as e:  # noqa: BLE001
+                bad += 1
+                print("self-deferred FAIL seed", seed, shape, th, step, C, batch, repr(e)[:400])
+    finally:
+        os.environ.pop("PTB_DEFER_ROWS", None)
+        _lazy.set_enabled(prev_l)
+        tiles.set_auto_plan(prev_a)
+        tiles._auto.clear()
+    print("self-deferred:", stats)
+    return bad
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 200
     seeds = range(first, first + count)
     only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
     fuzzers = {"modes": fuzz_merger_modes, "fused": fuzz_fused, "losses": fuzz_losses, "deferred": fuzz_deferred, "region": fuzz_region_losses,
-               "lovasz": fuzz_lovasz, "literal": fuzz_literal}
+               "lovasz": fuzz_lovasz, "literal": fuzz_literal, "selfdeferred": fuzz_self_deferred}
     run = [f for k, f in fuzzers.items() if only is None or k in only]
     total = sum(f(seeds) for f in run)
     print(f"fuzz: {len(run) * count} cases, {total} failures")
