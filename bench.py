@@ -571,6 +571,10 @@ def main_cfg5(args):
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if parity1 is not None and not parity1["max_abs_diff_vs_plain_merger"] <= parity1["tolerance"]:
+        print(f"[bench] the timed merger's output differs from the plain merger's by {parity1['max_abs_diff_vs_plain_merger']:.3g}: the timing above is not a "
+              "valid result", file=sys.stderr, flush=True)
+        sys.exit(3)
     if parity is not None and not parity["parity_max_abs_diff"] <= parity["parity_tolerance"]:
         print(f"[bench] rank {rank}: the sharded merge differs from the single-device merge by {parity['parity_max_abs_diff']:.3g} "
               f"(tolerance {parity['parity_tolerance']}): the timing above is not a valid result", file=sys.stderr, flush=True)
@@ -872,6 +876,22 @@ def main():
         return wall, e0.elapsed_time(e1)
 
     runs = [timed_run(step, args.steps) for _ in range(max(1, args.repeats))]
+    # ---- N = 1: the timed path's OUTPUT, checked right after the timed runs against the plain HIP merger (accumulate now, divide in
+    # merge(): the reference's data flow, tiles.py:321-346, pinned to the oracle and to the reference's goldens by the -m gpu suite) on
+    # the same model outputs: every value of the merged map, not a digest.  Planned and deferred mergers are bit-identical to it.
+    parity1 = None
+    if not sharded:
+        timed_out = step()
+        plain = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, auto_plan=False)
+        for t, c in zip(batch_tensors, batch_crops):
+            plain.integrate_batch_deaugment(t, c, group="d4", reduction="mean")
+        want1 = plain.merge()
+        parity1 = {"max_abs_diff_vs_plain_merger": float((timed_out - want1).abs().nan_to_num(nan=float("inf")).max()),
+                   "bit_identical": bool(torch.equal(timed_out, want1)), "values_checked": int(want1.numel()), "tolerance": 1e-5,
+                   "against": "TileMerger(auto_plan=False): one accumulate launch per batch + merge() on the same resident model outputs "
+                              "(itself checked against the numpy oracle and the reference's golden vectors by tests/test_fullsize_gpu.py)"}
+        del plain, want1, timed_out
+        torch.cuda.empty_cache()
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     elapsed, region_event_ms = runs[order[len(order) // 2]]    # the median run is the reported one
     repeat_ms = [round(r[0] / args.steps * 1e3, 4) for r in runs]
@@ -1232,6 +1252,7 @@ def main():
                                      "note": "`value` IS the first-allocation figure: the model-output pool as torch's allocator first handed it out"},
                 "best_placement": best_placement,
                 "fallback": fallback,
+                "parity": parity1,
                 "dropin_literal": None if variants is None else {
                     "ms_per_step": variants["dropin_literal_new_merger_per_image_ms"],
                     "value_MP_s": round(IMAGE[0] * IMAGE[1] / 1e3 / variants["dropin_literal_new_merger_per_image_ms"], 1),
@@ -1297,6 +1318,10 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if parity1 is not None and not parity1["max_abs_diff_vs_plain_merger"] <= parity1["tolerance"]:
+        print(f"[bench] the timed merger's output differs from the plain merger's by {parity1['max_abs_diff_vs_plain_merger']:.3g}: the timing above is not a "
+              "valid result", file=sys.stderr, flush=True)
+        sys.exit(3)
     if parity is not None and not parity["parity_max_abs_diff"] <= parity["parity_tolerance"]:
         print(f"[bench] rank {rank}: the sharded merge differs from the single-device merge by {parity['parity_max_abs_diff']:.3g} "
               f"(tolerance {parity['parity_tolerance']}): the timing above is not a valid result", file=sys.stderr, flush=True)

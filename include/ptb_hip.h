@@ -385,6 +385,15 @@ int ptb_ms_deaug_reduce_bwd(const float* const* inputs, const int* hs, const int
 int ptb_resize_nearest(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
                        ptb_stream_t stream);
 
+/* The two remaining 4-D modes F.interpolate offers (the reference forwards any `mode`, inference/tta.py:599-621, 645-689), same layout
+ * and backward convention as ptb_resize_nearest:
+ * "nearest-exact": out[p, y, x] = in[p, min(floor((y + 0.5) * hin / hout), hin - 1), min(floor((x + 0.5) * win / wout), win - 1)];
+ * "area" (= adaptive_avg_pool2d): out[p, y, x] = mean of in[p, floor(y hin / hout) : ceil((y + 1) hin / hout),
+ *                                                           floor(x win / wout) : ceil((x + 1) win / wout)]. */
+int ptb_resize_nearest_exact(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
+                             ptb_stream_t stream);
+int ptb_resize_area(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward, ptb_stream_t stream);
+
 /* F.interpolate(x, size, mode="bicubic", align_corners) for [planes, hin, win] -> [planes, hout, wout] (multiscale TTA with
  * mode="bicubic"): 4 x 4 taps around floor(src) (src without the clamp at 0 of the linear modes), indices clamped into the image,
  * cubic convolution weights with A = -0.75, rows first (aten UpSampleBicubic2d).  backward != 0: `in` is grad_out

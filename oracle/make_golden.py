@@ -695,6 +695,42 @@ def gen_tta4():
     save("tta4.npz", A, cases)
 
 
+def gen_tta6():
+    """ms_image_augment / ms_image_deaugment with the two remaining 4-D modes of F.interpolate, "nearest-exact" and "area" (the
+    reference forwards any mode, inference/tta.py:599-621, 645-689; align_corners=None is the only value these modes take): values and
+    autograd gradients of the unmodified reference, up- and down-scaling, unequal offsets per axis."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(53)
+    x = torch.rand((2, 3, 24, 36), generator=g) * 0.9 + 0.05
+    A["x"] = t2n(x)
+    offsets = [-9, 0, 13, (5, -7)]
+    offs_json = [list(o) if isinstance(o, tuple) else o for o in offsets]
+    for mode in ("nearest-exact", "area"):
+        xin = x.clone().requires_grad_(True)
+        outs = rtta.ms_image_augment(xin, offsets, mode=mode, align_corners=None)
+        tot = sum((o * (torch.arange(o.numel(), dtype=torch.float32).reshape(o.shape) % 5 + 1.0)).sum() for o in outs)
+        tot.backward()
+        key = f"aug_{mode}"
+        for i, o in enumerate(outs):
+            A[f"{key}_{i}"] = t2n(o)
+        A[f"{key}_grad"] = t2n(xin.grad)
+        cases.append(dict(name=key, fn="ms_image_augment_grad", kwargs=dict(size_offsets=offs_json, mode=mode, align_corners=None)))
+    fmaps = [torch.rand((2, 3, 24 + (o[0] if isinstance(o, tuple) else o), 36 + (o[1] if isinstance(o, tuple) else o)), generator=g) * 0.9 + 0.05 for o in offsets]
+    for i, f in enumerate(fmaps):
+        A[f"fm_{i}"] = t2n(f)
+    for mode in ("nearest-exact", "area"):
+        for red in ("mean", "gmean", "logodd"):
+            ins = [f.clone().requires_grad_(True) for f in fmaps]
+            out = rtta.ms_image_deaugment(ins, offsets, reduction=red, mode=mode, align_corners=None)
+            (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 7 + 1.0)).sum().backward()
+            key = f"deaug_{mode}_{red}"
+            A[key] = t2n(out)
+            for i, t in enumerate(ins):
+                A[f"{key}_grad_{i}"] = t2n(t.grad)
+            cases.append(dict(name=key, fn="ms_image_deaugment_grad", kwargs=dict(size_offsets=offs_json, mode=mode, align_corners=None, reduction=red)))
+    save("tta6.npz", A, cases)
+
+
 def gen_tta5():
     """The view ops as index permutations of ANY dtype and rank >= 4 (inference/functional.py:47-132: x.flip(3), x.rot90(k, dims=(2, 3)),
     x.transpose(2, 3)), and the augment / de-augment(reduction=None) groups built on them (inference/tta.py:257-524): outputs of the
@@ -1001,5 +1037,6 @@ if __name__ == "__main__":
     gen_tta3()
     gen_tta4()
     gen_tta5()
+    gen_tta6()
     gen_volumes()
     gen_fullsize()

@@ -221,6 +221,34 @@ def nearest_resize(x, size):
     return x[:, :, idx(x.shape[2], size[0])][:, :, :, idx(x.shape[3], size[1])]
 
 
+def nearest_exact_resize(x, size):
+    """F.interpolate(x, size=size, mode='nearest-exact'): src = min(floor((dst + 0.5) * in / out), in - 1), float32 like 'nearest'
+    (aten UpSample.h nearest_neighbor_exact_compute_source_index; reference inference/tta.py:599-621 forwards any mode)."""
+    def idx(n_in, n_out):
+        scale = np.float32(n_in / n_out)
+        return np.minimum(np.floor((np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * scale).astype(np.int64), n_in - 1)
+    return x[:, :, idx(x.shape[2], size[0])][:, :, :, idx(x.shape[3], size[1])]
+
+
+def area_resize(x, size):
+    """F.interpolate(x, size=size, mode='area') == adaptive_avg_pool2d: output o averages the window
+    [floor(o * in / out), ceil((o + 1) * in / out)) of each axis (aten AdaptiveAveragePooling.cpp start_index / end_index), the window
+    summed row by row in the tensor's dtype, then divided by its element count."""
+    B, C, H, W = x.shape
+    ho, wo = int(size[0]), int(size[1])
+    out = np.empty((B, C, ho, wo), dtype=x.dtype)
+    for oy in range(ho):
+        y0, y1 = (oy * H) // ho, -((-(oy + 1) * H) // ho)
+        for ox in range(wo):
+            x0, x1 = (ox * W) // wo, -((-(ox + 1) * W) // wo)
+            acc = np.zeros((B, C), dtype=x.dtype)
+            for yy in range(y0, y1):
+                for xx in range(x0, x1):
+                    acc = acc + x[:, :, yy, xx]
+            out[:, :, oy, ox] = acc / x.dtype.type((y1 - y0) * (x1 - x0))
+    return out
+
+
 def _cubic_taps(n_in, n_out, align_corners, dtype):
     """Taps of torch's bicubic upsample (aten UpSampleBicubic2d / UpSample.h): source index WITHOUT the clamp at 0 of the linear
     modes, 4 neighbours floor(src) - 1 .. + 2 clamped into the image (upsample_get_value_bounded), cubic convolution weights with
@@ -266,10 +294,10 @@ def bicubic_resize(x, size, align_corners):
 
 
 def _resize(x, size, mode, align_corners):
-    if mode == "nearest":
+    if mode in ("nearest", "nearest-exact", "area"):
         if align_corners is not None:
             raise ValueError("align_corners option can only be set with the interpolating modes")
-        return nearest_resize(x, size)
+        return {"nearest": nearest_resize, "nearest-exact": nearest_exact_resize, "area": area_resize}[mode](x, size)
     if mode == "bicubic":
         return bicubic_resize(x, size, bool(align_corners))
     return bilinear_resize(x, size, bool(align_corners))

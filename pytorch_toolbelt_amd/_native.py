@@ -92,6 +92,8 @@ SIGNATURES = {
     "ptb_stack_reduce": (_c_int, [_vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
     "ptb_stack_reduce_bwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_i64, _c_int, _c_d, _vp, _vp]),
     "ptb_resize_nearest": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_resize_nearest_exact": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "ptb_resize_area": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_flip_deaug_reduce_strip": (_c_int, [_vp, _ip, _ip, _ip, _ip, _c_int, _c_int, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_ms_flip_deaug_reduce": (_c_int, [_vp, _ip, _ip, _c_int, _c_int, _ip, _c_int, _vp, _c_i64, _c_int, _c_int, _c_int, _c_int, _vp]),
     "ptb_seg_loss_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_i64, _c_int, _c_int, _c_f, _c_f, _c_f, _c_i64, _c_f, _vp]),

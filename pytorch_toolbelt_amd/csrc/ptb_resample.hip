@@ -548,6 +548,56 @@ __global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __rest
     }
 }
 
+// F.interpolate(mode="nearest-exact"): src = min(floor((dst + 0.5) * in / out), in - 1) (ATen nearest_neighbor_exact_compute_source_index)
+__device__ __forceinline__ int nearest_exact_src(int dst, float scale, int n_in) { return min((int)floorf(((float)dst + 0.5f) * scale), n_in - 1); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void resize_nearest_exact_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int hin, int win,
+                                                                   int hout, int wout, float sh, float sw) {
+    const long long total = (long long)planes * hout * wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % wout);
+        const long long rest = idx / wout;
+        const int oy = (int)(rest % hout);
+        const long long p = rest / hout;
+        const long long src = (p * hin + nearest_exact_src(oy, sh, hin)) * (long long)win + nearest_exact_src(ox, sw, win);
+        if (BWD) atomicAdd(out + src, in[idx]);
+        else out[idx] = in[src];
+    }
+}
+
+// F.interpolate(mode="area") == adaptive_avg_pool2d (aten AdaptiveAveragePooling): output o averages the input window
+// [floor(o * in / out), ceil((o + 1) * in / out)) of each axis (integer arithmetic), rows outer, columns inner, one division by the
+// window's element count.  BWD: every element of the window receives grad_out / count (atomic adds into the zeroed grad_in, like aten).
+template <bool BWD>
+__global__ __launch_bounds__(256) void resize_area_kernel(const float* __restrict__ in, float* __restrict__ out, int planes, int hin, int win, int hout,
+                                                          int wout) {
+    const long long total = (long long)planes * hout * wout;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int ox = (int)(idx % wout);
+        const long long rest = idx / wout;
+        const int oy = (int)(rest % hout);
+        const long long p = rest / hout;
+        const int y0 = (int)(((long long)oy * hin) / hout), y1 = (int)((((long long)oy + 1) * hin + hout - 1) / hout);
+        const int x0 = (int)(((long long)ox * win) / wout), x1 = (int)((((long long)ox + 1) * win + wout - 1) / wout);
+        const float count = (float)((y1 - y0) * (x1 - x0));
+        if (BWD) {
+            const float g = in[idx] / count;
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(out + (p * hin + y) * (long long)win + x, g);
+        } else {
+            float sum = 0.f;
+            for (int y = y0; y < y1; ++y) {
+                const float* row = in + (p * hin + y) * (long long)win;
+                for (int x = x0; x < x1; ++x) sum = __fadd_rn(sum, row[x]);
+            }
+            out[idx] = sum / count;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bicubic (F.interpolate mode="bicubic")
 // aten UpSampleBicubic2d: source coordinate WITHOUT the clamp at 0 of the linear modes, the 4 x 4 neighbours floor(src) - 1 .. + 2
 // clamped into the image, cubic convolution weights with A = -0.75; rows are interpolated along x first, then the 4 results along y.
@@ -921,6 +971,28 @@ extern "C" int ptb_resize_nearest(const float* in, float* out, int64_t planes, i
     const dim3 grid(grid_1d(planes * hout * wout)), block(256);
     if (backward) hipLaunchKernelGGL(resize_nearest_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
     else hipLaunchKernelGGL(resize_nearest_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    return check_launch();
+}
+
+extern "C" int ptb_resize_nearest_exact(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward,
+                                        ptb_stream_t stream) {
+    if (!in || !out || planes < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    const float sh = (float)hin / (float)hout, sw = (float)win / (float)wout;
+    const dim3 grid(grid_1d(planes * hout * wout)), block(256);
+    if (backward) hipLaunchKernelGGL(resize_nearest_exact_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    else hipLaunchKernelGGL(resize_nearest_exact_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout, sh, sw);
+    return check_launch();
+}
+
+extern "C" int ptb_resize_area(const float* in, float* out, int64_t planes, int hin, int win, int hout, int wout, int backward, ptb_stream_t stream) {
+    if (!in || !out || planes < 0 || hin < 1 || win < 1 || hout < 1 || wout < 1) return PTB_EINVAL;
+    if (planes == 0) return PTB_OK;
+    if (planes > 0x7fffffffLL) return PTB_EUNSUPPORTED;
+    const dim3 grid(grid_1d(planes * hout * wout)), block(256);
+    if (backward) hipLaunchKernelGGL(resize_area_kernel<true>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout);
+    else hipLaunchKernelGGL(resize_area_kernel<false>, grid, block, 0, (hipStream_t)stream, in, out, (int)planes, hin, win, hout, wout);
     return check_launch();
 }
 

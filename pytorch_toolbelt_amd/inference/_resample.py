@@ -1,4 +1,5 @@
-"""Resizing on the GPU for multiscale TTA: HIP kernels ptb_resize_bilinear / ptb_resize_bicubic / ptb_resize_nearest (+ their adjoints),
+"""Resizing on the GPU for multiscale TTA: HIP kernels ptb_resize_bilinear / ptb_resize_bicubic / ptb_resize_nearest / ptb_resize_nearest_exact /
+ptb_resize_area (+ their adjoints),
 ptb_ms_deaug_reduce (+ adjoint) and the fused flips + multiscale pass ptb_ms_flip_deaug_reduce.
 
 The reference calls ``torch.nn.functional.interpolate`` (inference/tta.py:599-621, 645-689) and gets gradients from autograd;
@@ -11,13 +12,14 @@ import torch
 from .. import _native as N
 from . import _host
 
-_MODES = ("bilinear", "nearest", "bicubic")
+_MODES = ("bilinear", "nearest", "bicubic", "nearest-exact", "area")      # every mode F.interpolate takes for a [B, C, H, W] tensor
 
 
 def _check_mode(mode, align_corners):
     if mode not in _MODES:
-        raise NotImplementedError(f"multiscale TTA: mode={mode!r} has no native kernel (available: 'bilinear', 'bicubic', 'nearest')")
-    if mode == "nearest" and align_corners is not None:
+        # (F.interpolate's own answer for a 4-D input: "linear" / "trilinear" want 3-D / 5-D tensors, anything else is unknown)
+        raise NotImplementedError(f"Got 4D input, but mode={mode!r} is not one of F.interpolate's 4-D modes {_MODES}")
+    if mode in ("nearest", "nearest-exact", "area") and align_corners is not None:
         # F.interpolate's own rule (the reference forwards both arguments, tta.py:613-615 / 683-685)
         raise ValueError("align_corners option can only be set with the interpolating modes: linear | bilinear | bicubic | trilinear")
 
@@ -41,6 +43,10 @@ class _Resize(torch.autograd.Function):
                 rc = lib.ptb_resize_bilinear(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 1 if align_corners else 0, N.stream_ptr(x.device))
             elif mode == "bicubic":
                 rc = lib.ptb_resize_bicubic(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 1 if align_corners else 0, 0, N.stream_ptr(x.device))
+            elif mode == "nearest-exact":
+                rc = lib.ptb_resize_nearest_exact(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 0, N.stream_ptr(x.device))
+            elif mode == "area":
+                rc = lib.ptb_resize_area(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 0, N.stream_ptr(x.device))
             else:
                 rc = lib.ptb_resize_nearest(x.data_ptr(), out.data_ptr(), B * C, H, W, ho, wo, 0, N.stream_ptr(x.device))
         N.bump()
@@ -59,6 +65,10 @@ class _Resize(torch.autograd.Function):
                 rc = lib.ptb_resize_bilinear_bwd(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1 if ac else 0, N.stream_ptr(g.device))
             elif mode == "bicubic":
                 rc = lib.ptb_resize_bicubic(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1 if ac else 0, 1, N.stream_ptr(g.device))
+            elif mode == "nearest-exact":
+                rc = lib.ptb_resize_nearest_exact(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1, N.stream_ptr(g.device))
+            elif mode == "area":
+                rc = lib.ptb_resize_area(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1, N.stream_ptr(g.device))
             else:
                 rc = lib.ptb_resize_nearest(g.data_ptr(), gin.data_ptr(), B * C, H, W, ho, wo, 1, N.stream_ptr(g.device))
         N.bump()
@@ -68,7 +78,7 @@ class _Resize(torch.autograd.Function):
 
 def resize(x: torch.Tensor, size, mode: str, align_corners) -> torch.Tensor:
     """``F.interpolate(x, size=size, mode=mode, align_corners=align_corners)`` for a [B, C, H, W] GPU tensor
-    (mode "bilinear" | "bicubic" | "nearest"), differentiable.  Host tensors go to ``F.interpolate`` itself (any mode)."""
+    (mode "bilinear" | "bicubic" | "nearest" | "nearest-exact" | "area"), differentiable.  Host tensors go to ``F.interpolate`` itself (any mode)."""
     if not x.is_cuda:
         return _host.resize(x, size, mode, align_corners)
     _check_mode(mode, align_corners)

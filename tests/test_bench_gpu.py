@@ -36,6 +36,8 @@ def test_single_gpu_line():
     # `value` IS the first-allocation figure (no placement search before it)
     assert d["config"]["first_allocation"]["ms_per_step"] == d["ms_per_step"] and d["config"]["best_placement"] is None
     assert 5000.0 < d["value"] < 16000.0
+    par = d["config"]["parity"]       # the timed path's output against the plain merger, every value of the merged map
+    assert par["bit_identical"] is True and par["max_abs_diff_vs_plain_merger"] == 0.0 and par["values_checked"] == 4 * 5120 * 5120
 
 
 def test_two_ranks_on_one_gpu_take_the_sharded_pipelined_path():

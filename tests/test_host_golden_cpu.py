@@ -351,3 +351,23 @@ def test_host_view_ops_of_any_dtype_and_rank_bit_exact():
         assert got.dtype == want.dtype and tuple(got.shape) == tuple(want.shape) and torch.equal(got, want), case["name"]
     with pytest.raises(IndexError):
         F.torch_fliplr(torch.zeros((3, 8, 8)))
+
+
+def test_host_multiscale_area_and_nearest_exact():
+    """tests/golden/tta6.npz through the host path (F.interpolate itself, whatever the mode)."""
+    tta = _tta()
+    G = load_golden("tta6.npz")
+    for case in G.cases:
+        kw = case["kwargs"]
+        offs = [tuple(o) if isinstance(o, list) else o for o in kw["size_offsets"]]
+        if case["fn"] == "ms_image_augment_grad":
+            outs = tta.ms_image_augment(_t(G["x"]), offs, mode=kw["mode"], align_corners=None)
+            for i, o in enumerate(outs):
+                np.testing.assert_allclose(o.numpy(), G[f"{case['name']}_{i}"], rtol=1e-6, atol=1e-6)
+        else:
+            ins = [_t(G[f"fm_{i}"]).requires_grad_(True) for i in range(len(offs))]
+            out = tta.ms_image_deaugment(ins, offs, reduction=kw["reduction"], mode=kw["mode"], align_corners=None)
+            np.testing.assert_allclose(out.detach().numpy(), G[case["name"]], **TOL)
+            (out * (torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) % 7 + 1.0)).sum().backward()
+            for i, t in enumerate(ins):
+                np.testing.assert_allclose(t.grad.numpy(), G[f"{case['name']}_grad_{i}"], rtol=2e-4, atol=2e-5)

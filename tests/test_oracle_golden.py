@@ -413,6 +413,22 @@ def test_long_stacks_and_eps_oracle(case):
     np.testing.assert_allclose(out, GT3[case["output"]], rtol=1e-5, atol=1e-6)
 
 
+GT6 = load_golden("tta6.npz")
+
+
+@pytest.mark.parametrize("case", GT6.cases, ids=lambda c: c["name"])
+def test_multiscale_area_and_nearest_exact_oracle(case):
+    """oracle.tta_oracle.nearest_exact_resize / area_resize against the unmodified reference (F.interpolate's remaining 4-D modes)."""
+    kw = case["kwargs"]
+    offs = _offs(kw)
+    if case["fn"] == "ms_image_augment_grad":
+        for i, o in enumerate(AO.ms_image_augment(GT6["x"], offs, None, mode=kw["mode"])):
+            np.testing.assert_allclose(o, GT6[f"{case['name']}_{i}"], rtol=1e-6, atol=1e-6)
+    else:
+        out = AO.ms_image_deaugment([GT6[f"fm_{i}"] for i in range(len(offs))], offs, kw["reduction"], None, mode=kw["mode"])
+        np.testing.assert_allclose(out, GT6[case["name"]], rtol=1e-5, atol=2e-6)
+
+
 GT4 = load_golden("tta4.npz")
 
 

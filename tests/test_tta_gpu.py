@@ -595,8 +595,10 @@ def test_ms_flips_fused_equals_composition_at_scale(dev):
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in yg)
     with pytest.raises(ValueError, match="align_corners"):
         tta.ms_image_augment(ys[1], [8], mode="nearest", align_corners=False)       # F.interpolate's own rule
+    with pytest.raises(ValueError, match="align_corners"):
+        tta.ms_image_augment(ys[1], [8], mode="area")                                # (area takes align_corners=None only, like nearest)
     with pytest.raises(NotImplementedError):
-        tta.ms_image_augment(ys[1], [8], mode="area")
+        tta.ms_image_augment(ys[1], [8], mode="trilinear", align_corners=False)      # not a 4-D mode: F.interpolate refuses it too
 
 
 @pytest.mark.parametrize("shape", [(1024, 1024), (500, 700), (330, 260)])
@@ -681,6 +683,40 @@ def test_long_stacks_and_explicit_eps_values_and_gradients(case, dev):
 
 
 # ------------------------------------------------------------------ multiscale with mode="bicubic"
+GT6 = load_golden("tta6.npz")
+
+
+@pytest.mark.parametrize("case", GT6.cases, ids=lambda c: c["name"])
+def test_multiscale_area_and_nearest_exact_values_and_gradients(case, dev):
+    """ms_image_augment / ms_image_deaugment with mode="nearest-exact" and mode="area" (ptb_resize_nearest_exact, ptb_resize_area and
+    their adjoints -- with "bilinear", "bicubic" and "nearest" every mode F.interpolate takes for a 4-D tensor; the reference forwards
+    any, inference/tta.py:599-621, 645-689) against the unmodified reference: values of every scale / of the merged map, and the
+    autograd gradients."""
+    tta = _tta()
+    kw = case["kwargs"]
+    offs = _offs2(kw)
+    if case["fn"] == "ms_image_augment_grad":
+        x = torch.from_numpy(GT6["x"]).to(dev).requires_grad_(True)
+        outs = tta.ms_image_augment(x, offs, mode=kw["mode"], align_corners=None)
+        tot = 0
+        for i, o in enumerate(outs):
+            want = GT6[f"{case['name']}_{i}"]
+            if kw["mode"] == "nearest-exact":
+                assert np.array_equal(o.detach().cpu().numpy(), want)          # a gather: bit-exact
+            else:
+                np.testing.assert_allclose(o.detach().cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+            tot = tot + (o * (torch.arange(o.numel(), dtype=torch.float32, device=dev).reshape(o.shape) % 5 + 1.0)).sum()
+        tot.backward()
+        np.testing.assert_allclose(x.grad.cpu().numpy(), GT6[case["name"] + "_grad"], rtol=1e-4, atol=2e-5)
+    else:
+        ins = [torch.from_numpy(GT6[f"fm_{i}"]).to(dev).requires_grad_(True) for i in range(len(offs))]
+        out = tta.ms_image_deaugment(ins, offs, reduction=kw["reduction"], mode=kw["mode"], align_corners=None)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), GT6[case["name"]], rtol=1e-5, atol=1e-5)
+        (out * (torch.arange(out.numel(), dtype=torch.float32, device=dev).reshape(out.shape) % 7 + 1.0)).sum().backward()
+        for i, t in enumerate(ins):
+            np.testing.assert_allclose(t.grad.cpu().numpy(), GT6[f"{case['name']}_grad_{i}"], rtol=2e-4, atol=2e-5)
+
+
 GT4 = load_golden("tta4.npz")
 
 
