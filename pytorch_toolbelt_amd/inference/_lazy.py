@@ -27,6 +27,10 @@ Code that takes the storage of a tensor without passing through the dispatcher o
 with an ``at::Tensor`` argument, the legacy ``torch.utils.dlpack.to_dlpack`` (guarded here, see ``_guard_legacy_dlpack``) -- sees a
 tensor without storage, as with every wrapper subclass (``FakeTensor``, ``DTensor``); hand it ``handle + 0`` or switch the handles off.
 
+Tensors made under ``torch.inference_mode()`` carry no version counter; they get a handle only when the call expression is their sole
+owner (``deaugment(model(x))`` written as one expression, the model keeping no reference to its output and nothing else sharing its
+storage): then nobody exists who could change the source.
+
 Only inference-shaped calls are lazy (float32 CUDA source, string reduction, no autograd, no tracing / compiling);
 everything else is evaluated on the spot exactly as before.  ``tta.set_lazy_deaugment(False)`` / ``PTB_LAZY_DEAUG=0``
 switch it off.
@@ -253,8 +257,27 @@ def remove_dlpack_guard():
     _dlpack_orig = None
 
 
-def maybe_lazy(source, group, views, code, compute):
-    """A ``LazyDeaugment`` for this call when it is inference-shaped, else None (the caller evaluates eagerly)."""
+def _storage_owners(t):
+    return torch._C._storage_Use_Count(t.untyped_storage()._cdata)
+
+
+try:
+    _ONE_OWNER = _storage_owners(torch.empty(1))      # what the count reads for a tensor that is its storage's only owner
+except Exception:  # noqa: BLE001  (a torch without the private counter: no handles for tensors without a version counter)
+    _ONE_OWNER = None
+
+
+def _sole_owner(t):
+    """Nobody but ``t`` can reach its memory: no view of it, no base tensor, no second tensor made from its storage is alive."""
+    try:
+        return _ONE_OWNER is not None and _storage_owners(t) <= _ONE_OWNER
+    except Exception:  # noqa: BLE001
+        return False
+
+
+def maybe_lazy(source, group, views, code, compute, owned=False):
+    """A ``LazyDeaugment`` for this call when it is inference-shaped, else None (the caller evaluates eagerly).  ``owned``: the public
+    function saw its argument referenced by nobody but the call expression (``tta._TEMP_REFS``)."""
     if not _ENABLED or type(source) is not torch.Tensor or not source.is_cuda or source.dtype != torch.float32 or source.dim() != 4:
         return None
     if source.requires_grad and torch.is_grad_enabled():
@@ -269,6 +292,11 @@ def maybe_lazy(source, group, views, code, compute):
     # A handle reads its source LATER.  That is only safe while an in-place change of the source in between can be noticed: tensors
     # made under torch.inference_mode() carry no version counter, and a stream that is being captured into a HIP graph replays into
     # the same (static) output buffers -- both are evaluated here and now, exactly like the reference.
-    if _source_version(source) is None or torch.cuda.is_current_stream_capturing():
+    # Round 5: without a version counter a handle is still safe when NOBODY else can reach the source -- a temporary of the call
+    # expression (`integrate_batch(d4_image_deaugment(model(x)), crops)` under torch.inference_mode(), the recommended context of an
+    # inference loop) that is the only owner of its storage: there is no one to change it before the handle is consumed.
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    if _source_version(source) is None and not (owned and _sole_owner(source)):
         return None
     return LazyDeaugment(source, group, views, code, compute)

@@ -10,6 +10,8 @@ the same kernels run with the inverse views.
 from functools import partial
 from typing import Callable, Dict, List, Mapping, Optional, Tuple, Union
 
+import sys
+
 import torch
 from torch import Tensor, nn
 
@@ -111,7 +113,7 @@ def _image_augment(image: Tensor, group: str) -> Tensor:
     return V.view_transform(image, AUGMENT_VIEWS[group], in_is_batch=True)
 
 
-def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable, lazy: bool = True) -> Tensor:
+def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable, lazy: bool = True, owned: bool = False) -> Tensor:
     views = DEAUGMENT_VIEWS[group]
     if image.size(0) % len(views) != 0:
         raise RuntimeError(f"Input batch size ({image.size(0)}) must be divisible by {len(views)}.")
@@ -119,7 +121,7 @@ def _image_deaugment(image: Tensor, group: str, reduction: MaybeStrOrCallable, l
     if code is not None:
         # inference-shaped calls come back as a handle that `TileMerger.integrate_batch` fuses into its own launch and that
         # turns into the real tensor on any other use (inference/_lazy.py); everything else is evaluated here and now
-        handle = _lazy.maybe_lazy(image, group, views, code, V.deaug_reduce) if lazy else None
+        handle = _lazy.maybe_lazy(image, group, views, code, V.deaug_reduce, owned=owned) if lazy else None
         return handle if handle is not None else V.deaug_reduce(image, views, code)
     if not (callable(reduction) or reduction in {None, "None", "none"}):
         raise KeyError(f"Unsupported reduction mode {reduction}")
@@ -232,26 +234,44 @@ def d4_image_augment(image: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------- image de-augment
+# A lazy result reads its argument LATER, so it is only handed out where a change of the argument in between would be noticed (a
+# version counter) -- or could not happen: the argument is a temporary nobody else references, `deaugment(model(x))` written as one
+# expression.  That is what `sys.getrefcount` says inside the public function itself: as many references as an argument created in
+# the call expression has (calibrated once, `_TEMP_REFS`; a tensor bound to a name, kept by the model or sitting in a list shows
+# more).  It matters under `torch.inference_mode()`, whose tensors carry no version counter (`_lazy.maybe_lazy` also asks the storage
+# for other owners).
+def _refs_of_argument(image, reduction="mean"):
+    return sys.getrefcount(image)
+
+
+_TEMP_REFS = _refs_of_argument(object())
+
+
 def fliplr_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
     """[2B,C,H,W] -> [B,C,H,W] (or the [2,B,C,H,W] stack when reduction is None)."""
-    return _image_deaugment(image, "fliplr", reduction)
+    owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)
+    return _image_deaugment(image, "fliplr", reduction, owned=owned)
 
 
 def flipud_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
-    return _image_deaugment(image, "flipud", reduction)
+    owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)
+    return _image_deaugment(image, "flipud", reduction, owned=owned)
 
 
 def flips_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
-    return _image_deaugment(image, "flips", reduction)
+    owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)
+    return _image_deaugment(image, "flips", reduction, owned=owned)
 
 
 def d2_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
-    return _image_deaugment(image, "d2", reduction)
+    owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)
+    return _image_deaugment(image, "d2", reduction, owned=owned)
 
 
 def d4_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
     """[8B,C,N,N] -> [B,C,N,N] (or the [8,B,C,N,N] stack when reduction is None)."""
-    return _image_deaugment(image, "d4", reduction)
+    owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)
+    return _image_deaugment(image, "d4", reduction, owned=owned)
 
 
 # ------------------------------------------------------------------------------------------------- labels

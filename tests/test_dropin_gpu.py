@@ -795,6 +795,55 @@ def test_handles_only_where_a_later_change_of_the_source_would_be_seen(dev, lazy
     assert torch.equal(got, want)
 
 
+def test_literal_loop_under_inference_mode(dev, lazy, autoplan):
+    """torch.inference_mode() -- the recommended context of an inference loop -- makes tensors without version counters, so an edit of
+    a handle's source could not be noticed.  A handle is still handed out when nobody exists who could make that edit: the argument
+    is a temporary of the call expression (``integrate_batch(d4_image_deaugment(model(x)), crops)``) and the only owner of its
+    storage.  A tensor bound to a name, kept by the model, or sharing its storage with another tensor is evaluated on the spot, as
+    before."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    TileMerger = autoplan.TileMerger
+    geom = TO.slicer_geometry((500, 420), 128, 64)
+    crops, C, batch = geom["crops"], 3, 8
+    w = TO.pyramid_window(128, 128)[0]
+    n = len(crops)
+    outputs = torch.randn((8 * n, C, 128, 128), device=dev, generator=torch.Generator(device=dev).manual_seed(77))
+    exact = _run_image(TileMerger(geom["target_shape"], C, w, device=dev, auto_plan=False), outputs, crops, batch, literal=False)
+
+    class Model:                     # returns a fresh tensor per call; `keep` makes it hold on to its last output
+        def __init__(self, keep=False):
+            self.keep, self.last = keep, None
+
+        def __call__(self, idx):
+            out = torch.cat([outputs[k * n + idx] for k in range(8)])
+            if self.keep:
+                self.last = out
+            return out
+
+    with torch.inference_mode():
+        for image in range(3):       # image 0 learns the geometry, 1 and 2 run deferred bands -- all through fused launches
+            model = Model()
+            m = TileMerger(geom["target_shape"], C, w, device=dev)
+            f0, e0 = lazy.fused, lazy.evaluations
+            for b0 in range(0, n, batch):
+                idx = torch.arange(b0, min(n, b0 + batch), device=dev)
+                m.integrate_batch(tta.d4_image_deaugment(model(idx)), crops[b0:b0 + batch])
+            assert lazy.fused - f0 == (n + batch - 1) // batch and lazy.evaluations == e0, "the nested literal call was not fused under inference_mode"
+            assert m.mode == ("incremental" if image == 0 else "deferred bands")
+            assert torch.equal(m.merge(), exact)
+        idx = torch.arange(0, batch, device=dev)
+        y = Model()(idx)             # bound to a name: its owner could still edit it -> evaluated at once
+        assert type(tta.d4_image_deaugment(y)) is torch.Tensor
+        keeper = Model(keep=True)    # the model keeps a reference to its output (a static buffer does): evaluated at once
+        assert type(tta.d4_image_deaugment(keeper(idx))) is torch.Tensor
+        big = torch.randn((16, C, 128, 128), device=dev)
+        assert type(tta.d4_image_deaugment(big[:8])) is torch.Tensor       # a temporary VIEW of memory somebody else owns: evaluated at once
+        handle = tta.d4_image_deaugment(Model()(idx))       # (not inside an `assert`: pytest's rewriting keeps the intermediate values alive)
+        assert type(handle) is lazy.LazyDeaugment
+        assert torch.equal(handle + 0, _eager(tta.d4_image_deaugment, y))
+
+
 def test_deferred_merger_next_to_a_real_model(dev):
     """The planned + deferred merger under the allocator churn of a real convolutional model (the 4-level conv-BN-ReLU UNet of
     bench.py, narrow): every batch is a fresh tensor the caching allocator carved out of memory the previous activations just
