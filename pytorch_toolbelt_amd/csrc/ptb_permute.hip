@@ -13,63 +13,92 @@
 // source is [planes or V*planes][H][W][run], the output [V*planes][Ho][Wo][run] with (Ho, Wo) = (W, H) for transposing views -- non-square
 // planes are fine, like x.rot90 on a non-square tensor.
 //
-// One workgroup moves one TS x TS tile of one output plane through LDS: the source region of the tile (TS source rows of TS
-// elements, or what the plane's edge leaves of them) is read row by row -- consecutive lanes read consecutive elements, whatever the
-// view -- into a padded tile, and written out row by row of the OUTPUT, each lane picking its element's source position in the
-// tile.  Both sides are coalesced for all eight views; the pad keeps the transposed read spread over the banks.  HBM-bound: every
-// element is read once and written once.
+// One workgroup moves one TS x TS tile of a SOURCE plane through LDS to its place in every view of the call (see view_permute_kernel):
+// an augmented batch is one read and V writes of the image, 16 bytes per lane on both global sides whenever the rows allow.
 #include "ptb_common.h"
 
 namespace ptb {
 
 typedef unsigned int E16 __attribute__((ext_vector_type(4)));     // an opaque 16-byte element (complex128, or 2 x 8 bytes of trailing dims)
 
-template <typename T> struct TileSize { static constexpr int value = 64; };
-template <> struct TileSize<E16> { static constexpr int value = 32; };
+// tile edge in elements: rows of at least 128 bytes, tiles of at most 32 KB
+template <typename T> struct TileSize { static constexpr int value = sizeof(T) <= 2 ? 128 : (sizeof(T) <= 8 ? 64 : 32); };
 
 struct PermArgs {
     const void* in;
     void* out;
     int V, codes;              // 3 bits per view
-    int in_is_batch;           // 1: every view reads plane p; 0: view k reads plane k * planes + p
+    int in_is_batch;           // 1: every view reads plane p (ONE read of the tile feeds all V views); 0: view k reads plane k * planes + p
     long long planes;          // B * C
     int H, W;                  // source plane
-    int tiles_y, tiles_x;      // of the OUTPUT plane
+    int tiles_y, tiles_x;      // of the SOURCE plane
+    int vec;                   // 1: both planes' rows are 16-byte multiples at 16-byte aligned bases (16-byte global accesses)
 };
 
+// One workgroup = one TS x TS tile of a SOURCE plane.  The tile is read once -- 16 bytes per lane along the source rows where the
+// rows allow -- into a padded LDS tile, then written to its place in every view of the call (augment: up to 8 views out of one read;
+// de-augment without a reduction: the view of that chunk): 16 bytes per lane along the OUTPUT rows, each lane collecting its
+// 16 / sizeof(T) elements from the tile at their source positions.  Both global sides are coalesced for all eight views; the
+// permutation happens on the LDS side, an element at a time.
 template <typename T>
 __global__ __launch_bounds__(256) void view_permute_kernel(const PermArgs a) {
     constexpr int TS = TileSize<T>::value;
+    constexpr int N = 16 / (int)sizeof(T);        // elements per 16-byte access
     __shared__ T tile[TS][TS + 1];
     const int tid = threadIdx.x;
     long long bid = blockIdx.x;
     const int tx = (int)(bid % a.tiles_x); bid /= a.tiles_x;
     const int ty = (int)(bid % a.tiles_y); bid /= a.tiles_y;
     const long long p = bid % a.planes;
-    const int k = (int)(bid / a.planes);
-    const int code = (a.codes >> (3 * k)) & 7;
-    const bool tr = code & 1, fr = code & 2, fc = code & 4;
-    const int Ho = tr ? a.W : a.H, Wo = tr ? a.H : a.W;
-    const int i0 = ty * TS, j0 = tx * TS;
-    const int th = min(TS, Ho - i0), tw = min(TS, Wo - j0);       // extent of the output tile
-    // the source rectangle of this tile: output rows (cols) map to source rows (cols), or -- transposed -- to source cols (rows)
-    const int ah = tr ? tw : th, aw = tr ? th : tw;                // extent in source orientation
-    const int a0 = tr ? j0 : i0, b0 = tr ? i0 : j0;                // un-flipped origin (a, b)
-    const int sr0 = fr ? a.H - a0 - ah : a0;                       // first source row / col of the rectangle (ascending addresses)
-    const int sc0 = fc ? a.W - b0 - aw : b0;
-    const T* __restrict__ src = static_cast<const T*>(a.in) + ((a.in_is_batch ? p : (long long)k * a.planes + p) * a.H + sr0) * (long long)a.W + sc0;
-    for (int e = tid; e < ah * TS; e += 256) {                     // row-major over the rectangle, TS lanes per source row
-        const int r = e / TS, c = e - r * TS;
-        if (c < aw) tile[r][c] = __builtin_nontemporal_load(src + (long long)r * a.W + c);
+    const int k0 = a.in_is_batch ? 0 : (int)(bid / a.planes);
+    const int r0 = ty * TS, c0 = tx * TS;                          // the tile's origin in the source plane
+    const int sh = min(TS, a.H - r0), sw = min(TS, a.W - c0);      // ... and extent
+    const T* __restrict__ src = static_cast<const T*>(a.in) + ((a.in_is_batch ? p : (long long)k0 * a.planes + p) * a.H + r0) * (long long)a.W + c0;
+    if (a.vec && sw == TS) {
+        constexpr int CPR = TS / N;                                // 16-byte chunks per tile row
+        for (int e = tid; e < sh * CPR; e += 256) {
+            const int r = e / CPR, c = (e - r * CPR) * N;
+            union { E16 v; T t[N]; } u;
+            u.v = __builtin_nontemporal_load(reinterpret_cast<const E16*>(src + (long long)r * a.W + c));
+#pragma unroll
+            for (int m = 0; m < N; ++m) tile[r][c + m] = u.t[m];
+        }
+    } else {
+        for (int e = tid; e < sh * TS; e += 256) {
+            const int r = e / TS, c = e - r * TS;
+            if (c < sw) tile[r][c] = src[(long long)r * a.W + c];
+        }
     }
     __syncthreads();
-    T* __restrict__ dst = static_cast<T*>(a.out) + (((long long)k * a.planes + p) * Ho + i0) * (long long)Wo + j0;
-    for (int e = tid; e < th * TS; e += 256) {
-        const int i = e / TS, j = e - i * TS;
-        if (j < tw) {
-            const int aa = tr ? j : i, bb = tr ? i : j;            // position in the un-flipped rectangle
-            const int r = fr ? ah - 1 - aa : aa, c = fc ? aw - 1 - bb : bb;
-            __builtin_nontemporal_store(tile[r][c], dst + (long long)i * Wo + j);
+    const int nk = a.in_is_batch ? a.V : 1;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int k = k0 + kk;
+        const int code = (a.codes >> (3 * k)) & 7;
+        const bool tr = code & 1, fr = code & 2, fc = code & 4;
+        const int Ho = tr ? a.W : a.H, Wo = tr ? a.H : a.W;
+        // where the tile lands: source (r, c) -> (a, b) = (fr ? H-1-r : r, fc ? W-1-c : c) -> output (i, j) = tr ? (b, a) : (a, b)
+        const int a0 = fr ? a.H - r0 - sh : r0, b0 = fc ? a.W - c0 - sw : c0;      // origin of the (flipped) rectangle
+        const int i0 = tr ? b0 : a0, j0 = tr ? a0 : b0;
+        const int oh = tr ? sw : sh, ow = tr ? sh : sw;                            // extent of the output tile
+        T* __restrict__ dst = static_cast<T*>(a.out) + (((long long)k * a.planes + p) * Ho + i0) * (long long)Wo + j0;
+        auto at = [&](int i, int j) -> T {                                          // output-tile (i, j) -> the element in the LDS tile
+            const int aa = tr ? j : i, bb = tr ? i : j;
+            return tile[fr ? sh - 1 - aa : aa][fc ? sw - 1 - bb : bb];
+        };
+        if (a.vec && ow == TS && (j0 % N) == 0) {
+            constexpr int CPR = TS / N;
+            for (int e = tid; e < oh * CPR; e += 256) {
+                const int i = e / CPR, j = (e - i * CPR) * N;
+                union { E16 v; T t[N]; } u;
+#pragma unroll
+                for (int m = 0; m < N; ++m) u.t[m] = at(i, j + m);
+                __builtin_nontemporal_store(u.v, reinterpret_cast<E16*>(dst + (long long)i * Wo + j));
+            }
+        } else {
+            for (int e = tid; e < oh * TS; e += 256) {
+                const int i = e / TS, j = e - i * TS;
+                if (j < ow) dst[(long long)i * Wo + j] = at(i, j);
+            }
         }
     }
 }
@@ -100,10 +129,13 @@ static int launch_permute(const PermArgs& a, long long run, hipStream_t s) {
     const int Ho = tr0 ? a.W : a.H, Wo = tr0 ? a.H : a.W;
     if (run == 1) {
         constexpr int TS = TileSize<T>::value;
+        constexpr int N = 16 / (int)sizeof(T);
         PermArgs b = a;
-        b.tiles_y = (Ho + TS - 1) / TS;
-        b.tiles_x = (Wo + TS - 1) / TS;
-        const long long blocks = (long long)a.V * a.planes * b.tiles_y * b.tiles_x;
+        b.tiles_y = (a.H + TS - 1) / TS;
+        b.tiles_x = (a.W + TS - 1) / TS;
+        // 16-byte accesses: rows of both planes are whole 16-byte chunks from 16-byte aligned bases (then every row starts aligned)
+        b.vec = !g_force_scalar && a.W % N == 0 && Wo % N == 0 && aligned16(a.in) && aligned16(a.out) ? 1 : 0;
+        const long long blocks = (long long)(a.in_is_batch ? 1 : a.V) * a.planes * b.tiles_y * b.tiles_x;
         if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
         hipLaunchKernelGGL(view_permute_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, b);
     } else {
