@@ -203,3 +203,34 @@ def _band_plan_checks(TO, item_rows):
     _, p = _c_band_plan(crops, 4, 512, 512, 5120, 5120, 1024, final=(128, 896), cuts=[128, 896])
     assert [(int(g[0]), int(g[1])) for g in p["groups"]][:4] == [(0, 128), (128, 896), (896, 1792), (1792, 2816)]   # groups restart at a cut
     assert p["bands"] == 22
+
+
+def test_custody_of_a_deferred_merger_is_what_the_byte_budget_assumes():
+    """``Bands.peak_tiles()`` (inference/_merge_modes.py) -- the most tiles a deferred merger holds at any launch, what self-planned
+    deferral sizes its launch groups by (PTB_DEFER_BYTES) -- against a simulation of the custody rules on the C plan: a batch stays
+    held until the last launch group that reads one of its tiles has gone out."""
+    from oracle import tiles_oracle as TO
+    from pytorch_toolbelt_amd.inference._merge_modes import Bands
+
+    for shape, tile, step, rows, want in (((5000, 5000), 512, 256, 1024, 95), ((5000, 5000), 512, 256, 512, 57), ((5000, 5000), 512, 256, 256, 38),
+                                          ((900, 420), 128, 64, 128, 18), ((900, 420), 128, 64, 1024, 84)):
+        geom = TO.slicer_geometry(shape, tile, step)
+        crops = geom["crops"]
+        H, W = geom["target_shape"]
+        _, p = _c_band_plan(crops, 2, tile, tile, H, W, rows)
+        groups = [tuple(int(v) for v in g) for g in p["groups"]]
+        lasts = [g[2] for g in groups]
+        b = Bands(None, None, groups, p["bands"], p["last_group"], all(x <= y for x, y in zip(lasts, lasts[1:])))
+        assert b.monotone and b.peak_tiles() == want, (shape, rows, b.peak_tiles())
+        # simulate: tiles arrive one by one; after tile t every group whose last tile is t launches; a tile leaves custody when the last
+        # group reading it has launched
+        held, peak, done = [], 0, 0
+        for t in range(len(crops)):
+            held.append(t)
+            peak = max(peak, len(held))
+            while done < len(groups) and groups[done][2] <= t:
+                done += 1
+            held = [h for h in held if p["last_group"][h] >= done]
+        assert peak == want and not held
+    # the headline geometry under the default budget: 95 tiles + one batch of 8, 33.5 MB each = 3.46 GB < 4 GiB
+    assert (95 + 8) * 8 * 4 * 512 * 512 * 4 < 4 << 30
