@@ -11,7 +11,7 @@ order, whether they take a batch:
     Incremental     the reference's semantics literally: accumulate now, divide in ``merge()``
 
 A strategy that cannot take a batch (a deviation from the planned crop sequence, a caller that reads ``norm_mask``, a geometry
-off the kernels' grid) says so and the next one does, bit-identically; ``SelfPlanning`` is the (opt-in) policy that gives a merger
+off the kernels' grid) says so and the next one does, bit-identically; ``SelfPlanning`` is the policy (on by default) that gives a merger
 constructed WITHOUT ``crops=`` a plan from the crop sequence of the previous image.  ``HeldBatches`` -- the custody contract of
 model outputs that are read by a later launch -- is shared with ``parallel.ShardedTileMerger``'s deferred bands.
 """
@@ -284,7 +284,8 @@ class DeferredBands:
     result -- the accumulator image never travels through HBM (the incremental path re-reads and re-writes every pixel once per
     overlapping tile row).  The fp32 operation order per pixel is the incremental path's, so the result is bit-identical.  Cost:
     the batches of the last ``rows / step + 1`` tile rows stay alive until their group is done, and they must not be modified in
-    place in the meantime -- which is why this is opt-in.
+    place in the meantime -- which is why, as an argument of the constructor, this is opt-in (``soft`` mergers -- the ones that planned
+    THEMSELVES into this mode -- come with the safeguards of ``SelfPlanning`` instead and never raise for what the caller did not ask for).
 
     Until the first group is launched any deviation from the plan simply replays the held batches through the incremental path;
     afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""

@@ -368,16 +368,18 @@ class TileMerger:
         horizontal band of the image in one launch as soon as all its tiles are in, without an accumulator in HBM; see
         ``_merge_modes.DeferredBands`` (the batches must stay unmodified until then).  ``defer_rows``: rows merged per launch (default 1024).
 
-        Without ``crops`` the merger can plan itself (``auto_plan``, opt-in: ``set_auto_plan(True)`` / ``PTB_AUTO_PLAN=1``): the crop
-        sequence an image ended with at ``merge()`` is remembered per geometry + window, and the next merger of that geometry
-        (or this one after ``reset()``) runs planned from it -- the reference's per-image ``TileMerger(shape, C, weight)``
-        gets the planned kernels from the second image on.  A deviating batch, a read of ``image`` / ``norm_mask`` or
-        ``merge_()`` drop back to the ordinary path, bit-exactly (a self-planned merger keeps its accumulators complete)."""
+        Without ``crops`` the merger plans itself (``auto_plan``; on by default, ``set_auto_plan(False)`` / ``PTB_AUTO_PLAN=0`` /
+        ``pytorch_toolbelt_amd.set_strict_dropin()`` switch it off): the crop sequence an image ended with at ``merge()`` is remembered
+        per geometry + window, and the next merger of that geometry (or this one after ``reset()``) runs from it -- as deferred bands
+        where the geometry, the byte budget (``PTB_DEFER_BYTES``) and what the first image showed of the model's outputs allow (see
+        ``_merge_modes.SelfPlanning``), else as planned blocks -- so the reference's per-image ``TileMerger(shape, C, weight)`` gets
+        the headline kernel from the second image on.  A deviating batch, a read of ``image`` / ``norm_mask`` or ``merge_()`` drop back
+        to the ordinary path without an exception (bit-exactly before any band was merged, within one float32 rounding after)."""
         device = _resolve_device(device, "TileMerger")
         # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
         # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
         # of that dtype are read as they are, and merge() / image / norm_mask hand out tensors of that dtype.  For float16 / bfloat16
-        # that is a strictly more accurate sum than the reference's.  (float64 never gets here: __new__ hands it to the torch-op merger.)
+        # that is a strictly more accurate sum than the reference's.  (float64: __new__ hands it to the torch-op merger; a subclass that gets here with it is refused below.)
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
         if dtype == torch.float64:
