@@ -28,7 +28,7 @@ from ._merge_modes import tensor_version as _tensor_version
 from ._merge_modes import _warned  # noqa: F401  (tests reset the once-only warnings)
 from ._merge_modes import warn_once as _warn_once
 
-__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "HostBackedTileMerger", "compute_pyramid_patch_weight_loss"]
+__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "HostBackedTileMerger", "compute_pyramid_patch_weight_loss", "set_auto_plan", "clear_auto_plans"]
 
 # OpenCV border codes accepted by split/cut_patch (the reference forwards them to cv2.copyMakeBorder,
 # inference/tiles.py:161,182,220).  Only constant padding is pinned by the oracle; the others map to the numpy
@@ -286,6 +286,16 @@ def set_auto_plan(flag: bool) -> bool:
     global _AUTO_PLAN
     prev, _AUTO_PLAN = _AUTO_PLAN, bool(flag)
     return prev
+
+
+def clear_auto_plans() -> int:
+    """Forget what self-planning mergers have learnt (per geometry: the crop sequence, a ``[1, H', W']`` normaliser and up to four band
+    plan tables in HBM, at most ``_merge_modes.AUTO_MAX`` = 8 geometries, least recently used first out).  Returns the number of
+    geometries dropped; mergers that are alive keep the plans they hold."""
+    with _auto_lock:
+        n = len(_auto)
+        _auto.clear()
+    return n
 
 
 def _weight_signature(weight: np.ndarray):
