@@ -330,6 +330,54 @@ def fuzz_literal(seeds):
     return bad
 
 
+def fuzz_views(seeds):
+    """ptb_view_permute / ptb_view_transform through inference/_views.view_transform against torch's own flip / transpose chains
+    (inference/_host.py on the same CUDA tensor): random dtype, rank 4-6, plane sizes around the kernel's tile edges, random view
+    lists (all transposing or none on non-square planes), augment and chunk-wise forms, sliced (offset) inputs.  torch.equal."""
+    from pytorch_toolbelt_amd.inference import _host
+    from pytorch_toolbelt_amd.inference import _views as V
+
+    dts = [torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool, torch.float16, torch.bfloat16, torch.float32, torch.float64,
+           torch.complex64, torch.complex128]
+    bad = 0
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        dt = dts[int(rng.integers(0, len(dts)))]
+        H = int(rng.choice([1, 3, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 257]))
+        square = rng.random() < 0.5
+        W = H if square else int(rng.choice([1, 4, 17, 64, 96, 128, 130, 255, 300]))
+        rest = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(0, 3))))
+        nv = int(rng.integers(1, 9))
+        if H == W:
+            views = [int(v) for v in rng.integers(0, 8, size=nv)]
+        else:
+            t = int(rng.integers(0, 2))
+            views = [int(v) * 2 + t for v in rng.integers(0, 4, size=nv)]
+        in_is_batch = bool(rng.integers(0, 2))
+        B, C = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        n = B if in_is_batch else B * nv
+        try:
+            g = torch.Generator().manual_seed(int(seed))
+            shape = (n + 1, C, H, W) + rest
+            if dt == torch.bool:
+                x = torch.rand(shape, generator=g) < 0.5
+            elif dt.is_complex:
+                x = torch.complex(torch.randn(shape, generator=g, dtype=torch.float64), torch.randn(shape, generator=g, dtype=torch.float64)).to(dt)
+            elif dt.is_floating_point:
+                x = torch.randn(shape, generator=g, dtype=torch.float64).to(dt)
+            else:
+                info = torch.iinfo(dt)
+                x = torch.randint(max(info.min, -2**40), min(info.max, 2**40), shape, generator=g, dtype=torch.int64).to(dt)
+            x = x.to(dev)[1:]                      # a storage offset: not every base is 16-byte aligned
+            got = V.view_transform(x, views, in_is_batch=in_is_batch)
+            want = _host.view_transform(x, views, in_is_batch)
+            assert got.dtype == want.dtype and got.shape == want.shape and torch.equal(got, want.contiguous()), "mismatch"
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            print("views FAIL seed", seed, dt, (n, C, H, W) + rest, views, in_is_batch, repr(e)[:300])
+    return bad
+
+
 def fuzz_self_deferred(seeds):
     """Self-planning mergers under callers that do NOT repeat themselves (round 5: mergers without crops= plan themselves into deferred
     bands by default).  Per seed a random geometry and a stream of images through new TileMerger(shape, C, weight) objects, every image
@@ -448,7 +496,7 @@ if __name__ == "__main__":
     seeds = range(first, first + count)
     only = set(sys.argv[3].split(",")) if len(sys.argv) > 3 else None
     fuzzers = {"modes": fuzz_merger_modes, "fused": fuzz_fused, "losses": fuzz_losses, "deferred": fuzz_deferred, "region": fuzz_region_losses,
-               "lovasz": fuzz_lovasz, "literal": fuzz_literal, "selfdeferred": fuzz_self_deferred}
+               "lovasz": fuzz_lovasz, "literal": fuzz_literal, "selfdeferred": fuzz_self_deferred, "views": fuzz_views}
     run = [f for k, f in fuzzers.items() if only is None or k in only]
     total = sum(f(seeds) for f in run)
     print(f"fuzz: {len(run) * count} cases, {total} failures")
