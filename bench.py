@@ -252,6 +252,34 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
                                                            "evaluates the loss) + backward",
                                   inputs_once_bytes=int(lov_in + probs.numel() * 4))
     del pg, probs
+    # ---- BASELINE.md section 3, second row: integrate + merge only (no TTA) at the headline geometry -- the reference's plain loop
+    # `merger.integrate_batch(model(tiles), crops)` ... `merger.merge()` (tiles.py:321-346), a new TileMerger(shape, C, weight) per
+    # image, library defaults (from the second image of the geometry the mergers plan themselves: deferred bands, identity view)
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    slicer = ImageSlicer(IMAGE, TILE, STEP, weight="pyramid")
+    crops = slicer.crops
+    preds = [torch.randn((min(BATCH, len(crops) - b0), CHANNELS, TILE, TILE), device=dev, generator=g) for b0 in range(0, len(crops), BATCH)]
+    pred_crops = [crops[b0:b0 + BATCH] for b0 in range(0, len(crops), BATCH)]
+    plain_bytes = len(crops) * CHANNELS * TILE * TILE * 4 + CHANNELS * slicer.target_shape[0] * slicer.target_shape[1] * 4      # 1 933 574 144
+
+    def plain_image(**kw):
+        m = TileMerger(slicer.target_shape, CHANNELS, slicer.weight, device=dev, **kw)
+        for t, c in zip(preds, pred_crops):
+            m.integrate_batch(t, c)
+        plain_image.mode = m.mode
+        return m.merge()
+
+    want_plain = plain_image(auto_plan=False)
+    t_inc = _gpu_ms(lambda: plain_image(auto_plan=False), 20)
+    plain_image()                                                      # the geometry's first image: learnt
+    t_self = _gpu_ms(plain_image, 20)
+    same = bool(torch.equal(plain_image(), want_plain))
+    out["no_tta_5000"] = entry(t_self, plain_bytes, what="integrate_batch(pred, crops) in batches of 8 tiles + merge() on a 5000x5000 image (361 tiles, C = 4, no TTA), "
+                                                         "new TileMerger(shape, C, weight) per image on the library's defaults (BASELINE.md section 3: 1 933 574 144 "
+                                                         "algorithmic bytes)", merger_mode=plain_image.mode, bit_identical_to_incremental=same,
+                               incremental_ms=round(t_inc, 4), incremental_frac=round(plain_bytes / (t_inc * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+    del preds, want_plain
     # ---- configs[4]
     n, c5 = 4096, 4
     offs = [-n // 4, 0, n // 4]

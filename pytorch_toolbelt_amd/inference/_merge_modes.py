@@ -148,7 +148,22 @@ class Plan:
         self.done = np.zeros_like(remaining0)
         self.pos = 0
         self.active = True
-        self.crops4 = None              # the planned (x, y, w, h) rows (what callers' crop arrays are compared with)
+        self._crops4 = None             # the planned (x, y, w, h) rows (what callers' crop arrays are compared with) ...
+        self.crops_bytes = b""          # ... and their bytes: `next(crops)` compares 32 B per tile instead of calling numpy
+
+    @property
+    def crops4(self):
+        return self._crops4
+
+    @crops4.setter
+    def crops4(self, value):
+        self._crops4 = value
+        self.crops_bytes = value.tobytes()
+
+    def next_are(self, crop_coords, B):
+        """Are these ``B`` crops (an int64 ``[B, 4]`` array) exactly the next planned ones?  (0.4 us: one ``tobytes`` and a bytes compare.)"""
+        pos = self.pos
+        return crop_coords.tobytes() == self.crops_bytes[32 * pos:32 * (pos + B)]
 
     @staticmethod
     def build(merger, crops, blocks=True):
@@ -217,19 +232,25 @@ class Bands:
         self.monotone = monotone        # groups complete in index order (row-major crops): batches can be released early
         self.ready = None               # event behind the table upload (a plan shared through the self-planning cache is used on other streams)
         self.rows = None                # rows per launch group it was built with
+        self._peak = None               # peak_tiles(), computed once
+        self.sorted_tiles = bool(np.all(np.diff(last_group) >= 0)) if len(last_group) > 1 else True      # (row-major crops: a later tile is never read by an earlier group)
 
     def peak_tiles(self):
         """The most tiles in custody at any launch: when group g goes out, every tile handed in so far that g or a later group reads
         is still held (row-major crops: a contiguous index range); a crop order whose groups do not complete in index order holds
         everything to the end."""
+        if self._peak is not None:
+            return self._peak
         n = len(self.last_group)
         if not self.monotone:
+            self._peak = n
             return n
         peak, first = 0, 0
         for g, (_y0, _y1, last) in enumerate(self.bands):
             while first < n and self.last_group[first] < g:
                 first += 1
             peak = max(peak, last + 1 - first)
+        self._peak = peak
         return peak
 
     def __del__(self):
@@ -276,7 +297,18 @@ def _fast_call(merger, batch, crop_coords):
             and batch.is_contiguous() and not batch.requires_grad and not merger._eager_norm and not merger._window_edited())
 
 
-class DeferredBands:
+class _OfMerger:
+    """A strategy object's way to its merger: a weak reference (one call per method; attribute access on the merger is then direct --
+    through a ``weakref.proxy`` every access paid the indirection, ~2 us per integrate call)."""
+
+    __slots__ = ()
+
+    @property
+    def m(self):
+        return self._m()
+
+
+class DeferredBands(_OfMerger):
     """Strategy "deferred bands" (``TileMerger(..., crops=tiler.crops, defer=True)``).
 
     The merger only keeps references to the model outputs it is handed, and when the last tile of a launch group has arrived ONE
@@ -291,7 +323,7 @@ class DeferredBands:
     afterwards ``merger.image``, a partial ``merge()`` or an unplanned tile raise."""
 
     def __init__(self, merger, bands, soft=False):
-        self.m = weakref.proxy(merger)   # (strategies never own their merger: no reference cycle, a dropped merger frees its HBM at once)
+        self._m = weakref.ref(merger)    # (strategies never own their merger: no reference cycle, a dropped merger frees its HBM at once)
         self.bands = bands               # Bands, or None: this merger does not defer (the strategy is never active)
         self.soft = soft                 # the merger planned ITSELF into this mode: nothing it was never asked for may raise (see soften)
         self.held = HeldBatches("TileMerger(defer=True)")
@@ -404,7 +436,8 @@ class DeferredBands:
         N.bump()
         if rc < 0:
             return rc
-        self.held.keep(batch, span, (coords, views, code), int(bands.last_group[pos:pos + B].max()))
+        lg = bands.last_group
+        self.held.keep(batch, span, (coords, views, code), int(lg[pos + B - 1]) if bands.sorted_tiles else int(lg[pos:pos + B].max()))
         plan.pos = pos + B
         if rc:
             done = self.done = self.done + rc
@@ -424,7 +457,7 @@ class DeferredBands:
             return False
         dcode = N.DTYPE_CODES.get(batch.dtype)
         B, pos = crop_coords.shape[0], plan.pos
-        if dcode is None or B == 0 or batch.device != m._image.device or not np.array_equal(crop_coords, plan.crops4[pos:pos + B]):
+        if dcode is None or B == 0 or batch.device != m._image.device or crop_coords.shape[1] != 4 or not plan.next_are(crop_coords, B):
             return False
         varr, n_views = m._view_array(key, views)
         if batch.shape != (B * n_views, m.channels, m.weight.shape[1], m.weight.shape[2]):
@@ -435,7 +468,7 @@ class DeferredBands:
                 return False       # (nothing was launched: the general path warns and replays)
             N.check(rc, "TileMerger.integrate_batch (deferred bands)")
         m.fast_submits += 1
-        m._log.append(np.ascontiguousarray(crop_coords[:, :2].T))
+        m._log.append(plan.xy[:, pos:pos + B])      # (the planned origins themselves: a view, no copy -- they were just compared equal)
         return True
 
     def take(self, batch, coords, xy, views, reduction, dcode):
@@ -468,14 +501,14 @@ class DeferredBands:
         return None
 
 
-class PlannedBlocks:
+class PlannedBlocks(_OfMerger):
     """Strategy "planned" (``TileMerger(..., crops=tiler.crops)`` and self-planned mergers): ``ptb_accumulate_planned2`` accumulates
     a batch and writes ``sum / norm`` of every block whose last planned tile this batch brings -- see ``Plan`` for what that
     restricts.  A self-planned merger asks the kernel to keep the weighted sums of finalised blocks as well
     (PTB_PLANNED_KEEP_SUMS), so its accumulators stay exact."""
 
     def __init__(self, merger):
-        self.m = weakref.proxy(merger)
+        self._m = weakref.ref(merger)
 
     def _launch(self, batch, dcode, n_views, varr, code, xs, ys, B):
         m = self.m
@@ -512,8 +545,8 @@ class PlannedBlocks:
             return False
         dcode = N.DTYPE_CODES.get(batch.dtype)
         B, pos = crop_coords.shape[0], plan.pos
-        if (dcode is None or B == 0 or batch.device != m._image.device or pos + B > plan.xy.shape[1]
-                or not np.array_equal(crop_coords, plan.crops4[pos:pos + B])):
+        if (dcode is None or B == 0 or batch.device != m._image.device or pos + B > plan.xy.shape[1] or crop_coords.shape[1] != 4
+                or not plan.next_are(crop_coords, B)):
             return False
         varr, n_views = m._view_array(key, views)
         if batch.shape != (B * n_views, m.channels, m.weight.shape[1], m.weight.shape[2]) or m._image.dtype != torch.float32:
@@ -593,12 +626,12 @@ class PlannedBlocks:
         return out
 
 
-class Incremental:
+class Incremental(_OfMerger):
     """Strategy "incremental": the reference's semantics literally (inference/tiles.py:321-346) -- one ``ptb_deaug_accumulate_t``
     launch per batch adds the weighted tiles to the accumulator in batch order, ``merge()`` divides."""
 
     def __init__(self, merger):
-        self.m = weakref.proxy(merger)
+        self._m = weakref.ref(merger)
 
     def take(self, batch, coords, xy, xs, ys, views, n_views, varr, reduction, dcode):
         m = self.m
@@ -700,13 +733,13 @@ def auto_entry(key, create=False):
         return ent
 
 
-class SelfPlanning:
+class SelfPlanning(_OfMerger):
     """The policy that gives a merger constructed without ``crops=`` a ``Plan`` -- and, where the geometry and the byte budget allow,
     the band plan of deferred merging (see the comment above).  ``key`` None: this merger never plans itself and every method is a
     no-op."""
 
     def __init__(self, merger, key):
-        self.m, self.key = weakref.proxy(merger), key
+        self._m, self.key = weakref.ref(merger), key
         self.planned = False      # merger._plan was made here (from the previous image's crops), not by the caller
         self.noted = None         # log length at the last merge() of this image
         self.bands = None         # the Bands this merger has checked out of its geometry's pool
