@@ -41,6 +41,10 @@ def block(path=DEFAULT):
         e = s.get(key)
         if isinstance(e, dict) and "ms" in e:
             rows.append((name, f"{e['ms']:.4f} ms", "", pct(e["frac"]) if "frac" in e else ""))
+    nt = s.get("no_tta_5000")
+    if isinstance(nt, dict) and "ms" in nt:
+        rows.append((f"no TTA: new `TileMerger(shape, C, weight)` per image + `integrate_batch(pred, crops)` + `merge()` (merger mode: {nt.get('merger_mode')}; "
+                     f"self-planning off: {nt.get('incremental_ms')} ms)", f"{nt['ms']:.3f} ms", "", pct(nt["frac"])))
     cb = d.get("cpu_baseline")
     if cb:
         rows.append((f"host CPU, the reference's op chain ({cb['cores']} threads)", "", f"{cb['value']:.1f} MP/s", ""))
