@@ -78,7 +78,9 @@ const char* ptb_last_hip_error(void);
  * scatter (0|1, default 1), 18 = one-launch finish of a rank's image in ptb_band_plan_finish_rank (0|1, default 1),
  * 19 = the gradient-binning scatter of the Lovasz training path also evaluates the loss (0|1, default 1; 0: separate lovasz_dot_kernel),
  * 20 = Dice / Jaccard statistics (logits + labels, no ignore) and the default BinaryFocalLoss on label maps run as the statistics-only /
- * focal-only instances of the packed streaming kernel of the fused loss (0|1, default 1; 0: the lean kernels).
+ * focal-only instances of the packed streaming kernel of the fused loss (0|1, default 1; 0: the lean kernels),
+ * 21 = the band plan kernel requests the next covering tile before it finishes the current one (0: never, 1: half / bf16 model outputs,
+ *      2: fp32 as well; default 2).
  * Every setting computes the same values (key 19: bit for bit for segments of up to 2^24 elements -- above that the separate dot kernel's
  * (float)(i + 1) positions round and the two settings may differ in the last bits, the default being the reference's telescoping
  * difference); the keys exist for same-box A/B runs and for tests that compare two code paths bit for bit. */

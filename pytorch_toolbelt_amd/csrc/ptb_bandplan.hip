@@ -40,7 +40,13 @@ struct GroupTiles {
     long long vs[PLAN_TILES];     // elements between consecutive views of this tile (its batch size * C * th * tw)
 };
 
-template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH>
+// PF (round 5): the loads of covering tile e + 1 are requested -- as they lie in memory: 16 registers for the eight d4 views of a half /
+// bf16 source, 32 for fp32 -- before tile e is transposed, reduced and blended.  Without it a workgroup has nothing in flight while it
+// works through its two barriers; with it the instances need 73-96 registers and one 1024-thread workgroup fits a CU instead of two,
+// and that still wins: 5000 x 5000, d4, C = 4 per image 1.49 -> 1.34 ms for half / bf16 model outputs (54 -> 60 % of 8 TB/s for their
+// 6.5 GB) and 2.14 -> 2.05 / 2.20 -> 2.16 ms for fp32 (two boxes); two tiles ahead loses (half 1.34 -> 1.70 ms, fp32 128 registers:
+// no gain) -- profiles/HISTORY.md section 9.5.  Instances whose view codes are read at run time keep the plain loop (they would spill).
+template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH, bool PF = false>
 __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
     __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
@@ -67,12 +73,34 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
     if (act && !partial) nfull = *reinterpret_cast<const float4*>(a.norm_full + pix);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nt = it->ntiles;
+    typename RawOf<LD>::type nxt[PF ? NV : 1];
+    if constexpr (PF) {
+        if (nt > 0) {
+            const unsigned long long cv = it->cover[0];
+            const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
+            gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H, a.W, lx,
+                                               ly, cw, ch, tid, nxt);
+        }
+    }
     for (int e = 0; e < nt; ++e) {
         const unsigned long long cv = it->cover[e];
         const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
-        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
-                                                                a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
-                                                                e + 1 < nt);
+        float4 val;
+        if constexpr (PF) {
+            float4 v[NV];
+            gather_widen<CH, NV, CODES, LD>(nxt, a.nviews, a.codes, cw, ch, tid, v);   // (the buffer is free again: tile e + 1 is requested into it)
+            if (e + 1 < nt) {
+                const unsigned long long cn = it->cover[e + 1];
+                const int sn = (int)(cn & 0xffff), nlx = (int)((cn >> 16) & 0xffff), nly = (int)((cn >> 32) & 0xffff);
+                gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H, a.W,
+                                                   nlx, nly, cw, ch, tid, nxt);
+            }
+            val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, e + 1 < nt);
+        } else {
+            val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
+                                                        a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
+                                                        e + 1 < nt);
+        }
         if (act) {
             const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338: tile * weight rounded, then added (no FMA contraction)
@@ -92,6 +120,14 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
 static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTiles& t, int blocks, int ch, hipStream_t s) {
     const dim3 grid(blocks), block(16 * ch);
     const bool nonlinear = a.op >= PTB_RED_GMEAN;
+#define PTB_PLAN_PF(NV, CODES, LD)                                                                                  \
+    do {                                                                                                            \
+        if (ch == 64) {                                                                                             \
+            if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, 64, true>), grid, block, 0, s, a, items, t); \
+            else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, 64, true>), grid, block, 0, s, a, items, t);       \
+        } else if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, PLAN_CH, true>), grid, block, 0, s, a, items, t);    \
+        else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, PLAN_CH, true>), grid, block, 0, s, a, items, t);              \
+    } while (0)
 #define PTB_PLAN_LD(NV, CODES, LD)                                                                                  \
     do {                                                                                                            \
         if (ch == 64) {                                                                                             \
@@ -101,6 +137,13 @@ static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTil
         else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD>), grid, block, 0, s, a, items, t);              \
     } while (0)
 #define PTB_PLAN(NV, CODES)                                                                                         \
+    do {                                                                                                            \
+        if (a.in_dtype == PTB_F16) { if (g_band_half_pf) PTB_PLAN_PF(NV, CODES, 2); else PTB_PLAN_LD(NV, CODES, 2); }      \
+        else if (a.in_dtype == PTB_BF16) { if (g_band_half_pf) PTB_PLAN_PF(NV, CODES, 3); else PTB_PLAN_LD(NV, CODES, 3); } \
+        else if (g_band_half_pf >= 2) PTB_PLAN_PF(NV, CODES, 1);                                                    \
+        else PTB_PLAN_LD(NV, CODES, 1);                                                                             \
+    } while (0)
+#define PTB_PLAN_RT(NV, CODES) /* view codes read at run time: no prefetching instance (it would spill) */          \
     do {                                                                                                            \
         if (a.in_dtype == PTB_F16) PTB_PLAN_LD(NV, CODES, 2);                                                       \
         else if (a.in_dtype == PTB_BF16) PTB_PLAN_LD(NV, CODES, 3);                                                 \
@@ -112,9 +155,11 @@ static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTil
     else if (a.nviews == 3 && a.codes == CODES_FLIPS) PTB_PLAN(3, CODES_FLIPS);
     else if (a.nviews == 4 && a.codes == CODES_D2) PTB_PLAN(4, CODES_D2);
     else if (a.nviews == 8 && a.codes == CODES_D4) PTB_PLAN(8, CODES_D4);
-    else PTB_PLAN(8, -1);
+    else PTB_PLAN_RT(8, -1);
 #undef PTB_PLAN
+#undef PTB_PLAN_RT
 #undef PTB_PLAN_LD
+#undef PTB_PLAN_PF
 }
 
 struct Group {
@@ -533,6 +578,8 @@ extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const
     return rc;
 }
 
+int ptb::g_band_half_pf = 2;       // ptb_set_tunable key 21: the band plan kernel requests covering tile e + 1 before it finishes tile e -- 0: never (round 4's
+                                   // instances), 1: for half / bf16 sources, 2: for fp32 sources as well
 int ptb::g_rank_finish_fused = 1;   // ptb_set_tunable key 18: 0 = ptb_rect_add + ptb_merge_div_ex launches (A/B, bit-identity test)
 
 // The end of a rank's image in one launch: over <= 2 row ranges of `merged` (full width, the rows that held partial sums),

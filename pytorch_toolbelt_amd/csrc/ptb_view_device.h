@@ -187,6 +187,34 @@ __device__ __forceinline__ float4 ld4(const float* base, long long off) {
     }
 }
 
+// Four source elements as they lie in memory -- 8 bytes (two registers) for half / bf16, the float4 itself for fp32: what a PREFETCHED
+// tile is kept as until its turn (gather_load_raw / gather_widen below); widen4 is ld4's conversion.
+typedef unsigned int raw2 __attribute__((ext_vector_type(2)));
+template <int LD> struct RawOf { typedef raw2 type; };
+template <> struct RawOf<0> { typedef v4f type; };
+template <> struct RawOf<1> { typedef v4f type; };
+template <int LD>
+__device__ __forceinline__ typename RawOf<LD>::type ld4_raw(const float* base, long long off) {
+    if constexpr (LD <= 1) {
+        const v4f* q = reinterpret_cast<const v4f*>(base + off);
+        return LD == 1 ? __builtin_nontemporal_load(q) : *q;
+    } else {
+        return __builtin_nontemporal_load(reinterpret_cast<const raw2*>(reinterpret_cast<const unsigned short*>(base) + off));
+    }
+}
+template <int LD>
+__device__ __forceinline__ float4 widen4(const typename RawOf<LD>::type r) {
+    if constexpr (LD <= 1) {
+        return make_float4(r.x, r.y, r.z, r.w);
+    } else if constexpr (LD == 2) {
+        const unsigned lo = r.x, hi = r.y;     // (element-wise: a bit cast of the 32-bit halves to _Float16 pairs converted the wrong lanes)
+        return make_float4((float)__builtin_bit_cast(_Float16, (unsigned short)(lo & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(lo >> 16)),
+                           (float)__builtin_bit_cast(_Float16, (unsigned short)(hi & 0xffffu)), (float)__builtin_bit_cast(_Float16, (unsigned short)(hi >> 16)));
+    } else {
+        return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+    }
+}
+
 __device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }
 
 // One source chunk (this thread's float4 `v` at chunk-local (r, 4q); chunk origin (x0, y0), extent cw x ch of tile b,
@@ -259,12 +287,11 @@ constexpr int CODES_D2 = pack_codes({0, 4, 2, 6});
 constexpr int CODES_D4 = pack_codes({0, 5, 6, 3, 1, 4, 7, 2});  // inverse views of d4_image_deaugment, tta.py:455-466
 
 
-// Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
-// tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
-template <int CH, int NV, int CODES, int OPK, int LD>
-__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt,
-                                                int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
-                                                float divisor, float* lds, int tid, bool more_entries) {
+// The second half of gather_reduce: this thread's NV loaded float4 (row-preserving views already in output orientation, transposing
+// views as read along the source rows) -> transposing views through the LDS tile -> reduction over the views.
+template <int CH, int NV, int CODES, int OPK>
+__device__ __forceinline__ float4 gather_tail(float4 (&v)[NV], int nv_rt, int codes_rt, int cw, int ch, int op, float divisor, float* lds, int tid,
+                                              bool more_entries) {
     constexpr int QPR = CH / 4;  // float4 per source row of a transposed block
     const int q = tid & 15, r = tid >> 4;
     const int rr = tid / QPR, qq = tid % QPR;
@@ -272,30 +299,6 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
     const bool tact = (rr < cw) && (4 * qq < ch);
     const int nv = CODES >= 0 ? NV : nv_rt;
     const int codes = CODES >= 0 ? CODES : codes_rt;
-
-    float4 v[NV];
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (k < nv) {
-            const int code = (codes >> (3 * k)) & 7;
-            const long long p = plane + (long long)k * view_stride;   // element offset of view k
-            if (!(code & 1)) {
-                if (act) {
-                    const int i = ly + r, j = lx + 4 * q;
-                    const int row = (code & 2) ? H - 1 - i : i;
-                    const int col = (code & 4) ? W - 4 - j : j;
-                    const float4 t = ld4<LD>(src, p + (long long)row * W + col);
-                    v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
-                }
-            } else if (tact) {
-                const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
-                const int C0 = (code & 4) ? W - ly - ch : ly;
-                v[k] = ld4<LD>(src, p + (long long)(R0 + rr) * W + C0 + 4 * qq);
-            }
-        }
-    }
-
     int tb = 0;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
@@ -342,6 +345,107 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
     }
     return make_float4(red_post<OPK>(s.x, op, divisor), red_post<OPK>(s.y, op, divisor), red_post<OPK>(s.z, op, divisor),
                        red_post<OPK>(s.w, op, divisor));
+}
+
+
+// Reduced value of one (tile, channel) for this thread's float4 at chunk-local (r, 4q); the chunk starts at
+// tile-local (ly, lx) and spans ch x cw.  `plane` = view 0 of this tile & channel.
+template <int CH, int NV, int CODES, int OPK, int LD>
+__device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt,
+                                                int codes_rt, int H, int W, int lx, int ly, int cw, int ch, int op,
+                                                float divisor, float* lds, int tid, bool more_entries) {
+    constexpr int QPR = CH / 4;  // float4 per source row of a transposed block
+    const int q = tid & 15, r = tid >> 4;
+    const int rr = tid / QPR, qq = tid % QPR;
+    const bool act = (r < ch) && (4 * q < cw);
+    const bool tact = (rr < cw) && (4 * qq < ch);
+    const int nv = CODES >= 0 ? NV : nv_rt;
+    const int codes = CODES >= 0 ? CODES : codes_rt;
+
+    float4 v[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (k < nv) {
+            const int code = (codes >> (3 * k)) & 7;
+            const long long p = plane + (long long)k * view_stride;   // element offset of view k
+            if (!(code & 1)) {
+                if (act) {
+                    const int i = ly + r, j = lx + 4 * q;
+                    const int row = (code & 2) ? H - 1 - i : i;
+                    const int col = (code & 4) ? W - 4 - j : j;
+                    const float4 t = ld4<LD>(src, p + (long long)row * W + col);
+                    v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
+                }
+            } else if (tact) {
+                const int R0 = (code & 2) ? H - lx - cw : lx;  // H == W for transposing views
+                const int C0 = (code & 4) ? W - ly - ch : ly;
+                v[k] = ld4<LD>(src, p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+            }
+        }
+    }
+
+    return gather_tail<CH, NV, CODES, OPK>(v, nv_rt, codes_rt, cw, ch, op, divisor, lds, tid, more_entries);
+}
+
+// gather_reduce in two steps: the loads of one covering tile as raw values (8 bytes per view for half / bf16 -- 16 registers for the
+// eight d4 views -- 16 bytes for fp32), held while the PREVIOUS tile is still being transposed, reduced and blended, and their
+// widening into gather_tail's input.  band_plan_kernel<.., PF> requests tile e + 1 before it finishes tile e.
+template <int CH, int NV, int CODES, int LD>
+__device__ __forceinline__ void gather_load_raw(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt, int codes_rt, int H,
+                                                int W, int lx, int ly, int cw, int ch, int tid, typename RawOf<LD>::type (&raw)[NV]) {
+    constexpr int QPR = CH / 4;
+    const int q = tid & 15, r = tid >> 4;
+    const int rr = tid / QPR, qq = tid % QPR;
+    const bool act = (r < ch) && (4 * q < cw);
+    const bool tact = (rr < cw) && (4 * qq < ch);
+    const int nv = CODES >= 0 ? NV : nv_rt;
+    const int codes = CODES >= 0 ? CODES : codes_rt;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        raw[k] = typename RawOf<LD>::type{};
+        if (k < nv) {
+            const int code = (codes >> (3 * k)) & 7;
+            const long long p = plane + (long long)k * view_stride;
+            if (!(code & 1)) {
+                if (act) {
+                    const int i = ly + r, j = lx + 4 * q;
+                    const int row = (code & 2) ? H - 1 - i : i;
+                    const int col = (code & 4) ? W - 4 - j : j;
+                    raw[k] = ld4_raw<LD>(src, p + (long long)row * W + col);
+                }
+            } else if (tact) {
+                const int R0 = (code & 2) ? H - lx - cw : lx;
+                const int C0 = (code & 4) ? W - ly - ch : ly;
+                raw[k] = ld4_raw<LD>(src, p + (long long)(R0 + rr) * W + C0 + 4 * qq);
+            }
+        }
+    }
+}
+template <int CH, int NV, int CODES, int LD>
+__device__ __forceinline__ void gather_widen(const typename RawOf<LD>::type (&raw)[NV], int nv_rt, int codes_rt, int cw, int ch, int tid, float4 (&v)[NV]) {
+    constexpr int QPR = CH / 4;
+    const int q = tid & 15, r = tid >> 4;
+    const int rr = tid / QPR, qq = tid % QPR;
+    const bool act = (r < ch) && (4 * q < cw);
+    const bool tact = (rr < cw) && (4 * qq < ch);
+    const int nv = CODES >= 0 ? NV : nv_rt;
+    const int codes = CODES >= 0 ? CODES : codes_rt;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        v[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (k < nv) {
+            const int code = (codes >> (3 * k)) & 7;
+            if (!(code & 1)) {
+                if (act) {
+                    const float4 t = widen4<LD>(raw[k]);
+                    v[k] = (code & 4) ? make_float4(t.w, t.z, t.y, t.x) : t;
+                }
+            } else if (tact) {
+                v[k] = widen4<LD>(raw[k]);
+            }
+        }
+    }
 }
 
 }  // namespace ptb

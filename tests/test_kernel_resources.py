@@ -61,9 +61,17 @@ def test_band_plan_kernel_has_no_scratch(reports):
     hits = _find(reports["bandplan"], "band_plan_kernel")
     for k, r in hits.items():
         assert r["ScratchSize"] == 0 and r.get("VGPRs Spill", 0) == 0, (k, r)
-    d4_mean = _find(hits, "ILi8ELi6166440ELi0ELi1E")          # the headline instance: 8 views, D4 codes, linear reduction, fp32 source
-    for k, r in d4_mean.items():
-        assert r["VGPRs"] <= 64 and r["Occupancy"] >= 8, (k, r)     # 512-thread workgroups: 8 waves per SIMD = 4 workgroups per CU
+    d4_mean = _find(hits, "ILi8ELi6166440ELi0ELi1E")          # 8 views, D4 codes, linear reduction, fp32 source
+    plain = {k: r for k, r in d4_mean.items() if "Lb0EEEv" in k}
+    prefetching = {k: r for k, r in d4_mean.items() if "Lb1EEEv" in k}       # the headline instances (ptb_set_tunable key 21, default 2)
+    assert len(plain) == 2 and len(prefetching) == 2, sorted(d4_mean)
+    for k, r in plain.items():
+        assert r["VGPRs"] <= 64 and r["Occupancy"] >= 8, (k, r)     # 8 waves per SIMD: two 1024-thread (four 512-thread) workgroups per CU
+    for k, r in prefetching.items():
+        assert r["VGPRs"] <= 96 and r["Occupancy"] >= 5, (k, r)     # one 1024-thread workgroup per CU (4 waves per SIMD) with the next tile in flight
+    for k, r in _find(hits, "ILi8ELi6166440ELi0ELi2E").items():    # fp16 source
+        if "Lb1EEEv" in k:
+            assert r["VGPRs"] <= 88, (k, r)
 
 
 def test_straight_line_loss_kernels_do_not_spill(reports):

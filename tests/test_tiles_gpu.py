@@ -921,3 +921,43 @@ def test_band_plan_item_rows_32_and_64_are_bit_identical(group, reduction, dtype
     for rows in (32, 64):
         assert mergers[rows]._bands is not None and mergers[rows]._bands_done == len(mergers[rows]._bands.bands)
         assert torch.equal(outs[rows], outs["plain"]), rows
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("group,reduction", [("d4", "mean"), ("d4", "gmean"), ("d2", "mean"), ("fliplr", "sum"), (None, None)])
+def test_band_plan_prefetch_is_bit_identical(group, reduction, dtype, dev):
+    """The band plan kernel requests covering tile e + 1 before it finishes tile e (ptb_set_tunable key 21: 0 never, 1 two-byte sources,
+    2 every source type -- the default): the same loads, the same sums in the same order, for 64- and 32-row items, on geometries with
+    ragged last rows / columns of items, and equal to the incremental merger."""
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+    from pytorch_toolbelt_amd.inference.tta import DEAUGMENT_VIEWS
+
+    lib = N.load()
+    for shape, tile, step, C in (((900, 700), 256, 128, 3), ((520, 392), 128, 96, 2)):
+        slicer = ImageSlicer(shape + (3,), tile, step, weight="pyramid")
+        crops, V = slicer.crops, len(DEAUGMENT_VIEWS[group]) if group else 1
+        g = torch.Generator().manual_seed(11)
+        ys = [(torch.rand((V * min(5, len(crops) - b0), C, tile, tile), generator=g) * 0.9 + 0.05).to(dev).to(dtype)
+              for b0 in range(0, len(crops), 5)]
+
+        def image(m):
+            for i, y in enumerate(ys):
+                cr = crops[5 * i:5 * i + 5]
+                if group:
+                    m.integrate_batch_deaugment(y, cr, group=group, reduction=reduction)
+                else:
+                    m.integrate_batch(y, cr)
+            return m.merge().clone()
+
+        want = image(TileMerger(slicer.target_shape, C, slicer.weight, device=dev, auto_plan=False))
+        try:
+            for rows in (64, 32):
+                assert lib.ptb_set_tunable(11, rows) == 0
+                m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+                for pf in (0, 1, 2):
+                    assert lib.ptb_set_tunable(21, pf) == 0
+                    m.reset()
+                    assert torch.equal(image(m), want), (shape, rows, pf)
+        finally:
+            assert lib.ptb_set_tunable(11, 64) == 0 and lib.ptb_set_tunable(21, 2) == 0
