@@ -13,7 +13,9 @@ rm -rf $OUT; mkdir -p $OUT
 BENCH="python /root/repo/bench.py --steps 3 --warmup 1 --repeats 1 --ramp-max-ms 600 --no-cpu-baseline --no-secondary"
 timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $BENCH > $OUT/trace.log 2>&1
 # PTB_PROFILE_LIGHT=1: HBM traffic only (FETCH_SIZE, WRITE_SIZE; a --pmc pass costs ~2 minutes of box time whatever it runs)
-if [ "${PTB_PROFILE_LIGHT:-0}" = "1" ]; then
+if [ "${PTB_PROFILE_LIGHT:-0}" = "2" ]; then      # kernel trace only (profiles/traffic.json keeps the last PMC passes and their date)
+  :
+elif [ "${PTB_PROFILE_LIGHT:-0}" = "1" ]; then
   for C in "FETCH_SIZE" "WRITE_SIZE"; do
     timeout 300 rocprofv3 --pmc $C --kernel-trace -d $OUT/$C -o run -- $BENCH --no-variants > $OUT/$C.log 2>&1
   done
