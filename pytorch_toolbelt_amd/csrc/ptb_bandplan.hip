@@ -46,12 +46,9 @@ struct GroupTiles {
 // and that still wins: 5000 x 5000, d4, C = 4 per image 1.49 -> 1.34 ms for half / bf16 model outputs (54 -> 60 % of 8 TB/s for their
 // 6.5 GB) and 2.14 -> 2.05 / 2.20 -> 2.16 ms for fp32 (two boxes); two tiles ahead loses (half 1.34 -> 1.70 ms, fp32 128 registers:
 // no gain) -- profiles/HISTORY.md section 9.5.  Instances whose view codes are read at run time keep the plain loop (they would spill).
-template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH, int PF = 0>
+template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH, bool PF = false>
 __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
-    constexpr int LDS_TILE_FLOATS = lds_tiles(NV, CODES) * CW * CH;
-    // PF == 2: two sets of transposed tiles, covering tiles alternate between them -- the barrier that kept tile e + 1's writes behind
-    // tile e's reads goes (128 KB for the d4 instance with 64-row items: gfx950 has 160 KB per CU and PF instances run one workgroup per CU)
-    __shared__ __attribute__((aligned(16))) float lds[LDS_TILE_FLOATS ? (PF == 2 ? 2 : 1) * LDS_TILE_FLOATS : 4];
+    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
     const int tid = threadIdx.x;
     unsigned bid = blockIdx.x;
     if (a.ncells == 1) {   // XCD-aware order (A/B, ptb_set_tunable key 10): every XCD walks a contiguous eighth of the (item, channel) list
@@ -98,8 +95,7 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
                 gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H, a.W,
                                                    nlx, nly, cw, ch, tid, nxt);
             }
-            if constexpr (PF == 2) val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds + (e & 1) * LDS_TILE_FLOATS, tid, false);
-            else val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, e + 1 < nt);
+            val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, e + 1 < nt);
         } else {
             val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
                                                         a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
@@ -124,18 +120,13 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
 static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTiles& t, int blocks, int ch, hipStream_t s) {
     const dim3 grid(blocks), block(16 * ch);
     const bool nonlinear = a.op >= PTB_RED_GMEAN;
-#define PTB_PLAN_PFN(NV, CODES, LD, PF)                                                                             \
-    do {                                                                                                            \
-        if (ch == 64) {                                                                                             \
-            if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, 64, PF>), grid, block, 0, s, a, items, t); \
-            else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, 64, PF>), grid, block, 0, s, a, items, t);       \
-        } else if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, PLAN_CH, PF>), grid, block, 0, s, a, items, t);    \
-        else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, PLAN_CH, PF>), grid, block, 0, s, a, items, t);              \
-    } while (0)
 #define PTB_PLAN_PF(NV, CODES, LD)                                                                                  \
     do {                                                                                                            \
-        if (g_band_half_pf >= 3) PTB_PLAN_PFN(NV, CODES, LD, 2);                                                    \
-        else PTB_PLAN_PFN(NV, CODES, LD, 1);                                                                        \
+        if (ch == 64) {                                                                                             \
+            if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, 64, true>), grid, block, 0, s, a, items, t); \
+            else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, 64, true>), grid, block, 0, s, a, items, t);       \
+        } else if (nonlinear) hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 1, LD, PLAN_CH, true>), grid, block, 0, s, a, items, t);    \
+        else hipLaunchKernelGGL((band_plan_kernel<NV, CODES, 0, LD, PLAN_CH, true>), grid, block, 0, s, a, items, t);              \
     } while (0)
 #define PTB_PLAN_LD(NV, CODES, LD)                                                                                  \
     do {                                                                                                            \
@@ -169,7 +160,6 @@ static void launch_plan(const ViewArgs& a, const BandItem* items, const GroupTil
 #undef PTB_PLAN_RT
 #undef PTB_PLAN_LD
 #undef PTB_PLAN_PF
-#undef PTB_PLAN_PFN
 }
 
 struct Group {

@@ -252,7 +252,7 @@ extern "C" int ptb_set_tunable(int key, int value) {
         return PTB_OK;
     }
     if (key == 21) {
-        g_band_half_pf = value < 0 ? 0 : (value > 3 ? 3 : value);
+        g_band_half_pf = value < 0 ? 0 : (value > 2 ? 2 : value);
         return PTB_OK;
     }
     if (key == 13) {

@@ -20,7 +20,8 @@ import itertools
 from pytorch_toolbelt_amd import _native as N  # noqa: E402
 
 ROWS = [int(v) for v in os.environ.get("PTB_HALF_ROWS", "64").split(",")]
-for rows, pf, dt in itertools.product(ROWS, (2, 0), (torch.float32, torch.float16, torch.bfloat16)):
+PFS = [int(v) for v in os.environ.get("PTB_HALF_PF", "2,0").split(",")]
+for rows, pf, dt in itertools.product(ROWS, PFS, (torch.float32, torch.float16, torch.bfloat16)):
     assert N.load().ptb_set_tunable(11, rows) == 0          # rows per work item of band plans created from now on
     assert N.load().ptb_set_tunable(21, pf) == 0            # prefetch the next covering tile of half / bf16 sources
     outs = [torch.randn((8 * min(8, n - b0), 4, 512, 512), device=dev).to(dt) for b0 in range(0, n, 8)]
