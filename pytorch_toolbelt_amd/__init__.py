@@ -11,8 +11,11 @@ def set_strict_dropin(flag: bool = True):
     ``*_image_deaugment`` return real tensors (no lazy handles: ``inference/_lazy.py``) and a ``TileMerger`` without ``crops=`` never
     plans itself from the previous image (``inference/tiles.py``).  Results are the same either way; what changes is that nothing
     is fused across the two calls of ``merger.integrate_batch(tta.d4_image_deaugment(y), crops)``, and no model output is read
-    after the ``integrate_batch`` call that was handed it.  ``flag=False`` switches both back on (the defaults).  Returns the previous
-    ``(lazy de-augmentation, self-planning)`` settings."""
+    after the ``integrate_batch`` call that was handed it.  Strict mode also keeps float16 / bfloat16 accumulators of a CUDA
+    ``TileMerger(dtype=...)`` in that dtype, like the reference (``tiles.set_reference_accumulators``: torch ops on the device instead of
+    the HIP merger's float32 sums -- the one place where the defaults are closer to the exact result than to the reference's bits).
+    ``flag=False`` switches everything back (the defaults).  Returns the previous ``(lazy de-augmentation, self-planning)`` settings."""
     from .inference import _lazy, tiles
 
+    tiles.set_reference_accumulators(flag)
     return _lazy.set_enabled(not flag), tiles.set_auto_plan(not flag)

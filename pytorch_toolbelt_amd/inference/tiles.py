@@ -28,7 +28,8 @@ from ._merge_modes import tensor_version as _tensor_version
 from ._merge_modes import _warned  # noqa: F401  (tests reset the once-only warnings)
 from ._merge_modes import warn_once as _warn_once
 
-__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "HostBackedTileMerger", "compute_pyramid_patch_weight_loss", "set_auto_plan", "clear_auto_plans"]
+__all__ = ["ImageSlicer", "TileMerger", "CudaTileMerger", "HostBackedTileMerger", "compute_pyramid_patch_weight_loss", "set_auto_plan", "clear_auto_plans",
+           "set_reference_accumulators"]
 
 # OpenCV border codes accepted by split/cut_patch (the reference forwards them to cv2.copyMakeBorder,
 # inference/tiles.py:161,182,220).  Only constant padding is pinned by the oracle; the others map to the numpy
@@ -288,6 +289,26 @@ def set_auto_plan(flag: bool) -> bool:
     return prev
 
 
+_REFERENCE_ACCUMULATORS = __import__("os").environ.get("PTB_REFERENCE_ACCUMULATORS", "0") == "1"
+
+
+def set_reference_accumulators(flag: bool) -> bool:
+    """``TileMerger(device="cuda", dtype=torch.float16 | torch.bfloat16)``: the reference accumulates in the caller's dtype
+    (inference/tiles.py:306-308, 334-339: every ``+=`` rounds to half precision); the HIP merger sums in float32 and rounds once when
+    ``merge()`` / ``image`` hand out the caller's dtype -- closer to the exact sum, not the reference's bits.  ``True`` (also set by
+    ``pytorch_toolbelt_amd.set_strict_dropin()``, ``PTB_REFERENCE_ACCUMULATORS=1``) builds such mergers as the torch-op merger on the
+    device, like ``dtype=torch.float64``: the reference's own op sequence, its bits, none of the fused kernels.  Default off; float32
+    mergers are not affected.  Returns the previous setting."""
+    global _REFERENCE_ACCUMULATORS
+    prev, _REFERENCE_ACCUMULATORS = _REFERENCE_ACCUMULATORS, bool(flag)
+    return prev
+
+
+def _torch_op_accumulators(dtype) -> bool:
+    """Accumulator dtypes of a CUDA merger that the torch-op merger keeps (``HostBackedTileMerger``) instead of the HIP kernels."""
+    return dtype == torch.float64 or (_REFERENCE_ACCUMULATORS and dtype in (torch.float16, torch.bfloat16))
+
+
 def clear_auto_plans() -> int:
     """Forget what self-planning mergers have learnt (per geometry: the crop sequence, a ``[1, H', W']`` normaliser and up to four band
     plan tables in HBM, at most ``_merge_modes.AUTO_MAX`` = 8 geometries, least recently used first out).  Returns the number of
@@ -363,7 +384,8 @@ class TileMerger:
             dtype = kwargs.get("dtype", args[0] if args else torch.float32)
             # float64 accumulators (reference tiles.py:306-308 accumulates in the caller's dtype): the HIP kernels sum in float32, so a
             # float64 merger -- on any device -- is the torch-op one, whose sums ARE float64 (said once for CUDA devices).
-            if torch.device(device).type != "cuda" or dtype == torch.float64:
+            # float16 / bfloat16 accumulators do the same when the reference's bits are asked for (set_reference_accumulators).
+            if torch.device(device).type != "cuda" or _torch_op_accumulators(dtype):
                 return object.__new__(HostBackedTileMerger)
         return object.__new__(cls)
 
@@ -389,7 +411,8 @@ class TileMerger:
         # The reference keeps image / norm_mask / weight in `dtype` (tiles.py:295-308) and so accumulates in it.  Here the accumulators
         # are always float32 (what the kernels read-modify-write); any other floating dtype is honoured at the boundary: tile batches
         # of that dtype are read as they are, and merge() / image / norm_mask hand out tensors of that dtype.  For float16 / bfloat16
-        # that is a strictly more accurate sum than the reference's.  (float64: __new__ hands it to the torch-op merger; a subclass that gets here with it is refused below.)
+        # that is a strictly more accurate sum than the reference's; set_reference_accumulators(True) / set_strict_dropin() build such
+        # mergers as the torch-op merger instead, for the reference's bits.  (float64: __new__ hands it to the torch-op merger; a subclass that gets here with it is refused below.)
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
         if dtype == torch.float64:
@@ -800,10 +823,15 @@ class HostBackedTileMerger(TileMerger):
 
         device = torch.device(device)
         if device.type == "cuda":
-            if dtype != torch.float64:
-                raise RuntimeError("the torch-op merger serves CUDA devices for float64 accumulators only; TileMerger(device='cuda') is the HIP merger")
-            _warn_once(("fp64-cuda",), "TileMerger(device='cuda', dtype=torch.float64): the HIP kernels accumulate in float32; float64 accumulators "
-                                       "are kept with torch ops on the device (exact float64 sums like the reference's, not the fused kernels).")
+            if not _torch_op_accumulators(dtype):
+                raise RuntimeError("the torch-op merger serves CUDA devices for float64 accumulators (and, under set_reference_accumulators(True), "
+                                   "float16 / bfloat16 ones) only; TileMerger(device='cuda') is the HIP merger")
+            if dtype == torch.float64:
+                _warn_once(("fp64-cuda",), "TileMerger(device='cuda', dtype=torch.float64): the HIP kernels accumulate in float32; float64 accumulators "
+                                           "are kept with torch ops on the device (exact float64 sums like the reference's, not the fused kernels).")
+            else:
+                _warn_once(("ref-acc-cuda", str(dtype)), f"TileMerger(device='cuda', dtype={dtype}) under set_reference_accumulators(True): accumulated in "
+                                                         f"{dtype} with torch ops on the device (the reference's bits, not the fused kernels).")
         self.dtype = dtype
         self._host = HostTileMerger(image_shape, channels, weight, device, dtype)
         self.image_height, self.image_width, self.channels = self._host.image_height, self._host.image_width, channels
@@ -877,7 +905,7 @@ class CudaTileMerger(TileMerger):
         # float64 accumulators get the torch-op merger on the device, exactly like TileMerger(..., device="cuda", dtype=torch.float64) does
         # (device="cpu" stays an error: this is the name of the GPU merger)
         dtype = kwargs.get("dtype", args[0] if args else torch.float32)
-        if cls is CudaTileMerger and torch.device(device).type == "cuda" and dtype == torch.float64:
+        if cls is CudaTileMerger and torch.device(device).type == "cuda" and _torch_op_accumulators(dtype):
             return HostBackedTileMerger(image_shape, channels, weight, device, *args, **kwargs)      # (not a CudaTileMerger: __init__ is not run again)
         return object.__new__(cls)
 

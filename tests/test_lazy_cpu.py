@@ -180,7 +180,7 @@ def test_autograd_on_an_evaluated_handle_and_the_legacy_dlpack_guard():
 def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes():
     """The to_dlpack guard is installed by the FIRST handle, not by `import pytorch_toolbelt_amd.inference`; switching the handles off
     (tta.set_lazy_deaugment(False) / pytorch_toolbelt_amd.set_strict_dropin()) takes it out again; strict drop-in mode also stops
-    mergers from planning themselves."""
+    mergers from planning themselves and routes half-precision accumulators of CUDA mergers to the torch-op merger."""
     import subprocess
     import sys
 
@@ -193,7 +193,10 @@ def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes()
             "prev = pytorch_toolbelt_amd.set_strict_dropin(True)\n"
             "assert prev == (True, True) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
             "T.set_auto_plan(True); assert pytorch_toolbelt_amd.set_strict_dropin(True) == (False, True) and not T._AUTO_PLAN\n"
+            "assert T._REFERENCE_ACCUMULATORS and type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda', dtype=torch.float16)) is T.HostBackedTileMerger\n"
+            "assert type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda')) is T.TileMerger\n"
             "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False) and L.enabled() and T._AUTO_PLAN\n"
+            "assert not T._REFERENCE_ACCUMULATORS and type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda', dtype=torch.float16)) is T.TileMerger\n"
             "print('OK')\n")
     import os
 

@@ -846,6 +846,62 @@ def test_deferred_launch_grouping_is_bit_identical(rows, dev):
         assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_reference_accumulators_keep_the_reference_bits(dtype, dev):
+    """`tiles.set_reference_accumulators(True)` (part of `set_strict_dropin()`): a CUDA merger with float16 / bfloat16 accumulators sums in
+    that dtype with the reference's own op sequence (tiles.py:306-308, 334-346) -- its bits, rounding after every `+=` -- instead of the HIP
+    merger's float32 sums, under both class names; float32 mergers and the default setting are untouched."""
+    import pytorch_toolbelt_amd
+    from pytorch_toolbelt_amd.inference import tiles as T
+    from pytorch_toolbelt_amd.inference import tta
+
+    slicer = T.ImageSlicer((200, 180, 3), 64, 32, weight="pyramid")
+    crops, C = slicer.crops, 2
+    g = torch.Generator().manual_seed(4)
+    pred = torch.rand((len(crops), C, 64, 64), generator=g).to(dev).to(dtype)
+    views = torch.rand((8 * 3, C, 64, 64), generator=g).to(dev).to(dtype)
+    # the reference's arithmetic, spelt out with torch ops on the device
+    w = torch.from_numpy(np.expand_dims(slicer.weight, 0)).to(dev).to(dtype)
+    image = torch.zeros((C, *slicer.target_shape), device=dev, dtype=dtype)
+    norm = torch.zeros((1, *slicer.target_shape), device=dev, dtype=dtype)
+    for tile, (x, y, tw, th) in zip(pred, crops):
+        image[:, y:y + th, x:x + tw] += tile * w
+        norm[:, y:y + th, x:x + tw] += w
+    want = image / norm
+    assert not T.set_reference_accumulators(False)
+    plain = T.TileMerger(slicer.target_shape, C, slicer.weight, device=dev, dtype=dtype)
+    assert not isinstance(plain, T.HostBackedTileMerger)
+    plain.integrate_batch(pred, crops)
+    prev = pytorch_toolbelt_amd.set_strict_dropin(True)
+    try:
+        for cls in (T.TileMerger, T.CudaTileMerger):
+            m = cls(slicer.target_shape, C, slicer.weight, device=dev, dtype=dtype)
+            assert isinstance(m, T.HostBackedTileMerger) and m.mode == "host" and m.image.dtype == dtype and m.image.is_cuda
+            for b0 in range(0, len(crops), 5):
+                m.integrate_batch(pred[b0:b0 + 5], crops[b0:b0 + 5])
+            got = m.merge()
+            assert got.dtype == dtype and torch.equal(got, want) and torch.equal(m.norm_mask, norm)
+            m.reset()
+            m.integrate_batch_deaugment(views, crops[:3], group="d4", reduction="mean")      # == integrate_batch(d4_image_deaugment(...))
+            r = cls(slicer.target_shape, C, slicer.weight, device=dev, dtype=dtype)
+            r.integrate_batch(tta.d4_image_deaugment(views), crops[:3])
+            assert torch.equal(m.image, r.image)
+        assert not isinstance(T.TileMerger(slicer.target_shape, C, slicer.weight, device=dev), T.HostBackedTileMerger)      # float32: the HIP merger
+    finally:
+        pytorch_toolbelt_amd.set_strict_dropin(False)
+        tta.set_lazy_deaugment(prev[0]); T.set_auto_plan(prev[1])
+    assert not T._REFERENCE_ACCUMULATORS
+    # the default (float32 sums, rounded once) is at least as close to the exact blend as the reference's half-precision sums
+    exact = (image.double() * 0)
+    n64 = torch.zeros_like(norm, dtype=torch.float64)
+    w64 = torch.from_numpy(np.expand_dims(slicer.weight, 0)).to(dev)
+    for tile, (x, y, tw, th) in zip(pred, crops):
+        exact[:, y:y + th, x:x + tw] += tile.double() * w64
+        n64[:, y:y + th, x:x + tw] += w64
+    exact = exact / n64
+    assert float((plain.merge().double() - exact).abs().max()) <= float((want.double() - exact).abs().max()) + 1e-12
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float64])
 def test_tile_merger_dtype_argument(dtype, dev):
     """TileMerger(..., dtype=...) (reference tiles.py:295: accumulators of any floating dtype): tile batches of that dtype are
