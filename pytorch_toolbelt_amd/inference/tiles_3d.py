@@ -133,7 +133,9 @@ class VolumeMerger:
         # torch-op merger, "cuda" the HIP one
         if cls is VolumeMerger:
             dtype = kwargs.get("dtype", args[0] if args else torch.float32)
-            if torch.device(device).type != "cuda" or dtype == torch.float64:
+            from .tiles import _torch_op_accumulators      # (float64 always; float16 / bfloat16 under tiles.set_reference_accumulators(True))
+
+            if torch.device(device).type != "cuda" or _torch_op_accumulators(dtype):
                 return object.__new__(HostBackedVolumeMerger)
         return object.__new__(cls)
 

@@ -887,6 +887,10 @@ def test_reference_accumulators_keep_the_reference_bits(dtype, dev):
             r.integrate_batch(tta.d4_image_deaugment(views), crops[:3])
             assert torch.equal(m.image, r.image)
         assert not isinstance(T.TileMerger(slicer.target_shape, C, slicer.weight, device=dev), T.HostBackedTileMerger)      # float32: the HIP merger
+        from pytorch_toolbelt_amd.inference.tiles_3d import HostBackedVolumeMerger, VolumeMerger
+
+        vm = VolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=dtype)
+        assert isinstance(vm, HostBackedVolumeMerger) and vm.volume.dtype == dtype and vm.volume.is_cuda
     finally:
         pytorch_toolbelt_amd.set_strict_dropin(False)
         tta.set_lazy_deaugment(prev[0]); T.set_auto_plan(prev[1])
