@@ -782,6 +782,39 @@ def gen_tta5():
     save("tta5.npz", A, cases)
 
 
+# ----------------------------------------------------------------------------------------------- TileMerger(dtype=...)
+def gen_tiles2():
+    """TileMerger with accumulators of the caller's dtype (inference/tiles.py:295-308: image / norm_mask / weight in `dtype`;
+    :330-339: integrate_batch casts the batch with type_as and every `+=` rounds to that dtype; :310-319: accumulate_single moves the
+    tile but does not cast it): image, norm_mask and merge() of the unmodified reference for float16 / bfloat16 / float64 accumulators fed
+    float32 and same-dtype tile batches.  Stored as raw bytes (bfloat16 does not survive an npz otherwise)."""
+    A, cases = {}, []
+
+    def raw(t):
+        return t.detach().contiguous().cpu().view(torch.uint8).numpy()
+
+    g = torch.Generator().manual_seed(77)
+    geoms = [dict(image_shape=[96, 80, 3], tile_size=32, tile_step=16), dict(image_shape=[70, 61, 3], tile_size=[24, 20], tile_step=[9, 11])]
+    for gi, kw in enumerate(geoms):
+        s = rt.ImageSlicer(kw["image_shape"], kw["tile_size"], kw["tile_step"], weight="pyramid")
+        C, n = 2 + gi, len(s.crops)
+        th, tw = s.tile_size
+        pred = torch.randn((n, C, th, tw), generator=g)
+        A[f"m{gi}_pred"] = t2n(pred)
+        for name in ("float16", "bfloat16", "float64"):
+            dt = getattr(torch, name)
+            for feed in ("float32", "same"):
+                m = rt.TileMerger(s.target_shape, C, s.weight, dtype=dt)
+                x = pred if feed == "float32" else pred.to(dt)
+                for b0 in range(0, n - 1, 5):
+                    m.integrate_batch(x[b0:min(n - 1, b0 + 5)], s.crops[b0:min(n - 1, b0 + 5)])
+                m.accumulate_single(pred[n - 1].to(dt), s.crops[n - 1])          # (no cast inside: the caller supplies the dtype)
+                key = f"m{gi}_{name}_{feed}"
+                A[key + "_image"], A[key + "_norm"], A[key + "_merged"] = raw(m.image), raw(m.norm_mask), raw(m.merge())
+                cases.append(dict(name=key, fn="tile_merger_dtype", kwargs=dict(kw, channels=C, dtype=name, feed=feed, batch=5)))
+    save("tiles2.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -1025,6 +1058,7 @@ if __name__ == "__main__":
         globals()[sys.argv[1]]()
         sys.exit(0)
     gen_tiles()
+    gen_tiles2()
     gen_tta()
     gen_losses()
     gen_edges()
