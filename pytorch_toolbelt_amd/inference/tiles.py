@@ -415,10 +415,11 @@ class TileMerger:
         # mergers as the torch-op merger instead, for the reference's bits.  (float64: __new__ hands it to the torch-op merger; a subclass that gets here with it is refused below.)
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"TileMerger: dtype must be a floating point type, got {dtype}")
-        if dtype == torch.float64:
-            # (TileMerger / CudaTileMerger route float64 to the torch-op merger in __new__; any other subclass of the HIP merger would
-            # silently sum in float32 and cast -- ADVICE round 4)
-            raise TypeError(f"{type(self).__name__}: float64 accumulators are kept by the torch-op merger (TileMerger(..., dtype=torch.float64) / "
+        if _torch_op_accumulators(dtype):
+            # (TileMerger / CudaTileMerger route these dtypes to the torch-op merger in __new__; any other subclass of the HIP merger would
+            # silently sum in float32 and cast -- ADVICE round 4; float16 / bfloat16 only once set_reference_accumulators(True) asked for
+            # the reference's bits)
+            raise TypeError(f"{type(self).__name__}: {str(dtype).replace('torch.', '')} accumulators are kept by the torch-op merger (TileMerger(..., dtype={dtype}) / "
                             "HostBackedTileMerger); the HIP kernels of this class accumulate in float32")
         self.dtype = dtype
         dtype = torch.float32

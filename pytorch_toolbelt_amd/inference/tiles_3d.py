@@ -145,8 +145,10 @@ class VolumeMerger:
         device = _resolve_device(device, "VolumeMerger")
         if dtype not in (torch.float32, torch.float16, torch.bfloat16, torch.float64):
             raise TypeError(f"VolumeMerger: dtype must be a floating point type, got {dtype}")
-        if dtype == torch.float64:  # (VolumeMerger(...) itself routes float64 to the torch-op merger in __new__; a subclass would sum in float32)
-            raise TypeError(f"{type(self).__name__}: float64 accumulators are kept by the torch-op merger (VolumeMerger(..., dtype=torch.float64) / "
+        from .tiles import _torch_op_accumulators
+
+        if _torch_op_accumulators(dtype):  # (VolumeMerger(...) itself routes these to the torch-op merger in __new__; a subclass would sum in float32)
+            raise TypeError(f"{type(self).__name__}: {str(dtype).replace('torch.', '')} accumulators are kept by the torch-op merger (VolumeMerger(..., dtype={dtype}) / "
                             "HostBackedVolumeMerger); the HIP kernels of this class accumulate in float32")
         self.dtype = dtype          # honoured by merge(); the accumulators themselves are float32 (see TileMerger)
         dtype = torch.float32

@@ -891,6 +891,12 @@ def test_reference_accumulators_keep_the_reference_bits(dtype, dev):
 
         vm = VolumeMerger((8, 8, 8), 1, np.ones((4, 4, 4), dtype=np.float32), device=dev, dtype=dtype)
         assert isinstance(vm, HostBackedVolumeMerger) and vm.volume.dtype == dtype and vm.volume.is_cuda
+
+        class MyMerger(T.TileMerger):          # any other subclass of the HIP merger would sum in float32: refused, like float64
+            pass
+
+        with pytest.raises(TypeError, match="accumulators are kept by the torch-op merger"):
+            MyMerger(slicer.target_shape, C, slicer.weight, device=dev, dtype=dtype)
     finally:
         pytorch_toolbelt_amd.set_strict_dropin(False)
         tta.set_lazy_deaugment(prev[0]); T.set_auto_plan(prev[1])
