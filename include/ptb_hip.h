@@ -58,6 +58,12 @@ typedef void* ptb_stream_t; /* hipStream_t */
 #define PTB_F32 0
 #define PTB_F16 1
 #define PTB_BF16 2
+/* or-ed into the `in_dtype` of ptb_deaug_accumulate_t / ptb_accumulate_planned(2) / ptb_merge_band / ptb_band_plan_submit(_rank): the
+ * reduced value is rounded to the (fp16 / bf16) source type -- round to nearest even, NaN -> quiet NaN, like torch's `.to(dtype)` --
+ * before it is multiplied by the window.  That is what the reference's two calls compute on half-precision model outputs
+ * (torch.autocast): `tta.*_image_deaugment(y)` returns a HALF tensor (inference/tta.py:442-467), `integrate_batch` widens it
+ * (inference/tiles.py:334-335).  No effect on PTB_F32 sources. */
+#define PTB_ROUND_SRC 0x100
 
 int ptb_version(void);
 /* hipGetErrorString of the last failing HIP call made by this library on this thread ("" if none). */

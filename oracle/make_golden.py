@@ -815,6 +815,43 @@ def gen_tiles2():
     save("tiles2.npz", A, cases)
 
 
+def gen_tiles3():
+    """The literal loop on HALF-PRECISION model outputs (torch.autocast): `merger.integrate_batch(tta.<group>_image_deaugment(y), crops)` of
+    the unmodified reference with float16 / bfloat16 `y` (inference/tta.py:287-316, 344-365, 442-467 feeding inference/tiles.py:321-339):
+    the de-augmentation returns a HALF tensor (the reduced value rounded to the source dtype), integrate_batch widens it to the float32
+    accumulator.  Stored: the model outputs and the de-augmented tiles as raw bytes, image / merge() of a float32 TileMerger."""
+    A, cases = {}, []
+
+    def raw(t):
+        return t.detach().contiguous().cpu().view(torch.uint8).numpy()
+
+    g = torch.Generator().manual_seed(2026)
+    s = rt.ImageSlicer([64, 48, 3], 32, 16, weight="pyramid")
+    C, n, B = 2, len(s.crops), 4
+    th, tw = s.tile_size
+    fns = {"d4": (rtta.d4_image_deaugment, 8), "d2": (rtta.d2_image_deaugment, 4), "flips": (rtta.flips_image_deaugment, 3),
+           "fliplr": (rtta.fliplr_image_deaugment, 2), "flipud": (rtta.flipud_image_deaugment, 2)}
+    for name in ("float16", "bfloat16"):
+        dt = getattr(torch, name)
+        for group, reduction in (("d4", "mean"), ("d4", "sum"), ("d4", "gmean"), ("d2", "mean"), ("flips", "mean"), ("fliplr", "hmean"), ("flipud", "mean")):
+            fn, V = fns[group]
+            positive = reduction in ("gmean", "hmean")
+            m = rt.TileMerger(s.target_shape, C, s.weight)
+            key = f"{name}_{group}_{reduction}"
+            for bi, b0 in enumerate(range(0, n, B)):
+                nb = min(B, n - b0)
+                y = torch.rand((V * nb, C, th, tw), generator=g).clamp(1e-3, 1.0) if positive else torch.randn((V * nb, C, th, tw), generator=g)
+                y = y.to(dt)
+                tiles = fn(y, reduction=reduction)
+                assert tiles.dtype == dt
+                m.integrate_batch(tiles, s.crops[b0:b0 + nb])
+                A[f"{key}_y{bi}"], A[f"{key}_t{bi}"] = raw(y), raw(tiles)
+            A[key + "_image"], A[key + "_merged"] = t2n(m.image), t2n(m.merge())
+            cases.append(dict(name=key, fn="literal_loop_half", kwargs=dict(image_shape=[64, 48, 3], tile_size=32, tile_step=16, channels=C, dtype=name,
+                                                                            group=group, reduction=reduction, batch=B, views=V)))
+    save("tiles3.npz", A, cases)
+
+
 # ----------------------------------------------------------------------------------------------- focal, activation="softmax"
 def gen_losses4():
     """focal_loss_with_logits / BinaryFocalLoss with activation="softmax" (functional.py:61-66): values and autograd gradients of
@@ -1059,6 +1096,7 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_tiles()
     gen_tiles2()
+    gen_tiles3()
     gen_tta()
     gen_losses()
     gen_edges()

@@ -21,6 +21,7 @@ IDENT, TRANSPOSE, FLIPUD, ROT90_CW, FLIPLR, ROT90_CCW, ROT180, ANTITRANSPOSE = r
 RED_SUM, RED_MEAN, RED_GMEAN, RED_HMEAN, RED_HARMONIC1P, RED_LOGODD, RED_LOG1P = range(7)
 F32, F16, BF16 = range(3)   # PTB_F32 / PTB_F16 / PTB_BF16: element type of the model outputs a `_t` entry point reads
 DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
+ROUND_SRC = 0x100           # PTB_ROUND_SRC, or-ed into a dtype code: round the reduced value to the (half) source type before blending
 
 EFRESH = -5
 PTB_EUNSUPPORTED = -2

@@ -101,6 +101,7 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
                                                         a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
                                                         e + 1 < nt);
         }
+        val = round_src4<LD>(val, a.round_src);
         if (act) {
             const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338: tile * weight rounded, then added (no FMA contraction)
@@ -444,6 +445,8 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
                                     const float* weight, ptb_stream_t stream) {
     if (!p || !batch || !merged || !norm_full || !weight || B < 1) return PTB_EINVAL;
     if (!p->dev_items) return PTB_EINVAL;
+    const int dtype_arg = in_dtype;      // (with PTB_ROUND_SRC: part of the image's configuration)
+    in_dtype &= ~PTB_ROUND_SRC;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
     if (V < 1 || V > MAX_VIEWS || !views) return PTB_EINVAL;
     int nT = 0;
@@ -456,7 +459,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     if (pos != p->pos || pos + B > p->n) return PTB_EUNSUPPORTED;
     const int codes = [&] { int v = 0; for (int k = 0; k < V; ++k) v |= (views[k] & 7) << (3 * k); return v; }();
     if (p->cfg_set) {
-        if (p->cfg_dtype != in_dtype || p->cfg_V != V || p->cfg_codes != codes || p->cfg_red != reduction || p->cfg_merged != merged ||
+        if (p->cfg_dtype != dtype_arg || p->cfg_V != V || p->cfg_codes != codes || p->cfg_red != reduction || p->cfg_merged != merged ||
             p->cfg_norm != norm_full || p->cfg_weight != weight) return PTB_EUNSUPPORTED;
     }
     const long long per_tile = (long long)p->C * p->th * p->tw;
@@ -465,7 +468,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     if (nT > MAX_T || tile_stride < per_tile || view_stride < per_tile || tile_stride % 4 || view_stride % 4 ||
         (reinterpret_cast<uintptr_t>(batch) & mask) || !aligned16(merged) || !aligned16(norm_full) || !aligned16(weight))
         return PTB_EUNSUPPORTED;
-    p->cfg_set = 1; p->cfg_dtype = in_dtype; p->cfg_V = V; p->cfg_codes = codes; p->cfg_red = reduction;
+    p->cfg_set = 1; p->cfg_dtype = dtype_arg; p->cfg_V = V; p->cfg_codes = codes; p->cfg_red = reduction;
     p->cfg_merged = merged; p->cfg_norm = norm_full; p->cfg_weight = weight;
     for (int b = 0; b < B; ++b) {
         p->src[pos + b] = static_cast<const char*>(batch) + (size_t)b * (size_t)tile_stride * esz;
@@ -475,6 +478,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     ViewArgs a{};
     a.weight = weight; a.merged = merged; a.norm_full = norm_full;
     a.in_dtype = in_dtype;
+    a.round_src = (dtype_arg & PTB_ROUND_SRC) ? 1 : 0;
     a.H = p->th; a.W = p->tw; a.C = p->C;
     a.dst_chan_stride = (long long)p->H * p->W;
     a.dst_row_stride = p->W;

@@ -62,6 +62,7 @@ struct ViewArgs {
     int ncells, total_chunks;
     int in_dtype;        // element type of src: PTB_F32 | PTB_F16 | PTB_BF16 (reduce / accumulate kernels)
     int keep_acc;        // planned accumulate: a finalised cell ALSO stores its weighted sum in the accumulator (PTB_PLANNED_KEEP_SUMS)
+    int round_src;       // PTB_ROUND_SRC: the reduced value is rounded to the (half / bf16) source type before it is blended
 };
 
 enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
@@ -213,6 +214,28 @@ __device__ __forceinline__ float4 widen4(const typename RawOf<LD>::type r) {
     } else {
         return make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
     }
+}
+
+// PTB_ROUND_SRC: what `tta.*_image_deaugment(half tensor)` hands to `integrate_batch` is a HALF tensor -- the reduced value rounded to
+// the source type (round to nearest even, torch's `.to(dtype)`), which integrate_batch then widens exactly (tiles.py:334-335).  The
+// fused launch of a lazy de-augmentation handle reproduces that rounding in registers: one v_cvt pair (fp16) / four integer
+// operations (bf16) per value, nothing for fp32 sources.
+template <int LD>
+__device__ __forceinline__ float round_src1(float x) {
+    if constexpr (LD == 2) {
+        return (float)(_Float16)x;
+    } else if constexpr (LD == 3) {
+        const unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float(0x7fc00000u);      // (torch's bf16 conversion: every NaN becomes the quiet NaN 0x7FC0)
+        return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+    } else {
+        return x;
+    }
+}
+template <int LD>
+__device__ __forceinline__ float4 round_src4(const float4 v, int on) {
+    if constexpr (LD <= 1) return v;
+    else return on ? make_float4(round_src1<LD>(v.x), round_src1<LD>(v.y), round_src1<LD>(v.z), round_src1<LD>(v.w)) : v;
 }
 
 __device__ __forceinline__ float comp(const float4& v, int m) { return m == 0 ? v.x : (m == 1 ? v.y : (m == 2 ? v.z : v.w)); }

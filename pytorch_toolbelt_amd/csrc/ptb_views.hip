@@ -95,8 +95,8 @@ __global__ __launch_bounds__(CH * 16) void view_accum_kernel(const ViewArgs a, c
         const int gt = cell.tile[e];
         const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
         const long long plane = (long long)g.tile_id[gt] * a.src_tile_stride + (long long)c * a.H * a.W;
-        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(a.src, plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
-                                                        ch, a.op, a.divisor, lds, tid, e + 1 < nt);
+        const float4 val = round_src4<LD>(gather_reduce<CH, NV, CODES, OPK, LD>(a.src, plane, a.src_view_stride, a.nviews, a.codes, a.H, a.W, lx, ly, cw,
+                                                        ch, a.op, a.divisor, lds, tid, e + 1 < nt), a.round_src);
         if (act) {
             // (requesting the window value before the gather was A/B-tested on one box: no gain, and 6 more VGPRs cost a wave
             // of occupancy -- the other resident workgroups already hide this L2 latency)
@@ -210,9 +210,9 @@ __global__ __launch_bounds__(512) void band_merge_kernel(const ViewArgs a, const
     for (int e = 0; e < nt; ++e) {
         const int gt = cell.tile[e];
         const int lx = ax - g.tile_x[gt], ly = ay - g.tile_y[gt];
-        const float4 val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(g.tile_src[gt]), (long long)c * a.H * a.W,
+        const float4 val = round_src4<LD>(gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(g.tile_src[gt]), (long long)c * a.H * a.W,
                                                                 g.tile_vs[gt], a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op,
-                                                                a.divisor, lds, tid, e + 1 < nt);
+                                                                a.divisor, lds, tid, e + 1 < nt), a.round_src);
         if (act) {
             const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338, no FMA contraction
@@ -783,6 +783,8 @@ static int probe_accum(const int* xs, const int* ys, int lo, int hi, int tw, int
 static int accumulate_impl(float* image, float* norm, const float* weight, const float* in, int V, const int* views,
                            int reduction, const int64_t* xs64, const int64_t* ys64, int B, int C, int th, int tw, int H, int W,
                            uint8_t* fresh, int fresh_rows, hipStream_t s, int in_dtype = PTB_F32) {
+    const int round_src = (in_dtype & PTB_ROUND_SRC) ? 1 : 0;
+    in_dtype &= ~PTB_ROUND_SRC;
     if (in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
     const bool norm_only = !image && !in;  // ptb_norm_accumulate
     if ((!norm_only && (!image || !in)) || (norm_only && !norm) || !weight || !xs64 || !ys64) return PTB_EINVAL;
@@ -801,6 +803,7 @@ static int accumulate_impl(float* image, float* norm, const float* weight, const
     ViewArgs a{};
     a.src = in; a.dst = image; a.norm = norm; a.weight = weight;
     a.in_dtype = in_dtype;
+    a.round_src = round_src;
     a.H = th; a.W = tw; a.C = C;
     a.src_view_stride = (long long)B * C * th * tw;
     a.src_tile_stride = (long long)C * th * tw;
@@ -883,6 +886,8 @@ extern "C" int ptb_accumulate_planned2(float* image, const float* norm_full, flo
                                        int tw, int H, int W, uint8_t* fresh, int fresh_rows, uint8_t* remaining, uint8_t* done, int flags,
                                        ptb_stream_t stream) {
     if (flags & ~1) return PTB_EINVAL;
+    const int round_src = (in_dtype & PTB_ROUND_SRC) ? 1 : 0;
+    in_dtype &= ~PTB_ROUND_SRC;
     if (!image || !norm_full || !merged || !weight || !in || !xs64 || !ys64 || !remaining || !done) return PTB_EINVAL;
     if (B < 0 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || fresh_rows < 1) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
@@ -898,6 +903,7 @@ extern "C" int ptb_accumulate_planned2(float* image, const float* norm_full, flo
     ViewArgs a{};
     a.src = static_cast<const float*>(in); a.dst = image; a.norm = nullptr; a.weight = weight; a.merged = merged; a.norm_full = norm_full;
     a.in_dtype = in_dtype;
+    a.round_src = round_src;
     a.keep_acc = flags & 1;
     a.H = th; a.W = tw; a.C = C;
     a.src_view_stride = (long long)B * C * th * tw;
@@ -956,6 +962,8 @@ extern "C" int ptb_merge_band(float* merged, const float* norm_full, const float
                               const int64_t* tile_view_stride, int in_dtype, int V, const int* views, int reduction,
                               const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W, int y0, int y1,
                               ptb_stream_t stream) {
+    const int round_src = (in_dtype & PTB_ROUND_SRC) ? 1 : 0;
+    in_dtype &= ~PTB_ROUND_SRC;
     if (!merged || !norm_full || !weight || !tile_src || !tile_view_stride || !xs64 || !ys64) return PTB_EINVAL;
     if (n < 1 || C < 1 || th < 1 || tw < 1 || H < 1 || W < 1 || y0 < 0 || y1 <= y0 || y1 > H) return PTB_EINVAL;
     if (reduction < PTB_RED_SUM || reduction > PTB_RED_LOG1P || in_dtype < PTB_F32 || in_dtype > PTB_BF16) return PTB_EINVAL;
@@ -964,6 +972,7 @@ extern "C" int ptb_merge_band(float* merged, const float* norm_full, const float
     ViewArgs a{};
     a.weight = weight; a.merged = merged; a.norm_full = norm_full;
     a.in_dtype = in_dtype;
+    a.round_src = round_src;
     a.H = th; a.W = tw; a.C = C;
     a.dst_chan_stride = (long long)H * W;
     a.dst_row_stride = W;

@@ -31,7 +31,7 @@ Tensors made under ``torch.inference_mode()`` carry no version counter; they get
 owner (``deaugment(model(x))`` written as one expression, the model keeping no reference to its output and nothing else sharing its
 storage): then nobody exists who could change the source.
 
-Only inference-shaped calls are lazy (float32 CUDA source, string reduction, no autograd, no tracing / compiling);
+Only inference-shaped calls are lazy (float32 / float16 / bfloat16 CUDA source, string reduction, no autograd, no tracing / compiling);
 everything else is evaluated on the spot exactly as before.  ``tta.set_lazy_deaugment(False)`` / ``PTB_LAZY_DEAUG=0``
 switch it off.
 """
@@ -137,7 +137,7 @@ class LazyDeaugment(torch.Tensor):
     def __init__(self, source, group, views, code, compute):
         if _dlpack_orig is None:
             _guard_legacy_dlpack()         # (first handle of the process: from here on to_dlpack(handle) must evaluate it first)
-        self._src = source                 # [V*B, C, H, W] contiguous float32 model output (chunk-major)
+        self._src = source                 # [V*B, C, H, W] contiguous float32 / float16 / bfloat16 model output (chunk-major)
         self._group = group                # "d4" | "d2" | "flips" | "fliplr" | "flipud"
         self._views = views                # inverse view codes, chunk order
         self._code = code                  # HIP reduction code
@@ -275,10 +275,16 @@ def _sole_owner(t):
         return False
 
 
+# float32, and (round 6) the half-precision outputs of a model under torch.autocast: the handle of a half source stands for the HALF
+# tensor the eager call returns (the fp32 reduction rounded once to the source dtype), and a merger that fuses it rounds the reduced value
+# the same way in registers (PTB_ROUND_SRC) -- fused and evaluated results are bit-identical
+_LAZY_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+
+
 def maybe_lazy(source, group, views, code, compute, owned=False):
     """A ``LazyDeaugment`` for this call when it is inference-shaped, else None (the caller evaluates eagerly).  ``owned``: the public
     function saw its argument referenced by nobody but the call expression (``tta._TEMP_REFS``)."""
-    if not _ENABLED or type(source) is not torch.Tensor or not source.is_cuda or source.dtype != torch.float32 or source.dim() != 4:
+    if not _ENABLED or type(source) is not torch.Tensor or not source.is_cuda or source.dtype not in _LAZY_DTYPES or source.dim() != 4:
         return None
     if source.requires_grad and torch.is_grad_enabled():
         return None

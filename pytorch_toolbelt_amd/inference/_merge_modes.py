@@ -27,6 +27,8 @@ import torch
 from .. import _native as N
 
 FRESH_ROWS = 32  # rows of a first-touch block = default chunk rows of the view kernels (64 columns wide)
+LAZY_SRC = 0x10000  # host-only bit of a batch's `how` flags (next to N.ROUND_SRC): the batch is the source of a lazy de-augmentation handle --
+                    # handed out only where a change of it would be noticed (version counter) or nobody else can reach it (inference/_lazy.py)
 
 
 def default_defer_rows():
@@ -369,8 +371,8 @@ class DeferredBands(_OfMerger):
         m._plan.active = keep_plan and m._plan.blocks      # (a band-only plan has no block strategy to hand the image to)
         m._merged = None                                   # (nothing was launched into it; the planned strategy makes its own)
         m._log, m._applied = [], 0
-        for batch, (coords, views, reduction), *_rest in held:
-            m._accumulate(batch, coords, views, reduction)
+        for batch, (coords, views, reduction, rnd), *_rest in held:
+            m._accumulate(batch, coords, views, reduction, rnd)
 
     def soften(self, what):
         """A merger that deferred ON ITS OWN ACCOUNT (self-planned) is asked for something deferred merging cannot serve after bands
@@ -394,8 +396,8 @@ class DeferredBands(_OfMerger):
         plan.active = False
         log = list(m._log)                 # every crop of the image so far (the normaliser is built from it); the replay must not log twice
         m._materialize()
-        for batch, (coords, views, reduction), *_rest in held:
-            m._accumulate(batch, coords, views, reduction)
+        for batch, (coords, views, reduction, rnd), *_rest in held:
+            m._accumulate(batch, coords, views, reduction, rnd)
         m._log = log
         m._norm_ready()
         for y0, y1 in launched:
@@ -419,6 +421,13 @@ class DeferredBands(_OfMerger):
         (``ptb_band_plan_submit``: the pointer bookkeeping and the launches happen in C).  Returns its code: < 0 nothing was taken."""
         m, bands = self.m, self.bands
         plan = m._plan
+        if self.soft and not (dcode & LAZY_SRC) and tensor_version(batch) is None:
+            # A merger that defers ON ITS OWN ACCOUNT reads this batch in a later launch, and nothing could tell it that the caller
+            # changed it in between: tensors made under torch.inference_mode() carry no version counter (ADVICE round 5: `m1.integrate_batch(y, c);
+            # y.sigmoid_(); m2.integrate_batch(y, c)` silently corrupted m1).  Such batches are read inside integrate_batch -- planned blocks.
+            m._selfplan.unprovable()
+            return N.PTB_EUNSUPPORTED
+        dcode &= ~LAZY_SRC
         if self.soft and not self.budget_checked:
             self.budget_checked = True
             per_tile = n_views * m.channels * int(m.weight.shape[1]) * int(m.weight.shape[2]) * batch.element_size()
@@ -437,7 +446,7 @@ class DeferredBands(_OfMerger):
         if rc < 0:
             return rc
         lg = bands.last_group
-        self.held.keep(batch, span, (coords, views, code), int(lg[pos + B - 1]) if bands.sorted_tiles else int(lg[pos:pos + B].max()))
+        self.held.keep(batch, span, (coords, views, code, dcode & N.ROUND_SRC), int(lg[pos + B - 1]) if bands.sorted_tiles else int(lg[pos:pos + B].max()))
         plan.pos = pos + B
         if rc:
             done = self.done = self.done + rc
@@ -447,7 +456,7 @@ class DeferredBands(_OfMerger):
                 self.held.release_before(done)
         return rc
 
-    def take_fast(self, batch, crop_coords, key, views, code):
+    def take_fast(self, batch, crop_coords, key, views, code, rnd=0):
         """The common call (see ``_fast_call``) for exactly the next planned crops: everything constant per merger / per
         (group, reduction) is cached, the rest is one C call: ~10 us of host time instead of ~20.  False: ``take`` decides (and
         reports)."""
@@ -459,6 +468,8 @@ class DeferredBands(_OfMerger):
         B, pos = crop_coords.shape[0], plan.pos
         if dcode is None or B == 0 or batch.device != m._image.device or crop_coords.shape[1] != 4 or not plan.next_are(crop_coords, B):
             return False
+        if rnd:
+            dcode |= (rnd & LAZY_SRC) | (rnd & N.ROUND_SRC if dcode else 0)
         varr, n_views = m._view_array(key, views)
         if batch.shape != (B * n_views, m.channels, m.weight.shape[1], m.weight.shape[2]):
             return False
@@ -478,14 +489,15 @@ class DeferredBands(_OfMerger):
         plan = m._plan
         B = xy.shape[1]
         rc = N.PTB_EUNSUPPORTED
+        soft = self.soft        # (read before _submit: its budget / provability exits rebind the strategy, and what follows is about the merger the caller made)
         if plan.active and not m._eager_norm and plan.follows(xy, B):
             varr = N.int_array(views) if views is not None else N.int_array([N.IDENT])
             rc = self._submit(batch, coords, views, plan.pos, B, dcode, len(views) if views is not None else 1, varr, reduction)
         if rc == N.PTB_EUNSUPPORTED:
-            if not self.soft:
+            if not soft:
                 warn_once(("defer-deviation",), "TileMerger(defer=True): a batch deviates from the planned crop sequence / configuration (or "
                                                 "norm_mask was read); leaving deferred mode for this image, the held batches are replayed incrementally.")
-            self.flush("a tile batch off the remembered crop sequence" if self.soft else "an unplanned tile batch", keep_plan=self.soft and self.done == 0
+            self.flush("a tile batch off the remembered crop sequence" if soft else "an unplanned tile batch", keep_plan=soft and self.done == 0
                        and plan.active and not m._eager_norm and plan.follows(xy, B))
             return False
         if rc < 0:
@@ -536,7 +548,7 @@ class PlannedBlocks(_OfMerger):
         N.bump()
         return rc
 
-    def take_fast(self, batch, crop_coords, key, views, code):
+    def take_fast(self, batch, crop_coords, key, views, code, rnd=0):
         """The common call (see ``_fast_call``) for exactly the next planned crops: ~12 us of host time instead of ~40.  False:
         ``take`` decides (and reports)."""
         m = self.m
@@ -544,6 +556,8 @@ class PlannedBlocks(_OfMerger):
         if plan is None or not plan.active or not plan.blocks or m._deferred.active or not _fast_call(m, batch, crop_coords):
             return False
         dcode = N.DTYPE_CODES.get(batch.dtype)
+        if dcode and rnd & N.ROUND_SRC:
+            dcode |= N.ROUND_SRC
         B, pos = crop_coords.shape[0], plan.pos
         if (dcode is None or B == 0 or batch.device != m._image.device or pos + B > plan.xy.shape[1] or crop_coords.shape[1] != 4
                 or not plan.next_are(crop_coords, B)):
@@ -654,6 +668,10 @@ class Incremental(_OfMerger):
                 rc = launch(None)
         N.bump()
         if rc == -2 and dcode != N.F32:   # shape needs the scalar kernels: take the reference's route (cast, then accumulate)
+            if dcode & N.ROUND_SRC:        # (the source of a lazy de-augmentation handle: evaluate it as the eager call would -- a half tensor -- and blend that)
+                from ._views import deaug_reduce
+
+                return m._accumulate(deaug_reduce(batch, views if views is not None else [N.IDENT], reduction).float(), coords, None, N.RED_SUM)
             return m._accumulate(batch.float(), coords, views, reduction)
         N.check(rc, "TileMerger.integrate_batch")
         if not m._eager_norm and B:
@@ -705,7 +723,7 @@ def defer_budget():
 
 
 class AutoEntry:
-    __slots__ = ("log", "seen", "need", "parts", "disabled", "static", "tile_bytes", "batch_tiles", "pool", "rows", "no_defer")
+    __slots__ = ("log", "seen", "need", "parts", "disabled", "static", "tile_bytes", "batch_tiles", "pool", "rows", "no_defer", "unversioned")
 
     def __init__(self):
         self.log = None        # bytes of the [n, 4] int64 crop sequence of the last merged image
@@ -719,6 +737,7 @@ class AutoEntry:
         self.pool = []         # free Bands built for `parts` with `rows` rows per launch
         self.rows = None       # rows per launch the budget allows (None: not decided; 0: deferral does not fit / not available)
         self.no_defer = False  # the band kernel does not take this geometry, or an image was over the byte budget
+        self.unversioned = False  # its batches carry no version counter and are not the sole-owned sources of lazy handles: never held (planned blocks)
 
 
 def auto_entry(key, create=False):
@@ -743,7 +762,8 @@ class SelfPlanning(_OfMerger):
         self.planned = False      # merger._plan was made here (from the previous image's crops), not by the caller
         self.noted = None         # log length at the last merge() of this image
         self.bands = None         # the Bands this merger has checked out of its geometry's pool
-        self.prev = None          # learning pass: the previous batch, kept alive for one call (observe)
+        self.prev = None          # learning pass: deque of (batch, p0, p1) -- the window of model outputs kept alive (observe); False: outputs are static
+        self.prev_bytes = 0
         self.tile_bytes = self.batch_tiles = 0
 
     def __del__(self):
@@ -766,7 +786,7 @@ class SelfPlanning(_OfMerger):
     def _acquire(self, ent, plan):
         """A band plan for ``plan`` whose custody fits the byte budget, or None (then the merger runs planned blocks)."""
         m = self.m
-        if ent.static or ent.no_defer or ent.rows == 0:
+        if ent.static or ent.no_defer or ent.unversioned or ent.rows == 0:
             return None
         with auto_lock:
             if ent.pool:
@@ -835,7 +855,7 @@ class SelfPlanning(_OfMerger):
         if ent.parts is None:
             crops4 = np.frombuffer(ent.log, dtype=np.int64).reshape(-1, 4)
             plan = Plan.build(m, crops4)
-            if plan is None and not ent.static:
+            if plan is None and not ent.static and not ent.unversioned:
                 plan = Plan.build(m, crops4, blocks=False)      # off the 64 x 32 block grid: deferred bands or nothing
             if plan is None:          # this geometry never plans
                 ent.disabled = True
@@ -851,7 +871,7 @@ class SelfPlanning(_OfMerger):
         plan.crops4 = crops4
         bands = self._acquire(ent, plan)
         if bands is None and not plan.blocks:      # a band-only plan without bands (budget, static outputs, the band kernel's grid): no plan at all
-            ent.disabled = ent.disabled or ent.no_defer or ent.static
+            ent.disabled = ent.disabled or ent.no_defer or ent.static or ent.unversioned
             m._plan, self.planned = None, False
             return
         m._plan, self.planned = plan, True
@@ -862,22 +882,50 @@ class SelfPlanning(_OfMerger):
         if self.key is not None:
             auto_entry(self.key, create=True).disabled = True
 
-    def observe(self, batch, n_views):
+    def observe(self, batch, n_views, lazy=0):
         """Learning pass (an image of a keyed merger that is not planned): remember how much model output a tile brings, and notice
-        model outputs that share memory while alive.  The previous batch is kept referenced for the length of one call -- with a
-        model that returns fresh tensors the allocator then cannot hand its block out again, so an overlap means a static buffer."""
+        model outputs that share memory while alive.  Round 6: the batches of the image are kept referenced as far back as a deferred
+        image of this geometry could ever keep them -- the byte budget of self-planned deferral (``PTB_DEFER_BYTES``) bounds that
+        custody, so it bounds this window too.  With a model that returns fresh tensors the allocator then cannot hand a block of the
+        window out again; an overlap means the model writes into a static buffer or cycles through a RING of output buffers (two captured
+        graphs, ``out=bufs[i % k]``) no deeper than what deferral would hold -- such a geometry never defers (planned blocks read every
+        batch inside ``integrate_batch``); a deeper ring is harmless by construction.  Batches without a version counter that are not
+        the sources of lazy handles (``torch.inference_mode()``) are noted too: nothing could tell a later launch that they changed."""
         if self.key is None or self.planned:
             return
         per_tile = n_views * int(np.prod(batch.shape[1:])) * batch.element_size()
         if per_tile > self.tile_bytes:
             self.tile_bytes = per_tile
         self.batch_tiles = max(self.batch_tiles, batch.shape[0] // n_views)
-        prev, self.prev = self.prev, batch
-        if prev is not None:
-            p0, p1, _v = held_entry(batch)
-            q0, q1, _v = held_entry(prev)
+        p0, p1, version = held_entry(batch)
+        if version is None and not lazy:
+            auto_entry(self.key, create=True).unversioned = True
+        window = self.prev
+        if window is None:
+            window = self.prev = collections.deque()
+            self.prev_bytes = 0
+        elif window is False:        # (static outputs already seen: nothing more to learn, nothing more to hold)
+            return
+        for _t, q0, q1 in window:
             if p0 < q1 and q0 < p1:
                 auto_entry(self.key, create=True).static = True
+                self.prev = False
+                return
+        window.append((batch, p0, p1))
+        self.prev_bytes += p1 - p0
+        budget = defer_budget()
+        while len(window) > 1 and self.prev_bytes > budget:
+            _t, q0, q1 = window.popleft()
+            self.prev_bytes -= q1 - q0
+
+    def unprovable(self):
+        """A self-deferred image is handed a batch nobody could vouch for later (no version counter, not a lazy handle's source): its
+        geometry stops deferring (planned blocks from here on; ``DeferredBands.take`` replays what is held)."""
+        with auto_lock:
+            ent = auto_cache.get(self.key)
+            if ent is not None:
+                ent.unversioned = True
+                ent.pool = []
 
     def note(self):
         """At merge(): remember the crop sequence this image was made of (what the next image of this geometry is planned from)."""

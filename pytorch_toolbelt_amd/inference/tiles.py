@@ -15,6 +15,7 @@ import torch
 from .. import _native as N
 from . import _lazy
 from ._merge_modes import FRESH_ROWS as _FRESH_ROWS
+from ._merge_modes import LAZY_SRC as _LAZY_SRC
 from ._merge_modes import Bands as _Bands
 from ._merge_modes import DeferredBands, Incremental, PlannedBlocks, SelfPlanning
 from ._merge_modes import Plan as _Plan
@@ -637,8 +638,11 @@ class TileMerger:
             if t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError("TileMerger accumulators must be contiguous float32 tensors")
 
-    def _accumulate(self, batch, coords, views, reduction):
-        """Any batch, validated once, offered to the strategies in order: deferred bands, planned blocks, incremental."""
+    def _accumulate(self, batch, coords, views, reduction, rnd=0):
+        """Any batch, validated once, offered to the strategies in order: deferred bands, planned blocks, incremental.  ``rnd`` (flags):
+        ``N.ROUND_SRC`` -- the batch is the half-precision source of a lazy de-augmentation handle (the reduced value is rounded to the
+        source dtype before it is blended, as the reference's two calls do); ``_LAZY_SRC`` -- it is the source of such a handle at all
+        (what a self-deferring merger may keep without a version counter: ``_merge_modes.DeferredBands._submit``)."""
         self._check_state()
         if self._plan is not None and self._plan.active and self._window_edited():
             self._planned.off("integrating with an edited blending window")   # (the planned normaliser was built from the original one)
@@ -654,9 +658,11 @@ class TileMerger:
             raise RuntimeError("crop size in crop_coords does not match the tile / weight size")
         xy = np.ascontiguousarray(coords[:, :2].T)          # [2, B] int64: xs row, ys row (host arrays for the C ABI)
         dcode = N.DTYPE_CODES[batch.dtype]
+        if rnd & N.ROUND_SRC and dcode != N.F32:
+            dcode |= N.ROUND_SRC
         if B:
-            self._selfplan.observe(batch, n_views)
-        if B and self._deferred.active and self._deferred.take(batch, coords, xy, views, reduction, dcode):
+            self._selfplan.observe(batch, n_views, rnd & _LAZY_SRC)
+        if B and self._deferred.active and self._deferred.take(batch, coords, xy, views, reduction, dcode | (rnd & _LAZY_SRC)):
             return
         xs = xy[0].ctypes.data_as(N._i64p)
         ys = xy[1].ctypes.data_as(N._i64p)
@@ -665,11 +671,11 @@ class TileMerger:
             return
         return self._incremental.take(batch, coords, xy, xs, ys, views, n_views, varr, reduction, dcode)
 
-    def _offer_fast(self, batch, crop_coords, key, views, code):
+    def _offer_fast(self, batch, crop_coords, key, views, code, rnd=0):
         """The live strategy's cheap host path for the common call; False: ``_accumulate`` validates and decides."""
         if self._deferred.active:
-            return self._deferred.take_fast(batch, crop_coords, key, views, code)
-        return self._plan is not None and self._planned.take_fast(batch, crop_coords, key, views, code)
+            return self._deferred.take_fast(batch, crop_coords, key, views, code, rnd)
+        return self._plan is not None and self._planned.take_fast(batch, crop_coords, key, views, code, rnd)
 
     # ------------------------------------------------------------------ reference API
     def accumulate_single(self, tile: torch.Tensor, coords):
@@ -687,9 +693,12 @@ class TileMerger:
             if taken is not None:
                 source, _group, views, code = taken
                 _lazy.fused += 1
-                if self._offer_fast(source, crop_coords, (_group, code), views, code):
+                # a half-precision source (torch.autocast): the handle stands for a HALF tensor, i.e. the reduced value rounded to
+                # the source dtype (tta.py:442-467) before tiles.py:334-335 widens it again -- the fused launch rounds in registers
+                rnd = _LAZY_SRC | (0 if source.dtype == torch.float32 else N.ROUND_SRC)
+                if self._offer_fast(source, crop_coords, (_group, code), views, code, rnd):
                     return
-                return self._accumulate(self._prep(source), _coords_xy(crop_coords), list(views), code)
+                return self._accumulate(self._prep(source), _coords_xy(crop_coords), list(views), code, rnd)
         if self._offer_fast(batch, crop_coords, None, None, N.RED_SUM):
             return
         self._accumulate(self._prep(batch), _coords_xy(crop_coords), None, N.RED_SUM)

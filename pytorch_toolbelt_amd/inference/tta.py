@@ -379,6 +379,8 @@ def _ms_fuse_lazy(images, size_offsets, reduction, mode, align_corners, stride):
         return None
     if any(v & 1 for v in first._views):
         return None                       # transposing groups are not combined with multiscale in the one-pass kernel
+    if any(t.dtype != torch.float32 for t in images):
+        return None                       # half-precision handles stand for half tensors (rounded per scale): evaluated, then composed
     taken = [t._take_source() for t in images]
     if any(x is None for x in taken):
         return None

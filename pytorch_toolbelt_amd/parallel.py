@@ -8,10 +8,10 @@ The reference has no multi-GPU tile path; the single-device ``TileMerger`` resul
   tile rows, 19 over 8 ranks, would leave one rank with 3 rows = 57 tiles); a rank's tiles cover a horizontal band;
 * every rank accumulates its band locally with the fused HIP kernels (no communication on the data path);
 * each rank **owns** a range of pixel rows of the result.  The only exchange is the part of a band that lies in
-  another rank's rows: when the boundary between two ranks coincides with the start of a tile row, one strip of
-  tile_size - tile_step rows travels to the next rank (21 MB for the headline config); when it falls inside a tile row,
-  the two ranks swap two half-height rectangles as wide as their share of that tile row (the same 21 MB in total, but
-  split over the two directions of the link).  All pairs run concurrently on distinct xGMI links as point-to-point
+  another rank's rows, and the ownership cut always lies in the middle of the rows two neighbours share: when the boundary
+  between two ranks coincides with the start of a tile row, each ships half of the tile_size - tile_step shared rows to the
+  other (2 x 10.5 MB for the headline config, in opposite directions of one link); when it falls inside a tile row, the two
+  ranks swap two half-height rectangles as wide as their share of that tile row (the same 21 MB in total).  All pairs run concurrently on distinct xGMI links as point-to-point
   send/receive, overlapped with the accumulation of the tiles that do not feed a rectangle.  Nothing is all-reduced: a
   ring all-reduce of the 524 MB accumulator would be per-link bound and ~30x slower than the kernels;
 * ``norm_mask`` is data independent, so every rank computes the global normaliser of its owned rows once, locally;
@@ -75,17 +75,63 @@ def pixel_row_partition(crops: np.ndarray, world: int, image_height: int) -> Lis
     return [order[(ys < cuts[r + 1]) & (ys + th > cuts[r])].astype(np.int64) for r in range(world)]
 
 
+def _cover_rects(tiles: np.ndarray, r0: int, r1: int, th: int, tw: int):
+    """The part of the union of ``tiles`` ((x, y, ...) rows) that lies on pixel rows ``r0:r1``, as rectangles ``(q0, q1, c0, c1)``: the
+    rows are split at the tiles' edges and every run gets the column extent of the tiles that reach it (contiguous tile ranges of a
+    row-major sequence: the extent is covered without holes); runs with equal extents are joined."""
+    ys = tiles[:, 1]
+    edges = sorted({r0, r1} | {int(v) for v in np.concatenate([ys, ys + th]) if r0 < v < r1})
+    out = []
+    for q0, q1 in zip(edges[:-1], edges[1:]):
+        hit = (ys < q1) & (ys + th > q0)
+        if not hit.any():
+            continue
+        c0, c1 = int(tiles[hit, 0].min()), int(tiles[hit, 0].max()) + tw
+        if out and out[-1][1] == q0 and out[-1][2:] == (c0, c1):
+            out[-1] = (out[-1][0], q1, c0, c1)
+        else:
+            out.append((q0, q1, c0, c1))
+    return out
+
+
+def _balanced_cut(upper: np.ndarray, lower: np.ndarray, y_s: int, lo: int, hi: int, th: int, tw: int, half: int) -> int:
+    """The ownership cut between two neighbouring ranks (``upper`` / ``lower``: their crop rows; ``y_s``: the top of the lower rank's
+    first tile): the row in ``lo..hi`` at which the partial sums the upper rank ships down (its tiles' area below the cut) and the ones
+    the lower rank ships up (its tiles' area above it) are as EQUAL as the 4-row grid of the band kernel allows -- the two transfers
+    share one full-duplex xGMI link, so the larger one is what an image waits for.  Round 5 cut at the top of the lower rank's first
+    tile row when it starts one (everything one way) and half a tile below it when the boundary falls inside a tile row (then the rank
+    with more tiles of that row shipped up to 18.9 MB at the headline geometry, the other 3 MB); balanced, no direction of any link
+    carries more than 11.8 MB of the same ~22 MB total.  A position on the 64-row grid of the kernel's work items is preferred
+    when it costs at most 1 % more."""
+    def cost(c):
+        down = sum((q1 - q0) * (c1 - c0) for q0, q1, c0, c1 in _cover_rects(upper, c, int(upper[:, 1].max()) + th, th, tw)) if c < int(upper[:, 1].max()) + th else 0
+        up = sum((q1 - q0) * (c1 - c0) for q0, q1, c0, c1 in _cover_rects(lower, int(lower[:, 1].min()), c, th, tw)) if c > int(lower[:, 1].min()) else 0
+        return max(down, up)
+
+    grid = 4 if (lo % 4 == 0 and th % 4 == 0 and y_s % 4 == 0) else 1
+    cands = [c for c in range(lo + (-lo) % grid, hi + 1, grid)] or [lo]
+    costs = {c: cost(c) for c in cands}
+    centre = y_s + half
+    best = min(cands, key=lambda c: (costs[c], abs(c - centre)))
+    on64 = [c for c in cands if c % 64 == 0 and costs[c] <= 1.01 * costs[best]]
+    if on64:
+        best = min(on64, key=lambda c: (costs[c], abs(c - centre)))
+    return int(best)
+
+
 def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str = "tiles"):
     """Who accumulates, owns and exchanges what.  Per rank a dict with
 
     * ``tiles``: its tile indices in ISSUE order -- the tiles feeding an outgoing rectangle first, so that the exchange
       overlaps the accumulation of the others;
     * ``band`` = (a, b): pixel rows touched by its tiles;  ``owned`` = (o0, o1): the rows of the result it produces.
-      The cut between consecutive ranks r, s lies at the top of s's first tile when s starts a tile row, and half a tile
-      (at most one tile step) lower when the boundary falls inside a tile row -- then r holds the larger share of the
-      rows above the cut and s of the rows below, and the two halo rectangles travel in opposite directions at once;
+      The cut between consecutive ranks r, s is the row that BALANCES what the two ship to each other (``_balanced_cut``, round 6):
+      the middle of the shared rows when s starts a tile row, and near half a tile below the top of s's first tile when the boundary
+      falls inside a tile row -- moved towards the rank that holds more tiles of that row.  r holds the rows above the cut, s the rows
+      below, and the halo rectangles travel in opposite directions of one full-duplex link at once;
     * ``sends`` = [(dst, r0, r1, c0, c1)], ``recvs`` = [(src, r0, r1, c0, c1)]: absolute pixel rectangles (rows r0:r1,
-      columns c0:c1 = the column extent of the sender's tiles on those rows) of the sender's partial sums that another
+      columns c0:c1 = the column extent of the sender's tiles on those rows; a neighbour may get two -- the rows its cut takes
+      from a full tile row and from the part of a tile row the sender holds) of the sender's partial sums that another
       rank owns.  ``boundary``: the tile indices that must be in before the sends are complete.
 
     Ranks without tiles have ``band`` = ``owned`` = None."""
@@ -104,8 +150,7 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
     cut = [0]
     for r, s in zip(live[:-1], live[1:]):
         y_s = int(crops[parts[s][0], 1])
-        mid_row = int(crops[parts[r][-1], 1]) == y_s
-        cut.append(min(image_height, max(cut[-1], y_s + (half if mid_row else 0))))
+        cut.append(_balanced_cut(crops[parts[r]], crops[parts[s]], y_s, max(cut[-1], y_s), min(image_height, y_s + th), th, tw, half))
     cut.append(image_height)
     for i, r in enumerate(live):
         plan[r]["owned"] = (cut[i], cut[i + 1])
@@ -118,13 +163,10 @@ def band_plan(crops: np.ndarray, world: int, image_height: int, partition: str =
             r0, r1 = max(a, o0), min(b, o1)
             if d == s or r0 >= r1:
                 continue
-            hit = (mine[:, 1] < r1) & (mine[:, 1] + th > r0)
-            if not hit.any():
-                continue
-            c0, c1 = int(mine[hit, 0].min()), int(mine[hit, 0].max()) + tw
-            plan[s]["sends"].append((d, r0, r1, c0, c1))
-            plan[d]["recvs"].append((s, r0, r1, c0, c1))
-            feeding |= hit
+            for q0, q1, c0, c1 in _cover_rects(mine, r0, r1, th, tw):      # (tight per run of rows: the columns of the tiles that reach them)
+                plan[s]["sends"].append((d, q0, q1, c0, c1))
+                plan[d]["recvs"].append((s, q0, q1, c0, c1))
+            feeding |= (mine[:, 1] < r1) & (mine[:, 1] + th > r0)
         plan[s]["boundary"] = parts[s][feeding]
         plan[s]["tiles"] = np.concatenate([parts[s][feeding], parts[s][~feeding]])
     return plan
@@ -903,6 +945,8 @@ class ShardedTileMerger:
             raise ValueError("Number of images in batch does not correspond to number of coordinates")
         from .inference import _lazy
 
+        if type(batch) is _lazy.LazyDeaugment and batch.dtype != torch.float32:
+            batch = batch._evaluate()                   # (half-precision handles -- a half tensor, rounded once -- are not fused on the sharded path)
         if type(batch) is _lazy.LazyDeaugment:      # integrate_batch(tta.<group>_image_deaugment(y), crops): fused, like TileMerger
             taken = batch._take_source()
             if taken is not None:

@@ -191,18 +191,24 @@ def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes()
             "h = L.LazyDeaugment(torch.randn(4, 1, 2, 2), 'fliplr', (0, 4), 1, lambda s, v, c: s.view(2, 2, 1, 2, 2).mean(0))\n"
             "assert D.to_dlpack is not orig and D.to_dlpack._ptb_lazy_guard\n"
             "prev = pytorch_toolbelt_amd.set_strict_dropin(True)\n"
-            "assert prev == (True, True) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
-            "T.set_auto_plan(True); assert pytorch_toolbelt_amd.set_strict_dropin(True) == (False, True) and not T._AUTO_PLAN\n"
+            "assert prev == (True, True, False) and D.to_dlpack is orig and not L.enabled() and not T._AUTO_PLAN\n"
+            "T.set_auto_plan(True); assert pytorch_toolbelt_amd.set_strict_dropin(True) == (False, True, True) and not T._AUTO_PLAN\n"
             "assert T._REFERENCE_ACCUMULATORS and type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda', dtype=torch.float16)) is T.HostBackedTileMerger\n"
             "assert type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda')) is T.TileMerger\n"
-            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False) and L.enabled() and T._AUTO_PLAN\n"
+            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (False, False, True) and L.enabled() and T._AUTO_PLAN\n"
             "assert not T._REFERENCE_ACCUMULATORS and type(T.TileMerger.__new__(T.TileMerger, (8, 8), 1, None, 'cuda', dtype=torch.float16)) is T.TileMerger\n"
+            # flag=False restores what was in force BEFORE strict mode, not hard-coded defaults, and is a no-op without a preceding True
+            "T.set_auto_plan(False); T.set_reference_accumulators(True)\n"
+            "assert pytorch_toolbelt_amd.set_strict_dropin(False) == (True, False, True) and not T._AUTO_PLAN and T._REFERENCE_ACCUMULATORS\n"
+            "pytorch_toolbelt_amd.set_strict_dropin(True); pytorch_toolbelt_amd.set_strict_dropin(False)\n"
+            "assert L.enabled() and not T._AUTO_PLAN and T._REFERENCE_ACCUMULATORS\n"
             "print('OK')\n")
     import os
 
     env = dict(os.environ)
     env.pop("PTB_AUTO_PLAN", None)
     env.pop("PTB_LAZY_DEAUG", None)
+    env.pop("PTB_REFERENCE_ACCUMULATORS", None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
