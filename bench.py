@@ -420,7 +420,7 @@ def e2e_unet(dev):
     of 8 tiles x 8 views, ONE timed image per variant after a warm-up on the first two batches and the ragged last one (MIOpen picks its
     convolution algorithms per shape there; ~20 s per dtype on a fresh box, untimed).  Variants: the reference's literal calls on a new TileMerger per image (fp32); the planned +
     deferred merger (crops= known, defer=True; fp32); the same with the model under bf16 autocast, its bfloat16 outputs read natively
-    by the band kernel.  The model is ~99.9 % of the time: MP/s says what a user gets end to end, `merge_share` what the library
+    by the band kernel; the literal calls under bf16 autocast (lazy handle of a bfloat16 tensor, fused with PTB_ROUND_SRC).  The model is ~99.9 % of the time: MP/s says what a user gets end to end, `merge_share` what the library
     costs inside it, `peak_GB` what holding batches (defer) adds next to the UNet's activations."""
     import numpy as np_
 
@@ -456,7 +456,8 @@ def e2e_unet(dev):
     res = {"what": "wall clock per 5000x5000x3 uint8 image, host to host, through the plain-torch 4-level conv3x3-BN-ReLU UNet (3 -> 4 channels, "
                    "32/64/128/256 features, manual_seed(0), eval): 46 batches of 8 tiles x 8 d4 views; one timed image per variant"}
     with torch.no_grad():
-        for name, kind, dt in (("literal_fp32", "literal", None), ("deferred_fp32", "deferred", None), ("deferred_bf16_autocast", "deferred", torch.bfloat16)):
+        for name, kind, dt in (("literal_fp32", "literal", None), ("deferred_fp32", "deferred", None), ("deferred_bf16_autocast", "deferred", torch.bfloat16),
+                               ("literal_bf16_autocast", "literal", torch.bfloat16)):
             run(kind, dt, batches=2)                      # warm-up: MIOpen's algorithm search, allocator
             torch.cuda.synchronize()
             torch.cuda.reset_peak_memory_stats(dev)
@@ -1000,7 +1001,8 @@ def main():
 
         from pytorch_toolbelt_amd.inference import tiles as _tiles
 
-        def variant(make, literal=False, fresh=False, eager=False, self_plan=True):
+        def variant(make, literal=False, fresh=False, eager=False, self_plan=True, tensors=None):
+            tensors = batch_tensors if tensors is None else tensors
             prev = (_tta.set_lazy_deaugment(not eager), _tiles.set_auto_plan(self_plan))
             _tiles._auto.clear()
             m = make()            # (after the switches: a merger reads the self-planning setting when it is constructed)
@@ -1011,7 +1013,7 @@ def main():
                     m = make()    # the README loop: a new merger for every image
                 else:
                     m.reset()
-                for t, c in zip(batch_tensors, batch_crops):
+                for t, c in zip(tensors, batch_crops):
                     if literal:   # the reference's two calls
                         m.integrate_batch(_tta.d4_image_deaugment(t), c)
                     else:
@@ -1035,6 +1037,13 @@ def main():
         lit_new, lit_new_mode = variant(mk(), literal=True, fresh=True)
         lit_inc, lit_inc_mode = variant(mk(), literal=True, self_plan=False)
         frac = lambda ms: round(region_bytes_all / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)  # noqa: E731
+        # the model under torch.autocast: bfloat16 outputs (half the bytes in, the fp32 map out).  The literal calls hand the merger a lazy
+        # handle of a HALF tensor; the fused launch rounds the reduced value to bfloat16 in registers (PTB_ROUND_SRC), as the eager pair does
+        half_tensors = [t.to(torch.bfloat16) for t in batch_tensors]
+        half_bytes = VIEWS * n_tiles * CHANNELS * TILE * TILE * 2 + CHANNELS * 5120 * 5120 * 4      # 6 476 005 376 B
+        lit_bf16, lit_bf16_mode = variant(mk(), literal=True, fresh=True, tensors=half_tensors)
+        ext_bf16 = variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None), tensors=half_tensors)[0]
+        del half_tensors
         variants = {
             "deferred_bands_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=args.defer_rows or None))[0],
             "deferred_one_band_per_launch_ms": variant(mk(crops=slicer.crops, defer=True, defer_rows=256))[0],
@@ -1049,6 +1058,11 @@ def main():
             "dropin_literal_no_self_planning_ms": lit_inc,
             "dropin_literal_no_self_planning_mode": lit_inc_mode,
             "dropin_literal_eager_ms": variant(mk(), literal=True, eager=True, self_plan=False)[0],
+            "dropin_literal_bf16_ms": lit_bf16,
+            "dropin_literal_bf16_mode": lit_bf16_mode,
+            "dropin_literal_bf16_hbm_frac": round(half_bytes / (lit_bf16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "deferred_bands_bf16_ms": ext_bf16,
+            "deferred_bands_bf16_hbm_frac": round(half_bytes / (ext_bf16 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "note": "ms per 5000x5000 image, median of 3 runs of K steps; deferred_bands = TileMerger(crops=, defer=True) + "
                     "integrate_batch_deaugment (the headline); planned_no_defer = TileMerger(crops=) + integrate_batch_deaugment; "
                     "unplanned_fused = TileMerger(auto_plan=False) + integrate_batch_deaugment + merge(); dropin_literal = the reference's "
@@ -1058,7 +1072,9 @@ def main():
                     "image; _new_merger_per_image: a new TileMerger per image as in the README); _no_self_planning: tiles.set_auto_plan(False) "
                     "(round 4's default: lazy handle fused, accumulator in HBM, separate merge pass); dropin_literal_eager = "
                     "pytorch_toolbelt_amd.set_strict_dropin(): no lazy handles, no self-planning -- the reduced tile travels through HBM; "
-                    "_hbm_frac = the region's 12 532 580 352 algorithmic bytes / ms / 8 TB/s",
+                    "_hbm_frac = the region's 12 532 580 352 algorithmic bytes / ms / 8 TB/s; dropin_literal_bf16 = the literal calls (new merger per "
+                    "image) on bfloat16 model outputs (torch.autocast), deferred_bands_bf16 = the headline's explicit form on the same tensors: "
+                    "6 476 005 376 algorithmic bytes (half-precision views in, fp32 map out)",
         }
 
     if args.diag and rank == 0 and not use_dist:   # (extra steps on one rank only would leave the others' halo exchanges unmatched)

@@ -28,6 +28,7 @@ extern "C" {
 #define PTB_EUNSUPPORTED (-2) /* legal for the reference but not implemented natively (caller must raise) */
 #define PTB_ELAUNCH (-3)     /* HIP launch failed; see ptb_last_hip_error() */
 #define PTB_EBOUNDS (-4)     /* tile rectangle leaves the accumulator */
+#define PTB_EHELD (-6)       /* ptb_band_plan_submit_next: the batch lives in memory of a batch a later launch still reads */
 #define PTB_EFRESH (-5)      /* first-touch bitmap cannot be honoured for this batch: zero-fill the fresh blocks, then call
                                 again with fresh = NULL */
 
@@ -86,7 +87,11 @@ const char* ptb_last_hip_error(void);
  * 20 = Dice / Jaccard statistics (logits + labels, no ignore) and the default BinaryFocalLoss on label maps run as the statistics-only /
  * focal-only instances of the packed streaming kernel of the fused loss (0|1, default 1; 0: the lean kernels),
  * 21 = the band plan kernel requests the next covering tile before it finishes the current one (0: never, 1: half / bf16 model outputs,
- *      2: fp32 as well; default 2).
+ *      2: fp32 as well; default 2),
+ * 22 = (A/B, round 6) odd work items of the band plan kernel issue the loads of their views starting at view V / 2 instead of view 0
+ *      (registers, reduction order and bits unchanged; default 0),
+ * 23 = the last 8-bit level of the key-only Lovasz forward (ptb_lovasz_fwd_keys) evaluates the loss from every key's final rank and the
+ *      foreground count in front of it -- both from the scanned histograms -- instead of scattering the keys a fourth time (0|1, default 1).
  * Every setting computes the same values (key 19: bit for bit for segments of up to 2^24 elements -- above that the separate dot kernel's
  * (float)(i + 1) positions round and the two settings may differ in the last bits, the default being the reference's telescoping
  * difference); the keys exist for same-box A/B runs and for tests that compare two code paths bit for bit. */
@@ -218,12 +223,18 @@ int ptb_band_plan_state(const ptb_band_plan* plan, int* pos, int* launched);
 int ptb_band_plan_submit(ptb_band_plan* plan, int pos, int B, const void* batch, int64_t tile_stride, int64_t view_stride, int in_dtype,
                          int V, const int* views, int reduction, float* merged, const float* norm_full, const float* weight,
                          ptb_stream_t stream);
+/* ptb_band_plan_submit_next: the next B planned tiles of an image whose configuration the image's first ptb_band_plan_submit has set
+ * (same dtype / views / reduction / merged / norm / weight), `batch` = a contiguous [V * B, C, th, tw] model output -- one integrate_batch
+ * of the reference's loop (inference/tiles.py:321-339) as a four-argument host call.  The plan keeps the byte ranges of the batches a later
+ * launch group still reads: a batch overlapping one of them is refused with PTB_EHELD before anything is recorded.  Returns the launches
+ * issued (>= 0); PTB_EUNSUPPORTED without a configuration or past the plan's last tile; else ptb_band_plan_submit's codes. */
+int ptb_band_plan_submit_next(ptb_band_plan* plan, const void* batch, int B, ptb_stream_t stream);
 void ptb_band_plan_destroy(ptb_band_plan* plan);
 
 /* Multi-GPU (no reference counterpart; the single-device result of inference/tiles.py:321-346 is the specification).
  * ptb_band_plan_create2 = ptb_band_plan_create + `early`: n_early row ranges [lo, hi) of the plan's rows (ends among the cuts) that a
- * neighbouring rank waits for.  With them launch groups are formed by class: all early bands in one launch (issued as soon as the
- * tiles feeding them are in, however far apart the rows lie), the others in groups of ~rows_per_launch rows that do not break at the cuts.
+ * neighbouring rank waits for.  With them launch groups are formed by class: the bands of every early range in one launch of their own
+ * (issued as soon as the tiles feeding that range are in), the others in groups of ~rows_per_launch rows that do not break at the cuts.
  * ptb_band_plan_rows_launched: 1 when every group writing rows r0 .. r1-1 has been issued for the current image, else 0.
  * ptb_halo_pack: strided rectangle -> contiguous send buffer, dst[c][r][x] = src[c * chan_stride + r * row_stride + x].
  * ptb_band_plan_submit_rank: ptb_band_plan_submit, then packs every outgoing rectangle (rects: n_sends x {r0, r1, c0, c1}, the plan's

@@ -960,6 +960,32 @@ def gen_losses5():
     save("losses5.npz", A, cases)
 
 
+def gen_losses6():
+    """The fractional-gamma x ignore_index corner of the sigmoid focal loss on LABEL targets: BinaryFocalLoss
+    writes `ignore_index` into every channel of an ignored pixel (losses/focal.py:99-105), `(1 - pt).pow(gamma)` of the then negative base
+    is NaN for a non-integer gamma (losses/functional.py:70), `masked_fill` hides it in the VALUE (:90-94) and `0 * NaN` brings it back
+    in the GRADIENT of exactly the ignored pixels.  Values and autograd gradients of the unmodified reference, NaNs included."""
+    A, cases = {}, []
+    g = torch.Generator().manual_seed(606)
+    B, C, H, W = 2, 4, 12, 16
+    logits = torch.randn((B, C, H, W), generator=g) * 2
+    labels = torch.randint(0, C, (B, H, W), generator=g)
+    labels[torch.rand((B, H, W), generator=g) < 0.2] = 255
+    A["logits"], A["labels_ign"] = t2n(logits), t2n(labels)
+    opts = [dict(gamma=1.5, ignore_index=255), dict(gamma=0.5, ignore_index=255, alpha=0.3), dict(gamma=1.5, ignore_index=255, normalized=True),
+            dict(gamma=2.5, ignore_index=255, reduced_threshold=0.5), dict(gamma=1.5, ignore_index=255, reduction="sum"),
+            dict(gamma=2.0, ignore_index=255)]
+    for i, kw in enumerate(opts):
+        x = logits.clone().requires_grad_(True)
+        value = rl.BinaryFocalLoss(**kw)(x, labels)
+        value.backward()
+        name = f"binary_focal_frac_ign_{i}"
+        A[name], A[name + "_grad"] = t2n(value), t2n(x.grad)
+        cases.append(dict(name=name, fn="binary_focal_loss_grad", kwargs=kw, inputs=["logits", "labels_ign"], output=name,
+                          nan_grads=int(torch.isnan(x.grad).sum())))
+    save("losses6.npz", A, cases)
+
+
 def gen_volumes():
     from pytorch_toolbelt.inference import tiles_3d as rt3
 
@@ -1105,6 +1131,7 @@ if __name__ == "__main__":
     gen_losses3()
     gen_losses4()
     gen_losses5()
+    gen_losses6()
     gen_tta2()
     gen_tta3()
     gen_tta4()

@@ -24,6 +24,7 @@ DTYPE_CODES = {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}
 ROUND_SRC = 0x100           # PTB_ROUND_SRC, or-ed into a dtype code: round the reduced value to the (half) source type before blending
 
 EFRESH = -5
+PTB_EHELD = -6
 PTB_EUNSUPPORTED = -2
 _ERR = {-1: "invalid argument", -2: "unsupported configuration", -3: "HIP launch failed", -4: "tile rectangle outside the accumulator"}
 
@@ -63,6 +64,7 @@ SIGNATURES = {
     "ptb_band_plan_reset": (_c_int, [_vp]),
     "ptb_band_plan_state": (_c_int, [_vp, _ip, _ip]),
     "ptb_band_plan_submit": (_c_int, [_vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _c_int, _c_int, _ip, _c_int, _vp, _vp, _vp, _vp]),
+    "ptb_band_plan_submit_next": (_c_int, [_vp, _vp, _c_int, _vp]),
     "ptb_band_plan_destroy": (None, [_vp]),
     "ptb_rccl_available": (_c_int, []),
     "ptb_rccl_unique_id": (_c_int, [_vp]),

@@ -73,13 +73,18 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
     if (act && !partial) nfull = *reinterpret_cast<const float4*>(a.norm_full + pix);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nt = it->ntiles;
+    const bool rot = PF && a.rot_views && (item & 1u);      // (wave-uniform; A/B of the view issue order, ptb_set_tunable key 22)
     typename RawOf<LD>::type nxt[PF ? NV : 1];
     if constexpr (PF) {
         if (nt > 0) {
             const unsigned long long cv = it->cover[0];
             const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
-            gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H, a.W, lx,
-                                               ly, cw, ch, tid, nxt);
+            if (NV >= 2 && rot)
+                gather_load_raw<CH, NV, CODES, LD, NV / 2>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H,
+                                                           a.W, lx, ly, cw, ch, tid, nxt);
+            else
+                gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H, a.W, lx,
+                                                   ly, cw, ch, tid, nxt);
         }
     }
     for (int e = 0; e < nt; ++e) {
@@ -92,8 +97,12 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
             if (e + 1 < nt) {
                 const unsigned long long cn = it->cover[e + 1];
                 const int sn = (int)(cn & 0xffff), nlx = (int)((cn >> 16) & 0xffff), nly = (int)((cn >> 32) & 0xffff);
-                gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H, a.W,
-                                                   nlx, nly, cw, ch, tid, nxt);
+                if (NV >= 2 && rot)
+                    gather_load_raw<CH, NV, CODES, LD, NV / 2>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H,
+                                                               a.W, nlx, nly, cw, ch, tid, nxt);
+                else
+                    gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H, a.W,
+                                                       nlx, nly, cw, ch, tid, nxt);
             }
             val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, e + 1 < nt);
         } else {
@@ -190,7 +199,13 @@ struct ptb_band_plan {
     std::vector<const void*> src;
     std::vector<long long> vs;
     int cfg_set = 0, cfg_dtype = 0, cfg_V = 0, cfg_codes = 0, cfg_red = 0;
+    int cfg_views[ptb::MAX_VIEWS] = {0};
     const void *cfg_merged = nullptr, *cfg_norm = nullptr, *cfg_weight = nullptr;
+    // custody (round 6): the byte ranges of the batches of this image that a later launch group still reads, in integration order --
+    // what ptb_band_plan_submit_next checks a new batch against (a model writing into a reused output buffer)
+    struct Held { uintptr_t p0, p1; int last_group; };
+    std::vector<Held> held;
+    bool monotone = true;                 // groups complete in index order (row-major crops): custody is released from the front
 };
 
 using namespace ptb;
@@ -247,9 +262,9 @@ extern "C" int64_t ptb_band_plan_create(const int64_t* xs64, const int64_t* ys64
 }
 
 // `early` = n_early row ranges [lo, hi) (their ends must be among the cuts): the rows a neighbouring rank waits for.  With them the
-// launch groups are formed by CLASS instead of by position: all early bands together (one launch as soon as the tiles feeding them
-// are in -- the caller issues those first -- however far apart the rows lie), and the remaining bands in groups of ~rows_per_launch
-// rows that do not break at the cuts.  A rank of an 8-way sharded 5000 x 5000 image gets 2 launches instead of 6.
+// launch groups are formed by CLASS instead of by position: the bands of every early range together (one launch per range, as soon as
+// the tiles feeding it are in -- the caller issues those first), and the remaining bands in groups of ~rows_per_launch
+// rows that do not break at the cuts.  A rank of an 8-way sharded 5000 x 5000 image gets 2-3 launches instead of 6.
 extern "C" int64_t ptb_band_plan_create2(const int64_t* xs64, const int64_t* ys64, int n, int C, int th, int tw, int H, int W,
                                          int rows_per_launch, int final_lo, int final_hi, const int64_t* cuts, int ncuts,
                                          const int64_t* early, int n_early, ptb_band_plan** out) {
@@ -343,19 +358,25 @@ extern "C" int64_t ptb_band_plan_create3(const int64_t* xs64, const int64_t* ys6
     if (n_early > 0) {
         for (int k = 0; k < n_early; ++k)
             if (early[2 * k] % 4 || early[2 * k + 1] % 4) { delete p; return PTB_EUNSUPPORTED; }
-        auto is_early = [&](const Band& b) {
-            for (int k = 0; k < n_early; ++k) if (b.y0 >= early[2 * k] && b.y1 <= early[2 * k + 1]) return true;
-            return false;
+        // the early range a band lies in (-1: none).  Round 6: ONE launch group per early range instead of one for all of them -- a rank
+        // that ships rows to BOTH neighbours (the balanced cuts of parallel.band_plan) would otherwise hold the rows for the upper
+        // neighbour back until the tiles feeding the lower one are in, i.e. until its last tile.
+        auto early_of = [&](const Band& b) {
+            for (int k = 0; k < n_early; ++k) if (b.y0 >= early[2 * k] && b.y1 <= early[2 * k + 1]) return k;
+            return -1;
         };
         for (int cls = 0; cls < 2; ++cls) {             // early bands first: their group indices come first too
             std::vector<size_t> members;
             std::vector<int> tiles;
-            int rows = 0;
+            int rows = 0, range = -2;
             for (size_t b = 0; b < bands.size(); ++b) {
-                if ((is_early(bands[b]) ? 0 : 1) != cls) continue;
+                const int er = early_of(bands[b]);
+                if ((er >= 0 ? 0 : 1) != cls) continue;
                 std::vector<int> merged_tiles = with_band(tiles, b);
                 const int h = bands[b].y1 - bands[b].y0;
-                if (!members.empty() && ((int)merged_tiles.size() > PLAN_TILES || (cls == 1 && rows + h > target && !tiles.empty()))) {
+                const bool new_range = cls == 0 && range != -2 && er != range;
+                range = er;
+                if (!members.empty() && ((int)merged_tiles.size() > PLAN_TILES || new_range || (cls == 1 && rows + h > target && !tiles.empty()))) {
                     const int rc = emit_group(members, tiles);
                     if (rc != PTB_OK) { delete p; return rc; }
                     members.clear(); rows = 0;
@@ -398,6 +419,8 @@ extern "C" int64_t ptb_band_plan_create3(const int64_t* xs64, const int64_t* ys6
     p->src.assign(n, nullptr);
     p->vs.assign(n, 0);
     p->group_launched.assign(p->groups.size(), 0);
+    for (size_t gi = 0; gi + 1 < p->groups.size(); ++gi)
+        if (p->groups[gi].last_tile > p->groups[gi + 1].last_tile) p->monotone = false;
     *out = p;
     return (int64_t)(p->items.size() * sizeof(BandItem));
 }
@@ -427,6 +450,7 @@ extern "C" int ptb_band_plan_info(const ptb_band_plan* p, int* n_groups, int* n_
 extern "C" int ptb_band_plan_reset(ptb_band_plan* p) {
     if (!p) return PTB_EINVAL;
     p->pos = 0; p->launched = 0; p->cfg_set = 0;
+    p->held.clear();
     std::fill(p->group_launched.begin(), p->group_launched.end(), 0);
     return PTB_OK;
 }
@@ -469,7 +493,14 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
         (reinterpret_cast<uintptr_t>(batch) & mask) || !aligned16(merged) || !aligned16(norm_full) || !aligned16(weight))
         return PTB_EUNSUPPORTED;
     p->cfg_set = 1; p->cfg_dtype = dtype_arg; p->cfg_V = V; p->cfg_codes = codes; p->cfg_red = reduction;
+    for (int k = 0; k < V; ++k) p->cfg_views[k] = views[k];
     p->cfg_merged = merged; p->cfg_norm = norm_full; p->cfg_weight = weight;
+    {
+        int lg = 0;
+        for (int b = 0; b < B; ++b) lg = std::max(lg, p->last_group[pos + b]);
+        const uintptr_t p0 = reinterpret_cast<uintptr_t>(batch);
+        p->held.push_back({p0, p0 + (size_t)((long long)(V - 1) * view_stride + (long long)(B - 1) * tile_stride + per_tile) * esz, lg});
+    }
     for (int b = 0; b < B; ++b) {
         p->src[pos + b] = static_cast<const char*>(batch) + (size_t)b * (size_t)tile_stride * esz;
         p->vs[pos + b] = view_stride;
@@ -479,6 +510,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     a.weight = weight; a.merged = merged; a.norm_full = norm_full;
     a.in_dtype = in_dtype;
     a.round_src = (dtype_arg & PTB_ROUND_SRC) ? 1 : 0;
+    a.rot_views = g_band_rot_views;
     a.H = p->th; a.W = p->tw; a.C = p->C;
     a.dst_chan_stride = (long long)p->H * p->W;
     a.dst_row_stride = p->W;
@@ -506,7 +538,36 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
             ++launched;
         }
     }
+    if (launched || p->launched == (int)p->groups.size()) {
+        if (p->launched == (int)p->groups.size()) p->held.clear();
+        else if (p->monotone) {      // groups 0 .. launched-1 are out: batches no later group reads leave custody
+            size_t k = 0;
+            while (k < p->held.size() && p->held[k].last_group < p->launched) ++k;
+            p->held.erase(p->held.begin(), p->held.begin() + (long)k);
+        }
+    }
     return launched;
+}
+
+// The next planned batch of an image as the shortest possible host call (round 6: one integrate_batch of the reference's loop, inference/
+// tiles.py:321-339, costs the interpreter ~7 us through the 14-argument form above -- more than the kernels of the plain, TTA-free loop).
+// Everything but the batch itself is what the image's first ptb_band_plan_submit set: dtype (+ PTB_ROUND_SRC), views, reduction, merged /
+// norm / weight; `batch` is a contiguous [V * B, C, th, tw] model output for the next B planned tiles.  Custody is checked here: a batch
+// whose bytes overlap one that a later launch group still reads is refused with PTB_EHELD before anything is recorded (the model writes
+// into a reused output buffer: the earlier predictions are gone).  Returns the launches issued (>= 0), PTB_EUNSUPPORTED when the image
+// has no configuration yet / the tiles run out, or a negative code of ptb_band_plan_submit.
+extern "C" int ptb_band_plan_submit_next(ptb_band_plan* p, const void* batch, int B, ptb_stream_t stream) {
+    if (!p || !batch || B < 1) return PTB_EINVAL;
+    if (!p->cfg_set || p->pos + B > p->n) return PTB_EUNSUPPORTED;
+    const int dt = p->cfg_dtype & ~PTB_ROUND_SRC;
+    const size_t esz = dt == PTB_F32 ? 4 : 2;
+    const long long per_tile = (long long)p->C * p->th * p->tw;
+    const uintptr_t p0 = reinterpret_cast<uintptr_t>(batch), p1 = p0 + (size_t)((long long)p->cfg_V * B * per_tile) * esz;
+    for (const ptb_band_plan::Held& h : p->held)
+        if (h.p0 < p1 && p0 < h.p1) return PTB_EHELD;
+    return ptb_band_plan_submit(p, p->pos, B, batch, per_tile, (long long)B * per_tile, p->cfg_dtype, p->cfg_V, p->cfg_views, p->cfg_red,
+                                static_cast<float*>(const_cast<void*>(p->cfg_merged)), static_cast<const float*>(p->cfg_norm),
+                                static_cast<const float*>(p->cfg_weight), stream);
 }
 
 // 1 when every launch group that writes rows r0 .. r1-1 of the merged map has been issued for the current image (a band the rows
@@ -582,6 +643,7 @@ extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const
     return rc;
 }
 
+int ptb::g_band_rot_views = 0;     // ptb_set_tunable key 22 (A/B): odd work items of the band plan kernel issue their view loads starting at view NV / 2
 int ptb::g_band_half_pf = 2;       // ptb_set_tunable key 21: the band plan kernel requests covering tile e + 1 before it finishes tile e -- 0: never (round 4's
                                    // instances), 1: for half / bf16 sources, 2: for fp32 sources as well
 int ptb::g_rank_finish_fused = 1;   // ptb_set_tunable key 18: 0 = ptb_rect_add + ptb_merge_div_ex launches (A/B, bit-identity test)

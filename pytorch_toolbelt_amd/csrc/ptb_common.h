@@ -51,6 +51,7 @@ extern int g_ms_tiled;       // 0 | 1: LDS-staged multiscale kernel
 extern int g_ms_tile_w;      // 64 | 128: output tile width of the fused multiscale kernel
 extern int g_rank_finish_fused;  // 0 | 1: one-launch finish of a rank's image (ShardedTileMerger, deferred bands)
 extern int g_rs_xcd_map;     // 0 | 1: XCD-contiguous tile order in the Lovasz radix scatter
+extern int g_lovasz_rankdot;     // 0 | 1: last level of the key-only Lovasz forward without a scatter
 extern int g_lovasz_fused_dot;   // 0 | 1: the binning scatter of the Lovasz training path also evaluates the loss
 extern int g_nt_grad_stores; // 0 | 1: non-temporal gradient stores in the fused loss backward
 extern int g_stats_pk;       // 0 | 1: statistics-only / focal-only instances of the packed streaming loss kernel
@@ -61,6 +62,7 @@ extern int g_loss_prefetch;   // 0 | 1: the fused loss forward fetches the next 
 extern int g_smf_bwd_stash;  // 0 | 2 | 4: softmax focal backward with the per-class terms kept in registers, pixels per lane
 extern int g_band_rows;     // 32 | 64: rows per work item of band plans created from now on (A/B)
 extern int g_band_half_pf;  // 0 | 1 | 2: the band plan kernel prefetches the next covering tile (1: half / bf16 sources only, 2: fp32 too)
+extern int g_band_rot_views;  // 0 | 1: odd work items of the band plan kernel issue their view loads starting at view NV / 2 (A/B)
 extern int g_band_xcd;      // 0 | 1: XCD-aware workgroup order in the band plan kernel (A/B)
 extern int g_ms_strip;       // 0 | 1..64: XCD-aware tile order of the fused multiscale kernel, strip width in tile columns
 extern int g_ms_tile_rows;   // 64 | 32: output tile height of the fused multiscale kernel

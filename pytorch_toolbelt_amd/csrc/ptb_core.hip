@@ -255,6 +255,14 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_band_half_pf = value < 0 ? 0 : (value > 2 ? 2 : value);
         return PTB_OK;
     }
+    if (key == 22) {
+        g_band_rot_views = value ? 1 : 0;
+        return PTB_OK;
+    }
+    if (key == 23) {
+        g_lovasz_rankdot = value ? 1 : 0;
+        return PTB_OK;
+    }
     if (key == 13) {
         if (value < 1) return PTB_EINVAL;
         g_focal_pk_grid = value;

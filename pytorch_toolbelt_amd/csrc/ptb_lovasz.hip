@@ -90,20 +90,27 @@ __device__ __forceinline__ unsigned tile_of_block(int xcd_map) {
 #define PTB_RS_HIST_COPIES 4
 #endif
 constexpr int RS_HIST_COPIES = PTB_RS_HIST_COPIES;   // wave-private counter copies (power of two)
-template <bool COUNT, bool HIST = true, bool INV = false>
+// FGH (the LAST level of the key-only forward, lovasz_rankdot_kernel): next to the digit histogram a second one of the same shape that
+// counts only the foreground keys of every digit -> hist_fg (keys are ~kappa: fg = ~key & 1).
+template <bool COUNT, bool HIST = true, bool INV = false, bool FGH = false>
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, long long P, int T, int shift, unsigned* __restrict__ hist,
-                                                      unsigned* __restrict__ chunk_count, int chunks_per_seg) {
+                                                      unsigned* __restrict__ chunk_count, int chunks_per_seg, unsigned* __restrict__ hist_fg = nullptr) {
     static_assert(RS_TILE == 2 * CHUNK && RS_WAVE_SPAN * 2 == CHUNK, "a tile is two chunks, a chunk two waves");
     // counts only, no order: LDS atomics (ds_add_u32 without return).  Four copies per wave (lane & 3) keep the same-address
     // serialisation short when the digit is nearly constant (the exponent byte of probabilities); a wave whose 64 keys share
     // one digit adds 64 from a single lane.
     __shared__ unsigned h[4][RS_HIST_COPIES][256];
+    __shared__ unsigned hf[FGH ? 4 : 1][FGH ? 2 : 1][FGH ? 256 : 1];
     const int seg = blockIdx.x / T, tile = blockIdx.x % T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w)
 #pragma unroll
         for (int c = 0; c < RS_HIST_COPIES; ++c) h[w][c][threadIdx.x] = 0;
+    if constexpr (FGH) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { hf[w][0][threadIdx.x] = 0; hf[w][1][threadIdx.x] = 0; }
+    }
     __syncthreads();
     const long long t0 = (long long)tile * RS_TILE;
     const unsigned* kp = keys + (long long)seg * P + t0;
@@ -135,8 +142,15 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
             const bool full = vec || wave * RS_WAVE_SPAN + j * 64 + 63 < left;      // (wave-uniform)
             if (full && __all(d == d0)) {
                 if (lane == 0) atomicAdd(&h[wave][0][d0], 64u);
+                if constexpr (FGH) {
+                    const unsigned nfg = (unsigned)__popcll(__ballot((~k[j] & 1u) != 0u));
+                    if (lane == 0 && nfg) atomicAdd(&hf[wave][0][d0], nfg);
+                }
             } else if (valid) {
                 atomicAdd(&h[wave][lane & (RS_HIST_COPIES - 1)][d], 1u);
+                if constexpr (FGH) {
+                    if (~k[j] & 1u) atomicAdd(&hf[wave][lane & 1][d], 1u);
+                }
             }
         }
     }
@@ -155,6 +169,12 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict
 #pragma unroll
         for (int c = 0; c < RS_HIST_COPIES; ++c) tot += h[w][c][threadIdx.x];
     if constexpr (HIST) hist[((long long)seg * T + tile) * 256 + threadIdx.x] = tot;
+    if constexpr (FGH) {
+        unsigned tf = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tf += hf[w][0][threadIdx.x] + hf[w][1][threadIdx.x];
+        hist_fg[((long long)seg * T + tile) * 256 + threadIdx.x] = tf;
+    }
     if constexpr (COUNT) {
         if (threadIdx.x < 2 && tile * 2 + (int)threadIdx.x < chunks_per_seg)
             chunk_count[(long long)seg * chunks_per_seg + tile * 2 + threadIdx.x] = wfg[2 * threadIdx.x] + wfg[2 * threadIdx.x + 1];
@@ -279,6 +299,12 @@ __device__ __forceinline__ void tilescan_block(unsigned block, unsigned* __restr
 }
 __global__ __launch_bounds__(256) void rs_tilescan_kernel(unsigned* __restrict__ hist, int T, int spans, unsigned* __restrict__ span_tot) {
     tilescan_block(blockIdx.x, hist, T, spans, span_tot);
+}
+// the digit histogram and the foreground histogram of the last level (same shape) in one launch: blocks n .. 2n-1 take the second pair
+__global__ __launch_bounds__(256) void rs_tilescan2_kernel(unsigned* __restrict__ hist, unsigned* __restrict__ hist_fg, int T, int spans,
+                                                           unsigned* __restrict__ span_tot, unsigned* __restrict__ span_tot_fg, unsigned n) {
+    if (blockIdx.x < n) tilescan_block(blockIdx.x, hist, T, spans, span_tot);
+    else tilescan_block(blockIdx.x - n, hist_fg, T, spans, span_tot_fg);
 }
 
 __device__ __forceinline__ float jaccard_at(float G, float k1, float cum) {  // lovasz.py:29-31 at sorted position k (k1 = k+1)
@@ -514,6 +540,135 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         const long long pos = base + digit_base[(kk >> shift) & 255u] + i;
         keys_out[pos] = kk;
         if constexpr (!KEYONLY) vals_out[pos] = sval[i];
+    }
+}
+
+// The LAST level of the key-only forward without a scatter (round 6).  After three passes a segment is ordered by the low 24 bits of its
+// keys; the fourth pass would only move every key to its final position -- and all the loss needs from that position is the position
+// itself, k, and the number of foreground keys in front of it: sum_k relu(e_k) * (J_k - J_{k-1}) with J from (k, cum fg)
+// (lovasz.py:29-33, :71 / :139).  Both follow from the scanned histograms exactly as the scatter computes its destinations -- k = (keys
+// of the segment with a smaller top digit) + (same digit, earlier tiles) + (same digit, earlier in this tile: the ballot-matched stable
+// rank) -- and the same three terms counted over foreground keys only (hist_fg).  So the keys are read once more and NOT written: no
+// fourth scatter's stores (67 MB at [4,16,512,512]), no foreground count over the sorted order, no chunk scan, no dot kernel re-reading
+// them (another 2 x 67 MB and three launches).  One partial sum per tile, added per segment in tile order by lovasz_segsum_kernel.
+// G (the segment's foreground total) = the sum of the foreground histogram; fg_total[seg] is written by tile 0 for the class reduction.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void lovasz_rankdot_kernel(const unsigned* __restrict__ keys_in, long long P, int T, int shift,
+                                                                const unsigned* __restrict__ hist, const unsigned* __restrict__ hist_fg, int spans,
+                                                                const unsigned* __restrict__ span_tot, const unsigned* __restrict__ span_tot_fg,
+                                                                int xcd_map, unsigned* __restrict__ fg_total, double* __restrict__ tile_partial) {
+    constexpr int ITEMS = RS_TILE / (NW * 64), SPAN = 64 * ITEMS;
+    static_assert(NW * 64 == 256, "thread = digit");
+    __shared__ unsigned wave_hist[NW][256], wave_fg[NW][256];   // per wave: running (all / foreground) counts per digit, then the wave's start inside the tile's digit run
+    __shared__ unsigned base_all[256], base_fg[256];            // position / foreground count in front of the tile's first key of digit d
+    __shared__ unsigned wave_tot[4];
+    __shared__ double wacc[NW];
+    const unsigned lin = tile_of_block(xcd_map & 1);
+    const int seg = lin / T, tile = lin % T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long t0 = (long long)tile * RS_TILE;
+    const long long base = (long long)seg * P;
+    const long long left = P - t0;
+    const int count = left < RS_TILE ? (int)left : RS_TILE;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { wave_hist[w][threadIdx.x] = 0; wave_fg[w][threadIdx.x] = 0; }
+    // thread = digit: this digit's keys (all / foreground) in earlier spans, in the whole segment, and in earlier tiles of this span
+    unsigned rs = 0, before = 0, rs_f = 0, before_f = 0;
+    {
+        const int my_span = tile / RS_SPAN;
+        for (int sp = 0; sp < spans; ++sp) {
+            const unsigned c = span_tot[((long long)seg * spans + sp) * 256 + threadIdx.x];
+            const unsigned f = span_tot_fg[((long long)seg * spans + sp) * 256 + threadIdx.x];
+            before += sp < my_span ? c : 0u; rs += c;
+            before_f += sp < my_span ? f : 0u; rs_f += f;
+        }
+    }
+    const unsigned tile_before = hist[((long long)seg * T + tile) * 256 + threadIdx.x];
+    const unsigned tile_before_f = hist_fg[((long long)seg * T + tile) * 256 + threadIdx.x];
+    unsigned k[ITEMS], rank[ITEMS];      // rank: position among the wave's keys of the digit | the same over foreground keys << 16 (both < 4096)
+    if (count == RS_TILE) {
+        const unsigned* kp = keys_in + base + t0 + wave * SPAN + lane;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) k[j] = kp[j * 64];
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const int idx = wave * SPAN + j * 64 + lane;
+            k[j] = idx < count ? keys_in[base + t0 + idx] : 0xFFFFFFFFu;      // (padding: kappa = 0 -- error 0, background, ranks behind every real key of the tile)
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned d = (k[j] >> shift) & 255u;
+        // lanes of the wave with my digit: mask halves as in match_digit, kept here because the foreground rank needs them as well
+        unsigned m_lo = 0xFFFFFFFFu, m_hi = 0xFFFFFFFFu;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int sb = __builtin_amdgcn_sbfe((int)k[j], (unsigned)(shift + b), 1u);
+            const unsigned long long bal = __ballot(sb < 0);
+            m_lo = __builtin_amdgcn_bitop3_b32(m_lo, (unsigned)bal, (unsigned)sb, 0x90);
+            m_hi = __builtin_amdgcn_bitop3_b32(m_hi, (unsigned)(bal >> 32), (unsigned)sb, 0x90);
+        }
+        const unsigned long long fgb = __ballot((~k[j] & 1u) != 0u);
+        const unsigned f_lo = m_lo & (unsigned)fgb, f_hi = m_hi & (unsigned)(fgb >> 32);
+        const unsigned below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const unsigned below_f = __builtin_amdgcn_mbcnt_hi(f_hi, __builtin_amdgcn_mbcnt_lo(f_lo, 0u));
+        const unsigned group = __popc(m_lo) + __popc(m_hi), group_f = __popc(f_lo) + __popc(f_hi);
+        const unsigned old = wave_hist[wave][d], old_f = wave_fg[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (below == 0) { wave_hist[wave][d] = old + group; wave_fg[wave][d] = old_f + group_f; }
+        __builtin_amdgcn_wave_barrier();
+        rank[j] = (old + below) | ((old_f + below_f) << 16);
+    }
+    __syncthreads();
+    unsigned tot = 0, tot_f = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const unsigned c = wave_hist[w][threadIdx.x], f = wave_fg[w][threadIdx.x];
+        wave_hist[w][threadIdx.x] = tot; wave_fg[w][threadIdx.x] = tot_f;
+        tot += c; tot_f += f;
+    }
+    const unsigned incl = block_inclusive_scan_n<NW>(rs, wave_tot);        // keys of the segment with a digit <= mine
+    const unsigned incl_f = block_inclusive_scan_n<NW>(rs_f, wave_tot);
+    base_all[threadIdx.x] = incl - rs + before + tile_before;
+    base_fg[threadIdx.x] = incl_f - rs_f + before_f + tile_before_f;
+    __shared__ unsigned g_total;
+    if (threadIdx.x == 255) g_total = incl_f;                              // the segment's foreground count
+    __syncthreads();
+    const float G = (float)g_total;
+    if (tile == 0 && threadIdx.x == 0) fg_total[seg] = g_total;
+    double acc = 0.0;
+#pragma unroll 4
+    for (int j = 0; j < ITEMS; ++j) {
+        const int idx = wave * SPAN + j * 64 + lane;
+        if (idx < count) {
+            const unsigned d = (k[j] >> shift) & 255u;
+            const unsigned kap = ~k[j];
+            const unsigned fg = kap & 1u;
+            const float e = __uint_as_float(kap >> 1);                     // kappa key: never negative; NaN stays NaN and poisons the sum like the reference's
+            const unsigned pos = base_all[d] + wave_hist[wave][d] + (rank[j] & 0xffffu);   // final 0-based position in the segment's sorted order
+            const unsigned cum = base_fg[d] + wave_fg[wave][d] + (rank[j] >> 16);          // foreground keys in front of it
+            // J_k and J_{k-1} (lovasz.py:29-33) with v_rcp_f32 instead of two IEEE divisions per key: both are functions of (G, k, cum)
+            // alone, so a key's J_k IS its successor's J_{k-1} bit for bit and the sum telescopes exactly as with the divisions; the
+            // 1-ulp reciprocal moves every J by <= 1.2e-7, i.e. the loss by <= 1.2e-7 x the total variation of the sorted errors (<= max e)
+            const float cf = (float)cum, pf = (float)pos;
+            const float ik = G - (cf + (float)fg), uk = G + ((pf + 1.0f) - (cf + (float)fg));
+            const float ip = G - cf, up = G + (pf - cf);
+            const float jk = 1.0f - ik * __builtin_amdgcn_rcpf(uk);
+            const float jp = pos == 0u ? 0.0f : 1.0f - ip * __builtin_amdgcn_rcpf(up);
+            acc += (double)(e * (jk - jp));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) wacc[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += wacc[w];
+        tile_partial[(long long)seg * T + tile] = t;
     }
 }
 
@@ -875,6 +1030,7 @@ static int fill(LovArgs& a, const float* pred, const int64_t* labels, const floa
 }
 
 int g_rs_xcd_map = 1;   // ptb_set_tunable key 17: XCD-contiguous tile order in the radix scatter
+int g_lovasz_rankdot = 1;   // ptb_set_tunable key 23: the last level of the key-only Lovasz forward evaluates the loss from ranks instead of scattering (0: four scatters + count + dot)
 int g_lovasz_fused_dot = 1;   // ptb_set_tunable key 19: the binning scatter of the training path also evaluates the loss (0: lovasz_dot_kernel)
 static void launch_scatter(unsigned tiles, hipStream_t s, const unsigned* kin, const unsigned* vin, unsigned* kout, unsigned* vout, long long P, int T,
                            int shift, const unsigned* hist, int spans, const unsigned* span_tot, bool iota = false) {
@@ -905,7 +1061,8 @@ extern "C" int64_t ptb_lovasz_temp_bytes(int64_t per_segment, int segments) {
     const int64_t tiles = (per_segment + RS_TILE - 1) / RS_TILE;
     const int64_t spans = (tiles + RS_SPAN - 1) / RS_SPAN;
     const int64_t chunks = (per_segment + CHUNK - 1) / CHUNK;
-    return ((int64_t)segments * 256 * tiles + (int64_t)segments * 256 * spans) * (int64_t)sizeof(unsigned) + (int64_t)segments * chunks * (int64_t)sizeof(double);
+    // (round 6: twice the histogram space -- the last level of the key-only forward keeps a foreground histogram of the same shape)
+    return 2 * ((int64_t)segments * 256 * tiles + (int64_t)segments * 256 * spans) * (int64_t)sizeof(unsigned) + (int64_t)segments * chunks * (int64_t)sizeof(double);
 }
 
 // Workspaces (all device, provided by the caller, n = P*S elements): keys_a, keys_b u32[n]; vals_a, vals_b u32[n];
@@ -1048,13 +1205,26 @@ extern "C" int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, con
         if (int rc = check_launch()) return rc;
     }
     unsigned *kin = keys_a, *kout = keys_b;
-    for (int shift = 0; shift < 32; shift += 8) {
+    const int scatter_passes = g_lovasz_rankdot ? 3 : 4;
+    for (int pass = 0; pass < scatter_passes; ++pass) {
+        const int shift = 8 * pass;
         if (shift) hipLaunchKernelGGL(rs_hist_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist, (unsigned*)nullptr, 0);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
         hipLaunchKernelGGL((rs_scatter_kernel<4, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr, a.P, T,
                            shift, hist, spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
+    }
+    if (g_lovasz_rankdot) {
+        // the last level: positions and foreground counts from the histograms, no scatter (lovasz_rankdot_kernel)
+        unsigned* hist_fg = reinterpret_cast<unsigned*>(partial + total_chunks);
+        unsigned* span_tot_fg = hist_fg + (long long)a.S * 256 * T;
+        hipLaunchKernelGGL((rs_hist_kernel<false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, 24, hist, (unsigned*)nullptr, 0, hist_fg);
+        hipLaunchKernelGGL(rs_tilescan2_kernel, dim3(2 * a.S * spans), dim3(256), 0, s, hist, hist_fg, T, spans, span_tot, span_tot_fg, (unsigned)(a.S * spans));
+        hipLaunchKernelGGL(lovasz_rankdot_kernel<4>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, 24, hist, hist_fg, spans, span_tot, span_tot_fg,
+                           g_rs_xcd_map, fg_total, partial);
+        hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, T, seg_loss);
+        return check_launch();
     }
     hipLaunchKernelGGL((rs_hist_kernel<true, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, 0, hist, chunk, cps);
     hipLaunchKernelGGL(lovasz_chunk_scan_kernel, dim3(a.S), dim3(256), 0, s, chunk, cps, fg_total);

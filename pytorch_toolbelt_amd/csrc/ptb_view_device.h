@@ -63,6 +63,7 @@ struct ViewArgs {
     int in_dtype;        // element type of src: PTB_F32 | PTB_F16 | PTB_BF16 (reduce / accumulate kernels)
     int keep_acc;        // planned accumulate: a finalised cell ALSO stores its weighted sum in the accumulator (PTB_PLANNED_KEEP_SUMS)
     int round_src;       // PTB_ROUND_SRC: the reduced value is rounded to the (half / bf16) source type before it is blended
+    int rot_views;       // band plan kernel (A/B, ptb_set_tunable key 22): odd work items issue their view loads starting at view NV / 2
 };
 
 enum { MODE_REDUCE = 0, MODE_PERVIEW = 1, MODE_ACCUM = 2 };
@@ -218,16 +219,14 @@ __device__ __forceinline__ float4 widen4(const typename RawOf<LD>::type r) {
 
 // PTB_ROUND_SRC: what `tta.*_image_deaugment(half tensor)` hands to `integrate_batch` is a HALF tensor -- the reduced value rounded to
 // the source type (round to nearest even, torch's `.to(dtype)`), which integrate_batch then widens exactly (tiles.py:334-335).  The
-// fused launch of a lazy de-augmentation handle reproduces that rounding in registers: one v_cvt pair (fp16) / four integer
-// operations (bf16) per value, nothing for fp32 sources.
+// fused launch of a lazy de-augmentation handle reproduces that rounding in registers: one conversion there and back per value
+// (v_cvt_f16_f32 / gfx950's v_cvt_pk_bf16_f32), nothing for fp32 sources.
 template <int LD>
 __device__ __forceinline__ float round_src1(float x) {
     if constexpr (LD == 2) {
         return (float)(_Float16)x;
     } else if constexpr (LD == 3) {
-        const unsigned u = __float_as_uint(x);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return __uint_as_float(0x7fc00000u);      // (torch's bf16 conversion: every NaN becomes the quiet NaN 0x7FC0)
-        return __uint_as_float((u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u);
+        return (float)(__bf16)x;      // gfx950's v_cvt_pk_bf16_f32: round to nearest even like torch's conversion (a NaN stays a NaN)
     } else {
         return x;
     }
@@ -414,7 +413,9 @@ __device__ __forceinline__ float4 gather_reduce(const float* __restrict__ src, l
 // gather_reduce in two steps: the loads of one covering tile as raw values (8 bytes per view for half / bf16 -- 16 registers for the
 // eight d4 views -- 16 bytes for fp32), held while the PREVIOUS tile is still being transposed, reduced and blended, and their
 // widening into gather_tail's input.  band_plan_kernel<.., PF> requests tile e + 1 before it finishes tile e.
-template <int CH, int NV, int CODES, int LD>
+// ROT: the loads are ISSUED starting at view ROT (then ROT + 1, ..., wrapping) -- which register receives which view, and so every bit of
+// the result, is unchanged; an A/B on whether workgroups that all walk the views in one order collide in DRAM (ptb_set_tunable key 22).
+template <int CH, int NV, int CODES, int LD, int ROT = 0>
 __device__ __forceinline__ void gather_load_raw(const float* __restrict__ src, long long plane, long long view_stride, int nv_rt, int codes_rt, int H,
                                                 int W, int lx, int ly, int cw, int ch, int tid, typename RawOf<LD>::type (&raw)[NV]) {
     constexpr int QPR = CH / 4;
@@ -425,7 +426,8 @@ __device__ __forceinline__ void gather_load_raw(const float* __restrict__ src, l
     const int nv = CODES >= 0 ? NV : nv_rt;
     const int codes = CODES >= 0 ? CODES : codes_rt;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
+    for (int kk = 0; kk < NV; ++kk) {
+        const int k = (kk + ROT) % NV;
         raw[k] = typename RawOf<LD>::type{};
         if (k < nv) {
             const int code = (codes >> (3 * k)) & 7;

@@ -26,6 +26,9 @@ import torch
 
 from .. import _native as N
 
+_current_device = torch._C._cuda_getDevice if hasattr(torch._C, "_cuda_getDevice") else torch.cuda.current_device
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+
 FRESH_ROWS = 32  # rows of a first-touch block = default chunk rows of the view kernels (64 columns wide)
 LAZY_SRC = 0x10000  # host-only bit of a batch's `how` flags (next to N.ROUND_SRC): the batch is the source of a lazy de-augmentation handle --
                     # handed out only where a change of it would be noticed (version counter) or nobody else can reach it (inference/_lazy.py)
@@ -332,6 +335,7 @@ class DeferredBands(_OfMerger):
         self.done = 0                    # launch groups issued for this image
         self.active = False
         self.budget_checked = False
+        self.slim = None                 # the image's configuration once its first batch went through take_fast (see take_slim)
         self.rebind(bands, soft)
         self.reset()
 
@@ -347,6 +351,7 @@ class DeferredBands(_OfMerger):
         self.held.clear()
         self.done = 0
         self.budget_checked = False
+        self.slim = None
         if self.bands is not None:
             N.load().ptb_band_plan_reset(self.bands.handle)
 
@@ -367,6 +372,7 @@ class DeferredBands(_OfMerger):
         m = self.m
         held = self.held.take_all()
         self.active = False
+        self.slim = None
         m._plan.restart()
         m._plan.active = keep_plan and m._plan.blocks      # (a band-only plan has no block strategy to hand the image to)
         m._merged = None                                   # (nothing was launched into it; the planned strategy makes its own)
@@ -390,6 +396,7 @@ class DeferredBands(_OfMerger):
         launched = [(y0, y1) for (y0, y1, _last) in bands.bands if y1 > y0 and lib.ptb_band_plan_rows_launched(bands.handle, y0, y1) == 1]
         held = self.held.take_all()
         self.active = False
+        self.slim = None
         merged, m._merged = m._merged, None
         plan = m._plan
         plan.restart()
@@ -456,10 +463,70 @@ class DeferredBands(_OfMerger):
                 self.held.release_before(done)
         return rc
 
+    def take_slim(self, batch, crop_coords, key, rnd):
+        """Every batch of an image after its first one, in ~4 us of host time (round 6; the 14-argument ``ptb_band_plan_submit`` path costs
+        ~7 us a call -- 0.33 ms per 5000 x 5000 image, more than the kernels of the TTA-free loop take): the image's configuration
+        (dtype, views, reduction, buffers) sits in the C plan since its first submit, custody overlap is checked there
+        (``ptb_band_plan_submit_next``), and what is left here is the contract of the call itself -- the next planned crops, a contiguous
+        batch of the image's dtype / shape on the merger's device, held batches unmodified when a launch is due.  None: not that call
+        (the ordinary fast path decides)."""
+        s = self.slim
+        if (key != s[0] or rnd != s[1] or type(crop_coords) is not np.ndarray or crop_coords.dtype.char != "l" or batch.dtype is not s[2]
+                or not batch.is_contiguous() or batch.requires_grad or not self.active):
+            return None
+        m = self._m()
+        plan = m._plan
+        B, pos = crop_coords.shape[0], plan.pos
+        shape = batch.shape
+        if (B == 0 or shape[0] != B * s[4] or shape[1:] != s[3] or m._eager_norm or not plan.active or batch.get_device() != s[5]
+                or _current_device() != s[5] or not plan.next_are(crop_coords, B)):
+            return None
+        bands, held = self.bands, self.held
+        try:
+            version = batch._version
+        except RuntimeError:
+            version = None
+            if self.soft and not (rnd & LAZY_SRC):
+                return None                      # (a version-less batch nobody vouches for: _submit leaves deferred mode)
+        end = pos + B
+        if not bands.monotone or (self.done < len(bands.bands) and end > bands.bands[self.done][2]):
+            # a launch is due: it reads the held batches (and the window) -- they must be what they were when they were handed in
+            if m._window_edited():
+                return None
+            for i, h in enumerate(held.rows):
+                if h[-1] is not None and tensor_version(h[0]) != h[-1]:
+                    check_held(held.rows, batch, (0, 0, None), True, held.what, held.hint)
+        p0 = batch.data_ptr()
+        rc = s[6](bands.handle, p0, B, _raw_stream(s[5]))
+        N.calls += 1
+        if rc < 0:
+            if rc == N.PTB_EHELD:
+                check_held(held.rows, batch, (p0, p0 + B * s[7], version), False, held.what, held.hint)      # (raises, naming the overlap)
+            if rc == N.PTB_EUNSUPPORTED:
+                return None
+            N.check(rc, "TileMerger.integrate_batch (deferred bands)")
+        lg = bands.last_group
+        held.rows.append((batch, (crop_coords, s[8], s[9], rnd & N.ROUND_SRC), int(lg[end - 1]) if bands.sorted_tiles else int(lg[pos:end].max()),
+                          p0, p0 + B * s[7], version))
+        plan.pos = end
+        if rc:
+            done = self.done = self.done + rc
+            if done == len(bands.bands):
+                held.rows = []
+            elif bands.monotone:
+                held.release_before(done)
+        m.fast_submits += 1
+        m._log.append(plan.xy[:, pos:end])
+        return True
+
     def take_fast(self, batch, crop_coords, key, views, code, rnd=0):
         """The common call (see ``_fast_call``) for exactly the next planned crops: everything constant per merger / per
-        (group, reduction) is cached, the rest is one C call: ~10 us of host time instead of ~20.  False: ``take`` decides (and
-        reports)."""
+        (group, reduction) is cached, the rest is one C call: ~7 us of host time instead of ~20 -- and ~4 us from the image's second batch
+        on (``take_slim``).  False: ``take`` decides (and reports)."""
+        if self.slim is not None:
+            taken = self.take_slim(batch, crop_coords, key, rnd)
+            if taken is not None:
+                return taken
         m = self.m
         plan = m._plan
         if not (self.active and plan.active and _fast_call(m, batch, crop_coords)):
@@ -480,6 +547,12 @@ class DeferredBands(_OfMerger):
             N.check(rc, "TileMerger.integrate_batch (deferred bands)")
         m.fast_submits += 1
         m._log.append(plan.xy[:, pos:pos + B])      # (the planned origins themselves: a view, no copy -- they were just compared equal)
+        if self.active and self.slim is None and self.bands is not None:
+            dev = m._image.device
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            th, tw = int(m.weight.shape[1]), int(m.weight.shape[2])
+            self.slim = (key, rnd, batch.dtype, torch.Size((m.channels, th, tw)), n_views, idx, N.load().ptb_band_plan_submit_next,
+                         n_views * m.channels * th * tw * batch.element_size(), views, code)
         return True
 
     def take(self, batch, coords, xy, views, reduction, dcode):

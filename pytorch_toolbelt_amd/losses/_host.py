@@ -43,10 +43,18 @@ def binary_focal(output, target, prob, gamma, alpha, reduction, normalized, redu
     (sigmoid of the logits, or their softmax along some dim); the BCE term always comes from the logits."""
     x, t = output.float(), target.float()
     p_true = prob * t + (1 - prob) * (1 - t)
+    base = 1.0 - p_true
+    if ignore_index is not None:
+        # Deviation (DESIGN section 4; tests/golden/losses6.npz): an ignored entry carries t = ignore_index, its base 1 - pt is negative
+        # for about half of the logits, and a non-integer power of it is NaN -- the reference's masked_fill hides that in the VALUE,
+        # but `0 * NaN` puts NaN into the GRADIENT of exactly the ignored entries (losses/functional.py:70, 90-94).  Here, as in the HIP
+        # kernels, an ignored entry contributes a gradient of 0: its base is replaced before the power (the value is masked below
+        # either way, so every finite number of the reference is unchanged).
+        base = base.masked_fill(t == ignore_index, 1.0)
     if reduced_threshold is None:
-        modulator = (1.0 - p_true) ** gamma
+        modulator = base ** gamma
     else:
-        modulator = ((1.0 - p_true) / (1 - reduced_threshold)) ** gamma
+        modulator = (base / (1 - reduced_threshold)) ** gamma
         modulator = torch.where(p_true < reduced_threshold, torch.ones_like(modulator), modulator)
     loss = modulator * F.binary_cross_entropy_with_logits(x, t, reduction="none")
     if alpha is not None:

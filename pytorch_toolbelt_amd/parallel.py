@@ -23,7 +23,7 @@ from typing import List, Sequence
 import numpy as np
 import torch
 
-__all__ = ["tile_row_partition", "tile_range_partition", "pixel_row_partition", "pixel_row_cuts", "band_plan", "PendingBand", "shared_exchange", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
+__all__ = ["tile_row_partition", "tile_range_partition", "pixel_row_partition", "pixel_row_cuts", "band_plan", "early_spans", "PendingBand", "shared_exchange", "deferred_geometry", "ShardedTileMerger", "RcclExchange", "all_reduce_sum", "sync_region_statistics", "ms_strip_plan", "ms_flips_image_deaugment_strip",
            "ms_image_deaugment_strip"]
 
 
@@ -268,6 +268,18 @@ def deferred_geometry(plan, rank: int, crops: np.ndarray, image_height: int):
     return final, sorted(int(c) for c in cuts)
 
 
+def early_spans(me, top: int = 0):
+    """The row runs (relative to ``top``) of a rank's outgoing rectangles, touching runs joined: the rows a neighbour waits for.  Each is
+    an `early` range of the rank's band plan (``ptb_band_plan_create2``): one launch of its own as soon as the tiles feeding it are in."""
+    spans = []
+    for a_, b_ in sorted({(int(r0) - top, int(r1) - top) for _d, r0, r1, _c0, _c1 in me["sends"]}):
+        if spans and a_ <= spans[-1][1]:      # (two rectangles for one neighbour: the rows its cut takes from a full tile row and from a part of one)
+            spans[-1] = (spans[-1][0], max(spans[-1][1], b_))
+        else:
+            spans.append((a_, b_))
+    return spans
+
+
 class _DeferredBand:
     """One rank's band merged without an accumulator: the C band plan of ``TileMerger(defer=True)`` over the rank's own tiles
     (csrc/ptb_bandplan.hip), in the rank's issue order and local row coordinates.  ``out`` [C, rows, W] receives ``sum / norm``
@@ -326,7 +338,7 @@ class _DeferredBand:
         cut_arr = np.ascontiguousarray(np.array([c - top for c in cuts if top < c < bottom], dtype=np.int64))
         # the rows neighbours wait for (the outgoing rectangles) form ONE early launch group, everything else is merged in groups of
         # `rows` rows that ignore the cuts: 2 launches per rank at N = 8 instead of 6 (ptb_band_plan_create2)
-        spans = sorted({(int(r0) - top, int(r1) - top) for _d, r0, r1, _c0, _c1 in me["sends"]})
+        spans = early_spans(me, top)
         early = np.ascontiguousarray(np.array(spans, dtype=np.int64).reshape(-1)) if (spans and merger.two_phase) else np.zeros(0, dtype=np.int64)
         lib = N.load()
         handle = ctypes.c_void_p()

@@ -357,6 +357,29 @@ def test_host_lovasz_larger_cases_with_gradients(case):
     np.testing.assert_allclose(x.grad.numpy(), GL5[case["grad"]], rtol=1e-4, atol=1e-7)
 
 
+GL6 = load_golden("losses6.npz")
+
+
+@pytest.mark.parametrize("case", GL6.cases, ids=lambda c: c["name"])
+def test_host_binary_focal_fractional_gamma_with_ignore_index(case):
+    """losses6.npz: BinaryFocalLoss(gamma=<non-integer>, ignore_index=k) on label targets.  The value equals the reference's; the
+    reference's autograd gradient is NaN on the ignored entries whose base 1 - pt is negative (functional.py:70, 90-94: `0 * NaN`) --
+    NAMED DEVIATION: this library's gradient is 0 there, on the host path and in the HIP kernels alike
+    (tests/test_losses2_gpu.py), and equal to the reference's everywhere else."""
+    L = _L()
+    x = _t(GL6[case["inputs"][0]]).requires_grad_(True)
+    t = _t(GL6[case["inputs"][1]])
+    out = L.BinaryFocalLoss(**case["kwargs"])(x, t)
+    np.testing.assert_allclose(out.detach().numpy(), GL6[case["output"]], rtol=1e-5, atol=1e-6)
+    out.backward()
+    got, want = x.grad.numpy(), GL6[case["output"] + "_grad"]
+    bad = np.isnan(want)
+    assert int(bad.sum()) == case["nan_grads"] and np.isfinite(got).all()
+    ignored = np.broadcast_to((t.numpy() == case["kwargs"]["ignore_index"])[:, None], want.shape)
+    assert not (bad & ~ignored).any() and (got[ignored] == 0).all()          # the reference's NaNs sit on ignored entries only; ours are exact zeros
+    np.testing.assert_allclose(got[~bad], want[~bad], rtol=2e-4, atol=1e-7)
+
+
 def test_host_fused_loss_equals_its_parts():
     L = _L()
     g = torch.Generator().manual_seed(2)

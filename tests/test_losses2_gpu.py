@@ -502,6 +502,35 @@ def test_lovasz_against_larger_reference_cases_with_gradients(case, dev):
     np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6)
 
 
+GL6 = load_golden("losses6.npz")
+
+
+@pytest.mark.parametrize("case", GL6.cases, ids=lambda c: c["name"])
+def test_binary_focal_fractional_gamma_with_ignore_index(case, dev):
+    """losses6.npz (oracle/make_golden.py:gen_losses6): BinaryFocalLoss(gamma=<non-integer>, ignore_index=k) on label targets -- value
+    and gradient of the HIP kernels (ptb_seg_loss_fwd / ptb_focal_bwd) against the unmodified reference.  NAMED DEVIATION:
+    the reference's autograd gradient is NaN on the ignored entries whose base 1 - pt is negative (losses/functional.py:70, 90-94,
+    losses/focal.py:99-105); here an ignored entry has gradient 0, on CUDA and CPU tensors alike, everything else matches."""
+    from pytorch_toolbelt_amd import losses as L
+
+    x = torch.from_numpy(GL6[case["inputs"][0]]).to(dev).requires_grad_(True)
+    t = torch.from_numpy(GL6[case["inputs"][1]]).to(dev)
+    out = L.BinaryFocalLoss(**case["kwargs"])(x, t)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), GL6[case["output"]], rtol=1e-5, atol=1e-5)
+    out.backward()
+    got, want = x.grad.cpu().numpy(), GL6[case["output"] + "_grad"]
+    bad = np.isnan(want)
+    assert int(bad.sum()) == case["nan_grads"] and np.isfinite(got).all()
+    ignored = np.broadcast_to((t.cpu().numpy() == case["kwargs"]["ignore_index"])[:, None], want.shape)
+    assert not (bad & ~ignored).any() and (got[ignored] == 0).all()
+    scale = np.abs(want[~bad]).max()
+    np.testing.assert_allclose(got[~bad], want[~bad], rtol=2e-4, atol=2e-6 * max(1.0, scale))
+    # the host path gives the same gradient (both zero on the ignored entries)
+    xc = torch.from_numpy(GL6[case["inputs"][0]]).requires_grad_(True)
+    L.BinaryFocalLoss(**case["kwargs"])(xc, t.cpu()).backward()
+    np.testing.assert_allclose(got, xc.grad.numpy(), rtol=2e-4, atol=2e-6 * max(1.0, scale))
+
+
 # ------------------------------------------------------------------ the forward without a gradient: key-only sort (ptb_lovasz_fwd_keys)
 @pytest.mark.parametrize("case", GL5.cases, ids=lambda c: c["name"])
 def test_lovasz_key_only_forward_matches_the_reference(case, dev):
@@ -528,6 +557,45 @@ def test_lovasz_key_only_forward_matches_the_reference(case, dev):
             LV.KEY_ONLY_FORWARD = True
     np.testing.assert_allclose(keys_only.cpu().numpy(), GL5[case["output"]], rtol=1e-5, atol=1e-6)
     assert abs(float(keys_only) - float(pairs)) <= 1e-6
+
+
+@pytest.mark.parametrize("mode", ["softmax", "softmax_per_image_ignore", "hinge"])
+def test_lovasz_last_level_without_a_scatter_equals_the_four_pass_sort(mode, dev, native):
+    """ptb_set_tunable(23): the key-only forward evaluates the loss at its LAST 8-bit level from every key's final rank and the foreground
+    count in front of it (lovasz_rankdot_kernel) instead of scattering a fourth time and re-reading the sorted keys -- the same multiset in
+    the same order, so the loss agrees with the four-pass form to the rounding of its float32 Jaccard terms; ragged segments, ties, a
+    class without foreground, ignored pixels, hinge errors above 2 (top key byte beyond the probabilities' exponent range)."""
+    from pytorch_toolbelt_amd import losses as L
+
+    lib = native.load()
+    g = torch.Generator(device="cpu").manual_seed(23)
+    if mode == "hinge":
+        x = (torch.randn((3, 130, 97), generator=g) * 4).to(dev)
+        x[0, :20] = x[0, :20].round()                                 # ties
+        y = (torch.rand((3, 130, 97), generator=g) < 0.3).float().to(dev)
+        crits = [L.BinaryLovaszLoss(), L.BinaryLovaszLoss(per_image=True)]
+        args = (x, y)
+    else:
+        C = 7
+        p = torch.softmax(torch.randn((2, C, 150, 113), generator=g) * 3, 1).to(dev)
+        lab = torch.randint(0, C - 1, (2, 150, 113), generator=g).to(dev)      # class C - 1 has no foreground
+        if mode == "softmax":
+            crits = [L.LovaszLoss()]
+        else:
+            lab[1, 30:60] = 255
+            crits = [L.LovaszLoss(per_image=True, ignore=255)]
+        args = (p, lab)
+    for crit in crits:
+        got = {}
+        for v in (1, 0):
+            assert lib.ptb_set_tunable(23, v) == 0
+            try:
+                with torch.no_grad():
+                    got[v] = float(crit(*args))
+            finally:
+                lib.ptb_set_tunable(23, 1)
+        with_grad = float(crit(args[0].clone().requires_grad_(True), args[1]))
+        assert abs(got[1] - got[0]) <= 1e-6 and abs(got[1] - with_grad) <= 1e-6, (mode, got, with_grad)
 
 
 def test_lovasz_key_only_forward_edge_cases(dev):

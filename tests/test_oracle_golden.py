@@ -458,3 +458,18 @@ def test_lovasz_oracle_against_larger_reference_cases(case):
     else:
         out = LO.lovasz_hinge(a, b, per_image=kw["per_image"], ignore_index=kw["ignore_index"])
     np.testing.assert_allclose(out, GL5[case["output"]], rtol=1e-5, atol=1e-6)
+
+
+GL6 = load_golden("losses6.npz")
+
+
+@pytest.mark.parametrize("case", GL6.cases, ids=lambda c: c["name"])
+def test_oracle_binary_focal_fractional_gamma_with_ignore_index(case):
+    """losses6.npz: the oracle restates the reference faithfully here -- np.power of the negative base of an ignored entry is NaN and
+    np.where masks it, exactly like functional.py:70, 90-94 -- so the VALUE matches; the fixture also records how many gradient entries
+    of the reference are NaN (the corner the library deviates on, see tests/test_losses2_gpu.py)."""
+    with np.errstate(invalid="ignore"):
+        got = LO.binary_focal_loss(GL6[case["inputs"][0]], GL6[case["inputs"][1]], **case["kwargs"])
+    np.testing.assert_allclose(got, GL6[case["output"]], rtol=1e-5, atol=1e-6)
+    assert int(np.isnan(GL6[case["output"] + "_grad"]).sum()) == case["nan_grads"]
+    assert (case["nan_grads"] > 0) == (float(case["kwargs"]["gamma"]) != int(case["kwargs"]["gamma"]))

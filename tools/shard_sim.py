@@ -165,8 +165,11 @@ def play_rank(args, slicer, r, dev, C=4, V=8, B=8):
         torch.cuda.synchronize()
         pipe = min(pipe, e0.elapsed_time(e1) / args.steps)
     pend.result()
-    out_b = {int(d): (r1 - r0) * (c1 - c0) * C * 4 for d, r0, r1, c0, c1 in m.sends}
-    in_b = {int(s): (r1 - r0) * (c1 - c0) * C * 4 for s, r0, r1, c0, c1 in m.recvs}
+    out_b, in_b = {}, {}       # bytes per directed link: a neighbour may get several rectangles (round 6: tight rectangles per row run)
+    for d, r0, r1, c0, c1 in m.sends:
+        out_b[int(d)] = out_b.get(int(d), 0) + (r1 - r0) * (c1 - c0) * C * 4
+    for s_, r0, r1, c0, c1 in m.recvs:
+        in_b[int(s_)] = in_b.get(int(s_), 0) + (r1 - r0) * (c1 - c0) * C * 4
     rec = dict(rank=r, tiles=len(crops), compute_ms=devms, pipelined_ms=pipe, early_ms=early_ms, finish_ms=finish_ms, host_ms=host, out=out_b, inn=in_b,
                owned=m.owned_rows, mode="deferred bands" if m._deferred is not None else "incremental", boundary=len(m.plan[r]["boundary"]), placed=placed)
     del m, outs
