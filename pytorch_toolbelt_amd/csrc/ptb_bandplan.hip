@@ -48,7 +48,13 @@ struct GroupTiles {
 // no gain) -- profiles/HISTORY.md section 9.5.  Instances whose view codes are read at run time keep the plain loop (they would spill).
 template <int NV, int CODES, int OPK, int LD, int CH = PLAN_CH, bool PF = false>
 __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, const BandItem* __restrict__ items, const GroupTiles t) {
-    __shared__ __attribute__((aligned(16))) float lds[lds_tiles(NV, CODES) ? lds_tiles(NV, CODES) * CW * CH : 4];
+    // DB (round 6): the prefetching instances run ONE 1024-thread workgroup per CU, so the transposing views' LDS tiles can be doubled
+    // (2 x 64 KiB of the CU's 160): covering tile e + 1 is scattered into the other set while slow waves still read set e, and the
+    // second barrier of every covering tile -- "the tiles are reused" -- goes away.  PMC on bf16 sources had the waves of this kernel
+    // 20 % of their time in barriers (SQ_WAIT_ANY - SQ_WAIT_INST_ANY, profiles/r06_band_half_pmc_raw.txt).
+    constexpr bool DB = PF && CH == 64 && lds_tiles(NV, CODES) > 0;
+    constexpr int LDS_SET = lds_tiles(NV, CODES) * CW * CH;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_SET ? LDS_SET * (DB ? 2 : 1) : 4];
     const int tid = threadIdx.x;
     unsigned bid = blockIdx.x;
     if (a.ncells == 1) {   // XCD-aware order (A/B, ptb_set_tunable key 10): every XCD walks a contiguous eighth of the (item, channel) list
@@ -104,7 +110,8 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
                     gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H, a.W,
                                                        nlx, nly, cw, ch, tid, nxt);
             }
-            val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, e + 1 < nt);
+            const bool db = DB && a.lds_db;      // (wave-uniform; ptb_set_tunable key 25 for same-process A/B runs)
+            val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, db ? lds + (e & 1) * LDS_SET : lds, tid, db ? false : e + 1 < nt);
         } else {
             val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
                                                         a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
@@ -511,6 +518,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
     a.in_dtype = in_dtype;
     a.round_src = (dtype_arg & PTB_ROUND_SRC) ? 1 : 0;
     a.rot_views = g_band_rot_views;
+    a.lds_db = g_band_lds_db;
     a.H = p->th; a.W = p->tw; a.C = p->C;
     a.dst_chan_stride = (long long)p->H * p->W;
     a.dst_row_stride = p->W;
@@ -643,6 +651,7 @@ extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const
     return rc;
 }
 
+int ptb::g_band_lds_db = 1;        // ptb_set_tunable key 25: the prefetching band instances alternate between two sets of LDS tiles (one barrier per covering tile instead of two)
 int ptb::g_band_rot_views = 0;     // ptb_set_tunable key 22 (A/B): odd work items of the band plan kernel issue their view loads starting at view NV / 2
 int ptb::g_band_half_pf = 2;       // ptb_set_tunable key 21: the band plan kernel requests covering tile e + 1 before it finishes tile e -- 0: never (round 4's
                                    // instances), 1: for half / bf16 sources, 2: for fp32 sources as well

@@ -68,10 +68,12 @@ def test_band_plan_kernel_has_no_scratch(reports):
     for k, r in plain.items():
         assert r["VGPRs"] <= 64 and r["Occupancy"] >= 8, (k, r)     # 8 waves per SIMD: two 1024-thread (four 512-thread) workgroups per CU
     for k, r in prefetching.items():
-        assert r["VGPRs"] <= 96 and r["Occupancy"] >= 5, (k, r)     # one 1024-thread workgroup per CU (4 waves per SIMD) with the next tile in flight
+        # one 1024-thread workgroup per CU (4 waves per SIMD: <= 128 registers) with the next tile in flight; round 6: the 64-row instance keeps TWO
+        # sets of LDS tiles (128 KiB: one barrier per covering tile), so the compiler's occupancy figure is LDS-bound at 4
+        assert r["VGPRs"] <= 112 and r["Occupancy"] >= 4 and r["LDS Size"] <= 128 * 1024, (k, r)
     for k, r in _find(hits, "ILi8ELi6166440ELi0ELi2E").items():    # fp16 source
         if "Lb1EEEv" in k:
-            assert r["VGPRs"] <= 88, (k, r)
+            assert r["VGPRs"] <= 96, (k, r)
 
 
 def test_straight_line_loss_kernels_do_not_spill(reports):

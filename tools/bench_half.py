@@ -21,7 +21,9 @@ from pytorch_toolbelt_amd import _native as N  # noqa: E402
 
 ROWS = [int(v) for v in os.environ.get("PTB_HALF_ROWS", "64").split(",")]
 PFS = [int(v) for v in os.environ.get("PTB_HALF_PF", "2,0").split(",")]
-for rows, pf, dt in itertools.product(ROWS, PFS, (torch.float32, torch.float16, torch.bfloat16)):
+DBS = [int(v) for v in os.environ.get("PTB_HALF_DB", "1").split(",")]      # ptb_set_tunable key 25: double-buffered LDS tiles
+for rows, pf, db, dt in itertools.product(ROWS, PFS, DBS, (torch.float32, torch.float16, torch.bfloat16)):
+    assert N.load().ptb_set_tunable(25, db) == 0
     assert N.load().ptb_set_tunable(11, rows) == 0          # rows per work item of band plans created from now on
     assert N.load().ptb_set_tunable(21, pf) == 0            # prefetch the next covering tile of half / bf16 sources
     outs = [torch.randn((8 * min(8, n - b0), 4, 512, 512), device=dev).to(dt) for b0 in range(0, n, 8)]
@@ -45,6 +47,6 @@ for rows, pf, dt in itertools.product(ROWS, PFS, (torch.float32, torch.float16, 
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 40
     nbytes = 8 * n * 4 * 512 * 512 * outs[0].element_size() + 4 * 5120 * 5120 * 4
-    print(f"item rows {rows:2d} prefetch {pf} {str(dt):15s} {ms:7.3f} ms per image   {nbytes / 1e9:6.2f} GB algorithmic   {nbytes / (ms * 1e-3) / 1e12:5.2f} TB/s = {nbytes / (ms * 1e-3) / 8e12 * 100:5.1f} % of 8 TB/s")
+    print(f"item rows {rows:2d} prefetch {pf} lds-db {db} {str(dt):15s} {ms:7.3f} ms per image   {nbytes / 1e9:6.2f} GB algorithmic   {nbytes / (ms * 1e-3) / 1e12:5.2f} TB/s = {nbytes / (ms * 1e-3) / 8e12 * 100:5.1f} % of 8 TB/s")
     del outs, m
     torch.cuda.empty_cache()
