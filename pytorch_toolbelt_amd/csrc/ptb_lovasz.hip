@@ -279,6 +279,10 @@ __global__ __launch_bounds__(256) void lovasz_error_hist_kernel(const LovArgs a,
     }
 }
 
+// (Measured and dropped, round 6: the tile scan done by the LAST histogram workgroup of a span instead of by this launch.  What crosses
+// workgroups inside a launch has to get past the XCDs' non-coherent L2s: with a device-wide release fence per workgroup (__threadfence) a
+// Lovasz call took +1.25 ms; with the rows published by agent-scope atomic stores and read back with atomic loads, +35-40 us -- against
+// the 5 us the launch costs.  tools/ab_lovasz.py on the experimental build; the launches stay.)
 // pass step 2: one workgroup per (segment, span of RS_SPAN tiles); thread = digit: running count over the span's tiles in place
 // (every access is a coalesced 1 KiB row, the loads of a span are independent of each other), span total -> span_tot
 constexpr int RS_SPAN = 32;
@@ -341,7 +345,10 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
 // IOTA (the first pass of the training path): the keys are the key-only kappa keys (error bits << 1 | fg, see keyonly_key) and the value
 // of element i is not loaded but made here: i << 1 | fg, the fg taken from its key -- the error kernel writes no values and this
 // pass reads none (134 MB of the training path's traffic at [4,16,512,512]).
-template <int NW, bool GRAD, bool KEYONLY = false, bool IOTA = false>
+// ANYORDER (the FIRST pass of the key-only sort): keys are all there is to an element, so the order in which equal digits of one wave
+// leave this pass cannot be told from any other once the remaining passes have run -- the rank inside the wave's digit group comes from a
+// returning LDS add (ds_add_rtn_u32: one instruction per key) instead of eight ballots and sixteen three-input bit operations.
+template <int NW, bool GRAD, bool KEYONLY = false, bool IOTA = false, bool ANYORDER = false>
 __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __restrict__ keys_in, const unsigned* __restrict__ vals_in,
                                                              unsigned* __restrict__ keys_out, unsigned* __restrict__ vals_out, long long P, int T,
                                                              int shift, const unsigned* __restrict__ hist, int spans,
@@ -478,13 +485,20 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
-        unsigned below;
-        const unsigned group = match_digit(k[j], shift, below);
-        const unsigned old = wave_hist[wave][d];                    // every lane of the group reads the counter ...
-        __builtin_amdgcn_wave_barrier();
-        if (below == 0) wave_hist[wave][d] = old + group;           // ... before its first lane advances it
-        __builtin_amdgcn_wave_barrier();
-        rank[j] = old + below;                                      // rank among the wave's elements with this digit, in order
+        if constexpr (ANYORDER) {
+            static_assert(!ANYORDER || KEYONLY, "only a key-only pass may reorder equal digits");
+            // some order among the wave's keys of this digit.  Padding keys (a segment's last tile) stay out: the stable ranking puts them
+            // behind every real key by construction, an arbitrary one would hand them slots of real keys
+            rank[j] = (full_tile || wave * SPAN + j * 64 + lane < count) ? atomicAdd(&wave_hist[wave][d], 1u) : 0xFFFFFFFFu;
+        } else {
+            unsigned below;
+            const unsigned group = match_digit(k[j], shift, below);
+            const unsigned old = wave_hist[wave][d];                    // every lane of the group reads the counter ...
+            __builtin_amdgcn_wave_barrier();
+            if (below == 0) wave_hist[wave][d] = old + group;           // ... before its first lane advances it
+            __builtin_amdgcn_wave_barrier();
+            rank[j] = old + below;                                      // rank among the wave's elements with this digit, in order
+        }
     }
     __syncthreads();
     // per digit (thread = digit, the first 256 threads): waves' starts inside the run, the tile's count, the run's start inside the tile
@@ -520,7 +534,11 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
         const unsigned slot = wave_hist[wave][d] + rank[j];
-        skey[slot] = k[j];
+        if constexpr (ANYORDER) {
+            if (rank[j] != 0xFFFFFFFFu) skey[slot] = k[j];
+        } else {
+            skey[slot] = k[j];
+        }
         if constexpr (!KEYONLY) sval[slot] = v[j];
     }
     __syncthreads();
@@ -1210,8 +1228,12 @@ extern "C" int ptb_lovasz_fwd_keys(const float* pred, const int64_t* labels, con
         const int shift = 8 * pass;
         if (shift) hipLaunchKernelGGL(rs_hist_kernel<false>, dim3((unsigned)tiles), dim3(256), 0, s, kin, a.P, T, shift, hist, (unsigned*)nullptr, 0);
         hipLaunchKernelGGL(rs_tilescan_kernel, dim3(a.S * spans), dim3(256), 0, s, hist, T, spans, span_tot);
-        hipLaunchKernelGGL((rs_scatter_kernel<4, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr, a.P, T,
-                           shift, hist, spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
+        if (pass == 0 && g_lovasz_rankdot)      // (tunable 23 = 0 keeps the round-5 pipeline as it was, for A/B runs)
+            hipLaunchKernelGGL((rs_scatter_kernel<4, false, true, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr,
+                               a.P, T, shift, hist, spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
+        else
+            hipLaunchKernelGGL((rs_scatter_kernel<4, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, kin, (const unsigned*)nullptr, kout, (unsigned*)nullptr, a.P, T,
+                               shift, hist, spans, span_tot, g_rs_xcd_map, (const unsigned*)nullptr, (const unsigned*)nullptr, 0);
         if (int rc = check_launch()) return rc;
         unsigned* tk = kin; kin = kout; kout = tk;
     }

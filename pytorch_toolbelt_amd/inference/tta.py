@@ -247,6 +247,29 @@ def _refs_of_argument(image, reduction="mean"):
 _TEMP_REFS = _refs_of_argument(object())
 
 
+def _probe_owned(image, reduction="mean"):
+    # (the shape of the public de-augment functions: the count is taken in the function's own frame)
+    return sys.getrefcount(image) <= _TEMP_REFS
+
+
+def _refcount_probe_works():
+    """the ownership test rests on CPython's reference counting and on how a call passes its arguments.  Checked once at
+    import on this interpreter: a temporary of the call expression must read as owned, the same object bound to a name, kept in a list or
+    passed by keyword from a name must not.  If any of that fails (another interpreter, a tracing tool that holds references) the test
+    is switched off: `owned` is then never true and tensors without a version counter are always evaluated on the spot."""
+    try:
+        named = object()
+        box = [object()]
+        return (_probe_owned(object()) and not _probe_owned(named) and not _probe_owned(box[0]) and not _probe_owned(image=named)
+                and _probe_owned(image=object()))
+    except Exception:  # noqa: BLE001
+        return False
+
+
+if not _refcount_probe_works():
+    _TEMP_REFS = -1      # (no argument ever counts as a temporary of the call expression)
+
+
 def fliplr_image_deaugment(image: Tensor, reduction: MaybeStrOrCallable = "mean") -> Tensor:
     """[2B,C,H,W] -> [B,C,H,W] (or the [2,B,C,H,W] stack when reduction is None)."""
     owned = sys.getrefcount(image) <= _TEMP_REFS      # (its own statement: inside the call below `image` already sits on the stack once more)

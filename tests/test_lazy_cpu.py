@@ -212,3 +212,22 @@ def test_importing_the_package_leaves_torch_alone_and_the_guard_comes_and_goes()
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_refcount_ownership_probe_checks_itself_at_import():
+    """`owned` (a de-augment argument that is a temporary of the call expression) rests on sys.getrefcount; the module
+    verifies at import that a temporary reads as owned and a name-bound / list-held / keyword-passed object does not, and switches the test off
+    (nothing is ever 'owned': version-less tensors are evaluated on the spot) when that fails."""
+    from pytorch_toolbelt_amd.inference import tta
+
+    assert tta._refcount_probe_works() and tta._TEMP_REFS > 0
+    named = object()
+    temp, bound = tta._probe_owned(object()), tta._probe_owned(named)       # (not inside an `assert`: pytest's rewriting keeps intermediate values alive)
+    assert temp and not bound
+    prev = tta._TEMP_REFS
+    try:
+        tta._TEMP_REFS = -1          # what a failed self-check leaves behind
+        temp = tta._probe_owned(object())
+        assert not temp
+    finally:
+        tta._TEMP_REFS = prev
