@@ -345,7 +345,8 @@ __device__ __forceinline__ unsigned block_inclusive_scan_n(unsigned v, unsigned*
 // IOTA (the first pass of the training path): the keys are the key-only kappa keys (error bits << 1 | fg, see keyonly_key) and the value
 // of element i is not loaded but made here: i << 1 | fg, the fg taken from its key -- the error kernel writes no values and this
 // pass reads none (134 MB of the training path's traffic at [4,16,512,512]).
-// ANYORDER (the FIRST pass of the key-only sort): keys are all there is to an element, so the order in which equal digits of one wave
+// ANYORDER (the FIRST pass of the key-only sort; the gradient BINNING pass, whose backward kernel places a block's pairs by their pixel
+// index and never looks at their order): keys are all there is to an element, so the order in which equal digits of one wave
 // leave this pass cannot be told from any other once the remaining passes have run -- the rank inside the wave's digit group comes from a
 // returning LDS add (ds_add_rtn_u32: one instruction per key) instead of eight ballots and sixteen three-input bit operations.
 template <int NW, bool GRAD, bool KEYONLY = false, bool IOTA = false, bool ANYORDER = false>
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
     for (int j = 0; j < ITEMS; ++j) {
         const unsigned d = (k[j] >> shift) & 255u;
         if constexpr (ANYORDER) {
-            static_assert(!ANYORDER || KEYONLY, "only a key-only pass may reorder equal digits");
+            static_assert(!ANYORDER || KEYONLY || GRAD, "only a key-only pass or the gradient binning (whose bins are unordered sets) may reorder equal digits");
             // some order among the wave's keys of this digit.  Padding keys (a segment's last tile) stay out: the stable ranking puts them
             // behind every real key by construction, an arbitrary one would hand them slots of real keys
             rank[j] = (full_tile || wave * SPAN + j * 64 + lane < count) ? atomicAdd(&wave_hist[wave][d], 1u) : 0xFFFFFFFFu;
@@ -535,11 +536,14 @@ __global__ __launch_bounds__(NW * 64) void rs_scatter_kernel(const unsigned* __r
         const unsigned d = (k[j] >> shift) & 255u;
         const unsigned slot = wave_hist[wave][d] + rank[j];
         if constexpr (ANYORDER) {
-            if (rank[j] != 0xFFFFFFFFu) skey[slot] = k[j];
+            if (rank[j] != 0xFFFFFFFFu) {
+                skey[slot] = k[j];
+                if constexpr (!KEYONLY) sval[slot] = v[j];
+            }
         } else {
             skey[slot] = k[j];
+            if constexpr (!KEYONLY) sval[slot] = v[j];
         }
-        if constexpr (!KEYONLY) sval[slot] = v[j];
     }
     __syncthreads();
     if (full_tile) {
@@ -1156,8 +1160,12 @@ static int lovasz_fwd_impl(const float* pred, const int64_t* labels, const float
         if (g_lovasz_fused_dot) {
             // the binning scatter also evaluates the loss (it computes every element's gradient anyway and reads its error key):
             // no lovasz_dot_kernel, the sorted values are read once instead of twice
-            hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift,
-                               hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps, kin, partial);
+            if (g_lovasz_rankdot)      // (the any-order ranking: tunable 23, with the key-only forward's)
+                hipLaunchKernelGGL((rs_scatter_kernel<4, true, false, false, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T,
+                                   shift, hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps, kin, partial);
+            else
+                hipLaunchKernelGGL((rs_scatter_kernel<4, true>), dim3((unsigned)tiles), dim3(256), 0, s, vin, (const unsigned*)nullptr, keys_b, vals_b, a.P, T, shift,
+                                   hist, spans, span_tot, g_rs_xcd_map, chunk, fg_total, cps, kin, partial);
             hipLaunchKernelGGL(lovasz_segsum_kernel, dim3(a.S), dim3(256), 0, s, partial, T, seg_loss);
         } else {
             hipLaunchKernelGGL(lovasz_dot_kernel<true>, dim3((unsigned)total_chunks), dim3(256), 0, s, kin, (const unsigned*)nullptr, a.P, cps, chunk, fg_total, partial, (float*)nullptr);
