@@ -235,18 +235,19 @@ def secondary_workloads(dev, with_cpu=True, cpu_budget_s=12.0):
     t_lfb = _gpu_ms(lov_fb, 20)
     # The roofline of a SORT is not its inputs read once: an LSD radix sort of 32-bit keys in 8-bit digits moves every element four
     # times.  Bytes the implemented pipeline has to move (n = 16.8 M elements, 4 B per key / value / gradient):
-    #   forward without gradient (key-only sort, ptb_lovasz_fwd_keys): error kernel (pred + labels in, keys out) + 3 histogram reads
-    #     (pass 0's histogram comes out of the error kernel) + 4 x (keys in + keys out) + foreground count + dot  = lov_in + 14 x 4n
+    #   forward without gradient (key-only sort, ptb_lovasz_fwd_keys; round 6: the last level ranks instead of scattering): error kernel
+    #     (pred + labels in, keys out) + 3 histogram reads (pass 0's histogram comes out of the error kernel) + 3 x (keys in + keys out)
+    #     + the rank-dot kernel's one read  = lov_in + 11 x 4n   (round 5: 4 scatters + foreground count + dot = lov_in + 14 x 4n)
     #   forward + backward (pair sort + binned gradient): error (pred + labels in, keys out) + 3 histogram reads + first pass (keys in,
     #     pairs out: it makes the values) + 3 x (pairs in + pairs out) + binning pass (count: values in; scatter: values + error keys
     #     in, pairs out -- it also evaluates the loss) + backward (pairs + pred + labels in, gradient out)
     #     = 2 x lov_in + (1 + 3 + 3 + 12 + 1 + 4 + 3) x 4n = 2 x lov_in + 27 x 4n
     n_el = probs.numel()
-    lov_sort_fwd = lov_in + 14 * 4 * n_el
+    lov_sort_fwd = lov_in + 11 * 4 * n_el
     lov_sort_fb = 2 * lov_in + 27 * 4 * n_el
     out["lovasz_fwd"] = entry(t_lf, lov_sort_fwd, what="LovaszLoss() forward on [4,16,512,512] probabilities under no_grad: 16 segments of 1 M elements, key-only "
-                                                       "4-pass LSD radix sort; `bytes` = what the sort pipeline must move (error kernel + 3 histogram reads + 4 x keys "
-                                                       "in / out + count + dot), `frac` against 8 TB/s", inputs_once_bytes=int(lov_in))
+                                                       "LSD radix sort (three scatters, the last level evaluated from ranks); `bytes` = what the sort pipeline must move (error kernel + 3 "
+                                                       "histogram reads + 3 x keys in / out + the rank-dot read), `frac` against 8 TB/s", inputs_once_bytes=int(lov_in))
     out["lovasz_fwd_bwd"] = entry(t_lfb, lov_sort_fb, what="same, forward + backward: (key, index) pair sort + gradient binned by pixel block; `bytes` = error (keys out) + "
                                                            "3 histogram reads + first pass (keys in, pairs out) + 3 x pairs in / out + binning pass (which also "
                                                            "evaluates the loss) + backward",

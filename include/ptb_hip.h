@@ -93,7 +93,10 @@ const char* ptb_last_hip_error(void);
  * 23 = the last 8-bit level of the key-only Lovasz forward (ptb_lovasz_fwd_keys) evaluates the loss from every key's final rank and the
  *      foreground count in front of it -- both from the scanned histograms -- instead of scattering the keys a fourth time (0|1, default 1),
  * 25 = the prefetching instances of the band plan kernel (one 1024-thread workgroup per CU) alternate between two sets of LDS tiles for
- *      the transposing views: one barrier per covering tile instead of two (0|1, default 1).
+ *      the transposing views: one barrier per covering tile instead of two (0|1, default 1),
+ * 27 = band launches of the identity view (the plain loop without TTA) run one workgroup per work item over ALL channels: the window and
+ *      the normaliser are loaded once per pixel instead of once per channel, every covering tile of a channel is requested at once (0|1,
+ *      default 1).
  * Every setting computes the same values (key 19: bit for bit for segments of up to 2^24 elements -- above that the separate dot kernel's
  * (float)(i + 1) positions round and the two settings may differ in the last bits, the default being the reference's telescoping
  * difference); the keys exist for same-box A/B runs and for tests that compare two code paths bit for bit. */

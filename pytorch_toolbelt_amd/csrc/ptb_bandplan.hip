@@ -64,7 +64,8 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
     }
     int c = bid % a.C;
     unsigned item = bid / a.C;
-    if (a.ncells == 2) {   // channel-major: consecutive workgroups = neighbouring chunks of ONE channel plane
+    if (a.chan_loop) { c = 0; item = bid; }      // (one workgroup per item, all channels: the identity-view instances)
+    else if (a.ncells == 2) {   // channel-major: consecutive workgroups = neighbouring chunks of ONE channel plane
         const unsigned n_items = (unsigned)a.total_chunks / (unsigned)a.C;
         c = bid / n_items;
         item = bid - c * n_items;
@@ -80,6 +81,65 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nt = it->ntiles;
     const bool rot = PF && a.rot_views && (item & 1u);      // (wave-uniform; A/B of the view issue order, ptb_set_tunable key 22)
+    // ALL (round 6): one or two row-preserving views -- the plain loop without TTA (`integrate_batch(pred, crops)`, tiles.py:321-339), the
+    // flips of one axis -- bring only 16-32 bytes per lane and covering tile, so one tile ahead leaves a CU with ~32 KiB in flight and a
+    // workgroup's <= 4 covering tiles a chain of exposed latencies (0.45 ms per 5000 x 5000 image: 54 % of its bytes' time).  These
+    // instances request EVERY covering tile of the item up front (<= 4 x NV raw values: <= 32 registers), no LDS, no barrier.
+    constexpr bool ALL = PF && lds_tiles(NV, CODES) == 0 && NV <= 2 && CODES >= 0;
+    if constexpr (ALL) {
+        // a.chan_loop (identity view): the workgroup walks ALL channels of its item -- the window values of the covering tiles and the
+        // normaliser are per PIXEL, and with one 16-byte load per lane, channel and covering tile they were as many bytes through the
+        // L1 as the model outputs themselves (and the normaliser, 105 MB, was re-read per channel).  They are loaded once, the next
+        // channel's tiles are requested while the current one is blended.
+        const int c_end = a.chan_loop ? a.C : c + 1;
+        if (a.chan_loop) { c = 0; }
+        float4 wv[MAX_COVER];
+#pragma unroll
+        for (int e = 0; e < MAX_COVER; ++e) {
+            wv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nt && act) {
+                const unsigned long long cv = it->cover[e];
+                const int lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
+                wv[e] = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
+            }
+        }
+        typename RawOf<LD>::type all[MAX_COVER][NV];
+        auto request = [&](int cc) {
+#pragma unroll
+            for (int e = 0; e < MAX_COVER; ++e) {
+                if (e < nt) {
+                    const unsigned long long cv = it->cover[e];
+                    const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
+                    gather_load_raw<CH, NV, CODES, LD>(static_cast<const float*>(t.src[slot]), (long long)cc * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H,
+                                                       a.W, lx, ly, cw, ch, tid, all[e]);
+                }
+            }
+        };
+        request(c);
+        for (; c < c_end; ++c) {
+            acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < MAX_COVER; ++e) {
+                if (e < nt) {
+                    float4 v[NV];
+                    gather_widen<CH, NV, CODES, LD>(all[e], a.nviews, a.codes, cw, ch, tid, v);
+                    float4 val = gather_tail<CH, NV, CODES, OPK>(v, a.nviews, a.codes, cw, ch, a.op, a.divisor, lds, tid, false);
+                    val = round_src4<LD>(val, a.round_src);
+                    acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, wv[e].x));   // tiles.py:338
+                    acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, wv[e].y));
+                    acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, wv[e].z));
+                    acc.w = __fadd_rn(acc.w, __fmul_rn(val.w, wv[e].w));
+                }
+            }
+            if (c + 1 < c_end) request(c + 1);      // (the raw registers are free again: the next channel's tiles travel while this one is divided and stored)
+            if (act) {
+                float* o = a.merged + (long long)c * a.dst_chan_stride + pix;
+                if (partial) *reinterpret_cast<float4*>(o) = acc;
+                else out_store4(o, make_float4(__fdiv_rn(acc.x, nfull.x), __fdiv_rn(acc.y, nfull.y), __fdiv_rn(acc.z, nfull.z), __fdiv_rn(acc.w, nfull.w)));
+            }
+        }
+        return;
+    }
     typename RawOf<LD>::type nxt[PF ? NV : 1];
     if constexpr (PF) {
         if (nt > 0) {
@@ -536,9 +596,11 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
             GroupTiles gt;
             for (size_t s = 0; s < g.tiles.size(); ++s) { gt.src[s] = p->src[g.tiles[s]]; gt.vs[s] = p->vs[g.tiles[s]]; }
             for (size_t s = g.tiles.size(); s < (size_t)PLAN_TILES; ++s) { gt.src[s] = nullptr; gt.vs[s] = 0; }
-            const long long blocks = (long long)g.item_cnt * p->C;
+            // identity view on the prefetching instances: one workgroup per item walks the channels (see band_plan_kernel, ALL)
+            a.chan_loop = (V == 1 && codes == CODES_ID && g_band_chan_loop && (in_dtype != PTB_F32 ? g_band_half_pf >= 1 : g_band_half_pf >= 2)) ? 1 : 0;
+            const long long blocks = (long long)g.item_cnt * (a.chan_loop ? 1 : p->C);
             if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
-            a.ncells = g_band_xcd; a.total_chunks = (int)blocks;
+            a.ncells = a.chan_loop ? 0 : g_band_xcd; a.total_chunks = (int)blocks;
             launch_plan(a, p->dev_items + g.item_off, gt, g_band_xcd == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, p->ch, (hipStream_t)stream);
             const int rc = check_launch();
             if (rc != PTB_OK) return rc;
@@ -651,6 +713,7 @@ extern "C" int ptb_band_plan_submit_rank(ptb_band_plan* p, int pos, int B, const
     return rc;
 }
 
+int ptb::g_band_chan_loop = 1;     // ptb_set_tunable key 27: identity-view band launches run one workgroup per item over all channels (window / normaliser loaded once per pixel)
 int ptb::g_band_lds_db = 1;        // ptb_set_tunable key 25: the prefetching band instances alternate between two sets of LDS tiles (one barrier per covering tile instead of two)
 int ptb::g_band_rot_views = 0;     // ptb_set_tunable key 22 (A/B): odd work items of the band plan kernel issue their view loads starting at view NV / 2
 int ptb::g_band_half_pf = 2;       // ptb_set_tunable key 21: the band plan kernel requests covering tile e + 1 before it finishes tile e -- 0: never (round 4's

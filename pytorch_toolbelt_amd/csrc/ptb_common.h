@@ -62,6 +62,7 @@ extern int g_loss_prefetch;   // 0 | 1: the fused loss forward fetches the next 
 extern int g_smf_bwd_stash;  // 0 | 2 | 4: softmax focal backward with the per-class terms kept in registers, pixels per lane
 extern int g_band_rows;     // 32 | 64: rows per work item of band plans created from now on (A/B)
 extern int g_band_half_pf;  // 0 | 1 | 2: the band plan kernel prefetches the next covering tile (1: half / bf16 sources only, 2: fp32 too)
+extern int g_band_chan_loop; // 0 | 1: identity-view band launches, one workgroup per item over all channels
 extern int g_band_lds_db;   // 0 | 1: double-buffered LDS tiles in the prefetching band plan instances
 extern int g_band_rot_views;  // 0 | 1: odd work items of the band plan kernel issue their view loads starting at view NV / 2 (A/B)
 extern int g_band_xcd;      // 0 | 1: XCD-aware workgroup order in the band plan kernel (A/B)

@@ -259,6 +259,10 @@ extern "C" int ptb_set_tunable(int key, int value) {
         g_band_rot_views = value ? 1 : 0;
         return PTB_OK;
     }
+    if (key == 27) {
+        g_band_chan_loop = value ? 1 : 0;
+        return PTB_OK;
+    }
     if (key == 25) {
         g_band_lds_db = value ? 1 : 0;
         return PTB_OK;

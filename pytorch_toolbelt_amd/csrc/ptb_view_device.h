@@ -63,6 +63,7 @@ struct ViewArgs {
     int in_dtype;        // element type of src: PTB_F32 | PTB_F16 | PTB_BF16 (reduce / accumulate kernels)
     int keep_acc;        // planned accumulate: a finalised cell ALSO stores its weighted sum in the accumulator (PTB_PLANNED_KEEP_SUMS)
     int round_src;       // PTB_ROUND_SRC: the reduced value is rounded to the (half / bf16) source type before it is blended
+    int chan_loop;       // band plan kernel, identity view: one workgroup per work item walks all channels (ptb_set_tunable key 27)
     int lds_db;          // band plan kernel, prefetching instances: alternate between two sets of LDS tiles (ptb_set_tunable key 25)
     int rot_views;       // band plan kernel (A/B, ptb_set_tunable key 22): odd work items issue their view loads starting at view NV / 2
 };
