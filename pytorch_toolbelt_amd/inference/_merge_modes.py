@@ -489,14 +489,16 @@ class DeferredBands(_OfMerger):
             if self.soft and not (rnd & LAZY_SRC):
                 return None                      # (a version-less batch nobody vouches for: _submit leaves deferred mode)
         end = pos + B
+        p0 = batch.data_ptr()
         if not bands.monotone or (self.done < len(bands.bands) and end > bands.bands[self.done][2]):
             # a launch is due: it reads the held batches (and the window) -- they must be what they were when they were handed in
             if m._window_edited():
                 return None
-            for i, h in enumerate(held.rows):
+            for h in held.rows:
                 if h[-1] is not None and tensor_version(h[0]) != h[-1]:
-                    check_held(held.rows, batch, (0, 0, None), True, held.what, held.hint)
-        p0 = batch.data_ptr()
+                    # (the full contract check words the refusal: a batch in a held batch's memory first -- a static output buffer
+                    # moves the counter of every slice of it too --, then the in-place edit)
+                    check_held(held.rows, batch, (p0, p0 + B * s[7], version), True, held.what, held.hint)
         rc = s[6](bands.handle, p0, B, _raw_stream(s[5]))
         N.calls += 1
         if rc < 0:

@@ -222,14 +222,14 @@ def test_host_tile_merger_accumulates_in_the_callers_dtype_bit_exact(case):
     assert merged.dtype == dt and np.array_equal(raw(merged), GTD[f"{n}_merged"])
 
 
-GT3 = load_golden("tiles3.npz")
+GTILES3 = load_golden("tiles3.npz")
 
 
 def _from_raw(arr, dt, shape):
     return torch.from_numpy(np.ascontiguousarray(arr)).view(dt).reshape(shape)
 
 
-@pytest.mark.parametrize("case", GT3.by_fn("literal_loop_half"), ids=lambda c: c["name"])
+@pytest.mark.parametrize("case", GTILES3.by_fn("literal_loop_half"), ids=lambda c: c["name"])
 def test_host_literal_loop_on_half_precision_model_outputs_bit_exact(case):
     """tests/golden/tiles3.npz: `merger.integrate_batch(tta.<group>_image_deaugment(y), crops)` of the unmodified reference with float16 /
     bfloat16 model outputs (torch.autocast): the de-augmentation returns a HALF tensor -- every op of the reduction rounded to the source
@@ -246,13 +246,13 @@ def test_host_literal_loop_on_half_precision_model_outputs_bit_exact(case):
     fn = getattr(tta, kw["group"] + "_image_deaugment")
     for bi, b0 in enumerate(range(0, len(s.crops), kw["batch"])):
         nb = min(kw["batch"], len(s.crops) - b0)
-        y = _from_raw(GT3[f"{n}_y{bi}"], dt, (kw["views"] * nb, kw["channels"], th, tw))
+        y = _from_raw(GTILES3[f"{n}_y{bi}"], dt, (kw["views"] * nb, kw["channels"], th, tw))
         tiles = fn(y, reduction=kw["reduction"])
         assert tiles.dtype == dt
-        assert np.array_equal(tiles.contiguous().view(torch.uint8).numpy().reshape(-1), GT3[f"{n}_t{bi}"].reshape(-1))
+        assert np.array_equal(tiles.contiguous().view(torch.uint8).numpy().reshape(-1), GTILES3[f"{n}_t{bi}"].reshape(-1))
         m.integrate_batch(tiles, s.crops[b0:b0 + nb])
-    assert np.array_equal(m.image.numpy(), GT3[f"{n}_image"])
-    assert np.array_equal(m.merge().numpy(), GT3[f"{n}_merged"], equal_nan=True)
+    assert np.array_equal(m.image.numpy(), GTILES3[f"{n}_image"])
+    assert np.array_equal(m.merge().numpy(), GTILES3[f"{n}_merged"], equal_nan=True)
 
 
 # ------------------------------------------------------------------------------------------------ losses

@@ -62,7 +62,7 @@ def test_report_separates_the_placement_search(tmp_path):
 
 def test_documents_quote_the_committed_bench_line():
     """README.md, INTEGRATION.md and DESIGN.md carry a numbers block generated from the round's committed bench line
-    (tools/docs_numbers.py over profiles/r05_bench.json): the documents cannot drift from the measurement (round 4's review found
+    (tools/docs_numbers.py over profiles/r06_bench.json): the documents cannot drift from the measurement (round 4's review found
     INTEGRATION.md quoting 2.43 ms for the literal loop against 2.59 in the last bench JSON)."""
     sys.path.insert(0, str(ROOT / "tools"))
     try:
@@ -73,7 +73,7 @@ def test_documents_quote_the_committed_bench_line():
     assert "deferred bands" in want and "literal loop" in want
     for name in docs_numbers.DOCS:
         text = (ROOT / name).read_text()
-        assert want in text, f"{name}: the numbers block is not the one tools/docs_numbers.py generates from profiles/r05_bench.json (python tools/docs_numbers.py --write)"
+        assert want in text, f"{name}: the numbers block is not the one tools/docs_numbers.py generates from profiles/r06_bench.json (python tools/docs_numbers.py --write)"
     line = json.loads([ln for ln in (ROOT / "profiles" / "r05_bench.json").read_text().splitlines() if ln.startswith("{")][-1])
     lit = line["config"]["dropin_literal"]
     assert lit["merger_mode"] == "deferred bands" and lit["region_hbm_frac"] >= 0.70, "the literal loop of the committed line is below the 70 % it is documented at"
