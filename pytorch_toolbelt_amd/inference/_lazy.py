@@ -137,6 +137,7 @@ class LazyDeaugment(torch.Tensor):
     def __init__(self, source, group, views, code, compute):
         if _dlpack_orig is None:
             _guard_legacy_dlpack()         # (first handle of the process: from here on to_dlpack(handle) must evaluate it first)
+        self._len = source.shape[0] // len(views)      # (len(handle) without the __torch_function__ round trip)
         self._src = source                 # [V*B, C, H, W] contiguous float32 / float16 / bfloat16 model output (chunk-major)
         self._group = group                # "d4" | "d2" | "flips" | "fliplr" | "flipud"
         self._views = views                # inverse view codes, chunk order
