@@ -91,7 +91,7 @@ def _worker(rank, world, port, partition, defer, q):
 
 
 @pytest.mark.parametrize("defer", [True, False], ids=["deferred-bands", "incremental"])
-@pytest.mark.parametrize("world,partition", [(2, "tiles"), (3, "tiles"), (3, "rows")])
+@pytest.mark.parametrize("world,partition", [(2, "tiles"), (3, "tiles"), (3, "rows"), (5, "tiles")])      # (5: a middle rank receives FOUR rectangles -- the one-launch finish at its limit)
 def test_sharded_merger_processes_on_one_gpu(world, partition, defer):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
