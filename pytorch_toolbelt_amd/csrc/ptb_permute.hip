@@ -40,11 +40,83 @@ struct PermArgs {
 // de-augment without a reduction: the view of that chunk): 16 bytes per lane along the OUTPUT rows, each lane collecting its
 // 16 / sizeof(T) elements from the tile at their source positions.  Both global sides are coalesced for all eight views; the
 // permutation happens on the LDS side, an element at a time.
+// 16 bytes of 1- or 2-byte elements with the element order reversed (a mirrored row segment)
+template <typename T>
+__device__ __forceinline__ E16 reverse16(const E16 v) {
+    if constexpr (sizeof(T) == 1) return E16{__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x)};
+    else return E16{(v.w >> 16) | (v.w << 16), (v.z >> 16) | (v.z << 16), (v.y >> 16) | (v.y << 16), (v.x >> 16) | (v.x << 16)};
+}
+
+// Label masks and half-precision maps (1- and 2-byte elements), FULL tiles with 16-byte rows (round 6).  The generic kernel below moves
+// these an element at a time through LDS: 16 (8) byte-sized LDS operations per 16 bytes read and again per 16 bytes written to every view
+// -- it ran at 35 % / 62 % of the HBM rate the 4-byte elements reach.  Here the tile is kept TWICE, as it lies in the source (one
+// ds_write_b128 per lane) and transposed (the lane's 16 / 8 elements scattered one by one: the only element-sized LDS traffic left), so
+// EVERY view is one ds_read_b128 per 16 output bytes -- from the straight copy for the row-preserving views, from the transposed one for
+// the transposing views -- plus, for a mirrored axis along the output row, a reversal of the 16 bytes in registers.  Rows are whole
+// multiples of 128 bytes (every row starts at bank 0), so the 16-byte groups of row R are stored at group ^ (R / N): the transposing
+// scatter of a wave (8 source rows x 8 or 4 x 16 chunks: LDS rows N apart) then spreads over the banks instead of piling onto one.
+template <typename T>
+__device__ __forceinline__ void permute_full_tile_small(const PermArgs& a, const T* __restrict__ src, long long p, int k0, int r0, int c0, unsigned char* lds) {
+    constexpr int TS = TileSize<T>::value, SZ = (int)sizeof(T);
+    constexpr int N = 16 / SZ;                   // elements per 16-byte group
+    constexpr int PB = TS * SZ;                  // bytes per LDS row
+    constexpr int CPR = PB / 16;                 // 16-byte groups per row
+    static_assert(SZ <= 2 && PB % 128 == 0, "1- and 2-byte elements");
+    unsigned char* S = lds;                      // S[r][c]   = source (r, c)
+    unsigned char* Tt = lds + TS * PB;           // Tt[c][r]  = source (r, c)
+    const int tid = threadIdx.x;
+    auto grp = [](int row, int g) { return (g ^ (row / N)) & (CPR - 1); };
+    for (int e = tid; e < TS * CPR; e += 256) {
+        const int r = e / CPR, g = e - r * CPR;
+        union { E16 v; T t[N]; } u;
+        u.v = __builtin_nontemporal_load(reinterpret_cast<const E16*>(src + (long long)r * a.W + g * N));
+        *reinterpret_cast<E16*>(S + r * PB + grp(r, g) * 16) = u.v;
+        const int tg = (r * SZ) / 16, to = (r * SZ) % 16;            // where element (., r) sits in a row of Tt
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int R = g * N + m;
+            *reinterpret_cast<T*>(Tt + R * PB + grp(R, tg) * 16 + to) = u.t[m];
+        }
+    }
+    __syncthreads();
+    const int nk = a.in_is_batch ? a.V : 1;
+    for (int kk = 0; kk < nk; ++kk) {
+        const int k = k0 + kk;
+        const int code = (a.codes >> (3 * k)) & 7;
+        const bool tr = code & 1, fr = code & 2, fc = code & 4;
+        const int Ho = tr ? a.W : a.H, Wo = tr ? a.H : a.W;
+        const int a0 = fr ? a.H - r0 - TS : r0, b0 = fc ? a.W - c0 - TS : c0;
+        const int i0 = tr ? b0 : a0, j0 = tr ? a0 : b0;
+        T* __restrict__ dst = static_cast<T*>(a.out) + (((long long)k * a.planes + p) * Ho + i0) * (long long)Wo + j0;
+        for (int e = tid; e < TS * CPR; e += 256) {
+            const int i = e / CPR, g = e - i * CPR;                  // output-tile row, 16-byte group along it
+            // output (i, j): (aa, bb) = tr ? (j, i) : (i, j); source row = fr ? TS-1-aa : aa, source col = fc ? TS-1-bb : bb
+            E16 v;
+            if (!tr) {
+                const int row = fr ? TS - 1 - i : i;
+                const int sg = fc ? CPR - 1 - g : g;                 // mirrored columns: the group from the other end, reversed below
+                v = *reinterpret_cast<const E16*>(S + row * PB + grp(row, sg) * 16);
+                if (fc) v = reverse16<T>(v);
+            } else {
+                const int row = fc ? TS - 1 - i : i;                 // a row of Tt = a source COLUMN
+                const int sg = fr ? CPR - 1 - g : g;                 // along it run the source ROWS
+                v = *reinterpret_cast<const E16*>(Tt + row * PB + grp(row, sg) * 16);
+                if (fr) v = reverse16<T>(v);
+            }
+            __builtin_nontemporal_store(v, reinterpret_cast<E16*>(dst + (long long)i * Wo + g * N));
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void view_permute_kernel(const PermArgs a) {
     constexpr int TS = TileSize<T>::value;
     constexpr int N = 16 / (int)sizeof(T);        // elements per 16-byte access
-    __shared__ T tile[TS][TS + 1];
+    constexpr bool SMALL = sizeof(T) <= 2;
+    // (1- / 2-byte elements: the two copies of permute_full_tile_small; a partial tile lays its padded tile over the same bytes)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SMALL ? 2 * TS * TS * sizeof(T) : sizeof(T) * TS * (TS + 1)];
+    static_assert(!SMALL || 2 * TS * TS >= TS * (TS + 1), "the padded tile fits");
+    T (*tile)[TS + 1] = reinterpret_cast<T (*)[TS + 1]>(lds_raw);
     const int tid = threadIdx.x;
     long long bid = blockIdx.x;
     const int tx = (int)(bid % a.tiles_x); bid /= a.tiles_x;
@@ -54,6 +126,12 @@ __global__ __launch_bounds__(256) void view_permute_kernel(const PermArgs a) {
     const int r0 = ty * TS, c0 = tx * TS;                          // the tile's origin in the source plane
     const int sh = min(TS, a.H - r0), sw = min(TS, a.W - c0);      // ... and extent
     const T* __restrict__ src = static_cast<const T*>(a.in) + ((a.in_is_batch ? p : (long long)k0 * a.planes + p) * a.H + r0) * (long long)a.W + c0;
+    if constexpr (SMALL) {
+        if (a.vec && sw == TS && sh == TS) {      // (wave-uniform: the whole workgroup takes one path)
+            permute_full_tile_small<T>(a, src, p, k0, r0, c0, lds_raw);
+            return;
+        }
+    }
     if (a.vec && sw == TS) {
         constexpr int CPR = TS / N;                                // 16-byte chunks per tile row
         for (int e = tid; e < sh * CPR; e += 256) {
