@@ -61,3 +61,22 @@ name, m = mergers[0]
 bufs = [torch.empty((4, 5120, 5120), device=dev) for _ in range(4)]
 for b in bufs:
     print(f"merger 0 writing into a map @{b.data_ptr():#x}: {timed(m, b):.4f} ms")
+# ping-pong: consecutive images write into DIFFERENT maps (what a caller that keeps the previous result alive gets from the allocator)
+for depth in (1, 2, 3):
+    ring = bufs[:depth]
+    state = {"i": 0}
+
+    def image_ring(m=m):
+        state["i"] += 1
+        return image(m, ring[state["i"] % depth])
+
+    for _ in range(4):
+        image_ring()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30):
+        image_ring()
+    e1.record()
+    torch.cuda.synchronize()
+    print(f"merger 0, consecutive images into a ring of {depth} map(s): {e0.elapsed_time(e1) / 30:.4f} ms")
