@@ -1027,3 +1027,39 @@ def test_band_plan_prefetch_is_bit_identical(group, reduction, dtype, dev):
                     assert torch.equal(image(m), want), (shape, rows, pf)
         finally:
             assert lib.ptb_set_tunable(11, 64) == 0 and lib.ptb_set_tunable(21, 2) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_channel_loop_of_the_identity_view_is_bit_identical(dtype, dev):
+    """The loop without TTA on a deferred merger (ptb_set_tunable key 27): one workgroup per (item, channel) [0] and one workgroup per item
+    walking the channels [1, default] write the same bits as the incremental merger -- ragged right / bottom items, rectangular tiles,
+    C = 1 and C = 5, two images per merger."""
+    from pytorch_toolbelt_amd import _native as N
+    from pytorch_toolbelt_amd.inference.tiles import ImageSlicer, TileMerger
+
+    lib = N.load()
+    for shape, tile, step, C in (((1100, 900), 512, 256, 5), ((1100, 1300), 512, 256, 1), ((900, 700), 256, 128, 3), ((520, 392), 128, 96, 2),
+                                 ((700, 1000), (256, 512), (128, 256), 2)):
+        slicer = ImageSlicer(shape + (3,), tile, step, weight="pyramid")
+        crops = slicer.crops
+        th, tw = slicer.tile_size
+        g = torch.Generator().manual_seed(5)
+        ys = [(torch.rand((min(6, len(crops) - b0), C, th, tw), generator=g) * 2 - 1).to(dev).to(dtype) for b0 in range(0, len(crops), 6)]
+
+        def image(m):
+            for i, y in enumerate(ys):
+                m.integrate_batch(y, crops[6 * i:6 * i + 6])
+            return m.merge().clone()
+
+        want = image(TileMerger(slicer.target_shape, C, slicer.weight, device=dev, auto_plan=False))
+        try:
+            for mode in (0, 1):
+                assert lib.ptb_set_tunable(27, mode) == 0
+                m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
+                for _ in range(2):
+                    m.reset()
+                    got = image(m)
+                    assert m._bands is not None and m._bands_done == len(m._bands.bands), (shape, mode)
+                    assert torch.equal(got, want), (shape, mode)
+        finally:
+            assert lib.ptb_set_tunable(27, 1) == 0

@@ -46,3 +46,54 @@ for dt in (torch.float32, torch.bfloat16):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 40
         print(f"{str(dt):15s} {name:55s} {ms:.4f} ms per image = {alg / (ms * 1e-3) / 8e12 * 100:5.1f} % of 8 TB/s for its {alg / 1e9:.2f} GB")
+
+    # rows merged per launch (defer_rows=): 5 launches of ~75 us at the default 1024 -- do fewer, longer launches pay here?
+    if os.environ.get("PTB_NO_TTA_ROWS"):
+        for rows in (512, 1024, 2048, 2560, 5120):
+            mr = TileMerger(slicer.target_shape, 4, slicer.weight, device=dev, crops=crops, defer=True, defer_rows=rows)
+
+            def explicit_rows(mr=mr):
+                mr.reset()
+                for t, c in zip(preds, pc):
+                    mr.integrate_batch(t, c)
+                return mr.merge()
+
+            for _ in range(10):
+                explicit_rows()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(40):
+                explicit_rows()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 40
+            print(f"{str(dt):15s} defer_rows={rows:5d}: {ms:.4f} ms per image = {alg / (ms * 1e-3) / 8e12 * 100:5.1f} %")
+
+    # in-process A/B of ptb_set_tunable settings on the explicit merger: PTB_NO_TTA_AB="11=32 11=64 27=0 27=1"
+    if os.environ.get("PTB_NO_TTA_AB"):
+        from pytorch_toolbelt_amd import _native as N
+
+        for rnd in range(2):
+            for kv in os.environ["PTB_NO_TTA_AB"].split():
+                k, v = (int(x) for x in kv.split("="))
+                assert N.load().ptb_set_tunable(k, v) == 0, kv
+                mr = TileMerger(slicer.target_shape, 4, slicer.weight, device=dev, crops=crops, defer=True)
+
+                def explicit_ab(mr=mr):
+                    mr.reset()
+                    for t, c in zip(preds, pc):
+                        mr.integrate_batch(t, c)
+                    return mr.merge()
+
+                for _ in range(10):
+                    explicit_ab()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(40):
+                    explicit_ab()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 40
+                print(f"{str(dt):15s} tunable {kv:6s}: {ms:.4f} ms per image = {alg / (ms * 1e-3) / 8e12 * 100:5.1f} %")
