@@ -601,7 +601,7 @@ extern "C" int ptb_band_plan_submit(ptb_band_plan* p, int pos, int B, const void
             const long long blocks = (long long)g.item_cnt * (a.chan_loop ? 1 : p->C);
             if (blocks > 0x7fffffffLL) return PTB_EUNSUPPORTED;
             a.ncells = a.chan_loop ? 0 : g_band_xcd; a.total_chunks = (int)blocks;
-            launch_plan(a, p->dev_items + g.item_off, gt, g_band_xcd == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, p->ch, (hipStream_t)stream);
+            launch_plan(a, p->dev_items + g.item_off, gt, a.ncells == 1 ? (int)(8 * ((blocks + 7) / 8)) : (int)blocks, p->ch, (hipStream_t)stream);   // (rounded up only where the kernel's XCD order guards the surplus)
             const int rc = check_launch();
             if (rc != PTB_OK) return rc;
             ++p->launched;

@@ -1056,10 +1056,11 @@ def test_channel_loop_of_the_identity_view_is_bit_identical(dtype, dev):
             for mode in (0, 1):
                 assert lib.ptb_set_tunable(27, mode) == 0
                 m = TileMerger(slicer.target_shape, C, slicer.weight, device=dev, crops=crops, defer=True)
-                for _ in range(2):
+                for order in (0, 1, 2, 0):      # (workgroup orders of the band kernel, key 10: the XCD order pads its grid to a multiple of 8)
+                    assert lib.ptb_set_tunable(10, order) == 0
                     m.reset()
                     got = image(m)
-                    assert m._bands is not None and m._bands_done == len(m._bands.bands), (shape, mode)
-                    assert torch.equal(got, want), (shape, mode)
+                    assert m._bands is not None and m._bands_done == len(m._bands.bands), (shape, mode, order)
+                    assert torch.equal(got, want), (shape, mode, order)
         finally:
-            assert lib.ptb_set_tunable(27, 1) == 0
+            assert lib.ptb_set_tunable(27, 1) == 0 and lib.ptb_set_tunable(10, 0) == 0
