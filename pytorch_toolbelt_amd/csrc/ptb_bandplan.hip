@@ -141,10 +141,15 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
         return;
     }
     typename RawOf<LD>::type nxt[PF ? NV : 1];
+    // The window values of a covering tile travel WITH its view loads (round 6): loaded after the prefetch of tile e + 1 had been issued --
+    // where tile e needs them -- they put an s_waitcnt vmcnt(0) at the end of every iteration (the loads sit behind divergent guards, so
+    // the compiler cannot count them), i.e. the workgroup waited for the whole prefetch plus one exposed L2 round trip per covering tile.
+    float4 wnxt = make_float4(0.f, 0.f, 0.f, 0.f);
     if constexpr (PF) {
         if (nt > 0) {
             const unsigned long long cv = it->cover[0];
             const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
+            if (act) wnxt = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             if (NV >= 2 && rot)
                 gather_load_raw<CH, NV, CODES, LD, NV / 2>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot], a.nviews, a.codes, a.H,
                                                            a.W, lx, ly, cw, ch, tid, nxt);
@@ -157,12 +162,15 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
         const unsigned long long cv = it->cover[e];
         const int slot = (int)(cv & 0xffff), lx = (int)((cv >> 16) & 0xffff), ly = (int)((cv >> 32) & 0xffff);
         float4 val;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (PF) {
             float4 v[NV];
             gather_widen<CH, NV, CODES, LD>(nxt, a.nviews, a.codes, cw, ch, tid, v);   // (the buffer is free again: tile e + 1 is requested into it)
+            w4 = wnxt;
             if (e + 1 < nt) {
                 const unsigned long long cn = it->cover[e + 1];
                 const int sn = (int)(cn & 0xffff), nlx = (int)((cn >> 16) & 0xffff), nly = (int)((cn >> 32) & 0xffff);
+                if (act) wnxt = *reinterpret_cast<const float4*>(a.weight + (long long)(nly + r) * a.W + nlx + 4 * q);
                 if (NV >= 2 && rot)
                     gather_load_raw<CH, NV, CODES, LD, NV / 2>(static_cast<const float*>(t.src[sn]), (long long)c * a.H * a.W, t.vs[sn], a.nviews, a.codes, a.H,
                                                                a.W, nlx, nly, cw, ch, tid, nxt);
@@ -176,10 +184,10 @@ __global__ __launch_bounds__(16 * CH) void band_plan_kernel(const ViewArgs a, co
             val = gather_reduce<CH, NV, CODES, OPK, LD>(static_cast<const float*>(t.src[slot]), (long long)c * a.H * a.W, t.vs[slot],
                                                         a.nviews, a.codes, a.H, a.W, lx, ly, cw, ch, a.op, a.divisor, lds, tid,
                                                         e + 1 < nt);
+            if (act) w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);      // (nothing else is in flight here; held across the views the run-time-code instances would spill)
         }
         val = round_src4<LD>(val, a.round_src);
         if (act) {
-            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + (long long)(ly + r) * a.W + lx + 4 * q);
             acc.x = __fadd_rn(acc.x, __fmul_rn(val.x, w4.x));   // tiles.py:338: tile * weight rounded, then added (no FMA contraction)
             acc.y = __fadd_rn(acc.y, __fmul_rn(val.y, w4.y));
             acc.z = __fadd_rn(acc.z, __fmul_rn(val.z, w4.z));

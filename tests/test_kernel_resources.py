@@ -70,10 +70,11 @@ def test_band_plan_kernel_has_no_scratch(reports):
     for k, r in prefetching.items():
         # one 1024-thread workgroup per CU (4 waves per SIMD: <= 128 registers) with the next tile in flight; round 6: the 64-row instance keeps TWO
         # sets of LDS tiles (128 KiB: one barrier per covering tile), so the compiler's occupancy figure is LDS-bound at 4
-        assert r["VGPRs"] <= 112 and r["Occupancy"] >= 4 and r["LDS Size"] <= 128 * 1024, (k, r)
+        # (+ the next tile's window values travelling with its views: 118 of the 128 registers a 1024-thread workgroup may use)
+        assert r["VGPRs"] <= 120 and r["Occupancy"] >= 4 and r["LDS Size"] <= 128 * 1024, (k, r)
     for k, r in _find(hits, "ILi8ELi6166440ELi0ELi2E").items():    # fp16 source
         if "Lb1EEEv" in k:
-            assert r["VGPRs"] <= 96, (k, r)
+            assert r["VGPRs"] <= 104, (k, r)
 
 
 def test_straight_line_loss_kernels_do_not_spill(reports):
